@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: simulated + rendered frames/s, forward + backward.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one video frame of the BASELINE.json metric workload: 100k particles / 128^3 grid / 200k Gaussians /
+1920x1080, S = 20 MPM substeps (each: elasticity net -> p2g/grid/g2p -> plasticity net) + V = 3 view renders +
+pixel loss, then the full backward sweep (the settings NeuMA ships for its 1080p scenes:
+experiments/configs/realworld/finetune-burger.yaml:109-113).  Synthetic data (neuma_amd/synth.py), real shipped
+constitutive weights + LoRA r=16.  Inputs are resident in HBM before the timed region.
+
+Multi-GPU: strong scaling of the same frame — simulation replicated, the V x tile-row render stripes split
+across ranks, one RCCL all-reduce of dL/dmeans3D per frame (neuma_amd/harness.py).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+
+def prof_table(lib):
+    import ctypes as C
+    buf = C.create_string_buffer(1 << 16)
+    lib.nm_prof_report(buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, calls, ms = line.rsplit(" ", 2)
+        out[name] = (int(calls), float(ms))
+    return out
+
+
+def algorithmic_bytes(kernel: str, rt, D: float) -> float:
+    """Compulsory HBM bytes of ONE launch of `kernel` (formulas stated in DESIGN.md §Kernels)."""
+    cfg = rt.scene.cfg
+    N, K, W, H = rt.N, rt.K, cfg["W"], cfg["H"]
+    T = rt.touched_nodes
+    base = kernel.split("<")[0]
+    table = {
+        "k_render_bwd": 40.0 * D + 20.0 * W * H + 36.0 * K,
+        "k_render": 40.0 * D + 20.0 * W * H,
+        "k_preprocess": (4 * (3 + 6 + 1) + 12 * (cfg["sh"] + 1) ** 2) * K + 60.0 * K,
+        "k_preprocess_bwd": (4 * (3 + 6) + 12 * (cfg["sh"] + 1) ** 2) * K + 36.0 * K + 12.0 * K,
+        "k_material_fwd": 72.0 * N,
+        "k_material_bwd": 108.0 * N,
+        "k_p2g": 124.0 * N + 16.0 * T,
+        "k_g2p": 64.0 * N + 16.0 * T + 96.0 * N,
+        "k_g2p_bwd": 192.0 * N + 32.0 * T,
+        "k_p2g_bwd": 124.0 * N + 16.0 * T + 108.0 * N,
+    }
+    return table.get(base, 0.0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="metric")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-op", action="store_true", help="use the per-operator drop-in path instead of the fused roll-out")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from neuma_amd import synth, _lib
+    from neuma_amd.harness import SceneRuntime
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    lib = _lib.lib()
+
+    scene = synth.make_scene(args.workload)
+    rt = SceneRuntime(scene, dev, fused=not args.per_op, rank=rank, world=world)
+    rt.make_ground_truth()
+    # touched grid nodes of the initial state (roofline accounting) and (Gaussian, tile) pairs per view
+    with torch.no_grad():
+        rt.rollout(rt.x0, rt.v0, rt.C0, rt.F0)
+        _, rt.touched_nodes = rt.model.grid_stats()
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    def zero_grads():
+        for p in rt.parameters():
+            p.grad = None
+
+    # ---- pick the dominant kernel from a fully profiled frame (outside the timed region)
+    for _ in range(max(1, args.warmup)):
+        zero_grads()
+        rt.frame()
+    sync()
+    lib.nm_prof_reset()
+    lib.nm_prof_enable(1, None)
+    zero_grads()
+    rt.frame()
+    sync()
+    lib.nm_prof_enable(0, None)
+    full = prof_table(lib)
+    lib.nm_prof_reset()
+    dominant = max(full.items(), key=lambda kv: kv[1][1])[0] if full else "k_render_bwd"
+    dom_base = dominant.split("<")[0]
+
+    # ---- timed region: K frames, HIP events on the dominant kernel only
+    lib.nm_prof_enable(1, dom_base.encode())
+    sync()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        zero_grads()
+        last = rt.frame()
+    sync()
+    elapsed = time.perf_counter() - t0
+    lib.nm_prof_enable(0, None)
+    dom = prof_table(lib)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    fps = args.steps / elapsed
+
+    # (Gaussian, tile) pairs of one full view, for the byte accounting
+    D = 0.0
+    try:
+        from neuma_amd.tune import compute_bindings_xyz, compute_bindings_F
+        from neuma_amd.render import _RasterizeGaussians
+        with torch.no_grad():
+            m3 = compute_bindings_xyz(last.x, rt.x0, rt.gaussians.get_xyz, rt.bindings)
+            dg = compute_bindings_F(last.F, rt.bindings)
+            from neuma_amd.render import deform_cov_by_F, get_rasterizer
+            cov = deform_cov_by_F(rt._cov, dg)
+            rast = get_rasterizer(rt.cameras[0], rt.gaussians.active_sh_degree, False, rt.background)
+            import ctypes as C
+            K = rt.K
+            radii = torch.zeros(K, dtype=torch.int32, device=dev)
+            gb = int(lib.nm_raster_geom_bytes(K))
+            geom = torch.empty(gb, dtype=torch.uint8, device=dev)
+            num = C.c_int64(0)
+            cfgc = rast._cam.cfg
+            lib.nm_raster_preprocess(C.byref(cfgc), K, rt._shs.size(1), _lib.ptr(m3.contiguous()), _lib.ptr(rt._shs), None,
+                                     _lib.ptr(rt._opacity), _lib.ptr(cov), _lib.ptr(radii), _lib.ptr(geom), gb, C.byref(num),
+                                     _lib.stream_ptr(dev))
+            D = float(num.value)
+    except Exception as e:  # accounting only
+        print(f"[bench] pair count unavailable: {e}", file=sys.stderr)
+
+    roof = None
+    if dom:
+        name, (calls, ms) = max(dom.items(), key=lambda kv: kv[1][1])
+        avg_s = ms / calls / 1e3
+        frac_view = 1.0
+        if world > 1 and name.startswith(("k_render", "k_preprocess")):
+            frac_view = 1.0 / world            # a rank composites 1/world of the tile rows per launch on average
+        ab = algorithmic_bytes(name, rt, D) * frac_view
+        achieved = ab / avg_s / 1e9 if avg_s > 0 else 0.0
+        roof = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 5), "traffic": None, "launches": calls, "avg_us": round(avg_s * 1e6, 2),
+                "algorithmic_bytes_per_launch": ab,
+                "note": "composite kernels are VALU/exp-bound (see DESIGN.md); HBM fraction reported as the contract asks"}
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        try:
+            from oracle import cbaseline
+            cpu = cbaseline.time_frame_sample(scene, rt)
+        except Exception as e:
+            print(f"[bench] cpu baseline unavailable: {e}", file=sys.stderr)
+
+    if rank == 0:
+        cfg = scene.cfg
+        total_ms = sum(v[1] for v in full.values()) or 1.0
+        out = {
+            "metric": "sim+render frames/sec (fwd+bwd), 100k pts / 128^3 grid / 1080p",
+            "value": round(fps, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {cfg['N']} particles / {cfg['G']}^3 grid / {cfg['K']} Gaussians / "
+                                   f"{cfg['W']}x{cfg['H']}", "substeps_per_frame": cfg["S"], "views_per_frame": cfg["V"],
+                       "sh_degree": cfg["sh"], "material": cfg["mat"] + "_0300 + LoRA r16", "path": "per-op" if args.per_op else "fused-rollout",
+                       "parallelism": "replicated sim + render stripes" if world > 1 else "single GPU",
+                       "touched_grid_nodes": int(rt.touched_nodes), "gaussian_tile_pairs_per_view": int(D)},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "kernel_breakdown_ms_per_frame": {k: round(v[1], 3) for k, v in sorted(full.items(), key=lambda kv: -kv[1][1])[:12]},
+            "kernel_time_fraction_of_frame": round(total_ms / (1e3 * elapsed / args.steps), 3),
+            "loss": float(last.loss),
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,255 @@
+/*
+ * neuma_hip.h — C ABI of libneuma_hip.so, the MI355X (gfx950) engine behind NeuMA's
+ * simulator / constitutive-net / Particle-GS render operators.
+ *
+ * The reference (XJay18/NeuMA) has no C ABI of its own: it reaches the GPU through Warp's JIT
+ * (`wp.launch`) and through the pybind11 torch extension `diff_gaussian_rasterization`.
+ * Each entry point below names the reference interface it replaces (file:line relative to the
+ * reference root).  INTEGRATION.md shows the ctypes binding a NeuMA maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into memory owned by the caller (PyTorch); the library
+ *     borrows it for the duration of the call and never frees or retains it.  Exceptions: the
+ *     opaque handles, which own their scratch (grid, active-block lists), and `*_cfg` structs
+ *     and `int* out` scalars, which are HOST pointers.
+ *   - fp32, contiguous, array-of-structures exactly as torch lays them out:
+ *     x,v (N,3); C,F,stress (N,3,3) row-major; statics float/int32 (N,); cov6 order
+ *     xx,xy,xz,yy,yz,zz; SH (K, M, 3); view/proj matrices 16 floats in torch row-major order of
+ *     the (already transposed, row-vector convention) tensors NeuMA passes.
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream).  All calls are
+ *     asynchronous on that stream unless stated; no device-wide synchronisation is issued.
+ *   - return 0 on success, negative on error; nm_last_error() gives the thread-local message.
+ *     Non-finite gradients are not an error (the Python shim applies nan_to_num like
+ *     modules/nclaw/sim/interface.py:65-74).
+ *   - a handle is not thread-safe; different handles may be used concurrently.
+ */
+#ifndef NEUMA_HIP_H
+#define NEUMA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NM_OK 0
+#define NM_ERR_INVALID (-1)
+#define NM_ERR_HIP (-2)
+#define NM_ERR_WORKSPACE (-3)
+
+int nm_version(void);
+const char* nm_last_error(void);
+
+/* ------------------------------------------------------------------ in-library kernel timing (bench.py roofline) */
+
+/* HIP-event timing of the library's own kernel launches, on the stream they are launched on.
+ * nm_prof_enable(1, NULL) times every kernel; nm_prof_enable(1, "k_render_bwd") only that one (two event
+ * records per launch); nm_prof_enable(0, NULL) stops.  nm_prof_report synchronises the recorded events and
+ * writes "name calls total_ms\n" lines (NUL-terminated, truncated to cap); nm_prof_reset drops the samples. */
+int nm_prof_enable(int32_t on, const char* only_kernel);
+int nm_prof_report(char* out, size_t cap);
+int nm_prof_reset(void);
+
+/* ------------------------------------------------------------------ MPM (modules/nclaw/sim) */
+
+/* MPMConstant, modules/nclaw/sim/mpm.py:158-167; parse_cfg 507-528 (dx = 1/num_grids). */
+typedef struct nm_mpm_cfg {
+  int32_t num_grids;
+  float dt;
+  int32_t bound;
+  float gravity[3];
+  float eps;
+  int32_t bc; /* 0 = noslip (mpm.py:402-429), 1 = freeslip (mpm.py:373-400) */
+} nm_mpm_cfg;
+
+/* MPMStatics, mpm.py:14-72 */
+typedef struct nm_statics {
+  const float* vol;
+  const float* rho;
+  const float* clip_bound;
+  const int32_t* enabled;
+} nm_statics;
+
+/* MPMParticleData, mpm.py:75-128 (values or gradients; unused members may be NULL) */
+typedef struct nm_particles {
+  float* x;      /* (N,3)   */
+  float* v;      /* (N,3)   */
+  float* C;      /* (N,3,3) */
+  float* F;      /* (N,3,3) */
+  float* stress; /* (N,3,3) */
+} nm_particles;
+
+typedef struct nm_mpm nm_mpm; /* MPMModel (mpm.py:245-258): owns the grid */
+
+/* MPMModelBuilder.finalize, mpm.py:543-551.  bc outside {0,1} -> NM_ERR_INVALID (ValueError there). */
+int nm_mpm_create(const nm_mpm_cfg* cfg, nm_mpm** out);
+int nm_mpm_destroy(nm_mpm* h);
+
+/* MPMModel.forward, mpm.py:279-297: grid clear, p2g, grid_op, g2p.  `next` may alias `cur`
+ * (MPMForwardSim, interface.py:131-135).  Writes next->x,v,C,F. */
+int nm_mpm_forward(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur,
+                   nm_particles* next, void* stream);
+
+/* MPMModel.backward, mpm.py:299-319: recompute p2g + grid_op, then the adjoints of g2p,
+ * grid_op, p2g.  gnext: incoming dL/d(x,v,C,F) of the next state (stress ignored);
+ * gcur: outgoing dL/d(x,v,C,F,stress) of the current state (overwritten).
+ * `next` holds the forward outputs of this step (v, C are read). */
+int nm_mpm_backward(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur,
+                    const nm_particles* next, const nm_particles* gnext, nm_particles* gcur,
+                    void* stream);
+
+/* MPMModel.forward_extra, mpm.py:260-277: p2g + grid_op from (st, cur), then g2p of a second,
+ * passive particle set in place. */
+int nm_mpm_forward_extra(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur,
+                         int32_t n_extra, const nm_statics* st_extra, nm_particles* extra,
+                         void* stream);
+
+/* Introspection for tests / roofline accounting: number of touched 4x4x4-node blocks and nodes with
+ * mass > 0 after the last p2g.  Synchronises the stream. */
+int nm_mpm_grid_stats(nm_mpm* h, int32_t* active_blocks, int32_t* nodes_with_mass, void* stream);
+/* Copies the dense grid of the last forward (mv (G,G,G,3), m (G,G,G), v (G,G,G,3)) for tests. */
+int nm_mpm_grid_export(nm_mpm* h, float* mv, float* m, float* v, void* stream);
+
+/* ------------------------------------------------------------------ SVD (modules/nclaw/warp/svd.py) */
+
+/* SVDFunction.forward / batch_svd, svd.py:12-38, 61-96.  F (N,3,3) -> U (N,3,3), sigma (N,3), Vh (N,3,3);
+ * U, V in SO(3), sigma0 >= sigma1 >= |sigma2|, sign(sigma2) = sign(det F). */
+int nm_svd3_fwd(int32_t n, const float* F, float* U, float* sigma, float* Vh, void* stream);
+/* SVDFunction.backward, svd.py:41-57 (adjoint of wp.svd3 with the 1e-6 denominator clamp). */
+int nm_svd3_bwd(int32_t n, const float* U, const float* sigma, const float* Vh, const float* gU,
+                const float* gsigma, const float* gVh, float* gF, void* stream);
+
+/* ------------------------------------------------------------------ constitutive nets (modules/nclaw/material/meta.py) */
+
+/* Effective (LoRA-merged, loralib.py:209-213) weights, row-major, no bias (meta.py:20-42):
+ * w0 (64,13), w1 (64,64), w2 (9,64). */
+typedef struct nm_mlp {
+  const float* w0;
+  const float* w1;
+  const float* w2;
+} nm_mlp;
+
+#define NM_ELASTICITY 0 /* InvariantFullMetaElasticity.forward, meta.py:196-221: out = R sym(X) F^T */
+#define NM_PLASTICITY 1 /* InvariantFullMetaPlasticity.forward, meta.py:468-489: out = F + alpha R sym(X) */
+
+int nm_material_fwd(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w,
+                    float* out, void* stream);
+/* Backward: gF (N,3,3) overwritten; gw0/gw1/gw2 (same shapes as the weights) overwritten with the
+ * sum over particles (may be NULL to skip weight gradients).  workspace: device scratch of at
+ * least nm_material_bwd_workspace(n) bytes. */
+size_t nm_material_bwd_workspace(int32_t n);
+int nm_material_bwd(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w,
+                    const float* gout, float* gF, float* gw0, float* gw1, float* gw2,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* Same, with accumulate != 0 adding into gw0/gw1/gw2 instead of overwriting (BPTT over substeps). */
+int nm_material_bwd_ex(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w,
+                       const float* gout, float* gF, float* gw0, float* gw1, float* gw2,
+                       int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ fused roll-out (experiments/finetune.py:360-364) */
+
+/* S substeps of   stress = E(F); (x,v,C,F) = sim(x,v,C,F,stress); F = P(F)   (finetune.py:362-364,
+ * render.py:305-309) enqueued natively, so the host pays one call per video frame instead of three
+ * autograd nodes per substep.  `states` is a caller-owned checkpoint buffer of (S+1) records; record t
+ * holds x (N,3) | v (N,3) | C (N,9) | F (N,9) contiguously (24*N floats).  Record 0 is the input,
+ * records 1..S are written.  Nothing else is kept: the backward pass recomputes stress, the trial F and
+ * the grid from the checkpoints (96 B/particle/substep instead of the reference's ~3.5 KB). */
+typedef struct nm_rollout_cfg {
+  int32_t substeps;
+  float plasticity_alpha;
+} nm_rollout_cfg;
+size_t nm_rollout_workspace(int32_t n, int32_t substeps);
+int nm_rollout_forward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cfg, const nm_statics* st,
+                       const nm_mlp* elasticity, const nm_mlp* plasticity, float* states,
+                       void* workspace, size_t workspace_bytes, void* stream);
+/* gstate_last: dL/d(record S) (24*N floats, same layout); gstate_first: dL/d(record 0) (written);
+ * gw_e / gw_p: 5504 floats each = dL/d(w0 | w1 | w2) of the elasticity / plasticity nets, summed over
+ * particles and substeps (overwritten). */
+int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cfg, const nm_statics* st,
+                        const nm_mlp* elasticity, const nm_mlp* plasticity, const float* states,
+                        const float* gstate_last, float* gstate_first, float* gw_e, float* gw_p,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ Particle-GS binding (modules/tune/utils.py) */
+
+/* torch.sparse.mm(bindings, X) of compute_bindings_xyz / compute_bindings_F, tune/utils.py:424-472,
+ * on a CSR copy of the COO binding matrix: out[r,:] = sum_j val[j] * in[col[j],:], D columns.
+ * The backward (B^T g) is the same call on the transposed CSR. */
+int nm_spmm_csr(int32_t rows, int32_t D, const int32_t* rowptr, const int32_t* col,
+                const float* val, const float* in, float* out, void* stream);
+/* deform_cov_by_F, modules/d3gs/utils/simulation_utils.py:25-48. */
+int nm_cov_deform(int32_t k, const float* cov6, const float* F, float* out_cov6, void* stream);
+/* Fused per-frame binding: means3D = k_prev + B (p_cur - p_prev);  F_k = B F;  cov' = F_k cov F_k^T
+ * (tune/utils.py:441-471 + simulation_utils.py:25-48 in one pass; F_k never reaches HBM unless F_out != NULL). */
+int nm_bind_frame(int32_t k, const int32_t* rowptr, const int32_t* col, const float* val,
+                  const float* p_cur, const float* p_prev, const float* k_prev, const float* F,
+                  const float* cov6, float* means3D, float* cov6_out, float* F_out, void* stream);
+
+/* ------------------------------------------------------------------ rasterizer (diff_gaussian_rasterization) */
+
+/* GaussianRasterizationSettings as filled by modules/d3gs/gaussian_renderer/__init__.py:103-116.
+ * tile_y0/tile_y1: half-open range of 16-pixel tile rows this call renders (0,0 = whole image);
+ * used to shard one view across GPUs. */
+typedef struct nm_raster_cfg {
+  int32_t image_height;
+  int32_t image_width;
+  float tanfovx;
+  float tanfovy;
+  float bg[3];
+  float scale_modifier;
+  float viewmatrix[16];
+  float projmatrix[16];
+  int32_t sh_degree;
+  float campos[3];
+  int32_t prefiltered;
+  int32_t debug;
+  int32_t tile_y0;
+  int32_t tile_y1;
+} nm_raster_cfg;
+
+/* Byte sizes of the caller-allocated buffers.  geom / binning / image are state kept for the backward
+ * pass (the geomBuffer / binningBuffer / imgBuffer tensors of the reference extension); scratch is only
+ * live during nm_raster_render (sort double-buffers) and may be dropped right after. */
+size_t nm_raster_geom_bytes(int32_t k);
+size_t nm_raster_binning_bytes(int64_t num_rendered, const nm_raster_cfg* cfg);
+size_t nm_raster_scratch_bytes(int64_t num_rendered);
+size_t nm_raster_image_bytes(const nm_raster_cfg* cfg);
+
+/* Stage 1 (GaussianRasterizer.forward, first half: preprocess + tile counts + scan).
+ * shs (K,M,3) or colors_precomp (K,3): exactly one non-NULL.  cov3D (K,6) required.
+ * Writes radii (K) and *num_rendered (host) = number of (Gaussian,tile) pairs.  Synchronises `stream`
+ * once to read that count (the reference extension does the same). */
+int nm_raster_preprocess(const nm_raster_cfg* cfg, int32_t k, int32_t m, const float* means3D,
+                         const float* shs, const float* colors_precomp, const float* opacities,
+                         const float* cov3D, int32_t* radii, void* geom, size_t geom_bytes,
+                         int64_t* num_rendered, void* stream);
+/* Stage 2: key emit, (tile, depth) sort, tile ranges, front-to-back composite -> out_color (3,H,W).
+ * Rows outside the cfg tile stripe are left untouched. */
+int nm_raster_render(const nm_raster_cfg* cfg, int32_t k, int64_t num_rendered, const void* geom,
+                     void* binning, size_t binning_bytes, void* scratch, size_t scratch_bytes,
+                     void* image, size_t image_bytes, float* out_color, void* stream);
+/* GaussianRasterizer.backward.  dL_dcolor (3,H,W) in; outputs (any may be NULL except dL_dmeans3D):
+ * dL_dmeans3D (K,3), dL_dmeans2D (K,3; screen-space mean gradient as the reference returns it),
+ * dL_dcov3D (K,6), dL_dopacity (K,1), dL_dshs (K,M,3) or dL_dcolors (K,3).
+ * workspace: device scratch of nm_raster_bwd_workspace(k) bytes. */
+size_t nm_raster_bwd_workspace(int32_t k);
+int nm_raster_backward(const nm_raster_cfg* cfg, int32_t k, int32_t m, int64_t num_rendered,
+                       const float* means3D, const float* shs, const float* colors_precomp,
+                       const float* opacities, const float* cov3D, const void* geom,
+                       const void* binning, const void* image, const float* dL_dcolor,
+                       float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcov3D, float* dL_dopacity,
+                       float* dL_dshs, float* dL_dcolors, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
+/* Fused pixel loss on the rendered image (modules/d3gs/utils/loss_utils.py:17-24):
+ * kind 0 = l1 (mean |a-b|), 1 = l2 (mean (a-b)^2); *loss_out (device float) += weight * loss;
+ * dL_dimg (3,H,W) = weight * dloss/dimg.  Rows outside [row0,row1) contribute nothing (sharded render). */
+int nm_pixel_loss(int32_t kind, float weight, int32_t h, int32_t w, int32_t row0, int32_t row1,
+                  const float* img, const float* gt, float* loss_out, float* dL_dimg, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEUMA_HIP_H */

@@ -1,0 +1,129 @@
+"""ctypes binding of libneuma_hip.so (C ABI declared in include/neuma_hip.h).
+
+There is no CPU fallback: if the library is missing or an entry point fails, an exception is raised.
+"""
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("NEUMA_HIP_LIB", _HERE / "lib" / "libneuma_hip.so"))
+
+c_float_p = C.c_void_p  # device pointers travel as integers
+
+
+class nm_mpm_cfg(C.Structure):
+    _fields_ = [("num_grids", C.c_int32), ("dt", C.c_float), ("bound", C.c_int32), ("gravity", C.c_float * 3),
+                ("eps", C.c_float), ("bc", C.c_int32)]
+
+
+class nm_statics(C.Structure):
+    _fields_ = [("vol", C.c_void_p), ("rho", C.c_void_p), ("clip_bound", C.c_void_p), ("enabled", C.c_void_p)]
+
+
+class nm_particles(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("v", C.c_void_p), ("C", C.c_void_p), ("F", C.c_void_p), ("stress", C.c_void_p)]
+
+
+class nm_mlp(C.Structure):
+    _fields_ = [("w0", C.c_void_p), ("w1", C.c_void_p), ("w2", C.c_void_p)]
+
+
+class nm_raster_cfg(C.Structure):
+    _fields_ = [("image_height", C.c_int32), ("image_width", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
+                ("bg", C.c_float * 3), ("scale_modifier", C.c_float), ("viewmatrix", C.c_float * 16),
+                ("projmatrix", C.c_float * 16), ("sh_degree", C.c_int32), ("campos", C.c_float * 3),
+                ("prefiltered", C.c_int32), ("debug", C.c_int32), ("tile_y0", C.c_int32), ("tile_y1", C.c_int32)]
+
+
+class nm_rollout_cfg(C.Structure):
+    _fields_ = [("substeps", C.c_int32), ("plasticity_alpha", C.c_float)]
+
+
+# name -> (restype, argtypes); kept in one table so tests can check the exports against the header
+_P, _I32, _I64, _F, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+SIGNATURES = {
+    "nm_version": (C.c_int, []),
+    "nm_last_error": (C.c_char_p, []),
+    "nm_prof_enable": (C.c_int, [_I32, C.c_char_p]),
+    "nm_prof_report": (C.c_int, [C.c_char_p, _SZ]),
+    "nm_prof_reset": (C.c_int, []),
+    "nm_material_bwd_ex": (C.c_int, [_I32, _I32, _F, _P, C.POINTER(nm_mlp), _P, _P, _P, _P, _P, _I32, _P, _SZ, _P]),
+    "nm_mpm_create": (C.c_int, [C.POINTER(nm_mpm_cfg), C.POINTER(C.c_void_p)]),
+    "nm_mpm_destroy": (C.c_int, [_P]),
+    "nm_mpm_forward": (C.c_int, [_P, _I32, C.POINTER(nm_statics), C.POINTER(nm_particles), C.POINTER(nm_particles), _P]),
+    "nm_mpm_backward": (C.c_int, [_P, _I32, C.POINTER(nm_statics), C.POINTER(nm_particles), C.POINTER(nm_particles),
+                                  C.POINTER(nm_particles), C.POINTER(nm_particles), _P]),
+    "nm_mpm_forward_extra": (C.c_int, [_P, _I32, C.POINTER(nm_statics), C.POINTER(nm_particles), _I32,
+                                       C.POINTER(nm_statics), C.POINTER(nm_particles), _P]),
+    "nm_mpm_grid_stats": (C.c_int, [_P, C.POINTER(_I32), C.POINTER(_I32), _P]),
+    "nm_mpm_grid_export": (C.c_int, [_P, _P, _P, _P, _P]),
+    "nm_svd3_fwd": (C.c_int, [_I32, _P, _P, _P, _P, _P]),
+    "nm_svd3_bwd": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "nm_material_fwd": (C.c_int, [_I32, _I32, _F, _P, C.POINTER(nm_mlp), _P, _P]),
+    "nm_material_bwd_workspace": (_SZ, [_I32]),
+    "nm_material_bwd": (C.c_int, [_I32, _I32, _F, _P, C.POINTER(nm_mlp), _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "nm_spmm_csr": (C.c_int, [_I32, _I32, _P, _P, _P, _P, _P, _P]),
+    "nm_cov_deform": (C.c_int, [_I32, _P, _P, _P, _P]),
+    "nm_bind_frame": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "nm_raster_geom_bytes": (_SZ, [_I32]),
+    "nm_raster_binning_bytes": (_SZ, [_I64, C.POINTER(nm_raster_cfg)]),
+    "nm_raster_scratch_bytes": (_SZ, [_I64]),
+    "nm_raster_image_bytes": (_SZ, [C.POINTER(nm_raster_cfg)]),
+    "nm_raster_preprocess": (C.c_int, [C.POINTER(nm_raster_cfg), _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _SZ,
+                                       C.POINTER(_I64), _P]),
+    "nm_raster_render": (C.c_int, [C.POINTER(nm_raster_cfg), _I32, _I64, _P, _P, _SZ, _P, _SZ, _P, _SZ, _P, _P]),
+    "nm_raster_bwd_workspace": (_SZ, [_I32]),
+    "nm_raster_backward": (C.c_int, [C.POINTER(nm_raster_cfg), _I32, _I32, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                     _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "nm_pixel_loss": (C.c_int, [_I32, _F, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
+    "nm_rollout_workspace": (_SZ, [_I32, _I32]),
+    "nm_rollout_forward": (C.c_int, [_P, _I32, C.POINTER(nm_rollout_cfg), C.POINTER(nm_statics), C.POINTER(nm_mlp),
+                                     C.POINTER(nm_mlp), _P, _P, _SZ, _P]),
+    "nm_rollout_backward": (C.c_int, [_P, _I32, C.POINTER(nm_rollout_cfg), C.POINTER(nm_statics), C.POINTER(nm_mlp),
+                                      C.POINTER(nm_mlp), _P, _P, _P, _P, _P, _SZ, _P]),
+}
+
+_lib = None
+
+
+class NeumaHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built — no silent fallback."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise NeumaHipError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                                f"(or `make -C neuma_amd/csrc`). neuma_amd has no CPU fallback.")
+        handle = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError here == header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().nm_last_error().decode(errors="replace")
+        raise NeumaHipError(f"{what or 'libneuma_hip'} failed (rc={rc}): {msg}")
+
+
+def stream_ptr(device=None) -> int:
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32/int32 CUDA(HIP) tensor, or None."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise NeumaHipError("neuma_amd operators need tensors on the GPU (no CPU path)")
+    if not t.is_contiguous():
+        raise NeumaHipError("tensor must be contiguous")
+    return t.data_ptr()

@@ -1,0 +1,145 @@
+// Particle -> Gaussian binding operators and the pixel loss (all HBM-bound, one pass each).
+//   nm_spmm_csr    torch.sparse.mm(bindings, X) of modules/tune/utils.py:424-472 on a CSR copy
+//   nm_cov_deform  modules/d3gs/utils/simulation_utils.py:25-48
+//   nm_bind_frame  both spmm's + the covariance push-forward fused (F_k stays in registers)
+//   nm_pixel_loss  modules/d3gs/utils/loss_utils.py:17-24 fused with its gradient
+#include "nm_common.h"
+
+// one 16-lane group per output row; lanes stride the D columns (D <= 16)
+__global__ void __launch_bounds__(256) k_spmm_csr(int rows, int D, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                  const float* __restrict__ val, const float* __restrict__ in,
+                                                  float* __restrict__ out) {
+  const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int c = threadIdx.x & 15;
+  if (r >= rows) return;
+  const int b = rowptr[r], e = rowptr[r + 1];
+  for (int cc = c; cc < D; cc += 16) {
+    float acc = 0.f;
+    for (int q = b; q < e; ++q) acc += val[q] * in[(size_t)col[q] * D + cc];
+    out[(size_t)r * D + cc] = acc;
+  }
+}
+
+extern "C" int nm_spmm_csr(int32_t rows, int32_t D, const int32_t* rowptr, const int32_t* col, const float* val,
+                           const float* in, float* out, void* stream) {
+  NM_REQUIRE(rows >= 0 && D > 0, "bad shape");
+  if (rows == 0) return NM_OK;
+  NM_REQUIRE(rowptr && col && val && in && out, "null pointer");
+  NM_LAUNCH(k_spmm_csr, dim3(nm_div_up((int64_t)rows * 16, 256)), dim3(256), 0, (hipStream_t)stream, rows, D, rowptr,
+                     col, val, in, out);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}
+
+__device__ __forceinline__ void cov_push(const float* __restrict__ c6, const M3& Fm, float* __restrict__ o6) {
+  M3 S;
+  S.m[0] = c6[0]; S.m[1] = c6[1]; S.m[2] = c6[2];
+  S.m[3] = c6[1]; S.m[4] = c6[3]; S.m[5] = c6[4];
+  S.m[6] = c6[2]; S.m[7] = c6[4]; S.m[8] = c6[5];
+  M3 R = m3_mul_nt(m3_mul(Fm, S), Fm);  // F S F^T
+  o6[0] = R.m[0]; o6[1] = R.m[1]; o6[2] = R.m[2]; o6[3] = R.m[4]; o6[4] = R.m[5]; o6[5] = R.m[8];
+}
+
+__global__ void __launch_bounds__(256) k_cov_deform(int k, const float* __restrict__ cov6, const float* __restrict__ F,
+                                                    float* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= k) return;
+  float c[6], o[6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) c[a] = cov6[6 * i + a];
+  cov_push(c, m3_load(F + 9 * i), o);
+#pragma unroll
+  for (int a = 0; a < 6; ++a) out[6 * i + a] = o[a];
+}
+
+extern "C" int nm_cov_deform(int32_t k, const float* cov6, const float* F, float* out_cov6, void* stream) {
+  NM_REQUIRE(k >= 0, "negative k");
+  if (k == 0) return NM_OK;
+  NM_REQUIRE(cov6 && F && out_cov6, "null pointer");
+  NM_LAUNCH(k_cov_deform, dim3(nm_div_up(k, 256)), dim3(256), 0, (hipStream_t)stream, k, cov6, F, out_cov6);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}
+
+__global__ void __launch_bounds__(256) k_bind_frame(int k, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                    const float* __restrict__ val, const float* __restrict__ pc,
+                                                    const float* __restrict__ pp, const float* __restrict__ kp,
+                                                    const float* __restrict__ F, const float* __restrict__ cov6,
+                                                    float* __restrict__ means, float* __restrict__ cov_out,
+                                                    float* __restrict__ F_out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= k) return;
+  float d[3] = {0.f, 0.f, 0.f};
+  M3 Fk = m3_zero();
+  for (int q = rowptr[i]; q < rowptr[i + 1]; ++q) {
+    int c = col[q];
+    float w = val[q];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) d[a] += w * (pc[3 * c + a] - pp[3 * c + a]);
+    if (F) {
+#pragma unroll
+      for (int a = 0; a < 9; ++a) Fk.m[a] += w * F[9 * (size_t)c + a];
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) means[3 * i + a] = kp[3 * i + a] + d[a];
+  if (F && cov_out) {
+    float c6[6], o[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) c6[a] = cov6[6 * i + a];
+    cov_push(c6, Fk, o);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) cov_out[6 * i + a] = o[a];
+  }
+  if (F && F_out) m3_store(F_out + 9 * (size_t)i, Fk);
+}
+
+extern "C" int nm_bind_frame(int32_t k, const int32_t* rowptr, const int32_t* col, const float* val, const float* p_cur,
+                             const float* p_prev, const float* k_prev, const float* F, const float* cov6, float* means3D,
+                             float* cov6_out, float* F_out, void* stream) {
+  NM_REQUIRE(k >= 0, "negative k");
+  if (k == 0) return NM_OK;
+  NM_REQUIRE(rowptr && col && val && p_cur && p_prev && k_prev && means3D, "null pointer");
+  NM_REQUIRE(!cov6_out || (F && cov6), "cov6_out needs F and cov6");
+  NM_LAUNCH(k_bind_frame, dim3(nm_div_up(k, 256)), dim3(256), 0, (hipStream_t)stream, k, rowptr, col, val, p_cur,
+                     p_prev, k_prev, F, cov6, means3D, cov6_out, F_out);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}
+
+// loss over (3,H,W): rows [row0,row1) only; grad written for every pixel (zero outside the stripe)
+__global__ void __launch_bounds__(256) k_pixel_loss(int kind, float scale, int h, int w, int row0, int row1,
+                                                    const float* __restrict__ img, const float* __restrict__ gt,
+                                                    float* __restrict__ loss, float* __restrict__ grad) {
+  const int total = 3 * h * w;
+  float acc = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int y = (i / w) % h;
+    float gval = 0.f;
+    if (y >= row0 && y < row1) {
+      float d = img[i] - gt[i];
+      if (kind == 0) { acc += fabsf(d); gval = d > 0.f ? scale : (d < 0.f ? -scale : 0.f); }
+      else { acc += d * d; gval = 2.f * d * scale; }
+    }
+    if (grad) grad[i] = gval;
+  }
+  acc = nm_wave_sum(acc);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(loss, (part[0] + part[1] + part[2] + part[3]) * scale);
+}
+
+extern "C" int nm_pixel_loss(int32_t kind, float weight, int32_t h, int32_t w, int32_t row0, int32_t row1, const float* img,
+                             const float* gt, float* loss_out, float* dL_dimg, void* stream) {
+  NM_REQUIRE(kind == 0 || kind == 1, "kind must be 0 (l1) or 1 (l2)");
+  NM_REQUIRE(h > 0 && w > 0 && img && gt && loss_out, "bad arguments");
+  if (row1 <= row0) { row0 = 0; row1 = h; }
+  float scale = weight / (3.0f * (float)h * (float)w);
+  int grid = nm_div_up((int64_t)3 * h * w, 256);
+  if (grid > 2048) grid = 2048;
+  NM_LAUNCH(k_pixel_loss, dim3(grid), dim3(256), 0, (hipStream_t)stream, kind, scale, h, w, row0, row1, img, gt,
+                     loss_out, dL_dimg);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}

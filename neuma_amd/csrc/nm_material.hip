@@ -1,0 +1,579 @@
+// Batched 3x3 SVD and the NeuMA neural constitutive nets (13 -> 64 -> 64 -> 9, GELU, no bias) for gfx950.
+//
+// Behaviour: /root/reference/modules/nclaw/warp/svd.py:61-96 (SVD convention),
+//            /root/reference/modules/nclaw/material/meta.py:196-221 (elasticity), 468-489 (plasticity),
+//            loralib.py:209-224 (LoRA enters as the merged weight W + (alpha/r) B A, computed by the host shim).
+//
+// Design: one kernel per direction.  A wave owns 64 particles: lane-per-particle VALU phases (SVD by
+// one-sided Jacobi, invariants, R X F^T epilogue) sandwich an MFMA phase in which the three layers run as
+// v_mfma_f32_16x16x4_f32 tiles over 16-particle column tiles.  Activations never leave registers between
+// layers: the 16x16 accumulator layout (row = 4*(lane>>4)+reg, col = lane&15) is fed straight back as the
+// next layer's B operand by permuting the K index of the weight operand instead (weights are stored in
+// LDS once per workgroup in exactly the lane order each MFMA consumes, so every ds_read is linear and
+// conflict free).  The backward kernel recomputes the forward, back-propagates in the same register
+// layouts, and forms the weight gradients as MFMA outer products over the particle index through two
+// small LDS transposes; per-workgroup partial sums are reduced by a second tiny kernel (deterministic).
+#include "nm_common.h"
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+#define NM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+#define NM_W0 (64 * 13)
+#define NM_W1 (64 * 64)
+#define NM_W2 (9 * 64)
+#define NM_WTOT (NM_W0 + NM_W1 + NM_W2)
+
+__device__ __forceinline__ float nm_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float nm_gelu_grad(float x) {
+  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+// ---------------------------------------------------------------- standalone SVD operator
+__global__ void __launch_bounds__(256) k_svd_fwd(int n, const float* __restrict__ F, float* __restrict__ U,
+                                                 float* __restrict__ sig, float* __restrict__ Vh) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  M3 A = m3_load(F + 9 * p), Um, Vm;
+  float s[3];
+  nm_svd3(A, Um, s, Vm);
+  m3_store(U + 9 * p, Um);
+  sig[3 * p] = s[0]; sig[3 * p + 1] = s[1]; sig[3 * p + 2] = s[2];
+  m3_store(Vh + 9 * p, m3_transpose(Vm));
+}
+
+// adjoint with the clamped denominators of warp's adj_svd3
+__global__ void __launch_bounds__(256) k_svd_bwd(int n, const float* __restrict__ U, const float* __restrict__ sig,
+                                                 const float* __restrict__ Vh, const float* __restrict__ gU,
+                                                 const float* __restrict__ gs, const float* __restrict__ gVh,
+                                                 float* __restrict__ gF) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  M3 Um = m3_load(U + 9 * p), Vhm = m3_load(Vh + 9 * p);
+  M3 gUm = gU ? m3_load(gU + 9 * p) : m3_zero();
+  M3 gVhm = gVh ? m3_load(gVh + 9 * p) : m3_zero();
+  float s[3] = {sig[3 * p], sig[3 * p + 1], sig[3 * p + 2]};
+  float g[3] = {0.f, 0.f, 0.f};
+  if (gs) { g[0] = gs[3 * p]; g[1] = gs[3 * p + 1]; g[2] = gs[3 * p + 2]; }
+  M3 UtgU = m3_mul_tn(Um, gUm);
+  M3 VtgV = m3_mul_nt(Vhm, gVhm);  // V^T gV = Vh (gVh)^T
+  M3 inner = m3_zero();
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (i == j) { inner.m[4 * i] = g[i]; continue; }
+      int a = i < j ? i : j, b = i < j ? j : i;
+      float e = 1.f / fminf(s[b] * s[b] - s[a] * s[a], -1e-6f);
+      if (i > j) e = -e;
+      float su = e * (UtgU.m[3 * i + j] - UtgU.m[3 * j + i]);
+      float sv = e * (VtgV.m[3 * i + j] - VtgV.m[3 * j + i]);
+      inner.m[3 * i + j] = su * s[j] + s[i] * sv;
+    }
+  m3_store(gF + 9 * p, m3_mul(m3_mul(Um, inner), Vhm));
+}
+
+extern "C" int nm_svd3_fwd(int32_t n, const float* F, float* U, float* sigma, float* Vh, void* stream) {
+  NM_REQUIRE(n >= 0, "negative n");
+  if (n == 0) return NM_OK;
+  NM_REQUIRE(F && U && sigma && Vh, "null pointer");
+  NM_LAUNCH(k_svd_fwd, dim3(nm_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, F, U, sigma, Vh);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}
+
+extern "C" int nm_svd3_bwd(int32_t n, const float* U, const float* sigma, const float* Vh, const float* gU,
+                           const float* gsigma, const float* gVh, float* gF, void* stream) {
+  NM_REQUIRE(n >= 0, "negative n");
+  if (n == 0) return NM_OK;
+  NM_REQUIRE(U && sigma && Vh && gF, "null pointer");
+  NM_LAUNCH(k_svd_bwd, dim3(nm_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, U, sigma, Vh, gU, gsigma,
+                     gVh, gF);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}
+
+// ---------------------------------------------------------------- weight staging (LDS, MFMA operand order)
+// forward operands
+//   P0[(ks*4+rt)*64 + l]            = W0[16rt + (l&15)][4ks + (l>>4)]             (k >= 13 -> 0)
+//   P1[((rtp*4+reg)*4+rt)*64 + l]   = W1[16rt + (l&15)][16rtp + 4(l>>4) + reg]
+//   P2[(rtp*4+reg)*64 + l]          = W2[l&15][16rtp + 4(l>>4) + reg]             (row >= 9 -> 0)
+// backward (transposed) operands
+//   Q2[(ks*4+rt)*64 + l]            = W2[4ks + (l>>4)][16rt + (l&15)]             (row >= 9 -> 0), ks < 3
+//   Q1[((rtp*4+reg)*4+rt)*64 + l]   = W1[16rtp + 4(l>>4) + reg][16rt + (l&15)]
+//   Q0[(rtp*4+reg)*64 + l]          = W0[16rtp + 4(l>>4) + reg][l&15]             (col >= 13 -> 0)
+__device__ __forceinline__ void stage_fwd_weights(const float* __restrict__ w0, const float* __restrict__ w1,
+                                                  const float* __restrict__ w2, float* P0, float* P1, float* P2) {
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < 16 * 64; idx += blockDim.x) {
+    int l = idx & 63, op = idx >> 6, ks = op >> 2, rt = op & 3, k = 4 * ks + (l >> 4);
+    P0[idx] = k < 13 ? w0[(16 * rt + (l & 15)) * 13 + k] : 0.f;
+    int reg = op & 3, rtp = op >> 2, row = l & 15;
+    P2[idx] = row < 9 ? w2[row * 64 + 16 * rtp + 4 * (l >> 4) + reg] : 0.f;
+  }
+  for (int idx = tid; idx < 64 * 64; idx += blockDim.x) {
+    int l = idx & 63, op = idx >> 6, rt = op & 3, reg = (op >> 2) & 3, rtp = op >> 4;
+    P1[idx] = w1[(16 * rt + (l & 15)) * 64 + 16 * rtp + 4 * (l >> 4) + reg];
+  }
+}
+__device__ __forceinline__ void stage_bwd_weights(const float* __restrict__ w0, const float* __restrict__ w1,
+                                                  const float* __restrict__ w2, float* Q0, float* Q1, float* Q2) {
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < 12 * 64; idx += blockDim.x) {
+    int l = idx & 63, op = idx >> 6, ks = op >> 2, rt = op & 3, row = 4 * ks + (l >> 4);
+    Q2[idx] = row < 9 ? w2[row * 64 + 16 * rt + (l & 15)] : 0.f;
+  }
+  for (int idx = tid; idx < 16 * 64; idx += blockDim.x) {
+    int l = idx & 63, op = idx >> 6, reg = op & 3, rtp = op >> 2, col = l & 15;
+    Q0[idx] = col < 13 ? w0[(16 * rtp + 4 * (l >> 4) + reg) * 13 + col] : 0.f;
+  }
+  for (int idx = tid; idx < 64 * 64; idx += blockDim.x) {
+    int l = idx & 63, op = idx >> 6, rt = op & 3, reg = (op >> 2) & 3, rtp = op >> 4;
+    Q1[idx] = w1[(16 * rtp + 4 * (l >> 4) + reg) * 64 + 16 * rt + (l & 15)];
+  }
+}
+
+// invariants of meta.py:197-213 for one particle: z[13], R = U V^T (also returns U, V, sigma)
+__device__ __forceinline__ void nm_features(const M3& F, float z[13], M3& R, M3& U, M3& V, float s[3]) {
+  nm_svd3(F, U, s, V);
+  R = m3_mul_nt(U, V);
+  M3 G = m3_mul_tn(F, F);
+  z[0] = s[0] - 1.f; z[1] = s[1] - 1.f; z[2] = s[2] - 1.f;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) z[3 + i] = G.m[i] - ((i % 4 == 0) ? 1.f : 0.f);
+  z[12] = m3_det(F) - 1.f;
+}
+
+// three-layer MLP on one 16-particle column tile; B operand of layer 0 comes from zrow (LDS, [particle][17])
+struct MlpFwd {
+  f4 pre1[4], pre2[4];
+  f4 y;
+};
+__device__ __forceinline__ void mlp_forward_tile(const float* __restrict__ P0, const float* __restrict__ P1,
+                                                 const float* __restrict__ P2, const float* __restrict__ zt, int lane,
+                                                 MlpFwd& o) {
+  const int j = lane & 15, g = lane >> 4;
+  const f4 zero = {0.f, 0.f, 0.f, 0.f};
+  f4 a1[4] = {zero, zero, zero, zero};
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    float b = zt[j * 17 + 4 * ks + g];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) a1[rt] = NM_MFMA(P0[(ks * 4 + rt) * 64 + lane], b, a1[rt]);
+  }
+  f4 a2[4] = {zero, zero, zero, zero};
+#pragma unroll
+  for (int rtp = 0; rtp < 4; ++rtp)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      float b = nm_gelu(a1[rtp][reg]);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) a2[rt] = NM_MFMA(P1[((rtp * 4 + reg) * 4 + rt) * 64 + lane], b, a2[rt]);
+    }
+  f4 ya = zero, yb = zero;
+#pragma unroll
+  for (int rtp = 0; rtp < 4; ++rtp)
+#pragma unroll
+    for (int reg = 0; reg < 4; reg += 2) {
+      ya = NM_MFMA(P2[(rtp * 4 + reg) * 64 + lane], nm_gelu(a2[rtp][reg]), ya);
+      yb = NM_MFMA(P2[(rtp * 4 + reg + 1) * 64 + lane], nm_gelu(a2[rtp][reg + 1]), yb);
+    }
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) { o.pre1[rt] = a1[rt]; o.pre2[rt] = a2[rt]; }
+  o.y = ya + yb;
+}
+
+// ---------------------------------------------------------------- forward
+template <int KIND>
+__global__ void __launch_bounds__(256) k_material_fwd(int n, float alpha, const float* __restrict__ F,
+                                                      const float* __restrict__ w0, const float* __restrict__ w1,
+                                                      const float* __restrict__ w2, float* __restrict__ out) {
+  __shared__ float sP0[16 * 64], sP1[64 * 64], sP2[16 * 64];
+  __shared__ float sZ[4][64 * 17];
+  __shared__ float sY[4][64 * 9];
+  stage_fwd_weights(w0, w1, w2, sP0, sP1, sP2);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = lane & 15, g = lane >> 4;
+  const int nbatch = (n + 63) >> 6;
+  float* zb = sZ[wave];
+  float* yb = sY[wave];
+  for (int batch = blockIdx.x * 4 + wave; batch < nbatch; batch += gridDim.x * 4) {
+    const int p = batch * 64 + lane;
+    const bool valid = p < n;
+    M3 Fp = valid ? m3_load(F + 9 * p) : m3_ident();
+    M3 R, U, V;
+    float z[13], s[3];
+    nm_features(Fp, z, R, U, V, s);
+#pragma unroll
+    for (int c = 0; c < 13; ++c) zb[lane * 17 + c] = z[c];
+    zb[lane * 17 + 13] = 0.f; zb[lane * 17 + 14] = 0.f; zb[lane * 17 + 15] = 0.f;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+    for (int ct = 0; ct < 4; ++ct) {
+      MlpFwd m;
+      mlp_forward_tile(sP0, sP1, sP2, zb + ct * 16 * 17, lane, m);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = 4 * g + r;
+        if (row < 9) yb[(ct * 16 + j) * 9 + row] = m.y[r];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    M3 X;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) X.m[i] = yb[lane * 9 + i];
+    M3 Xs;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Xs.m[3 * r + c] = 0.5f * (X.m[3 * r + c] + X.m[3 * c + r]);
+    M3 RX = m3_mul(R, Xs), o;
+    if (KIND == NM_ELASTICITY) {
+      o = m3_mul_nt(RX, Fp);  // R X F^T  (meta.py:219-221)
+    } else {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) o.m[i] = alpha * RX.m[i] + Fp.m[i];  // meta.py:486-488
+    }
+    if (valid) m3_store(out + 9 * p, o);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+extern "C" int nm_material_fwd(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, float* out,
+                               void* stream) {
+  NM_REQUIRE(n >= 0, "negative n");
+  NM_REQUIRE(kind == NM_ELASTICITY || kind == NM_PLASTICITY, "kind must be NM_ELASTICITY or NM_PLASTICITY");
+  if (n == 0) return NM_OK;
+  NM_REQUIRE(F && out && w && w->w0 && w->w1 && w->w2, "null pointer");
+  int grid = nm_div_up(n, 256);
+  if (grid > 768) grid = 768;
+  hipStream_t s = (hipStream_t)stream;
+  if (kind == NM_ELASTICITY)
+    NM_LAUNCH(k_material_fwd<NM_ELASTICITY>, dim3(grid), dim3(256), 0, s, n, alpha, F, w->w0, w->w1, w->w2, out);
+  else
+    NM_LAUNCH(k_material_fwd<NM_PLASTICITY>, dim3(grid), dim3(256), 0, s, n, alpha, F, w->w0, w->w1, w->w2, out);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}
+
+// ---------------------------------------------------------------- backward
+#define NM_BWD_GRID 256
+struct BwdLds {
+  float P0[16 * 64], P1[64 * 64], P2[16 * 64];
+  float Q0[16 * 64], Q1[64 * 64], Q2[12 * 64];
+  float Z[4][64 * 17];    // features [particle][17]
+  float GY[4][64 * 13];   // ybar     [particle][13] (rows 9..12 zero)
+  float Y[4][64 * 9];     // forward y
+  float GZ[4][64 * 13];   // zbar     [particle][13]
+  float TA[4][64 * 17];   // [feature][16 particles + pad]
+  float TB[4][64 * 17];
+};
+
+template <int KIND>
+__global__ void __launch_bounds__(256, 1) k_material_bwd(int n, float alpha, const float* __restrict__ F,
+                                                         const float* __restrict__ w0, const float* __restrict__ w1,
+                                                         const float* __restrict__ w2, const float* __restrict__ gout,
+                                                         float* __restrict__ gF, float* __restrict__ wpart, int want_w) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  BwdLds& L = *reinterpret_cast<BwdLds*>(smem_raw);
+  stage_fwd_weights(w0, w1, w2, L.P0, L.P1, L.P2);
+  stage_bwd_weights(w0, w1, w2, L.Q0, L.Q1, L.Q2);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = lane & 15, g = lane >> 4;
+  const int nbatch = (n + 63) >> 6;
+  float* zb = L.Z[wave];
+  float* gyb = L.GY[wave];
+  float* yb = L.Y[wave];
+  float* gzb = L.GZ[wave];
+  float* ta = L.TA[wave];
+  float* tb = L.TB[wave];
+  const f4 zero = {0.f, 0.f, 0.f, 0.f};
+  f4 gW1[4][4], gW0[4], gW2[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    gW0[a] = zero; gW2[a] = zero;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) gW1[a][b] = zero;
+  }
+  for (int batch = blockIdx.x * 4 + wave; batch < nbatch; batch += gridDim.x * 4) {
+    const int p = batch * 64 + lane;
+    const bool valid = p < n;
+    M3 Fp = valid ? m3_load(F + 9 * p) : m3_ident();
+    M3 go = valid ? m3_load(gout + 9 * p) : m3_zero();
+    M3 R, U, V;
+    float z[13], s[3];
+    nm_features(Fp, z, R, U, V, s);
+#pragma unroll
+    for (int c = 0; c < 13; ++c) zb[lane * 17 + c] = z[c];
+    zb[lane * 17 + 13] = 0.f; zb[lane * 17 + 14] = 0.f; zb[lane * 17 + 15] = 0.f;
+    // ybar = sym(Xbar):  elasticity Xbar = R^T g F ; plasticity Xbar = alpha R^T g
+    M3 Rtg = m3_mul_tn(R, go);
+    M3 Xb;
+    if (KIND == NM_ELASTICITY) Xb = m3_mul(Rtg, Fp);
+    else {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Xb.m[i] = alpha * Rtg.m[i];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gyb[lane * 13 + 3 * r + c] = 0.5f * (Xb.m[3 * r + c] + Xb.m[3 * c + r]);
+    gyb[lane * 13 + 9] = 0.f; gyb[lane * 13 + 10] = 0.f; gyb[lane * 13 + 11] = 0.f; gyb[lane * 13 + 12] = 0.f;
+    __builtin_amdgcn_wave_barrier();
+
+#pragma unroll 1
+    for (int ct = 0; ct < 4; ++ct) {
+      MlpFwd m;
+      mlp_forward_tile(L.P0, L.P1, L.P2, zb + ct * 16 * 17, lane, m);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = 4 * g + r;
+        if (row < 9) yb[(ct * 16 + j) * 9 + row] = m.y[r];
+      }
+      const float* gyt = gyb + ct * 16 * 13;  // [particle][13]
+      // (a) W2bar += ybar h2^T : A[yrow][particle], B[particle][h2 idx] via TB = h2 [feature][particle]
+      if (want_w) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tb[(16 * rt + 4 * g + r) * 17 + j] = nm_gelu(m.pre2[rt][r]);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          float a = j < 9 ? gyt[(4 * ks + g) * 13 + j] : 0.f;
+#pragma unroll
+          for (int ctp = 0; ctp < 4; ++ctp) gW2[ctp] = NM_MFMA(a, tb[(16 * ctp + j) * 17 + 4 * ks + g], gW2[ctp]);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      // (b) h2bar = W2^T ybar ; pre2bar = h2bar * gelu'(pre2)
+      f4 d2[4] = {zero, zero, zero, zero};
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        float b = gyt[j * 13 + 4 * ks + g];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) d2[rt] = NM_MFMA(L.Q2[(ks * 4 + rt) * 64 + lane], b, d2[rt]);
+      }
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d2[rt][r] *= nm_gelu_grad(m.pre2[rt][r]);
+      // (c) W1bar += pre2bar h1^T
+      if (want_w) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            ta[(16 * rt + 4 * g + r) * 17 + j] = d2[rt][r];
+            tb[(16 * rt + 4 * g + r) * 17 + j] = nm_gelu(m.pre1[rt][r]);
+          }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          float bq[4];
+#pragma unroll
+          for (int ctp = 0; ctp < 4; ++ctp) bq[ctp] = tb[(16 * ctp + j) * 17 + 4 * ks + g];
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) {
+            float a = ta[(16 * rt + j) * 17 + 4 * ks + g];
+#pragma unroll
+            for (int ctp = 0; ctp < 4; ++ctp) gW1[rt][ctp] = NM_MFMA(a, bq[ctp], gW1[rt][ctp]);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      // (d) h1bar = W1^T pre2bar ; pre1bar = h1bar * gelu'(pre1)
+      f4 d1[4] = {zero, zero, zero, zero};
+#pragma unroll
+      for (int rtp = 0; rtp < 4; ++rtp)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          float b = d2[rtp][reg];
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) d1[rt] = NM_MFMA(L.Q1[((rtp * 4 + reg) * 4 + rt) * 64 + lane], b, d1[rt]);
+        }
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d1[rt][r] *= nm_gelu_grad(m.pre1[rt][r]);
+      // (e) W0bar += pre1bar z^T : B[particle][z idx] straight from zb ([particle][17])
+      if (want_w) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ta[(16 * rt + 4 * g + r) * 17 + j] = d1[rt][r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          float b = zb[(ct * 16 + 4 * ks + g) * 17 + j];
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) gW0[rt] = NM_MFMA(ta[(16 * rt + j) * 17 + 4 * ks + g], b, gW0[rt]);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      // (f) zbar = W0^T pre1bar
+      f4 dza = zero, dzb = zero;
+#pragma unroll
+      for (int rtp = 0; rtp < 4; ++rtp)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg += 2) {
+          dza = NM_MFMA(L.Q0[(rtp * 4 + reg) * 64 + lane], d1[rtp][reg], dza);
+          dzb = NM_MFMA(L.Q0[(rtp * 4 + reg + 1) * 64 + lane], d1[rtp][reg + 1], dzb);
+        }
+      dza += dzb;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = 4 * g + r;
+        if (row < 13) gzb[(ct * 16 + j) * 13 + row] = dza[r];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // per-particle epilogue: gradients through R X F^T / F + alpha R X and through the invariants
+    M3 X;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) X.m[i] = yb[lane * 9 + i];
+    M3 Xs;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Xs.m[3 * r + c] = 0.5f * (X.m[3 * r + c] + X.m[3 * c + r]);
+    float zbv[13];
+#pragma unroll
+    for (int c = 0; c < 13; ++c) zbv[c] = gzb[lane * 13 + c];
+    M3 Fb, Rb;
+    if (KIND == NM_ELASTICITY) {
+      M3 gFm = m3_mul(go, Fp);        // g F
+      Rb = m3_mul(gFm, Xs);           // Rbar = g F X   (X symmetric)
+      M3 RX = m3_mul(R, Xs);
+      Fb = m3_mul_tn(go, RX);         // direct: g^T R X
+    } else {
+      M3 gX = m3_mul(go, Xs);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { Rb.m[i] = alpha * gX.m[i]; Fb.m[i] = go.m[i]; }
+    }
+    // sigma path + rotation path, both in the singular basis:  U [diag(sbar) + (At - At^T)/(s_i + s_j)] V^T
+    M3 At = m3_mul(m3_mul_tn(U, Rb), V);
+    M3 inner;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if (r == c) { inner.m[4 * r] = zbv[r]; continue; }
+        float den = s[r] + s[c];
+        den = fabsf(den) < 1e-6f ? copysignf(1e-6f, den) : den;
+        inner.m[3 * r + c] = (At.m[3 * r + c] - At.m[3 * c + r]) / den;
+      }
+    M3 t = m3_mul_nt(m3_mul(U, inner), V);
+    // G = F^T F:  F (Gbar + Gbar^T) ; det:  zbar12 * cof(F)
+    M3 Gs;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Gs.m[3 * r + c] = zbv[3 + 3 * r + c] + zbv[3 + 3 * c + r];
+    M3 FG = m3_mul(Fp, Gs);
+    M3 cof = m3_cofactor(Fp);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Fb.m[i] += t.m[i] + FG.m[i] + zbv[12] * cof.m[i];
+    if (valid) m3_store(gF + 9 * p, Fb);
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  if (!want_w) return;
+  // reduce the four waves' weight-gradient accumulators through LDS (weights no longer needed), write the
+  // workgroup partial in plain (out,in) layout
+  __syncthreads();
+  float* red = L.P0;  // >= NM_WTOT floats available contiguously (P0,P1,P2 = 6144 floats)
+  for (int i = threadIdx.x; i < NM_WTOT; i += blockDim.x) red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int row = 16 * rt + 4 * g + r;
+      if (j < 13) unsafeAtomicAdd(&red[row * 13 + j], gW0[rt][r]);
+#pragma unroll
+      for (int ctp = 0; ctp < 4; ++ctp) unsafeAtomicAdd(&red[NM_W0 + row * 64 + 16 * ctp + j], gW1[rt][ctp][r]);
+    }
+  }
+#pragma unroll
+  for (int ctp = 0; ctp < 4; ++ctp)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int row = 4 * g + r;
+      if (row < 9) unsafeAtomicAdd(&red[NM_W0 + NM_W1 + row * 64 + 16 * ctp + j], gW2[ctp][r]);
+    }
+  __syncthreads();
+  float* dst = wpart + (size_t)blockIdx.x * NM_WTOT;
+  for (int i = threadIdx.x; i < NM_WTOT; i += blockDim.x) dst[i] = red[i];
+}
+
+__global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ wpart, int nparts, float* __restrict__ g0,
+                                                      float* __restrict__ g1, float* __restrict__ g2, int accumulate) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NM_WTOT) return;
+  float acc = 0.f;
+  for (int b = 0; b < nparts; ++b) acc += wpart[(size_t)b * NM_WTOT + i];
+  float* dst = i < NM_W0 ? g0 + i : (i < NM_W0 + NM_W1 ? g1 + (i - NM_W0) : g2 + (i - NM_W0 - NM_W1));
+  *dst = accumulate ? *dst + acc : acc;
+}
+
+extern "C" size_t nm_material_bwd_workspace(int32_t n) {
+  (void)n;
+  return (size_t)NM_BWD_GRID * NM_WTOT * sizeof(float);
+}
+
+extern "C" int nm_material_bwd(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* gout,
+                               float* gF, float* gw0, float* gw1, float* gw2, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+  return nm_material_bwd_ex(n, kind, alpha, F, w, gout, gF, gw0, gw1, gw2, 0, workspace, workspace_bytes, stream);
+}
+
+// accumulate != 0: gw* += sum over particles (used by the fused roll-out, one call per substep)
+extern "C" int nm_material_bwd_ex(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* gout,
+                                  float* gF, float* gw0, float* gw1, float* gw2, int32_t accumulate, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  NM_REQUIRE(n >= 0, "negative n");
+  NM_REQUIRE(kind == NM_ELASTICITY || kind == NM_PLASTICITY, "kind must be NM_ELASTICITY or NM_PLASTICITY");
+  const int want_w = (gw0 && gw1 && gw2) ? 1 : 0;
+  NM_REQUIRE(want_w || (!gw0 && !gw1 && !gw2), "weight gradient outputs must be all set or all NULL");
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) {
+    if (want_w && !accumulate) {
+      NM_HIP_CHECK(hipMemsetAsync(gw0, 0, NM_W0 * sizeof(float), s));
+      NM_HIP_CHECK(hipMemsetAsync(gw1, 0, NM_W1 * sizeof(float), s));
+      NM_HIP_CHECK(hipMemsetAsync(gw2, 0, NM_W2 * sizeof(float), s));
+    }
+    return NM_OK;
+  }
+  NM_REQUIRE(F && gout && gF && w && w->w0 && w->w1 && w->w2, "null pointer");
+  if (want_w && (!workspace || workspace_bytes < nm_material_bwd_workspace(n))) {
+    nm_set_error("material backward workspace too small: need %zu bytes, got %zu", nm_material_bwd_workspace(n),
+                 workspace_bytes);
+    return NM_ERR_WORKSPACE;
+  }
+  int grid = nm_div_up(n, 256);
+  if (grid > NM_BWD_GRID) grid = NM_BWD_GRID;
+  static bool attr_set = false;
+  if (!attr_set) {
+    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd<NM_ELASTICITY>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)sizeof(BwdLds)));
+    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd<NM_PLASTICITY>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)sizeof(BwdLds)));
+    attr_set = true;
+  }
+  if (kind == NM_ELASTICITY)
+    NM_LAUNCH(k_material_bwd<NM_ELASTICITY>, dim3(grid), dim3(256), sizeof(BwdLds), s, n, alpha, F, w->w0, w->w1,
+                       w->w2, gout, gF, (float*)workspace, want_w);
+  else
+    NM_LAUNCH(k_material_bwd<NM_PLASTICITY>, dim3(grid), dim3(256), sizeof(BwdLds), s, n, alpha, F, w->w0, w->w1,
+                       w->w2, gout, gF, (float*)workspace, want_w);
+  NM_LAUNCH_CHECK();
+  if (want_w) {
+    NM_LAUNCH(k_wgrad_reduce, dim3(nm_div_up(NM_WTOT, 256)), dim3(256), 0, s, (const float*)workspace, grid, gw0,
+                       gw1, gw2, (int)accumulate);
+    NM_LAUNCH_CHECK();
+  }
+  return NM_OK;
+}

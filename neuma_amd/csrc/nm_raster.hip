@@ -1,0 +1,693 @@
+// Particle-GS rasterizer (3DGS tile rasterizer, forward + backward) for gfx950.
+//
+// Replaces the un-vendored CUDA extension `diff_gaussian_rasterization` that the reference calls from
+// modules/d3gs/gaussian_renderer/__init__.py:92-119 and modules/tune/utils.py:385-419.  Algorithm and
+// constants follow the published 3DGS rasterizer (see SURVEY.md App. D and oracle/raster.py); the code is
+// organised for 64-wide wavefronts:
+//   * a 16x16 tile is four waves, each wave a 16x4 pixel strip; Gaussians of a tile are staged through LDS
+//     in batches of 256 and read back as wave-uniform broadcasts;
+//   * the backward pass never issues per-pixel atomics: each wave reduces a Gaussian's nine partial
+//     gradients over its 64 lanes with DPP row operations (no LDS traffic), waves combine through
+//     ds_add_f32 into a per-batch LDS table, and one thread per Gaussian flushes the tile total with global
+//     atomics (one set per (tile, Gaussian) pair instead of one per (pixel, Gaussian));
+//   * (tile, depth) ordering uses rocPRIM's device radix sort on 32 + log2(tiles) key bits.
+#include "nm_common.h"
+
+#include <rocprim/rocprim.hpp>
+
+#define NM_TILE 16
+#define NM_TPB 256
+
+struct RK {
+  int W, H, gx, gy, ty0, ty1, deg, M;
+  float tanx, tany, fx, fy;
+  float view[16], proj[16], cam[3], bg[3];
+};
+
+static int make_rk(const nm_raster_cfg* c, int m, RK& k) {
+  NM_REQUIRE(c, "null raster cfg");
+  NM_REQUIRE(c->image_width > 0 && c->image_height > 0, "bad image size");
+  NM_REQUIRE(c->sh_degree >= 0 && c->sh_degree <= 3, "sh_degree must be 0..3");
+  k.W = c->image_width; k.H = c->image_height;
+  k.gx = (k.W + NM_TILE - 1) / NM_TILE; k.gy = (k.H + NM_TILE - 1) / NM_TILE;
+  k.ty0 = 0; k.ty1 = k.gy;
+  if (c->tile_y1 > c->tile_y0) {
+    NM_REQUIRE(c->tile_y0 >= 0 && c->tile_y1 <= k.gy, "tile stripe out of range");
+    k.ty0 = c->tile_y0; k.ty1 = c->tile_y1;
+  }
+  k.deg = c->sh_degree; k.M = m;
+  k.tanx = c->tanfovx; k.tany = c->tanfovy;
+  k.fx = k.W / (2.0f * c->tanfovx); k.fy = k.H / (2.0f * c->tanfovy);
+  memcpy(k.view, c->viewmatrix, sizeof(k.view));
+  memcpy(k.proj, c->projmatrix, sizeof(k.proj));
+  memcpy(k.cam, c->campos, sizeof(k.cam));
+  memcpy(k.bg, c->bg, sizeof(k.bg));
+  return NM_OK;
+}
+
+// ---------------------------------------------------------------- buffer carving
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Geom {
+  float2* xy; float* depth; float4* conop; float* rgb; uint32_t* clamped; uint32_t* tiles; uint32_t* offs; int* rad;
+  void* scan_tmp; size_t scan_bytes; size_t total;
+};
+static size_t scan_temp_bytes(int k) {
+  size_t b = 0;
+  (void)rocprim::inclusive_scan(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)(k > 0 ? k : 1),
+                                rocprim::plus<uint32_t>());
+  return b;
+}
+static Geom carve_geom(void* base, int k) {
+  Geom g; char* p = (char*)base; size_t o = 0; size_t K = (size_t)(k > 0 ? k : 1);
+  g.xy = (float2*)(p + o); o += al256(K * sizeof(float2));
+  g.depth = (float*)(p + o); o += al256(K * sizeof(float));
+  g.conop = (float4*)(p + o); o += al256(K * sizeof(float4));
+  g.rgb = (float*)(p + o); o += al256(K * 3 * sizeof(float));
+  g.clamped = (uint32_t*)(p + o); o += al256(K * sizeof(uint32_t));
+  g.tiles = (uint32_t*)(p + o); o += al256(K * sizeof(uint32_t));
+  g.offs = (uint32_t*)(p + o); o += al256(K * sizeof(uint32_t));
+  g.rad = (int*)(p + o); o += al256(K * sizeof(int));
+  g.scan_bytes = scan_temp_bytes(k);
+  g.scan_tmp = (void*)(p + o); o += al256(g.scan_bytes);
+  g.total = o;
+  return g;
+}
+struct Binning { uint32_t* point_list; uint2* ranges; size_t total; };
+static Binning carve_binning(void* base, int64_t D, int ntiles) {
+  Binning b; char* p = (char*)base; size_t o = 0; size_t n = (size_t)(D > 0 ? D : 1);
+  b.point_list = (uint32_t*)(p + o); o += al256(n * sizeof(uint32_t));
+  b.ranges = (uint2*)(p + o); o += al256((size_t)ntiles * sizeof(uint2));
+  b.total = o;
+  return b;
+}
+struct Scratch { uint64_t* keys_in; uint64_t* keys_out; uint32_t* vals_in; void* sort_tmp; size_t sort_bytes; size_t total; };
+static Scratch carve_scratch(void* base, int64_t D) {
+  Scratch s; char* p = (char*)base; size_t o = 0; size_t n = (size_t)(D > 0 ? D : 1);
+  s.keys_in = (uint64_t*)(p + o); o += al256(n * sizeof(uint64_t));
+  s.keys_out = (uint64_t*)(p + o); o += al256(n * sizeof(uint64_t));
+  s.vals_in = (uint32_t*)(p + o); o += al256(n * sizeof(uint32_t));
+  size_t b = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, b, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
+                                  (uint32_t*)nullptr, n, 0u, 64u);
+  s.sort_bytes = b;
+  s.sort_tmp = (void*)(p + o); o += al256(b);
+  s.total = o;
+  return s;
+}
+struct Img { float* final_T; uint32_t* n_contrib; size_t total; };
+static Img carve_img(void* base, int W, int H) {
+  Img i; char* p = (char*)base; size_t o = 0; size_t n = (size_t)W * H;
+  i.final_T = (float*)(p + o); o += al256(n * sizeof(float));
+  i.n_contrib = (uint32_t*)(p + o); o += al256(n * sizeof(uint32_t));
+  i.total = o;
+  return i;
+}
+
+extern "C" size_t nm_raster_geom_bytes(int32_t k) { return carve_geom(nullptr, k).total; }
+extern "C" size_t nm_raster_binning_bytes(int64_t D, const nm_raster_cfg* c) {
+  int gx = (c->image_width + NM_TILE - 1) / NM_TILE, gy = (c->image_height + NM_TILE - 1) / NM_TILE;
+  return carve_binning(nullptr, D, gx * gy).total;
+}
+extern "C" size_t nm_raster_scratch_bytes(int64_t D) { return carve_scratch(nullptr, D).total; }
+extern "C" size_t nm_raster_image_bytes(const nm_raster_cfg* c) { return carve_img(nullptr, c->image_width, c->image_height).total; }
+
+// ---------------------------------------------------------------- device helpers
+__device__ __forceinline__ float3 xf43(const float* m, float x, float y, float z) {  // [p,1] * M, first 3 columns
+  return make_float3(m[0] * x + m[4] * y + m[8] * z + m[12], m[1] * x + m[5] * y + m[9] * z + m[13],
+                     m[2] * x + m[6] * y + m[10] * z + m[14]);
+}
+__device__ __forceinline__ float4 xf44(const float* m, float x, float y, float z) {
+  return make_float4(m[0] * x + m[4] * y + m[8] * z + m[12], m[1] * x + m[5] * y + m[9] * z + m[13],
+                     m[2] * x + m[6] * y + m[10] * z + m[14], m[3] * x + m[7] * y + m[11] * z + m[15]);
+}
+__device__ __forceinline__ void get_rect(const RK& k, float px, float py, int r, int& x0, int& y0, int& x1, int& y1, int ylo,
+                                         int yhi) {
+  x0 = min(k.gx, max(0, (int)((px - r) / NM_TILE)));
+  y0 = min(yhi, max(ylo, (int)((py - r) / NM_TILE)));
+  x1 = min(k.gx, max(0, (int)((px + r + NM_TILE - 1) / NM_TILE)));
+  y1 = min(yhi, max(ylo, (int)((py + r + NM_TILE - 1) / NM_TILE)));
+}
+
+#define SH_C0 0.28209479177387814f
+#define SH_C1 0.4886025119029199f
+__constant__ float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
+                               0.5462742152960396f};
+__constant__ float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                               -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+
+// projected 2D covariance (a, b, c) + the 2x3 matrix T = J * Rv and the clamped view-space point
+struct Cov2D { float a, b, c; float T[2][3]; float tx, ty, tz; float xmul, ymul; };
+__device__ __forceinline__ Cov2D compute_cov2d(const RK& k, float mx, float my, float mz, const float* __restrict__ c6) {
+  Cov2D o;
+  float3 t = xf43(k.view, mx, my, mz);
+  float limx = 1.3f * k.tanx, limy = 1.3f * k.tany;
+  float txtz = t.x / t.z, tytz = t.y / t.z;
+  o.xmul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+  o.ymul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+  t.x = fminf(limx, fmaxf(-limx, txtz)) * t.z;
+  t.y = fminf(limy, fmaxf(-limy, tytz)) * t.z;
+  o.tx = t.x; o.ty = t.y; o.tz = t.z;
+  float j00 = k.fx / t.z, j02 = -(k.fx * t.x) / (t.z * t.z), j11 = k.fy / t.z, j12 = -(k.fy * t.y) / (t.z * t.z);
+  // Rv[r][c] = view[4c + r]
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    o.T[0][c] = j00 * k.view[4 * c + 0] + j02 * k.view[4 * c + 2];
+    o.T[1][c] = j11 * k.view[4 * c + 1] + j12 * k.view[4 * c + 2];
+  }
+  float S[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+  float ST0[3], ST1[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    ST0[i] = S[i][0] * o.T[0][0] + S[i][1] * o.T[0][1] + S[i][2] * o.T[0][2];
+    ST1[i] = S[i][0] * o.T[1][0] + S[i][1] * o.T[1][1] + S[i][2] * o.T[1][2];
+  }
+  o.a = o.T[0][0] * ST0[0] + o.T[0][1] * ST0[1] + o.T[0][2] * ST0[2] + 0.3f;
+  o.b = o.T[0][0] * ST1[0] + o.T[0][1] * ST1[1] + o.T[0][2] * ST1[2];
+  o.c = o.T[1][0] * ST1[0] + o.T[1][1] * ST1[1] + o.T[1][2] * ST1[2] + 0.3f;
+  return o;
+}
+
+// ---------------------------------------------------------------- forward kernels
+__global__ void __launch_bounds__(256) k_preprocess(RK k, int K, const float* __restrict__ means, const float* __restrict__ shs,
+                                                    const float* __restrict__ colors, const float* __restrict__ opac,
+                                                    const float* __restrict__ cov3D, int* __restrict__ radii, float2* __restrict__ xy,
+                                                    float* __restrict__ depth, float4* __restrict__ conop, float* __restrict__ rgb,
+                                                    uint32_t* __restrict__ clamped, uint32_t* __restrict__ tiles, int* __restrict__ grad_) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K) return;
+  radii[i] = 0;
+  grad_[i] = 0;
+  tiles[i] = 0;
+  float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
+  float3 pv = xf43(k.view, mx, my, mz);
+  if (!(pv.z > 0.2f)) return;  // near-plane cull
+  float4 ph = xf44(k.proj, mx, my, mz);
+  float pw = 1.0f / (ph.w + 0.0000001f);
+  float ndx = ph.x * pw, ndy = ph.y * pw;
+  float c6[6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) c6[a] = cov3D[6 * i + a];
+  Cov2D cv = compute_cov2d(k, mx, my, mz, c6);
+  float det = cv.a * cv.c - cv.b * cv.b;
+  if (det == 0.0f) return;
+  float det_inv = 1.f / det;
+  float mid = 0.5f * (cv.a + cv.c);
+  float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+  int r = (int)ceilf(3.f * sqrtf(lam));
+  float px = ((ndx + 1.0f) * k.W - 1.0f) * 0.5f, py = ((ndy + 1.0f) * k.H - 1.0f) * 0.5f;
+  int x0, y0, x1, y1;
+  get_rect(k, px, py, r, x0, y0, x1, y1, 0, k.gy);
+  if ((x1 - x0) * (y1 - y0) == 0) return;
+  // colour
+  uint32_t cl = 0;
+  float col[3];
+  if (colors) {
+    col[0] = colors[3 * i]; col[1] = colors[3 * i + 1]; col[2] = colors[3 * i + 2];
+  } else {
+    float dx = mx - k.cam[0], dy = my - k.cam[1], dz = mz - k.cam[2];
+    float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+    float x = dx * inv, y = dy * inv, z = dz * inv;
+    const float* sh = shs + (size_t)i * k.M * 3;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      float res = SH_C0 * sh[ch];
+      if (k.deg > 0) {
+        res = res - SH_C1 * y * sh[3 + ch] + SH_C1 * z * sh[6 + ch] - SH_C1 * x * sh[9 + ch];
+        if (k.deg > 1) {
+          float xx = x * x, yy = y * y, zz = z * z, xy_ = x * y, yz = y * z, xz = x * z;
+          res = res + SH_C2[0] * xy_ * sh[12 + ch] + SH_C2[1] * yz * sh[15 + ch] + SH_C2[2] * (2.f * zz - xx - yy) * sh[18 + ch] +
+                SH_C2[3] * xz * sh[21 + ch] + SH_C2[4] * (xx - yy) * sh[24 + ch];
+          if (k.deg > 2) {
+            res = res + SH_C3[0] * y * (3.f * xx - yy) * sh[27 + ch] + SH_C3[1] * xy_ * z * sh[30 + ch] +
+                  SH_C3[2] * y * (4.f * zz - xx - yy) * sh[33 + ch] + SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * sh[36 + ch] +
+                  SH_C3[4] * x * (4.f * zz - xx - yy) * sh[39 + ch] + SH_C3[5] * z * (xx - yy) * sh[42 + ch] +
+                  SH_C3[6] * x * (xx - 3.f * yy) * sh[45 + ch];
+          }
+        }
+      }
+      res += 0.5f;
+      if (res < 0.f) { cl |= (1u << ch); res = 0.f; }
+      col[ch] = res;
+    }
+  }
+  int sx0, sy0, sx1, sy1;
+  get_rect(k, px, py, r, sx0, sy0, sx1, sy1, k.ty0, k.ty1);
+  radii[i] = r;
+  grad_[i] = r;
+  xy[i] = make_float2(px, py);
+  depth[i] = pv.z;
+  conop[i] = make_float4(cv.c * det_inv, -cv.b * det_inv, cv.a * det_inv, opac[i]);
+  rgb[3 * i] = col[0]; rgb[3 * i + 1] = col[1]; rgb[3 * i + 2] = col[2];
+  clamped[i] = cl;
+  tiles[i] = (uint32_t)(max(0, sx1 - sx0) * max(0, sy1 - sy0));
+}
+
+__global__ void __launch_bounds__(256) k_emit_keys(RK k, int K, const int* __restrict__ radii, const float2* __restrict__ xy,
+                                                   const float* __restrict__ depth, const uint32_t* __restrict__ offs,
+                                                   const uint32_t* __restrict__ tiles, uint64_t* __restrict__ keys,
+                                                   uint32_t* __restrict__ vals) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K || tiles[i] == 0) return;
+  uint32_t off = (i == 0) ? 0u : offs[i - 1];
+  float2 p = xy[i];
+  int x0, y0, x1, y1;
+  get_rect(k, p.x, p.y, radii[i], x0, y0, x1, y1, k.ty0, k.ty1);
+  uint64_t dbits = (uint64_t)__float_as_uint(depth[i]);
+  for (int y = y0; y < y1; ++y)
+    for (int x = x0; x < x1; ++x) {
+      keys[off] = ((uint64_t)(uint32_t)(y * k.gx + x) << 32) | dbits;
+      vals[off] = (uint32_t)i;
+      ++off;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_tile_ranges(int64_t D, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= D) return;
+  uint32_t t = (uint32_t)(keys[i] >> 32);
+  if (i == 0) ranges[t].x = 0;
+  else {
+    uint32_t tp = (uint32_t)(keys[i - 1] >> 32);
+    if (t != tp) { ranges[tp].y = (uint32_t)i; ranges[t].x = (uint32_t)i; }
+  }
+  if (i == D - 1) ranges[t].y = (uint32_t)D;
+}
+
+// front-to-back composite of one 16x16 tile (upstream renderCUDA forward)
+__global__ void __launch_bounds__(NM_TPB) k_render(RK k, const uint2* __restrict__ ranges, const uint32_t* __restrict__ plist,
+                                                   const float2* __restrict__ xy, const float* __restrict__ rgb,
+                                                   const float4* __restrict__ conop, float* __restrict__ final_T,
+                                                   uint32_t* __restrict__ n_contrib, float* __restrict__ out) {
+  __shared__ float2 s_xy[NM_TPB];
+  __shared__ float4 s_co[NM_TPB];
+  __shared__ float s_rgb[NM_TPB * 3];
+  const int tile_x = blockIdx.x, tile_y = blockIdx.y + k.ty0;
+  const int tid = threadIdx.x;
+  const int px = tile_x * NM_TILE + (tid & 15), py = tile_y * NM_TILE + (tid >> 4);
+  const bool inside = px < k.W && py < k.H;
+  const float fxp = (float)px, fyp = (float)py;
+  const uint2 range = ranges[tile_y * k.gx + tile_x];
+  int todo = (int)(range.y - range.x);
+  const int rounds = (todo + NM_TPB - 1) / NM_TPB;
+  bool done = !inside;
+  float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+  uint32_t contributor = 0, last = 0;
+  for (int rd = 0; rd < rounds; ++rd, todo -= NM_TPB) {
+    if (__syncthreads_count(done) == NM_TPB) break;
+    int prog = rd * NM_TPB + tid;
+    if (range.x + prog < range.y) {
+      uint32_t id = plist[range.x + prog];
+      s_xy[tid] = xy[id];
+      s_co[tid] = conop[id];
+      s_rgb[3 * tid] = rgb[3 * id]; s_rgb[3 * tid + 1] = rgb[3 * id + 1]; s_rgb[3 * tid + 2] = rgb[3 * id + 2];
+    }
+    __syncthreads();
+    const int nb = min(NM_TPB, todo);
+    for (int j = 0; !done && j < nb; ++j) {
+      contributor++;
+      float2 p = s_xy[j];
+      float4 co = s_co[j];
+      float dx = p.x - fxp, dy = p.y - fyp;
+      float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+      if (power > 0.f) continue;
+      float alpha = fminf(0.99f, co.w * __expf(power));
+      if (alpha < 1.0f / 255.0f) continue;
+      float test_T = T * (1.f - alpha);
+      if (test_T < 0.0001f) { done = true; continue; }
+      float w = alpha * T;
+      C0 += s_rgb[3 * j] * w; C1 += s_rgb[3 * j + 1] * w; C2 += s_rgb[3 * j + 2] * w;
+      T = test_T;
+      last = contributor;
+    }
+  }
+  if (inside) {
+    size_t pix = (size_t)py * k.W + px, hw = (size_t)k.H * k.W;
+    final_T[pix] = T;
+    n_contrib[pix] = last;
+    out[pix] = C0 + T * k.bg[0];
+    out[hw + pix] = C1 + T * k.bg[1];
+    out[2 * hw + pix] = C2 + T * k.bg[2];
+  }
+}
+
+// ---------------------------------------------------------------- backward kernels
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float x) {
+  int y = __builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true);
+  return x + __int_as_float(y);
+}
+// sum over the 64 lanes using DPP inside each row of 16 and four readlanes across rows (wave-uniform result)
+__device__ __forceinline__ float wave_sum_dpp(float x) {
+  x = dpp_add<0xB1>(x);   // quad_perm [1,0,3,2]
+  x = dpp_add<0x4E>(x);   // quad_perm [2,3,0,1]
+  x = dpp_add<0x141>(x);  // row_half_mirror
+  x = dpp_add<0x140>(x);  // row_mirror
+  int xi = __float_as_int(x);
+  return __int_as_float(__builtin_amdgcn_readlane(xi, 0)) + __int_as_float(__builtin_amdgcn_readlane(xi, 16)) +
+         __int_as_float(__builtin_amdgcn_readlane(xi, 32)) + __int_as_float(__builtin_amdgcn_readlane(xi, 48));
+}
+
+#define NM_NG 9  // reduced per-Gaussian quantities: mean2D(2) conic(3) opacity(1) colour(3)
+
+__global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, const uint2* __restrict__ ranges, const uint32_t* __restrict__ plist,
+                                                       const float2* __restrict__ xy, const float* __restrict__ rgb,
+                                                       const float4* __restrict__ conop, const float* __restrict__ final_T,
+                                                       const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
+                                                       float* __restrict__ acc /* (K, 9) */) {
+  __shared__ uint32_t s_id[NM_TPB];
+  __shared__ float2 s_xy[NM_TPB];
+  __shared__ float4 s_co[NM_TPB];
+  __shared__ float s_rgb[NM_TPB * 3];
+  __shared__ float s_acc[NM_TPB * NM_NG];
+  const int tile_x = blockIdx.x, tile_y = blockIdx.y + k.ty0;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int px = tile_x * NM_TILE + (tid & 15), py = tile_y * NM_TILE + (tid >> 4);
+  const bool inside = px < k.W && py < k.H;
+  const float fxp = (float)px, fyp = (float)py;
+  const uint2 range = ranges[tile_y * k.gx + tile_x];
+  int todo = (int)(range.y - range.x);
+  const int rounds = (todo + NM_TPB - 1) / NM_TPB;
+  const size_t pix = (size_t)py * k.W + px, hw = (size_t)k.H * k.W;
+  const float T_final = inside ? final_T[pix] : 0.f;
+  float T = T_final;
+  uint32_t contributor = (uint32_t)todo;
+  const uint32_t last_contributor = inside ? n_contrib[pix] : 0u;
+  float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f;
+  if (inside) { dp0 = dL_dpix[pix]; dp1 = dL_dpix[hw + pix]; dp2 = dL_dpix[2 * hw + pix]; }
+  const float bg_dot = k.bg[0] * dp0 + k.bg[1] * dp1 + k.bg[2] * dp2;
+  float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
+  const float ddelx_dx = 0.5f * k.W, ddely_dy = 0.5f * k.H;
+  for (int i = tid; i < NM_TPB * NM_NG; i += NM_TPB) s_acc[i] = 0.f;
+  for (int rd = 0; rd < rounds; ++rd, todo -= NM_TPB) {
+    __syncthreads();
+    int prog = rd * NM_TPB + tid;
+    if (range.x + prog < range.y) {
+      uint32_t id = plist[range.y - prog - 1];  // back to front
+      s_id[tid] = id;
+      s_xy[tid] = xy[id];
+      s_co[tid] = conop[id];
+      s_rgb[3 * tid] = rgb[3 * id]; s_rgb[3 * tid + 1] = rgb[3 * id + 1]; s_rgb[3 * tid + 2] = rgb[3 * id + 2];
+    }
+    __syncthreads();
+    const int nb = min(NM_TPB, todo);
+    for (int j = 0; j < nb; ++j) {
+      contributor--;
+      bool act = contributor < last_contributor;
+      float2 p = s_xy[j];
+      float4 co = s_co[j];
+      float dx = p.x - fxp, dy = p.y - fyp;
+      float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+      float G = __expf(power);
+      float alpha = fminf(0.99f, co.w * G);
+      act = act && !(power > 0.f) && !(alpha < 1.0f / 255.0f);
+      if (__ballot(act) == 0ull) continue;  // whole wave skips this Gaussian
+      float g[NM_NG];
+#pragma unroll
+      for (int q = 0; q < NM_NG; ++q) g[q] = 0.f;
+      if (act) {
+        T = T / (1.f - alpha);
+        float dch = alpha * T;
+        float c0 = s_rgb[3 * j], c1 = s_rgb[3 * j + 1], c2 = s_rgb[3 * j + 2];
+        ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = c0;
+        ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = c1;
+        ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = c2;
+        float dL_dalpha = (c0 - ar0) * dp0 + (c1 - ar1) * dp1 + (c2 - ar2) * dp2;
+        g[6] = dch * dp0; g[7] = dch * dp1; g[8] = dch * dp2;
+        dL_dalpha *= T;
+        last_alpha = alpha;
+        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+        float dL_dG = co.w * dL_dalpha;
+        float gdx = G * dx, gdy = G * dy;
+        float dG_ddelx = -gdx * co.x - gdy * co.y;
+        float dG_ddely = -gdy * co.z - gdx * co.y;
+        g[0] = dL_dG * dG_ddelx * ddelx_dx;   // d/d(ndc x)
+        g[1] = dL_dG * dG_ddely * ddely_dy;
+        g[2] = -0.5f * gdx * dx * dL_dG;       // d/d conic.x
+        g[3] = -gdx * dy * dL_dG;              // d/d conic.y (full off-diagonal derivative)
+        g[4] = -0.5f * gdy * dy * dL_dG;       // d/d conic.z
+        g[5] = G * dL_dalpha;                  // d/d opacity
+      }
+#pragma unroll
+      for (int q = 0; q < NM_NG; ++q) g[q] = wave_sum_dpp(g[q]);
+      if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < NM_NG; ++q) unsafeAtomicAdd(&s_acc[j * NM_NG + q], g[q]);
+      }
+    }
+    __syncthreads();
+    // one global atomic set per (tile, Gaussian)
+    if (tid < nb) {
+      uint32_t id = s_id[tid];
+      float* dst = acc + (size_t)id * NM_NG;
+#pragma unroll
+      for (int q = 0; q < NM_NG; ++q) {
+        float v = s_acc[tid * NM_NG + q];
+        if (v != 0.f) unsafeAtomicAdd(dst + q, v);
+        s_acc[tid * NM_NG + q] = 0.f;
+      }
+    }
+  }
+}
+
+// adjoint of k_preprocess: per-Gaussian chain rule to means3D / cov3D / SH (upstream computeCov2DCUDA +
+// preprocessCUDA backward)
+__global__ void __launch_bounds__(256) k_preprocess_bwd(RK k, int K, const float* __restrict__ means, const float* __restrict__ shs,
+                                                        const float* __restrict__ cov3D, const int* __restrict__ tiles_or_radii,
+                                                        const uint32_t* __restrict__ clamped, const float* __restrict__ acc,
+                                                        float* __restrict__ dmeans, float* __restrict__ dmeans2D,
+                                                        float* __restrict__ dcov, float* __restrict__ dopac, float* __restrict__ dsh,
+                                                        float* __restrict__ dcol, int has_sh) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K) return;
+  float gm[3] = {0.f, 0.f, 0.f};
+  float gc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool vis = tiles_or_radii[i] > 0;
+  const float* a = acc + (size_t)i * NM_NG;
+  if (vis) {
+    float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
+    // ---- colour -> SH / view direction
+    float dRGB[3] = {a[6], a[7], a[8]};
+    if (has_sh) {
+      uint32_t cl = clamped[i];
+      float dx = mx - k.cam[0], dy = my - k.cam[1], dz = mz - k.cam[2];
+      float len2 = dx * dx + dy * dy + dz * dz;
+      float inv = 1.f / sqrtf(len2);
+      float x = dx * inv, y = dy * inv, z = dz * inv;
+      const float* sh = shs + (size_t)i * k.M * 3;
+      float* gsh = dsh ? dsh + (size_t)i * k.M * 3 : nullptr;
+      float ddir[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        float dl = (cl & (1u << ch)) ? 0.f : dRGB[ch];
+        float rx = 0.f, ry = 0.f, rz = 0.f;
+        if (gsh) gsh[ch] = SH_C0 * dl;
+        if (k.deg > 0) {
+          float s1 = sh[3 + ch], s2 = sh[6 + ch], s3 = sh[9 + ch];
+          if (gsh) { gsh[3 + ch] = -SH_C1 * y * dl; gsh[6 + ch] = SH_C1 * z * dl; gsh[9 + ch] = -SH_C1 * x * dl; }
+          rx = -SH_C1 * s3; ry = -SH_C1 * s1; rz = SH_C1 * s2;
+          if (k.deg > 1) {
+            float xx = x * x, yy = y * y, zz = z * z, xy_ = x * y, yz = y * z, xz = x * z;
+            float s4 = sh[12 + ch], s5 = sh[15 + ch], s6 = sh[18 + ch], s7 = sh[21 + ch], s8 = sh[24 + ch];
+            if (gsh) {
+              gsh[12 + ch] = SH_C2[0] * xy_ * dl; gsh[15 + ch] = SH_C2[1] * yz * dl;
+              gsh[18 + ch] = SH_C2[2] * (2.f * zz - xx - yy) * dl; gsh[21 + ch] = SH_C2[3] * xz * dl;
+              gsh[24 + ch] = SH_C2[4] * (xx - yy) * dl;
+            }
+            rx += SH_C2[0] * y * s4 + SH_C2[2] * 2.f * -x * s6 + SH_C2[3] * z * s7 + SH_C2[4] * 2.f * x * s8;
+            ry += SH_C2[0] * x * s4 + SH_C2[1] * z * s5 + SH_C2[2] * 2.f * -y * s6 + SH_C2[4] * 2.f * -y * s8;
+            rz += SH_C2[1] * y * s5 + SH_C2[2] * 4.f * z * s6 + SH_C2[3] * x * s7;
+            if (k.deg > 2) {
+              float s9 = sh[27 + ch], s10 = sh[30 + ch], s11 = sh[33 + ch], s12 = sh[36 + ch], s13 = sh[39 + ch],
+                    s14 = sh[42 + ch], s15 = sh[45 + ch];
+              if (gsh) {
+                gsh[27 + ch] = SH_C3[0] * y * (3.f * xx - yy) * dl; gsh[30 + ch] = SH_C3[1] * xy_ * z * dl;
+                gsh[33 + ch] = SH_C3[2] * y * (4.f * zz - xx - yy) * dl;
+                gsh[36 + ch] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * dl;
+                gsh[39 + ch] = SH_C3[4] * x * (4.f * zz - xx - yy) * dl; gsh[42 + ch] = SH_C3[5] * z * (xx - yy) * dl;
+                gsh[45 + ch] = SH_C3[6] * x * (xx - 3.f * yy) * dl;
+              }
+              rx += SH_C3[0] * s9 * 6.f * xy_ + SH_C3[1] * s10 * yz + SH_C3[2] * s11 * -2.f * xy_ + SH_C3[3] * s12 * -6.f * xz +
+                    SH_C3[4] * s13 * (4.f * zz - 3.f * xx - yy) + SH_C3[5] * s14 * 2.f * xz + SH_C3[6] * s15 * 3.f * (xx - yy);
+              ry += SH_C3[0] * s9 * 3.f * (xx - yy) + SH_C3[1] * s10 * xz + SH_C3[2] * s11 * (4.f * zz - xx - 3.f * yy) +
+                    SH_C3[3] * s12 * -6.f * yz + SH_C3[4] * s13 * -2.f * xy_ + SH_C3[5] * s14 * -2.f * yz + SH_C3[6] * s15 * -6.f * xy_;
+              rz += SH_C3[1] * s10 * xy_ + SH_C3[2] * s11 * 8.f * yz + SH_C3[3] * s12 * 3.f * (2.f * zz - xx - yy) +
+                    SH_C3[4] * s13 * 8.f * xz + SH_C3[5] * s14 * (xx - yy);
+            }
+          }
+        }
+        ddir[0] += rx * dl; ddir[1] += ry * dl; ddir[2] += rz * dl;
+      }
+      // through the normalisation  n = d / |d|
+      float dot = x * ddir[0] + y * ddir[1] + z * ddir[2];
+      gm[0] += (ddir[0] - x * dot) * inv;
+      gm[1] += (ddir[1] - y * dot) * inv;
+      gm[2] += (ddir[2] - z * dot) * inv;
+    } else if (dcol) {
+      dcol[3 * i] = dRGB[0]; dcol[3 * i + 1] = dRGB[1]; dcol[3 * i + 2] = dRGB[2];
+    }
+    // ---- conic -> cov2D -> cov3D and view-space point
+    float c6[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) c6[q] = cov3D[6 * i + q];
+    Cov2D cv = compute_cov2d(k, mx, my, mz, c6);
+    float denom = cv.a * cv.c - cv.b * cv.b;
+    float d2inv = 1.f / (denom * denom + 0.0000001f);
+    if (denom * denom + 0.0000001f != 0.f) {
+      float dA = a[2], dB = a[3], dC = a[4];
+      float dL_da = d2inv * (-cv.c * cv.c * dA + cv.b * cv.c * dB - cv.b * cv.b * dC);
+      float dL_dc = d2inv * (-cv.b * cv.b * dA + cv.a * cv.b * dB - cv.a * cv.a * dC);
+      float dL_db = d2inv * (2.f * cv.b * cv.c * dA - (cv.a * cv.c + cv.b * cv.b) * dB + 2.f * cv.a * cv.b * dC);
+      const float(*T)[3] = cv.T;
+      gc[0] = T[0][0] * T[0][0] * dL_da + T[0][0] * T[1][0] * dL_db + T[1][0] * T[1][0] * dL_dc;
+      gc[3] = T[0][1] * T[0][1] * dL_da + T[0][1] * T[1][1] * dL_db + T[1][1] * T[1][1] * dL_dc;
+      gc[5] = T[0][2] * T[0][2] * dL_da + T[0][2] * T[1][2] * dL_db + T[1][2] * T[1][2] * dL_dc;
+      gc[1] = 2.f * T[0][0] * T[0][1] * dL_da + (T[0][0] * T[1][1] + T[0][1] * T[1][0]) * dL_db + 2.f * T[1][0] * T[1][1] * dL_dc;
+      gc[2] = 2.f * T[0][0] * T[0][2] * dL_da + (T[0][0] * T[1][2] + T[0][2] * T[1][0]) * dL_db + 2.f * T[1][0] * T[1][2] * dL_dc;
+      gc[4] = 2.f * T[0][2] * T[0][1] * dL_da + (T[0][1] * T[1][2] + T[0][2] * T[1][1]) * dL_db + 2.f * T[1][1] * T[1][2] * dL_dc;
+      // dL/dT
+      float S[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+      float dT0[3], dT1[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        float st0 = S[q][0] * T[0][0] + S[q][1] * T[0][1] + S[q][2] * T[0][2];
+        float st1 = S[q][0] * T[1][0] + S[q][1] * T[1][1] + S[q][2] * T[1][2];
+        dT0[q] = 2.f * dL_da * st0 + dL_db * st1;
+        dT1[q] = 2.f * dL_dc * st1 + dL_db * st0;
+      }
+      // dL/dJ[r][m] = sum_q dT[r][q] Rv[m][q],  Rv[m][q] = view[4q + m]
+      float dJ00 = dT0[0] * k.view[0] + dT0[1] * k.view[4] + dT0[2] * k.view[8];
+      float dJ02 = dT0[0] * k.view[2] + dT0[1] * k.view[6] + dT0[2] * k.view[10];
+      float dJ11 = dT1[0] * k.view[1] + dT1[1] * k.view[5] + dT1[2] * k.view[9];
+      float dJ12 = dT1[0] * k.view[2] + dT1[1] * k.view[6] + dT1[2] * k.view[10];
+      float tz = 1.f / cv.tz, tz2 = tz * tz, tz3 = tz2 * tz;
+      float dtx = cv.xmul * -k.fx * tz2 * dJ02;
+      float dty = cv.ymul * -k.fy * tz2 * dJ12;
+      float dtz = -k.fx * tz2 * dJ00 - k.fy * tz2 * dJ11 + (2.f * k.fx * cv.tx) * tz3 * dJ02 + (2.f * k.fy * cv.ty) * tz3 * dJ12;
+      // t = Rv mu + tv  ->  dmu_c = sum_r Rv[r][c] dt_r = view[4c + r] dt_r
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gm[c] += k.view[4 * c] * dtx + k.view[4 * c + 1] * dty + k.view[4 * c + 2] * dtz;
+    }
+    // ---- 2D mean -> 3D mean through the perspective divide
+    float4 mh = xf44(k.proj, mx, my, mz);
+    float mw = 1.0f / (mh.w + 0.0000001f);
+    float mul1 = mh.x * mw * mw, mul2 = mh.y * mw * mw;
+    float d0 = a[0], d1 = a[1];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      gm[c] += (k.proj[4 * c] * mw - k.proj[4 * c + 3] * mul1) * d0 + (k.proj[4 * c + 1] * mw - k.proj[4 * c + 3] * mul2) * d1;
+  } else {
+    if (has_sh && dsh) {
+      float* gsh = dsh + (size_t)i * k.M * 3;
+      for (int q = 0; q < k.M * 3; ++q) gsh[q] = 0.f;
+    }
+    if (!has_sh && dcol) { dcol[3 * i] = 0.f; dcol[3 * i + 1] = 0.f; dcol[3 * i + 2] = 0.f; }
+  }
+  if (vis && has_sh && dsh) {
+    float* gsh = dsh + (size_t)i * k.M * 3;
+    int used = (k.deg + 1) * (k.deg + 1);
+    for (int q = used * 3; q < k.M * 3; ++q) gsh[q] = 0.f;
+  }
+  dmeans[3 * i] = gm[0]; dmeans[3 * i + 1] = gm[1]; dmeans[3 * i + 2] = gm[2];
+  if (dmeans2D) { dmeans2D[3 * i] = vis ? a[0] : 0.f; dmeans2D[3 * i + 1] = vis ? a[1] : 0.f; dmeans2D[3 * i + 2] = 0.f; }
+  if (dcov) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) dcov[6 * i + q] = gc[q];
+  }
+  if (dopac) dopac[i] = vis ? a[5] : 0.f;
+}
+
+// ---------------------------------------------------------------- host API
+extern "C" int nm_raster_preprocess(const nm_raster_cfg* cfg, int32_t K, int32_t m, const float* means3D, const float* shs,
+                                    const float* colors_precomp, const float* opacities, const float* cov3D, int32_t* radii,
+                                    void* geom, size_t geom_bytes, int64_t* num_rendered, void* stream) {
+  RK k;
+  int rc = make_rk(cfg, m, k);
+  if (rc) return rc;
+  NM_REQUIRE(K >= 0 && num_rendered, "bad arguments");
+  *num_rendered = 0;
+  if (K == 0) return NM_OK;
+  NM_REQUIRE((shs != nullptr) != (colors_precomp != nullptr), "provide exactly one of shs / colors_precomp");
+  NM_REQUIRE(!shs || m >= (cfg->sh_degree + 1) * (cfg->sh_degree + 1), "shs has too few coefficients for sh_degree");
+  NM_REQUIRE(means3D && opacities && cov3D && radii && geom, "null pointer");
+  Geom g = carve_geom(geom, K);
+  if (geom_bytes < g.total) { nm_set_error("geom buffer too small: need %zu got %zu", g.total, geom_bytes); return NM_ERR_WORKSPACE; }
+  hipStream_t s = (hipStream_t)stream;
+  NM_LAUNCH(k_preprocess, dim3(nm_div_up(K, 256)), dim3(256), 0, s, k, K, means3D, shs, colors_precomp, opacities, cov3D,
+                     radii, g.xy, g.depth, g.conop, g.rgb, g.clamped, g.tiles, g.rad);
+  NM_LAUNCH_CHECK();
+  size_t tb = g.scan_bytes;
+  NM_HIP_CHECK(rocprim::inclusive_scan(g.scan_tmp, tb, g.tiles, g.offs, (size_t)K, rocprim::plus<uint32_t>(), s));
+  uint32_t total = 0;
+  NM_HIP_CHECK(hipMemcpyAsync(&total, g.offs + (K - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  NM_HIP_CHECK(hipStreamSynchronize(s));
+  *num_rendered = (int64_t)total;
+  return NM_OK;
+}
+
+extern "C" int nm_raster_render(const nm_raster_cfg* cfg, int32_t K, int64_t D, const void* geom, void* binning,
+                                size_t binning_bytes, void* scratch, size_t scratch_bytes, void* image, size_t image_bytes,
+                                float* out_color, void* stream) {
+  RK k;
+  int rc = make_rk(cfg, 0, k);
+  if (rc) return rc;
+  NM_REQUIRE(K >= 0 && D >= 0 && out_color && image && binning, "bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  Geom g = carve_geom((void*)geom, K);
+  Binning b = carve_binning(binning, D, k.gx * k.gy);
+  Img im = carve_img(image, k.W, k.H);
+  if (binning_bytes < b.total) { nm_set_error("binning buffer too small: need %zu got %zu", b.total, binning_bytes); return NM_ERR_WORKSPACE; }
+  if (image_bytes < im.total) { nm_set_error("image buffer too small: need %zu got %zu", im.total, image_bytes); return NM_ERR_WORKSPACE; }
+  NM_HIP_CHECK(hipMemsetAsync(b.ranges, 0, (size_t)k.gx * k.gy * sizeof(uint2), s));
+  if (D > 0) {
+    NM_REQUIRE(geom && scratch, "null geom/scratch");
+    Scratch sc = carve_scratch(scratch, D);
+    if (scratch_bytes < sc.total) { nm_set_error("scratch buffer too small: need %zu got %zu", sc.total, scratch_bytes); return NM_ERR_WORKSPACE; }
+    NM_LAUNCH(k_emit_keys, dim3(nm_div_up(K, 256)), dim3(256), 0, s, k, K, (const int*)g.rad, g.xy,
+                       g.depth, g.offs, g.tiles, sc.keys_in, sc.vals_in);
+    NM_LAUNCH_CHECK();
+    int bits = 0;
+    while ((1 << bits) < k.gx * k.gy) ++bits;
+    size_t tb = sc.sort_bytes;
+    NM_HIP_CHECK(rocprim::radix_sort_pairs(sc.sort_tmp, tb, sc.keys_in, sc.keys_out, sc.vals_in, b.point_list, (size_t)D, 0u,
+                                           (unsigned)(32 + bits), s));
+    NM_LAUNCH(k_tile_ranges, dim3(nm_div_up(D, 256)), dim3(256), 0, s, D, sc.keys_out, b.ranges);
+    NM_LAUNCH_CHECK();
+  }
+  NM_LAUNCH(k_render, dim3(k.gx, k.ty1 - k.ty0), dim3(NM_TPB), 0, s, k, b.ranges, b.point_list, g.xy, g.rgb, g.conop,
+                     im.final_T, im.n_contrib, out_color);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}
+
+extern "C" size_t nm_raster_bwd_workspace(int32_t K) { return al256((size_t)(K > 0 ? K : 1) * NM_NG * sizeof(float)); }
+
+extern "C" int nm_raster_backward(const nm_raster_cfg* cfg, int32_t K, int32_t m, int64_t D, const float* means3D,
+                                  const float* shs, const float* colors_precomp, const float* opacities, const float* cov3D,
+                                  const void* geom, const void* binning, const void* image, const float* dL_dcolor,
+                                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcov3D, float* dL_dopacity, float* dL_dshs,
+                                  float* dL_dcolors, void* workspace, size_t workspace_bytes, void* stream) {
+  (void)opacities; (void)colors_precomp;
+  RK k;
+  int rc = make_rk(cfg, m, k);
+  if (rc) return rc;
+  NM_REQUIRE(K >= 0 && D >= 0, "bad arguments");
+  if (K == 0) return NM_OK;
+  NM_REQUIRE(means3D && cov3D && geom && binning && image && dL_dcolor && dL_dmeans3D && workspace, "null pointer");
+  if (workspace_bytes < nm_raster_bwd_workspace(K)) { nm_set_error("raster backward workspace too small"); return NM_ERR_WORKSPACE; }
+  hipStream_t s = (hipStream_t)stream;
+  Geom g = carve_geom((void*)geom, K);
+  Binning b = carve_binning((void*)binning, D, k.gx * k.gy);
+  Img im = carve_img((void*)image, k.W, k.H);
+  float* acc = (float*)workspace;
+  NM_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)K * NM_NG * sizeof(float), s));
+  if (D > 0) {
+    NM_LAUNCH(k_render_bwd, dim3(k.gx, k.ty1 - k.ty0), dim3(NM_TPB), 0, s, k, b.ranges, b.point_list, g.xy, g.rgb, g.conop,
+                       im.final_T, im.n_contrib, dL_dcolor, acc);
+    NM_LAUNCH_CHECK();
+  }
+  NM_LAUNCH(k_preprocess_bwd, dim3(nm_div_up(K, 256)), dim3(256), 0, s, k, K, means3D, shs, cov3D, (const int*)g.tiles,
+                     g.clamped, acc, dL_dmeans3D, dL_dmeans2D, dL_dcov3D, dL_dopacity, dL_dshs, dL_dcolors, shs ? 1 : 0);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}

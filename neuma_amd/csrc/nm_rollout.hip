@@ -1,0 +1,150 @@
+// Fused roll-out of S substeps with checkpointed BPTT.
+// Operator order follows /root/reference/experiments/finetune.py:360-364 (stress = E(F); sim; F = P(F)),
+// the reverse sweep follows interface.py:41-76 + mpm.py:299-319 per step.  Only (x,v,C,F) per substep is
+// kept (96 B/particle); stress, the trial deformation gradient and the grid are recomputed.
+#include "nm_common.h"
+
+#define NM_WTOT_ (64 * 13 + 64 * 64 + 9 * 64)
+
+static inline size_t al256r(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct RolloutWs {
+  float* stress;   // N*9
+  float* ftrial;   // N*9   trial F out of g2p (input of plasticity)
+  float* ga;       // N*24  gradient ping
+  float* gb;       // N*24  gradient pong (+ stress grad N*9 appended)
+  float* gS;       // N*9
+  float* gFe;      // N*9
+  float* gFtr;     // N*9
+  void* mat;       // material backward workspace
+  size_t mat_bytes;
+  size_t total;
+};
+
+static RolloutWs carve_ws(void* base, int n) {
+  RolloutWs w;
+  char* p = (char*)base;
+  size_t o = 0, N = (size_t)(n > 0 ? n : 1);
+  auto take = [&](size_t floats) { float* r = (float*)(p + o); o += al256r(floats * sizeof(float)); return r; };
+  w.stress = take(N * 9);
+  w.ftrial = take(N * 9);
+  w.ga = take(N * 24);
+  w.gb = take(N * 24);
+  w.gS = take(N * 9);
+  w.gFe = take(N * 9);
+  w.gFtr = take(N * 9);
+  w.mat_bytes = nm_material_bwd_workspace(n);
+  w.mat = (void*)(p + o);
+  o += al256r(w.mat_bytes);
+  w.total = o;
+  return w;
+}
+
+extern "C" size_t nm_rollout_workspace(int32_t n, int32_t substeps) {
+  (void)substeps;
+  return carve_ws(nullptr, n).total;
+}
+
+static inline nm_particles rec(float* base, int n, int t) {
+  float* r = base + (size_t)t * 24 * n;
+  nm_particles p;
+  p.x = r;
+  p.v = r + 3 * (size_t)n;
+  p.C = r + 6 * (size_t)n;
+  p.F = r + 15 * (size_t)n;
+  p.stress = nullptr;
+  return p;
+}
+
+// Ftrial = (I + dt C') F   (mpm.py:489) recomputed from the checkpoints
+__global__ void __launch_bounds__(256) k_trial_F(int n, float dt, const int* __restrict__ enabled, const float* __restrict__ Cn,
+                                                 const float* __restrict__ F, float* __restrict__ out) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  M3 Fp = m3_load(F + 9 * (size_t)p);
+  if (enabled[p] == 0) { m3_store(out + 9 * (size_t)p, Fp); return; }
+  M3 T = m3_load(Cn + 9 * (size_t)p);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) T.m[i] *= dt;
+  T.m[0] += 1.f; T.m[4] += 1.f; T.m[8] += 1.f;
+  m3_store(out + 9 * (size_t)p, m3_mul(T, Fp));
+}
+
+__global__ void __launch_bounds__(256) k_add_inplace(size_t n, float* __restrict__ dst, const float* __restrict__ src) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+
+extern "C" int nm_rollout_forward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cfg, const nm_statics* st, const nm_mlp* we,
+                                  const nm_mlp* wp, float* states, void* workspace, size_t workspace_bytes, void* stream) {
+  NM_REQUIRE(h && cfg && st && we && wp && states, "null pointer");
+  NM_REQUIRE(n >= 0 && cfg->substeps >= 1, "bad sizes");
+  if (n == 0) return NM_OK;
+  RolloutWs w = carve_ws(workspace, n);
+  if (!workspace || workspace_bytes < w.total) {
+    nm_set_error("rollout workspace too small: need %zu got %zu", w.total, workspace_bytes);
+    return NM_ERR_WORKSPACE;
+  }
+  int rc;
+  for (int t = 0; t < cfg->substeps; ++t) {
+    nm_particles cur = rec(states, n, t), nxt = rec(states, n, t + 1);
+    rc = nm_material_fwd(n, NM_ELASTICITY, 0.f, cur.F, we, w.stress, stream);  // finetune.py:362
+    if (rc) return rc;
+    cur.stress = w.stress;
+    nm_particles out = nxt;
+    out.F = w.ftrial;
+    rc = nm_mpm_forward(h, n, st, &cur, &out, stream);                          // finetune.py:363
+    if (rc) return rc;
+    rc = nm_material_fwd(n, NM_PLASTICITY, cfg->plasticity_alpha, w.ftrial, wp, nxt.F, stream);  // finetune.py:364
+    if (rc) return rc;
+  }
+  return NM_OK;
+}
+
+extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cfg, const nm_statics* st, const nm_mlp* we,
+                                   const nm_mlp* wp, const float* states, const float* gstate_last, float* gstate_first,
+                                   float* gw_e, float* gw_p, void* workspace, size_t workspace_bytes, void* stream) {
+  NM_REQUIRE(h && cfg && st && we && wp && states && gstate_last && gstate_first && gw_e && gw_p, "null pointer");
+  NM_REQUIRE(n >= 0 && cfg->substeps >= 1, "bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  NM_HIP_CHECK(hipMemsetAsync(gw_e, 0, NM_WTOT_ * sizeof(float), s));
+  NM_HIP_CHECK(hipMemsetAsync(gw_p, 0, NM_WTOT_ * sizeof(float), s));
+  if (n == 0) return NM_OK;
+  RolloutWs w = carve_ws(workspace, n);
+  if (!workspace || workspace_bytes < w.total) {
+    nm_set_error("rollout workspace too small: need %zu got %zu", w.total, workspace_bytes);
+    return NM_ERR_WORKSPACE;
+  }
+  const size_t N = (size_t)n;
+  float* states_m = const_cast<float*>(states);
+  const float* gin = gstate_last;
+  int rc;
+  for (int t = cfg->substeps - 1; t >= 0; --t) {
+    nm_particles cur = rec(states_m, n, t), nxt = rec(states_m, n, t + 1);
+    float* gout = (t == 0) ? gstate_first : ((gin == w.ga) ? w.gb : w.ga);
+    // trial F of this step, then plasticity backward: dL/dF_{t+1} -> dL/dFtrial
+    NM_LAUNCH(k_trial_F, dim3(nm_div_up(n, 256)), dim3(256), 0, s, n, nm_mpm_get_dt(h), st->enabled, nxt.C, cur.F, w.ftrial);
+    NM_LAUNCH_CHECK();
+    rc = nm_material_bwd_ex(n, NM_PLASTICITY, cfg->plasticity_alpha, w.ftrial, wp, gin + 15 * N, w.gFtr, gw_p, gw_p + 64 * 13,
+                            gw_p + 64 * 13 + 64 * 64, 1, w.mat, w.mat_bytes, stream);
+    if (rc) return rc;
+    // recompute stress, sim backward
+    rc = nm_material_fwd(n, NM_ELASTICITY, 0.f, cur.F, we, w.stress, stream);
+    if (rc) return rc;
+    cur.stress = w.stress;
+    nm_particles gn, gc;
+    gn.x = const_cast<float*>(gin); gn.v = const_cast<float*>(gin) + 3 * N; gn.C = const_cast<float*>(gin) + 6 * N;
+    gn.F = w.gFtr; gn.stress = nullptr;
+    gc.x = gout; gc.v = gout + 3 * N; gc.C = gout + 6 * N; gc.F = gout + 15 * N; gc.stress = w.gS;
+    rc = nm_mpm_backward(h, n, st, &cur, &nxt, &gn, &gc, stream);
+    if (rc) return rc;
+    // elasticity backward: dL/dstress -> dL/dF (added to the sim's dL/dF)
+    rc = nm_material_bwd_ex(n, NM_ELASTICITY, 0.f, cur.F, we, w.gS, w.gFe, gw_e, gw_e + 64 * 13, gw_e + 64 * 13 + 64 * 64, 1,
+                            w.mat, w.mat_bytes, stream);
+    if (rc) return rc;
+    NM_LAUNCH(k_add_inplace, dim3(nm_div_up((int64_t)N * 9, 256)), dim3(256), 0, s, N * 9, gc.F, w.gFe);
+    NM_LAUNCH_CHECK();
+    gin = gout;
+  }
+  return NM_OK;
+}

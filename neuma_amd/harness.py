@@ -1,0 +1,205 @@
+"""Frame-level driver: the caller side of the hot path.
+
+Reproduces the operator order of /root/reference/experiments/finetune.py:331-414 (finetune_constitutive inner
+loop) and render.py:304-332 for one video frame:
+    S x [ stress = E(F); x,v,C,F = sim(statics, it, x,v,C,F, stress); F = P(F) ]            (finetune.py:362-364)
+    de_x = denormalize(x); means3D = g_prev + B (de_x - de_x_prev); F_k = B F               (373-376)
+    for view: render = diff_rasterization(...); loss += decay * pixel_loss(render, gt)      (378-389)
+    loss.backward()                                                                        (413-414)
+Multi-GPU (torch.distributed over RCCL): the simulation is replicated (a 100k-particle substep is shorter than
+one xGMI collective); the V views x tile rows of a frame are split into contiguous stripes, one
+per rank; each rank back-propagates its stripes to dL/dmeans3D and ONE all-reduce (sum, K x 3 fp32) per frame
+merges them before the binding transpose.
+"""
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import synth
+from .material import InvariantFullMetaElasticity, InvariantFullMetaPlasticity
+from .render.gaussian_model import GaussianModel
+from .rollout import MPMFusedDiffSim
+from .sim import MPMModelBuilder, MPMCacheDiffSim, MPMStatics
+from .tune import Bindings, compute_bindings_xyz, compute_bindings_F, diff_rasterization, l1_loss, l2_loss
+
+PIXEL_LOSSES = {"l1": l1_loss, "l2": l2_loss}
+
+
+def stripe_plan(num_views: int, tile_rows: int, world: int, rank: int) -> List[Tuple[int, int, int]]:
+    """Split the V*tile_rows work units of a frame into `world` contiguous chunks; return this rank's
+    (view, row0, row1) stripes.  Pure host logic (covered by the gloo CPU tests)."""
+    total = num_views * tile_rows
+    lo = (total * rank) // world
+    hi = (total * (rank + 1)) // world
+    out = []
+    for v in range(num_views):
+        a, b = max(lo, v * tile_rows), min(hi, (v + 1) * tile_rows)
+        if b > a:
+            out.append((v, a - v * tile_rows, b - v * tile_rows))
+    return out
+
+
+class _AllReduceSum(torch.autograd.Function):
+    """Identity in forward; all-reduce(sum) of the gradient in backward — merges per-rank dL/dmeans3D."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        import torch.distributed as dist
+        g = g.contiguous()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
+        return g, None
+
+
+def merge_grad_across_ranks(x: torch.Tensor, group=None) -> torch.Tensor:
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return x
+    return _AllReduceSum.apply(x, group)
+
+
+def make_material_cfg(alpha=1e-3):
+    return dict(layer_widths=[64, 64], norm=None, nonlinearity="gelu", no_bias=True, normalize_input=True, alpha=alpha)
+
+
+@dataclass
+class FrameResult:
+    loss: torch.Tensor
+    x: torch.Tensor
+    F: torch.Tensor
+
+
+class SceneRuntime(object):
+    """Everything resident on one GPU for a synthetic scene: particles, statics, nets (+LoRA), Gaussians, bindings,
+    cameras and ground-truth images."""
+
+    def __init__(self, scene: synth.Scene, device, lora_r: int = 16, lora_alpha: int = 16, fused: bool = True,
+                 bc: str = "noslip", gravity=(0.0, -9.8, 0.0), pixel_loss: str = "l2", white_bg: bool = True,
+                 rank: int = 0, world: int = 1, group=None):
+        self.scene, self.device, self.fused = scene, torch.device(device), fused
+        self.rank, self.world, self.group = rank, world, group
+        cfg = scene.cfg
+        self.S, self.V = int(cfg["S"]), int(cfg["V"])
+        sim_cfg = dict(gravity=list(gravity), bc=bc, num_grids=cfg["G"], dt=cfg["dt"], bound=1, eps=6e-7)   # finetune.py:47,270
+        self.model = MPMModelBuilder().parse_cfg(sim_cfg).finalize(self.device, requires_grad=True)
+        N = scene.x0.shape[0]
+        self.N = N
+        st = MPMStatics()
+        st.init(N, self.device)
+        st.vol.fill_(scene.vol); st.rho.fill_(1000.0); st.clip_bound.fill_(0.1); st.enabled.fill_(1)
+        self.statics = st
+        self.x0 = torch.tensor(scene.x0, device=self.device)
+        self.v0 = torch.tensor(scene.v0, device=self.device)
+        self.C0 = torch.zeros(N, 3, 3, device=self.device)
+        self.F0 = torch.eye(3, device=self.device).repeat(N, 1, 1)
+        # constitutive nets: shipped checkpoint + LoRA (finetune.py:295-313)
+        w = synth.load_base_weights(cfg["mat"])
+        mcfg = make_material_cfg()
+        self.elasticity = InvariantFullMetaElasticity(mcfg).to(self.device)
+        self.plasticity = InvariantFullMetaPlasticity(mcfg).to(self.device)
+        for net, tag in ((self.elasticity, "e"), (self.plasticity, "p")):
+            net.layers[0].fc.weight.data.copy_(torch.tensor(w[tag][0]))
+            net.layers[1].fc.weight.data.copy_(torch.tensor(w[tag][1]))
+            net.final_layer.fc.weight.data.copy_(torch.tensor(w[tag][2]))
+        if lora_r > 0:
+            g = torch.Generator().manual_seed(0)
+            for net in (self.elasticity, self.plasticity):
+                net.init_lora_layers(r=lora_r, lora_alpha=lora_alpha)
+                net.freeze_all_except_lora()
+                for lin in (net.layers[0].fc, net.layers[1].fc, net.final_layer.fc):
+                    lin.lora_B.data.copy_(0.01 * torch.randn(lin.lora_B.shape, generator=g))   # non-zero B
+        self.sim_cached = MPMCacheDiffSim(self.model, 4096)
+        self.sim_fused = MPMFusedDiffSim(self.model, self.elasticity, self.plasticity, self.S)
+        # Gaussians
+        gm = GaussianModel(cfg["sh"])
+        sh = torch.tensor(scene.g_sh, device=self.device)
+        gm.set_params(torch.tensor(scene.g_xyz, device=self.device), sh[:, :1].contiguous(), sh[:, 1:].contiguous(),
+                      torch.tensor(scene.g_logscale, device=self.device), torch.tensor(scene.g_rot, device=self.device),
+                      torch.tensor(scene.g_opacity_logit, device=self.device))
+        self.gaussians = gm
+        self._opacity = gm.get_opacity.contiguous()
+        self._shs = gm.get_features.contiguous()
+        self._cov = gm.get_covariance(1.0)
+        K, nb = scene.bind_idx.shape
+        rows = torch.arange(K).repeat_interleave(nb)
+        ind = torch.stack([rows, torch.tensor(scene.bind_idx.reshape(-1))], 0)
+        self.bindings = Bindings(ind, torch.tensor(scene.bind_w.reshape(-1)), (K, N), self.device)
+        self.K = K
+        self.background = (torch.ones(3) if white_bg else torch.zeros(3)).to(self.device)
+        self.cameras = synth.ring_cameras(self.V, cfg["W"], cfg["H"], device=self.device)
+        self.pixel_loss = PIXEL_LOSSES[pixel_loss]
+        self.tile_rows = (cfg["H"] + 15) // 16
+        self.gt: List[Optional[torch.Tensor]] = [None] * self.V
+        self.center = torch.zeros(3, device=self.device)
+        self.size = torch.ones(3, device=self.device)
+
+    # ---- pieces
+    def parameters(self):
+        return [p for net in (self.elasticity, self.plasticity) for p in net.parameters() if p.requires_grad]
+
+    def rollout(self, x, v, C, F, step0: int = 0):
+        """S substeps (finetune.py:360-364)."""
+        if self.fused:
+            return self.sim_fused(self.statics, x, v, C, F)
+        for it in range(self.S):
+            stress = self.elasticity(F)
+            x, v, C, F = self.sim_cached(self.statics, step0 + it, x, v, C, F, stress)
+            F = self.plasticity(F)
+        return x, v, C, F
+
+    def render_view(self, means3D, deform_grad, view: int, tile_rows=None):
+        return diff_rasterization(means3D, deform_grad, None, self.cameras[view], self.background,
+                                  gaussians_active_sh=self.gaussians.active_sh_degree, guassians_cov=self._cov,
+                                  gaussians_opa=self._opacity, gaussians_shs=self._shs, tile_rows=tile_rows)
+
+    @torch.no_grad()
+    def make_ground_truth(self, perturb: float = 0.02, steps: int = 5, seed: int = 2):
+        """GT image per view = render of the state after a few perturbed substeps."""
+        g = torch.Generator().manual_seed(seed)
+        v = self.v0 + (perturb * torch.randn(self.v0.shape, generator=g)).to(self.device)
+        x, C, F = self.x0, self.C0, self.F0
+        was = self.fused
+        self.fused = False
+        S = self.S
+        self.S = steps
+        x, v, C, F = self.rollout(x, v, C, F, step0=2048)
+        self.S, self.fused = S, was
+        means3D = compute_bindings_xyz(x, self.x0, self.gaussians.get_xyz, self.bindings)
+        dg = compute_bindings_F(F, self.bindings)
+        for vi in range(self.V):
+            self.gt[vi] = self.render_view(means3D, dg, vi).detach().clone()
+
+    # ---- one frame, forward + backward
+    def frame(self, weight: float = 1.0, backward: bool = True) -> FrameResult:
+        x, v, C, F = self.x0, self.v0, self.C0, self.F0
+        de_x_prev = (self.x0 - self.center) / self.size
+        g_prev = self.gaussians.get_xyz
+        x, v, C, F = self.rollout(x, v, C, F)
+        de_x = (x - self.center) / self.size                                  # finetune.py:373
+        means3D = compute_bindings_xyz(de_x, de_x_prev, g_prev, self.bindings)  # :375
+        deform_grad = compute_bindings_F(F, self.bindings)                      # :376
+        means3D = merge_grad_across_ranks(means3D, self.group)
+        loss = torch.zeros((), device=self.device)
+        H = self.scene.cfg["H"]
+        if self.world == 1:
+            for vi in range(self.V):                                            # :378-389
+                render = self.render_view(means3D, deform_grad, vi)
+                loss = loss + weight * self.pixel_loss(render, self.gt[vi])
+        else:
+            for (vi, r0, r1) in stripe_plan(self.V, self.tile_rows, self.world, self.rank):
+                render = self.render_view(means3D, deform_grad, vi, tile_rows=(r0, r1))
+                y0, y1 = r0 * 16, min(H, r1 * 16)
+                # partial sums of the mean over the full image: the ranks' losses add up to the 1-GPU loss
+                d = render[:, y0:y1] - self.gt[vi][:, y0:y1]
+                part = (d.abs().sum() if self.pixel_loss is l1_loss else (d * d).sum()) / render.numel()
+                loss = loss + weight * part
+        if backward:
+            loss.backward()
+        return FrameResult(loss.detach(), x.detach(), F.detach())

@@ -1,0 +1,110 @@
+"""LoRA for the constitutive nets' dense layers.
+
+Same parameter names / state-dict keys / merge semantics as the Microsoft loralib copy the reference ships
+(/root/reference/modules/nclaw/material/loralib.py: LinearLoRA 162-224, replace_with_linear_lora 52-59,
+init_linear_lora 62-81, mark_only_lora_as_trainable 13-30, lora_state_dict 33-49), written against the
+fused HIP MLP: a layer never runs by itself, it only hands its *effective* weight
+    W_eff = W + (lora_B @ lora_A) * (lora_alpha / r)          (loralib.py:209-213 == 216-224 algebraically)
+to the kernel; torch autograd carries dL/dW_eff back to lora_A / lora_B.
+"""
+import math
+from typing import Dict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class LinearLoRA(nn.Linear):
+    def __init__(self, in_features: int, out_features: int, r: int = 0, lora_alpha: int = 1, lora_dropout: float = 0.,
+                 merge_weights: bool = True, **kwargs):
+        nn.Linear.__init__(self, in_features, out_features, **kwargs)
+        if lora_dropout and lora_dropout > 0.:
+            raise NotImplementedError("lora_dropout > 0 is never used by NeuMA and not supported by the fused MLP")
+        self.r = r
+        self.lora_alpha = lora_alpha
+        self.merged = False
+        self.merge_weights = merge_weights
+        if r > 0:
+            self.lora_A = nn.Parameter(self.weight.new_zeros((r, in_features)))
+            self.lora_B = nn.Parameter(self.weight.new_zeros((out_features, r)))
+            self.scaling = self.lora_alpha / self.r
+            self.weight.requires_grad = False
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.Linear.reset_parameters(self)
+        if hasattr(self, 'lora_A'):
+            nn.init.kaiming_uniform_(self.lora_A, a=math.sqrt(5))   # loralib.py:190-193
+            nn.init.zeros_(self.lora_B)
+
+    def train(self, mode: bool = True):
+        nn.Linear.train(self, mode)
+        if mode:
+            if self.merge_weights and self.merged:
+                if self.r > 0:
+                    self.weight.data -= (self.lora_B @ self.lora_A) * self.scaling
+                self.merged = False
+        else:
+            if self.merge_weights and not self.merged:
+                if self.r > 0:
+                    self.weight.data += (self.lora_B @ self.lora_A) * self.scaling
+                self.merged = True
+        return self
+
+    def effective_weight(self) -> torch.Tensor:
+        if self.r > 0 and not self.merged:
+            return self.weight + (self.lora_B @ self.lora_A) * self.scaling
+        return self.weight
+
+    def forward(self, x: torch.Tensor):
+        # stand-alone use (not on the fused path): loralib.py:216-224
+        if self.r > 0 and not self.merged:
+            result = F.linear(x, self.weight, bias=self.bias)
+            result = result + (x @ self.lora_A.transpose(0, 1) @ self.lora_B.transpose(0, 1)) * self.scaling
+            return result
+        return F.linear(x, self.weight, bias=self.bias)
+
+
+def init_linear_lora(linear: nn.Linear, r: int, lora_alpha: int) -> LinearLoRA:
+    """loralib.py:62-81: new LinearLoRA carrying the old layer's weight."""
+    new = LinearLoRA(linear.in_features, linear.out_features, r=r, lora_alpha=lora_alpha, bias=linear.bias is not None)
+    new = new.to(device=linear.weight.device, dtype=linear.weight.dtype)
+    new.weight.data = linear.weight.data.clone()
+    if linear.bias is not None:
+        new.bias.data = linear.bias.data.clone()
+    return new
+
+
+def replace_with_linear_lora(model, old, r, lora_alpha):
+    """loralib.py:52-59"""
+    for n, module in model.named_children():
+        if len(list(module.children())) > 0:
+            replace_with_linear_lora(module, old, r=r, lora_alpha=lora_alpha)
+        if isinstance(module, old) and not isinstance(module, LinearLoRA):
+            setattr(model, n, init_linear_lora(module, r=r, lora_alpha=lora_alpha))
+
+
+def mark_only_lora_as_trainable(model: nn.Module, bias: str = 'none') -> None:
+    """loralib.py:13-30"""
+    for n, p in model.named_parameters():
+        if 'lora_' not in n:
+            p.requires_grad = False
+    if bias == 'none':
+        return
+    if bias == 'all':
+        for n, p in model.named_parameters():
+            if 'bias' in n:
+                p.requires_grad = True
+        return
+    raise NotImplementedError
+
+
+def lora_state_dict(model: nn.Module, bias: str = 'none') -> Dict[str, torch.Tensor]:
+    """loralib.py:33-49"""
+    sd = model.state_dict()
+    if bias == 'none':
+        return {k: sd[k] for k in sd if 'lora_' in k}
+    if bias == 'all':
+        return {k: sd[k] for k in sd if 'lora_' in k or 'bias' in k}
+    raise NotImplementedError

@@ -1,0 +1,199 @@
+"""Particle-GS render operator: drop-in for the `diff_gaussian_rasterization` extension plus the glue of
+/root/reference/modules/d3gs/gaussian_renderer/__init__.py:92-119 (get_rasterizer) and
+/root/reference/modules/d3gs/utils/simulation_utils.py:25-48 (deform_cov_by_F).
+
+    GaussianRasterizationSettings(NamedTuple)   12 fields, same order as the reference fills them
+    GaussianRasterizer(raster_settings)(means3D, means2D, opacities, shs=None, colors_precomp=None,
+                                        scales=None, rotations=None, cov3D_precomp=None) -> (color, radii)
+"""
+import ctypes as C
+import math
+from typing import NamedTuple, Optional, Tuple
+
+import torch
+import torch.autograd as autograd
+import torch.nn as nn
+from torch import Tensor
+
+from .. import _lib as L
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: Tensor
+    scale_modifier: float
+    viewmatrix: Tensor
+    projmatrix: Tensor
+    sh_degree: int
+    campos: Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _c_cfg(s: GaussianRasterizationSettings, tile_rows: Optional[Tuple[int, int]] = None) -> L.nm_raster_cfg:
+    """Host copy of the settings (three tiny D2H reads per camera; cache the result per camera in hot loops)."""
+    bg = [float(v) for v in s.bg.detach().float().cpu().reshape(-1)]
+    vm = [float(v) for v in s.viewmatrix.detach().float().cpu().reshape(-1)]
+    pm = [float(v) for v in s.projmatrix.detach().float().cpu().reshape(-1)]
+    cp = [float(v) for v in s.campos.detach().float().cpu().reshape(-1)]
+    t0, t1 = tile_rows if tile_rows is not None else (0, 0)
+    return L.nm_raster_cfg(int(s.image_height), int(s.image_width), float(s.tanfovx), float(s.tanfovy), (C.c_float * 3)(*bg),
+                           float(s.scale_modifier), (C.c_float * 16)(*vm), (C.c_float * 16)(*pm), int(s.sh_degree),
+                           (C.c_float * 3)(*cp), int(bool(s.prefiltered)), int(bool(s.debug)), int(t0), int(t1))
+
+
+class RasterCamera(object):
+    """Pre-marshalled camera: build once per (view, frame) and reuse, so the hot loop performs no host reads."""
+
+    def __init__(self, settings: GaussianRasterizationSettings, tile_rows: Optional[Tuple[int, int]] = None):
+        self.settings = settings
+        self.tile_rows = tile_rows
+        self.cfg = _c_cfg(settings, tile_rows)
+
+
+def build_cov3D(scales: Tensor, rotations: Tensor, scale_modifier: float = 1.0) -> Tensor:
+    """general_utils.py:93-139 + gaussian_model.py:27-31 in torch (differentiable; off the hot path:
+    NeuMA always passes cov3D_precomp)."""
+    q = rotations / rotations.norm(dim=1, keepdim=True)
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.stack([
+        torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y)], -1),
+        torch.stack([2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x)], -1),
+        torch.stack([2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], -1)], -2)
+    Lm = R * (scale_modifier * scales)[:, None, :]
+    S = Lm @ Lm.transpose(-1, -2)
+    return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], -1)
+
+
+class _RasterizeGaussians(autograd.Function):
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, cov3D, cam: RasterCamera):
+        lib = L.lib()
+        dev = means3D.device
+        stream = L.stream_ptr(dev)
+        cfg = cam.cfg
+        K = means3D.size(0)
+        m3 = means3D.detach().float().contiguous()
+        op = opacities.detach().float().contiguous()
+        cv = cov3D.detach().float().contiguous()
+        sh = None if shs is None else shs.detach().float().contiguous()
+        cp = None if colors_precomp is None else colors_precomp.detach().float().contiguous()
+        M = 0 if sh is None else sh.size(1)
+        H, W = cfg.image_height, cfg.image_width
+        radii = torch.zeros(K, dtype=torch.int32, device=dev)
+        geom_bytes = int(lib.nm_raster_geom_bytes(K))
+        geom = torch.empty(geom_bytes, dtype=torch.uint8, device=dev)
+        num = C.c_int64(0)
+        L.check(lib.nm_raster_preprocess(C.byref(cfg), K, M, L.ptr(m3), L.ptr(sh), L.ptr(cp), L.ptr(op), L.ptr(cv), L.ptr(radii),
+                                         L.ptr(geom), geom_bytes, C.byref(num), stream), "nm_raster_preprocess")
+        D = int(num.value)
+        bin_bytes = int(lib.nm_raster_binning_bytes(D, C.byref(cfg)))
+        img_bytes = int(lib.nm_raster_image_bytes(C.byref(cfg)))
+        scr_bytes = int(lib.nm_raster_scratch_bytes(D))
+        binning = torch.empty(bin_bytes, dtype=torch.uint8, device=dev)
+        imgbuf = torch.empty(img_bytes, dtype=torch.uint8, device=dev)
+        scratch = torch.empty(scr_bytes, dtype=torch.uint8, device=dev)
+        color = torch.zeros(3, H, W, dtype=torch.float32, device=dev)
+        L.check(lib.nm_raster_render(C.byref(cfg), K, D, L.ptr(geom), L.ptr(binning), bin_bytes, L.ptr(scratch), scr_bytes,
+                                     L.ptr(imgbuf), img_bytes, L.ptr(color), stream), "nm_raster_render")
+        del scratch
+        ctx.cam, ctx.K, ctx.M, ctx.D = cam, K, M, D
+        ctx.has_sh = sh is not None
+        ctx.save_for_backward(m3, sh if sh is not None else cp, op, cv, geom, binning, imgbuf)
+        ctx.mark_non_differentiable(radii)
+        ctx.num_rendered = D
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_color, _grad_radii):
+        lib = L.lib()
+        m3, shcol, op, cv, geom, binning, imgbuf = ctx.saved_tensors
+        dev = m3.device
+        cfg = ctx.cam.cfg
+        K, M, D = ctx.K, ctx.M, ctx.D
+        g = grad_color.float().contiguous()
+        need = ctx.needs_input_grad  # means3D, means2D, shs, colors, opac, cov3D, cam
+        dmeans3D = torch.empty(K, 3, dtype=torch.float32, device=dev)
+        dmeans2D = torch.empty(K, 3, dtype=torch.float32, device=dev) if need[1] else None
+        dcov = torch.empty(K, 6, dtype=torch.float32, device=dev) if need[5] else None
+        dop = torch.empty(K, 1, dtype=torch.float32, device=dev) if need[4] else None
+        dsh = torch.empty(K, M, 3, dtype=torch.float32, device=dev) if (ctx.has_sh and need[2]) else None
+        dcol = torch.empty(K, 3, dtype=torch.float32, device=dev) if ((not ctx.has_sh) and need[3]) else None
+        ws_bytes = int(lib.nm_raster_bwd_workspace(K))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        sh = shcol if ctx.has_sh else None
+        cp = None if ctx.has_sh else shcol
+        L.check(lib.nm_raster_backward(C.byref(cfg), K, M, D, L.ptr(m3), L.ptr(sh), L.ptr(cp), L.ptr(op), L.ptr(cv), L.ptr(geom),
+                                       L.ptr(binning), L.ptr(imgbuf), L.ptr(g), L.ptr(dmeans3D), L.ptr(dmeans2D), L.ptr(dcov),
+                                       L.ptr(dop), L.ptr(dsh), L.ptr(dcol), L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
+                "nm_raster_backward")
+        return dmeans3D, dmeans2D, dsh, dcol, dop, dcov, None
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings, tile_rows: Optional[Tuple[int, int]] = None):
+        super().__init__()
+        self.raster_settings = raster_settings
+        self._cam = RasterCamera(raster_settings, tile_rows) if not isinstance(raster_settings, RasterCamera) else raster_settings
+
+    def markVisible(self, positions: Tensor) -> Tensor:
+        s = self._cam.settings
+        hom = torch.cat([positions, torch.ones_like(positions[:, :1])], 1)
+        return (hom @ s.viewmatrix.to(positions))[:, 2] > 0.2
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        if cov3D_precomp is None:
+            cov3D_precomp = build_cov3D(scales, rotations, self._cam.settings.scale_modifier)
+        if means2D is None:
+            means2D = torch.zeros_like(means3D)
+        return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, cov3D_precomp, self._cam)
+
+
+def get_rasterizer(viewpoint_camera, active_sh_degree: int, debug, bg_color: Tensor, scaling_modifier=1.0,
+                   tile_rows: Optional[Tuple[int, int]] = None) -> GaussianRasterizer:
+    """gaussian_renderer/__init__.py:92-119 (viewpoint_camera: anything with FoVx, FoVy, image_height, image_width,
+    world_view_transform, full_proj_transform, camera_center — Camera / PhysCamera / MiniCam of cameras.py)."""
+    cached = getattr(viewpoint_camera, "_nm_raster_cache", None)
+    key = (int(active_sh_degree), float(scaling_modifier), tile_rows, bg_color.data_ptr())
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    raster_settings = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height),
+        image_width=int(viewpoint_camera.image_width),
+        tanfovx=math.tan(viewpoint_camera.FoVx * 0.5),
+        tanfovy=math.tan(viewpoint_camera.FoVy * 0.5),
+        bg=bg_color,
+        scale_modifier=scaling_modifier,
+        viewmatrix=viewpoint_camera.world_view_transform,
+        projmatrix=viewpoint_camera.full_proj_transform,
+        sh_degree=active_sh_degree,
+        campos=viewpoint_camera.camera_center,
+        prefiltered=False,
+        debug=debug,
+    )
+    rast = GaussianRasterizer(raster_settings=raster_settings, tile_rows=tile_rows)
+    try:
+        viewpoint_camera._nm_raster_cache = (key, rast)
+    except Exception:
+        pass
+    return rast
+
+
+def deform_cov_by_F(cov6: Tensor, F: Tensor) -> Tensor:
+    """simulation_utils.py:25-48: Sigma' = F Sigma F^T on packed (K,6); not differentiable, as in the reference
+    (tune/utils.py:365-373 launches it outside any tape)."""
+    c = cov6.detach().float().contiguous()
+    Fc = F.detach().float().reshape(-1, 3, 3).contiguous()
+    out = torch.empty_like(c)
+    L.check(L.lib().nm_cov_deform(c.size(0), L.ptr(c), L.ptr(Fc), L.ptr(out), L.stream_ptr(c.device)), "nm_cov_deform")
+    return out

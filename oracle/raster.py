@@ -99,8 +99,13 @@ def preprocess(s: Settings, means3D: Tensor, cov3D: Tensor, opacities: Tensor,
     fy = H / (2.0 * s.tanfovy)
     limx, limy = 1.3 * s.tanfovx, 1.3 * s.tanfovy
     tz = torch.where(visible, t[:, 2], torch.ones_like(t[:, 2]))
-    tx = torch.clamp(t[:, 0] / tz, -limx, limx) * tz
-    ty = torch.clamp(t[:, 1] / tz, -limy, limy) * tz
+    # upstream clamps t.xy/t.z to +-1.3 tanfov and, in its backward, treats the clamped value as a constant
+    # (x_grad_mul = 0) — also w.r.t. t.z; reproduce that instead of autograd's d(clamp*tz)/dtz
+    rx, ry = t[:, 0] / tz, t[:, 1] / tz
+    in_x = (rx >= -limx) & (rx <= limx)
+    in_y = (ry >= -limy) & (ry <= limy)
+    tx = torch.where(in_x, t[:, 0], (torch.clamp(rx, -limx, limx) * tz).detach())
+    ty = torch.where(in_y, t[:, 1], (torch.clamp(ry, -limy, limy) * tz).detach())
     zero = torch.zeros_like(tz)
     J = torch.stack([torch.stack([fx / tz, zero, -(fx * tx) / (tz * tz)], -1),
                      torch.stack([zero, fy / tz, -(fy * ty) / (tz * tz)], -1)], -2)   # (K,2,3)

@@ -1,0 +1,60 @@
+"""Shared helpers for the GPU parity tests (oracle = checker, HIP path = thing under test)."""
+import numpy as np
+import torch
+
+from oracle import mpm as om
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def rel_max(a: torch.Tensor, b: torch.Tensor) -> float:
+    """max-norm relative error of a (GPU fp32) against b (oracle)."""
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
+
+
+def abs_max(a, b) -> float:
+    return float((a.detach().double().cpu() - b.detach().double().cpu()).abs().max())
+
+
+def mpm_case(N=4096, G=32, seed=0, bc="noslip", near_wall=True, disabled=True, dt=1e-3):
+    g = torch.Generator().manual_seed(seed)
+    const = om.MPMConstant(num_grids=G, dt=dt, bound=1, gravity=(0.0, -9.8, 0.0), eps=6e-7, bc=bc)
+    dx = const.dx
+    x = 0.3 + 0.4 * torch.rand(N, 3, generator=g, dtype=torch.float64)
+    if near_wall:
+        k = N // 16
+        x[:k] = 0.1 * dx + 0.9 * dx * torch.rand(k, 3, generator=g, dtype=torch.float64)          # low wall, < 1 cell
+        x[k:2 * k] = 1.0 - 1.6 * dx - 0.9 * dx * torch.rand(k, 3, generator=g, dtype=torch.float64)  # high wall
+        x[2 * k:3 * k, 1] = 0.1 * dx + 0.5 * dx * torch.rand(k, generator=g, dtype=torch.float64)    # floor contact
+    v = torch.randn(N, 3, generator=g, dtype=torch.float64)
+    C = 2.0 * torch.randn(N, 3, 3, generator=g, dtype=torch.float64)
+    F = torch.eye(3, dtype=torch.float64)[None] + 0.1 * torch.randn(N, 3, 3, generator=g, dtype=torch.float64)
+    S = 50.0 * torch.randn(N, 3, 3, generator=g, dtype=torch.float64)
+    vol = torch.full((N,), (dx / 2) ** 3, dtype=torch.float64)
+    rho = torch.full((N,), 1000.0, dtype=torch.float64)
+    clip = torch.full((N,), 0.1, dtype=torch.float64)
+    en = torch.ones(N, dtype=torch.int32)
+    if disabled:
+        en[N // 2: N // 2 + N // 10] = 0
+    # sort by cell so that workgroups are spatially coherent (LDS-tile path); tests also run unsorted
+    cell = torch.floor(x * G).long()
+    key = (cell[:, 0] * G + cell[:, 1]) * G + cell[:, 2]
+    o = torch.argsort(key)
+    return const, vol, rho, clip, en[o].contiguous(), x[o].contiguous(), v[o].contiguous(), C[o].contiguous(), \
+        F[o].contiguous(), S[o].contiguous()
+
+
+def build_model(const, device):
+    from neuma_amd.sim import MPMModelBuilder
+    cfg = dict(gravity=list(const.gravity), bc=const.bc, num_grids=const.num_grids, dt=const.dt, bound=const.bound, eps=const.eps)
+    return MPMModelBuilder().parse_cfg(cfg).finalize(device, requires_grad=True)
+
+
+def build_statics(model, vol, rho, clip, en, device):
+    st = model.statics(vol.shape[0])
+    st.vol.copy_(vol.float()); st.rho.copy_(rho.float()); st.clip_bound.copy_(clip.float()); st.enabled.copy_(en)
+    return st

@@ -1,0 +1,162 @@
+"""GPU parity: binding spmm / covariance push-forward / rasterizer forward+backward vs the oracle.
+Tolerances: images max-abs 1e-3, mean-abs 1e-5 per channel; gradients max-norm relative 1e-3..2e-3."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import raster as orr
+from gpu_util import dev, rel_max, abs_max
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(K=1200, W=128, H=96, deg=3, seed=0, spread=0.35, scale=(0.02, 0.08)):
+    g = torch.Generator().manual_seed(seed)
+    means = 0.5 + spread * (torch.rand(K, 3, generator=g) - 0.5) * 2
+    logs = torch.log(scale[0] + (scale[1] - scale[0]) * torch.rand(K, 3, generator=g))
+    q = torch.randn(K, 4, generator=g)
+    op = torch.sigmoid(torch.randn(K, 1, generator=g) * 1.5 + 1.0)
+    op[:8] = 0.999                      # alpha clamp (0.99) branch
+    M = (deg + 1) ** 2
+    shs = 0.4 * torch.randn(K, M, 3, generator=g)
+    fov = math.radians(50.0)
+    fovy = 2 * math.atan(math.tan(fov / 2) * H / W)
+    wv, full, cam = orr.look_at_camera([0.5 + 1.2, 0.5 + 0.3, 0.5 - 1.0], [0.5, 0.5, 0.5], [0, -1, 0], fov, fovy)
+    means[-6:] = cam + 0.05 * torch.randn(6, 3, generator=g)          # behind / at the near plane -> culled
+    s = orr.Settings(H, W, math.tan(fov / 2), math.tan(fovy / 2), torch.tensor([1.0, 1.0, 1.0]), 1.0, wv, full, deg, cam)
+    cov = orr.build_cov3D(torch.exp(logs), q, 1.0)
+    return s, means, cov, op, shs, logs, q
+
+
+def _gpu_raster(s, tile_rows=None):
+    from neuma_amd.render import GaussianRasterizationSettings, GaussianRasterizer
+    gs = GaussianRasterizationSettings(s.image_height, s.image_width, s.tanfovx, s.tanfovy, s.bg.to(dev()), 1.0,
+                                       s.viewmatrix.to(dev()), s.projmatrix.to(dev()), s.sh_degree, s.campos.to(dev()), False, False)
+    return GaussianRasterizer(gs, tile_rows=tile_rows)
+
+
+@pytest.mark.parametrize("deg", [0, 3])
+def test_raster_forward_backward_vs_oracle(deg):
+    s, means, cov, op, shs, _, _ = _scene(deg=deg)
+    rast = _gpu_raster(s)
+    ins = [t.to(dev()).requires_grad_(True) for t in (means, shs, op, cov)]
+    img, radii = rast(means3D=ins[0], means2D=None, opacities=ins[2], shs=ins[1], cov3D_precomp=ins[3])
+    oins = [t.double().requires_grad_(True) for t in (means, shs, op, cov)]
+    sd = orr.Settings(*[(f.double() if torch.is_tensor(f) else f) for f in s])
+    oimg, oradii, aux = orr.render(sd, oins[0], oins[3], oins[2], shs=oins[1], return_aux=True)
+    assert torch.equal(radii.cpu(), oradii)
+    assert (radii > 0).sum() > 500 and aux["D"] > 2000
+    assert abs_max(img, oimg) < 1e-3
+    assert float((img.detach().cpu().double() - oimg.detach()).abs().mean()) < 1e-5
+    torch.manual_seed(3)
+    gw = torch.randn(3, s.image_height, s.image_width)
+    grads = torch.autograd.grad((img * gw.to(dev())).sum(), ins)
+    ograds = torch.autograd.grad((oimg * gw.double()).sum(), oins)
+    for nme, a, b, tol in zip(["means3D", "shs", "opacity", "cov3D"], grads, ograds, [2e-3, 1e-3, 1e-3, 2e-3]):
+        assert rel_max(a, b) < tol, nme
+        assert torch.isfinite(a).all()
+
+
+def test_raster_colors_precomp_mask_path_and_scale_rot_inputs():
+    s, means, cov, op, shs, logs, q = _scene(deg=0, K=600)
+    rast = _gpu_raster(s)
+    ones = torch.ones(means.shape[0], 3)
+    img, _ = rast(means3D=means.to(dev()), means2D=None, opacities=op.to(dev()), colors_precomp=ones.to(dev()),
+                  cov3D_precomp=cov.to(dev()))
+    sd = orr.Settings(*[(f.double() if torch.is_tensor(f) else f) for f in s])
+    oimg, _ = orr.render(sd, means.double(), cov.double(), op.double(), colors_precomp=ones.double())
+    assert abs_max(img, oimg) < 1e-3
+    sc = torch.exp(logs).to(dev()).requires_grad_(True)
+    img2, _ = rast(means3D=means.to(dev()), means2D=None, opacities=op.to(dev()), colors_precomp=ones.to(dev()),
+                   scales=sc, rotations=q.to(dev()))
+    assert abs_max(img2, img) < 1e-5
+    (g,) = torch.autograd.grad(img2.sum(), sc)
+    assert torch.isfinite(g).all() and g.abs().max() > 0
+    with pytest.raises(Exception):
+        rast(means3D=means.to(dev()), means2D=None, opacities=op.to(dev()), cov3D_precomp=cov.to(dev()))
+
+
+def test_raster_tile_stripes_reassemble_the_full_image_and_gradient():
+    s, means, cov, op, shs, _, _ = _scene(deg=3, K=900)
+    full = _gpu_raster(s)
+    m = means.to(dev()).requires_grad_(True)
+    args = dict(means2D=None, opacities=op.to(dev()), shs=shs.to(dev()), cov3D_precomp=cov.to(dev()))
+    img, _ = full(means3D=m, **args)
+    gw = torch.randn(3, s.image_height, s.image_width, generator=torch.Generator().manual_seed(1)).to(dev())
+    (gfull,) = torch.autograd.grad((img * gw).sum(), m)
+    rows = (s.image_height + 15) // 16
+    acc_img = torch.zeros_like(img)
+    acc_g = torch.zeros_like(gfull)
+    for r0, r1 in [(0, 2), (2, 3), (3, rows)]:
+        part, _ = _gpu_raster(s, tile_rows=(r0, r1))(means3D=m, **args)
+        y0, y1 = r0 * 16, min(s.image_height, r1 * 16)
+        assert torch.equal(part[:, y0:y1], img[:, y0:y1])          # same pixels, bit for bit
+        assert float(part[:, :y0].abs().sum()) == 0 and float(part[:, y1:].abs().sum()) == 0
+        acc_img += part
+        (gp,) = torch.autograd.grad((part * gw).sum(), m)
+        acc_g += gp
+    assert torch.equal(acc_img, img)
+    assert rel_max(acc_g, gfull) < 1e-5
+
+
+def test_raster_empty_and_all_culled():
+    s, means, cov, op, shs, _, _ = _scene(K=50)
+    rast = _gpu_raster(s)
+    far = means.clone()
+    far[:, :] = s.campos + torch.tensor([0.0, 0.0, 0.0])      # at the camera centre: z <= 0.2 -> culled
+    img, radii = rast(means3D=far.to(dev()), means2D=None, opacities=op.to(dev()), shs=shs.to(dev()), cov3D_precomp=cov.to(dev()))
+    assert int(radii.sum()) == 0 and torch.allclose(img, torch.ones_like(img))
+    img0, r0 = rast(means3D=means[:0].to(dev()), means2D=None, opacities=op[:0].to(dev()), shs=shs[:0].to(dev()),
+                    cov3D_precomp=cov[:0].to(dev()))
+    assert r0.numel() == 0 and torch.allclose(img0, torch.ones_like(img0))
+
+
+def test_bindings_and_cov_deform():
+    from neuma_amd.tune import Bindings, compute_bindings_xyz, compute_bindings_F
+    from neuma_amd.render import deform_cov_by_F
+    from neuma_amd import _lib as L
+    import ctypes as C
+    g = torch.Generator().manual_seed(0)
+    K, N, nb = 700, 300, 6
+    idx = torch.stack([torch.arange(K).repeat_interleave(nb), torch.randint(0, N, (K * nb,), generator=g)])
+    val = torch.rand(K * nb, generator=g)
+    B = torch.sparse_coo_tensor(idx, val, (K, N)).coalesce()
+    Bd = B.to_dense().double()
+    p = torch.randn(N, 3, generator=g); pp = torch.randn(N, 3, generator=g); kp = torch.randn(K, 3, generator=g)
+    F = torch.randn(N, 3, 3, generator=g)
+    pc = p.to(dev()).requires_grad_(True)
+    Bg = B.to(dev())
+    k = compute_bindings_xyz(pc, pp.to(dev()), kp.to(dev()), Bg)           # accepts the torch sparse tensor, like the reference
+    ref = orr.bindings_xyz(p.double(), pp.double(), kp.double(), Bd)
+    assert abs_max(k, ref) < 1e-5
+    gk = torch.randn(K, 3, generator=g)
+    (gp,) = torch.autograd.grad((k * gk.to(dev())).sum(), pc)
+    assert abs_max(gp, Bd.T @ gk.double()) < 1e-4
+    Fk = compute_bindings_F(F.to(dev()), Bg)
+    assert abs_max(Fk, orr.bindings_F(F.double(), Bd)) < 1e-4
+    cov = orr.build_cov3D(torch.rand(K, 3, generator=g) + 0.1, torch.randn(K, 4, generator=g))
+    out = deform_cov_by_F(cov.to(dev()), Fk)
+    assert rel_max(out, orr.deform_cov_by_F(cov.double(), Fk.cpu().double())) < 1e-5
+    # fused frame binding == the three separate operators
+    b = Bindings.of(Bg)
+    means = torch.empty(K, 3, device=dev()); cov2 = torch.empty(K, 6, device=dev()); Fo = torch.empty(K, 3, 3, device=dev())
+    pcd, ppd, kpd, Fd, cvd = p.to(dev()), pp.to(dev()), kp.to(dev()), F.to(dev()).contiguous(), cov.to(dev()).contiguous()
+    L.check(L.lib().nm_bind_frame(K, L.ptr(b.rowptr), L.ptr(b.col), L.ptr(b.val), L.ptr(pcd), L.ptr(ppd), L.ptr(kpd), L.ptr(Fd),
+                                  L.ptr(cvd), L.ptr(means), L.ptr(cov2), L.ptr(Fo), L.stream_ptr(dev())))
+    assert abs_max(means, k) < 1e-5 and abs_max(Fo, Fk) < 1e-5 and rel_max(cov2, out) < 1e-5
+
+
+def test_pixel_loss_kernel():
+    from neuma_amd import _lib as L
+    g = torch.Generator().manual_seed(0)
+    H, W = 37, 53
+    a = torch.rand(3, H, W, generator=g).to(dev()); b = torch.rand(3, H, W, generator=g).to(dev())
+    for kind, fn in ((0, orr.l1_loss), (1, orr.l2_loss)):
+        loss = torch.zeros(1, device=dev()); grad = torch.empty_like(a)
+        L.check(L.lib().nm_pixel_loss(kind, 0.7, H, W, 0, 0, L.ptr(a), L.ptr(b), L.ptr(loss), L.ptr(grad), L.stream_ptr(dev())))
+        ad = a.cpu().double().requires_grad_(True)
+        ref = 0.7 * fn(ad, b.cpu().double())
+        (gr,) = torch.autograd.grad(ref, ad)
+        assert abs(float(loss) - float(ref)) < 1e-6 and abs_max(grad, gr) < 1e-7

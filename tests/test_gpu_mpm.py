@@ -1,0 +1,150 @@
+"""GPU parity: MLS-MPM substep (p2g / grid_op / g2p and adjoints) through the C ABI vs the fp64 oracle.
+Tolerances from SURVEY.md §8d: single step atol x 5e-7, v 2e-6 (scaled by |v|max), C 5e-5*|C|scale, F 5e-7;
+gradients max-norm relative 2e-3."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mpm as om
+from gpu_util import dev, rel_max, abs_max, mpm_case, build_model, build_statics
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu_step(model, st, x, v, C, F, S, sim=None):
+    from neuma_amd.sim import MPMDiffSim
+    sim = sim or MPMDiffSim(model)
+    ins = [t.float().to(dev()).requires_grad_(True) for t in (x, v, C, F, S)]
+    outs = sim(st, *ins)
+    return ins, outs
+
+
+@pytest.mark.parametrize("bc", ["noslip", "freeslip"])
+@pytest.mark.parametrize("N,G", [(4096, 32), (3001, 16)])
+def test_forward_one_step(bc, N, G):
+    const, vol, rho, clip, en, x, v, C, F, S = mpm_case(N=N, G=G, bc=bc)
+    model = build_model(const, dev())
+    st = build_statics(model, vol, rho, clip, en, dev())
+    ins, outs = _gpu_step(model, st, x, v, C, F, S)
+    # the fp32 inputs are what the GPU saw: run the oracle on exactly those values
+    xi, vi, Ci, Fi, Si = [t.detach().cpu().double() for t in ins]
+    (ox, ov, oC, oF), (gmv, gm, gv) = om.step(const, vol, rho, clip, en, xi, vi, Ci, Fi, Si, return_grid=True)
+    mv, m, vg = model.grid_export()
+    assert rel_max(m, gm) < 2e-6
+    assert rel_max(mv, gmv) < 5e-6
+    assert rel_max(vg, gv) < 2e-5
+    e = (en != 0)
+    assert abs_max(outs[0][e], ox[e]) < 5e-7
+    assert rel_max(outs[1][e], ov[e]) < 2e-5
+    assert rel_max(outs[2][e], oC[e]) < 5e-5
+    assert abs_max(outs[3][e], oF[e]) < 5e-6
+    # disabled particles pass through
+    d = ~e
+    assert torch.equal(outs[0].detach().cpu()[d], ins[0].detach().cpu()[d])
+    assert torch.equal(outs[3].detach().cpu()[d], ins[3].detach().cpu()[d])
+    nb, nm = model.grid_stats()
+    assert nm == int((gm > 0).sum())
+    assert nb * 64 >= nm
+
+
+@pytest.mark.parametrize("bc", ["noslip", "freeslip"])
+def test_backward_one_step(bc):
+    const, vol, rho, clip, en, x, v, C, F, S = mpm_case(N=4096, G=32, bc=bc)
+    model = build_model(const, dev())
+    st = build_statics(model, vol, rho, clip, en, dev())
+    ins, outs = _gpu_step(model, st, x, v, C, F, S)
+    torch.manual_seed(11)
+    gws = [torch.randn(o.shape) for o in outs]
+    loss = sum((o * g.to(dev())).sum() for o, g in zip(outs, gws))
+    grads = torch.autograd.grad(loss, ins)
+    oins = [t.detach().cpu().double().requires_grad_(True) for t in ins]
+    oo = om.step(const, vol, rho, clip, en, *oins)
+    ol = sum((o * g.double()).sum() for o, g in zip(oo, gws))
+    og = torch.autograd.grad(ol, oins)
+    names = ["x", "v", "C", "F", "stress"]
+    for nme, a, b in zip(names, grads, og):
+        assert rel_max(a, b) < 2e-3, nme
+        assert torch.isfinite(a).all()
+    assert (grads[0].cpu()[en == 0] == 0).all() and (grads[4].cpu()[en == 0] == 0).all()
+
+
+def test_unsorted_particles_take_the_fallback_path_with_same_result():
+    const, vol, rho, clip, en, x, v, C, F, S = mpm_case(N=8192, G=64, near_wall=False, disabled=False)
+    model = build_model(const, dev())
+    st = build_statics(model, vol, rho, clip, en, dev())
+    _, outs = _gpu_step(model, st, x, v, C, F, S)
+    perm = torch.randperm(x.shape[0], generator=torch.Generator().manual_seed(5))
+    ins_p, outs_p = _gpu_step(model, st, x[perm], v[perm], C[perm], F[perm], S[perm])
+    for a, b in zip(outs, outs_p):
+        assert abs_max(a[perm.to(dev())], b) < 1e-4 * max(1.0, float(a.abs().max()))
+    g = torch.autograd.grad(outs_p[1].sum() + outs_p[3].sum(), ins_p)
+    assert all(torch.isfinite(t).all() for t in g)
+
+
+def test_in_place_forward_sim_and_extra():
+    from neuma_amd.sim import MPMForwardSim, MPMExtraSim
+    const, vol, rho, clip, en, x, v, C, F, S = mpm_case(N=2048, G=32, disabled=False)
+    model = build_model(const, dev())
+    st = build_statics(model, vol, rho, clip, en, dev())
+    state = model.state(x.shape[0])
+    state.from_torch(x=x.float().to(dev()), v=v.float().to(dev()), C=C.float().to(dev()), F=F.float().to(dev()),
+                     stress=S.float().to(dev()))
+    xi, vi, Ci, Fi, Si = [t.clone().cpu().double() for t in state.to_torch()]
+    ox, ov, oC, oF = om.step(const, vol, rho, clip, en, xi, vi, Ci, Fi, Si)
+    # passive extra particles sampled on the same grid (mpm.py:260-277) — before the in-place step mutates state
+    M = 300
+    xe = x[:M] + 0.3 * const.dx
+    st_e = build_statics(model, vol[:M], rho[:M], clip[:M], en[:M], dev())
+    state_e = model.state(M)
+    state_e.from_torch(x=xe.float().to(dev()))
+    Fe = state_e.particle.F.clone().cpu().double()
+    x_extra = MPMExtraSim(model)(st, state, st_e, state_e)
+    gmv, gm = om.p2g(const, vol, rho, en, xi, vi, Ci, Si)
+    gv = om.grid_op(const, gmv, gm)
+    oxe, _, _, _ = om.g2p(const, clip[:M], en[:M], xe.float().double(), Fe, gv)
+    assert abs_max(x_extra, oxe) < 5e-7
+    x2, v2, C2, F2 = MPMForwardSim(model)(st, state)
+    assert abs_max(x2, ox) < 5e-7 and rel_max(v2, ov) < 2e-5 and rel_max(C2, oC) < 5e-5 and abs_max(F2, oF) < 5e-6
+
+
+def test_fifty_step_rollout_drift_vs_fp64():
+    """Contact-free roll-out with a smooth neo-Hookean-like stress; horizon tolerance of SURVEY §8d."""
+    from neuma_amd.sim import MPMForwardSim
+    const, vol, rho, clip, en, x, v, C, F, S = mpm_case(N=4096, G=32, near_wall=False, disabled=False)
+    v = 0.1 * v
+    C = torch.zeros_like(C)
+    F = torch.eye(3, dtype=torch.float64).repeat(x.shape[0], 1, 1)
+    model = build_model(const, dev())
+    st = build_statics(model, vol, rho, clip, en, dev())
+    state = model.state(x.shape[0])
+    state.from_torch(x=x.float().to(dev()), v=v.float().to(dev()), C=C.float().to(dev()), F=F.float().to(dev()))
+    sim = MPMForwardSim(model)
+    xo, vo, Co, Fo = [t.clone().cpu().double() for t in state.to_torch()[:4]]
+
+    def stress_of(Fm):   # mu (F F^T - I)
+        return 200.0 * (Fm @ Fm.transpose(-1, -2) - torch.eye(3, dtype=Fm.dtype, device=Fm.device))
+
+    for _ in range(50):
+        state.from_torch(stress=stress_of(state.particle.F))
+        sim(st, state)
+        xo, vo, Co, Fo = om.step(const, vol, rho, clip, en, xo, vo, Co, Fo, stress_of(Fo))
+    xg, vg, Cg, Fg, _ = state.to_torch()
+    assert abs_max(xg, xo) < 5e-6 and abs_max(vg, vo) < 5e-5 and abs_max(Cg, Co) < 1e-3 and abs_max(Fg, Fo) < 1e-5
+
+
+def test_error_paths():
+    from neuma_amd.sim import MPMModelBuilder
+    from neuma_amd import NeumaHipError
+    cfg = dict(gravity=[0, 0, 0], bc="sticky", num_grids=16, dt=1e-3, bound=1, eps=0.0)
+    with pytest.raises(ValueError):
+        MPMModelBuilder().parse_cfg(cfg).finalize(dev())                 # mpm.py:550
+    with pytest.raises(RuntimeError):
+        MPMModelBuilder().finalize(dev())                                # abstract.py:83-84
+    cfg["bc"] = "noslip"
+    model = MPMModelBuilder().parse_cfg(cfg).finalize(dev())
+    st = model.statics(0)
+    s0 = model.state(0)
+    model.forward(st, s0, s0)                                             # empty input is a no-op
+    model_cpu = MPMModelBuilder().parse_cfg(cfg).finalize("cpu")
+    with pytest.raises(NeumaHipError):
+        model_cpu.forward(model_cpu.statics(4), model_cpu.state(4), model_cpu.state(4))

@@ -1,0 +1,119 @@
+"""GPU parity: fused roll-out (nm_rollout_*) vs the per-operator drop-in path vs the fp64 oracle chain, and the
+frame-level harness (sim + binding + render + loss, forward and backward)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import material as omat
+from oracle import mpm as om
+from oracle import raster as orr
+from gpu_util import dev, rel_max, abs_max
+
+pytestmark = pytest.mark.gpu
+
+
+def _runtime(name="tiny", fused=True, **over):
+    from neuma_amd import synth
+    from neuma_amd.harness import SceneRuntime
+    scene = synth.make_scene(name, override=over or None)
+    return SceneRuntime(scene, dev(), fused=fused)
+
+
+def _oracle_rollout(rt, S, x, v, C, F):
+    """fp64 chain stress=E(F); sim; F=P(F) with the runtime's merged weights (finetune.py:362-364)."""
+    c = rt.model.constant
+    const = om.MPMConstant(int(c.num_grids), float(c.dt), int(c.bound), tuple(float(g) for g in c.gravity), float(c.eps), rt.model.bc)
+    We = [w.detach().cpu().double().requires_grad_(True) for w in rt.elasticity.effective_weights()]
+    Wp = [w.detach().cpu().double().requires_grad_(True) for w in rt.plasticity.effective_weights()]
+    st = rt.statics
+    vol, rho, clip, en = st.vol.cpu().double(), st.rho.cpu().double(), st.clip_bound.cpu().double(), st.enabled.cpu()
+    for _ in range(S):
+        stress = omat.elasticity(F, We)
+        x, v, C, F = om.step(const, vol, rho, clip, en, x, v, C, F, stress)
+        F = omat.plasticity(F, Wp, rt.plasticity.alpha)
+    return (x, v, C, F), We, Wp
+
+
+def test_fused_rollout_equals_per_operator_path_and_oracle():
+    S = 3
+    rt = _runtime("tiny", fused=True, S=S)
+    params = rt.parameters()
+    torch.manual_seed(0)
+    gws = [torch.randn(rt.N, 3), torch.randn(rt.N, 3), torch.randn(rt.N, 3, 3), torch.randn(rt.N, 3, 3)]
+    # start away from F = I (where the reference's SVD adjoint is clamped noise)
+    g = torch.Generator().manual_seed(4)
+    F0 = (torch.eye(3) + 0.05 * torch.randn(rt.N, 3, 3, generator=g)).to(dev())
+    res = {}
+    for fused in (True, False):
+        rt.fused = fused
+        ins = [t.clone().requires_grad_(True) for t in (rt.x0, rt.v0, rt.C0, F0)]
+        outs = rt.rollout(*ins)
+        loss = sum((o * w.to(dev())).sum() for o, w in zip(outs, gws))
+        grads = torch.autograd.grad(loss, ins + params)
+        res[fused] = ([o.detach() for o in outs], grads)
+    for a, b in zip(res[True][0], res[False][0]):
+        assert abs_max(a, b) < 1e-5 * max(1.0, float(b.abs().max()))
+    for a, b in zip(res[True][1], res[False][1]):
+        assert rel_max(a, b) < 1e-3
+    oins = [t.detach().cpu().double().requires_grad_(True) for t in (rt.x0, rt.v0, rt.C0, F0)]
+    oouts, We, Wp = _oracle_rollout(rt, S, *oins)
+    for nme, a, b, tol in zip("xvCF", res[True][0], oouts, [5e-6, 5e-5, 1e-3, 1e-5]):
+        assert abs_max(a, b) < tol * max(1.0, float(b.abs().max())), nme
+    ol = sum((o * w.double()).sum() for o, w in zip(oouts, gws))
+    og = torch.autograd.grad(ol, oins + We + Wp)
+    for nme, a, b in zip("xvCF", res[True][1][:4], og[:4]):
+        assert rel_max(a, b) < 5e-3, nme
+    # LoRA factor gradients from the effective-weight gradients (chain rule through W + s B A)
+    k = 0
+    for net, dW in ((rt.elasticity, og[4:7]), (rt.plasticity, og[7:10])):
+        for lin, d in zip((net.layers[0].fc, net.layers[1].fc, net.final_layer.fc), dW):
+            gA_ref = lin.scaling * lin.lora_B.detach().cpu().double().T @ d
+            gB_ref = lin.scaling * d @ lin.lora_A.detach().cpu().double().T
+            assert rel_max(res[True][1][4 + k], gA_ref) < 1e-2, (k, "A")
+            assert rel_max(res[True][1][5 + k], gB_ref) < 1e-2, (k, "B")
+            k += 2
+
+
+def test_frame_forward_backward_finite_and_consistent():
+    rt = _runtime("tiny", fused=True)
+    rt.make_ground_truth()
+    r1 = rt.frame()
+    g1 = [p.grad.clone() for p in rt.parameters()]
+    assert torch.isfinite(r1.loss) and float(r1.loss) > 0
+    assert all(torch.isfinite(g).all() for g in g1) and any(float(g.abs().max()) > 0 for g in g1)
+    for p in rt.parameters():
+        p.grad = None
+    rt.fused = False
+    r2 = rt.frame()
+    g2 = [p.grad.clone() for p in rt.parameters()]
+    assert abs(float(r1.loss) - float(r2.loss)) < 1e-5 * max(1.0, abs(float(r2.loss)))
+    for a, b in zip(g1, g2):
+        assert rel_max(a, b) < 2e-2
+    # striped (multi-rank style) loss pieces add up to the full loss
+    from neuma_amd.harness import stripe_plan
+    rt.fused = True
+    total = 0.0
+    for rank in range(3):
+        rt.world, rt.rank = 3, rank
+        total += float(rt.frame(backward=False).loss)
+    rt.world, rt.rank = 1, 0
+    assert abs(total - float(r1.loss)) < 1e-5 * max(1.0, abs(float(r1.loss)))
+
+
+def test_frame_image_matches_oracle_render():
+    """End-to-end image parity on the tiny scene: HIP sim+binding+raster vs oracle raster on the HIP state."""
+    rt = _runtime("tiny", fused=True)
+    from neuma_amd.tune import compute_bindings_xyz, compute_bindings_F
+    with torch.no_grad():
+        x, v, C, F = rt.rollout(rt.x0, rt.v0, rt.C0, rt.F0)
+        means3D = compute_bindings_xyz(x, rt.x0, rt.gaussians.get_xyz, rt.bindings)
+        dg = compute_bindings_F(F, rt.bindings)
+        img = rt.render_view(means3D, dg, 0)
+    cam = rt.cameras[0]
+    import math
+    s = orr.Settings(cam.image_height, cam.image_width, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), rt.background.cpu().double(),
+                     1.0, cam.world_view_transform.cpu().double(), cam.full_proj_transform.cpu().double(),
+                     rt.gaussians.active_sh_degree, cam.camera_center.cpu().double())
+    cov = orr.deform_cov_by_F(rt._cov.cpu().double(), dg.cpu().double())
+    oimg, _ = orr.render(s, means3D.cpu().double(), cov, rt._opacity.cpu().double(), shs=rt._shs.cpu().double())
+    assert abs_max(img, oimg) < 1e-3
