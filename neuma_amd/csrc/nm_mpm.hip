@@ -5,21 +5,28 @@
 //   * the grid lives in HBM as 4x4x4-node blocks of float4 {mv.xyz, m} / {v.xyz, -} (1 KiB per block),
 //     and only blocks touched by a particle stencil are ever cleared or updated (active-block list built
 //     by p2g with an epoch flag per block) — the reference sweeps all G^3 cells 12 times per step;
-//   * scatters (p2g, g2p-adjoint) accumulate in an LDS tile covering the bounding box of the
-//     workgroup's 256 particles with ds_add_f32 and flush each touched node once with global atomics;
-//     a workgroup whose particles are too spread out falls back to direct global atomics, so the
-//     particle order only affects speed, never results beyond fp32 summation order;
+//   * scatters (p2g, g2p-adjoint) accumulate in a per-wave LDS tile covering the bounding box of the wave's
+//     particles and flush each touched node once with global atomics.  ds_add_f32 is NOT used: measured on
+//     MI355X it retires ~0.33 lanes/clk/CU (tools/ubench_atomics.hip), 20x slower than a plain LDS
+//     read-modify-write.  Instead a workgroup is ONE wave that owns its tile; for a fixed stencil offset two
+//     lanes collide only if they share a base cell, so lanes elect one owner per base cell (LDS ticket) and
+//     the owners do plain ds_read_b128 / add / ds_write_b128; losers retry in the next round.  Lanes take
+//     particles with stride PB, so cell-sorted inputs give ~1 round.  A wave whose particles are too spread
+//     out falls back to direct global atomics: particle order affects speed only, never results beyond
+//     fp32 summation order;
 //   * stencil nodes with an index >= G (reference: out-of-bounds access when x > 1-1.5dx) land in
 //     padding blocks whose velocity is defined as zero.
 #include "nm_common.h"
+#include <stdlib.h>
 
-#define NM_TILE_CAP 2048  // LDS tile nodes (x16 B = 32 KiB)
 
 struct MpmK {
   int G, Gp, nb;
   float dt, dx, inv_dx, eps;
   float gdt[3];
   int bound, bc;
+  int dbg;  // NM_DBG experiment switches (0 in production)
+  long long* dbg_buf;
 };
 
 struct nm_mpm {
@@ -78,84 +85,253 @@ __device__ __forceinline__ void mark_block(int b, int* __restrict__ flags, int* 
   }
 }
 
-// ---------------------------------------------------------------- workgroup LDS tile for scatters
+// ---------------------------------------------------------------- per-wave LDS tile for scatters
+#define NM_WT_CAP 1024   // nodes per wave tile: 16 KiB of float4 + 4 KiB of owner tickets
+#define NM_WT_PB 8       // consecutive particles per lane (workgroup = one wave = 512 particles)
+#define NM_WT_BOX 10     // edge of the fixed box used when a chunk's bounding box exceeds the tile (10^3 nodes)
+#define NM_WT_MAXPASS 12 // boxes tried per chunk before the leftovers go to direct global atomics
+
 struct TileGeom {
   int o[3];
   int n[3];
   int vol;
-  bool any, use;
+  bool use;
 };
 
-__device__ __forceinline__ TileGeom tile_setup(bool active, const int* b, int* s_mm, float* s_tile) {
-  const int tid = threadIdx.x;
-  if (tid < 3) { s_mm[tid] = 0x7fffffff; s_mm[3 + tid] = -0x7fffffff; }
-  __syncthreads();
-  if (active) {
+__device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { atomicMin(&s_mm[a], b[a]); atomicMax(&s_mm[3 + a], b[a]); }
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ void base_cell(const MpmK& K, const float* __restrict__ xp, int* bb) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    int q = (int)(xp[a] * K.inv_dx - 0.5f);
+    bb[a] = max(0, min(q, K.Gp - 3));
   }
-  __syncthreads();
+}
+__device__ __forceinline__ void tile_zero(const TileGeom& g, float4* s_tile) {
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = threadIdx.x; i < g.vol; i += 64) s_tile[i] = z;
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ TileGeom tile_box(const MpmK& K, const int* anchor) {
   TileGeom g;
-  g.any = s_mm[0] != 0x7fffffff;
 #pragma unroll
-  for (int a = 0; a < 3; ++a) { g.o[a] = s_mm[a]; g.n[a] = g.any ? s_mm[3 + a] - s_mm[a] + 3 : 0; }
-  g.vol = g.n[0] * g.n[1] * g.n[2];
-  g.use = g.any && g.vol <= NM_TILE_CAP;
-  if (g.use) {
-    for (int i = tid; i < g.vol * 4; i += blockDim.x) s_tile[i] = 0.f;
+  for (int a = 0; a < 3; ++a) {
+    g.o[a] = max(0, min(anchor[a] - 2, K.Gp - NM_WT_BOX));
+    g.n[a] = NM_WT_BOX;
   }
-  __syncthreads();
+  g.vol = NM_WT_BOX * NM_WT_BOX * NM_WT_BOX;
+  g.use = true;
   return g;
 }
+__device__ __forceinline__ bool tile_holds(const TileGeom& g, const int* b) {
+  return b[0] >= g.o[0] && b[0] + 3 <= g.o[0] + g.n[0] && b[1] >= g.o[1] && b[1] + 3 <= g.o[1] + g.n[1] && b[2] >= g.o[2] &&
+         b[2] + 3 <= g.o[2] + g.n[2];
+}
 
-// flush the LDS tile: one global atomic set per touched node; mark the blocks it overlaps
+// flush the tile: one global atomic set per touched node; mark the grid blocks the tile overlaps
 template <int NCH>
-__device__ __forceinline__ void tile_flush(const TileGeom& g, const float* s_tile, float4* __restrict__ grid,
-                                           int nb, int* flags, int* list, int* count, int epoch) {
-  __syncthreads();
-  const int tid = threadIdx.x;
-  if (g.use) {
-    const int nyz = g.n[1] * g.n[2];
-    for (int idx = tid; idx < g.vol; idx += blockDim.x) {
-      float t0 = s_tile[idx * 4], t1 = s_tile[idx * 4 + 1], t2 = s_tile[idx * 4 + 2], t3 = s_tile[idx * 4 + 3];
-      if (t0 != 0.f || t1 != 0.f || t2 != 0.f || t3 != 0.f) {
-        int i = idx / nyz, r = idx - i * nyz;
-        int j = r / g.n[2], k = r - j * g.n[2];
-        float* dst = (float*)&grid[node_addr(g.o[0] + i, g.o[1] + j, g.o[2] + k, nb)];
-        unsafeAtomicAdd(dst, t0);
-        unsafeAtomicAdd(dst + 1, t1);
-        unsafeAtomicAdd(dst + 2, t2);
-        if (NCH == 4) unsafeAtomicAdd(dst + 3, t3);
-      }
+__device__ __forceinline__ void tile_flush(const TileGeom& g, const float4* s_tile, float4* __restrict__ grid, int nb, int* flags,
+                                           int* list, int* count, int epoch) {
+  __builtin_amdgcn_wave_barrier();
+  const int lane = threadIdx.x;
+  const int nyz = g.n[1] * g.n[2];
+  for (int idx = lane; idx < g.vol; idx += 64) {
+    float4 t = s_tile[idx];
+    if (t.x != 0.f || t.y != 0.f || t.z != 0.f || t.w != 0.f) {
+      int i = idx / nyz, r = idx - i * nyz;
+      int j = r / g.n[2], k = r - j * g.n[2];
+      float* dst = (float*)&grid[node_addr(g.o[0] + i, g.o[1] + j, g.o[2] + k, nb)];
+      unsafeAtomicAdd(dst, t.x);
+      unsafeAtomicAdd(dst + 1, t.y);
+      unsafeAtomicAdd(dst + 2, t.z);
+      if (NCH == 4) unsafeAtomicAdd(dst + 3, t.w);
     }
-    if (flags) {
-      int b0 = g.o[0] >> 2, b1 = g.o[1] >> 2, b2 = g.o[2] >> 2;
-      int m0 = ((g.o[0] + g.n[0] - 1) >> 2) - b0 + 1, m1 = ((g.o[1] + g.n[1] - 1) >> 2) - b1 + 1,
-          m2 = ((g.o[2] + g.n[2] - 1) >> 2) - b2 + 1;
-      for (int t = tid; t < m0 * m1 * m2; t += blockDim.x) {
-        int i = t / (m1 * m2), r = t - i * (m1 * m2);
-        int j = r / m2, k = r - j * m2;
-        mark_block(((b0 + i) * nb + (b1 + j)) * nb + (b2 + k), flags, list, count, epoch);
-      }
+  }
+  if (flags) {
+    int b0 = g.o[0] >> 2, b1 = g.o[1] >> 2, b2 = g.o[2] >> 2;
+    int m0 = ((g.o[0] + g.n[0] - 1) >> 2) - b0 + 1, m1 = ((g.o[1] + g.n[1] - 1) >> 2) - b1 + 1,
+        m2 = ((g.o[2] + g.n[2] - 1) >> 2) - b2 + 1;
+    for (int t = lane; t < m0 * m1 * m2; t += 64) {
+      int i = t / (m1 * m2), r = t - i * (m1 * m2);
+      int j = r / m2, k = r - j * m2;
+      mark_block(((b0 + i) * nb + (b1 + j)) * nb + (b2 + k), flags, list, count, epoch);
     }
   }
 }
 
-template <int NCH>
-__device__ __forceinline__ void scatter_node(const TileGeom& g, float* s_tile, float4* __restrict__ grid, int nb,
-                                             int i, int j, int k, float a0, float a1, float a2, float a3) {
-  if (g.use) {
-    int idx = (((i - g.o[0]) * g.n[1] + (j - g.o[1])) * g.n[2] + (k - g.o[2])) * 4;
-    unsafeAtomicAdd(&s_tile[idx], a0);
-    unsafeAtomicAdd(&s_tile[idx + 1], a1);
-    unsafeAtomicAdd(&s_tile[idx + 2], a2);
-    if (NCH == 4) unsafeAtomicAdd(&s_tile[idx + 3], a3);
-  } else {
-    float* dst = (float*)&grid[node_addr(i, j, k, nb)];
-    unsafeAtomicAdd(dst, a0);
-    unsafeAtomicAdd(dst + 1, a1);
-    unsafeAtomicAdd(dst + 2, a2);
-    if (NCH == 4) unsafeAtomicAdd(dst + 3, a3);
+// Scatter of one chunk (64 lanes x PB consecutive particles each) into `grid`.
+//   prep(p, st, q)            loads particle p: stencil + payload
+//   contrib(st, q, i, j, k)   its contribution to stencil node (i,j,k)
+// A lane first sums, in registers, the contributions of all of its particles that share a base cell (cell-sorted
+// input: usually all PB of them), then lanes elect one owner per base cell through an LDS ticket and the owners
+// add their 27 float4 sums to the tile with plain ds_read_b128 / ds_write_b128; losers retry.  Chunks whose
+// bounding box exceeds the tile are processed box by box; leftovers use global atomics.
+template <int NCH, class P, class PrepF, class ContribF>
+__device__ __forceinline__ void wave_scatter(const MpmK& K, int n, const int* __restrict__ enabled, const float* __restrict__ x,
+                                             float4* __restrict__ grid, int* flags, int* list, int* count, int epoch,
+                                             float4* s_tile, int* s_own, PrepF prep, ContribF contrib) {
+  const int lane = threadIdx.x;
+  const int p0 = (blockIdx.x * 64 + lane) * NM_WT_PB;
+  // which of my particles are enabled, and the chunk bounding box in base-cell coordinates
+  unsigned todo = 0u;
+  int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-0x7fffffff, -0x7fffffff, -0x7fffffff};
+#pragma unroll
+  for (int b = 0; b < NM_WT_PB; ++b) {
+    const int p = p0 + b;
+    if (p < n && enabled[p] != 0) {
+      todo |= 1u << b;
+      int bb[3];
+      base_cell(K, x + 3 * p, bb);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { lo[a] = min(lo[a], bb[a]); hi[a] = max(hi[a], bb[a]); }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { lo[a] = wave_min_i(lo[a]); hi[a] = wave_max_i(hi[a]); }
+  if (lo[0] == 0x7fffffff) return;  // nothing enabled in this chunk
+  TileGeom g;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { g.o[a] = lo[a]; g.n[a] = hi[a] - lo[a] + 3; }
+  g.vol = g.n[0] * g.n[1] * g.n[2];
+  const bool single = g.vol <= NM_WT_CAP;
+  g.use = true;
+
+  int dbg_pass = 0, dbg_sweep = 0, dbg_round = 0;
+  for (int pass = 0; pass <= NM_WT_MAXPASS; ++pass) {
+    const bool direct = !single && pass == NM_WT_MAXPASS;   // last resort: global atomics for what is left
+    if (!single && !direct) {                                // anchor a box at the first particle still pending
+      unsigned long long m = __ballot(todo != 0u);
+      if (m == 0ull) break;
+      int src = __ffsll((long long)m) - 1;
+      int bb[3] = {0, 0, 0};
+      if (todo) base_cell(K, x + 3 * (p0 + (__ffs(todo) - 1)), bb);
+      int anchor[3] = {__shfl(bb[0], src, 64), __shfl(bb[1], src, 64), __shfl(bb[2], src, 64)};
+      g = tile_box(K, anchor);
+    }
+    if (!direct) tile_zero(g, s_tile);
+    ++dbg_pass;
+    // particles of mine that belong to this pass
+    unsigned mine_now = 0u;
+#pragma unroll
+    for (int b = 0; b < NM_WT_PB; ++b) {
+      if (todo & (1u << b)) {
+        int bb[3];
+        base_cell(K, x + 3 * (p0 + b), bb);
+        if (direct || single || tile_holds(g, bb)) mine_now |= 1u << b;
+      }
+    }
+    todo &= ~mine_now;
+    while (__ballot(mine_now != 0u) != 0ull) {
+      const bool has = mine_now != 0u;
+      ++dbg_sweep;
+      Stencil st;
+      float4 acc[27];
+      if (has) {
+        const int b0 = __ffs(mine_now) - 1;
+        P q;
+        prep(p0 + b0, st, q);
+        mine_now &= ~(1u << b0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc[(i * 3 + j) * 3 + k] = contrib(st, q, i, j, k);
+        // fold in my other particles with the same base cell
+#pragma unroll 1
+        for (int b = b0 + 1; b < NM_WT_PB; ++b) {
+          if (!(mine_now & (1u << b))) continue;
+          int bb[3];
+          base_cell(K, x + 3 * (p0 + b), bb);
+          if (bb[0] != st.b[0] || bb[1] != st.b[1] || bb[2] != st.b[2]) continue;
+          Stencil st2;
+          P q2;
+          prep(p0 + b, st2, q2);
+          mine_now &= ~(1u << b);
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+              for (int k = 0; k < 3; ++k) {
+                float4 c = contrib(st2, q2, i, j, k);
+                float4& t = acc[(i * 3 + j) * 3 + k];
+                t.x += c.x; t.y += c.y; t.z += c.z; t.w += c.w;
+              }
+        }
+      } else {
+        st.b[0] = st.b[1] = st.b[2] = 0;
+      }
+      if (direct) {
+        if (has) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+              for (int k = 0; k < 3; ++k) {
+                const float4 c = acc[(i * 3 + j) * 3 + k];
+                float* dst = (float*)&grid[node_addr(st.b[0] + i, st.b[1] + j, st.b[2] + k, K.nb)];
+                unsafeAtomicAdd(dst, c.x);
+                unsafeAtomicAdd(dst + 1, c.y);
+                unsafeAtomicAdd(dst + 2, c.z);
+                if (NCH == 4) unsafeAtomicAdd(dst + 3, c.w);
+              }
+          if (flags) {
+            for (int i = st.b[0] >> 2; i <= (st.b[0] + 2) >> 2; ++i)
+              for (int j = st.b[1] >> 2; j <= (st.b[1] + 2) >> 2; ++j)
+                for (int k = st.b[2] >> 2; k <= (st.b[2] + 2) >> 2; ++k)
+                  mark_block((i * K.nb + j) * K.nb + k, flags, list, count, epoch);
+          }
+        }
+        continue;
+      }
+      // owner election per base cell, then plain LDS read-modify-write by the owners
+      const int ci = has ? ((st.b[0] - g.o[0]) * g.n[1] + (st.b[1] - g.o[1])) * g.n[2] + (st.b[2] - g.o[2]) : 0;
+      bool pending = has;
+      while (__ballot(pending) != 0ull) {
+        ++dbg_round;
+        if (pending) __hip_atomic_store(&s_own[ci], lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __builtin_amdgcn_wave_barrier();
+        const bool won = pending && __hip_atomic_load(&s_own[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == lane;
+        if (won) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+              for (int k = 0; k < 3; ++k) {
+                const int idx = ci + (i * g.n[1] + j) * g.n[2] + k;
+                const float4 c = acc[(i * 3 + j) * 3 + k];
+                float4 t = s_tile[idx];
+                t.x += c.x; t.y += c.y; t.z += c.z;
+                if (NCH == 4) t.w += c.w;
+                s_tile[idx] = t;
+                // keep the wave-level order of LDS accesses between offsets: another lane's next offset may be
+                // this lane's current node
+                asm volatile("" ::: "memory");
+              }
+        }
+        pending = pending && !won;
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (direct) break;
+    tile_flush<NCH>(g, s_tile, grid, K.nb, flags, list, count, epoch);
+    if (single) break;
+  }
+  if (K.dbg_buf && threadIdx.x == 0 && blockIdx.x < 4096 && NCH == 4) {
+    K.dbg_buf[blockIdx.x * 4 + 1] = dbg_pass;
+    K.dbg_buf[blockIdx.x * 4 + 2] = dbg_sweep;
+    K.dbg_buf[blockIdx.x * 4 + 3] = dbg_round;
   }
 }
 
@@ -176,61 +352,39 @@ __global__ void __launch_bounds__(256) k_clear(float4* __restrict__ gm, float4* 
   if (blockIdx.x == 0 && threadIdx.x == 0) *count_cur = 0;
 }
 
-// mpm.py:321-371
-__global__ void __launch_bounds__(256) k_p2g(MpmK K, int n, const float* __restrict__ vol, const float* __restrict__ rho,
-                                             const int* __restrict__ enabled, const float* __restrict__ x,
-                                             const float* __restrict__ v, const float* __restrict__ C,
-                                             const float* __restrict__ S, float4* __restrict__ gm, int* flags,
-                                             int* list, int* count, int epoch) {
-  __shared__ int s_mm[6];
-  __shared__ float s_tile[NM_TILE_CAP * 4];
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = p < n && enabled[p] != 0;
-  Stencil st;
-  float pm = 0.f, mom[3] = {0.f, 0.f, 0.f};
-  M3 A = m3_zero();
-  if (active) {
+struct P2gP {  // per-particle payload of p2g
+  float pm, mom[3];
+  M3 A;
+};
+// mpm.py:321-371.  One wave per workgroup; lane l handles particles (64*blockIdx + l)*PB + b, b < PB.
+__global__ void __launch_bounds__(64) k_p2g(MpmK K, int n, const float* __restrict__ vol, const float* __restrict__ rho,
+                                            const int* __restrict__ enabled, const float* __restrict__ x,
+                                            const float* __restrict__ v, const float* __restrict__ C,
+                                            const float* __restrict__ S, float4* __restrict__ gm, int* flags, int* list,
+                                            int* count, int epoch) {
+  __shared__ float4 s_tile[NM_WT_CAP];
+  __shared__ int s_own[NM_WT_CAP];
+  const long long t_start = K.dbg_buf ? clock64() : 0;
+  auto prep = [&](int p, Stencil& st, P2gP& q) {
     make_stencil(K, x + 3 * p, st);
     float vl = vol[p];
-    pm = vl * rho[p];
+    q.pm = vl * rho[p];
     float ks = -K.dt * vl * 4.0f * K.inv_dx * K.inv_dx;  // mpm.py:357
     M3 Sp = m3_load(S + 9 * p), Cp = m3_load(C + 9 * p);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) A.m[i] = ks * Sp.m[i] + pm * Cp.m[i];
+    for (int i = 0; i < 9; ++i) q.A.m[i] = ks * Sp.m[i] + q.pm * Cp.m[i];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) mom[a] = pm * v[3 * p + a];
-  } else {
-    st.b[0] = st.b[1] = st.b[2] = 0;
-  }
-  TileGeom g = tile_setup(active, st.b, s_mm, s_tile);
-  if (!g.any) return;
-  if (active) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      float d0 = ((float)i - st.f[0]) * K.dx;
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        float d1 = ((float)j - st.f[1]) * K.dx;
-        float wij = st.w[0][i] * st.w[1][j];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          float d2 = ((float)k - st.f[2]) * K.dx;
-          float w = wij * st.w[2][k];
-          float m0 = w * (mom[0] + A.m[0] * d0 + A.m[1] * d1 + A.m[2] * d2);
-          float m1 = w * (mom[1] + A.m[3] * d0 + A.m[4] * d1 + A.m[5] * d2);
-          float m2 = w * (mom[2] + A.m[6] * d0 + A.m[7] * d1 + A.m[8] * d2);
-          scatter_node<4>(g, s_tile, gm, K.nb, st.b[0] + i, st.b[1] + j, st.b[2] + k, m0, m1, m2, w * pm);
-        }
-      }
-    }
-    if (!g.use) {
-      for (int i = st.b[0] >> 2; i <= (st.b[0] + 2) >> 2; ++i)
-        for (int j = st.b[1] >> 2; j <= (st.b[1] + 2) >> 2; ++j)
-          for (int k = st.b[2] >> 2; k <= (st.b[2] + 2) >> 2; ++k)
-            mark_block((i * K.nb + j) * K.nb + k, flags, list, count, epoch);
-    }
-  }
-  tile_flush<4>(g, s_tile, gm, K.nb, flags, list, count, epoch);
+    for (int a = 0; a < 3; ++a) q.mom[a] = q.pm * v[3 * p + a];
+  };
+  auto contrib = [&](const Stencil& st, const P2gP& q, int i, int j, int k) -> float4 {
+    float d0 = ((float)i - st.f[0]) * K.dx, d1 = ((float)j - st.f[1]) * K.dx, d2 = ((float)k - st.f[2]) * K.dx;
+    float w = st.w[0][i] * st.w[1][j] * st.w[2][k];
+    return make_float4(w * (q.mom[0] + q.A.m[0] * d0 + q.A.m[1] * d1 + q.A.m[2] * d2),
+                       w * (q.mom[1] + q.A.m[3] * d0 + q.A.m[4] * d1 + q.A.m[5] * d2),
+                       w * (q.mom[2] + q.A.m[6] * d0 + q.A.m[7] * d1 + q.A.m[8] * d2), w * q.pm);
+  };
+  wave_scatter<4, P2gP>(K, n, enabled, x, gm, flags, list, count, epoch, s_tile, s_own, prep, contrib);
+  if (K.dbg_buf && threadIdx.x == 0 && blockIdx.x < 4096) K.dbg_buf[blockIdx.x * 4] = clock64() - t_start;
 }
 
 __device__ __forceinline__ void block_coords(int b, int nb, int lane, int& i, int& j, int& k) {
@@ -372,96 +526,125 @@ __global__ void __launch_bounds__(256, 4) k_g2p(MpmK K, int n, const float* __re
   m3_store(Fn + 9 * p, Fo);
 }
 
-// adjoint of g2p: writes gx (direct part), gF; scatters vbar into gg
-__global__ void __launch_bounds__(256, 2) k_g2p_bwd(MpmK K, int n, const float* __restrict__ clip, const int* __restrict__ enabled,
-                                                 const float* __restrict__ x, const float* __restrict__ F,
-                                                 const float* __restrict__ vnext, const float* __restrict__ Cnext,
-                                                 const float* __restrict__ gxn, const float* __restrict__ gvn,
-                                                 const float* __restrict__ gCn, const float* __restrict__ gFn,
-                                                 const float4* __restrict__ gv, float4* __restrict__ gg,
-                                                 float* __restrict__ gx, float* __restrict__ gF) {
-  __shared__ int s_mm[6];
-  __shared__ float s_tile[NM_TILE_CAP * 4];
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = p < n && enabled[p] != 0;
+// adjoint of g2p: writes gx (direct part), gF; scatters vbar into gg (same wave-tile scheme as p2g)
+struct G2pBwdP {  // per-particle quantities of the g2p adjoint
   Stencil st;
-  float vt[3] = {0.f, 0.f, 0.f}, xbar[3] = {0.f, 0.f, 0.f};
-  M3 Ct = m3_zero(), Fbar = m3_zero();
+  float vt[3], xbar[3];
+  M3 Ct, Fbar;
+};
+__device__ __forceinline__ bool g2p_bwd_particle(const MpmK& K, int n, int p, const float* __restrict__ clip,
+                                                 const int* __restrict__ enabled, const float* __restrict__ x,
+                                                 const float* __restrict__ F, const float* __restrict__ vnext,
+                                                 const float* __restrict__ Cnext, const float* __restrict__ gxn,
+                                                 const float* __restrict__ gvn, const float* __restrict__ gCn,
+                                                 const float* __restrict__ gFn, G2pBwdP& q) {
+  const bool active = p < n && enabled[p] != 0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { q.vt[a] = 0.f; q.xbar[a] = 0.f; }
+  q.Ct = m3_zero();
+  q.Fbar = m3_zero();
   if (active) {
     float xp[3] = {x[3 * p], x[3 * p + 1], x[3 * p + 2]};
-    make_stencil(K, xp, st);
+    make_stencil(K, xp, q.st);
     float bnd = clip[p] * K.dx;
     float lo = 0.0f + bnd, hi = 1.0f - bnd;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       float t = xp[a] + K.dt * vnext[3 * p + a];
       float xe = (t >= lo && t <= hi) ? gxn[3 * p + a] : 0.f;  // clamp passes the gradient only inside
-      xbar[a] = xe;
-      vt[a] = gvn[3 * p + a] + K.dt * xe;
+      q.xbar[a] = xe;
+      q.vt[a] = gvn[3 * p + a] + K.dt * xe;
     }
     M3 Fp = m3_load(F + 9 * p), gFp = m3_load(gFn + 9 * p), Cn = m3_load(Cnext + 9 * p), gCp = m3_load(gCn + 9 * p);
     M3 T = Cn;
 #pragma unroll
     for (int i = 0; i < 9; ++i) T.m[i] *= K.dt;
     T.m[0] += 1.f; T.m[4] += 1.f; T.m[8] += 1.f;
-    Fbar = m3_mul_tn(T, gFp);           // (I + dt C')^T Fbar'
-    M3 FF = m3_mul_nt(gFp, Fp);         // Fbar' F^T
+    q.Fbar = m3_mul_tn(T, gFp);           // (I + dt C')^T Fbar'
+    M3 FF = m3_mul_nt(gFp, Fp);           // Fbar' F^T
 #pragma unroll
-    for (int i = 0; i < 9; ++i) Ct.m[i] = gCp.m[i] + K.dt * FF.m[i];
+    for (int i = 0; i < 9; ++i) q.Ct.m[i] = gCp.m[i] + K.dt * FF.m[i];
   } else {
-    st.b[0] = st.b[1] = st.b[2] = 0;
-  }
-  TileGeom g = tile_setup(active, st.b, s_mm, s_tile);
-  if (!g.any) {
-    if (p < n) {
+    q.st.b[0] = q.st.b[1] = q.st.b[2] = 0;
 #pragma unroll
-      for (int a = 0; a < 3; ++a) gx[3 * p + a] = 0.f;
-      m3_store(gF + 9 * p, m3_zero());
+    for (int a = 0; a < 3; ++a) {
+      q.st.f[a] = 0.f;
+      q.st.w[a][0] = q.st.w[a][1] = q.st.w[a][2] = 0.f;
+      q.st.dw[a][0] = q.st.dw[a][1] = q.st.dw[a][2] = 0.f;
     }
-    return;
   }
-  if (active) {
-    const float kap = 4.0f * K.inv_dx * K.inv_dx;
+  return active;
+}
+
+__global__ void __launch_bounds__(64) k_g2p_bwd(MpmK K, int n, const float* __restrict__ clip, const int* __restrict__ enabled,
+                                                const float* __restrict__ x, const float* __restrict__ F,
+                                                const float* __restrict__ vnext, const float* __restrict__ Cnext,
+                                                const float* __restrict__ gxn, const float* __restrict__ gvn,
+                                                const float* __restrict__ gCn, const float* __restrict__ gFn,
+                                                const float4* __restrict__ gv, float4* __restrict__ gg,
+                                                float* __restrict__ gx, float* __restrict__ gF) {
+  __shared__ float4 s_tile[NM_WT_CAP];
+  __shared__ int s_own[NM_WT_CAP];
+  const float kap = 4.0f * K.inv_dx * K.inv_dx;
+  // (1) per-particle outputs: gF and gx (direct + through weights/dpos, gathering the forward grid velocity)
 #pragma unroll 1
-    for (int i = 0; i < 3; ++i) {
-      float d0 = ((float)i - st.f[0]) * K.dx;
-      const float w0i = sel3(st.w[0], i), dw0i = sel3(st.dw[0], i);
+  for (int b = 0; b < NM_WT_PB; ++b) {
+    const int p = (blockIdx.x * 64 + threadIdx.x) * NM_WT_PB + b;
+    G2pBwdP q;
+    const bool active = g2p_bwd_particle(K, n, p, clip, enabled, x, F, vnext, Cnext, gxn, gvn, gCn, gFn, q);
+    if (active) {
+#pragma unroll 1
+      for (int i = 0; i < 3; ++i) {
+        float d0 = ((float)i - q.st.f[0]) * K.dx;
+        const float w0i = sel3(q.st.w[0], i), dw0i = sel3(q.st.dw[0], i);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        float d1 = ((float)j - st.f[1]) * K.dx;
+        for (int j = 0; j < 3; ++j) {
+          float d1 = ((float)j - q.st.f[1]) * K.dx;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          float d2 = ((float)k - st.f[2]) * K.dx;
-          float w = w0i * st.w[1][j] * st.w[2][k];
-          float4 gn = gv[node_addr(st.b[0] + i, st.b[1] + j, st.b[2] + k, K.nb)];
-          // Ct dpos
-          float c0 = Ct.m[0] * d0 + Ct.m[1] * d1 + Ct.m[2] * d2;
-          float c1 = Ct.m[3] * d0 + Ct.m[4] * d1 + Ct.m[5] * d2;
-          float c2 = Ct.m[6] * d0 + Ct.m[7] * d1 + Ct.m[8] * d2;
-          float kw = kap * w;
-          scatter_node<3>(g, s_tile, gg, K.nb, st.b[0] + i, st.b[1] + j, st.b[2] + k,
-                          w * vt[0] + kw * c0, w * vt[1] + kw * c1, w * vt[2] + kw * c2, 0.f);
-          float dLdw = vt[0] * gn.x + vt[1] * gn.y + vt[2] * gn.z + kap * (gn.x * c0 + gn.y * c1 + gn.z * c2);
-          float gw0 = dw0i * st.w[1][j] * st.w[2][k] * K.inv_dx;
-          float gw1 = w0i * st.dw[1][j] * st.w[2][k] * K.inv_dx;
-          float gw2 = w0i * st.w[1][j] * st.dw[2][k] * K.inv_dx;
-          // Ct^T v_i
-          float t0 = Ct.m[0] * gn.x + Ct.m[3] * gn.y + Ct.m[6] * gn.z;
-          float t1 = Ct.m[1] * gn.x + Ct.m[4] * gn.y + Ct.m[7] * gn.z;
-          float t2 = Ct.m[2] * gn.x + Ct.m[5] * gn.y + Ct.m[8] * gn.z;
-          xbar[0] += dLdw * gw0 - kw * t0;
-          xbar[1] += dLdw * gw1 - kw * t1;
-          xbar[2] += dLdw * gw2 - kw * t2;
+          for (int k = 0; k < 3; ++k) {
+            float d2 = ((float)k - q.st.f[2]) * K.dx;
+            float w = w0i * q.st.w[1][j] * q.st.w[2][k];
+            float4 gn = gv[node_addr(q.st.b[0] + i, q.st.b[1] + j, q.st.b[2] + k, K.nb)];
+            const M3& Ct = q.Ct;
+            float c0_ = Ct.m[0] * d0 + Ct.m[1] * d1 + Ct.m[2] * d2;
+            float c1_ = Ct.m[3] * d0 + Ct.m[4] * d1 + Ct.m[5] * d2;
+            float c2_ = Ct.m[6] * d0 + Ct.m[7] * d1 + Ct.m[8] * d2;
+            float kw = kap * w;
+            float dLdw = q.vt[0] * gn.x + q.vt[1] * gn.y + q.vt[2] * gn.z + kap * (gn.x * c0_ + gn.y * c1_ + gn.z * c2_);
+            float gw0 = dw0i * q.st.w[1][j] * q.st.w[2][k] * K.inv_dx;
+            float gw1 = w0i * q.st.dw[1][j] * q.st.w[2][k] * K.inv_dx;
+            float gw2 = w0i * q.st.w[1][j] * q.st.dw[2][k] * K.inv_dx;
+            float t0 = Ct.m[0] * gn.x + Ct.m[3] * gn.y + Ct.m[6] * gn.z;
+            float t1 = Ct.m[1] * gn.x + Ct.m[4] * gn.y + Ct.m[7] * gn.z;
+            float t2 = Ct.m[2] * gn.x + Ct.m[5] * gn.y + Ct.m[8] * gn.z;
+            q.xbar[0] += dLdw * gw0 - kw * t0;
+            q.xbar[1] += dLdw * gw1 - kw * t1;
+            q.xbar[2] += dLdw * gw2 - kw * t2;
+          }
         }
       }
     }
-  }
-  if (p < n) {
+    if (p < n) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a) gx[3 * p + a] = xbar[a];
-    m3_store(gF + 9 * p, Fbar);
+      for (int a = 0; a < 3; ++a) gx[3 * p + a] = q.xbar[a];
+      m3_store(gF + 9 * p, q.Fbar);
+    }
   }
-  tile_flush<3>(g, s_tile, gg, K.nb, nullptr, nullptr, nullptr, 0);
+  // (2) scatter of the node-velocity adjoint
+  auto prep = [&](int p, Stencil& st, G2pBwdP& q) {
+    g2p_bwd_particle(K, n, p, clip, enabled, x, F, vnext, Cnext, gxn, gvn, gCn, gFn, q);
+    st = q.st;
+  };
+  auto contrib = [&](const Stencil& st, const G2pBwdP& q, int i, int j, int k) -> float4 {
+    float d0 = ((float)i - st.f[0]) * K.dx, d1 = ((float)j - st.f[1]) * K.dx, d2 = ((float)k - st.f[2]) * K.dx;
+    float w = st.w[0][i] * st.w[1][j] * st.w[2][k];
+    float kw = kap * w;
+    float c0_ = q.Ct.m[0] * d0 + q.Ct.m[1] * d1 + q.Ct.m[2] * d2;
+    float c1_ = q.Ct.m[3] * d0 + q.Ct.m[4] * d1 + q.Ct.m[5] * d2;
+    float c2_ = q.Ct.m[6] * d0 + q.Ct.m[7] * d1 + q.Ct.m[8] * d2;
+    return make_float4(w * q.vt[0] + kw * c0_, w * q.vt[1] + kw * c1_, w * q.vt[2] + kw * c2_, 0.f);
+  };
+  wave_scatter<3, G2pBwdP>(K, n, enabled, x, gg, nullptr, nullptr, nullptr, 0, s_tile, s_own, prep, contrib);
 }
 
 // adjoint of p2g: gathers {mvbar, mbar}; writes gv, gC, gS and adds to gx
@@ -580,6 +763,9 @@ extern "C" int nm_mpm_create(const nm_mpm_cfg* cfg, nm_mpm** out) {
   for (int a = 0; a < 3; ++a) K.gdt[a] = cfg->gravity[a] * cfg->dt;
   K.bound = cfg->bound;
   K.bc = cfg->bc;
+  K.dbg = getenv("NM_DBG") ? atoi(getenv("NM_DBG")) : 0;
+  K.dbg_buf = nullptr;
+  if (K.dbg & 8) { NM_HIP_CHECK(hipMalloc(&K.dbg_buf, 4096 * 4 * sizeof(long long))); NM_HIP_CHECK(hipMemset(K.dbg_buf, 0, 4096 * 4 * sizeof(long long))); }
   h->nblocks = K.nb * K.nb * K.nb;
   size_t nodes = (size_t)h->nblocks * 64;
   h->gm = h->gv = h->gg = nullptr;
@@ -622,7 +808,7 @@ static int mpm_build_grid(nm_mpm* h, int n, const nm_statics* st, const nm_parti
                      h->count + now);
   NM_LAUNCH_CHECK();
   if (n > 0) {
-    NM_LAUNCH(k_p2g, dim3(nm_div_up(n, 256)), dim3(256), 0, s, h->k, n, st->vol, st->rho, st->enabled, cur->x,
+    NM_LAUNCH(k_p2g, dim3(nm_div_up(n, 64 * NM_WT_PB)), dim3(64), 0, s, h->k, n, st->vol, st->rho, st->enabled, cur->x,
                        cur->v, cur->C, cur->stress, h->gm, h->flags, h->list[now], h->count + now, h->epoch);
     NM_LAUNCH_CHECK();
   }
@@ -643,6 +829,7 @@ extern "C" int nm_mpm_forward(nm_mpm* h, int32_t n, const nm_statics* st, const 
                               void* stream) {
   NM_REQUIRE(h, "null handle");
   NM_REQUIRE(n >= 0, "negative particle count");
+  if (n == 0) return NM_OK;  // empty input: nothing to scatter or gather
   int rc = check_particles(st, cur, true);
   if (rc) return rc;
   rc = check_particles(st, next, false);
@@ -662,9 +849,10 @@ extern "C" int nm_mpm_forward_extra(nm_mpm* h, int32_t n, const nm_statics* st, 
                                     const nm_statics* st_extra, nm_particles* extra, void* stream) {
   NM_REQUIRE(h, "null handle");
   NM_REQUIRE(n >= 0 && n_extra >= 0, "negative particle count");
-  int rc = check_particles(st, cur, true);
+  int rc = NM_OK;
+  if (n > 0) rc = check_particles(st, cur, true);
   if (rc) return rc;
-  rc = check_particles(st_extra, extra, false);
+  if (n_extra > 0) rc = check_particles(st_extra, extra, false);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   rc = mpm_build_grid(h, n, st, cur, s);
@@ -682,6 +870,7 @@ extern "C" int nm_mpm_backward(nm_mpm* h, int32_t n, const nm_statics* st, const
                                const nm_particles* next, const nm_particles* gnext, nm_particles* gcur, void* stream) {
   NM_REQUIRE(h, "null handle");
   NM_REQUIRE(n >= 0, "negative particle count");
+  if (n == 0) return NM_OK;
   int rc = check_particles(st, cur, true);
   if (rc) return rc;
   NM_REQUIRE(next && next->v && next->C, "next state (v, C) required");
@@ -693,7 +882,7 @@ extern "C" int nm_mpm_backward(nm_mpm* h, int32_t n, const nm_statics* st, const
   if (n == 0) return NM_OK;
   const int now = h->cur;
   const int nwg = nm_div_up(n, 256);
-  NM_LAUNCH(k_g2p_bwd, dim3(nwg), dim3(256), 0, s, h->k, n, st->clip_bound, st->enabled, cur->x, cur->F, next->v,
+  NM_LAUNCH(k_g2p_bwd, dim3(nm_div_up(n, 64 * NM_WT_PB)), dim3(64), 0, s, h->k, n, st->clip_bound, st->enabled, cur->x, cur->F, next->v,
                      next->C, gnext->x, gnext->v, gnext->C, gnext->F, h->gv, h->gg, gcur->x, gcur->F);
   NM_LAUNCH_CHECK();
   NM_LAUNCH(k_grid_op_bwd, dim3(kSweepGrid), dim3(256), 0, s, h->k, h->gm, h->gg, h->list[now], h->count + now);
@@ -716,6 +905,13 @@ extern "C" int nm_mpm_grid_stats(nm_mpm* h, int32_t* active_blocks, int32_t* nod
   NM_HIP_CHECK(hipStreamSynchronize(s));
   if (active_blocks) *active_blocks = host[0];
   if (nodes_with_mass) *nodes_with_mass = host[1];
+  return NM_OK;
+}
+
+extern "C" int nm_mpm_debug_fetch(nm_mpm* h, long long* host, int n) {
+  if (!h->k.dbg_buf) return NM_ERR_INVALID;
+  NM_HIP_CHECK(hipDeviceSynchronize());
+  NM_HIP_CHECK(hipMemcpy(host, h->k.dbg_buf, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost));
   return NM_OK;
 }
 

@@ -129,6 +129,39 @@ __device__ __forceinline__ void get_rect(const RK& k, float px, float py, int r,
   y1 = min(yhi, max(ylo, (int)((py + r + NM_TILE - 1) / NM_TILE)));
 }
 
+
+// Largest exponent `power` any pixel of the 16x16 tile (tx,ty) can see from a Gaussian at (mx,my) with conic
+// (ca, cb, cc):  power = -0.5 q,  q(d) = ca dx^2 + 2 cb dx dy + cc dy^2 minimised over the tile's pixel rectangle
+// (a convex quadratic over a box: zero if the centre is inside, else on one of the four edges).
+__device__ __forceinline__ float tile_max_power(float mx, float my, float ca, float cb, float cc, int tx, int ty) {
+  const float x0 = (float)(tx * NM_TILE), x1 = x0 + (float)(NM_TILE - 1);
+  const float y0 = (float)(ty * NM_TILE), y1 = y0 + (float)(NM_TILE - 1);
+  if (mx >= x0 && mx <= x1 && my >= y0 && my <= y1) return 0.f;
+  float qmin = 3.0e38f;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {  // vertical edges x = x0 / x1: minimise over y
+    float dx = (e ? x1 : x0) - mx;
+    float y = fminf(fmaxf(my - cb * dx / cc, y0), y1);
+    float dy = y - my;
+    qmin = fminf(qmin, ca * dx * dx + 2.f * cb * dx * dy + cc * dy * dy);
+  }
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {  // horizontal edges y = y0 / y1: minimise over x
+    float dy = (e ? y1 : y0) - my;
+    float x = fminf(fmaxf(mx - cb * dy / ca, x0), x1);
+    float dx = x - mx;
+    qmin = fminf(qmin, ca * dx * dx + 2.f * cb * dx * dy + cc * dy * dy);
+  }
+  return -0.5f * qmin;
+}
+// A (Gaussian, tile) pair is kept iff some pixel of the tile can reach alpha >= 1/255 (the compositing kernels skip
+// anything below, so dropping the pair leaves every pixel bit-identical).  0.01 of slack in the exponent keeps the
+// test conservative against fp32 rounding of the per-pixel evaluation.
+__device__ __forceinline__ bool tile_contributes(float mx, float my, const float4& co, int tx, int ty) {
+  float thresh = -__logf(255.f * co.w) - 0.01f;
+  return !(tile_max_power(mx, my, co.x, co.y, co.z, tx, ty) < thresh);
+}
+
 #define SH_C0 0.28209479177387814f
 #define SH_C1 0.4886025119029199f
 __constant__ float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
@@ -240,22 +273,31 @@ __global__ void __launch_bounds__(256) k_preprocess(RK k, int K, const float* __
   conop[i] = make_float4(cv.c * det_inv, -cv.b * det_inv, cv.a * det_inv, opac[i]);
   rgb[3 * i] = col[0]; rgb[3 * i + 1] = col[1]; rgb[3 * i + 2] = col[2];
   clamped[i] = cl;
-  tiles[i] = (uint32_t)(max(0, sx1 - sx0) * max(0, sy1 - sy0));
+  {
+    const float4 co = make_float4(cv.c * det_inv, -cv.b * det_inv, cv.a * det_inv, opac[i]);
+    uint32_t cnt = 0;
+    for (int y = sy0; y < sy1; ++y)
+      for (int x = sx0; x < sx1; ++x) cnt += tile_contributes(px, py, co, x, y) ? 1u : 0u;
+    tiles[i] = cnt;
+  }
 }
 
 __global__ void __launch_bounds__(256) k_emit_keys(RK k, int K, const int* __restrict__ radii, const float2* __restrict__ xy,
-                                                   const float* __restrict__ depth, const uint32_t* __restrict__ offs,
-                                                   const uint32_t* __restrict__ tiles, uint64_t* __restrict__ keys,
-                                                   uint32_t* __restrict__ vals) {
+                                                   const float* __restrict__ depth, const float4* __restrict__ conop,
+                                                   const uint32_t* __restrict__ offs, const uint32_t* __restrict__ tiles,
+                                                   uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= K || tiles[i] == 0) return;
   uint32_t off = (i == 0) ? 0u : offs[i - 1];
+  const uint32_t end = offs[i];
   float2 p = xy[i];
+  const float4 co = conop[i];
   int x0, y0, x1, y1;
   get_rect(k, p.x, p.y, radii[i], x0, y0, x1, y1, k.ty0, k.ty1);
   uint64_t dbits = (uint64_t)__float_as_uint(depth[i]);
   for (int y = y0; y < y1; ++y)
     for (int x = x0; x < x1; ++x) {
+      if (!tile_contributes(p.x, p.y, co, x, y) || off >= end) continue;  // same predicate as the count in k_preprocess
       keys[off] = ((uint64_t)(uint32_t)(y * k.gx + x) << 32) | dbits;
       vals[off] = (uint32_t)i;
       ++off;
@@ -333,23 +375,48 @@ __global__ void __launch_bounds__(NM_TPB) k_render(RK k, const uint2* __restrict
 
 // ---------------------------------------------------------------- backward kernels
 template <int CTRL>
-__device__ __forceinline__ float dpp_add(float x) {
-  int y = __builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true);
-  return x + __int_as_float(y);
+__device__ __forceinline__ float dpp_mov(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
 }
-// sum over the 64 lanes using DPP inside each row of 16 and four readlanes across rows (wave-uniform result)
+// Sum 8 per-lane values over the 64 lanes of a wave with a folding butterfly: every step halves the number of
+// live values per lane (lanes split on one index bit keep one half and hand the other half to their partner), so
+// the whole reduction costs 4+2+1 DPP exchanges inside a row plus 3 single-value steps instead of 8 full
+// reductions.  On return lane l (l < 8) holds the wave total of value  4*(l&1) + 2*((l>>1)&1) + ((l>>2)&1).
+__device__ __forceinline__ float wave_fold8(const float* v, int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+  float a[4], c[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float keep = b0 ? v[i + 4] : v[i], send = b0 ? v[i] : v[i + 4];
+    a[i] = keep + dpp_mov<0xB1>(send);   // quad_perm [1,0,3,2]: lane ^ 1
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float keep = b1 ? a[i + 2] : a[i], send = b1 ? a[i] : a[i + 2];
+    c[i] = keep + dpp_mov<0x4E>(send);   // quad_perm [2,3,0,1]: lane ^ 2
+  }
+  float keep = b2 ? c[1] : c[0], send = b2 ? c[0] : c[1];
+  float d = keep + dpp_mov<0x124>(send);  // row_ror:4 — partner has bit 2 flipped, bits 0,1 equal
+  d += dpp_mov<0x128>(d);                 // row_ror:8 == lane ^ 8 within the row of 16
+  d += __shfl_xor(d, 16, 64);
+  d += __shfl_xor(d, 32, 64);
+  return d;
+}
 __device__ __forceinline__ float wave_sum_dpp(float x) {
-  x = dpp_add<0xB1>(x);   // quad_perm [1,0,3,2]
-  x = dpp_add<0x4E>(x);   // quad_perm [2,3,0,1]
-  x = dpp_add<0x141>(x);  // row_half_mirror
-  x = dpp_add<0x140>(x);  // row_mirror
-  int xi = __float_as_int(x);
-  return __int_as_float(__builtin_amdgcn_readlane(xi, 0)) + __int_as_float(__builtin_amdgcn_readlane(xi, 16)) +
-         __int_as_float(__builtin_amdgcn_readlane(xi, 32)) + __int_as_float(__builtin_amdgcn_readlane(xi, 48));
+  x += dpp_mov<0xB1>(x);
+  x += dpp_mov<0x4E>(x);
+  x += dpp_mov<0x141>(x);  // row_half_mirror
+  x += dpp_mov<0x140>(x);  // row_mirror
+  x += __shfl_xor(x, 16, 64);
+  x += __shfl_xor(x, 32, 64);
+  return x;
 }
 
-#define NM_NG 9  // reduced per-Gaussian quantities: mean2D(2) conic(3) opacity(1) colour(3)
+#define NM_NG 9  // per-Gaussian reduced quantities: ndc-mean(2) conic(3) colour(3) | opacity(1)
+// slot order inside an accumulator row: [0..7] = values of wave_fold8 order, [8] = opacity
+//   v[0]=d/dndc.x v[1]=d/dndc.y v[2]=d/dconic.x v[3]=d/dconic.y v[4]=d/dconic.z v[5..7]=d/drgb
 
+template <bool WITH_OPACITY>
 __global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, const uint2* __restrict__ ranges, const uint32_t* __restrict__ plist,
                                                        const float2* __restrict__ xy, const float* __restrict__ rgb,
                                                        const float4* __restrict__ conop, const float* __restrict__ final_T,
@@ -359,9 +426,9 @@ __global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, const uint2* __rest
   __shared__ float2 s_xy[NM_TPB];
   __shared__ float4 s_co[NM_TPB];
   __shared__ float s_rgb[NM_TPB * 3];
-  __shared__ float s_acc[NM_TPB * NM_NG];
+  __shared__ float s_acc[4][NM_TPB * NM_NG];   // one private table per wave: plain stores, no LDS atomics
   const int tile_x = blockIdx.x, tile_y = blockIdx.y + k.ty0;
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = tile_x * NM_TILE + (tid & 15), py = tile_y * NM_TILE + (tid >> 4);
   const bool inside = px < k.W && py < k.H;
   const float fxp = (float)px, fyp = (float)py;
@@ -378,7 +445,10 @@ __global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, const uint2* __rest
   const float bg_dot = k.bg[0] * dp0 + k.bg[1] * dp1 + k.bg[2] * dp2;
   float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
   const float ddelx_dx = 0.5f * k.W, ddely_dy = 0.5f * k.H;
-  for (int i = tid; i < NM_TPB * NM_NG; i += NM_TPB) s_acc[i] = 0.f;
+  float* my_acc = s_acc[wave];
+  // lane l < 8 owns fold slot value index:
+  const int slot = 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1);
+  for (int i = lane; i < NM_TPB * NM_NG; i += 64) my_acc[i] = 0.f;
   for (int rd = 0; rd < rounds; ++rd, todo -= NM_TPB) {
     __syncthreads();
     int prog = rd * NM_TPB + tid;
@@ -402,9 +472,9 @@ __global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, const uint2* __rest
       float alpha = fminf(0.99f, co.w * G);
       act = act && !(power > 0.f) && !(alpha < 1.0f / 255.0f);
       if (__ballot(act) == 0ull) continue;  // whole wave skips this Gaussian
-      float g[NM_NG];
+      float g[8], gop = 0.f;
 #pragma unroll
-      for (int q = 0; q < NM_NG; ++q) g[q] = 0.f;
+      for (int q = 0; q < 8; ++q) g[q] = 0.f;
       if (act) {
         T = T / (1.f - alpha);
         float dch = alpha * T;
@@ -413,7 +483,7 @@ __global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, const uint2* __rest
         ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = c1;
         ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = c2;
         float dL_dalpha = (c0 - ar0) * dp0 + (c1 - ar1) * dp1 + (c2 - ar2) * dp2;
-        g[6] = dch * dp0; g[7] = dch * dp1; g[8] = dch * dp2;
+        g[5] = dch * dp0; g[6] = dch * dp1; g[7] = dch * dp2;
         dL_dalpha *= T;
         last_alpha = alpha;
         dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
@@ -426,27 +496,29 @@ __global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, const uint2* __rest
         g[2] = -0.5f * gdx * dx * dL_dG;       // d/d conic.x
         g[3] = -gdx * dy * dL_dG;              // d/d conic.y (full off-diagonal derivative)
         g[4] = -0.5f * gdy * dy * dL_dG;       // d/d conic.z
-        g[5] = G * dL_dalpha;                  // d/d opacity
+        gop = G * dL_dalpha;                   // d/d opacity
       }
-#pragma unroll
-      for (int q = 0; q < NM_NG; ++q) g[q] = wave_sum_dpp(g[q]);
-      if (lane == 0) {
-#pragma unroll
-        for (int q = 0; q < NM_NG; ++q) unsafeAtomicAdd(&s_acc[j * NM_NG + q], g[q]);
+      float tot = wave_fold8(g, lane);
+      if (lane < 8) my_acc[j * NM_NG + slot] += tot;
+      if (WITH_OPACITY) {
+        float to = wave_sum_dpp(gop);
+        if (lane == 0) my_acc[j * NM_NG + 8] += to;
       }
     }
     __syncthreads();
-    // one global atomic set per (tile, Gaussian)
+    // one global atomic set per (tile, Gaussian): sum the four wave tables
     if (tid < nb) {
       uint32_t id = s_id[tid];
       float* dst = acc + (size_t)id * NM_NG;
 #pragma unroll
-      for (int q = 0; q < NM_NG; ++q) {
-        float v = s_acc[tid * NM_NG + q];
+      for (int q = 0; q < (WITH_OPACITY ? NM_NG : 8); ++q) {
+        int o = tid * NM_NG + q;
+        float v = (s_acc[0][o] + s_acc[1][o]) + (s_acc[2][o] + s_acc[3][o]);
         if (v != 0.f) unsafeAtomicAdd(dst + q, v);
-        s_acc[tid * NM_NG + q] = 0.f;
       }
     }
+    __syncthreads();
+    for (int i = lane; i < nb * NM_NG; i += 64) my_acc[i] = 0.f;
   }
 }
 
@@ -467,7 +539,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(RK k, int K, const float
   if (vis) {
     float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
     // ---- colour -> SH / view direction
-    float dRGB[3] = {a[6], a[7], a[8]};
+    float dRGB[3] = {a[5], a[6], a[7]};
     if (has_sh) {
       uint32_t cl = clamped[i];
       float dx = mx - k.cam[0], dy = my - k.cam[1], dz = mz - k.cam[2];
@@ -594,7 +666,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(RK k, int K, const float
 #pragma unroll
     for (int q = 0; q < 6; ++q) dcov[6 * i + q] = gc[q];
   }
-  if (dopac) dopac[i] = vis ? a[5] : 0.f;
+  if (dopac) dopac[i] = vis ? a[8] : 0.f;
 }
 
 // ---------------------------------------------------------------- host API
@@ -644,7 +716,7 @@ extern "C" int nm_raster_render(const nm_raster_cfg* cfg, int32_t K, int64_t D, 
     Scratch sc = carve_scratch(scratch, D);
     if (scratch_bytes < sc.total) { nm_set_error("scratch buffer too small: need %zu got %zu", sc.total, scratch_bytes); return NM_ERR_WORKSPACE; }
     NM_LAUNCH(k_emit_keys, dim3(nm_div_up(K, 256)), dim3(256), 0, s, k, K, (const int*)g.rad, g.xy,
-                       g.depth, g.offs, g.tiles, sc.keys_in, sc.vals_in);
+                       g.depth, g.conop, g.offs, g.tiles, sc.keys_in, sc.vals_in);
     NM_LAUNCH_CHECK();
     int bits = 0;
     while ((1 << bits) < k.gx * k.gy) ++bits;
@@ -682,8 +754,12 @@ extern "C" int nm_raster_backward(const nm_raster_cfg* cfg, int32_t K, int32_t m
   float* acc = (float*)workspace;
   NM_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)K * NM_NG * sizeof(float), s));
   if (D > 0) {
-    NM_LAUNCH(k_render_bwd, dim3(k.gx, k.ty1 - k.ty0), dim3(NM_TPB), 0, s, k, b.ranges, b.point_list, g.xy, g.rgb, g.conop,
-                       im.final_T, im.n_contrib, dL_dcolor, acc);
+    if (dL_dopacity)
+      NM_LAUNCH(k_render_bwd<true>, dim3(k.gx, k.ty1 - k.ty0), dim3(NM_TPB), 0, s, k, b.ranges, b.point_list, g.xy, g.rgb, g.conop,
+                im.final_T, im.n_contrib, dL_dcolor, acc);
+    else
+      NM_LAUNCH(k_render_bwd<false>, dim3(k.gx, k.ty1 - k.ty0), dim3(NM_TPB), 0, s, k, b.ranges, b.point_list, g.xy, g.rgb, g.conop,
+                im.final_T, im.n_contrib, dL_dcolor, acc);
     NM_LAUNCH_CHECK();
   }
   NM_LAUNCH(k_preprocess_bwd, dim3(nm_div_up(K, 256)), dim3(256), 0, s, k, K, means3D, shs, cov3D, (const int*)g.tiles,

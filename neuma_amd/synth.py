@@ -20,10 +20,20 @@ CONFIGS = {
 }
 
 
+def stencil_order(P: np.ndarray, G: int) -> np.ndarray:
+    """Permutation that sorts particles by the origin of their 3x3x3 stencil, base = int(x*G - 0.5) (mpm.py:336-339),
+    grouped in 4x4x4 blocks of base cells.  Particles sharing a base touch the same 27 nodes, so the scatter kernels
+    can pre-add them in registers; consecutive lanes then work on neighbouring nodes.  Any order gives the same
+    results — this one is the fast one (a load-time sort like the reference's `sort` option, mpm.py:640-642)."""
+    base = np.trunc(P.astype(np.float64) * G - 0.5).astype(np.int64)
+    blk = base // 4
+    key = ((blk[:, 0] * 4096 + blk[:, 1]) * 4096 + blk[:, 2]) * 64 + ((base[:, 0] % 4) * 16 + (base[:, 1] % 4) * 4 + base[:, 2] % 4)
+    return np.argsort(key, kind="stable")
+
+
 def ball_particles(N: int, G: int, centers=((0.5, 0.5, 0.5),), seed: int = 0):
     """Jittered lattice at spacing dx/2 (8 particles per cell), the N/len(centers) lattice points nearest each
-    centre, jitter U(-dx/8, dx/8).  Returned in 4x4x4-cell block-major order (spatially coherent: consecutive
-    particles share grid blocks, which is what the LDS-tile scatters like; any order gives the same results)."""
+    centre, jitter U(-dx/8, dx/8).  Returned in stencil order (see stencil_order)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     dx = 1.0 / G
     h = dx / 2
@@ -40,10 +50,7 @@ def ball_particles(N: int, G: int, centers=((0.5, 0.5, 0.5),), seed: int = 0):
         P = P + rng.uniform(-dx / 8, dx / 8, size=P.shape)
         out.append(P)
     P = np.concatenate(out, 0)
-    cell = np.floor(P * G).astype(np.int64)
-    blk = cell // 4
-    key = ((blk[:, 0] * 4096 + blk[:, 1]) * 4096 + blk[:, 2]) * 64 + ((cell[:, 0] % 4) * 16 + (cell[:, 1] % 4) * 4 + cell[:, 2] % 4)
-    P = P[np.argsort(key, kind="stable")]
+    P = P[stencil_order(P, G)]
     assert P.min() > 0.05 and P.max() < 0.95
     return P.astype(np.float32)
 

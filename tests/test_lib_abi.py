@@ -31,6 +31,19 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert not extra, f"ctypes table has undeclared {extra}"
 
 
+def test_ctypes_arity_matches_header_prototypes():
+    from neuma_amd import _lib
+    text = (ROOT / "include" / "neuma_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    seen = 0
+    for m in re.finditer(r"\b(nm_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        name, args = m.group(1), m.group(2).strip()
+        n = 0 if args in ("void", "") else len(args.split(","))
+        assert len(_lib.SIGNATURES[name][1]) == n, f"{name}: header has {n} parameters, ctypes table {len(_lib.SIGNATURES[name][1])}"
+        seen += 1
+    assert seen >= 25
+
+
 def test_host_only_entry_points():
     from neuma_amd import _lib
     lib = _lib.lib()
