@@ -178,7 +178,7 @@ def main():
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
         try:
-            from oracle import cbaseline
+            from oracle import cpu_baseline as cbaseline
             cpu = cbaseline.time_frame_sample(scene, rt)
         except Exception as e:
             print(f"[bench] cpu baseline unavailable: {e}", file=sys.stderr)

@@ -167,32 +167,72 @@ __device__ __forceinline__ void tile_flush(const TileGeom& g, const float4* s_ti
   }
 }
 
-// Scatter of one chunk (64 lanes x PB consecutive particles each) into `grid`.
-//   prep(p, st, q)            loads particle p: stencil + payload
-//   contrib(st, q, i, j, k)   its contribution to stencil node (i,j,k)
-// A lane first sums, in registers, the contributions of all of its particles that share a base cell (cell-sorted
-// input: usually all PB of them), then lanes elect one owner per base cell through an LDS ticket and the owners
-// add their 27 float4 sums to the tile with plain ds_read_b128 / ds_write_b128; losers retry.  Chunks whose
-// bounding box exceeds the tile are processed box by box; leftovers use global atomics.
-template <int NCH, class P, class PrepF, class ContribF>
+#define NM_WT_CHUNK (64 * NM_WT_PB)
+#define NM_WT_REC 16  // floats per staged particle record: x(3) + payload(13)
+
+struct ScatterLds {
+  float4 tile[NM_WT_CAP];
+  int cnt[NM_WT_CAP];                 // particles per stencil origin (tile-local cell), then exclusive offsets
+  float rec[NM_WT_CHUNK * NM_WT_REC];
+  int key[NM_WT_CHUNK];               // global origin key per staged particle (-1: disabled / not staged)
+  short rank[NM_WT_CHUNK];            // arrival order inside its cell
+  short order[NM_WT_CHUNK];           // particle slots sorted by cell
+  short run_cell[NM_WT_CAP];          // compacted list of non-empty cells
+};
+
+__device__ __forceinline__ int wave_excl_scan_i(int v, int lane, int& total) {
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  total = __shfl(x, 63, 64);
+  return x - v;
+}
+
+// Scatter of one chunk of NM_WT_CHUNK consecutive particles into `grid` by one wave.
+//   stage(p, rec)              loads particle p and writes x(3) + payload(13) to rec[16]      (coalesced phase)
+//   contrib(st, rec, i, j, k)  contribution of a staged particle to its stencil node (i,j,k)
+// A: every particle is staged once (coalesced global loads, all in flight together).
+// B: the chunk is counting-sorted in LDS by stencil origin (tile-local cell): integer LDS atomics give each
+//    particle its rank inside its cell, a wave scan gives the cell offsets.  So whatever order the caller keeps
+//    its particles in (sorted at load time, gone stale since), every non-empty cell becomes exactly one run.
+// C: lane r sums the 27 float4 contributions of run r in registers and adds them to the tile with plain
+//    ds_read_b128 / ds_write_b128 — two lanes never share a cell, and for a fixed stencil offset distinct cells
+//    hit distinct nodes, so no atomics and no retries are needed.
+// D: the tile is flushed with one global atomic set per touched node.
+// Chunks whose bounding box exceeds the tile are processed box by box (anchored at the first pending particle);
+// after NM_WT_MAXPASS boxes the leftovers use per-particle global atomics.
+template <int NCH, class StageF, class ContribF>
 __device__ __forceinline__ void wave_scatter(const MpmK& K, int n, const int* __restrict__ enabled, const float* __restrict__ x,
                                              float4* __restrict__ grid, int* flags, int* list, int* count, int epoch,
-                                             float4* s_tile, int* s_own, PrepF prep, ContribF contrib) {
+                                             ScatterLds& L, StageF stage, ContribF contrib) {
   const int lane = threadIdx.x;
-  const int p0 = (blockIdx.x * 64 + lane) * NM_WT_PB;
-  // which of my particles are enabled, and the chunk bounding box in base-cell coordinates
-  unsigned todo = 0u;
+  const int c0 = blockIdx.x * NM_WT_CHUNK;
+  const int GG = K.Gp * K.Gp;
+  long long tm[6] = {0, 0, 0, 0, 0, 0};
+  long long t0 = K.dbg_buf ? clock64() : 0;
+#define NM_TICK(i) if (K.dbg_buf) { long long t1 = clock64(); tm[i] += t1 - t0; t0 = t1; }
+  // ---- A: stage records + origin keys; bounding box of the origins
   int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-0x7fffffff, -0x7fffffff, -0x7fffffff};
 #pragma unroll
-  for (int b = 0; b < NM_WT_PB; ++b) {
-    const int p = p0 + b;
+  for (int it = 0; it < NM_WT_PB; ++it) {
+    const int t = it * 64 + lane, p = c0 + t;
+    int key = -1;
     if (p < n && enabled[p] != 0) {
-      todo |= 1u << b;
+      float rec[NM_WT_REC];
+      stage(p, rec);
       int bb[3];
-      base_cell(K, x + 3 * p, bb);
+      base_cell(K, rec, bb);
+      key = (bb[0] * K.Gp + bb[1]) * K.Gp + bb[2];
 #pragma unroll
       for (int a = 0; a < 3; ++a) { lo[a] = min(lo[a], bb[a]); hi[a] = max(hi[a], bb[a]); }
+      float4* dst = reinterpret_cast<float4*>(&L.rec[t * NM_WT_REC]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dst[q] = make_float4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
     }
+    L.key[t] = key;
   }
 #pragma unroll
   for (int a = 0; a < 3; ++a) { lo[a] = wave_min_i(lo[a]); hi[a] = wave_max_i(hi[a]); }
@@ -202,136 +242,166 @@ __device__ __forceinline__ void wave_scatter(const MpmK& K, int n, const int* __
   for (int a = 0; a < 3; ++a) { g.o[a] = lo[a]; g.n[a] = hi[a] - lo[a] + 3; }
   g.vol = g.n[0] * g.n[1] * g.n[2];
   const bool single = g.vol <= NM_WT_CAP;
-  g.use = true;
+  __builtin_amdgcn_wave_barrier();
+  NM_TICK(0)
 
-  int dbg_pass = 0, dbg_sweep = 0, dbg_round = 0;
   for (int pass = 0; pass <= NM_WT_MAXPASS; ++pass) {
-    const bool direct = !single && pass == NM_WT_MAXPASS;   // last resort: global atomics for what is left
-    if (!single && !direct) {                                // anchor a box at the first particle still pending
-      unsigned long long m = __ballot(todo != 0u);
-      if (m == 0ull) break;
-      int src = __ffsll((long long)m) - 1;
-      int bb[3] = {0, 0, 0};
-      if (todo) base_cell(K, x + 3 * (p0 + (__ffs(todo) - 1)), bb);
-      int anchor[3] = {__shfl(bb[0], src, 64), __shfl(bb[1], src, 64), __shfl(bb[2], src, 64)};
-      g = tile_box(K, anchor);
-    }
-    if (!direct) tile_zero(g, s_tile);
-    ++dbg_pass;
-    // particles of mine that belong to this pass
-    unsigned mine_now = 0u;
+    if (!single) {
+      if (pass == NM_WT_MAXPASS) {   // last resort: per-particle global atomics for what is still pending
+        for (int it = 0; it < NM_WT_PB; ++it) {
+          const int t = it * 64 + lane;
+          const int key = L.key[t];
+          if (key < 0) continue;
+          float rec[NM_WT_REC];
+          const float4* src = reinterpret_cast<const float4*>(&L.rec[t * NM_WT_REC]);
 #pragma unroll
-    for (int b = 0; b < NM_WT_PB; ++b) {
-      if (todo & (1u << b)) {
-        int bb[3];
-        base_cell(K, x + 3 * (p0 + b), bb);
-        if (direct || single || tile_holds(g, bb)) mine_now |= 1u << b;
-      }
-    }
-    todo &= ~mine_now;
-    while (__ballot(mine_now != 0u) != 0ull) {
-      const bool has = mine_now != 0u;
-      ++dbg_sweep;
-      Stencil st;
-      float4 acc[27];
-      if (has) {
-        const int b0 = __ffs(mine_now) - 1;
-        P q;
-        prep(p0 + b0, st, q);
-        mine_now &= ~(1u << b0);
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) acc[(i * 3 + j) * 3 + k] = contrib(st, q, i, j, k);
-        // fold in my other particles with the same base cell
-#pragma unroll 1
-        for (int b = b0 + 1; b < NM_WT_PB; ++b) {
-          if (!(mine_now & (1u << b))) continue;
-          int bb[3];
-          base_cell(K, x + 3 * (p0 + b), bb);
-          if (bb[0] != st.b[0] || bb[1] != st.b[1] || bb[2] != st.b[2]) continue;
-          Stencil st2;
-          P q2;
-          prep(p0 + b, st2, q2);
-          mine_now &= ~(1u << b);
+          for (int q = 0; q < 4; ++q) { float4 v4 = src[q]; rec[4 * q] = v4.x; rec[4 * q + 1] = v4.y; rec[4 * q + 2] = v4.z; rec[4 * q + 3] = v4.w; }
+          Stencil sp;
+          make_stencil(K, rec, sp);
 #pragma unroll
           for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = 0; j < 3; ++j)
 #pragma unroll
-              for (int k = 0; k < 3; ++k) {
-                float4 c = contrib(st2, q2, i, j, k);
-                float4& t = acc[(i * 3 + j) * 3 + k];
-                t.x += c.x; t.y += c.y; t.z += c.z; t.w += c.w;
-              }
-        }
-      } else {
-        st.b[0] = st.b[1] = st.b[2] = 0;
-      }
-      if (direct) {
-        if (has) {
-#pragma unroll
-          for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-#pragma unroll
-              for (int k = 0; k < 3; ++k) {
-                const float4 c = acc[(i * 3 + j) * 3 + k];
-                float* dst = (float*)&grid[node_addr(st.b[0] + i, st.b[1] + j, st.b[2] + k, K.nb)];
+              for (int kk = 0; kk < 3; ++kk) {
+                const float4 c = contrib(sp, rec, i, j, kk);
+                float* dst = (float*)&grid[node_addr(sp.b[0] + i, sp.b[1] + j, sp.b[2] + kk, K.nb)];
                 unsafeAtomicAdd(dst, c.x);
                 unsafeAtomicAdd(dst + 1, c.y);
                 unsafeAtomicAdd(dst + 2, c.z);
                 if (NCH == 4) unsafeAtomicAdd(dst + 3, c.w);
               }
           if (flags) {
-            for (int i = st.b[0] >> 2; i <= (st.b[0] + 2) >> 2; ++i)
-              for (int j = st.b[1] >> 2; j <= (st.b[1] + 2) >> 2; ++j)
-                for (int k = st.b[2] >> 2; k <= (st.b[2] + 2) >> 2; ++k)
-                  mark_block((i * K.nb + j) * K.nb + k, flags, list, count, epoch);
+            for (int i = sp.b[0] >> 2; i <= (sp.b[0] + 2) >> 2; ++i)
+              for (int j = sp.b[1] >> 2; j <= (sp.b[1] + 2) >> 2; ++j)
+                for (int kk = sp.b[2] >> 2; kk <= (sp.b[2] + 2) >> 2; ++kk)
+                  mark_block((i * K.nb + j) * K.nb + kk, flags, list, count, epoch);
           }
         }
-        continue;
+        break;
       }
-      // owner election per base cell, then plain LDS read-modify-write by the owners
-      const int ci = has ? ((st.b[0] - g.o[0]) * g.n[1] + (st.b[1] - g.o[1])) * g.n[2] + (st.b[2] - g.o[2]) : 0;
-      bool pending = has;
-      while (__ballot(pending) != 0ull) {
-        ++dbg_round;
-        if (pending) __hip_atomic_store(&s_own[ci], lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        __builtin_amdgcn_wave_barrier();
-        const bool won = pending && __hip_atomic_load(&s_own[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == lane;
-        if (won) {
+      // anchor a box at the first particle still pending
+      int first = 0x7fffffff;
+      for (int it = 0; it < NM_WT_PB; ++it)
+        if (L.key[it * 64 + lane] >= 0) { first = it * 64 + lane; break; }
+      first = wave_min_i(first);
+      if (first == 0x7fffffff) break;
+      const int key = L.key[first];
+      int anchor[3] = {key / GG, (key / K.Gp) % K.Gp, key % K.Gp};
+      g = tile_box(K, anchor);
+    }
+    // ---- B: counting sort of the pass's particles by tile-local cell
+    for (int i = lane; i < g.vol; i += 64) { L.tile[i] = make_float4(0.f, 0.f, 0.f, 0.f); L.cnt[i] = 0; }
+    __builtin_amdgcn_wave_barrier();
+    int myci[NM_WT_PB];
+#pragma unroll
+    for (int it = 0; it < NM_WT_PB; ++it) {
+      const int t = it * 64 + lane;
+      const int key = L.key[t];
+      myci[it] = -1;
+      if (key >= 0) {
+        int bb[3] = {key / GG, (key / K.Gp) % K.Gp, key % K.Gp};
+        if (single || tile_holds(g, bb)) {
+          const int ci = ((bb[0] - g.o[0]) * g.n[1] + (bb[1] - g.o[1])) * g.n[2] + (bb[2] - g.o[2]);
+          myci[it] = ci;
+          L.rank[t] = (short)atomicAdd(&L.cnt[ci], 1);
+          L.key[t] = -1;   // consumed by this pass
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // exclusive scan of cnt over the tile cells (each lane owns a contiguous slice) + list of non-empty cells
+    const int per = (g.vol + 63) >> 6;
+    int nruns, tot;
+    {
+      int sum = 0, nz = 0;
+      for (int i = 0; i < per; ++i) {
+        int c = lane * per + i;
+        if (c < g.vol) { int v = L.cnt[c]; sum += v; nz += v > 0; }
+      }
+      int off = wave_excl_scan_i(sum, lane, tot);
+      int roff = wave_excl_scan_i(nz, lane, nruns);
+      for (int i = 0; i < per; ++i) {
+        int c = lane * per + i;
+        if (c < g.vol) {
+          int v = L.cnt[c];
+          L.cnt[c] = off;
+          off += v;
+          if (v > 0) L.run_cell[roff++] = (short)c;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < NM_WT_PB; ++it)
+      if (myci[it] >= 0) L.order[L.cnt[myci[it]] + L.rank[it * 64 + lane]] = (short)(it * 64 + lane);
+    __builtin_amdgcn_wave_barrier();
+    NM_TICK(1)
+    // ---- C: one lane per non-empty cell
+    const int nyz = g.n[1] * g.n[2];
+#pragma unroll 1
+    for (int r0 = 0; r0 < nruns; r0 += 64) {
+      const int r = r0 + lane;
+      const bool has = r < nruns;
+      float4 acc[27];
+      int ci = 0;
+      if (has) {
+        ci = L.run_cell[r];
+        const int start = L.cnt[ci];
+        // cnt[] holds exclusive offsets: this run ends where the next non-empty cell starts (the last one at `tot`)
+        const int end = (r + 1 < nruns) ? L.cnt[L.run_cell[r + 1]] : tot;
+#pragma unroll
+        for (int q = 0; q < 27; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s_ = start; s_ < end; ++s_) {
+          const int t = L.order[s_];
+          float rec[NM_WT_REC];
+          const float4* src = reinterpret_cast<const float4*>(&L.rec[t * NM_WT_REC]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { float4 v4 = src[q]; rec[4 * q] = v4.x; rec[4 * q + 1] = v4.y; rec[4 * q + 2] = v4.z; rec[4 * q + 3] = v4.w; }
+          Stencil sp;
+          make_stencil(K, rec, sp);
 #pragma unroll
           for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = 0; j < 3; ++j)
 #pragma unroll
-              for (int k = 0; k < 3; ++k) {
-                const int idx = ci + (i * g.n[1] + j) * g.n[2] + k;
-                const float4 c = acc[(i * 3 + j) * 3 + k];
-                float4 t = s_tile[idx];
-                t.x += c.x; t.y += c.y; t.z += c.z;
-                if (NCH == 4) t.w += c.w;
-                s_tile[idx] = t;
-                // keep the wave-level order of LDS accesses between offsets: another lane's next offset may be
-                // this lane's current node
-                asm volatile("" ::: "memory");
+              for (int kk = 0; kk < 3; ++kk) {
+                float4 c = contrib(sp, rec, i, j, kk);
+                float4& a4 = acc[(i * 3 + j) * 3 + kk];
+                a4.x += c.x; a4.y += c.y; a4.z += c.z; a4.w += c.w;
               }
         }
-        pending = pending && !won;
-        __builtin_amdgcn_wave_barrier();
       }
+      NM_TICK(2)
+      if (has) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+              const int idx = ci + (i * g.n[1] + j) * g.n[2] + kk;
+              const float4 c = acc[(i * 3 + j) * 3 + kk];
+              float4 t4 = L.tile[idx];
+              t4.x += c.x; t4.y += c.y; t4.z += c.z;
+              if (NCH == 4) t4.w += c.w;
+              L.tile[idx] = t4;
+              // keep the wave-level order of LDS accesses between offsets: another lane's next offset may be this
+              // lane's current node
+              asm volatile("" ::: "memory");
+            }
+      }
+      __builtin_amdgcn_wave_barrier();
+      NM_TICK(3)
     }
-    if (direct) break;
-    tile_flush<NCH>(g, s_tile, grid, K.nb, flags, list, count, epoch);
+    (void)nyz;
+    tile_flush<NCH>(g, L.tile, grid, K.nb, flags, list, count, epoch);
+    NM_TICK(4)
     if (single) break;
   }
-  if (K.dbg_buf && threadIdx.x == 0 && blockIdx.x < 4096 && NCH == 4) {
-    K.dbg_buf[blockIdx.x * 4 + 1] = dbg_pass;
-    K.dbg_buf[blockIdx.x * 4 + 2] = dbg_sweep;
-    K.dbg_buf[blockIdx.x * 4 + 3] = dbg_round;
+  if (K.dbg_buf && NCH == 4 && lane == 0 && blockIdx.x < 512) {
+    for (int i = 0; i < 5; ++i) K.dbg_buf[4096 * 2 + blockIdx.x * 8 + i] = tm[i];
+    K.dbg_buf[4096 * 2 + blockIdx.x * 8 + 7] = single ? 1 : 0;
   }
 }
 
@@ -352,38 +422,34 @@ __global__ void __launch_bounds__(256) k_clear(float4* __restrict__ gm, float4* 
   if (blockIdx.x == 0 && threadIdx.x == 0) *count_cur = 0;
 }
 
-struct P2gP {  // per-particle payload of p2g
-  float pm, mom[3];
-  M3 A;
-};
-// mpm.py:321-371.  One wave per workgroup; lane l handles particles (64*blockIdx + l)*PB + b, b < PB.
+// mpm.py:321-371.  One wave per workgroup and per chunk of NM_WT_CHUNK consecutive particles.
+// staged record: x(3) | mom(3) pm(1) | A(9)
 __global__ void __launch_bounds__(64) k_p2g(MpmK K, int n, const float* __restrict__ vol, const float* __restrict__ rho,
                                             const int* __restrict__ enabled, const float* __restrict__ x,
                                             const float* __restrict__ v, const float* __restrict__ C,
                                             const float* __restrict__ S, float4* __restrict__ gm, int* flags, int* list,
                                             int* count, int epoch) {
-  __shared__ float4 s_tile[NM_WT_CAP];
-  __shared__ int s_own[NM_WT_CAP];
+  __shared__ ScatterLds L;
   const long long t_start = K.dbg_buf ? clock64() : 0;
-  auto prep = [&](int p, Stencil& st, P2gP& q) {
-    make_stencil(K, x + 3 * p, st);
+  auto stage = [&](int p, float* rec) {
     float vl = vol[p];
-    q.pm = vl * rho[p];
+    float pm = vl * rho[p];
     float ks = -K.dt * vl * 4.0f * K.inv_dx * K.inv_dx;  // mpm.py:357
     M3 Sp = m3_load(S + 9 * p), Cp = m3_load(C + 9 * p);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) q.A.m[i] = ks * Sp.m[i] + q.pm * Cp.m[i];
+    for (int a = 0; a < 3; ++a) { rec[a] = x[3 * p + a]; rec[3 + a] = pm * v[3 * p + a]; }
+    rec[6] = pm;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) q.mom[a] = q.pm * v[3 * p + a];
+    for (int i = 0; i < 9; ++i) rec[7 + i] = ks * Sp.m[i] + pm * Cp.m[i];
   };
-  auto contrib = [&](const Stencil& st, const P2gP& q, int i, int j, int k) -> float4 {
+  auto contrib = [&](const Stencil& st, const float* rec, int i, int j, int k) -> float4 {
     float d0 = ((float)i - st.f[0]) * K.dx, d1 = ((float)j - st.f[1]) * K.dx, d2 = ((float)k - st.f[2]) * K.dx;
     float w = st.w[0][i] * st.w[1][j] * st.w[2][k];
-    return make_float4(w * (q.mom[0] + q.A.m[0] * d0 + q.A.m[1] * d1 + q.A.m[2] * d2),
-                       w * (q.mom[1] + q.A.m[3] * d0 + q.A.m[4] * d1 + q.A.m[5] * d2),
-                       w * (q.mom[2] + q.A.m[6] * d0 + q.A.m[7] * d1 + q.A.m[8] * d2), w * q.pm);
+    return make_float4(w * (rec[3] + rec[7] * d0 + rec[8] * d1 + rec[9] * d2),
+                       w * (rec[4] + rec[10] * d0 + rec[11] * d1 + rec[12] * d2),
+                       w * (rec[5] + rec[13] * d0 + rec[14] * d1 + rec[15] * d2), w * rec[6]);
   };
-  wave_scatter<4, P2gP>(K, n, enabled, x, gm, flags, list, count, epoch, s_tile, s_own, prep, contrib);
+  wave_scatter<4>(K, n, enabled, x, gm, flags, list, count, epoch, L, stage, contrib);
   if (K.dbg_buf && threadIdx.x == 0 && blockIdx.x < 4096) K.dbg_buf[blockIdx.x * 4] = clock64() - t_start;
 }
 
@@ -583,13 +649,12 @@ __global__ void __launch_bounds__(64) k_g2p_bwd(MpmK K, int n, const float* __re
                                                 const float* __restrict__ gCn, const float* __restrict__ gFn,
                                                 const float4* __restrict__ gv, float4* __restrict__ gg,
                                                 float* __restrict__ gx, float* __restrict__ gF) {
-  __shared__ float4 s_tile[NM_WT_CAP];
-  __shared__ int s_own[NM_WT_CAP];
+  __shared__ ScatterLds L;
   const float kap = 4.0f * K.inv_dx * K.inv_dx;
   // (1) per-particle outputs: gF and gx (direct + through weights/dpos, gathering the forward grid velocity)
 #pragma unroll 1
   for (int b = 0; b < NM_WT_PB; ++b) {
-    const int p = (blockIdx.x * 64 + threadIdx.x) * NM_WT_PB + b;
+    const int p = blockIdx.x * NM_WT_CHUNK + b * 64 + threadIdx.x;
     G2pBwdP q;
     const bool active = g2p_bwd_particle(K, n, p, clip, enabled, x, F, vnext, Cnext, gxn, gvn, gCn, gFn, q);
     if (active) {
@@ -630,21 +695,26 @@ __global__ void __launch_bounds__(64) k_g2p_bwd(MpmK K, int n, const float* __re
       m3_store(gF + 9 * p, q.Fbar);
     }
   }
-  // (2) scatter of the node-velocity adjoint
-  auto prep = [&](int p, Stencil& st, G2pBwdP& q) {
+  // (2) scatter of the node-velocity adjoint; staged record: x(3) | vt(3) - | Ct(9)
+  auto stage = [&](int p, float* rec) {
+    G2pBwdP q;
     g2p_bwd_particle(K, n, p, clip, enabled, x, F, vnext, Cnext, gxn, gvn, gCn, gFn, q);
-    st = q.st;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { rec[a] = x[3 * p + a]; rec[3 + a] = q.vt[a]; }
+    rec[6] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) rec[7 + i] = q.Ct.m[i];
   };
-  auto contrib = [&](const Stencil& st, const G2pBwdP& q, int i, int j, int k) -> float4 {
+  auto contrib = [&](const Stencil& st, const float* rec, int i, int j, int k) -> float4 {
     float d0 = ((float)i - st.f[0]) * K.dx, d1 = ((float)j - st.f[1]) * K.dx, d2 = ((float)k - st.f[2]) * K.dx;
     float w = st.w[0][i] * st.w[1][j] * st.w[2][k];
     float kw = kap * w;
-    float c0_ = q.Ct.m[0] * d0 + q.Ct.m[1] * d1 + q.Ct.m[2] * d2;
-    float c1_ = q.Ct.m[3] * d0 + q.Ct.m[4] * d1 + q.Ct.m[5] * d2;
-    float c2_ = q.Ct.m[6] * d0 + q.Ct.m[7] * d1 + q.Ct.m[8] * d2;
-    return make_float4(w * q.vt[0] + kw * c0_, w * q.vt[1] + kw * c1_, w * q.vt[2] + kw * c2_, 0.f);
+    float c0_ = rec[7] * d0 + rec[8] * d1 + rec[9] * d2;
+    float c1_ = rec[10] * d0 + rec[11] * d1 + rec[12] * d2;
+    float c2_ = rec[13] * d0 + rec[14] * d1 + rec[15] * d2;
+    return make_float4(w * rec[3] + kw * c0_, w * rec[4] + kw * c1_, w * rec[5] + kw * c2_, 0.f);
   };
-  wave_scatter<3, G2pBwdP>(K, n, enabled, x, gg, nullptr, nullptr, nullptr, 0, s_tile, s_own, prep, contrib);
+  wave_scatter<3>(K, n, enabled, x, gg, nullptr, nullptr, nullptr, 0, L, stage, contrib);
 }
 
 // adjoint of p2g: gathers {mvbar, mbar}; writes gv, gC, gS and adds to gx
@@ -808,7 +878,7 @@ static int mpm_build_grid(nm_mpm* h, int n, const nm_statics* st, const nm_parti
                      h->count + now);
   NM_LAUNCH_CHECK();
   if (n > 0) {
-    NM_LAUNCH(k_p2g, dim3(nm_div_up(n, 64 * NM_WT_PB)), dim3(64), 0, s, h->k, n, st->vol, st->rho, st->enabled, cur->x,
+    NM_LAUNCH(k_p2g, dim3(nm_div_up(n, NM_WT_CHUNK)), dim3(64), 0, s, h->k, n, st->vol, st->rho, st->enabled, cur->x,
                        cur->v, cur->C, cur->stress, h->gm, h->flags, h->list[now], h->count + now, h->epoch);
     NM_LAUNCH_CHECK();
   }
@@ -882,7 +952,7 @@ extern "C" int nm_mpm_backward(nm_mpm* h, int32_t n, const nm_statics* st, const
   if (n == 0) return NM_OK;
   const int now = h->cur;
   const int nwg = nm_div_up(n, 256);
-  NM_LAUNCH(k_g2p_bwd, dim3(nm_div_up(n, 64 * NM_WT_PB)), dim3(64), 0, s, h->k, n, st->clip_bound, st->enabled, cur->x, cur->F, next->v,
+  NM_LAUNCH(k_g2p_bwd, dim3(nm_div_up(n, NM_WT_CHUNK)), dim3(64), 0, s, h->k, n, st->clip_bound, st->enabled, cur->x, cur->F, next->v,
                      next->C, gnext->x, gnext->v, gnext->C, gnext->F, h->gv, h->gg, gcur->x, gcur->F);
   NM_LAUNCH_CHECK();
   NM_LAUNCH(k_grid_op_bwd, dim3(kSweepGrid), dim3(256), 0, s, h->k, h->gm, h->gg, h->list[now], h->count + now);

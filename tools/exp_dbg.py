@@ -22,12 +22,9 @@ if os.environ.get("NM_DBG") and int(os.environ["NM_DBG"]) & 8:
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     buf = np.zeros(4096 * 4, dtype=np.int64)
     print("fetch rc", fn(rt.model.handle(), buf.ctypes.data, 4096 * 4))
-    b = buf.reshape(-1, 4)[:196]
-    cyc = b[:, 0]
-    print("cycles: mean %.0f median %.0f p90 %.0f max %.0f" % (cyc.mean(), np.median(cyc), np.percentile(cyc, 90), cyc.max()))
-    for c, nm in ((1, "passes"), (2, "sweeps"), (3, "rounds")):
-        print(nm, "mean %.1f median %.0f max %d" % (b[:, c].mean(), np.median(b[:, c]), b[:, c].max()))
-    slow = np.argsort(-cyc)[:10]
-    print("slowest:", [(int(i), int(cyc[i]), int(b[i, 1]), int(b[i, 2])) for i in slow])
-    fast = np.argsort(cyc)[:5]
-    print("fastest:", [(int(i), int(cyc[i]), int(b[i, 1]), int(b[i, 2])) for i in fast])
+    cyc = buf[:4 * 196:4]
+    print("total cycles: mean %.0f median %.0f p90 %.0f max %.0f" % (cyc.mean(), np.median(cyc), np.percentile(cyc, 90), cyc.max()))
+    ph = buf[4096 * 2: 4096 * 2 + 196 * 8].reshape(196, 8)
+    names = ["A stage", "B sort", "C accumulate", "C rmw", "flush", "-", "-", "single"]
+    for i, nm in enumerate(names):
+        print("  %-14s mean %9.0f median %9.0f max %9.0f" % (nm, ph[:, i].mean(), np.median(ph[:, i]), ph[:, i].max()))
