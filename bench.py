@@ -77,11 +77,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world == 1 and args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)          # NEUMA_DIST_BACKEND=gloo dry runs put several ranks on one GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("NEUMA_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     lib = _lib.lib()
 
     scene = synth.make_scene(args.workload)
@@ -97,6 +103,9 @@ def main():
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize(dev)
+
+    group = dist.group.WORLD if world > 1 else None
+    rt.group = group
 
     def zero_grads():
         for p in rt.parameters():

@@ -449,7 +449,18 @@ __global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, const uint2* __rest
   // lane l < 8 owns fold slot value index:
   const int slot = 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1);
   for (int i = lane; i < NM_TPB * NM_NG; i += 64) my_acc[i] = 0.f;
+  // Gaussians behind every pixel's last contributor (the forward pass stopped compositing there) cannot
+  // contribute: the wave skips them before doing any arithmetic, the tile skips whole batches of them
+  uint32_t wave_last = last_contributor;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, o, 64));
+  __shared__ uint32_t s_last[4];
+  if (lane == 0) s_last[wave] = wave_last;
+  __syncthreads();
+  const uint32_t tile_last = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
   for (int rd = 0; rd < rounds; ++rd, todo -= NM_TPB) {
+    // this batch covers list positions [todo - NM_TPB, todo): skip it entirely if all of them are >= tile_last
+    if ((uint32_t)max(todo - NM_TPB, 0) >= tile_last) { contributor -= (uint32_t)min(NM_TPB, todo); continue; }
     __syncthreads();
     int prog = rd * NM_TPB + tid;
     if (range.x + prog < range.y) {
@@ -463,6 +474,7 @@ __global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, const uint2* __rest
     const int nb = min(NM_TPB, todo);
     for (int j = 0; j < nb; ++j) {
       contributor--;
+      if (contributor >= wave_last) continue;   // wave-uniform
       bool act = contributor < last_contributor;
       float2 p = s_xy[j];
       float4 co = s_co[j];

@@ -55,6 +55,8 @@ def time_frame_sample(scene, rt=None, max_seconds: float = 60.0):
     """Returns the `cpu_baseline` JSON object."""
     cfg = scene.cfg
     torch.manual_seed(0)
+    # many tiny ops: more than ~16 intra-op threads only adds overhead on a 128/256-core host
+    torch.set_num_threads(min(16, torch.get_num_threads()))
     from neuma_amd import synth          # data generator only (host numpy) — not a compute path
     w = synth.load_base_weights(cfg["mat"])
     We = [torch.tensor(a) for a in w["e"]]
