@@ -26,7 +26,6 @@ struct MpmK {
   float gdt[3];
   int bound, bc;
   int dbg;  // NM_DBG experiment switches (0 in production)
-  long long* dbg_buf;
 };
 
 struct nm_mpm {
@@ -85,17 +84,17 @@ __device__ __forceinline__ void mark_block(int b, int* __restrict__ flags, int* 
   }
 }
 
-// ---------------------------------------------------------------- per-wave LDS tile for scatters
-#define NM_WT_CAP 1024   // nodes per wave tile: 16 KiB of float4 + 4 KiB of owner tickets
-#define NM_WT_PB 8       // consecutive particles per lane (workgroup = one wave = 512 particles)
-#define NM_WT_BOX 10     // edge of the fixed box used when a chunk's bounding box exceeds the tile (10^3 nodes)
+// ---------------------------------------------------------------- workgroup scatter (p2g, g2p adjoint)
+#define NM_SC_T 256      // threads = particles per workgroup
+#define NM_WT_CAP 2048   // tile nodes a workgroup can own (NM_NPT per thread)
+#define NM_NPT (NM_WT_CAP / NM_SC_T)
+#define NM_WT_BOX 12     // edge of the fixed box used when a chunk's bounding box exceeds the tile (12^3 nodes)
 #define NM_WT_MAXPASS 12 // boxes tried per chunk before the leftovers go to direct global atomics
 
 struct TileGeom {
   int o[3];
   int n[3];
   int vol;
-  bool use;
 };
 
 __device__ __forceinline__ int wave_min_i(int v) {
@@ -108,78 +107,6 @@ __device__ __forceinline__ int wave_max_i(int v) {
   for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
   return v;
 }
-__device__ __forceinline__ void base_cell(const MpmK& K, const float* __restrict__ xp, int* bb) {
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    int q = (int)(xp[a] * K.inv_dx - 0.5f);
-    bb[a] = max(0, min(q, K.Gp - 3));
-  }
-}
-__device__ __forceinline__ void tile_zero(const TileGeom& g, float4* s_tile) {
-  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int i = threadIdx.x; i < g.vol; i += 64) s_tile[i] = z;
-  __builtin_amdgcn_wave_barrier();
-}
-__device__ __forceinline__ TileGeom tile_box(const MpmK& K, const int* anchor) {
-  TileGeom g;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    g.o[a] = max(0, min(anchor[a] - 2, K.Gp - NM_WT_BOX));
-    g.n[a] = NM_WT_BOX;
-  }
-  g.vol = NM_WT_BOX * NM_WT_BOX * NM_WT_BOX;
-  g.use = true;
-  return g;
-}
-__device__ __forceinline__ bool tile_holds(const TileGeom& g, const int* b) {
-  return b[0] >= g.o[0] && b[0] + 3 <= g.o[0] + g.n[0] && b[1] >= g.o[1] && b[1] + 3 <= g.o[1] + g.n[1] && b[2] >= g.o[2] &&
-         b[2] + 3 <= g.o[2] + g.n[2];
-}
-
-// flush the tile: one global atomic set per touched node; mark the grid blocks the tile overlaps
-template <int NCH>
-__device__ __forceinline__ void tile_flush(const TileGeom& g, const float4* s_tile, float4* __restrict__ grid, int nb, int* flags,
-                                           int* list, int* count, int epoch) {
-  __builtin_amdgcn_wave_barrier();
-  const int lane = threadIdx.x;
-  const int nyz = g.n[1] * g.n[2];
-  for (int idx = lane; idx < g.vol; idx += 64) {
-    float4 t = s_tile[idx];
-    if (t.x != 0.f || t.y != 0.f || t.z != 0.f || t.w != 0.f) {
-      int i = idx / nyz, r = idx - i * nyz;
-      int j = r / g.n[2], k = r - j * g.n[2];
-      float* dst = (float*)&grid[node_addr(g.o[0] + i, g.o[1] + j, g.o[2] + k, nb)];
-      unsafeAtomicAdd(dst, t.x);
-      unsafeAtomicAdd(dst + 1, t.y);
-      unsafeAtomicAdd(dst + 2, t.z);
-      if (NCH == 4) unsafeAtomicAdd(dst + 3, t.w);
-    }
-  }
-  if (flags) {
-    int b0 = g.o[0] >> 2, b1 = g.o[1] >> 2, b2 = g.o[2] >> 2;
-    int m0 = ((g.o[0] + g.n[0] - 1) >> 2) - b0 + 1, m1 = ((g.o[1] + g.n[1] - 1) >> 2) - b1 + 1,
-        m2 = ((g.o[2] + g.n[2] - 1) >> 2) - b2 + 1;
-    for (int t = lane; t < m0 * m1 * m2; t += 64) {
-      int i = t / (m1 * m2), r = t - i * (m1 * m2);
-      int j = r / m2, k = r - j * m2;
-      mark_block(((b0 + i) * nb + (b1 + j)) * nb + (b2 + k), flags, list, count, epoch);
-    }
-  }
-}
-
-#define NM_WT_CHUNK (64 * NM_WT_PB)
-#define NM_WT_REC 16  // floats per staged particle record: x(3) + payload(13)
-
-struct ScatterLds {
-  float4 tile[NM_WT_CAP];
-  int cnt[NM_WT_CAP];                 // particles per stencil origin (tile-local cell), then exclusive offsets
-  float rec[NM_WT_CHUNK * NM_WT_REC];
-  int key[NM_WT_CHUNK];               // global origin key per staged particle (-1: disabled / not staged)
-  short rank[NM_WT_CHUNK];            // arrival order inside its cell
-  short order[NM_WT_CHUNK];           // particle slots sorted by cell
-  short run_cell[NM_WT_CAP];          // compacted list of non-empty cells
-};
-
 __device__ __forceinline__ int wave_excl_scan_i(int v, int lane, int& total) {
   int x = v;
 #pragma unroll
@@ -190,218 +117,213 @@ __device__ __forceinline__ int wave_excl_scan_i(int v, int lane, int& total) {
   total = __shfl(x, 63, 64);
   return x - v;
 }
-
-// Scatter of one chunk of NM_WT_CHUNK consecutive particles into `grid` by one wave.
-//   stage(p, rec)              loads particle p and writes x(3) + payload(13) to rec[16]      (coalesced phase)
-//   contrib(st, rec, i, j, k)  contribution of a staged particle to its stencil node (i,j,k)
-// A: every particle is staged once (coalesced global loads, all in flight together).
-// B: the chunk is counting-sorted in LDS by stencil origin (tile-local cell): integer LDS atomics give each
-//    particle its rank inside its cell, a wave scan gives the cell offsets.  So whatever order the caller keeps
-//    its particles in (sorted at load time, gone stale since), every non-empty cell becomes exactly one run.
-// C: lane r sums the 27 float4 contributions of run r in registers and adds them to the tile with plain
-//    ds_read_b128 / ds_write_b128 — two lanes never share a cell, and for a fixed stencil offset distinct cells
-//    hit distinct nodes, so no atomics and no retries are needed.
-// D: the tile is flushed with one global atomic set per touched node.
-// Chunks whose bounding box exceeds the tile are processed box by box (anchored at the first pending particle);
-// after NM_WT_MAXPASS boxes the leftovers use per-particle global atomics.
-template <int NCH, class StageF, class ContribF>
-__device__ __forceinline__ void wave_scatter(const MpmK& K, int n, const int* __restrict__ enabled, const float* __restrict__ x,
-                                             float4* __restrict__ grid, int* flags, int* list, int* count, int epoch,
-                                             ScatterLds& L, StageF stage, ContribF contrib) {
-  const int lane = threadIdx.x;
-  const int c0 = blockIdx.x * NM_WT_CHUNK;
-  const int GG = K.Gp * K.Gp;
-  long long tm[6] = {0, 0, 0, 0, 0, 0};
-  long long t0 = K.dbg_buf ? clock64() : 0;
-#define NM_TICK(i) if (K.dbg_buf) { long long t1 = clock64(); tm[i] += t1 - t0; t0 = t1; }
-  // ---- A: stage records + origin keys; bounding box of the origins
-  int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-0x7fffffff, -0x7fffffff, -0x7fffffff};
+__device__ __forceinline__ TileGeom tile_box(const MpmK& K, const int* anchor) {
+  TileGeom g;
 #pragma unroll
-  for (int it = 0; it < NM_WT_PB; ++it) {
-    const int t = it * 64 + lane, p = c0 + t;
-    int key = -1;
-    if (p < n && enabled[p] != 0) {
-      float rec[NM_WT_REC];
-      stage(p, rec);
-      int bb[3];
-      base_cell(K, rec, bb);
-      key = (bb[0] * K.Gp + bb[1]) * K.Gp + bb[2];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) { lo[a] = min(lo[a], bb[a]); hi[a] = max(hi[a], bb[a]); }
-      float4* dst = reinterpret_cast<float4*>(&L.rec[t * NM_WT_REC]);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) dst[q] = make_float4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
-    }
-    L.key[t] = key;
+  for (int a = 0; a < 3; ++a) {
+    g.o[a] = max(0, min(anchor[a] - 2, K.Gp - NM_WT_BOX));
+    g.n[a] = NM_WT_BOX;
   }
+  g.vol = NM_WT_BOX * NM_WT_BOX * NM_WT_BOX;
+  return g;
+}
+__device__ __forceinline__ bool tile_holds(const TileGeom& g, const int* b) {
+  return b[0] >= g.o[0] && b[0] + 3 <= g.o[0] + g.n[0] && b[1] >= g.o[1] && b[1] + 3 <= g.o[1] + g.n[1] && b[2] >= g.o[2] &&
+         b[2] + 3 <= g.o[2] + g.n[2];
+}
+
+struct ScatterLds {
+  float4 C[NM_SC_T * 9];     // one i-slab (9 stencil nodes) of every particle's contributions, in cell-sorted order
+  float4 tile[NM_WT_CAP];    // node sums of the workgroup's bounding box
+  int cnt[NM_WT_CAP + 4];    // particles per stencil origin -> exclusive offsets (+ total as sentinel)
+  short run_cell[NM_SC_T];   // compacted list of non-empty origin cells (<= one per particle)
+  int red[32];               // block reductions / broadcasts
+};
+
+// Scatter of the workgroup's 256 particles (one per thread) into `grid` WITHOUT floating-point atomics in LDS
+// (ds_add_f32 retires ~0.33 lanes/clk/CU on gfx950) and without serial per-wave chains:
+//   1. the particles are counting-sorted by stencil origin inside LDS (256 integer LDS atomics + a block scan), so
+//      the members of every origin cell are contiguous whatever order the caller keeps its particles in;
+//   2. for each of the three i-slabs of the 3x3x3 stencil every thread writes its 9 float4 contributions to its
+//      sorted slot; then thread r sums the members of non-empty cell r (contiguous slots, independent reads) and the
+//      cell sums are pushed into the LDS tile one stencil offset at a time: for a FIXED offset distinct cells hit
+//      distinct nodes, so plain ds_read_b128 / ds_write_b128 never conflict; a workgroup barrier separates offsets;
+//   3. every touched node is flushed with one global atomic set.
+// Chunks whose bounding box exceeds the tile (row breaks of the particle order) are processed box by box; after
+// NM_WT_MAXPASS boxes the leftovers use per-particle global atomics, so any order is correct.
+//   contrib(i, j, k) -> float4 contribution of THIS thread's particle to stencil node (i,j,k)
+template <int NCH, class ContribF>
+__device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* base, float4* __restrict__ grid, int* flags,
+                                           int* list, int* count, int epoch, ScatterLds& L, ContribF contrib) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // ---- bounding box of the stencil origins
+  int lo[3], hi[3];
 #pragma unroll
-  for (int a = 0; a < 3; ++a) { lo[a] = wave_min_i(lo[a]); hi[a] = wave_max_i(hi[a]); }
-  if (lo[0] == 0x7fffffff) return;  // nothing enabled in this chunk
+  for (int a = 0; a < 3; ++a) {
+    lo[a] = wave_min_i(en ? base[a] : 0x7fffffff);
+    hi[a] = wave_max_i(en ? base[a] : -0x7fffffff);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { L.red[wave * 6 + a] = lo[a]; L.red[wave * 6 + 3 + a] = hi[a]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    lo[a] = min(min(L.red[a], L.red[6 + a]), min(L.red[12 + a], L.red[18 + a]));
+    hi[a] = max(max(L.red[3 + a], L.red[9 + a]), max(L.red[15 + a], L.red[21 + a]));
+  }
+  __syncthreads();
+  if (lo[0] == 0x7fffffff) return;  // nothing enabled in this workgroup
   TileGeom g;
 #pragma unroll
   for (int a = 0; a < 3; ++a) { g.o[a] = lo[a]; g.n[a] = hi[a] - lo[a] + 3; }
   g.vol = g.n[0] * g.n[1] * g.n[2];
   const bool single = g.vol <= NM_WT_CAP;
-  __builtin_amdgcn_wave_barrier();
-  NM_TICK(0)
+  bool pending = en;
+  if (K.dbg & 4) return;
+  if ((K.dbg & 16) && !single) return;
 
   for (int pass = 0; pass <= NM_WT_MAXPASS; ++pass) {
     if (!single) {
       if (pass == NM_WT_MAXPASS) {   // last resort: per-particle global atomics for what is still pending
-        for (int it = 0; it < NM_WT_PB; ++it) {
-          const int t = it * 64 + lane;
-          const int key = L.key[t];
-          if (key < 0) continue;
-          float rec[NM_WT_REC];
-          const float4* src = reinterpret_cast<const float4*>(&L.rec[t * NM_WT_REC]);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { float4 v4 = src[q]; rec[4 * q] = v4.x; rec[4 * q + 1] = v4.y; rec[4 * q + 2] = v4.z; rec[4 * q + 3] = v4.w; }
-          Stencil sp;
-          make_stencil(K, rec, sp);
+        if (pending) {
 #pragma unroll
           for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = 0; j < 3; ++j)
 #pragma unroll
-              for (int kk = 0; kk < 3; ++kk) {
-                const float4 c = contrib(sp, rec, i, j, kk);
-                float* dst = (float*)&grid[node_addr(sp.b[0] + i, sp.b[1] + j, sp.b[2] + kk, K.nb)];
+              for (int k = 0; k < 3; ++k) {
+                const float4 c = contrib(i, j, k);
+                float* dst = (float*)&grid[node_addr(base[0] + i, base[1] + j, base[2] + k, K.nb)];
                 unsafeAtomicAdd(dst, c.x);
                 unsafeAtomicAdd(dst + 1, c.y);
                 unsafeAtomicAdd(dst + 2, c.z);
                 if (NCH == 4) unsafeAtomicAdd(dst + 3, c.w);
               }
           if (flags) {
-            for (int i = sp.b[0] >> 2; i <= (sp.b[0] + 2) >> 2; ++i)
-              for (int j = sp.b[1] >> 2; j <= (sp.b[1] + 2) >> 2; ++j)
-                for (int kk = sp.b[2] >> 2; kk <= (sp.b[2] + 2) >> 2; ++kk)
-                  mark_block((i * K.nb + j) * K.nb + kk, flags, list, count, epoch);
+            for (int i = base[0] >> 2; i <= (base[0] + 2) >> 2; ++i)
+              for (int j = base[1] >> 2; j <= (base[1] + 2) >> 2; ++j)
+                for (int k = base[2] >> 2; k <= (base[2] + 2) >> 2; ++k)
+                  mark_block((i * K.nb + j) * K.nb + k, flags, list, count, epoch);
           }
         }
         break;
       }
-      // anchor a box at the first particle still pending
-      int first = 0x7fffffff;
-      for (int it = 0; it < NM_WT_PB; ++it)
-        if (L.key[it * 64 + lane] >= 0) { first = it * 64 + lane; break; }
-      first = wave_min_i(first);
+      // anchor a box at the pending particle with the lowest thread id
+      int first = wave_min_i(pending ? tid : 0x7fffffff);
+      if (lane == 0) L.red[wave] = first;
+      __syncthreads();
+      first = min(min(L.red[0], L.red[1]), min(L.red[2], L.red[3]));
+      __syncthreads();
       if (first == 0x7fffffff) break;
-      const int key = L.key[first];
-      int anchor[3] = {key / GG, (key / K.Gp) % K.Gp, key % K.Gp};
+      if (tid == first) { L.red[8] = base[0]; L.red[9] = base[1]; L.red[10] = base[2]; }
+      __syncthreads();
+      int anchor[3] = {L.red[8], L.red[9], L.red[10]};
       g = tile_box(K, anchor);
+      __syncthreads();
     }
-    // ---- B: counting sort of the pass's particles by tile-local cell
-    for (int i = lane; i < g.vol; i += 64) { L.tile[i] = make_float4(0.f, 0.f, 0.f, 0.f); L.cnt[i] = 0; }
-    __builtin_amdgcn_wave_barrier();
-    int myci[NM_WT_PB];
-#pragma unroll
-    for (int it = 0; it < NM_WT_PB; ++it) {
-      const int t = it * 64 + lane;
-      const int key = L.key[t];
-      myci[it] = -1;
-      if (key >= 0) {
-        int bb[3] = {key / GG, (key / K.Gp) % K.Gp, key % K.Gp};
-        if (single || tile_holds(g, bb)) {
-          const int ci = ((bb[0] - g.o[0]) * g.n[1] + (bb[1] - g.o[1])) * g.n[2] + (bb[2] - g.o[2]);
-          myci[it] = ci;
-          L.rank[t] = (short)atomicAdd(&L.cnt[ci], 1);
-          L.key[t] = -1;   // consumed by this pass
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    // exclusive scan of cnt over the tile cells (each lane owns a contiguous slice) + list of non-empty cells
-    const int per = (g.vol + 63) >> 6;
-    int nruns, tot;
-    {
-      int sum = 0, nz = 0;
-      for (int i = 0; i < per; ++i) {
-        int c = lane * per + i;
-        if (c < g.vol) { int v = L.cnt[c]; sum += v; nz += v > 0; }
-      }
-      int off = wave_excl_scan_i(sum, lane, tot);
-      int roff = wave_excl_scan_i(nz, lane, nruns);
-      for (int i = 0; i < per; ++i) {
-        int c = lane * per + i;
-        if (c < g.vol) {
-          int v = L.cnt[c];
-          L.cnt[c] = off;
-          off += v;
-          if (v > 0) L.run_cell[roff++] = (short)c;
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int it = 0; it < NM_WT_PB; ++it)
-      if (myci[it] >= 0) L.order[L.cnt[myci[it]] + L.rank[it * 64 + lane]] = (short)(it * 64 + lane);
-    __builtin_amdgcn_wave_barrier();
-    NM_TICK(1)
-    // ---- C: one lane per non-empty cell
+    const bool in = pending && (single || tile_holds(g, base));
     const int nyz = g.n[1] * g.n[2];
-#pragma unroll 1
-    for (int r0 = 0; r0 < nruns; r0 += 64) {
-      const int r = r0 + lane;
-      const bool has = r < nruns;
-      float4 acc[27];
-      int ci = 0;
-      if (has) {
-        ci = L.run_cell[r];
-        const int start = L.cnt[ci];
-        // cnt[] holds exclusive offsets: this run ends where the next non-empty cell starts (the last one at `tot`)
-        const int end = (r + 1 < nruns) ? L.cnt[L.run_cell[r + 1]] : tot;
+    const int ci = in ? ((base[0] - g.o[0]) * g.n[1] + (base[1] - g.o[1])) * g.n[2] + (base[2] - g.o[2]) : 0;
+    // ---- counting sort by origin cell (+ compacted list of the non-empty cells)
+    for (int i = tid; i < g.vol + 4; i += NM_SC_T) L.cnt[i] = 0;
+    for (int i = tid; i < g.vol; i += NM_SC_T) L.tile[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    const int rank = in ? atomicAdd(&L.cnt[ci], 1) : 0;
+    __syncthreads();
+    int nruns;
+    {
+      int v[NM_NPT], sum = 0, nz = 0;
 #pragma unroll
-        for (int q = 0; q < 27; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int s_ = start; s_ < end; ++s_) {
-          const int t = L.order[s_];
-          float rec[NM_WT_REC];
-          const float4* src = reinterpret_cast<const float4*>(&L.rec[t * NM_WT_REC]);
+      for (int q = 0; q < NM_NPT; ++q) {
+        int c = tid * NM_NPT + q;
+        v[q] = c < g.vol ? L.cnt[c] : 0;
+        sum += v[q];
+        nz += v[q] > 0;
+      }
+      int wtot, wnz;
+      int off = wave_excl_scan_i(sum, lane, wtot);
+      int roff = wave_excl_scan_i(nz, lane, wnz);
+      if (lane == 0) { L.red[wave] = wtot; L.red[4 + wave] = wnz; }
+      __syncthreads();
+      for (int w2 = 0; w2 < wave; ++w2) { off += L.red[w2]; roff += L.red[4 + w2]; }
+      nruns = L.red[4] + L.red[5] + L.red[6] + L.red[7];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) { float4 v4 = src[q]; rec[4 * q] = v4.x; rec[4 * q + 1] = v4.y; rec[4 * q + 2] = v4.z; rec[4 * q + 3] = v4.w; }
-          Stencil sp;
-          make_stencil(K, rec, sp);
-#pragma unroll
-          for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-#pragma unroll
-              for (int kk = 0; kk < 3; ++kk) {
-                float4 c = contrib(sp, rec, i, j, kk);
-                float4& a4 = acc[(i * 3 + j) * 3 + kk];
-                a4.x += c.x; a4.y += c.y; a4.z += c.z; a4.w += c.w;
-              }
+      for (int q = 0; q < NM_NPT; ++q) {
+        int c = tid * NM_NPT + q;
+        if (c < g.vol) {
+          L.cnt[c] = off;
+          off += v[q];
+          if (v[q] > 0) L.run_cell[roff++] = (short)c;
         }
       }
-      NM_TICK(2)
-      if (has) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int kk = 0; kk < 3; ++kk) {
-              const int idx = ci + (i * g.n[1] + j) * g.n[2] + kk;
-              const float4 c = acc[(i * 3 + j) * 3 + kk];
-              float4 t4 = L.tile[idx];
-              t4.x += c.x; t4.y += c.y; t4.z += c.z;
-              if (NCH == 4) t4.w += c.w;
-              L.tile[idx] = t4;
-              // keep the wave-level order of LDS accesses between offsets: another lane's next offset may be this
-              // lane's current node
-              asm volatile("" ::: "memory");
-            }
-      }
-      __builtin_amdgcn_wave_barrier();
-      NM_TICK(3)
+      if (tid == NM_SC_T - 1) L.cnt[g.vol] = off;   // last thread's running offset == total
     }
-    (void)nyz;
-    tile_flush<NCH>(g, L.tile, grid, K.nb, flags, list, count, epoch);
-    NM_TICK(4)
+    __syncthreads();
+    const int slot = in ? L.cnt[ci] + rank : 0;
+    const bool owner = tid < nruns;                   // thread r owns non-empty cell r
+    const int mycell = owner ? (int)L.run_cell[tid] : 0;
+    const int s0 = owner ? L.cnt[mycell] : 0, s1 = owner ? L.cnt[mycell + 1] : 0;
+#pragma unroll 1
+    for (int i = 0; i < 3; ++i) {
+      if (in) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) L.C[slot * 9 + j * 3 + k] = contrib(i, j, k);
+      }
+      __syncthreads();
+      float4 acc[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int s_ = s0; s_ < s1; ++s_) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+          const float4 t4 = L.C[s_ * 9 + q];
+          acc[q].x += t4.x; acc[q].y += t4.y; acc[q].z += t4.z; acc[q].w += t4.w;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          if (owner) {
+            const int node = mycell + (i * g.n[1] + j) * g.n[2] + k;
+            float4 t4 = L.tile[node];
+            const float4 c4 = acc[j * 3 + k];
+            t4.x += c4.x; t4.y += c4.y; t4.z += c4.z; t4.w += c4.w;
+            L.tile[node] = t4;
+          }
+          __syncthreads();   // next offset: another cell's target may be this cell's current node
+        }
+    }
+    // ---- flush: one global atomic set per touched node
+    for (int nidx = tid; nidx < g.vol; nidx += NM_SC_T) {
+      const float4 t = L.tile[nidx];
+      if (!(K.dbg & 1) && (t.x != 0.f || t.y != 0.f || t.z != 0.f || t.w != 0.f)) {
+        int a_ = nidx / nyz, r = nidx - a_ * nyz;
+        int b_ = r / g.n[2], c_ = r - b_ * g.n[2];
+        float* dst = (float*)&grid[node_addr(g.o[0] + a_, g.o[1] + b_, g.o[2] + c_, K.nb)];
+        unsafeAtomicAdd(dst, t.x);
+        unsafeAtomicAdd(dst + 1, t.y);
+        unsafeAtomicAdd(dst + 2, t.z);
+        if (NCH == 4) unsafeAtomicAdd(dst + 3, t.w);
+      }
+    }
+    if (flags && !(K.dbg & 2)) {
+      int b0 = g.o[0] >> 2, b1 = g.o[1] >> 2, b2 = g.o[2] >> 2;
+      int m0 = ((g.o[0] + g.n[0] - 1) >> 2) - b0 + 1, m1 = ((g.o[1] + g.n[1] - 1) >> 2) - b1 + 1,
+          m2 = ((g.o[2] + g.n[2] - 1) >> 2) - b2 + 1;
+      for (int t = tid; t < m0 * m1 * m2; t += NM_SC_T) {
+        int i = t / (m1 * m2), r = t - i * (m1 * m2);
+        int j = r / m2, k = r - j * m2;
+        mark_block(((b0 + i) * K.nb + (b1 + j)) * K.nb + (b2 + k), flags, list, count, epoch);
+      }
+    }
+    pending = pending && !in;
     if (single) break;
-  }
-  if (K.dbg_buf && NCH == 4 && lane == 0 && blockIdx.x < 512) {
-    for (int i = 0; i < 5; ++i) K.dbg_buf[4096 * 2 + blockIdx.x * 8 + i] = tm[i];
-    K.dbg_buf[4096 * 2 + blockIdx.x * 8 + 7] = single ? 1 : 0;
+    __syncthreads();
   }
 }
 
@@ -422,35 +344,41 @@ __global__ void __launch_bounds__(256) k_clear(float4* __restrict__ gm, float4* 
   if (blockIdx.x == 0 && threadIdx.x == 0) *count_cur = 0;
 }
 
-// mpm.py:321-371.  One wave per workgroup and per chunk of NM_WT_CHUNK consecutive particles.
-// staged record: x(3) | mom(3) pm(1) | A(9)
-__global__ void __launch_bounds__(64) k_p2g(MpmK K, int n, const float* __restrict__ vol, const float* __restrict__ rho,
-                                            const int* __restrict__ enabled, const float* __restrict__ x,
-                                            const float* __restrict__ v, const float* __restrict__ C,
-                                            const float* __restrict__ S, float4* __restrict__ gm, int* flags, int* list,
-                                            int* count, int epoch) {
+// mpm.py:321-371.  One particle per thread, 256 per workgroup.
+__global__ void __launch_bounds__(NM_SC_T) k_p2g(MpmK K, int n, const float* __restrict__ vol, const float* __restrict__ rho,
+                                                 const int* __restrict__ enabled, const float* __restrict__ x,
+                                                 const float* __restrict__ v, const float* __restrict__ C,
+                                                 const float* __restrict__ S, float4* __restrict__ gm, int* flags, int* list,
+                                                 int* count, int epoch) {
   __shared__ ScatterLds L;
-  const long long t_start = K.dbg_buf ? clock64() : 0;
-  auto stage = [&](int p, float* rec) {
+  const int p = blockIdx.x * NM_SC_T + threadIdx.x;
+  const bool en = p < n && enabled[p] != 0;
+  Stencil st;
+  float pm = 0.f, mom[3] = {0.f, 0.f, 0.f};
+  M3 A = m3_zero();
+  if (en) {
+    make_stencil(K, x + 3 * p, st);
     float vl = vol[p];
-    float pm = vl * rho[p];
+    pm = vl * rho[p];
     float ks = -K.dt * vl * 4.0f * K.inv_dx * K.inv_dx;  // mpm.py:357
     M3 Sp = m3_load(S + 9 * p), Cp = m3_load(C + 9 * p);
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { rec[a] = x[3 * p + a]; rec[3 + a] = pm * v[3 * p + a]; }
-    rec[6] = pm;
+    for (int i = 0; i < 9; ++i) A.m[i] = ks * Sp.m[i] + pm * Cp.m[i];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) rec[7 + i] = ks * Sp.m[i] + pm * Cp.m[i];
-  };
-  auto contrib = [&](const Stencil& st, const float* rec, int i, int j, int k) -> float4 {
+    for (int a = 0; a < 3; ++a) mom[a] = pm * v[3 * p + a];
+  } else {
+    st.b[0] = st.b[1] = st.b[2] = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { st.f[a] = 0.f; st.w[a][0] = st.w[a][1] = st.w[a][2] = 0.f; }
+  }
+  auto contrib = [&](int i, int j, int k) -> float4 {
     float d0 = ((float)i - st.f[0]) * K.dx, d1 = ((float)j - st.f[1]) * K.dx, d2 = ((float)k - st.f[2]) * K.dx;
-    float w = st.w[0][i] * st.w[1][j] * st.w[2][k];
-    return make_float4(w * (rec[3] + rec[7] * d0 + rec[8] * d1 + rec[9] * d2),
-                       w * (rec[4] + rec[10] * d0 + rec[11] * d1 + rec[12] * d2),
-                       w * (rec[5] + rec[13] * d0 + rec[14] * d1 + rec[15] * d2), w * rec[6]);
+    float w = sel3(st.w[0], i) * st.w[1][j] * st.w[2][k];
+    return make_float4(w * (mom[0] + A.m[0] * d0 + A.m[1] * d1 + A.m[2] * d2),
+                       w * (mom[1] + A.m[3] * d0 + A.m[4] * d1 + A.m[5] * d2),
+                       w * (mom[2] + A.m[6] * d0 + A.m[7] * d1 + A.m[8] * d2), w * pm);
   };
-  wave_scatter<4>(K, n, enabled, x, gm, flags, list, count, epoch, L, stage, contrib);
-  if (K.dbg_buf && threadIdx.x == 0 && blockIdx.x < 4096) K.dbg_buf[blockIdx.x * 4] = clock64() - t_start;
+  wg_scatter<4>(K, en, st.b, gm, flags, list, count, epoch, L, contrib);
 }
 
 __device__ __forceinline__ void block_coords(int b, int nb, int lane, int& i, int& j, int& k) {
@@ -642,79 +570,67 @@ __device__ __forceinline__ bool g2p_bwd_particle(const MpmK& K, int n, int p, co
   return active;
 }
 
-__global__ void __launch_bounds__(64) k_g2p_bwd(MpmK K, int n, const float* __restrict__ clip, const int* __restrict__ enabled,
-                                                const float* __restrict__ x, const float* __restrict__ F,
-                                                const float* __restrict__ vnext, const float* __restrict__ Cnext,
-                                                const float* __restrict__ gxn, const float* __restrict__ gvn,
-                                                const float* __restrict__ gCn, const float* __restrict__ gFn,
-                                                const float4* __restrict__ gv, float4* __restrict__ gg,
-                                                float* __restrict__ gx, float* __restrict__ gF) {
+__global__ void __launch_bounds__(NM_SC_T) k_g2p_bwd(MpmK K, int n, const float* __restrict__ clip, const int* __restrict__ enabled,
+                                                     const float* __restrict__ x, const float* __restrict__ F,
+                                                     const float* __restrict__ vnext, const float* __restrict__ Cnext,
+                                                     const float* __restrict__ gxn, const float* __restrict__ gvn,
+                                                     const float* __restrict__ gCn, const float* __restrict__ gFn,
+                                                     const float4* __restrict__ gv, float4* __restrict__ gg,
+                                                     float* __restrict__ gx, float* __restrict__ gF) {
   __shared__ ScatterLds L;
   const float kap = 4.0f * K.inv_dx * K.inv_dx;
+  const int p = blockIdx.x * NM_SC_T + threadIdx.x;
+  G2pBwdP q;
+  const bool active = g2p_bwd_particle(K, n, p, clip, enabled, x, F, vnext, Cnext, gxn, gvn, gCn, gFn, q);
   // (1) per-particle outputs: gF and gx (direct + through weights/dpos, gathering the forward grid velocity)
+  if (active) {
 #pragma unroll 1
-  for (int b = 0; b < NM_WT_PB; ++b) {
-    const int p = blockIdx.x * NM_WT_CHUNK + b * 64 + threadIdx.x;
-    G2pBwdP q;
-    const bool active = g2p_bwd_particle(K, n, p, clip, enabled, x, F, vnext, Cnext, gxn, gvn, gCn, gFn, q);
-    if (active) {
-#pragma unroll 1
-      for (int i = 0; i < 3; ++i) {
-        float d0 = ((float)i - q.st.f[0]) * K.dx;
-        const float w0i = sel3(q.st.w[0], i), dw0i = sel3(q.st.dw[0], i);
+    for (int i = 0; i < 3; ++i) {
+      float d0 = ((float)i - q.st.f[0]) * K.dx;
+      const float w0i = sel3(q.st.w[0], i), dw0i = sel3(q.st.dw[0], i);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          float d1 = ((float)j - q.st.f[1]) * K.dx;
+      for (int j = 0; j < 3; ++j) {
+        float d1 = ((float)j - q.st.f[1]) * K.dx;
 #pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            float d2 = ((float)k - q.st.f[2]) * K.dx;
-            float w = w0i * q.st.w[1][j] * q.st.w[2][k];
-            float4 gn = gv[node_addr(q.st.b[0] + i, q.st.b[1] + j, q.st.b[2] + k, K.nb)];
-            const M3& Ct = q.Ct;
-            float c0_ = Ct.m[0] * d0 + Ct.m[1] * d1 + Ct.m[2] * d2;
-            float c1_ = Ct.m[3] * d0 + Ct.m[4] * d1 + Ct.m[5] * d2;
-            float c2_ = Ct.m[6] * d0 + Ct.m[7] * d1 + Ct.m[8] * d2;
-            float kw = kap * w;
-            float dLdw = q.vt[0] * gn.x + q.vt[1] * gn.y + q.vt[2] * gn.z + kap * (gn.x * c0_ + gn.y * c1_ + gn.z * c2_);
-            float gw0 = dw0i * q.st.w[1][j] * q.st.w[2][k] * K.inv_dx;
-            float gw1 = w0i * q.st.dw[1][j] * q.st.w[2][k] * K.inv_dx;
-            float gw2 = w0i * q.st.w[1][j] * q.st.dw[2][k] * K.inv_dx;
-            float t0 = Ct.m[0] * gn.x + Ct.m[3] * gn.y + Ct.m[6] * gn.z;
-            float t1 = Ct.m[1] * gn.x + Ct.m[4] * gn.y + Ct.m[7] * gn.z;
-            float t2 = Ct.m[2] * gn.x + Ct.m[5] * gn.y + Ct.m[8] * gn.z;
-            q.xbar[0] += dLdw * gw0 - kw * t0;
-            q.xbar[1] += dLdw * gw1 - kw * t1;
-            q.xbar[2] += dLdw * gw2 - kw * t2;
-          }
+        for (int k = 0; k < 3; ++k) {
+          float d2 = ((float)k - q.st.f[2]) * K.dx;
+          float w = w0i * q.st.w[1][j] * q.st.w[2][k];
+          float4 gn = gv[node_addr(q.st.b[0] + i, q.st.b[1] + j, q.st.b[2] + k, K.nb)];
+          const M3& Ct = q.Ct;
+          float c0_ = Ct.m[0] * d0 + Ct.m[1] * d1 + Ct.m[2] * d2;
+          float c1_ = Ct.m[3] * d0 + Ct.m[4] * d1 + Ct.m[5] * d2;
+          float c2_ = Ct.m[6] * d0 + Ct.m[7] * d1 + Ct.m[8] * d2;
+          float kw = kap * w;
+          float dLdw = q.vt[0] * gn.x + q.vt[1] * gn.y + q.vt[2] * gn.z + kap * (gn.x * c0_ + gn.y * c1_ + gn.z * c2_);
+          float gw0 = dw0i * q.st.w[1][j] * q.st.w[2][k] * K.inv_dx;
+          float gw1 = w0i * q.st.dw[1][j] * q.st.w[2][k] * K.inv_dx;
+          float gw2 = w0i * q.st.w[1][j] * q.st.dw[2][k] * K.inv_dx;
+          float t0 = Ct.m[0] * gn.x + Ct.m[3] * gn.y + Ct.m[6] * gn.z;
+          float t1 = Ct.m[1] * gn.x + Ct.m[4] * gn.y + Ct.m[7] * gn.z;
+          float t2 = Ct.m[2] * gn.x + Ct.m[5] * gn.y + Ct.m[8] * gn.z;
+          q.xbar[0] += dLdw * gw0 - kw * t0;
+          q.xbar[1] += dLdw * gw1 - kw * t1;
+          q.xbar[2] += dLdw * gw2 - kw * t2;
         }
       }
     }
-    if (p < n) {
-#pragma unroll
-      for (int a = 0; a < 3; ++a) gx[3 * p + a] = q.xbar[a];
-      m3_store(gF + 9 * p, q.Fbar);
-    }
   }
-  // (2) scatter of the node-velocity adjoint; staged record: x(3) | vt(3) - | Ct(9)
-  auto stage = [&](int p, float* rec) {
-    G2pBwdP q;
-    g2p_bwd_particle(K, n, p, clip, enabled, x, F, vnext, Cnext, gxn, gvn, gCn, gFn, q);
+  if (p < n) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { rec[a] = x[3 * p + a]; rec[3 + a] = q.vt[a]; }
-    rec[6] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) rec[7 + i] = q.Ct.m[i];
-  };
-  auto contrib = [&](const Stencil& st, const float* rec, int i, int j, int k) -> float4 {
-    float d0 = ((float)i - st.f[0]) * K.dx, d1 = ((float)j - st.f[1]) * K.dx, d2 = ((float)k - st.f[2]) * K.dx;
-    float w = st.w[0][i] * st.w[1][j] * st.w[2][k];
+    for (int a = 0; a < 3; ++a) gx[3 * p + a] = q.xbar[a];
+    m3_store(gF + 9 * p, q.Fbar);
+  }
+  // (2) scatter of the node-velocity adjoint
+  auto contrib = [&](int i, int j, int k) -> float4 {
+    float d0 = ((float)i - q.st.f[0]) * K.dx, d1 = ((float)j - q.st.f[1]) * K.dx, d2 = ((float)k - q.st.f[2]) * K.dx;
+    float w = sel3(q.st.w[0], i) * q.st.w[1][j] * q.st.w[2][k];
     float kw = kap * w;
-    float c0_ = rec[7] * d0 + rec[8] * d1 + rec[9] * d2;
-    float c1_ = rec[10] * d0 + rec[11] * d1 + rec[12] * d2;
-    float c2_ = rec[13] * d0 + rec[14] * d1 + rec[15] * d2;
-    return make_float4(w * rec[3] + kw * c0_, w * rec[4] + kw * c1_, w * rec[5] + kw * c2_, 0.f);
+    float c0_ = q.Ct.m[0] * d0 + q.Ct.m[1] * d1 + q.Ct.m[2] * d2;
+    float c1_ = q.Ct.m[3] * d0 + q.Ct.m[4] * d1 + q.Ct.m[5] * d2;
+    float c2_ = q.Ct.m[6] * d0 + q.Ct.m[7] * d1 + q.Ct.m[8] * d2;
+    return make_float4(w * q.vt[0] + kw * c0_, w * q.vt[1] + kw * c1_, w * q.vt[2] + kw * c2_, 0.f);
   };
-  wave_scatter<3>(K, n, enabled, x, gg, nullptr, nullptr, nullptr, 0, L, stage, contrib);
+  wg_scatter<3>(K, active, q.st.b, gg, nullptr, nullptr, nullptr, 0, L, contrib);
 }
 
 // adjoint of p2g: gathers {mvbar, mbar}; writes gv, gC, gS and adds to gx
@@ -834,8 +750,6 @@ extern "C" int nm_mpm_create(const nm_mpm_cfg* cfg, nm_mpm** out) {
   K.bound = cfg->bound;
   K.bc = cfg->bc;
   K.dbg = getenv("NM_DBG") ? atoi(getenv("NM_DBG")) : 0;
-  K.dbg_buf = nullptr;
-  if (K.dbg & 8) { NM_HIP_CHECK(hipMalloc(&K.dbg_buf, 4096 * 4 * sizeof(long long))); NM_HIP_CHECK(hipMemset(K.dbg_buf, 0, 4096 * 4 * sizeof(long long))); }
   h->nblocks = K.nb * K.nb * K.nb;
   size_t nodes = (size_t)h->nblocks * 64;
   h->gm = h->gv = h->gg = nullptr;
@@ -878,7 +792,7 @@ static int mpm_build_grid(nm_mpm* h, int n, const nm_statics* st, const nm_parti
                      h->count + now);
   NM_LAUNCH_CHECK();
   if (n > 0) {
-    NM_LAUNCH(k_p2g, dim3(nm_div_up(n, NM_WT_CHUNK)), dim3(64), 0, s, h->k, n, st->vol, st->rho, st->enabled, cur->x,
+    NM_LAUNCH(k_p2g, dim3(nm_div_up(n, NM_SC_T)), dim3(NM_SC_T), 0, s, h->k, n, st->vol, st->rho, st->enabled, cur->x,
                        cur->v, cur->C, cur->stress, h->gm, h->flags, h->list[now], h->count + now, h->epoch);
     NM_LAUNCH_CHECK();
   }
@@ -952,7 +866,7 @@ extern "C" int nm_mpm_backward(nm_mpm* h, int32_t n, const nm_statics* st, const
   if (n == 0) return NM_OK;
   const int now = h->cur;
   const int nwg = nm_div_up(n, 256);
-  NM_LAUNCH(k_g2p_bwd, dim3(nm_div_up(n, NM_WT_CHUNK)), dim3(64), 0, s, h->k, n, st->clip_bound, st->enabled, cur->x, cur->F, next->v,
+  NM_LAUNCH(k_g2p_bwd, dim3(nm_div_up(n, NM_SC_T)), dim3(NM_SC_T), 0, s, h->k, n, st->clip_bound, st->enabled, cur->x, cur->F, next->v,
                      next->C, gnext->x, gnext->v, gnext->C, gnext->F, h->gv, h->gg, gcur->x, gcur->F);
   NM_LAUNCH_CHECK();
   NM_LAUNCH(k_grid_op_bwd, dim3(kSweepGrid), dim3(256), 0, s, h->k, h->gm, h->gg, h->list[now], h->count + now);
@@ -975,13 +889,6 @@ extern "C" int nm_mpm_grid_stats(nm_mpm* h, int32_t* active_blocks, int32_t* nod
   NM_HIP_CHECK(hipStreamSynchronize(s));
   if (active_blocks) *active_blocks = host[0];
   if (nodes_with_mass) *nodes_with_mass = host[1];
-  return NM_OK;
-}
-
-extern "C" int nm_mpm_debug_fetch(nm_mpm* h, long long* host, int n) {
-  if (!h->k.dbg_buf) return NM_ERR_INVALID;
-  NM_HIP_CHECK(hipDeviceSynchronize());
-  NM_HIP_CHECK(hipMemcpy(host, h->k.dbg_buf, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost));
   return NM_OK;
 }
 

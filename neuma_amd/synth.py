@@ -27,7 +27,19 @@ def stencil_order(P: np.ndarray, G: int) -> np.ndarray:
     results — this one is the fast one (a load-time sort like the reference's `sort` option, mpm.py:640-642)."""
     base = np.trunc(P.astype(np.float64) * G - 0.5).astype(np.int64)
     blk = base // 4
-    key = ((blk[:, 0] * 4096 + blk[:, 1]) * 4096 + blk[:, 2]) * 64 + ((base[:, 0] % 4) * 16 + (base[:, 1] % 4) * 4 + base[:, 2] % 4)
+
+    def spread(v):  # Morton bit spread of a 10-bit integer
+        v = v & 0x3FF
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        v = (v | (v << 2)) & 0x09249249
+        return v
+
+    # blocks along a Morton (Z-order) curve: any run of consecutive particles stays compact in all three axes, so the
+    # scatter kernels' per-workgroup tiles stay small (row-major block order breaks at every row end)
+    morton = (spread(blk[:, 0]) << 2) | (spread(blk[:, 1]) << 1) | spread(blk[:, 2])
+    key = morton * 64 + ((base[:, 0] % 4) * 16 + (base[:, 1] % 4) * 4 + base[:, 2] % 4)
     return np.argsort(key, kind="stable")
 
 
