@@ -16,6 +16,19 @@
 #include "nm_common.h"
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+#ifdef NM_PHASES
+__device__ long long g_nm_phase[8 * 2048];
+extern "C" int nm_debug_phases(long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nm_phase), (size_t)n * sizeof(long long)) == hipSuccess ? 0 : -2;
+}
+#define NM_PH_DECL long long ph_t0 = clock64(); long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define NM_PH(i) { long long t1 = clock64(); ph[i] += t1 - ph_t0; ph_t0 = t1; }
+#define NM_PH_STORE if ((threadIdx.x & 63) == 0) { int w = blockIdx.x * 4 + (threadIdx.x >> 6); if (w < 2048) for (int i = 0; i < 8; ++i) g_nm_phase[w * 8 + i] = ph[i]; }
+#else
+#define NM_PH_DECL
+#define NM_PH(i)
+#define NM_PH_STORE
+#endif
 #define NM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 #define NM_W0 (64 * 13)
@@ -23,9 +36,32 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #define NM_W2 (9 * 64)
 #define NM_WTOT (NM_W0 + NM_W1 + NM_W2)
 
-__device__ __forceinline__ float nm_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float nm_gelu_grad(float x) {
-  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+// Standard normal cdf Phi(x) and pdf phi(x) sharing ONE exponential: Abramowitz-Stegun 7.1.26 writes
+// erf(z) = 1 - poly(t) e^{-z^2}, t = 1/(1 + p z) (|error| <= 1.5e-7, the fp32 rounding level), and with z = |x|/sqrt2
+// the factor e^{-z^2} = e^{-x^2/2} is sqrt(2 pi) phi(x).  ~16 VALU instructions for GELU value AND derivative, against
+// ~3 erff + 1 expf library calls (the constitutive kernels are VALU-bound on exactly this).
+__device__ __forceinline__ void nm_phi(float x, float& Phi, float& phi) {
+  const float ax = fabsf(x);
+  const float e = __expf(-0.5f * x * x);
+  const float t = __frcp_rn(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.0f));
+  float poly = fmaf(t, 1.061405429f, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float half_tail = 0.5f * poly * t * e;      // 0.5 * erfc(|x|/sqrt2)
+  Phi = x >= 0.f ? 1.0f - half_tail : half_tail;
+  phi = 0.3989422804014327f * e;
+}
+__device__ __forceinline__ float nm_gelu(float x) {   // exact-erf GELU of material/utils.py:16-17
+  float P, p;
+  nm_phi(x, P, p);
+  return x * P;
+}
+__device__ __forceinline__ void nm_gelu_both(float x, float& h, float& dh) {
+  float P, p;
+  nm_phi(x, P, p);
+  h = x * P;
+  dh = fmaf(x, p, P);
 }
 
 // ---------------------------------------------------------------- standalone SVD operator
@@ -101,8 +137,18 @@ extern "C" int nm_svd3_bwd(int32_t n, const float* U, const float* sigma, const 
 //   Q2[(ks*4+rt)*64 + l]            = W2[4ks + (l>>4)][16rt + (l&15)]             (row >= 9 -> 0), ks < 3
 //   Q1[((rtp*4+reg)*4+rt)*64 + l]   = W1[16rtp + 4(l>>4) + reg][16rt + (l&15)]
 //   Q0[(rtp*4+reg)*64 + l]          = W0[16rtp + 4(l>>4) + reg][l&15]             (col >= 13 -> 0)
-__device__ __forceinline__ void stage_fwd_weights(const float* __restrict__ w0, const float* __restrict__ w1,
-                                                  const float* __restrict__ w2, float* P0, float* P1, float* P2) {
+// Raw weights are first copied to LDS with coalesced loads (w0 | w1 | w2 back to back, NM_WTOT floats), then permuted
+// LDS -> LDS into MFMA operand order (a direct permuting gather from global costs ~12k cycles per workgroup: 64
+// scattered 4-byte reads per wave-instruction).
+__device__ __forceinline__ void stage_raw_weights(const float* __restrict__ w0, const float* __restrict__ w1,
+                                                  const float* __restrict__ w2, float* raw) {
+  const int tid = threadIdx.x;
+  for (int i = tid; i < NM_W0; i += blockDim.x) raw[i] = w0[i];
+  for (int i = tid; i < NM_W1 / 4; i += blockDim.x) reinterpret_cast<float4*>(raw + NM_W0)[i] = reinterpret_cast<const float4*>(w1)[i];
+  for (int i = tid; i < NM_W2; i += blockDim.x) raw[NM_W0 + NM_W1 + i] = w2[i];
+}
+__device__ __forceinline__ void stage_fwd_weights(const float* raw, float* P0, float* P1, float* P2) {
+  const float *w0 = raw, *w1 = raw + NM_W0, *w2 = raw + NM_W0 + NM_W1;
   const int tid = threadIdx.x;
   for (int idx = tid; idx < 16 * 64; idx += blockDim.x) {
     int l = idx & 63, op = idx >> 6, ks = op >> 2, rt = op & 3, k = 4 * ks + (l >> 4);
@@ -115,8 +161,8 @@ __device__ __forceinline__ void stage_fwd_weights(const float* __restrict__ w0, 
     P1[idx] = w1[(16 * rt + (l & 15)) * 64 + 16 * rtp + 4 * (l >> 4) + reg];
   }
 }
-__device__ __forceinline__ void stage_bwd_weights(const float* __restrict__ w0, const float* __restrict__ w1,
-                                                  const float* __restrict__ w2, float* Q0, float* Q1, float* Q2) {
+__device__ __forceinline__ void stage_bwd_weights(const float* raw, float* Q0, float* Q1, float* Q2) {
+  const float *w0 = raw, *w1 = raw + NM_W0, *w2 = raw + NM_W0 + NM_W1;
   const int tid = threadIdx.x;
   for (int idx = tid; idx < 12 * 64; idx += blockDim.x) {
     int l = idx & 63, op = idx >> 6, ks = op >> 2, rt = op & 3, row = 4 * ks + (l >> 4);
@@ -143,11 +189,13 @@ __device__ __forceinline__ void nm_features(const M3& F, float z[13], M3& R, M3&
   z[12] = m3_det(F) - 1.f;
 }
 
-// three-layer MLP on one 16-particle column tile; B operand of layer 0 comes from zrow (LDS, [particle][17])
+// three-layer MLP on one 16-particle column tile; B operand of layer 0 comes from zrow (LDS, [particle][17]).
+// WITH_GRAD additionally keeps the hidden activations and GELU derivatives for the backward pass.
 struct MlpFwd {
-  f4 pre1[4], pre2[4];
+  f4 h1[4], h2[4], g1[4], g2[4];
   f4 y;
 };
+template <bool WITH_GRAD>
 __device__ __forceinline__ void mlp_forward_tile(const float* __restrict__ P0, const float* __restrict__ P1,
                                                  const float* __restrict__ P2, const float* __restrict__ zt, int lane,
                                                  MlpFwd& o) {
@@ -160,25 +208,41 @@ __device__ __forceinline__ void mlp_forward_tile(const float* __restrict__ P0, c
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) a1[rt] = NM_MFMA(P0[(ks * 4 + rt) * 64 + lane], b, a1[rt]);
   }
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float h, dh;
+      nm_gelu_both(a1[rt][r], h, dh);
+      o.h1[rt][r] = h;
+      if (WITH_GRAD) o.g1[rt][r] = dh;
+    }
   f4 a2[4] = {zero, zero, zero, zero};
 #pragma unroll
   for (int rtp = 0; rtp < 4; ++rtp)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-      float b = nm_gelu(a1[rtp][reg]);
+      float b = o.h1[rtp][reg];
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) a2[rt] = NM_MFMA(P1[((rtp * 4 + reg) * 4 + rt) * 64 + lane], b, a2[rt]);
+    }
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float h, dh;
+      nm_gelu_both(a2[rt][r], h, dh);
+      o.h2[rt][r] = h;
+      if (WITH_GRAD) o.g2[rt][r] = dh;
     }
   f4 ya = zero, yb = zero;
 #pragma unroll
   for (int rtp = 0; rtp < 4; ++rtp)
 #pragma unroll
     for (int reg = 0; reg < 4; reg += 2) {
-      ya = NM_MFMA(P2[(rtp * 4 + reg) * 64 + lane], nm_gelu(a2[rtp][reg]), ya);
-      yb = NM_MFMA(P2[(rtp * 4 + reg + 1) * 64 + lane], nm_gelu(a2[rtp][reg + 1]), yb);
+      ya = NM_MFMA(P2[(rtp * 4 + reg) * 64 + lane], o.h2[rtp][reg], ya);
+      yb = NM_MFMA(P2[(rtp * 4 + reg + 1) * 64 + lane], o.h2[rtp][reg + 1], yb);
     }
-#pragma unroll
-  for (int rt = 0; rt < 4; ++rt) { o.pre1[rt] = a1[rt]; o.pre2[rt] = a2[rt]; }
   o.y = ya + yb;
 }
 
@@ -188,10 +252,17 @@ __global__ void __launch_bounds__(256) k_material_fwd(int n, float alpha, const 
                                                       const float* __restrict__ w0, const float* __restrict__ w1,
                                                       const float* __restrict__ w2, float* __restrict__ out) {
   __shared__ float sP0[16 * 64], sP1[64 * 64], sP2[16 * 64];
-  __shared__ float sZ[4][64 * 17];
-  __shared__ float sY[4][64 * 9];
-  stage_fwd_weights(w0, w1, w2, sP0, sP1, sP2);
+  // per-wave buffers (features 64x17, outputs 64x9); before the main loop the same memory holds the raw weights
+  __shared__ __attribute__((aligned(16))) float sBuf[4 * 64 * 17 + 4 * 64 * 9];
+  static_assert(4 * 64 * 17 + 4 * 64 * 9 >= NM_WTOT, "raw weights must fit the per-wave buffers");
+  float (*sZ)[64 * 17] = reinterpret_cast<float (*)[64 * 17]>(sBuf);
+  float (*sY)[64 * 9] = reinterpret_cast<float (*)[64 * 9]>(sBuf + 4 * 64 * 17);
+  NM_PH_DECL
+  stage_raw_weights(w0, w1, w2, sBuf);
   __syncthreads();
+  stage_fwd_weights(sBuf, sP0, sP1, sP2);
+  __syncthreads();
+  NM_PH(0)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int j = lane & 15, g = lane >> 4;
   const int nbatch = (n + 63) >> 6;
@@ -208,10 +279,11 @@ __global__ void __launch_bounds__(256) k_material_fwd(int n, float alpha, const 
     for (int c = 0; c < 13; ++c) zb[lane * 17 + c] = z[c];
     zb[lane * 17 + 13] = 0.f; zb[lane * 17 + 14] = 0.f; zb[lane * 17 + 15] = 0.f;
     __builtin_amdgcn_wave_barrier();
-#pragma unroll 1
-    for (int ct = 0; ct < 4; ++ct) {
+    NM_PH(1)
+#pragma unroll 2
+    for (int ct = 0; ct < 4; ++ct) {   // two column tiles per trip: one tile's GELU (VALU) can overlap the other's MFMAs
       MlpFwd m;
-      mlp_forward_tile(sP0, sP1, sP2, zb + ct * 16 * 17, lane, m);
+      mlp_forward_tile<false>(sP0, sP1, sP2, zb + ct * 16 * 17, lane, m);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int row = 4 * g + r;
@@ -219,6 +291,7 @@ __global__ void __launch_bounds__(256) k_material_fwd(int n, float alpha, const 
       }
     }
     __builtin_amdgcn_wave_barrier();
+    NM_PH(2)
     M3 X;
 #pragma unroll
     for (int i = 0; i < 9; ++i) X.m[i] = yb[lane * 9 + i];
@@ -236,7 +309,9 @@ __global__ void __launch_bounds__(256) k_material_fwd(int n, float alpha, const 
     }
     if (valid) m3_store(out + 9 * p, o);
     __builtin_amdgcn_wave_barrier();
+    NM_PH(3)
   }
+  NM_PH_STORE
 }
 
 extern "C" int nm_material_fwd(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, float* out,
@@ -276,9 +351,14 @@ __global__ void __launch_bounds__(256, 1) k_material_bwd(int n, float alpha, con
                                                          float* __restrict__ gF, float* __restrict__ wpart, int want_w) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   BwdLds& L = *reinterpret_cast<BwdLds*>(smem_raw);
-  stage_fwd_weights(w0, w1, w2, L.P0, L.P1, L.P2);
-  stage_bwd_weights(w0, w1, w2, L.Q0, L.Q1, L.Q2);
-  __syncthreads();
+  {
+    float* raw = &L.Z[0][0];   // the per-wave buffers (>= 22 016 floats) are free until the main loop
+    stage_raw_weights(w0, w1, w2, raw);
+    __syncthreads();
+    stage_fwd_weights(raw, L.P0, L.P1, L.P2);
+    stage_bwd_weights(raw, L.Q0, L.Q1, L.Q2);
+    __syncthreads();
+  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int j = lane & 15, g = lane >> 4;
   const int nbatch = (n + 63) >> 6;
@@ -325,7 +405,7 @@ __global__ void __launch_bounds__(256, 1) k_material_bwd(int n, float alpha, con
 #pragma unroll 1
     for (int ct = 0; ct < 4; ++ct) {
       MlpFwd m;
-      mlp_forward_tile(L.P0, L.P1, L.P2, zb + ct * 16 * 17, lane, m);
+      mlp_forward_tile<true>(L.P0, L.P1, L.P2, zb + ct * 16 * 17, lane, m);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int row = 4 * g + r;
@@ -337,7 +417,7 @@ __global__ void __launch_bounds__(256, 1) k_material_bwd(int n, float alpha, con
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) tb[(16 * rt + 4 * g + r) * 17 + j] = nm_gelu(m.pre2[rt][r]);
+          for (int r = 0; r < 4; ++r) tb[(16 * rt + 4 * g + r) * 17 + j] = m.h2[rt][r];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -358,7 +438,7 @@ __global__ void __launch_bounds__(256, 1) k_material_bwd(int n, float alpha, con
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) d2[rt][r] *= nm_gelu_grad(m.pre2[rt][r]);
+        for (int r = 0; r < 4; ++r) d2[rt][r] *= m.g2[rt][r];
       // (c) W1bar += pre2bar h1^T
       if (want_w) {
 #pragma unroll
@@ -366,7 +446,7 @@ __global__ void __launch_bounds__(256, 1) k_material_bwd(int n, float alpha, con
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             ta[(16 * rt + 4 * g + r) * 17 + j] = d2[rt][r];
-            tb[(16 * rt + 4 * g + r) * 17 + j] = nm_gelu(m.pre1[rt][r]);
+            tb[(16 * rt + 4 * g + r) * 17 + j] = m.h1[rt][r];
           }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -396,7 +476,7 @@ __global__ void __launch_bounds__(256, 1) k_material_bwd(int n, float alpha, con
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) d1[rt][r] *= nm_gelu_grad(m.pre1[rt][r]);
+        for (int r = 0; r < 4; ++r) d1[rt][r] *= m.g1[rt][r];
       // (e) W0bar += pre1bar z^T : B[particle][z idx] straight from zb ([particle][17])
       if (want_w) {
 #pragma unroll

@@ -1,0 +1,127 @@
+"""GPU parity at BASELINE.json's full sizes through size-independent properties (the oracle is too slow there):
+conservation, frame indifference, linearity, stripe/stencil-order invariance.  All through the C ABI."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import dev, rel_max, abs_max
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def scene():
+    from neuma_amd import synth
+    return synth.make_scene("metric")          # 100k particles / 128^3 / 200k Gaussians / 1920x1080
+
+
+@pytest.fixture(scope="module")
+def rt(scene):
+    from neuma_amd.harness import SceneRuntime
+    return SceneRuntime(scene, dev(), fused=True)
+
+
+def test_p2g_conserves_mass_and_momentum_at_100k(rt):
+    from neuma_amd.sim import MPMDiffSim
+    N = rt.N
+    g = torch.Generator().manual_seed(0)
+    v = torch.randn(N, 3, generator=g).to(dev())
+    zero = torch.zeros(N, 3, 3, device=dev())
+    with torch.no_grad():
+        MPMDiffSim(rt.model)(rt.statics, rt.x0, v, zero, rt.F0, zero)     # stress = 0, C = 0: pure mass / momentum transfer
+    mv, m, vg = rt.model.grid_export()
+    pm = (rt.statics.vol * rt.statics.rho).double()
+    assert abs(float(m.double().sum()) - float(pm.sum())) < 1e-5 * float(pm.sum())
+    ref = (pm[:, None] * v.double()).sum(0)
+    assert float((mv.double().sum((0, 1, 2)) - ref).abs().max()) < 1e-4 * float(pm.sum())
+    nb, nm = rt.model.grid_stats()
+    assert 15_000 < nm < 25_000 and nb * 64 >= nm         # ~18k touched nodes out of 2.1M
+
+
+def test_step_is_invariant_under_particle_order_at_100k(rt):
+    """Stencil-sorted vs randomly permuted input: same physics up to fp32 summation order."""
+    from neuma_amd.sim import MPMDiffSim
+    N = rt.N
+    g = torch.Generator().manual_seed(1)
+    v = (0.3 * torch.randn(N, 3, generator=g)).to(dev())
+    C = (0.5 * torch.randn(N, 3, 3, generator=g)).to(dev())
+    F = (torch.eye(3) + 0.05 * torch.randn(N, 3, 3, generator=g)).to(dev())
+    S = (100.0 * torch.randn(N, 3, 3, generator=g)).to(dev())
+    sim = MPMDiffSim(rt.model)
+    with torch.no_grad():
+        a = sim(rt.statics, rt.x0, v, C, F, S)
+        a = [t.clone() for t in a]
+        perm = torch.randperm(N, generator=g).to(dev())
+        b = sim(rt.statics, rt.x0[perm].contiguous(), v[perm].contiguous(), C[perm].contiguous(), F[perm].contiguous(),
+                S[perm].contiguous())
+    for x, y, tol in zip(a, b, [5e-7, 2e-5, 5e-5, 5e-6]):
+        assert abs_max(x[perm], y) < tol * max(1.0, float(x.abs().max()))
+
+
+def test_constitutive_nets_are_frame_indifferent_at_100k(rt):
+    """stress(QF) = Q stress(F) Q^T and plasticity(QF) = Q plasticity(F) for a rotation Q (invariants of meta.py:204-213)."""
+    N = rt.N
+    g = torch.Generator().manual_seed(2)
+    F = (torch.eye(3) + 0.08 * torch.randn(N, 3, 3, generator=g)).to(dev())
+    A = torch.randn(3, 3, generator=g, dtype=torch.float64)
+    Q, _ = torch.linalg.qr(A)
+    if torch.linalg.det(Q) < 0:
+        Q[:, 0] *= -1
+    Q = Q.float().to(dev())
+    with torch.no_grad():
+        s, sq = rt.elasticity(F), rt.elasticity(Q @ F)
+        p, pq = rt.plasticity(F), rt.plasticity(Q @ F)
+    assert rel_max(sq, Q @ s @ Q.T) < 2e-4
+    assert abs_max(pq, Q @ p) < 2e-6
+
+
+def test_render_1080p_stripes_background_linearity_and_gradient_consistency(rt):
+    from neuma_amd.tune import compute_bindings_xyz, compute_bindings_F
+    with torch.no_grad():
+        means = compute_bindings_xyz(rt.x0 + 0.001, rt.x0, rt.gaussians.get_xyz, rt.bindings)
+        dg = compute_bindings_F(rt.F0, rt.bindings)
+    m = means.clone().requires_grad_(True)
+    full = rt.render_view(m, dg, 0)
+    H = full.shape[1]
+    rows = rt.tile_rows
+    gw = torch.randn(full.shape, generator=torch.Generator().manual_seed(3)).to(dev())
+    (gfull,) = torch.autograd.grad((full * gw).sum(), m)
+    acc = torch.zeros_like(full)
+    gacc = torch.zeros_like(gfull)
+    for r0, r1 in [(0, rows // 3), (rows // 3, rows // 2), (rows // 2, rows)]:
+        part = rt.render_view(m, dg, 0, tile_rows=(r0, r1))
+        y0, y1 = r0 * 16, min(H, r1 * 16)
+        assert torch.equal(part[:, y0:y1], full[:, y0:y1])
+        acc += part.detach()
+        (gp,) = torch.autograd.grad((part * gw).sum(), m)
+        gacc += gp
+    assert torch.equal(acc, full.detach())
+    assert rel_max(gacc, gfull) < 1e-4
+    # out = C + T_final * bg is affine in the background colour
+    bg0 = rt.background
+    rt.background = torch.zeros(3, device=dev()); black = rt.render_view(means, dg, 0)
+    rt.background = torch.full((3,), 0.5, device=dev()); grey = rt.render_view(means, dg, 0)
+    rt.background = bg0
+    assert abs_max(grey, 0.5 * (black + full.detach())) < 2e-6
+    assert float(full.min()) >= 0.0 and torch.isfinite(full).all() and torch.isfinite(gfull).all()
+
+
+def test_fused_rollout_matches_per_operator_path_at_100k(rt):
+    S = 3
+    rt.sim_fused.substeps = S
+    old = rt.S
+    rt.S = S
+    try:
+        with torch.no_grad():
+            rt.fused = True
+            a = [t.clone() for t in rt.rollout(rt.x0, rt.v0, rt.C0, rt.F0)]
+            rt.fused = False
+            b = rt.rollout(rt.x0, rt.v0, rt.C0, rt.F0)
+        for x, y, tol in zip(a, b, [1e-6, 1e-5, 1e-3, 1e-5]):
+            assert abs_max(x, y) < tol * max(1.0, float(y.abs().max()))
+    finally:
+        rt.S = old
+        rt.sim_fused.substeps = old
+        rt.fused = True
