@@ -153,9 +153,10 @@ int nm_material_bwd_ex(int32_t n, int32_t kind, float alpha, const float* F, con
 /* S substeps of   stress = E(F); (x,v,C,F) = sim(x,v,C,F,stress); F = P(F)   (finetune.py:362-364,
  * render.py:305-309) enqueued natively, so the host pays one call per video frame instead of three
  * autograd nodes per substep.  `states` is a caller-owned checkpoint buffer of (S+1) records; record t
- * holds x (N,3) | v (N,3) | C (N,9) | F (N,9) contiguously (24*N floats).  Record 0 is the input,
- * records 1..S are written.  Nothing else is kept: the backward pass recomputes stress, the trial F and
- * the grid from the checkpoints (96 B/particle/substep instead of the reference's ~3.5 KB). */
+ * holds x (N,3) | v (N,3) | C (N,9) | F (N,9) | stress (N,9) contiguously (33*N floats; stress = E(F) of that
+ * record, written by the forward pass for t < S).  The caller fills x,v,C,F of record 0; records 1..S are
+ * written.  Nothing else is kept: the backward pass recomputes the trial F, the grid and all MLP activations
+ * from the checkpoints (132 B/particle/substep instead of the reference's ~3.5 KB). */
 typedef struct nm_rollout_cfg {
   int32_t substeps;
   float plasticity_alpha;
@@ -164,7 +165,7 @@ size_t nm_rollout_workspace(int32_t n, int32_t substeps);
 int nm_rollout_forward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cfg, const nm_statics* st,
                        const nm_mlp* elasticity, const nm_mlp* plasticity, float* states,
                        void* workspace, size_t workspace_bytes, void* stream);
-/* gstate_last: dL/d(record S) (24*N floats, same layout); gstate_first: dL/d(record 0) (written);
+/* gstate_last: dL/d(x,v,C,F of record S) (24*N floats: x|v|C|F); gstate_first: dL/d(x,v,C,F of record 0) (written);
  * gw_e / gw_p: 5504 floats each = dL/d(w0 | w1 | w2) of the elasticity / plasticity nets, summed over
  * particles and substeps (overwritten). */
 int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cfg, const nm_statics* st,

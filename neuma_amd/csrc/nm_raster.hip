@@ -10,7 +10,8 @@
 //     gradients over its 64 lanes with DPP row operations (no LDS traffic), waves combine through
 //     ds_add_f32 into a per-batch LDS table, and one thread per Gaussian flushes the tile total with global
 //     atomics (one set per (tile, Gaussian) pair instead of one per (pixel, Gaussian));
-//   * (tile, depth) ordering uses rocPRIM's device radix sort on 32 + log2(tiles) key bits.
+//   * (tile, depth) ordering: Gaussians are depth-sorted once (K keys), pairs are emitted in that order and a STABLE
+//     rocPRIM radix sort on the log2(tiles) tile bits alone finishes the job (2 passes over D instead of 6 over 64-bit keys).
 #include "nm_common.h"
 
 #include <rocprim/rocprim.hpp>
@@ -50,12 +51,20 @@ static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Geom {
   float2* xy; float* depth; float4* conop; float* rgb; uint32_t* clamped; uint32_t* tiles; uint32_t* offs; int* rad;
-  void* scan_tmp; size_t scan_bytes; size_t total;
+  uint32_t* order;                                 // Gaussian ids sorted by (depth, id); culled ones last
+  uint32_t *dkey_in, *dkey_out, *dval_in, *tiles_sorted;
+  void* scan_tmp; size_t scan_bytes; void* dsort_tmp; size_t dsort_bytes; size_t total;
 };
 static size_t scan_temp_bytes(int k) {
   size_t b = 0;
   (void)rocprim::inclusive_scan(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)(k > 0 ? k : 1),
                                 rocprim::plus<uint32_t>());
+  return b;
+}
+static size_t dsort_temp_bytes(int k) {
+  size_t b = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                  (size_t)(k > 0 ? k : 1), 0u, 32u);
   return b;
 }
 static Geom carve_geom(void* base, int k) {
@@ -68,8 +77,15 @@ static Geom carve_geom(void* base, int k) {
   g.tiles = (uint32_t*)(p + o); o += al256(K * sizeof(uint32_t));
   g.offs = (uint32_t*)(p + o); o += al256(K * sizeof(uint32_t));
   g.rad = (int*)(p + o); o += al256(K * sizeof(int));
+  g.order = (uint32_t*)(p + o); o += al256(K * sizeof(uint32_t));
+  g.dkey_in = (uint32_t*)(p + o); o += al256(K * sizeof(uint32_t));
+  g.dkey_out = (uint32_t*)(p + o); o += al256(K * sizeof(uint32_t));
+  g.dval_in = (uint32_t*)(p + o); o += al256(K * sizeof(uint32_t));
+  g.tiles_sorted = (uint32_t*)(p + o); o += al256(K * sizeof(uint32_t));
   g.scan_bytes = scan_temp_bytes(k);
   g.scan_tmp = (void*)(p + o); o += al256(g.scan_bytes);
+  g.dsort_bytes = dsort_temp_bytes(k);
+  g.dsort_tmp = (void*)(p + o); o += al256(g.dsort_bytes);
   g.total = o;
   return g;
 }
@@ -81,15 +97,15 @@ static Binning carve_binning(void* base, int64_t D, int ntiles) {
   b.total = o;
   return b;
 }
-struct Scratch { uint64_t* keys_in; uint64_t* keys_out; uint32_t* vals_in; void* sort_tmp; size_t sort_bytes; size_t total; };
+struct Scratch { uint32_t* keys_in; uint32_t* keys_out; uint32_t* vals_in; void* sort_tmp; size_t sort_bytes; size_t total; };
 static Scratch carve_scratch(void* base, int64_t D) {
   Scratch s; char* p = (char*)base; size_t o = 0; size_t n = (size_t)(D > 0 ? D : 1);
-  s.keys_in = (uint64_t*)(p + o); o += al256(n * sizeof(uint64_t));
-  s.keys_out = (uint64_t*)(p + o); o += al256(n * sizeof(uint64_t));
+  s.keys_in = (uint32_t*)(p + o); o += al256(n * sizeof(uint32_t));
+  s.keys_out = (uint32_t*)(p + o); o += al256(n * sizeof(uint32_t));
   s.vals_in = (uint32_t*)(p + o); o += al256(n * sizeof(uint32_t));
   size_t b = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, b, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
-                                  (uint32_t*)nullptr, n, 0u, 64u);
+  (void)rocprim::radix_sort_pairs(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                  (uint32_t*)nullptr, n, 0u, 32u);
   s.sort_bytes = b;
   s.sort_tmp = (void*)(p + o); o += al256(b);
   s.total = o;
@@ -206,12 +222,15 @@ __global__ void __launch_bounds__(256) k_preprocess(RK k, int K, const float* __
                                                     const float* __restrict__ colors, const float* __restrict__ opac,
                                                     const float* __restrict__ cov3D, int* __restrict__ radii, float2* __restrict__ xy,
                                                     float* __restrict__ depth, float4* __restrict__ conop, float* __restrict__ rgb,
-                                                    uint32_t* __restrict__ clamped, uint32_t* __restrict__ tiles, int* __restrict__ grad_) {
+                                                    uint32_t* __restrict__ clamped, uint32_t* __restrict__ tiles, int* __restrict__ grad_,
+                                                    uint32_t* __restrict__ dkey, uint32_t* __restrict__ dval) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= K) return;
   radii[i] = 0;
   grad_[i] = 0;
   tiles[i] = 0;
+  dkey[i] = 0xFFFFFFFFu;   // culled Gaussians sort last
+  dval[i] = (uint32_t)i;
   float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
   float3 pv = xf43(k.view, mx, my, mz);
   if (!(pv.z > 0.2f)) return;  // near-plane cull
@@ -279,38 +298,48 @@ __global__ void __launch_bounds__(256) k_preprocess(RK k, int K, const float* __
     for (int y = sy0; y < sy1; ++y)
       for (int x = sx0; x < sx1; ++x) cnt += tile_contributes(px, py, co, x, y) ? 1u : 0u;
     tiles[i] = cnt;
+    if (cnt) dkey[i] = __float_as_uint(pv.z);   // positive floats order like their bit patterns
   }
 }
 
-__global__ void __launch_bounds__(256) k_emit_keys(RK k, int K, const int* __restrict__ radii, const float2* __restrict__ xy,
-                                                   const float* __restrict__ depth, const float4* __restrict__ conop,
+__global__ void __launch_bounds__(256) k_gather_tiles(int K, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles,
+                                                      uint32_t* __restrict__ tiles_sorted) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < K) tiles_sorted[r] = tiles[order[r]];
+}
+
+// One thread per depth RANK: pairs are emitted already ordered by (depth, id), so the (tile, depth) order the
+// compositor needs is obtained by a STABLE sort on the tile id alone (13 key bits instead of 45).
+__global__ void __launch_bounds__(256) k_emit_keys(RK k, int K, const uint32_t* __restrict__ order, const int* __restrict__ radii,
+                                                   const float2* __restrict__ xy, const float4* __restrict__ conop,
                                                    const uint32_t* __restrict__ offs, const uint32_t* __restrict__ tiles,
-                                                   uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= K || tiles[i] == 0) return;
-  uint32_t off = (i == 0) ? 0u : offs[i - 1];
-  const uint32_t end = offs[i];
+                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= K) return;
+  const uint32_t i = order[r];
+  if (tiles[i] == 0) return;
+  uint32_t off = (r == 0) ? 0u : offs[r - 1];
+  const uint32_t end = offs[r];
   float2 p = xy[i];
   const float4 co = conop[i];
   int x0, y0, x1, y1;
   get_rect(k, p.x, p.y, radii[i], x0, y0, x1, y1, k.ty0, k.ty1);
-  uint64_t dbits = (uint64_t)__float_as_uint(depth[i]);
   for (int y = y0; y < y1; ++y)
     for (int x = x0; x < x1; ++x) {
       if (!tile_contributes(p.x, p.y, co, x, y) || off >= end) continue;  // same predicate as the count in k_preprocess
-      keys[off] = ((uint64_t)(uint32_t)(y * k.gx + x) << 32) | dbits;
-      vals[off] = (uint32_t)i;
+      keys[off] = (uint32_t)(y * k.gx + x);
+      vals[off] = i;
       ++off;
     }
 }
 
-__global__ void __launch_bounds__(256) k_tile_ranges(int64_t D, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges) {
+__global__ void __launch_bounds__(256) k_tile_ranges(int64_t D, const uint32_t* __restrict__ keys, uint2* __restrict__ ranges) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= D) return;
-  uint32_t t = (uint32_t)(keys[i] >> 32);
+  uint32_t t = keys[i];
   if (i == 0) ranges[t].x = 0;
   else {
-    uint32_t tp = (uint32_t)(keys[i - 1] >> 32);
+    uint32_t tp = keys[i - 1];
     if (t != tp) { ranges[tp].y = (uint32_t)i; ranges[t].x = (uint32_t)i; }
   }
   if (i == D - 1) ranges[t].y = (uint32_t)D;
@@ -698,10 +727,15 @@ extern "C" int nm_raster_preprocess(const nm_raster_cfg* cfg, int32_t K, int32_t
   if (geom_bytes < g.total) { nm_set_error("geom buffer too small: need %zu got %zu", g.total, geom_bytes); return NM_ERR_WORKSPACE; }
   hipStream_t s = (hipStream_t)stream;
   NM_LAUNCH(k_preprocess, dim3(nm_div_up(K, 256)), dim3(256), 0, s, k, K, means3D, shs, colors_precomp, opacities, cov3D,
-                     radii, g.xy, g.depth, g.conop, g.rgb, g.clamped, g.tiles, g.rad);
+                     radii, g.xy, g.depth, g.conop, g.rgb, g.clamped, g.tiles, g.rad, g.dkey_in, g.dval_in);
+  NM_LAUNCH_CHECK();
+  // depth order of the Gaussians (stable: ties keep index order), then tile counts / offsets in that order
+  size_t db = g.dsort_bytes;
+  NM_HIP_CHECK(rocprim::radix_sort_pairs(g.dsort_tmp, db, g.dkey_in, g.dkey_out, g.dval_in, g.order, (size_t)K, 0u, 32u, s));
+  NM_LAUNCH(k_gather_tiles, dim3(nm_div_up(K, 256)), dim3(256), 0, s, K, g.order, g.tiles, g.tiles_sorted);
   NM_LAUNCH_CHECK();
   size_t tb = g.scan_bytes;
-  NM_HIP_CHECK(rocprim::inclusive_scan(g.scan_tmp, tb, g.tiles, g.offs, (size_t)K, rocprim::plus<uint32_t>(), s));
+  NM_HIP_CHECK(rocprim::inclusive_scan(g.scan_tmp, tb, g.tiles_sorted, g.offs, (size_t)K, rocprim::plus<uint32_t>(), s));
   uint32_t total = 0;
   NM_HIP_CHECK(hipMemcpyAsync(&total, g.offs + (K - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   NM_HIP_CHECK(hipStreamSynchronize(s));
@@ -727,14 +761,14 @@ extern "C" int nm_raster_render(const nm_raster_cfg* cfg, int32_t K, int64_t D, 
     NM_REQUIRE(geom && scratch, "null geom/scratch");
     Scratch sc = carve_scratch(scratch, D);
     if (scratch_bytes < sc.total) { nm_set_error("scratch buffer too small: need %zu got %zu", sc.total, scratch_bytes); return NM_ERR_WORKSPACE; }
-    NM_LAUNCH(k_emit_keys, dim3(nm_div_up(K, 256)), dim3(256), 0, s, k, K, (const int*)g.rad, g.xy,
-                       g.depth, g.conop, g.offs, g.tiles, sc.keys_in, sc.vals_in);
+    NM_LAUNCH(k_emit_keys, dim3(nm_div_up(K, 256)), dim3(256), 0, s, k, K, g.order, (const int*)g.rad, g.xy, g.conop, g.offs,
+              g.tiles, sc.keys_in, sc.vals_in);
     NM_LAUNCH_CHECK();
-    int bits = 0;
+    int bits = 1;
     while ((1 << bits) < k.gx * k.gy) ++bits;
     size_t tb = sc.sort_bytes;
     NM_HIP_CHECK(rocprim::radix_sort_pairs(sc.sort_tmp, tb, sc.keys_in, sc.keys_out, sc.vals_in, b.point_list, (size_t)D, 0u,
-                                           (unsigned)(32 + bits), s));
+                                           (unsigned)bits, s));
     NM_LAUNCH(k_tile_ranges, dim3(nm_div_up(D, 256)), dim3(256), 0, s, D, sc.keys_out, b.ranges);
     NM_LAUNCH_CHECK();
   }

@@ -1,7 +1,7 @@
 // Fused roll-out of S substeps with checkpointed BPTT.
 // Operator order follows /root/reference/experiments/finetune.py:360-364 (stress = E(F); sim; F = P(F)),
-// the reverse sweep follows interface.py:41-76 + mpm.py:299-319 per step.  Only (x,v,C,F) per substep is
-// kept (96 B/particle); stress, the trial deformation gradient and the grid are recomputed.
+// the reverse sweep follows interface.py:41-76 + mpm.py:299-319 per step.  Only (x,v,C,F,stress) per substep is
+// kept (132 B/particle); the trial deformation gradient, the grid and every MLP activation are recomputed.
 #include "nm_common.h"
 
 #define NM_WTOT_ (64 * 13 + 64 * 64 + 9 * 64)
@@ -45,14 +45,15 @@ extern "C" size_t nm_rollout_workspace(int32_t n, int32_t substeps) {
   return carve_ws(nullptr, n).total;
 }
 
+#define NM_REC 33  // floats per particle per checkpoint record: x3 v3 C9 F9 stress9
 static inline nm_particles rec(float* base, int n, int t) {
-  float* r = base + (size_t)t * 24 * n;
+  float* r = base + (size_t)t * NM_REC * n;
   nm_particles p;
   p.x = r;
   p.v = r + 3 * (size_t)n;
   p.C = r + 6 * (size_t)n;
   p.F = r + 15 * (size_t)n;
-  p.stress = nullptr;
+  p.stress = r + 24 * (size_t)n;   // stress computed FROM this record's F (input of the step that leaves it)
   return p;
 }
 
@@ -88,9 +89,8 @@ extern "C" int nm_rollout_forward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cf
   int rc;
   for (int t = 0; t < cfg->substeps; ++t) {
     nm_particles cur = rec(states, n, t), nxt = rec(states, n, t + 1);
-    rc = nm_material_fwd(n, NM_ELASTICITY, 0.f, cur.F, we, w.stress, stream);  // finetune.py:362
+    rc = nm_material_fwd(n, NM_ELASTICITY, 0.f, cur.F, we, cur.stress, stream);  // finetune.py:362
     if (rc) return rc;
-    cur.stress = w.stress;
     nm_particles out = nxt;
     out.F = w.ftrial;
     rc = nm_mpm_forward(h, n, st, &cur, &out, stream);                          // finetune.py:363
@@ -128,10 +128,7 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
     rc = nm_material_bwd_ex(n, NM_PLASTICITY, cfg->plasticity_alpha, w.ftrial, wp, gin + 15 * N, w.gFtr, gw_p, gw_p + 64 * 13,
                             gw_p + 64 * 13 + 64 * 64, 1, w.mat, w.mat_bytes, stream);
     if (rc) return rc;
-    // recompute stress, sim backward
-    rc = nm_material_fwd(n, NM_ELASTICITY, 0.f, cur.F, we, w.stress, stream);
-    if (rc) return rc;
-    cur.stress = w.stress;
+    // sim backward (stress of this step was checkpointed by the forward pass)
     nm_particles gn, gc;
     gn.x = const_cast<float*>(gin); gn.v = const_cast<float*>(gin) + 3 * N; gn.C = const_cast<float*>(gin) + 6 * N;
     gn.F = w.gFtr; gn.stress = nullptr;

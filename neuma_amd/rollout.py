@@ -1,6 +1,6 @@
 """Fused roll-out fast path: S substeps of  stress=E(F); x,v,C,F=sim(...); F=P(F)  (finetune.py:360-364) as ONE
 autograd node backed by nm_rollout_forward / nm_rollout_backward.  Keeps 96 B/particle/substep of checkpoints
-and recomputes everything else in the reverse sweep.  Results equal the per-operator path
+and recomputes everything else in the reverse sweep (the substep's stress is checkpointed too: 132 B/particle).  Results equal the per-operator path
 (MPMCacheDiffSim + material modules) up to fp32 summation order; tests/test_gpu_rollout.py checks that."""
 import ctypes as C
 
@@ -23,12 +23,12 @@ class _Rollout(autograd.Function):
         dev = x.device
         n = x.size(0)
         S = int(substeps)
-        states = torch.empty(S + 1, 24 * n, dtype=torch.float32, device=dev)
+        states = torch.empty(S + 1, 33 * n, dtype=torch.float32, device=dev)   # x|v|C|F|stress per record
         rec0 = states[0]
         rec0[:3 * n].copy_(x.detach().float().reshape(-1))
         rec0[3 * n:6 * n].copy_(v.detach().float().reshape(-1))
         rec0[6 * n:15 * n].copy_(C_.detach().float().reshape(-1))
-        rec0[15 * n:].copy_(F.detach().float().reshape(-1))
+        rec0[15 * n:24 * n].copy_(F.detach().float().reshape(-1))
         we = [t.detach().float().contiguous() for t in (e0, e1, e2)]
         wp = [t.detach().float().contiguous() for t in (p0, p1, p2)]
         ws_bytes = int(lib.nm_rollout_workspace(n, S))
@@ -43,7 +43,7 @@ class _Rollout(autograd.Function):
         ctx.save_for_backward(states, *we, *wp)
         last = states[S]
         return (last[:3 * n].view(n, 3), last[3 * n:6 * n].view(n, 3), last[6 * n:15 * n].view(n, 3, 3),
-                last[15 * n:].view(n, 3, 3))
+                last[15 * n:24 * n].view(n, 3, 3))
 
     @staticmethod
     def backward(ctx, gx, gv, gC, gF):
