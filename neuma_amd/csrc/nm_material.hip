@@ -197,14 +197,13 @@ struct MlpFwd {
 };
 template <bool WITH_GRAD>
 __device__ __forceinline__ void mlp_forward_tile(const float* __restrict__ P0, const float* __restrict__ P1,
-                                                 const float* __restrict__ P2, const float* __restrict__ zt, int lane,
-                                                 MlpFwd& o) {
-  const int j = lane & 15, g = lane >> 4;
+                                                 const float* __restrict__ P2, const float* zin /* 4 B operands of layer 0 */,
+                                                 int lane, MlpFwd& o) {
   const f4 zero = {0.f, 0.f, 0.f, 0.f};
   f4 a1[4] = {zero, zero, zero, zero};
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    float b = zt[j * 17 + 4 * ks + g];
+    float b = zin[ks];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) a1[rt] = NM_MFMA(P0[(ks * 4 + rt) * 64 + lane], b, a1[rt]);
   }
@@ -280,16 +279,27 @@ __global__ void __launch_bounds__(256) k_material_fwd(int n, float alpha, const 
     zb[lane * 17 + 13] = 0.f; zb[lane * 17 + 14] = 0.f; zb[lane * 17 + 15] = 0.f;
     __builtin_amdgcn_wave_barrier();
     NM_PH(1)
-#pragma unroll 2
-    for (int ct = 0; ct < 4; ++ct) {   // two column tiles per trip: one tile's GELU (VALU) can overlap the other's MFMAs
+    // layer-0 B operands of all four column tiles first, results kept in registers: the tile loop itself then has
+    // no LDS traffic besides the (hoisted) weights, so the scheduler may overlap one tile's GELU with another's MFMAs
+    float zin[4][4];
+    f4 yv[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) zin[ct][ks] = zb[(ct * 16 + j) * 17 + 4 * ks + g];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
       MlpFwd m;
-      mlp_forward_tile<false>(sP0, sP1, sP2, zb + ct * 16 * 17, lane, m);
+      mlp_forward_tile<false>(sP0, sP1, sP2, zin[ct], lane, m);
+      yv[ct] = m.y;
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int row = 4 * g + r;
-        if (row < 9) yb[(ct * 16 + j) * 9 + row] = m.y[r];
+        if (row < 9) yb[(ct * 16 + j) * 9 + row] = yv[ct][r];
       }
-    }
     __builtin_amdgcn_wave_barrier();
     NM_PH(2)
     M3 X;
@@ -351,6 +361,7 @@ __global__ void __launch_bounds__(256, 1) k_material_bwd(int n, float alpha, con
                                                          float* __restrict__ gF, float* __restrict__ wpart, int want_w) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   BwdLds& L = *reinterpret_cast<BwdLds*>(smem_raw);
+  NM_PH_DECL
   {
     float* raw = &L.Z[0][0];   // the per-wave buffers (>= 22 016 floats) are free until the main loop
     stage_raw_weights(w0, w1, w2, raw);
@@ -359,6 +370,7 @@ __global__ void __launch_bounds__(256, 1) k_material_bwd(int n, float alpha, con
     stage_bwd_weights(raw, L.Q0, L.Q1, L.Q2);
     __syncthreads();
   }
+  NM_PH(0)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int j = lane & 15, g = lane >> 4;
   const int nbatch = (n + 63) >> 6;
@@ -401,16 +413,21 @@ __global__ void __launch_bounds__(256, 1) k_material_bwd(int n, float alpha, con
       for (int c = 0; c < 3; ++c) gyb[lane * 13 + 3 * r + c] = 0.5f * (Xb.m[3 * r + c] + Xb.m[3 * c + r]);
     gyb[lane * 13 + 9] = 0.f; gyb[lane * 13 + 10] = 0.f; gyb[lane * 13 + 11] = 0.f; gyb[lane * 13 + 12] = 0.f;
     __builtin_amdgcn_wave_barrier();
+    NM_PH(1)
 
 #pragma unroll 1
     for (int ct = 0; ct < 4; ++ct) {
       MlpFwd m;
-      mlp_forward_tile<true>(L.P0, L.P1, L.P2, zb + ct * 16 * 17, lane, m);
+      float zin[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) zin[ks] = zb[(ct * 16 + j) * 17 + 4 * ks + g];
+      mlp_forward_tile<true>(L.P0, L.P1, L.P2, zin, lane, m);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int row = 4 * g + r;
         if (row < 9) yb[(ct * 16 + j) * 9 + row] = m.y[r];
       }
+      NM_PH(2)
       const float* gyt = gyb + ct * 16 * 13;  // [particle][13]
       // (a) W2bar += ybar h2^T : A[yrow][particle], B[particle][h2 idx] via TB = h2 [feature][particle]
       if (want_w) {
@@ -427,6 +444,7 @@ __global__ void __launch_bounds__(256, 1) k_material_bwd(int n, float alpha, con
         }
         __builtin_amdgcn_wave_barrier();
       }
+      NM_PH(3)
       // (b) h2bar = W2^T ybar ; pre2bar = h2bar * gelu'(pre2)
       f4 d2[4] = {zero, zero, zero, zero};
 #pragma unroll
@@ -439,6 +457,7 @@ __global__ void __launch_bounds__(256, 1) k_material_bwd(int n, float alpha, con
       for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) d2[rt][r] *= m.g2[rt][r];
+      NM_PH(4)
       // (c) W1bar += pre2bar h1^T
       if (want_w) {
 #pragma unroll
@@ -463,6 +482,7 @@ __global__ void __launch_bounds__(256, 1) k_material_bwd(int n, float alpha, con
         }
         __builtin_amdgcn_wave_barrier();
       }
+      NM_PH(5)
       // (d) h1bar = W1^T pre2bar ; pre1bar = h1bar * gelu'(pre1)
       f4 d1[4] = {zero, zero, zero, zero};
 #pragma unroll
@@ -477,6 +497,7 @@ __global__ void __launch_bounds__(256, 1) k_material_bwd(int n, float alpha, con
       for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) d1[rt][r] *= m.g1[rt][r];
+      NM_PH(6)
       // (e) W0bar += pre1bar z^T : B[particle][z idx] straight from zb ([particle][17])
       if (want_w) {
 #pragma unroll
@@ -558,7 +579,9 @@ __global__ void __launch_bounds__(256, 1) k_material_bwd(int n, float alpha, con
     for (int i = 0; i < 9; ++i) Fb.m[i] += t.m[i] + FG.m[i] + zbv[12] * cof.m[i];
     if (valid) m3_store(gF + 9 * p, Fb);
     __builtin_amdgcn_wave_barrier();
+    NM_PH(7)
   }
+  NM_PH_STORE
 
   if (!want_w) return;
   // reduce the four waves' weight-gradient accumulators through LDS (weights no longer needed), write the

@@ -16,14 +16,24 @@ dev = torch.device("cuda", 0)
 scene = synth.make_scene("metric", override=dict(K=1000))
 rt = SceneRuntime(scene, dev)
 F = (torch.eye(3, device=dev) + 0.02 * torch.randn(rt.N, 3, 3, device=dev)).contiguous()
-with torch.no_grad():
+import sys as _s
+BWD = len(_s.argv) > 1 and _s.argv[1] == "bwd"
+if BWD:
+    Fg = F.clone().requires_grad_(True)
     for _ in range(3):
-        rt.elasticity(F)
+        out = rt.elasticity(Fg)
+        g = torch.autograd.grad(out.sum(), [Fg] + rt.parameters()[:6])
+    torch.cuda.synchronize()
+else:
+    with torch.no_grad():
+        for _ in range(3):
+            rt.elasticity(F)
     torch.cuda.synchronize()
 fn = lib.nm_debug_phases; fn.argtypes = [C.c_void_p, C.c_int]
 buf = np.zeros(8 * 2048, dtype=np.int64)
 print("rc", fn(buf.ctypes.data, 8 * 2048))
-b = buf.reshape(2048, 8)[:1563]
-for i, nm in enumerate(["stage weights", "svd+features", "mlp 4 tiles", "epilogue"]):
+b = buf.reshape(2048, 8)[:1024 if BWD else 1563]
+names = ["stage weights", "svd+feat+ybar", "fwd recompute", "(a) W2 grad", "(b) h2bar", "(c) W1 grad", "(d) h1bar", "(e,f)+epilogue"] if BWD else ["stage weights", "svd+features", "mlp 4 tiles", "epilogue"]
+for i, nm in enumerate(names):
     print(f"{nm:16s} mean {b[:, i].mean():9.0f} median {np.median(b[:, i]):9.0f} max {b[:, i].max():9.0f}")
-print("total mean", b[:, :4].sum(1).mean())
+print("total mean", b.sum(1).mean(), "max", b.sum(1).max())
