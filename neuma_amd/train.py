@@ -1,0 +1,204 @@
+"""Training harness around the hot path: LoRA fine-tuning of the two constitutive nets by BPTT through
+simulation + rendering.  Counterpart of /root/reference/experiments/finetune.py:234-488 (finetune_constitutive)
+and modules/tune/scheduler/__init__.py:
+
+  * two RAdam optimisers + LambdaLR schedules (cosine / exponential, scheduler/__init__.py:29-118), optional warm-up
+    (finetune.py:345-351), schedulers stepped once per epoch after warm-up (482-484);
+  * roll-out loss decay  rate(epoch) = decay_init + (decay_final - decay_init) * min(epoch / (lambda * num_epochs), 1),
+    weight of frame f = rate ** ((f - 1) // decay_steps)                                   (finetune.py:353-358, 388);
+  * previous particle / kernel positions are re-detached every rendered frame (391-392), frames listed in
+    `exclude_steps` skip rendering AND the prev-state update (371-372);
+  * one loss.backward() per epoch, clip_grad_norm_(error_if_nonfinite=True) per net, then the optimiser steps (413-427);
+  * LoRA-only checkpoints `{epoch:04d}_lora.pt` = {'elasticity', 'plasticity', 'loss'} at epoch 1, every 10th and the
+    last, newest `num_lora_ckpts` kept (470-480); resume reloads the newest one with strict=False (299-309).
+
+Everything numeric runs in the HIP kernels (neuma_amd.rollout / neuma_amd.tune / neuma_amd.render); this file is host
+control flow only.
+"""
+import math
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+from torch.nn.utils import clip_grad_norm_
+from torch.optim import RAdam, lr_scheduler
+
+from .tune import compute_bindings_xyz, compute_bindings_F
+
+
+def _get(cfg, key, default=None):
+    if isinstance(cfg, dict):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default)
+
+
+class CosineDecayScheduler(object):
+    """scheduler/__init__.py:76-102: linear warm-up to `warm_up_end`, then cosine to learning_rate_alpha * lr."""
+
+    def __init__(self, config) -> None:
+        self.warm_up_end = _get(config, "warm_up_end") or 0
+        self.max_steps = _get(config, "max_steps") or 1e5
+        a = _get(config, "learning_rate_alpha")
+        self.alpha = 0.05 if a is None else a
+
+    def factor(self, step: int) -> float:
+        if step < self.warm_up_end:
+            return step / self.warm_up_end
+        progress = (step - self.warm_up_end) / (self.max_steps - self.warm_up_end)
+        return (math.cos(math.pi * progress) + 1.0) * 0.5 * (1 - self.alpha) + self.alpha
+
+    def get_scheduler(self, optimizer, lr_init: float):
+        return lr_scheduler.LambdaLR(optimizer, lr_lambda=self.factor)
+
+
+class ExponentialDecayScheduler(object):
+    """scheduler/__init__.py:29-73: linear / cosine ramp from lr_pre_warmup, then log-linear decay to lr_final."""
+
+    def __init__(self, config) -> None:
+        self.lr_pre_warmup = _get(config, "lr_pre_warmup") if _get(config, "lr_pre_warmup") is not None else 1e-8
+        self.warmup_steps = _get(config, "warmup_steps") or 0
+        self.max_steps = _get(config, "max_steps") or 1e5
+        self.ramp = _get(config, "ramp") or "linear"
+        self.lr_final = _get(config, "lr_final")
+
+    def get_scheduler(self, optimizer, lr_init: float):
+        lr_final = lr_init if self.lr_final is None else self.lr_final
+
+        def func(step):
+            if step < self.warmup_steps:
+                if self.ramp == "cosine":
+                    lr = self.lr_pre_warmup + (lr_init - self.lr_pre_warmup) * math.sin(
+                        0.5 * math.pi * min(max(step / self.warmup_steps, 0), 1))
+                else:
+                    lr = self.lr_pre_warmup + (lr_init - self.lr_pre_warmup) * step / self.warmup_steps
+            else:
+                t = min(max((step - self.warmup_steps) / (self.max_steps - self.warmup_steps), 0), 1)
+                lr = math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
+            return lr / lr_init
+
+        return lr_scheduler.LambdaLR(optimizer, lr_lambda=func)
+
+
+def fetch_scheduler(config):
+    """scheduler/__init__.py:105-118"""
+    t = _get(config, "type")
+    if t == "exp":
+        return ExponentialDecayScheduler(config)
+    if t == "cos":
+        return CosineDecayScheduler(config)
+    raise ValueError(f"Scheduler {t} not supported.")
+
+
+def rollout_decay_rate(cfg, epoch: int) -> float:
+    """finetune.py:353-358"""
+    lam = _get(cfg, "lambda_max_decay", 0)
+    ratio = min((1.0 / lam) * epoch / _get(cfg, "num_epochs"), 1.0) if lam > 0 else 1.0
+    return _get(cfg, "decay_init") + (_get(cfg, "decay_final") - _get(cfg, "decay_init")) * ratio
+
+
+DEFAULT_CFG = dict(   # experiments/configs/synthetic/finetune-bb.yaml:61-107 (sizes reduced by the caller)
+    elasticity_lr=0.008, elasticity_wd=0.0, elasticity_grad_max_norm=1.0,
+    elasticity_scheduler=dict(type="cos", max_steps=1000, learning_rate_alpha=0.025),
+    plasticity_lr=0.0008, plasticity_wd=0.0, plasticity_grad_max_norm=1.0,
+    plasticity_scheduler=dict(type="cos", max_steps=1000, learning_rate_alpha=0.025),
+    warmup_step=0, decay_init=0.5, decay_final=1.0, decay_steps=80, lambda_max_decay=0.33,
+    num_epochs=1000, num_frames=400, exclude_steps=(), num_lora_ckpts=3, resume=False,
+)
+
+
+@torch.no_grad()
+def simulate_video(rt, num_frames: int, views: Optional[Sequence[int]] = None, deform_cov: bool = True) -> List[List[torch.Tensor]]:
+    """Forward-only roll-out (render.py:304-332 order) that renders every frame: used to synthesise ground truth.
+    Returns frames[f][view] images for f = 1..num_frames."""
+    views = list(range(rt.V)) if views is None else list(views)
+    x, v, C, F = rt.x0, rt.v0, rt.C0, rt.F0
+    de_prev = (x - rt.center) / rt.size
+    g_prev = rt.gaussians.get_xyz
+    out = []
+    for _ in range(num_frames):
+        x, v, C, F = rt.rollout(x, v, C, F)
+        de_x = (x - rt.center) / rt.size
+        means3D = compute_bindings_xyz(de_x, de_prev, g_prev, rt.bindings)
+        dg = compute_bindings_F(F, rt.bindings) if deform_cov else None
+        out.append([rt.render_view(means3D, dg, vi).clone() for vi in views])
+        de_prev, g_prev = de_x.clone(), means3D.clone()
+    return out
+
+
+def video_loss(rt, gt_frames, c, decay_rate: float, views: Sequence[int], deform_cov: bool = True) -> torch.Tensor:
+    """One epoch's forward pass (finetune.py:334-392): roll the simulation out frame by frame from the initial state,
+    bind + render the requested views of every frame, accumulate the decayed pixel loss.
+    NB (reference semantics, tune/utils.py:353-373): the covariance push-forward by F is not differentiable, so the
+    gradient of this loss deliberately omits the d(image)/dF path; deform_cov=False renders with the rest covariances
+    (what the reference does for its first frame), which makes the returned gradient the exact one."""
+    nframes = int(c["num_frames"])
+    x, v, C, F = rt.x0, rt.v0, rt.C0, rt.F0
+    de_prev = ((x - rt.center) / rt.size).clone().detach()
+    g_prev = rt.gaussians.get_xyz.clone().detach()
+    loss_rgb = torch.zeros((), device=rt.device)
+    for cur_step in range(1, nframes + 1):
+        x, v, C, F = rt.rollout(x, v, C, F, step0=(cur_step - 1) * rt.S)      # `substeps` substeps (362-364)
+        if cur_step in c["exclude_steps"]:
+            continue                                                          # finetune.py:371-372
+        de_x = (x - rt.center) / rt.size
+        means3D = compute_bindings_xyz(de_x, de_prev, g_prev, rt.bindings)
+        dg = compute_bindings_F(F, rt.bindings) if deform_cov else None
+        w = decay_rate ** ((cur_step - 1) // c["decay_steps"])
+        for i, vi in enumerate(views):
+            render = rt.render_view(means3D, dg, vi)
+            loss_rgb = loss_rgb + w * rt.pixel_loss(render, gt_frames[cur_step - 1][i])
+        de_prev = de_x.clone().detach()
+        g_prev = means3D.clone().detach()
+    return loss_rgb
+
+
+def finetune_constitutive(rt, gt_frames: List[List[torch.Tensor]], cfg: Optional[Dict] = None, tune_root: Optional[Path] = None,
+                          views: Optional[Sequence[int]] = None, log=None) -> List[float]:
+    """finetune.py:234-488 on a SceneRuntime.  gt_frames[f-1][i] = ground-truth image of frame f for views[i].
+    Returns the per-epoch losses."""
+    c = dict(DEFAULT_CFG)
+    c.update(cfg or {})
+    views = list(range(rt.V)) if views is None else list(views)
+    E, P = rt.elasticity, rt.plasticity
+    if tune_root is not None:
+        tune_root = Path(tune_root)
+        tune_root.mkdir(parents=True, exist_ok=True)
+        if c["resume"]:                                                          # finetune.py:299-309
+            prev = sorted(tune_root.glob("*_lora.pt"))
+            if prev:
+                ck = torch.load(prev[-1], map_location=rt.device)
+                E.load_state_dict(ck["elasticity"], strict=False)
+                P.load_state_dict(ck["plasticity"], strict=False)
+    E.freeze_all_except_lora(); P.freeze_all_except_lora()
+    e_opt = RAdam([p for p in E.parameters() if p.requires_grad], lr=c["elasticity_lr"], weight_decay=c["elasticity_wd"])
+    p_opt = RAdam([p for p in P.parameters() if p.requires_grad], lr=c["plasticity_lr"], weight_decay=c["plasticity_wd"])
+    e_sch = fetch_scheduler(c["elasticity_scheduler"]).get_scheduler(e_opt, c["elasticity_lr"])
+    p_sch = fetch_scheduler(c["plasticity_scheduler"]).get_scheduler(p_opt, c["plasticity_lr"])
+    losses = []
+    for epoch in range(1, int(c["num_epochs"]) + 1):
+        if c["warmup_step"] != 0 and epoch <= c["warmup_step"]:                  # finetune.py:345-351
+            for opt, lr in ((e_opt, c["elasticity_lr"]), (p_opt, c["plasticity_lr"])):
+                for g in opt.param_groups:
+                    g["lr"] = lr * float(epoch) / c["warmup_step"]
+        decay_rate = rollout_decay_rate(c, epoch)
+        loss_rgb = video_loss(rt, gt_frames, c, decay_rate, views)
+        e_opt.zero_grad(set_to_none=True); p_opt.zero_grad(set_to_none=True)
+        loss_rgb.backward()
+        e_gn = clip_grad_norm_(E.parameters(), max_norm=c["elasticity_grad_max_norm"], error_if_nonfinite=True)
+        e_opt.step()
+        p_gn = clip_grad_norm_(P.parameters(), max_norm=c["plasticity_grad_max_norm"], error_if_nonfinite=True)
+        p_opt.step()
+        losses.append(float(loss_rgb))
+        if log is not None:
+            log(f"[Epoch {epoch}/{c['num_epochs']} | L rgb: {losses[-1]:.4e} | e-lr: {e_opt.param_groups[0]['lr']:.2e} | "
+                f"e-gd: {float(e_gn):.2e} | p-lr: {p_opt.param_groups[0]['lr']:.2e} | p-gd: {float(p_gn):.2e} | decay: {decay_rate:.2f}]")
+        if tune_root is not None and (epoch == 1 or epoch % 10 == 0 or epoch == c["num_epochs"]):   # finetune.py:470-480
+            torch.save({"elasticity": E.lora_state_dict(), "plasticity": P.lora_state_dict(), "loss": losses[-1]},
+                       tune_root / f"{epoch:04d}_lora.pt")
+            files = sorted(tune_root.glob("*_lora.pt"))
+            if len(files) > c["num_lora_ckpts"]:
+                files[0].unlink()
+        if c["warmup_step"] == 0 or epoch > c["warmup_step"]:                   # finetune.py:482-484
+            e_sch.step(); p_sch.step()
+    return losses

@@ -13,6 +13,7 @@ Outputs (data only — inputs and expected outputs):
     tests/golden/base_models.npz              the three shipped checkpoints as plain arrays
     tests/golden/material_<name>.npz          F, LoRA A/B, stress, F_p, and autograd gradients
     tests/golden/camera_sh_golden.npz         view/proj matrices, SH evaluations, l1/l2 loss values
+    tests/golden/scheduler_golden.npz         learning-rate curves of the reference's cosine / exponential schedulers
 """
 import sys
 import types
@@ -54,6 +55,7 @@ def install_stubs():
 
     class DictConfig(dict):
         __getattr__ = dict.__getitem__
+        __setattr__ = dict.__setitem__
 
     oc.DictConfig = DictConfig
     oc.OmegaConf = object
@@ -184,6 +186,22 @@ def main():
     a = torch.tensor(rng.random((3, 8, 9))); b = torch.tensor(rng.random((3, 8, 9)))
     cam.update(loss_a=a.numpy(), loss_b=b.numpy(), l1=lu.l1_loss(a, b).numpy(), l2=lu.l2_loss(a, b).numpy())
     np.savez_compressed(OUT / "camera_sh_golden.npz", **cam)
+
+    # ---- LR schedulers (modules/tune/scheduler/__init__.py:29-118) evaluated through torch LambdaLR
+    sch = load(REF / "modules/tune/scheduler/__init__.py", "ref_scheduler")
+    out = {}
+    for tag, cfgd, lr0 in [("cos", dict(type="cos", max_steps=1000, learning_rate_alpha=0.025), 0.008),
+                           ("cos_warm", dict(type="cos", max_steps=200, learning_rate_alpha=0.01, warm_up_end=20), 1.0),
+                           ("exp", dict(type="exp", lr_final=1e-4, max_steps=500, warmup_steps=10), 0.01)]:
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([p], lr=lr0)
+        sc = sch.fetch_scheduler(DictConfig(cfgd)).get_scheduler(opt, lr0)
+        lrs = []
+        for _ in range(int(cfgd["max_steps"]) + 5):
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step(); sc.step()
+        out[tag] = np.array(lrs)
+    np.savez_compressed(OUT / "scheduler_golden.npz", **out)
     print("done")
 
 

@@ -141,3 +141,26 @@ def test_two_rank_gloo_gradient_merge_equals_single_rank():
     for rank, ok, tot, ref in res:
         assert ok, f"rank {rank}: merged gradient differs from the single-rank gradient"
         assert abs(tot - ref) < 1e-3 * max(1.0, abs(ref))
+
+
+def test_lr_schedulers_match_reference_curves(golden_dir):
+    """neuma_amd.train schedulers vs curves produced by the reference's modules/tune/scheduler (gen_material_golden.py)."""
+    from neuma_amd.train import fetch_scheduler, rollout_decay_rate
+    g = np.load(golden_dir / "scheduler_golden.npz")
+    for tag, cfgd, lr0 in [("cos", dict(type="cos", max_steps=1000, learning_rate_alpha=0.025), 0.008),
+                           ("cos_warm", dict(type="cos", max_steps=200, learning_rate_alpha=0.01, warm_up_end=20), 1.0),
+                           ("exp", dict(type="exp", lr_final=1e-4, max_steps=500, warmup_steps=10), 0.01)]:
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([p], lr=lr0)
+        sc = fetch_scheduler(cfgd).get_scheduler(opt, lr0)
+        lrs = []
+        for _ in range(int(cfgd["max_steps"]) + 5):
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step(); sc.step()
+        assert np.allclose(np.array(lrs), g[tag], rtol=1e-12, atol=1e-15), tag
+    with pytest.raises(ValueError):
+        fetch_scheduler(dict(type="step"))
+    c = dict(decay_init=0.5, decay_final=1.0, lambda_max_decay=0.33, num_epochs=1000)
+    assert rollout_decay_rate(c, 0) == 0.5 and rollout_decay_rate(c, 1000) == 1.0      # finetune.py:353-358
+    assert abs(rollout_decay_rate(c, 165) - (0.5 + 0.5 * (165 / 0.33 / 1000))) < 1e-12
+    assert rollout_decay_rate(dict(c, lambda_max_decay=0), 3) == 1.0
