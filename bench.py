@@ -124,8 +124,11 @@ def main():
     lib.nm_prof_enable(0, None)
     full = prof_table(lib)
     lib.nm_prof_reset()
-    dominant = max(full.items(), key=lambda kv: kv[1][1])[0] if full else "k_render_bwd"
-    dom_base = dominant.split("<")[0]
+    by_base = {}
+    for name, (calls, ms) in full.items():      # template instances (k_material_bwd<...>) count as one kernel
+        b = name.split("<")[0]
+        by_base[b] = (by_base.get(b, (0, 0.0))[0] + calls, by_base.get(b, (0, 0.0))[1] + ms)
+    dom_base = max(by_base.items(), key=lambda kv: kv[1][1])[0] if by_base else "k_render_bwd"
 
     # ---- timed region: K frames, HIP events on the dominant kernel only
     lib.nm_prof_enable(1, dom_base.encode())
@@ -172,9 +175,11 @@ def main():
 
     roof = None
     if dom:
-        name, (calls, ms) = max(dom.items(), key=lambda kv: kv[1][1])
+        calls = sum(v[0] for v in dom.values())
+        ms = sum(v[1] for v in dom.values())
+        name = dom_base + ("<*>" if any("<" in k for k in dom) else "")
         avg_s = ms / calls / 1e3
-        base = name.split("<")[0]
+        base = dom_base
         if base in ("k_material_fwd", "k_material_bwd"):
             # MFMA-bound: 2*(13*64 + 64*64 + 64*9) = 11 008 flop per particle per net forward; the backward recomputes
             # the forward and adds data-gradient and weight-gradient GEMMs of the same size (3x)

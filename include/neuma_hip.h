@@ -99,6 +99,19 @@ int nm_mpm_backward(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particl
                     const nm_particles* next, const nm_particles* gnext, nm_particles* gcur,
                     void* stream);
 
+/* Grid cache (no reference counterpart; removes the reference's p2g recompute of mpm.py:312-315 from the reverse
+ * sweep).  nm_mpm_forward_ex additionally writes a record of the substep's touched 4x4x4-node blocks ({mv, m} of
+ * those blocks + the block list; nm_mpm_gridcache_bytes(cap_blocks) bytes, caller-owned device memory);
+ * nm_mpm_backward_ex restores the grid from it instead of re-scattering.  A substep that touches more than
+ * cap_blocks blocks marks its record invalid and the backward transparently falls back to the recompute, so results
+ * never depend on the capacity.  gridrec == NULL: identical to nm_mpm_forward / nm_mpm_backward. */
+size_t nm_mpm_gridcache_bytes(int32_t cap_blocks);
+int nm_mpm_forward_ex(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur,
+                      nm_particles* next, void* gridrec, int32_t cap_blocks, void* stream);
+int nm_mpm_backward_ex(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur,
+                       const nm_particles* next, const nm_particles* gnext, nm_particles* gcur,
+                       const void* gridrec, int32_t cap_blocks, void* stream);
+
 /* MPMModel.forward_extra, mpm.py:260-277: p2g + grid_op from (st, cur), then g2p of a second,
  * passive particle set in place. */
 int nm_mpm_forward_extra(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur,
@@ -160,18 +173,23 @@ int nm_material_bwd_ex(int32_t n, int32_t kind, float alpha, const float* F, con
 typedef struct nm_rollout_cfg {
   int32_t substeps;
   float plasticity_alpha;
+  int32_t grid_cache_blocks; /* capacity (in 4x4x4-node blocks) of each substep's grid cache record; 0 = no cache */
 } nm_rollout_cfg;
 size_t nm_rollout_workspace(int32_t n, int32_t substeps);
+/* bytes of the optional `gridcache` buffer: substeps records of nm_mpm_gridcache_bytes(grid_cache_blocks) */
+size_t nm_rollout_gridcache_bytes(int32_t substeps, int32_t grid_cache_blocks);
+/* gridcache (may be NULL): written by the forward pass, handed unchanged to nm_rollout_backward, which then restores
+ * each substep's grid instead of recomputing p2g (see nm_mpm_forward_ex). */
 int nm_rollout_forward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cfg, const nm_statics* st,
-                       const nm_mlp* elasticity, const nm_mlp* plasticity, float* states,
+                       const nm_mlp* elasticity, const nm_mlp* plasticity, float* states, void* gridcache,
                        void* workspace, size_t workspace_bytes, void* stream);
 /* gstate_last: dL/d(x,v,C,F of record S) (24*N floats: x|v|C|F); gstate_first: dL/d(x,v,C,F of record 0) (written);
  * gw_e / gw_p: 5504 floats each = dL/d(w0 | w1 | w2) of the elasticity / plasticity nets, summed over
  * particles and substeps (overwritten). */
 int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cfg, const nm_statics* st,
                         const nm_mlp* elasticity, const nm_mlp* plasticity, const float* states,
-                        const float* gstate_last, float* gstate_first, float* gw_e, float* gw_p,
-                        void* workspace, size_t workspace_bytes, void* stream);
+                        const void* gridcache, const float* gstate_last, float* gstate_first, float* gw_e,
+                        float* gw_p, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ Particle-GS binding (modules/tune/utils.py) */
 

@@ -37,7 +37,7 @@ class nm_raster_cfg(C.Structure):
 
 
 class nm_rollout_cfg(C.Structure):
-    _fields_ = [("substeps", C.c_int32), ("plasticity_alpha", C.c_float)]
+    _fields_ = [("substeps", C.c_int32), ("plasticity_alpha", C.c_float), ("grid_cache_blocks", C.c_int32)]
 
 
 # name -> (restype, argtypes); kept in one table so tests can check the exports against the header
@@ -52,6 +52,11 @@ SIGNATURES = {
     "nm_mpm_create": (C.c_int, [C.POINTER(nm_mpm_cfg), C.POINTER(C.c_void_p)]),
     "nm_mpm_destroy": (C.c_int, [_P]),
     "nm_mpm_forward": (C.c_int, [_P, _I32, C.POINTER(nm_statics), C.POINTER(nm_particles), C.POINTER(nm_particles), _P]),
+    "nm_mpm_gridcache_bytes": (_SZ, [_I32]),
+    "nm_mpm_forward_ex": (C.c_int, [_P, _I32, C.POINTER(nm_statics), C.POINTER(nm_particles), C.POINTER(nm_particles), _P, _I32,
+                                    _P]),
+    "nm_mpm_backward_ex": (C.c_int, [_P, _I32, C.POINTER(nm_statics), C.POINTER(nm_particles), C.POINTER(nm_particles),
+                                     C.POINTER(nm_particles), C.POINTER(nm_particles), _P, _I32, _P]),
     "nm_mpm_backward": (C.c_int, [_P, _I32, C.POINTER(nm_statics), C.POINTER(nm_particles), C.POINTER(nm_particles),
                                   C.POINTER(nm_particles), C.POINTER(nm_particles), _P]),
     "nm_mpm_forward_extra": (C.c_int, [_P, _I32, C.POINTER(nm_statics), C.POINTER(nm_particles), _I32,
@@ -78,10 +83,11 @@ SIGNATURES = {
                                      _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "nm_pixel_loss": (C.c_int, [_I32, _F, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
     "nm_rollout_workspace": (_SZ, [_I32, _I32]),
+    "nm_rollout_gridcache_bytes": (_SZ, [_I32, _I32]),
     "nm_rollout_forward": (C.c_int, [_P, _I32, C.POINTER(nm_rollout_cfg), C.POINTER(nm_statics), C.POINTER(nm_mlp),
-                                     C.POINTER(nm_mlp), _P, _P, _SZ, _P]),
+                                     C.POINTER(nm_mlp), _P, _P, _P, _SZ, _P]),
     "nm_rollout_backward": (C.c_int, [_P, _I32, C.POINTER(nm_rollout_cfg), C.POINTER(nm_statics), C.POINTER(nm_mlp),
-                                      C.POINTER(nm_mlp), _P, _P, _P, _P, _P, _P, _SZ, _P]),
+                                      C.POINTER(nm_mlp), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
 }
 
 _lib = None

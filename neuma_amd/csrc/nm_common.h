@@ -140,27 +140,40 @@ NM_HD M3 m3_cofactor(const M3& A) {
 // A = U diag(s) V^T with U, V in SO(3), s0 >= s1 >= |s2|, sign(s2) = sign(det A): the convention
 // modules/nclaw/warp/svd.py:61-96 produces from wp.svd3 + its det fix-up.
 // Hestenes rotations act on the columns of B = A V directly (no A^T A squaring), so small singular
-// values keep full relative accuracy; fixed sweep count keeps the wave convergent (no divergence).
-NM_HD void nm_jacobi_pair(float* __restrict__ B, float* __restrict__ V, int p, int q) {
+// values keep full relative accuracy.
+// fast 1-ulp device transcendentals (v_rcp_f32 / v_rsq_f32 / v_sqrt_f32): the IEEE-rounded forms expand to 10-15 VALU
+// instructions each and the Jacobi iteration is self-correcting
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NM_RCP(x) __builtin_amdgcn_rcpf(x)
+#define NM_RSQ(x) __builtin_amdgcn_rsqf(x)
+#define NM_SQRT(x) __builtin_amdgcn_sqrtf(x)
+#else
+#define NM_RCP(x) (1.f / (x))
+#define NM_RSQ(x) (1.f / sqrtf(x))
+#define NM_SQRT(x) sqrtf(x)
+#endif
+// one Hestenes rotation of columns p,q.  With a = |q|^2 - |p|^2, b = 2 p.q the tangent of the rotation angle is
+//   t = sgn(a) b / (|a| + sqrt(a^2 + b^2))          (the smaller root of t^2 + 2 (a/b) t - 1 = 0, division-free form)
+// Returns whether the pair was already orthogonal to fp32 rounding before the rotation: |p.q| <= 5e-7 |p| |q|.
+NM_HD bool nm_jacobi_pair(float* __restrict__ B, float* __restrict__ V, int p, int q) {
   float bp0 = B[p], bp1 = B[3 + p], bp2 = B[6 + p];
   float bq0 = B[q], bq1 = B[3 + q], bq2 = B[6 + q];
   float alpha = bp0 * bp0 + bp1 * bp1 + bp2 * bp2;
   float beta = bq0 * bq0 + bq1 * bq1 + bq2 * bq2;
   float gamma = bp0 * bq0 + bp1 * bq1 + bp2 * bq2;
-  float c = 1.f, s = 0.f;
-  if (gamma != 0.f) {
-    float zeta = (beta - alpha) / (2.f * gamma);
-    float t = copysignf(1.f, zeta) / (fabsf(zeta) + sqrtf(1.f + zeta * zeta));
-    if (!(fabsf(zeta) < 1e18f)) t = 0.5f / zeta;  // overflow of zeta*zeta; also maps inf -> 0
-    c = 1.f / sqrtf(1.f + t * t);
-    s = c * t;
-  }
+  float a = beta - alpha, b = gamma + gamma;
+  float den = fabsf(a) + NM_SQRT(a * a + b * b);
+  float t = b * NM_RCP(fmaxf(den, 1e-37f));
+  t = a < 0.f ? -t : t;
+  float c = NM_RSQ(1.f + t * t);
+  float s = c * t;
   B[p] = c * bp0 - s * bq0; B[3 + p] = c * bp1 - s * bq1; B[6 + p] = c * bp2 - s * bq2;
   B[q] = s * bp0 + c * bq0; B[3 + q] = s * bp1 + c * bq1; B[6 + q] = s * bp2 + c * bq2;
   float vp0 = V[p], vp1 = V[3 + p], vp2 = V[6 + p];
   float vq0 = V[q], vq1 = V[3 + q], vq2 = V[6 + q];
   V[p] = c * vp0 - s * vq0; V[3 + p] = c * vp1 - s * vq1; V[6 + p] = c * vp2 - s * vq2;
   V[q] = s * vp0 + c * vq0; V[3 + q] = s * vp1 + c * vq1; V[6 + q] = s * vp2 + c * vq2;
+  return gamma * gamma <= 2.5e-13f * alpha * beta;
 }
 // swap columns p,q of B and V keeping det(V) = +1 (negate the column that moves up)
 NM_HD void nm_swap_cols(float* __restrict__ B, float* __restrict__ V, int p, int q, bool doit) {
@@ -178,11 +191,14 @@ NM_HD void nm_svd3(const M3& A, M3& U, float s[3], M3& Vm) {
   float B[9], V[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i) { B[i] = A.m[i]; V[i] = (i % 4 == 0) ? 1.f : 0.f; }
+  // at most 5 sweeps (enough for fp32 on any input); a particle stops as soon as a whole sweep found all three pairs
+  // orthogonal to rounding, so the result of a particle never depends on its wave-mates
 #pragma unroll 1
   for (int sweep = 0; sweep < 5; ++sweep) {
-    nm_jacobi_pair(B, V, 0, 1);
-    nm_jacobi_pair(B, V, 0, 2);
-    nm_jacobi_pair(B, V, 1, 2);
+    bool c01 = nm_jacobi_pair(B, V, 0, 1);
+    bool c02 = nm_jacobi_pair(B, V, 0, 2);
+    bool c12 = nm_jacobi_pair(B, V, 1, 2);
+    if (c01 && c02 && c12) break;
   }
   float n0 = B[0] * B[0] + B[3] * B[3] + B[6] * B[6];
   float n1 = B[1] * B[1] + B[4] * B[4] + B[7] * B[7];
@@ -191,21 +207,21 @@ NM_HD void nm_svd3(const M3& A, M3& U, float s[3], M3& Vm) {
   bool sw = n0 < n1; nm_swap_cols(B, V, 0, 1, sw); { float a = sw ? n1 : n0, b = sw ? n0 : n1; n0 = a; n1 = b; }
   sw = n0 < n2;      nm_swap_cols(B, V, 0, 2, sw); { float a = sw ? n2 : n0, b = sw ? n0 : n2; n0 = a; n2 = b; }
   sw = n1 < n2;      nm_swap_cols(B, V, 1, 2, sw); { float a = sw ? n2 : n1, b = sw ? n1 : n2; n1 = a; n2 = b; }
-  float s0 = sqrtf(n0), s1 = sqrtf(n1);
+  float s0 = NM_SQRT(n0), s1 = NM_SQRT(n1);
   float u00, u10, u20, u01, u11, u21;
-  if (s0 > 1e-30f) { float r = 1.f / s0; u00 = B[0] * r; u10 = B[3] * r; u20 = B[6] * r; }
+  if (s0 > 1e-30f) { float r = NM_RSQ(n0); u00 = B[0] * r; u10 = B[3] * r; u20 = B[6] * r; }
   else { u00 = 1.f; u10 = 0.f; u20 = 0.f; }
   // second column: remove any residual component along u0 (also the rank-1 guard)
   float d = u00 * B[1] + u10 * B[4] + u20 * B[7];
   float c0 = B[1] - d * u00, c1 = B[4] - d * u10, c2 = B[7] - d * u20;
-  float cn = sqrtf(c0 * c0 + c1 * c1 + c2 * c2);
-  if (cn > 1e-30f && s1 > 1e-20f * s0) { float r = 1.f / cn; u01 = c0 * r; u11 = c1 * r; u21 = c2 * r; }
+  float cn2 = c0 * c0 + c1 * c1 + c2 * c2;
+  if (cn2 > 1e-37f && s1 > 1e-20f * s0) { float r = NM_RSQ(cn2); u01 = c0 * r; u11 = c1 * r; u21 = c2 * r; }
   else {  // pick any unit vector orthogonal to u0
     float ax = fabsf(u00), ay = fabsf(u10), az = fabsf(u20);
     float e0 = (ax <= ay && ax <= az) ? 1.f : 0.f, e1 = (e0 == 0.f && ay <= az) ? 1.f : 0.f, e2 = 1.f - e0 - e1;
     float dd = e0 * u00 + e1 * u10 + e2 * u20;
     c0 = e0 - dd * u00; c1 = e1 - dd * u10; c2 = e2 - dd * u20;
-    float r = 1.f / sqrtf(c0 * c0 + c1 * c1 + c2 * c2);
+    float r = NM_RSQ(c0 * c0 + c1 * c1 + c2 * c2);
     u01 = c0 * r; u11 = c1 * r; u21 = c2 * r;
   }
   // third column = u0 x u1 (det U = +1 by construction); signed sigma2 = b2 . u2

@@ -349,8 +349,9 @@ __global__ void __launch_bounds__(NM_SC_T) k_p2g(MpmK K, int n, const float* __r
                                                  const int* __restrict__ enabled, const float* __restrict__ x,
                                                  const float* __restrict__ v, const float* __restrict__ C,
                                                  const float* __restrict__ S, float4* __restrict__ gm, int* flags, int* list,
-                                                 int* count, int epoch) {
+                                                 int* count, int epoch, const int* __restrict__ skip_hdr) {
   __shared__ ScatterLds L;
+  if (skip_hdr && *skip_hdr >= 0) return;   // the grid of this substep was restored from a cache record
   const int p = blockIdx.x * NM_SC_T + threadIdx.x;
   const bool en = p < n && enabled[p] != 0;
   Stencil st;
@@ -413,23 +414,77 @@ __device__ __forceinline__ void grid_velocity(const MpmK& K, int i, int j, int k
   }
 }
 
-// mpm.py:373-429 on the active blocks only
+// A grid cache record (optional, one per substep of a roll-out): the active-block list and the scattered node values
+// {mv, m} of those blocks, so that the reverse sweep restores the grid instead of re-running p2g.
+//   int hdr[4]  (hdr[0] = number of blocks, -1 = record invalid because the substep touched more than `cap` blocks)
+//   int list[cap]   float4 gm[cap * 64]
+struct GridRec {
+  int* hdr;
+  int* list;
+  float4* gm;
+};
+static inline size_t gridrec_list_bytes(int cap) { return ((size_t)cap * sizeof(int) + 255) & ~(size_t)255; }
+static inline size_t gridrec_bytes(int cap) { return 256 + gridrec_list_bytes(cap) + (size_t)cap * 64 * sizeof(float4); }
+static inline GridRec gridrec_at(void* base, int cap) {
+  GridRec r;
+  char* p = (char*)base;
+  r.hdr = (int*)p;
+  r.list = (int*)(p + 256);
+  r.gm = (float4*)(p + 256 + gridrec_list_bytes(cap));
+  return r;
+}
+
+// mpm.py:373-429 on the active blocks only; optionally saves the pre-grid-op node values into a cache record
 __global__ void __launch_bounds__(256) k_grid_op(MpmK K, const float4* __restrict__ gm, float4* __restrict__ gv,
-                                                 const int* __restrict__ list, const int* __restrict__ count) {
+                                                 const int* __restrict__ list, const int* __restrict__ count, GridRec rec,
+                                                 int cap, const int* __restrict__ skip_hdr) {
+  if (skip_hdr && *skip_hdr >= 0) return;
   const int cnt = *count;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool save = rec.hdr != nullptr && cnt <= cap;
+  if (rec.hdr && blockIdx.x == 0 && threadIdx.x == 0) rec.hdr[0] = save ? cnt : -1;
   for (int li = blockIdx.x * 4 + wave; li < cnt; li += gridDim.x * 4) {
     int b = list[li];
     int i, j, k;
     block_coords(b, K.nb, lane, i, j, k);
     int node = (b << 6) + lane;
+    float4 a = gm[node];
     float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < K.G && j < K.G && k < K.G) {
       float u[3], mk[3];
-      grid_velocity(K, i, j, k, gm[node], u, mk);
+      grid_velocity(K, i, j, k, a, u, mk);
       out.x = u[0] * mk[0]; out.y = u[1] * mk[1]; out.z = u[2] * mk[2];
     }
     gv[node] = out;
+    if (save) {
+      rec.gm[(li << 6) + lane] = a;
+      if (lane == 0) rec.list[li] = b;
+    }
+  }
+}
+
+// reverse sweep: rebuild {mv, m}, the post-grid-op velocities and the active list from a cache record
+__global__ void __launch_bounds__(256) k_grid_restore(MpmK K, GridRec rec, float4* __restrict__ gm, float4* __restrict__ gv,
+                                                      int* __restrict__ list, int* __restrict__ count) {
+  const int cnt = rec.hdr[0];
+  if (cnt < 0) return;   // invalid record: the p2g / grid_op launches that follow do the work
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *count = cnt;
+  for (int li = blockIdx.x * 4 + wave; li < cnt; li += gridDim.x * 4) {
+    int b = rec.list[li];
+    int i, j, k;
+    block_coords(b, K.nb, lane, i, j, k);
+    int node = (b << 6) + lane;
+    float4 a = rec.gm[(li << 6) + lane];
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < K.G && j < K.G && k < K.G) {
+      float u[3], mk[3];
+      grid_velocity(K, i, j, k, a, u, mk);
+      out.x = u[0] * mk[0]; out.y = u[1] * mk[1]; out.z = u[2] * mk[2];
+    }
+    gm[node] = a;
+    gv[node] = out;
+    if (lane == 0) list[li] = b;
   }
 }
 
@@ -784,23 +839,37 @@ extern "C" int nm_mpm_destroy(nm_mpm* h) {
 
 static const int kSweepGrid = 512;  // workgroups for the active-block sweeps (grid-stride over the list)
 
-// clear + p2g + grid_op (shared by forward, backward-recompute and forward_extra)
-static int mpm_build_grid(nm_mpm* h, int n, const nm_statics* st, const nm_particles* cur, hipStream_t s) {
+// clear + p2g + grid_op (shared by forward, backward-recompute and forward_extra).
+// save != null: the forward pass also writes a grid cache record.  restore != null: the reverse sweep restores the
+// grid from the record; p2g / grid_op are still enqueued but return at once unless the record is marked invalid.
+static int mpm_build_grid(nm_mpm* h, int n, const nm_statics* st, const nm_particles* cur, hipStream_t s, void* save = nullptr,
+                          const void* restore = nullptr, int cap = 0) {
   const int prev = h->cur, now = prev ^ 1;
   h->epoch += 1;
   NM_LAUNCH(k_clear, dim3(kSweepGrid), dim3(256), 0, s, h->gm, h->gv, h->gg, h->list[prev], h->count + prev,
                      h->count + now);
   NM_LAUNCH_CHECK();
+  GridRec none = {nullptr, nullptr, nullptr};
+  GridRec srec = save ? gridrec_at(save, cap) : none;
+  const int* skip = nullptr;
+  if (restore) {
+    GridRec rrec = gridrec_at(const_cast<void*>(restore), cap);
+    NM_LAUNCH(k_grid_restore, dim3(kSweepGrid), dim3(256), 0, s, h->k, rrec, h->gm, h->gv, h->list[now], h->count + now);
+    NM_LAUNCH_CHECK();
+    skip = rrec.hdr;
+  }
   if (n > 0) {
     NM_LAUNCH(k_p2g, dim3(nm_div_up(n, NM_SC_T)), dim3(NM_SC_T), 0, s, h->k, n, st->vol, st->rho, st->enabled, cur->x,
-                       cur->v, cur->C, cur->stress, h->gm, h->flags, h->list[now], h->count + now, h->epoch);
+                       cur->v, cur->C, cur->stress, h->gm, h->flags, h->list[now], h->count + now, h->epoch, skip);
     NM_LAUNCH_CHECK();
   }
-  NM_LAUNCH(k_grid_op, dim3(kSweepGrid), dim3(256), 0, s, h->k, h->gm, h->gv, h->list[now], h->count + now);
+  NM_LAUNCH(k_grid_op, dim3(kSweepGrid), dim3(256), 0, s, h->k, h->gm, h->gv, h->list[now], h->count + now, srec, cap, skip);
   NM_LAUNCH_CHECK();
   h->cur = now;
   return NM_OK;
 }
+
+extern "C" size_t nm_mpm_gridcache_bytes(int32_t cap_blocks) { return cap_blocks > 0 ? gridrec_bytes(cap_blocks) : 0; }
 
 static int check_particles(const nm_statics* st, const nm_particles* p, bool need_stress) {
   NM_REQUIRE(st && st->vol && st->rho && st->clip_bound && st->enabled, "null statics");
@@ -811,7 +880,13 @@ static int check_particles(const nm_statics* st, const nm_particles* p, bool nee
 
 extern "C" int nm_mpm_forward(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, nm_particles* next,
                               void* stream) {
+  return nm_mpm_forward_ex(h, n, st, cur, next, nullptr, 0, stream);
+}
+
+extern "C" int nm_mpm_forward_ex(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, nm_particles* next,
+                                 void* gridrec, int32_t cap_blocks, void* stream) {
   NM_REQUIRE(h, "null handle");
+  NM_REQUIRE(!gridrec || cap_blocks > 0, "grid cache record without capacity");
   NM_REQUIRE(n >= 0, "negative particle count");
   if (n == 0) return NM_OK;  // empty input: nothing to scatter or gather
   int rc = check_particles(st, cur, true);
@@ -819,7 +894,7 @@ extern "C" int nm_mpm_forward(nm_mpm* h, int32_t n, const nm_statics* st, const 
   rc = check_particles(st, next, false);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  rc = mpm_build_grid(h, n, st, cur, s);
+  rc = mpm_build_grid(h, n, st, cur, s, gridrec, nullptr, cap_blocks);
   if (rc) return rc;
   if (n > 0) {
     NM_LAUNCH(k_g2p, dim3(nm_div_up(n, 256)), dim3(256), 0, s, h->k, n, st->clip_bound, st->enabled, cur->x,
@@ -852,7 +927,14 @@ extern "C" int nm_mpm_forward_extra(nm_mpm* h, int32_t n, const nm_statics* st, 
 
 extern "C" int nm_mpm_backward(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur,
                                const nm_particles* next, const nm_particles* gnext, nm_particles* gcur, void* stream) {
+  return nm_mpm_backward_ex(h, n, st, cur, next, gnext, gcur, nullptr, 0, stream);
+}
+
+extern "C" int nm_mpm_backward_ex(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur,
+                                  const nm_particles* next, const nm_particles* gnext, nm_particles* gcur,
+                                  const void* gridrec, int32_t cap_blocks, void* stream) {
   NM_REQUIRE(h, "null handle");
+  NM_REQUIRE(!gridrec || cap_blocks > 0, "grid cache record without capacity");
   NM_REQUIRE(n >= 0, "negative particle count");
   if (n == 0) return NM_OK;
   int rc = check_particles(st, cur, true);
@@ -861,7 +943,7 @@ extern "C" int nm_mpm_backward(nm_mpm* h, int32_t n, const nm_statics* st, const
   NM_REQUIRE(gnext && gnext->x && gnext->v && gnext->C && gnext->F, "null incoming gradients");
   NM_REQUIRE(gcur && gcur->x && gcur->v && gcur->C && gcur->F && gcur->stress, "null outgoing gradients");
   hipStream_t s = (hipStream_t)stream;
-  rc = mpm_build_grid(h, n, st, cur, s);  // recompute, mpm.py:312-315
+  rc = mpm_build_grid(h, n, st, cur, s, nullptr, gridrec, cap_blocks);  // recompute (mpm.py:312-315) or restore
   if (rc) return rc;
   if (n == 0) return NM_OK;
   const int now = h->cur;

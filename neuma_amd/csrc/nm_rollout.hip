@@ -1,7 +1,8 @@
 // Fused roll-out of S substeps with checkpointed BPTT.
 // Operator order follows /root/reference/experiments/finetune.py:360-364 (stress = E(F); sim; F = P(F)),
 // the reverse sweep follows interface.py:41-76 + mpm.py:299-319 per step.  Only (x,v,C,F,stress) per substep is
-// kept (132 B/particle); the trial deformation gradient, the grid and every MLP activation are recomputed.
+// kept (132 B/particle), plus - optionally - each substep's touched grid blocks (the grid cache, see nm_mpm_forward_ex);
+// the trial deformation gradient and every MLP activation are recomputed.
 #include "nm_common.h"
 
 #define NM_WTOT_ (64 * 13 + 64 * 64 + 9 * 64)
@@ -76,8 +77,18 @@ __global__ void __launch_bounds__(256) k_add_inplace(size_t n, float* __restrict
   if (i < n) dst[i] += src[i];
 }
 
+extern "C" size_t nm_rollout_gridcache_bytes(int32_t substeps, int32_t grid_cache_blocks) {
+  if (substeps < 1 || grid_cache_blocks < 1) return 0;
+  return (size_t)substeps * nm_mpm_gridcache_bytes(grid_cache_blocks);
+}
+static inline void* grid_rec(const void* gridcache, const nm_rollout_cfg* cfg, int t) {
+  if (!gridcache || cfg->grid_cache_blocks < 1) return nullptr;
+  return (char*)const_cast<void*>(gridcache) + (size_t)t * nm_mpm_gridcache_bytes(cfg->grid_cache_blocks);
+}
+
 extern "C" int nm_rollout_forward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cfg, const nm_statics* st, const nm_mlp* we,
-                                  const nm_mlp* wp, float* states, void* workspace, size_t workspace_bytes, void* stream) {
+                                  const nm_mlp* wp, float* states, void* gridcache, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
   NM_REQUIRE(h && cfg && st && we && wp && states, "null pointer");
   NM_REQUIRE(n >= 0 && cfg->substeps >= 1, "bad sizes");
   if (n == 0) return NM_OK;
@@ -93,7 +104,7 @@ extern "C" int nm_rollout_forward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cf
     if (rc) return rc;
     nm_particles out = nxt;
     out.F = w.ftrial;
-    rc = nm_mpm_forward(h, n, st, &cur, &out, stream);                          // finetune.py:363
+    rc = nm_mpm_forward_ex(h, n, st, &cur, &out, grid_rec(gridcache, cfg, t), cfg->grid_cache_blocks, stream);  // finetune.py:363
     if (rc) return rc;
     rc = nm_material_fwd(n, NM_PLASTICITY, cfg->plasticity_alpha, w.ftrial, wp, nxt.F, stream);  // finetune.py:364
     if (rc) return rc;
@@ -102,8 +113,9 @@ extern "C" int nm_rollout_forward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cf
 }
 
 extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cfg, const nm_statics* st, const nm_mlp* we,
-                                   const nm_mlp* wp, const float* states, const float* gstate_last, float* gstate_first,
-                                   float* gw_e, float* gw_p, void* workspace, size_t workspace_bytes, void* stream) {
+                                   const nm_mlp* wp, const float* states, const void* gridcache, const float* gstate_last,
+                                   float* gstate_first, float* gw_e, float* gw_p, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
   NM_REQUIRE(h && cfg && st && we && wp && states && gstate_last && gstate_first && gw_e && gw_p, "null pointer");
   NM_REQUIRE(n >= 0 && cfg->substeps >= 1, "bad sizes");
   hipStream_t s = (hipStream_t)stream;
@@ -133,7 +145,7 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
     gn.x = const_cast<float*>(gin); gn.v = const_cast<float*>(gin) + 3 * N; gn.C = const_cast<float*>(gin) + 6 * N;
     gn.F = w.gFtr; gn.stress = nullptr;
     gc.x = gout; gc.v = gout + 3 * N; gc.C = gout + 6 * N; gc.F = gout + 15 * N; gc.stress = w.gS;
-    rc = nm_mpm_backward(h, n, st, &cur, &nxt, &gn, &gc, stream);
+    rc = nm_mpm_backward_ex(h, n, st, &cur, &nxt, &gn, &gc, grid_rec(gridcache, cfg, t), cfg->grid_cache_blocks, stream);
     if (rc) return rc;
     // elasticity backward: dL/dstress -> dL/dF (added to the sim's dL/dF)
     rc = nm_material_bwd_ex(n, NM_ELASTICITY, 0.f, cur.F, we, w.gS, w.gFe, gw_e, gw_e + 64 * 13, gw_e + 64 * 13 + 64 * 64, 1,

@@ -18,7 +18,8 @@ _WSZ = (64 * 13, 64 * 64, 9 * 64)
 class _Rollout(autograd.Function):
 
     @staticmethod
-    def forward(ctx, model: MPMModel, statics: MPMStatics, substeps: int, alpha: float, x, v, C_, F, e0, e1, e2, p0, p1, p2):
+    def forward(ctx, model: MPMModel, statics: MPMStatics, substeps: int, alpha: float, cache_blocks: int,
+                x, v, C_, F, e0, e1, e2, p0, p1, p2):
         lib = L.lib()
         dev = x.device
         n = x.size(0)
@@ -33,13 +34,19 @@ class _Rollout(autograd.Function):
         wp = [t.detach().float().contiguous() for t in (p0, p1, p2)]
         ws_bytes = int(lib.nm_rollout_workspace(n, S))
         ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
-        cfg = L.nm_rollout_cfg(S, float(alpha))
+        # grid cache: only when a backward pass can follow (ground-truth / inference roll-outs skip it)
+        cache_blocks = int(cache_blocks) if any(ctx.needs_input_grad) else 0
+        gc_bytes = int(lib.nm_rollout_gridcache_bytes(S, cache_blocks)) if cache_blocks > 0 else 0
+        gcache = torch.empty(gc_bytes, dtype=torch.uint8, device=dev) if gc_bytes > 0 else None
+        cfg = L.nm_rollout_cfg(S, float(alpha), cache_blocks if gcache is not None else 0)
         st = statics.c_struct()
         mle = L.nm_mlp(*[L.ptr(t) for t in we])
         mlp = L.nm_mlp(*[L.ptr(t) for t in wp])
         L.check(lib.nm_rollout_forward(model.handle(), n, C.byref(cfg), C.byref(st), C.byref(mle), C.byref(mlp), L.ptr(states),
-                                       L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "nm_rollout_forward")
+                                       L.ptr(gcache) if gcache is not None else None, L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
+                "nm_rollout_forward")
         ctx.model, ctx.statics, ctx.S, ctx.alpha, ctx.n = model, statics, S, float(alpha), n
+        ctx.cache_blocks, ctx.gcache = int(cfg.grid_cache_blocks), gcache
         ctx.save_for_backward(states, *we, *wp)
         last = states[S]
         return (last[:3 * n].view(n, 3), last[3 * n:6 * n].view(n, 3), last[6 * n:15 * n].view(n, 3, 3),
@@ -63,16 +70,18 @@ class _Rollout(autograd.Function):
         gwp = torch.empty(sum(_WSZ), dtype=torch.float32, device=dev)
         ws_bytes = int(lib.nm_rollout_workspace(n, S))
         ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
-        cfg = L.nm_rollout_cfg(S, ctx.alpha)
+        cfg = L.nm_rollout_cfg(S, ctx.alpha, ctx.cache_blocks)
+        gcache = ctx.gcache
         st = ctx.statics.c_struct()
         mle = L.nm_mlp(L.ptr(e0), L.ptr(e1), L.ptr(e2))
         mlp = L.nm_mlp(L.ptr(p0), L.ptr(p1), L.ptr(p2))
         L.check(lib.nm_rollout_backward(ctx.model.handle(), n, C.byref(cfg), C.byref(st), C.byref(mle), C.byref(mlp),
-                                        L.ptr(states), L.ptr(glast), L.ptr(gfirst), L.ptr(gwe), L.ptr(gwp), L.ptr(ws), ws_bytes,
-                                        L.stream_ptr(dev)), "nm_rollout_backward")
+                                        L.ptr(states), L.ptr(gcache) if gcache is not None else None, L.ptr(glast), L.ptr(gfirst),
+                                        L.ptr(gwe), L.ptr(gwp), L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "nm_rollout_backward")
+        ctx.gcache = None
         torch.nan_to_num_(gfirst, 0.0, 0.0, 0.0)   # interface.py:65-74 at the boundary of the fused node
         a, b = _WSZ[0], _WSZ[0] + _WSZ[1]
-        return (None, None, None, None,
+        return (None, None, None, None, None,
                 gfirst[:3 * n].view(n, 3), gfirst[3 * n:6 * n].view(n, 3), gfirst[6 * n:15 * n].view(n, 3, 3),
                 gfirst[15 * n:].view(n, 3, 3),
                 gwe[:a].view(64, 13), gwe[a:b].view(64, 64), gwe[b:].view(9, 64),
@@ -80,13 +89,28 @@ class _Rollout(autograd.Function):
 
 
 class MPMFusedDiffSim(nn.Module):
-    """sim(statics, x, v, C, F) -> (x, v, C, F) after `substeps` substeps, constitutive nets included."""
+    """sim(statics, x, v, C, F) -> (x, v, C, F) after `substeps` substeps, constitutive nets included.
 
-    def __init__(self, model: MPMModel, elasticity: nn.Module, plasticity: nn.Module, substeps: int) -> None:
+    grid_cache: "auto" (default) keeps each substep's touched grid blocks for the backward pass (the reverse sweep then
+    restores the grid instead of re-running p2g); the per-substep capacity is sized once from the number of blocks the
+    first roll-out touches (x1.5 + 64; one host sync) - a substep that outgrows it falls back to the recompute on its
+    own.  An int fixes the capacity in 4x4x4-node blocks; 0 / None disables the cache (the reference's behaviour)."""
+
+    def __init__(self, model: MPMModel, elasticity: nn.Module, plasticity: nn.Module, substeps: int, grid_cache="auto") -> None:
         super().__init__()
         self.model, self.elasticity, self.plasticity, self.substeps = model, elasticity, plasticity, int(substeps)
+        self.grid_cache = grid_cache
+        self._cache_blocks = None if grid_cache == "auto" else int(grid_cache or 0)
+
+    def grid_cache_blocks(self) -> int:
+        return int(self._cache_blocks or 0)
 
     def forward(self, statics: MPMStatics, x: Tensor, v: Tensor, C_: Tensor, F: Tensor):
         e = self.elasticity.effective_weights()
         p = self.plasticity.effective_weights()
-        return _Rollout.apply(self.model, statics, self.substeps, self.plasticity.alpha, x, v, C_, F, *e, *p)
+        out = _Rollout.apply(self.model, statics, self.substeps, self.plasticity.alpha, self.grid_cache_blocks(), x, v, C_, F,
+                             *e, *p)
+        if self._cache_blocks is None:      # first roll-out: size the cache from what the scene touches
+            blocks, _ = self.model.grid_stats()
+            self._cache_blocks = int(1.5 * blocks) + 64
+        return out

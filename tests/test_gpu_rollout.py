@@ -117,3 +117,78 @@ def test_frame_image_matches_oracle_render():
     cov = orr.deform_cov_by_F(rt._cov.cpu().double(), dg.cpu().double())
     oimg, _ = orr.render(s, means3D.cpu().double(), cov, rt._opacity.cpu().double(), shs=rt._shs.cpu().double())
     assert abs_max(img, oimg) < 1e-3
+
+
+def test_grid_cache_restores_the_same_grid_as_the_recompute():
+    """Reverse sweep with the grid cache (nm_mpm_forward_ex / nm_mpm_backward_ex) == recompute of mpm.py:312-315:
+    same gradients with an ample capacity, with the auto-sized one, and with a capacity every substep overflows
+    (record marked invalid -> transparent fallback)."""
+    S = 4
+    rt = _runtime("tiny", fused=True, S=S)
+    params = rt.parameters()
+    torch.manual_seed(1)
+    gws = [torch.randn(rt.N, 3), torch.randn(rt.N, 3), torch.randn(rt.N, 3, 3), torch.randn(rt.N, 3, 3)]
+    g = torch.Generator().manual_seed(5)
+    F0 = (torch.eye(3) + 0.05 * torch.randn(rt.N, 3, 3, generator=g)).to(dev())
+    blocks, _ = (rt.rollout(rt.x0, rt.v0, rt.C0, F0), rt.model.grid_stats())[1]
+    assert blocks > 1
+    res = {}
+    for tag, cap in (("off", 0), ("ample", 4 * blocks), ("overflow", 1), ("auto", None)):
+        rt.sim_fused._cache_blocks = cap
+        if cap is None:      # auto: the first call sizes the cache, the second one uses it
+            rt.rollout(rt.x0, rt.v0, rt.C0, F0)
+            assert rt.sim_fused.grid_cache_blocks() == int(1.5 * blocks) + 64
+        ins = [t.clone().requires_grad_(True) for t in (rt.x0, rt.v0, rt.C0, F0)]
+        outs = rt.rollout(*ins)
+        loss = sum((o * w.to(dev())).sum() for o, w in zip(outs, gws))
+        res[tag] = torch.autograd.grad(loss, ins + params)
+    for tag in ("ample", "overflow", "auto"):
+        for a, b in zip(res[tag], res["off"]):
+            assert torch.isfinite(a).all()
+            assert rel_max(a, b) < 2e-4, tag
+
+
+def test_grid_cache_per_step_api_matches_plain_backward():
+    """nm_mpm_forward_ex + nm_mpm_backward_ex against nm_mpm_forward + nm_mpm_backward on one substep."""
+    import ctypes as C
+    from neuma_amd import _lib as L
+    rt = _runtime("tiny", fused=False, S=1)
+    lib = L.lib()
+    n = rt.N
+    d = dev()
+    torch.manual_seed(2)
+    x, v = rt.x0.clone(), rt.v0.clone() + 0.1 * torch.randn(n, 3, device=d)
+    Cm = 0.1 * torch.randn(n, 3, 3, device=d)
+    F = torch.eye(3, device=d).repeat(n, 1, 1) + 0.02 * torch.randn(n, 3, 3, device=d)
+    stress = torch.randn(n, 3, 3, device=d)
+    st = rt.statics.c_struct()
+
+    def parts(*ts):
+        return L.nm_particles(*[L.ptr(t) if t is not None else None for t in ts])
+
+    outs = {}
+    for tag in ("plain", "cached"):
+        nx, nv, nC, nF = (torch.empty_like(t) for t in (x, v, Cm, F))
+        cur, nxt = parts(x, v, Cm, F, stress), parts(nx, nv, nC, nF, None)
+        torch.manual_seed(3)
+        gn = [torch.randn(t.shape, device=d) for t in (x, v, Cm, F)]
+        gc = [torch.empty_like(t) for t in (x, v, Cm, F, stress)]
+        gnp, gcp = parts(*gn, None), parts(*gc)
+        h, s = rt.model.handle(), L.stream_ptr(d)
+        if tag == "plain":
+            L.check(lib.nm_mpm_forward(h, n, C.byref(st), C.byref(cur), C.byref(nxt), s), "fwd")
+            L.check(lib.nm_mpm_backward(h, n, C.byref(st), C.byref(cur), C.byref(nxt), C.byref(gnp), C.byref(gcp), s), "bwd")
+        else:
+            cap = 4096
+            rec = torch.empty(int(lib.nm_mpm_gridcache_bytes(cap)), dtype=torch.uint8, device=d)
+            L.check(lib.nm_mpm_forward_ex(h, n, C.byref(st), C.byref(cur), C.byref(nxt), L.ptr(rec), cap, s), "fwd_ex")
+            hdr = rec[:4].view(torch.int32)
+            assert int(hdr[0]) == rt.model.grid_stats()[0] > 0
+            # an unrelated step in between must not matter: the record carries everything the adjoint needs
+            L.check(lib.nm_mpm_forward(h, n, C.byref(st), C.byref(parts(x + 0.01, v, Cm, F, stress)), C.byref(parts(*[torch.empty_like(t) for t in (x, v, Cm, F)], None)), s), "fwd")
+            L.check(lib.nm_mpm_backward_ex(h, n, C.byref(st), C.byref(cur), C.byref(nxt), C.byref(gnp), C.byref(gcp),
+                                           L.ptr(rec), cap, s), "bwd_ex")
+        torch.cuda.synchronize()
+        outs[tag] = [nx, nv, nC, nF] + gc
+    for a, b in zip(outs["cached"], outs["plain"]):
+        assert rel_max(a, b) < 1e-4
