@@ -47,6 +47,9 @@ extern int g_nm_prof_on;
 
 // internal cross-file helpers
 float nm_mpm_get_dt(const nm_mpm* h);
+int nm_material_bwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* gout, float* gF,
+                           float* wpart, int wmode, void* stream);
+int nm_material_wgrad_reduce(const float* wpart, int32_t n, float* gw0, float* gw1, float* gw2, int accumulate, void* stream);
 
 static inline int nm_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

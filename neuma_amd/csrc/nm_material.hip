@@ -31,6 +31,7 @@ extern "C" int nm_debug_phases(long long* out, int n) {
 #endif
 #define NM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+#define NM_BWD_GRID 256   // workgroups of the constitutive kernels = CUs
 #define NM_W0 (64 * 13)
 #define NM_W1 (64 * 64)
 #define NM_W2 (9 * 64)
@@ -141,33 +142,62 @@ extern "C" int nm_svd3_bwd(int32_t n, const float* U, const float* sigma, const 
 // Raw weights are first copied to LDS with coalesced loads (w0 | w1 | w2 back to back, NM_WTOT floats), then permuted
 // LDS -> LDS into MFMA operand order (a direct permuting gather from global costs ~12k cycles per workgroup: 64
 // scattered 4-byte reads per wave-instruction).
+#define NM_RLD 65
+#define NM_RAW1 NM_W0
+#define NM_RAW2 (NM_W0 + 64 * NM_RLD)
+#define NM_RAWTOT (NM_RAW2 + 9 * NM_RLD)
 __device__ __forceinline__ void stage_raw_weights(const float* __restrict__ w0, const float* __restrict__ w1,
                                                   const float* __restrict__ w2, float* raw) {
+  // all 11 loads of a thread are issued before the first LDS write: a rolled copy loop pays one L2 round trip per
+  // iteration (~1k cycles each, 11 of them), this pays one.  Requires blockDim.x == 256.
   const int tid = threadIdx.x;
-  for (int i = tid; i < NM_W0; i += blockDim.x) raw[i] = w0[i];
-  for (int i = tid; i < NM_W1 / 4; i += blockDim.x) reinterpret_cast<float4*>(raw + NM_W0)[i] = reinterpret_cast<const float4*>(w1)[i];
-  for (int i = tid; i < NM_W2; i += blockDim.x) raw[NM_W0 + NM_W1 + i] = w2[i];
+  float a0[4], a2[3];
+  float4 a1[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int i = tid + 256 * k;
+    a0[k] = i < NM_W0 ? w0[i] : 0.f;
+    a1[k] = reinterpret_cast<const float4*>(w1)[i];
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    int i = tid + 256 * k;
+    a2[k] = i < NM_W2 ? w2[i] : 0.f;
+  }
+  // w1 / w2 rows are padded to NM_RLD floats so that the column-major gathers of the permute pass are conflict free
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int i = tid + 256 * k;
+    if (i < NM_W0) raw[i] = a0[k];
+    float* d = raw + NM_RAW1 + (i >> 4) * NM_RLD + 4 * (i & 15);
+    d[0] = a1[k].x; d[1] = a1[k].y; d[2] = a1[k].z; d[3] = a1[k].w;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    int i = tid + 256 * k;
+    if (i < NM_W2) raw[NM_RAW2 + (i >> 6) * NM_RLD + (i & 63)] = a2[k];
+  }
 }
 __device__ __forceinline__ void stage_fwd_weights(const float* raw, float* P0, float* P1, float* P2) {
-  const float *w0 = raw, *w1 = raw + NM_W0, *w2 = raw + NM_W0 + NM_W1;
+  const float *w0 = raw, *w1 = raw + NM_RAW1, *w2 = raw + NM_RAW2;
   const int tid = threadIdx.x;
   for (int idx = tid; idx < 16 * 64; idx += blockDim.x) {
     int l = idx & 63, op = idx >> 6, ks = op >> 2, rt = op & 3, k = 4 * ks + (l >> 4);
     P0[idx] = k < 13 ? w0[(16 * rt + (l & 15)) * 13 + k] : 0.f;
     int reg = op & 3, rtp = op >> 2, row = l & 15;
-    P2[idx] = row < 9 ? w2[row * 64 + 16 * rtp + 4 * (l >> 4) + reg] : 0.f;
+    P2[idx] = row < 9 ? w2[row * NM_RLD + 16 * rtp + 4 * (l >> 4) + reg] : 0.f;
   }
   for (int idx = tid; idx < 64 * 64; idx += blockDim.x) {
     int l = idx & 63, op = idx >> 6, rt = op & 3, reg = (op >> 2) & 3, rtp = op >> 4;
-    P1[idx] = w1[(16 * rt + (l & 15)) * 64 + 16 * rtp + 4 * (l >> 4) + reg];
+    P1[idx] = w1[(16 * rt + (l & 15)) * NM_RLD + 16 * rtp + 4 * (l >> 4) + reg];
   }
 }
 __device__ __forceinline__ void stage_bwd_weights(const float* raw, float* Q0, float* Q1, float* Q2) {
-  const float *w0 = raw, *w1 = raw + NM_W0, *w2 = raw + NM_W0 + NM_W1;
+  const float *w0 = raw, *w1 = raw + NM_RAW1, *w2 = raw + NM_RAW2;
   const int tid = threadIdx.x;
   for (int idx = tid; idx < 12 * 64; idx += blockDim.x) {
     int l = idx & 63, op = idx >> 6, ks = op >> 2, rt = op & 3, row = 4 * ks + (l >> 4);
-    Q2[idx] = row < 9 ? w2[row * 64 + 16 * rt + (l & 15)] : 0.f;
+    Q2[idx] = row < 9 ? w2[row * NM_RLD + 16 * rt + (l & 15)] : 0.f;
   }
   for (int idx = tid; idx < 16 * 64; idx += blockDim.x) {
     int l = idx & 63, op = idx >> 6, reg = op & 3, rtp = op >> 2, col = l & 15;
@@ -175,7 +205,7 @@ __device__ __forceinline__ void stage_bwd_weights(const float* raw, float* Q0, f
   }
   for (int idx = tid; idx < 64 * 64; idx += blockDim.x) {
     int l = idx & 63, op = idx >> 6, rt = op & 3, reg = (op >> 2) & 3, rtp = op >> 4;
-    Q1[idx] = w1[(16 * rtp + 4 * (l >> 4) + reg) * 64 + 16 * rt + (l & 15)];
+    Q1[idx] = w1[(16 * rtp + 4 * (l >> 4) + reg) * NM_RLD + 16 * rt + (l & 15)];
   }
 }
 
@@ -247,14 +277,27 @@ __device__ __forceinline__ void mlp_forward_tile(const float* __restrict__ P0, c
 }
 
 // ---------------------------------------------------------------- forward
+// Work split of the constitutive kernels: one workgroup (4 waves, one per SIMD) per CU, each wave owns q consecutive
+// particles, q = the per-wave share rounded up to whole 16-particle MFMA tiles.  At 100k particles every wave gets
+// 112 particles = 2 SVD rounds + 7 tiles, instead of a 64-particle batch granularity that leaves half the SIMDs with
+// 2 batches (8 tiles) and the rest with 1.
+static inline void nm_wave_quota(int n, int& grid, int& q) {
+  const int waves = NM_BWD_GRID * 4;
+  q = (n + waves - 1) / waves;
+  q = ((q + 15) / 16) * 16;
+  if (q < 16) q = 16;
+  grid = nm_div_up(n, 4 * (int64_t)q);
+  if (grid < 1) grid = 1;
+}
+
 template <int KIND>
-__global__ void __launch_bounds__(256) k_material_fwd(int n, float alpha, const float* __restrict__ F,
+__global__ void __launch_bounds__(256) k_material_fwd(int n, int q, float alpha, const float* __restrict__ F,
                                                       const float* __restrict__ w0, const float* __restrict__ w1,
                                                       const float* __restrict__ w2, float* __restrict__ out) {
   __shared__ float sP0[16 * 64], sP1[64 * 64], sP2[16 * 64];
   // per-wave buffers (features 64x17, outputs 64x9); before the main loop the same memory holds the raw weights
   __shared__ __attribute__((aligned(16))) float sBuf[4 * 64 * 17 + 4 * 64 * 9];
-  static_assert(4 * 64 * 17 + 4 * 64 * 9 >= NM_WTOT, "raw weights must fit the per-wave buffers");
+  static_assert(4 * 64 * 17 + 4 * 64 * 9 >= NM_RAWTOT, "raw weights must fit the per-wave buffers");
   float (*sZ)[64 * 17] = reinterpret_cast<float (*)[64 * 17]>(sBuf);
   float (*sY)[64 * 9] = reinterpret_cast<float (*)[64 * 9]>(sBuf + 4 * 64 * 17);
   NM_PH_DECL
@@ -265,12 +308,15 @@ __global__ void __launch_bounds__(256) k_material_fwd(int n, float alpha, const 
   NM_PH(0)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int j = lane & 15, g = lane >> 4;
-  const int nbatch = (n + 63) >> 6;
   float* zb = sZ[wave];
   float* yb = sY[wave];
-  for (int batch = blockIdx.x * 4 + wave; batch < nbatch; batch += gridDim.x * 4) {
-    const int p = batch * 64 + lane;
-    const bool valid = p < n;
+  // wave w owns particles [w*q, (w+1)*q), q a multiple of 16 (nm_wave_quota): every wave runs the same number of SVD
+  // rounds and - because a round only visits the 16-particle tiles it actually holds - (almost) the same number of tiles
+  const int pbeg = min(n, (blockIdx.x * 4 + wave) * q), pend = min(n, pbeg + q);
+  for (int c0 = pbeg; c0 < pend; c0 += 64) {
+    const int p = c0 + lane;
+    const bool valid = p < pend;
+    const int ntile = (min(64, pend - c0) + 15) >> 4;
     M3 Fp = valid ? m3_load(F + 9 * p) : m3_ident();
     M3 R, U, V;
     float z[13], s[3];
@@ -290,9 +336,13 @@ __global__ void __launch_bounds__(256) k_material_fwd(int n, float alpha, const 
       for (int ks = 0; ks < 4; ++ks) zin[ct][ks] = zb[(ct * 16 + j) * 17 + 4 * ks + g];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
-      MlpFwd m;
-      mlp_forward_tile<false>(sP0, sP1, sP2, zin[ct], lane, m);
-      yv[ct] = m.y;
+      if (ct < ntile) {     // wave-uniform
+        MlpFwd m;
+        mlp_forward_tile<false>(sP0, sP1, sP2, zin[ct], lane, m);
+        yv[ct] = m.y;
+      } else {
+        yv[ct] = (f4){0.f, 0.f, 0.f, 0.f};
+      }
     }
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
@@ -331,19 +381,18 @@ extern "C" int nm_material_fwd(int32_t n, int32_t kind, float alpha, const float
   NM_REQUIRE(kind == NM_ELASTICITY || kind == NM_PLASTICITY, "kind must be NM_ELASTICITY or NM_PLASTICITY");
   if (n == 0) return NM_OK;
   NM_REQUIRE(F && out && w && w->w0 && w->w1 && w->w2, "null pointer");
-  int grid = nm_div_up(n, 256);
-  if (grid > 768) grid = 768;
+  int grid, q;
+  nm_wave_quota(n, grid, q);
   hipStream_t s = (hipStream_t)stream;
   if (kind == NM_ELASTICITY)
-    NM_LAUNCH(k_material_fwd<NM_ELASTICITY>, dim3(grid), dim3(256), 0, s, n, alpha, F, w->w0, w->w1, w->w2, out);
+    NM_LAUNCH(k_material_fwd<NM_ELASTICITY>, dim3(grid), dim3(256), 0, s, n, q, alpha, F, w->w0, w->w1, w->w2, out);
   else
-    NM_LAUNCH(k_material_fwd<NM_PLASTICITY>, dim3(grid), dim3(256), 0, s, n, alpha, F, w->w0, w->w1, w->w2, out);
+    NM_LAUNCH(k_material_fwd<NM_PLASTICITY>, dim3(grid), dim3(256), 0, s, n, q, alpha, F, w->w0, w->w1, w->w2, out);
   NM_LAUNCH_CHECK();
   return NM_OK;
 }
 
 // ---------------------------------------------------------------- backward
-#define NM_BWD_GRID 256
 struct BwdLds {
   float P0[16 * 64], P1[64 * 64], P2[16 * 64];
   float Q0[16 * 64], Q1[64 * 64], Q2[12 * 64];
@@ -356,7 +405,7 @@ struct BwdLds {
 };
 
 template <int KIND>
-__global__ void __launch_bounds__(256, 1) k_material_bwd(int n, float alpha, const float* __restrict__ F,
+__global__ void __launch_bounds__(256, 1) k_material_bwd(int n, int q, float alpha, const float* __restrict__ F,
                                                          const float* __restrict__ w0, const float* __restrict__ w1,
                                                          const float* __restrict__ w2, const float* __restrict__ gout,
                                                          float* __restrict__ gF, float* __restrict__ wpart, int want_w) {
@@ -374,7 +423,6 @@ __global__ void __launch_bounds__(256, 1) k_material_bwd(int n, float alpha, con
   NM_PH(0)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int j = lane & 15, g = lane >> 4;
-  const int nbatch = (n + 63) >> 6;
   float* zb = L.Z[wave];
   float* gyb = L.GY[wave];
   float* yb = L.Y[wave];
@@ -389,9 +437,11 @@ __global__ void __launch_bounds__(256, 1) k_material_bwd(int n, float alpha, con
 #pragma unroll
     for (int b = 0; b < 4; ++b) gW1[a][b] = zero;
   }
-  for (int batch = blockIdx.x * 4 + wave; batch < nbatch; batch += gridDim.x * 4) {
-    const int p = batch * 64 + lane;
-    const bool valid = p < n;
+  const int pbeg = min(n, (blockIdx.x * 4 + wave) * q), pend = min(n, pbeg + q);   // see nm_wave_quota
+  for (int c0 = pbeg; c0 < pend; c0 += 64) {
+    const int p = c0 + lane;
+    const bool valid = p < pend;
+    const int ntile = (min(64, pend - c0) + 15) >> 4;
     M3 Fp = valid ? m3_load(F + 9 * p) : m3_ident();
     M3 go = valid ? m3_load(gout + 9 * p) : m3_zero();
     M3 R, U, V;
@@ -417,7 +467,7 @@ __global__ void __launch_bounds__(256, 1) k_material_bwd(int n, float alpha, con
     NM_PH(1)
 
 #pragma unroll 1
-    for (int ct = 0; ct < 4; ++ct) {
+    for (int ct = 0; ct < ntile; ++ct) {
       MlpFwd m;
       float zin[4];
 #pragma unroll
@@ -585,20 +635,21 @@ __global__ void __launch_bounds__(256, 1) k_material_bwd(int n, float alpha, con
   NM_PH_STORE
 
   if (!want_w) return;
-  // reduce the four waves' weight-gradient accumulators through LDS (weights no longer needed), write the
-  // workgroup partial in plain (out,in) layout
+  // combine the four waves' weight-gradient accumulators: every wave stores its own copy in plain (out,in) layout to a
+  // private LDS region (the weights and per-wave buffers are dead by now), then the workgroup sums the four copies.
+  // (LDS float atomics would serialise here: ds_add_f32 sustains ~0.3 lanes/clk/CU on gfx950, i.e. ~70k cycles for the
+  // 24 576 lane-adds, against ~3k for this.)
   __syncthreads();
-  float* red = L.P0;  // >= NM_WTOT floats available contiguously (P0,P1,P2 = 6144 floats)
-  for (int i = threadIdx.x; i < NM_WTOT; i += blockDim.x) red[i] = 0.f;
-  __syncthreads();
+  static_assert(sizeof(BwdLds) >= 4 * NM_WTOT * sizeof(float), "four weight-gradient copies must fit");
+  float* red = reinterpret_cast<float*>(smem_raw) + wave * NM_WTOT;
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       int row = 16 * rt + 4 * g + r;
-      if (j < 13) unsafeAtomicAdd(&red[row * 13 + j], gW0[rt][r]);
+      if (j < 13) red[row * 13 + j] = gW0[rt][r];
 #pragma unroll
-      for (int ctp = 0; ctp < 4; ++ctp) unsafeAtomicAdd(&red[NM_W0 + row * 64 + 16 * ctp + j], gW1[rt][ctp][r]);
+      for (int ctp = 0; ctp < 4; ++ctp) red[NM_W0 + row * 64 + 16 * ctp + j] = gW1[rt][ctp][r];
     }
   }
 #pragma unroll
@@ -606,11 +657,17 @@ __global__ void __launch_bounds__(256, 1) k_material_bwd(int n, float alpha, con
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       int row = 4 * g + r;
-      if (row < 9) unsafeAtomicAdd(&red[NM_W0 + NM_W1 + row * 64 + 16 * ctp + j], gW2[ctp][r]);
+      if (row < 9) red[NM_W0 + NM_W1 + row * 64 + 16 * ctp + j] = gW2[ctp][r];
     }
   __syncthreads();
+  // want_w == 2: add to the partial this workgroup wrote in earlier launches (the roll-out sums over substeps and
+  // reduces once); the order of additions is fixed, so the result stays deterministic
+  const float* all = reinterpret_cast<const float*>(smem_raw);
   float* dst = wpart + (size_t)blockIdx.x * NM_WTOT;
-  for (int i = threadIdx.x; i < NM_WTOT; i += blockDim.x) dst[i] = red[i];
+  for (int i = threadIdx.x; i < NM_WTOT; i += blockDim.x) {
+    float v = (all[i] + all[NM_WTOT + i]) + (all[2 * NM_WTOT + i] + all[3 * NM_WTOT + i]);
+    dst[i] = want_w == 2 ? dst[i] + v : v;
+  }
 }
 
 // sum the per-workgroup partials: a workgroup owns 64 consecutive weights, its four waves each sum a quarter of the
@@ -640,6 +697,40 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
     float* dst = i < NM_W0 ? g0 + i : (i < NM_W0 + NM_W1 ? g1 + (i - NM_W0) : g2 + (i - NM_W0 - NM_W1));
     *dst = accumulate ? *dst + acc : acc;
   }
+}
+
+// internal (also used by the fused roll-out): launch the backward kernel only.  wmode 0: no weight gradients,
+// 1: write this launch's per-workgroup partial sums to wpart, 2: add them to wpart.
+int nm_material_bwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* gout, float* gF,
+                           float* wpart, int wmode, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  int grid, q;
+  nm_wave_quota(n, grid, q);
+  static bool attr_set = false;
+  if (!attr_set) {
+    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd<NM_ELASTICITY>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)sizeof(BwdLds)));
+    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd<NM_PLASTICITY>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)sizeof(BwdLds)));
+    attr_set = true;
+  }
+  if (kind == NM_ELASTICITY)
+    NM_LAUNCH(k_material_bwd<NM_ELASTICITY>, dim3(grid), dim3(256), sizeof(BwdLds), s, n, q, alpha, F, w->w0, w->w1,
+                       w->w2, gout, gF, wpart, wmode);
+  else
+    NM_LAUNCH(k_material_bwd<NM_PLASTICITY>, dim3(grid), dim3(256), sizeof(BwdLds), s, n, q, alpha, F, w->w0, w->w1,
+                       w->w2, gout, gF, wpart, wmode);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}
+// internal: gw (+)= sum of the per-workgroup partials of a launch over n particles
+int nm_material_wgrad_reduce(const float* wpart, int32_t n, float* gw0, float* gw1, float* gw2, int accumulate, void* stream) {
+  int grid, q;
+  nm_wave_quota(n, grid, q);
+  NM_LAUNCH(k_wgrad_reduce, dim3(nm_div_up(NM_WTOT, 64)), dim3(256), 0, (hipStream_t)stream, wpart, grid, gw0, gw1, gw2,
+                     accumulate);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
 }
 
 extern "C" size_t nm_material_bwd_workspace(int32_t n) {
@@ -676,27 +767,8 @@ extern "C" int nm_material_bwd_ex(int32_t n, int32_t kind, float alpha, const fl
                  workspace_bytes);
     return NM_ERR_WORKSPACE;
   }
-  int grid = nm_div_up(n, 256);
-  if (grid > NM_BWD_GRID) grid = NM_BWD_GRID;
-  static bool attr_set = false;
-  if (!attr_set) {
-    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd<NM_ELASTICITY>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)sizeof(BwdLds)));
-    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd<NM_PLASTICITY>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)sizeof(BwdLds)));
-    attr_set = true;
-  }
-  if (kind == NM_ELASTICITY)
-    NM_LAUNCH(k_material_bwd<NM_ELASTICITY>, dim3(grid), dim3(256), sizeof(BwdLds), s, n, alpha, F, w->w0, w->w1,
-                       w->w2, gout, gF, (float*)workspace, want_w);
-  else
-    NM_LAUNCH(k_material_bwd<NM_PLASTICITY>, dim3(grid), dim3(256), sizeof(BwdLds), s, n, alpha, F, w->w0, w->w1,
-                       w->w2, gout, gF, (float*)workspace, want_w);
-  NM_LAUNCH_CHECK();
-  if (want_w) {
-    NM_LAUNCH(k_wgrad_reduce, dim3(nm_div_up(NM_WTOT, 64)), dim3(256), 0, s, (const float*)workspace, grid, gw0,
-                       gw1, gw2, (int)accumulate);
-    NM_LAUNCH_CHECK();
-  }
+  int rc = nm_material_bwd_launch(n, kind, alpha, F, w, gout, gF, (float*)workspace, want_w, stream);
+  if (rc) return rc;
+  if (want_w) return nm_material_wgrad_reduce((const float*)workspace, n, gw0, gw1, gw2, accumulate, stream);
   return NM_OK;
 }

@@ -17,8 +17,8 @@ struct RolloutWs {
   float* gS;       // N*9
   float* gFe;      // N*9
   float* gFtr;     // N*9
-  void* mat;       // material backward workspace
-  size_t mat_bytes;
+  float* part_e;   // per-workgroup weight-gradient partials, summed over substeps, one buffer per net
+  float* part_p;
   size_t total;
 };
 
@@ -34,9 +34,9 @@ static RolloutWs carve_ws(void* base, int n) {
   w.gS = take(N * 9);
   w.gFe = take(N * 9);
   w.gFtr = take(N * 9);
-  w.mat_bytes = nm_material_bwd_workspace(n);
-  w.mat = (void*)(p + o);
-  o += al256r(w.mat_bytes);
+  const size_t part = nm_material_bwd_workspace(n) / sizeof(float);
+  w.part_e = take(part);
+  w.part_p = take(part);
   w.total = o;
   return w;
 }
@@ -119,9 +119,11 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
   NM_REQUIRE(h && cfg && st && we && wp && states && gstate_last && gstate_first && gw_e && gw_p, "null pointer");
   NM_REQUIRE(n >= 0 && cfg->substeps >= 1, "bad sizes");
   hipStream_t s = (hipStream_t)stream;
-  NM_HIP_CHECK(hipMemsetAsync(gw_e, 0, NM_WTOT_ * sizeof(float), s));
-  NM_HIP_CHECK(hipMemsetAsync(gw_p, 0, NM_WTOT_ * sizeof(float), s));
-  if (n == 0) return NM_OK;
+  if (n == 0) {
+    NM_HIP_CHECK(hipMemsetAsync(gw_e, 0, NM_WTOT_ * sizeof(float), s));
+    NM_HIP_CHECK(hipMemsetAsync(gw_p, 0, NM_WTOT_ * sizeof(float), s));
+    return NM_OK;
+  }
   RolloutWs w = carve_ws(workspace, n);
   if (!workspace || workspace_bytes < w.total) {
     nm_set_error("rollout workspace too small: need %zu got %zu", w.total, workspace_bytes);
@@ -137,8 +139,8 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
     // trial F of this step, then plasticity backward: dL/dF_{t+1} -> dL/dFtrial
     NM_LAUNCH(k_trial_F, dim3(nm_div_up(n, 256)), dim3(256), 0, s, n, nm_mpm_get_dt(h), st->enabled, nxt.C, cur.F, w.ftrial);
     NM_LAUNCH_CHECK();
-    rc = nm_material_bwd_ex(n, NM_PLASTICITY, cfg->plasticity_alpha, w.ftrial, wp, gin + 15 * N, w.gFtr, gw_p, gw_p + 64 * 13,
-                            gw_p + 64 * 13 + 64 * 64, 1, w.mat, w.mat_bytes, stream);
+    const int wmode = (t == cfg->substeps - 1) ? 1 : 2;   // first visit writes the partials, later ones add
+    rc = nm_material_bwd_launch(n, NM_PLASTICITY, cfg->plasticity_alpha, w.ftrial, wp, gin + 15 * N, w.gFtr, w.part_p, wmode, stream);
     if (rc) return rc;
     // sim backward (stress of this step was checkpointed by the forward pass)
     nm_particles gn, gc;
@@ -148,12 +150,14 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
     rc = nm_mpm_backward_ex(h, n, st, &cur, &nxt, &gn, &gc, grid_rec(gridcache, cfg, t), cfg->grid_cache_blocks, stream);
     if (rc) return rc;
     // elasticity backward: dL/dstress -> dL/dF (added to the sim's dL/dF)
-    rc = nm_material_bwd_ex(n, NM_ELASTICITY, 0.f, cur.F, we, w.gS, w.gFe, gw_e, gw_e + 64 * 13, gw_e + 64 * 13 + 64 * 64, 1,
-                            w.mat, w.mat_bytes, stream);
+    rc = nm_material_bwd_launch(n, NM_ELASTICITY, 0.f, cur.F, we, w.gS, w.gFe, w.part_e, wmode, stream);
     if (rc) return rc;
     NM_LAUNCH(k_add_inplace, dim3(nm_div_up((int64_t)N * 9, 256)), dim3(256), 0, s, N * 9, gc.F, w.gFe);
     NM_LAUNCH_CHECK();
     gin = gout;
   }
-  return NM_OK;
+  // one deterministic reduction per net for the whole roll-out
+  rc = nm_material_wgrad_reduce(w.part_e, n, gw_e, gw_e + 64 * 13, gw_e + 64 * 13 + 64 * 64, 0, stream);
+  if (rc) return rc;
+  return nm_material_wgrad_reduce(w.part_p, n, gw_p, gw_p + 64 * 13, gw_p + 64 * 13 + 64 * 64, 0, stream);
 }

@@ -60,6 +60,42 @@ __global__ void __launch_bounds__(256) k_mfma(float* out, long long* cyc, int re
   if (lane == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
+// bf16 matrix-core variant: v_mfma_f32_16x16x32_bf16, optional gelu per 4 MFMAs (MODE bit1), interleave hint (bit2)
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+template <int MODE, int VPER = 6>
+__global__ void __launch_bounds__(256) k_mfma_bf16(float* out, long long* cyc, int reps) {
+  const int lane = threadIdx.x & 63;
+  f4 acc[4];
+  for (int i = 0; i < 4; ++i) acc[i] = (f4){0.f, 0.f, 0.f, 0.f};
+  bf8 a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.01f * (lane + i)); b[i] = (__bf16)(0.02f * (lane - i)); }
+  float gx = 0.1f * lane, gh = 0.f, gd = 0.f;
+  long long t0 = clock64();
+  for (int r = 0; r < reps; ++r) {
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+      acc[k % 4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[k % 4], 0, 0, 0);
+      if ((MODE & 2) && (k & 3) == 3) {
+        float h, d;
+        gelu_both(gx, h, d);
+        gh += h; gd += d; gx += 0.001f;
+      }
+    }
+    if (MODE & 4) {
+#pragma unroll
+      for (int k = 0; k < 64; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, VPER, 0);
+      }
+    }
+  }
+  long long t1 = clock64();
+  float s = gh + gd;
+  for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+  if (lane == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
 // gelu only
 __global__ void __launch_bounds__(256) k_gelu(float* out, long long* cyc, int reps) {
   const int lane = threadIdx.x & 63;
@@ -111,6 +147,12 @@ int main() {
       if (it) report("mfma regs + gelu/4, interleaved 1:8", blocks, reps * 64.0, reps * 16.0);
       hipLaunchKernelGGL((k_mfma<7, 4, 6>), dim3(blocks), dim3(256), 0, 0, out, cyc, reps);
       if (it) report("mfma LDS + gelu/4, interleaved 1:6", blocks, reps * 64.0, reps * 16.0);
+      hipLaunchKernelGGL((k_mfma_bf16<0>), dim3(blocks), dim3(256), 0, 0, out, cyc, reps);
+      if (it) report("bf16 16x16x32 mfma only", blocks, reps * 64.0, 0);
+      hipLaunchKernelGGL((k_mfma_bf16<2>), dim3(blocks), dim3(256), 0, 0, out, cyc, reps);
+      if (it) report("bf16 mfma + gelu/4", blocks, reps * 64.0, reps * 16.0);
+      hipLaunchKernelGGL((k_mfma_bf16<6, 6>), dim3(blocks), dim3(256), 0, 0, out, cyc, reps);
+      if (it) report("bf16 mfma + gelu/4 interleaved 1:6", blocks, reps * 64.0, reps * 16.0);
       hipLaunchKernelGGL(k_gelu, dim3(blocks), dim3(256), 0, 0, out, cyc, reps);
       if (it) report("gelu only", blocks, 0, reps * 16.0);
     }
