@@ -47,8 +47,13 @@ extern int g_nm_prof_on;
 
 // internal cross-file helpers
 float nm_mpm_get_dt(const nm_mpm* h);
-int nm_material_bwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* gout, float* gF,
-                           float* wpart, int wmode, void* stream);
+int nm_material_bwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* wperm,
+                           const float* gout, float* gF, float* wpart, int wmode, const float* trial_C, const int* enabled,
+                           float dt, int add_to_gF, void* stream);
+int nm_material_fwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* wperm, float* out,
+                           void* stream);
+int nm_material_prepare(const nm_mlp* w, float* wperm, void* stream);   // weights -> MFMA operand order, once per roll-out
+size_t nm_material_prepared_floats();
 int nm_material_wgrad_reduce(const float* wpart, int32_t n, float* gw0, float* gw1, float* gw2, int accumulate, void* stream);
 
 static inline int nm_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

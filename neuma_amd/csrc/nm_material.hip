@@ -14,6 +14,7 @@
 // layouts, and forms the weight gradients as MFMA outer products over the particle index through two
 // small LDS transposes; per-workgroup partial sums are reduced by a second tiny kernel (deterministic).
 #include "nm_common.h"
+#include <cstddef>
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 #ifdef NM_PHASES
@@ -209,6 +210,38 @@ __device__ __forceinline__ void stage_bwd_weights(const float* raw, float* Q0, f
   }
 }
 
+// Weights already in MFMA operand order (nm_material_prepare): P0 | P1 | P2 | Q0 | Q1 | Q2, NM_PERM_FWD floats for the
+// forward operands, NM_PERM_ALL with the transposed ones.  Staging is then a straight 16-byte copy.
+#define NM_PERM_FWD (16 * 64 + 64 * 64 + 16 * 64)
+#define NM_PERM_ALL (NM_PERM_FWD + 16 * 64 + 64 * 64 + 12 * 64)
+template <int NFLOAT>
+__device__ __forceinline__ void stage_permuted(const float* __restrict__ wperm, float* dst) {
+  constexpr int NV = NFLOAT / 4, PER = (NV + 255) / 256;
+  float4 v[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    int i = threadIdx.x + 256 * k;
+    v[k] = i < NV ? reinterpret_cast<const float4*>(wperm)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    int i = threadIdx.x + 256 * k;
+    if (i < NV) reinterpret_cast<float4*>(dst)[i] = v[k];
+  }
+}
+// one workgroup: raw (out,in) weights -> operand order in global memory (once per roll-out and net)
+__global__ void __launch_bounds__(256) k_permute_weights(const float* __restrict__ w0, const float* __restrict__ w1,
+                                                         const float* __restrict__ w2, float* __restrict__ wperm) {
+  __shared__ float raw[NM_RAWTOT];
+  __shared__ float perm[NM_PERM_ALL];
+  stage_raw_weights(w0, w1, w2, raw);
+  __syncthreads();
+  stage_fwd_weights(raw, perm, perm + 16 * 64, perm + 16 * 64 + 64 * 64);
+  stage_bwd_weights(raw, perm + NM_PERM_FWD, perm + NM_PERM_FWD + 16 * 64, perm + NM_PERM_FWD + 16 * 64 + 64 * 64);
+  __syncthreads();
+  for (int i = threadIdx.x; i < NM_PERM_ALL; i += 256) wperm[i] = perm[i];
+}
+
 // invariants of meta.py:197-213 for one particle: z[13], R = U V^T (also returns U, V, sigma)
 __device__ __forceinline__ void nm_features(const M3& F, float z[13], M3& R, M3& U, M3& V, float s[3]) {
   nm_svd3(F, U, s, V);
@@ -293,17 +326,23 @@ static inline void nm_wave_quota(int n, int& grid, int& q) {
 template <int KIND>
 __global__ void __launch_bounds__(256) k_material_fwd(int n, int q, float alpha, const float* __restrict__ F,
                                                       const float* __restrict__ w0, const float* __restrict__ w1,
-                                                      const float* __restrict__ w2, float* __restrict__ out) {
-  __shared__ float sP0[16 * 64], sP1[64 * 64], sP2[16 * 64];
+                                                      const float* __restrict__ w2, const float* __restrict__ wperm,
+                                                      float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float sP[NM_PERM_FWD];
+  float *sP0 = sP, *sP1 = sP + 16 * 64, *sP2 = sP + 16 * 64 + 64 * 64;
   // per-wave buffers (features 64x17, outputs 64x9); before the main loop the same memory holds the raw weights
   __shared__ __attribute__((aligned(16))) float sBuf[4 * 64 * 17 + 4 * 64 * 9];
   static_assert(4 * 64 * 17 + 4 * 64 * 9 >= NM_RAWTOT, "raw weights must fit the per-wave buffers");
   float (*sZ)[64 * 17] = reinterpret_cast<float (*)[64 * 17]>(sBuf);
   float (*sY)[64 * 9] = reinterpret_cast<float (*)[64 * 9]>(sBuf + 4 * 64 * 17);
   NM_PH_DECL
-  stage_raw_weights(w0, w1, w2, sBuf);
-  __syncthreads();
-  stage_fwd_weights(sBuf, sP0, sP1, sP2);
+  if (wperm) {
+    stage_permuted<NM_PERM_FWD>(wperm, sP);
+  } else {
+    stage_raw_weights(w0, w1, w2, sBuf);
+    __syncthreads();
+    stage_fwd_weights(sBuf, sP0, sP1, sP2);
+  }
   __syncthreads();
   NM_PH(0)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -375,24 +414,44 @@ __global__ void __launch_bounds__(256) k_material_fwd(int n, int q, float alpha,
   NM_PH_STORE
 }
 
+// internal (fused roll-out): wperm != NULL -> weights come pre-permuted from nm_material_prepare
+int nm_material_fwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* wperm, float* out,
+                           void* stream) {
+  int grid, q;
+  nm_wave_quota(n, grid, q);
+  hipStream_t s = (hipStream_t)stream;
+  const float *w0 = w ? w->w0 : nullptr, *w1 = w ? w->w1 : nullptr, *w2 = w ? w->w2 : nullptr;
+  if (kind == NM_ELASTICITY)
+    NM_LAUNCH(k_material_fwd<NM_ELASTICITY>, dim3(grid), dim3(256), 0, s, n, q, alpha, F, w0, w1, w2, wperm, out);
+  else
+    NM_LAUNCH(k_material_fwd<NM_PLASTICITY>, dim3(grid), dim3(256), 0, s, n, q, alpha, F, w0, w1, w2, wperm, out);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}
+int nm_material_prepare(const nm_mlp* w, float* wperm, void* stream) {
+  NM_LAUNCH(k_permute_weights, dim3(1), dim3(256), 0, (hipStream_t)stream, w->w0, w->w1, w->w2, wperm);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}
+size_t nm_material_prepared_floats() { return NM_PERM_ALL; }
+
 extern "C" int nm_material_fwd(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, float* out,
                                void* stream) {
   NM_REQUIRE(n >= 0, "negative n");
   NM_REQUIRE(kind == NM_ELASTICITY || kind == NM_PLASTICITY, "kind must be NM_ELASTICITY or NM_PLASTICITY");
   if (n == 0) return NM_OK;
   NM_REQUIRE(F && out && w && w->w0 && w->w1 && w->w2, "null pointer");
-  int grid, q;
-  nm_wave_quota(n, grid, q);
-  hipStream_t s = (hipStream_t)stream;
-  if (kind == NM_ELASTICITY)
-    NM_LAUNCH(k_material_fwd<NM_ELASTICITY>, dim3(grid), dim3(256), 0, s, n, q, alpha, F, w->w0, w->w1, w->w2, out);
-  else
-    NM_LAUNCH(k_material_fwd<NM_PLASTICITY>, dim3(grid), dim3(256), 0, s, n, q, alpha, F, w->w0, w->w1, w->w2, out);
-  NM_LAUNCH_CHECK();
-  return NM_OK;
+  return nm_material_fwd_launch(n, kind, alpha, F, w, nullptr, out, stream);
 }
 
 // ---------------------------------------------------------------- backward
+// optional fusions used by the roll-out's reverse sweep
+struct BwdFuse {
+  const float* trial_C;   // != NULL: F_in = (I + dt * trial_C) F for enabled particles (replaces a separate trial-F pass)
+  const int* enabled;
+  float dt;
+  int add_to_gF;          // gF += result instead of gF = result
+};
 struct BwdLds {
   float P0[16 * 64], P1[64 * 64], P2[16 * 64];
   float Q0[16 * 64], Q1[64 * 64], Q2[12 * 64];
@@ -407,12 +466,17 @@ struct BwdLds {
 template <int KIND>
 __global__ void __launch_bounds__(256, 1) k_material_bwd(int n, int q, float alpha, const float* __restrict__ F,
                                                          const float* __restrict__ w0, const float* __restrict__ w1,
-                                                         const float* __restrict__ w2, const float* __restrict__ gout,
-                                                         float* __restrict__ gF, float* __restrict__ wpart, int want_w) {
+                                                         const float* __restrict__ w2, const float* __restrict__ wperm,
+                                                         const float* __restrict__ gout, float* __restrict__ gF,
+                                                         float* __restrict__ wpart, int want_w, BwdFuse fz) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   BwdLds& L = *reinterpret_cast<BwdLds*>(smem_raw);
   NM_PH_DECL
-  {
+  if (wperm) {
+    static_assert(offsetof(BwdLds, Z) == NM_PERM_ALL * sizeof(float), "P0..Q2 must be contiguous in operand order");
+    stage_permuted<NM_PERM_ALL>(wperm, L.P0);
+    __syncthreads();
+  } else {
     float* raw = &L.Z[0][0];   // the per-wave buffers (>= 22 016 floats) are free until the main loop
     stage_raw_weights(w0, w1, w2, raw);
     __syncthreads();
@@ -444,6 +508,13 @@ __global__ void __launch_bounds__(256, 1) k_material_bwd(int n, int q, float alp
     const int ntile = (min(64, pend - c0) + 15) >> 4;
     M3 Fp = valid ? m3_load(F + 9 * p) : m3_ident();
     M3 go = valid ? m3_load(gout + 9 * p) : m3_zero();
+    if (fz.trial_C && valid && fz.enabled[p] != 0) {   // roll-out: input is the trial F = (I + dt C') F of mpm.py:489
+      M3 T = m3_load(fz.trial_C + 9 * p);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) T.m[i] *= fz.dt;
+      T.m[0] += 1.f; T.m[4] += 1.f; T.m[8] += 1.f;
+      Fp = m3_mul(T, Fp);
+    }
     M3 R, U, V;
     float z[13], s[3];
     nm_features(Fp, z, R, U, V, s);
@@ -628,7 +699,14 @@ __global__ void __launch_bounds__(256, 1) k_material_bwd(int n, int q, float alp
     M3 cof = m3_cofactor(Fp);
 #pragma unroll
     for (int i = 0; i < 9; ++i) Fb.m[i] += t.m[i] + FG.m[i] + zbv[12] * cof.m[i];
-    if (valid) m3_store(gF + 9 * p, Fb);
+    if (valid) {
+      if (fz.add_to_gF) {   // roll-out: dL/dF of the sim step is already there, the elasticity path adds to it
+        M3 prev = m3_load(gF + 9 * p);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Fb.m[i] += prev.m[i];
+      }
+      m3_store(gF + 9 * p, Fb);
+    }
     __builtin_amdgcn_wave_barrier();
     NM_PH(7)
   }
@@ -701,8 +779,10 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
 
 // internal (also used by the fused roll-out): launch the backward kernel only.  wmode 0: no weight gradients,
 // 1: write this launch's per-workgroup partial sums to wpart, 2: add them to wpart.
-int nm_material_bwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* gout, float* gF,
-                           float* wpart, int wmode, void* stream) {
+int nm_material_bwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* wperm,
+                           const float* gout, float* gF, float* wpart, int wmode, const float* trial_C, const int* enabled,
+                           float dt, int add_to_gF, void* stream) {
+  BwdFuse fz = {trial_C, enabled, dt, add_to_gF};
   hipStream_t s = (hipStream_t)stream;
   int grid, q;
   nm_wave_quota(n, grid, q);
@@ -714,12 +794,13 @@ int nm_material_bwd_launch(int32_t n, int32_t kind, float alpha, const float* F,
                                      (int)sizeof(BwdLds)));
     attr_set = true;
   }
+  const float *w0 = w ? w->w0 : nullptr, *w1 = w ? w->w1 : nullptr, *w2 = w ? w->w2 : nullptr;
   if (kind == NM_ELASTICITY)
-    NM_LAUNCH(k_material_bwd<NM_ELASTICITY>, dim3(grid), dim3(256), sizeof(BwdLds), s, n, q, alpha, F, w->w0, w->w1,
-                       w->w2, gout, gF, wpart, wmode);
+    NM_LAUNCH(k_material_bwd<NM_ELASTICITY>, dim3(grid), dim3(256), sizeof(BwdLds), s, n, q, alpha, F, w0, w1, w2, wperm,
+                       gout, gF, wpart, wmode, fz);
   else
-    NM_LAUNCH(k_material_bwd<NM_PLASTICITY>, dim3(grid), dim3(256), sizeof(BwdLds), s, n, q, alpha, F, w->w0, w->w1,
-                       w->w2, gout, gF, wpart, wmode);
+    NM_LAUNCH(k_material_bwd<NM_PLASTICITY>, dim3(grid), dim3(256), sizeof(BwdLds), s, n, q, alpha, F, w0, w1, w2, wperm,
+                       gout, gF, wpart, wmode, fz);
   NM_LAUNCH_CHECK();
   return NM_OK;
 }
@@ -767,7 +848,8 @@ extern "C" int nm_material_bwd_ex(int32_t n, int32_t kind, float alpha, const fl
                  workspace_bytes);
     return NM_ERR_WORKSPACE;
   }
-  int rc = nm_material_bwd_launch(n, kind, alpha, F, w, gout, gF, (float*)workspace, want_w, stream);
+  int rc = nm_material_bwd_launch(n, kind, alpha, F, w, nullptr, gout, gF, (float*)workspace, want_w, nullptr, nullptr, 0.f, 0,
+                                  stream);
   if (rc) return rc;
   if (want_w) return nm_material_wgrad_reduce((const float*)workspace, n, gw0, gw1, gw2, accumulate, stream);
   return NM_OK;

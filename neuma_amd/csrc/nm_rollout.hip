@@ -15,10 +15,11 @@ struct RolloutWs {
   float* ga;       // N*24  gradient ping
   float* gb;       // N*24  gradient pong (+ stress grad N*9 appended)
   float* gS;       // N*9
-  float* gFe;      // N*9
   float* gFtr;     // N*9
   float* part_e;   // per-workgroup weight-gradient partials, summed over substeps, one buffer per net
   float* part_p;
+  float* perm_e;   // weights in MFMA operand order (nm_material_prepare), shared by all substeps
+  float* perm_p;
   size_t total;
 };
 
@@ -32,11 +33,12 @@ static RolloutWs carve_ws(void* base, int n) {
   w.ga = take(N * 24);
   w.gb = take(N * 24);
   w.gS = take(N * 9);
-  w.gFe = take(N * 9);
   w.gFtr = take(N * 9);
   const size_t part = nm_material_bwd_workspace(n) / sizeof(float);
   w.part_e = take(part);
   w.part_p = take(part);
+  w.perm_e = take(nm_material_prepared_floats());
+  w.perm_p = take(nm_material_prepared_floats());
   w.total = o;
   return w;
 }
@@ -56,25 +58,6 @@ static inline nm_particles rec(float* base, int n, int t) {
   p.F = r + 15 * (size_t)n;
   p.stress = r + 24 * (size_t)n;   // stress computed FROM this record's F (input of the step that leaves it)
   return p;
-}
-
-// Ftrial = (I + dt C') F   (mpm.py:489) recomputed from the checkpoints
-__global__ void __launch_bounds__(256) k_trial_F(int n, float dt, const int* __restrict__ enabled, const float* __restrict__ Cn,
-                                                 const float* __restrict__ F, float* __restrict__ out) {
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  M3 Fp = m3_load(F + 9 * (size_t)p);
-  if (enabled[p] == 0) { m3_store(out + 9 * (size_t)p, Fp); return; }
-  M3 T = m3_load(Cn + 9 * (size_t)p);
-#pragma unroll
-  for (int i = 0; i < 9; ++i) T.m[i] *= dt;
-  T.m[0] += 1.f; T.m[4] += 1.f; T.m[8] += 1.f;
-  m3_store(out + 9 * (size_t)p, m3_mul(T, Fp));
-}
-
-__global__ void __launch_bounds__(256) k_add_inplace(size_t n, float* __restrict__ dst, const float* __restrict__ src) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] += src[i];
 }
 
 extern "C" size_t nm_rollout_gridcache_bytes(int32_t substeps, int32_t grid_cache_blocks) {
@@ -97,16 +80,19 @@ extern "C" int nm_rollout_forward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cf
     nm_set_error("rollout workspace too small: need %zu got %zu", w.total, workspace_bytes);
     return NM_ERR_WORKSPACE;
   }
-  int rc;
+  int rc = nm_material_prepare(we, w.perm_e, stream);
+  if (rc) return rc;
+  rc = nm_material_prepare(wp, w.perm_p, stream);
+  if (rc) return rc;
   for (int t = 0; t < cfg->substeps; ++t) {
     nm_particles cur = rec(states, n, t), nxt = rec(states, n, t + 1);
-    rc = nm_material_fwd(n, NM_ELASTICITY, 0.f, cur.F, we, cur.stress, stream);  // finetune.py:362
+    rc = nm_material_fwd_launch(n, NM_ELASTICITY, 0.f, cur.F, we, w.perm_e, cur.stress, stream);  // finetune.py:362
     if (rc) return rc;
     nm_particles out = nxt;
     out.F = w.ftrial;
     rc = nm_mpm_forward_ex(h, n, st, &cur, &out, grid_rec(gridcache, cfg, t), cfg->grid_cache_blocks, stream);  // finetune.py:363
     if (rc) return rc;
-    rc = nm_material_fwd(n, NM_PLASTICITY, cfg->plasticity_alpha, w.ftrial, wp, nxt.F, stream);  // finetune.py:364
+    rc = nm_material_fwd_launch(n, NM_PLASTICITY, cfg->plasticity_alpha, w.ftrial, wp, w.perm_p, nxt.F, stream);  // finetune.py:364
     if (rc) return rc;
   }
   return NM_OK;
@@ -119,6 +105,7 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
   NM_REQUIRE(h && cfg && st && we && wp && states && gstate_last && gstate_first && gw_e && gw_p, "null pointer");
   NM_REQUIRE(n >= 0 && cfg->substeps >= 1, "bad sizes");
   hipStream_t s = (hipStream_t)stream;
+  (void)s;
   if (n == 0) {
     NM_HIP_CHECK(hipMemsetAsync(gw_e, 0, NM_WTOT_ * sizeof(float), s));
     NM_HIP_CHECK(hipMemsetAsync(gw_p, 0, NM_WTOT_ * sizeof(float), s));
@@ -132,15 +119,17 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
   const size_t N = (size_t)n;
   float* states_m = const_cast<float*>(states);
   const float* gin = gstate_last;
-  int rc;
+  int rc = nm_material_prepare(we, w.perm_e, stream);
+  if (rc) return rc;
+  rc = nm_material_prepare(wp, w.perm_p, stream);
+  if (rc) return rc;
   for (int t = cfg->substeps - 1; t >= 0; --t) {
     nm_particles cur = rec(states_m, n, t), nxt = rec(states_m, n, t + 1);
     float* gout = (t == 0) ? gstate_first : ((gin == w.ga) ? w.gb : w.ga);
-    // trial F of this step, then plasticity backward: dL/dF_{t+1} -> dL/dFtrial
-    NM_LAUNCH(k_trial_F, dim3(nm_div_up(n, 256)), dim3(256), 0, s, n, nm_mpm_get_dt(h), st->enabled, nxt.C, cur.F, w.ftrial);
-    NM_LAUNCH_CHECK();
+    // plasticity backward on the trial F of this step (recomputed in-kernel from the checkpoints): dL/dF_{t+1} -> dL/dFtrial
     const int wmode = (t == cfg->substeps - 1) ? 1 : 2;   // first visit writes the partials, later ones add
-    rc = nm_material_bwd_launch(n, NM_PLASTICITY, cfg->plasticity_alpha, w.ftrial, wp, gin + 15 * N, w.gFtr, w.part_p, wmode, stream);
+    rc = nm_material_bwd_launch(n, NM_PLASTICITY, cfg->plasticity_alpha, cur.F, wp, w.perm_p, gin + 15 * N, w.gFtr, w.part_p, wmode,
+                                nxt.C, st->enabled, nm_mpm_get_dt(h), 0, stream);
     if (rc) return rc;
     // sim backward (stress of this step was checkpointed by the forward pass)
     nm_particles gn, gc;
@@ -150,10 +139,9 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
     rc = nm_mpm_backward_ex(h, n, st, &cur, &nxt, &gn, &gc, grid_rec(gridcache, cfg, t), cfg->grid_cache_blocks, stream);
     if (rc) return rc;
     // elasticity backward: dL/dstress -> dL/dF (added to the sim's dL/dF)
-    rc = nm_material_bwd_launch(n, NM_ELASTICITY, 0.f, cur.F, we, w.gS, w.gFe, w.part_e, wmode, stream);
+    rc = nm_material_bwd_launch(n, NM_ELASTICITY, 0.f, cur.F, we, w.perm_e, w.gS, gc.F, w.part_e, wmode, nullptr, nullptr, 0.f, 1,
+                                stream);
     if (rc) return rc;
-    NM_LAUNCH(k_add_inplace, dim3(nm_div_up((int64_t)N * 9, 256)), dim3(256), 0, s, N * 9, gc.F, w.gFe);
-    NM_LAUNCH_CHECK();
     gin = gout;
   }
   // one deterministic reduction per net for the whole roll-out

@@ -23,7 +23,7 @@ from .material import InvariantFullMetaElasticity, InvariantFullMetaPlasticity
 from .render.gaussian_model import GaussianModel
 from .rollout import MPMFusedDiffSim
 from .sim import MPMModelBuilder, MPMCacheDiffSim, MPMStatics
-from .tune import Bindings, compute_bindings_xyz, compute_bindings_F, diff_rasterization, l1_loss, l2_loss
+from .tune import Bindings, compute_bindings_xyz, compute_bindings_F, diff_rasterization, l1_loss, l2_loss, pixel_loss_rows
 
 PIXEL_LOSSES = {"l1": l1_loss, "l2": l2_loss}
 
@@ -197,8 +197,7 @@ class SceneRuntime(object):
                 render = self.render_view(means3D, deform_grad, vi, tile_rows=(r0, r1))
                 y0, y1 = r0 * 16, min(H, r1 * 16)
                 # partial sums of the mean over the full image: the ranks' losses add up to the 1-GPU loss
-                d = render[:, y0:y1] - self.gt[vi][:, y0:y1]
-                part = (d.abs().sum() if self.pixel_loss is l1_loss else (d * d).sum()) / render.numel()
+                part = pixel_loss_rows(render, self.gt[vi], 0 if self.pixel_loss is l1_loss else 1, y0, y1)
                 loss = loss + weight * part
         if backward:
             loss.backward()

@@ -102,13 +102,49 @@ def denormalize_points_helper_func(points: Tensor, size, center) -> Tensor:
     return (points.clone() - center) / size
 
 
+class _PixelLoss(torch.autograd.Function):
+    """mean |a-b| (kind 0) or mean (a-b)^2 (kind 1) over a (3,H,W) image, restricted to pixel rows [row0,row1) (the mean
+    is still over the full image, so stripes add up): one fused kernel (nm_pixel_loss) produces the value and dL/dimage."""
+
+    @staticmethod
+    def forward(ctx, img, gt, kind, row0, row1):
+        lib = L.lib()
+        a = img.detach().contiguous().float()
+        b = gt.detach().contiguous().float()
+        h, w = int(a.shape[-2]), int(a.shape[-1])
+        loss = torch.zeros((), dtype=torch.float32, device=a.device)
+        grad = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        L.check(lib.nm_pixel_loss(int(kind), 1.0, h, w, int(row0), int(row1), L.ptr(a), L.ptr(b), L.ptr(loss),
+                                  L.ptr(grad) if grad is not None else None, L.stream_ptr(a.device)), "nm_pixel_loss")
+        ctx.grad = grad
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        grad, ctx.grad = ctx.grad, None
+        return (grad * g if grad is not None else None), None, None, None, None
+
+
+def _fused_loss_ok(a, b):
+    return a.is_cuda and b.is_cuda and a.dim() == 3 and a.shape == b.shape and a.shape[0] == 3 and not b.requires_grad
+
+
+def pixel_loss_rows(network_output, gt, kind: int, row0: int = 0, row1: int = 0):
+    """Loss of pixel rows [row0,row1) normalised by the FULL image size (multi-GPU stripes sum to the 1-GPU loss)."""
+    return _PixelLoss.apply(network_output, gt, kind, row0, row1)
+
+
 def l1_loss(network_output, gt):
     """loss_utils.py:17-18"""
+    if _fused_loss_ok(network_output, gt):
+        return _PixelLoss.apply(network_output, gt, 0, 0, 0)
     return torch.abs((network_output - gt)).mean()
 
 
 def l2_loss(network_output, gt):
     """loss_utils.py:23-24"""
+    if _fused_loss_ok(network_output, gt):
+        return _PixelLoss.apply(network_output, gt, 1, 0, 0)
     return ((network_output - gt) ** 2).mean()
 
 
