@@ -161,6 +161,13 @@ int nm_material_bwd_ex(int32_t n, int32_t kind, float alpha, const float* F, con
                        const float* gout, float* gF, float* gw0, float* gw1, float* gw2,
                        int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
+/* LinearLoRA merge, modules/nclaw/material/loralib.py:209-213: Weff (out,in) = W + scaling * B (out,r) @ A (r,in), and its
+ * adjoint gB = scaling * gW A^T, gA = scaling * B^T gW (what autograd derives from loralib.py:216-224). */
+int nm_lora_merge(int32_t out_f, int32_t in_f, int32_t r, float scaling, const float* W, const float* B,
+                  const float* A, float* Weff, void* stream);
+int nm_lora_merge_bwd(int32_t out_f, int32_t in_f, int32_t r, float scaling, const float* gW, const float* B,
+                      const float* A, float* gB, float* gA, void* stream);
+
 /* ------------------------------------------------------------------ fused roll-out (experiments/finetune.py:360-364) */
 
 /* S substeps of   stress = E(F); (x,v,C,F) = sim(x,v,C,F,stress); F = P(F)   (finetune.py:362-364,

@@ -82,6 +82,8 @@ SIGNATURES = {
     "nm_raster_backward": (C.c_int, [C.POINTER(nm_raster_cfg), _I32, _I32, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                      _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "nm_pixel_loss": (C.c_int, [_I32, _F, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
+    "nm_lora_merge": (C.c_int, [_I32, _I32, _I32, _F, _P, _P, _P, _P, _P]),
+    "nm_lora_merge_bwd": (C.c_int, [_I32, _I32, _I32, _F, _P, _P, _P, _P, _P, _P]),
     "nm_rollout_workspace": (_SZ, [_I32, _I32]),
     "nm_rollout_gridcache_bytes": (_SZ, [_I32, _I32]),
     "nm_rollout_forward": (C.c_int, [_P, _I32, C.POINTER(nm_rollout_cfg), C.POINTER(nm_statics), C.POINTER(nm_mlp),

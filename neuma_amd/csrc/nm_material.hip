@@ -854,3 +854,55 @@ extern "C" int nm_material_bwd_ex(int32_t n, int32_t kind, float alpha, const fl
   if (want_w) return nm_material_wgrad_reduce((const float*)workspace, n, gw0, gw1, gw2, accumulate, stream);
   return NM_OK;
 }
+
+// ---------------------------------------------------------------- LoRA merge (loralib.py:209-213)
+// W_eff = W + scaling * B A for one dense layer, and its adjoint.  The matrices are tiny (<= 64x64, r = 16): one thread per
+// output element; replaces a GEMM + scale + add chain of library kernels per layer and direction.
+__global__ void __launch_bounds__(256) k_lora_merge(int out_f, int in_f, int r, float scaling, const float* __restrict__ W,
+                                                    const float* __restrict__ B, const float* __restrict__ A,
+                                                    float* __restrict__ Weff) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= out_f * in_f) return;
+  int o = e / in_f, i = e - o * in_f;
+  float acc = 0.f;
+  for (int k = 0; k < r; ++k) acc = fmaf(B[o * r + k], A[k * in_f + i], acc);
+  Weff[e] = fmaf(scaling, acc, W[e]);
+}
+__global__ void __launch_bounds__(256) k_lora_merge_bwd(int out_f, int in_f, int r, float scaling, const float* __restrict__ gW,
+                                                        const float* __restrict__ B, const float* __restrict__ A,
+                                                        float* __restrict__ gB, float* __restrict__ gA) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < out_f * r) {          // gB[o][k] = s * sum_i gW[o][i] A[k][i]
+    int o = e / r, k = e - o * r;
+    float acc = 0.f;
+    for (int i = 0; i < in_f; ++i) acc = fmaf(gW[o * in_f + i], A[k * in_f + i], acc);
+    gB[e] = scaling * acc;
+    return;
+  }
+  e -= out_f * r;
+  if (e < r * in_f) {           // gA[k][i] = s * sum_o B[o][k] gW[o][i]
+    int k = e / in_f, i = e - k * in_f;
+    float acc = 0.f;
+    for (int o = 0; o < out_f; ++o) acc = fmaf(B[o * r + k], gW[o * in_f + i], acc);
+    gA[e] = scaling * acc;
+  }
+}
+
+extern "C" int nm_lora_merge(int32_t out_f, int32_t in_f, int32_t r, float scaling, const float* W, const float* B, const float* A,
+                             float* Weff, void* stream) {
+  NM_REQUIRE(out_f > 0 && in_f > 0 && r > 0, "bad LoRA shape");
+  NM_REQUIRE(W && B && A && Weff, "null pointer");
+  NM_LAUNCH(k_lora_merge, dim3(nm_div_up((int64_t)out_f * in_f, 256)), dim3(256), 0, (hipStream_t)stream, out_f, in_f, r, scaling,
+                     W, B, A, Weff);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}
+extern "C" int nm_lora_merge_bwd(int32_t out_f, int32_t in_f, int32_t r, float scaling, const float* gW, const float* B,
+                                 const float* A, float* gB, float* gA, void* stream) {
+  NM_REQUIRE(out_f > 0 && in_f > 0 && r > 0, "bad LoRA shape");
+  NM_REQUIRE(gW && B && A && gB && gA, "null pointer");
+  NM_LAUNCH(k_lora_merge_bwd, dim3(nm_div_up((int64_t)(out_f + in_f) * r, 256)), dim3(256), 0, (hipStream_t)stream, out_f, in_f, r,
+                     scaling, gW, B, A, gB, gA);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}

@@ -93,7 +93,7 @@ struct Binning { uint32_t* point_list; uint2* ranges; size_t total; };
 static Binning carve_binning(void* base, int64_t D, int ntiles) {
   Binning b; char* p = (char*)base; size_t o = 0; size_t n = (size_t)(D > 0 ? D : 1);
   b.point_list = (uint32_t*)(p + o); o += al256(n * sizeof(uint32_t));
-  b.ranges = (uint2*)(p + o); o += al256((size_t)ntiles * sizeof(uint2));
+  b.ranges = (uint2*)(p + o); o += al256((size_t)(ntiles + 1) * sizeof(uint2));   // + one never-rendered dummy tile
   b.total = o;
   return b;
 }
@@ -149,33 +149,50 @@ __device__ __forceinline__ void get_rect(const RK& k, float px, float py, int r,
 // Largest exponent `power` any pixel of the 16x16 tile (tx,ty) can see from a Gaussian at (mx,my) with conic
 // (ca, cb, cc):  power = -0.5 q,  q(d) = ca dx^2 + 2 cb dx dy + cc dy^2 minimised over the tile's pixel rectangle
 // (a convex quadratic over a box: zero if the centre is inside, else on one of the four edges).
-__device__ __forceinline__ float tile_max_power(float mx, float my, float ca, float cb, float cc, int tx, int ty) {
+struct TileCull {   // per-Gaussian constants of the tile test (the two divisions and the log are hoisted out of the tile loop)
+  float mx, my, ca, cb, cc, cb_over_cc, cb_over_ca, qmax;
+};
+// fp contraction is switched off in the two functions below: the count pass (k_preprocess) and the emit pass
+// (k_emit_keys) must take bit-identical decisions, and a multiply-add fused in one inlined copy but not in the other
+// would let them disagree on a borderline tile.
+__device__ __forceinline__ TileCull make_tile_cull(float mx, float my, const float4& co) {
+#pragma clang fp contract(off)
+  TileCull t;
+  t.mx = mx; t.my = my; t.ca = co.x; t.cb = co.y; t.cc = co.z;
+  t.cb_over_cc = co.y / co.z;
+  t.cb_over_ca = co.y / co.x;
+  // keep iff max power >= -log(255 o) - 0.01  <=>  min q <= 2 (log(255 o) + 0.01)
+  t.qmax = 2.f * (__logf(255.f * co.w) + 0.01f);
+  return t;
+}
+__device__ __forceinline__ float tile_min_q(const TileCull& t, int tx, int ty) {
+#pragma clang fp contract(off)
   const float x0 = (float)(tx * NM_TILE), x1 = x0 + (float)(NM_TILE - 1);
   const float y0 = (float)(ty * NM_TILE), y1 = y0 + (float)(NM_TILE - 1);
-  if (mx >= x0 && mx <= x1 && my >= y0 && my <= y1) return 0.f;
+  if (t.mx >= x0 && t.mx <= x1 && t.my >= y0 && t.my <= y1) return 0.f;
   float qmin = 3.0e38f;
 #pragma unroll
   for (int e = 0; e < 2; ++e) {  // vertical edges x = x0 / x1: minimise over y
-    float dx = (e ? x1 : x0) - mx;
-    float y = fminf(fmaxf(my - cb * dx / cc, y0), y1);
-    float dy = y - my;
-    qmin = fminf(qmin, ca * dx * dx + 2.f * cb * dx * dy + cc * dy * dy);
+    float dx = (e ? x1 : x0) - t.mx;
+    float y = fminf(fmaxf(t.my - t.cb_over_cc * dx, y0), y1);
+    float dy = y - t.my;
+    qmin = fminf(qmin, t.ca * dx * dx + 2.f * t.cb * dx * dy + t.cc * dy * dy);
   }
 #pragma unroll
   for (int e = 0; e < 2; ++e) {  // horizontal edges y = y0 / y1: minimise over x
-    float dy = (e ? y1 : y0) - my;
-    float x = fminf(fmaxf(mx - cb * dy / ca, x0), x1);
-    float dx = x - mx;
-    qmin = fminf(qmin, ca * dx * dx + 2.f * cb * dx * dy + cc * dy * dy);
+    float dy = (e ? y1 : y0) - t.my;
+    float x = fminf(fmaxf(t.mx - t.cb_over_ca * dy, x0), x1);
+    float dx = x - t.mx;
+    qmin = fminf(qmin, t.ca * dx * dx + 2.f * t.cb * dx * dy + t.cc * dy * dy);
   }
-  return -0.5f * qmin;
+  return qmin;
 }
 // A (Gaussian, tile) pair is kept iff some pixel of the tile can reach alpha >= 1/255 (the compositing kernels skip
 // anything below, so dropping the pair leaves every pixel bit-identical).  0.01 of slack in the exponent keeps the
-// test conservative against fp32 rounding of the per-pixel evaluation.
-__device__ __forceinline__ bool tile_contributes(float mx, float my, const float4& co, int tx, int ty) {
-  float thresh = -__logf(255.f * co.w) - 0.01f;
-  return !(tile_max_power(mx, my, co.x, co.y, co.z, tx, ty) < thresh);
+// test conservative against fp32 rounding of the per-pixel evaluation.  k_preprocess (count) and k_emit_keys (emit)
+// evaluate this same function on the same inputs, so the two passes always agree.
+__device__ __forceinline__ bool tile_contributes(const TileCull& t, int tx, int ty) {
+  return !(tile_min_q(t, tx, ty) > t.qmax);
 }
 
 #define SH_C0 0.28209479177387814f
@@ -294,9 +311,10 @@ __global__ void __launch_bounds__(256) k_preprocess(RK k, int K, const float* __
   clamped[i] = cl;
   {
     const float4 co = make_float4(cv.c * det_inv, -cv.b * det_inv, cv.a * det_inv, opac[i]);
+    const TileCull tc = make_tile_cull(px, py, co);
     uint32_t cnt = 0;
     for (int y = sy0; y < sy1; ++y)
-      for (int x = sx0; x < sx1; ++x) cnt += tile_contributes(px, py, co, x, y) ? 1u : 0u;
+      for (int x = sx0; x < sx1; ++x) cnt += tile_contributes(tc, x, y) ? 1u : 0u;
     tiles[i] = cnt;
     if (cnt) dkey[i] = __float_as_uint(pv.z);   // positive floats order like their bit patterns
   }
@@ -324,13 +342,20 @@ __global__ void __launch_bounds__(256) k_emit_keys(RK k, int K, const uint32_t* 
   const float4 co = conop[i];
   int x0, y0, x1, y1;
   get_rect(k, p.x, p.y, radii[i], x0, y0, x1, y1, k.ty0, k.ty1);
+  const TileCull tc = make_tile_cull(p.x, p.y, co);
   for (int y = y0; y < y1; ++y)
     for (int x = x0; x < x1; ++x) {
-      if (!tile_contributes(p.x, p.y, co, x, y) || off >= end) continue;  // same predicate as the count in k_preprocess
+      if (!tile_contributes(tc, x, y) || off >= end) continue;  // same predicate as the count in k_preprocess
       keys[off] = (uint32_t)(y * k.gx + x);
       vals[off] = i;
       ++off;
     }
+  // belt and braces: should the two passes ever disagree, no slot is left uninitialised - leftovers go to a dummy
+  // tile (id gx*gy) that has a range entry but is never composited
+  for (; off < end; ++off) {
+    keys[off] = (uint32_t)(k.gx * k.gy);
+    vals[off] = i;
+  }
 }
 
 __global__ void __launch_bounds__(256) k_tile_ranges(int64_t D, const uint32_t* __restrict__ keys, uint2* __restrict__ ranges) {
@@ -756,7 +781,7 @@ extern "C" int nm_raster_render(const nm_raster_cfg* cfg, int32_t K, int64_t D, 
   Img im = carve_img(image, k.W, k.H);
   if (binning_bytes < b.total) { nm_set_error("binning buffer too small: need %zu got %zu", b.total, binning_bytes); return NM_ERR_WORKSPACE; }
   if (image_bytes < im.total) { nm_set_error("image buffer too small: need %zu got %zu", im.total, image_bytes); return NM_ERR_WORKSPACE; }
-  NM_HIP_CHECK(hipMemsetAsync(b.ranges, 0, (size_t)k.gx * k.gy * sizeof(uint2), s));
+  NM_HIP_CHECK(hipMemsetAsync(b.ranges, 0, ((size_t)k.gx * k.gy + 1) * sizeof(uint2), s));
   if (D > 0) {
     NM_REQUIRE(geom && scratch, "null geom/scratch");
     Scratch sc = carve_scratch(scratch, D);
@@ -765,7 +790,7 @@ extern "C" int nm_raster_render(const nm_raster_cfg* cfg, int32_t K, int64_t D, 
               g.tiles, sc.keys_in, sc.vals_in);
     NM_LAUNCH_CHECK();
     int bits = 1;
-    while ((1 << bits) < k.gx * k.gy) ++bits;
+    while ((1 << bits) <= k.gx * k.gy) ++bits;   // tile ids 0 .. gx*gy (the last one is the dummy tile)
     size_t tb = sc.sort_bytes;
     NM_HIP_CHECK(rocprim::radix_sort_pairs(sc.sort_tmp, tb, sc.keys_in, sc.keys_out, sc.vals_in, b.point_list, (size_t)D, 0u,
                                            (unsigned)bits, s));

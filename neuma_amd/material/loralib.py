@@ -15,6 +15,31 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+class _LoraMerge(torch.autograd.Function):
+    """W + scaling * B @ A and its adjoint through nm_lora_merge / nm_lora_merge_bwd (GPU tensors only)."""
+
+    @staticmethod
+    def forward(ctx, W, B, A, scaling):
+        from .. import _lib as L
+        Wc, Bc, Ac = W.detach().contiguous().float(), B.detach().contiguous().float(), A.detach().contiguous().float()
+        out = torch.empty_like(Wc)
+        L.check(L.lib().nm_lora_merge(Wc.shape[0], Wc.shape[1], Bc.shape[1], float(scaling), L.ptr(Wc), L.ptr(Bc), L.ptr(Ac),
+                                      L.ptr(out), L.stream_ptr(Wc.device)), "nm_lora_merge")
+        ctx.save_for_backward(Bc, Ac)
+        ctx.scaling = float(scaling)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _lib as L
+        Bc, Ac = ctx.saved_tensors
+        g = g.contiguous().float()
+        gB, gA = torch.empty_like(Bc), torch.empty_like(Ac)
+        L.check(L.lib().nm_lora_merge_bwd(g.shape[0], g.shape[1], Bc.shape[1], ctx.scaling, L.ptr(g), L.ptr(Bc), L.ptr(Ac),
+                                          L.ptr(gB), L.ptr(gA), L.stream_ptr(g.device)), "nm_lora_merge_bwd")
+        return (g if ctx.needs_input_grad[0] else None), gB, gA, None
+
+
 class LinearLoRA(nn.Linear):
     def __init__(self, in_features: int, out_features: int, r: int = 0, lora_alpha: int = 1, lora_dropout: float = 0.,
                  merge_weights: bool = True, **kwargs):
@@ -54,7 +79,9 @@ class LinearLoRA(nn.Linear):
 
     def effective_weight(self) -> torch.Tensor:
         if self.r > 0 and not self.merged:
-            return self.weight + (self.lora_B @ self.lora_A) * self.scaling
+            if self.weight.is_cuda:
+                return _LoraMerge.apply(self.weight, self.lora_B, self.lora_A, self.scaling)
+            return self.weight + (self.lora_B @ self.lora_A) * self.scaling      # host tensors (CPU-side unit tests)
         return self.weight
 
     def forward(self, x: torch.Tensor):

@@ -159,3 +159,24 @@ def test_material_empty_and_compose(golden_dir):
         assert E(F[:0]).shape == (0, 3, 3)
         comp = ComposeMaterial([E, E2, E], [20, 0, 48])(F)       # empty section skipped (preset.py:23-25)
         assert torch.equal(comp[:20], E(F[:20])) and torch.equal(comp[20:], E(F[20:]))
+
+
+def test_lora_merge_kernel_matches_loralib_expression():
+    """nm_lora_merge / nm_lora_merge_bwd == W + (B @ A) * scaling and its autograd (loralib.py:209-224), all three layer
+    shapes of the constitutive nets."""
+    from neuma_amd.material.loralib import LinearLoRA
+    torch.manual_seed(0)
+    for out_f, in_f in ((64, 13), (64, 64), (9, 64)):
+        lin = LinearLoRA(in_f, out_f, r=16, lora_alpha=16, bias=False).to(dev())
+        lin.lora_B.data.normal_(0, 0.1)
+        w = lin.effective_weight()
+        ref_B = lin.lora_B.detach().double().cpu().requires_grad_(True)
+        ref_A = lin.lora_A.detach().double().cpu().requires_grad_(True)
+        ref = lin.weight.detach().double().cpu() + (ref_B @ ref_A) * lin.scaling
+        assert abs_max(w, ref) < 1e-6
+        g = torch.randn(out_f, in_f, device=dev())
+        gB, gA = torch.autograd.grad((w * g).sum(), [lin.lora_B, lin.lora_A])
+        rB, rA = torch.autograd.grad((ref * g.double().cpu()).sum(), [ref_B, ref_A])
+        assert rel_max(gB, rB) < 1e-5 and rel_max(gA, rA) < 1e-5
+        lin.eval()       # merged path: plain weight, loralib.py:199-214
+        assert abs_max(lin.effective_weight(), ref) < 1e-6
