@@ -25,7 +25,8 @@ struct MpmK {
   float dt, dx, inv_dx, eps;
   float gdt[3];
   int bound, bc;
-  int dbg;  // NM_DBG experiment switches (0 in production)
+  int dbg;
+  int maxpass;  // NM_DBG experiment switches (0 in production)
 };
 
 struct nm_mpm {
@@ -37,7 +38,7 @@ struct nm_mpm {
   float4* gg;  // adjoint scratch: {vbar.xyz,0} -> {mvbar.xyz, mbar}
   int* flags;
   int* list[2];
-  int* count;  // [2] counters + [2] stats
+  int* count;  // [0..1] ping-pong block counters, [2..3] stats
   int cur;
   int epoch;
 };
@@ -91,6 +92,19 @@ __device__ __forceinline__ void mark_block(int b, int* __restrict__ flags, int* 
 #define NM_WT_BOX 12     // edge of the fixed box used when a chunk's bounding box exceeds the tile (12^3 nodes)
 #define NM_WT_MAXPASS 12 // boxes tried per chunk before the leftovers go to direct global atomics
 
+#ifdef NM_PHASES
+__device__ long long g_nm_scatter[8 * 4096];
+extern "C" int nm_debug_scatter(long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nm_scatter), (size_t)n * sizeof(long long)) == hipSuccess ? 0 : -2;
+}
+#define SC_DECL long long sc_t0 = clock64(); long long sc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SC_PH(i) { long long t1 = clock64(); sc[i] += t1 - sc_t0; sc_t0 = t1; }
+#define SC_STORE(npass) if (threadIdx.x == 0 && blockIdx.x < 4096) { sc[7] = (npass); for (int i = 0; i < 8; ++i) g_nm_scatter[blockIdx.x * 8 + i] = sc[i]; }
+#else
+#define SC_DECL
+#define SC_PH(i)
+#define SC_STORE(npass)
+#endif
 struct TileGeom {
   int o[3];
   int n[3];
@@ -156,6 +170,8 @@ template <int NCH, class ContribF>
 __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* base, float4* __restrict__ grid, int* flags,
                                            int* list, int* count, int epoch, ScatterLds& L, ContribF contrib) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  SC_DECL
+  int sc_pass = 0;
   // ---- bounding box of the stencil origins
   int lo[3], hi[3];
 #pragma unroll
@@ -184,9 +200,11 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
   if (K.dbg & 4) return;
   if ((K.dbg & 16) && !single) return;
 
-  for (int pass = 0; pass <= NM_WT_MAXPASS; ++pass) {
+  SC_PH(0)
+  for (int pass = 0; pass <= K.maxpass; ++pass) {
+    sc_pass = pass + 1;
     if (!single) {
-      if (pass == NM_WT_MAXPASS) {   // last resort: per-particle global atomics for what is still pending
+      if (pass == K.maxpass) {   // last resort: per-particle global atomics for what is still pending
         if (pending) {
 #pragma unroll
           for (int i = 0; i < 3; ++i)
@@ -223,6 +241,7 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
       g = tile_box(K, anchor);
       __syncthreads();
     }
+    SC_PH(1)
     const bool in = pending && (single || tile_holds(g, base));
     const int nyz = g.n[1] * g.n[2];
     const int ci = in ? ((base[0] - g.o[0]) * g.n[1] + (base[1] - g.o[1])) * g.n[2] + (base[2] - g.o[2]) : 0;
@@ -261,10 +280,11 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
       if (tid == NM_SC_T - 1) L.cnt[g.vol] = off;   // last thread's running offset == total
     }
     __syncthreads();
+    SC_PH(2)
     const int slot = in ? L.cnt[ci] + rank : 0;
     const bool owner = tid < nruns;                   // thread r owns non-empty cell r
     const int mycell = owner ? (int)L.run_cell[tid] : 0;
-    const int s0 = owner ? L.cnt[mycell] : 0, s1 = owner ? L.cnt[mycell + 1] : 0;
+    const int s0 = owner ? L.cnt[mycell] : 0;
 #pragma unroll 1
     for (int i = 0; i < 3; ++i) {
       if (in) {
@@ -274,16 +294,22 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
           for (int k = 0; k < 3; ++k) L.C[slot * 9 + j * 3 + k] = contrib(i, j, k);
       }
       __syncthreads();
-      float4 acc[9];
-#pragma unroll
-      for (int q = 0; q < 9; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int s_ = s0; s_ < s1; ++s_) {
-#pragma unroll
-        for (int q = 0; q < 9; ++q) {
+      SC_PH(3)
+      // cell sums, in place: thread u handles (cell r, stencil offset q) = (u / 9, u % 9) and leaves the sum of the
+      // cell's members in the first member's slot (only this thread touches column q of that cell's slots)
+      for (int u = tid; u < nruns * 9; u += NM_SC_T) {
+        const int r = u / 9, q = u - 9 * r;
+        const int cell = (int)L.run_cell[r];
+        const int a0 = L.cnt[cell], a1 = L.cnt[cell + 1];
+        float4 acc = L.C[a0 * 9 + q];
+        for (int s_ = a0 + 1; s_ < a1; ++s_) {
           const float4 t4 = L.C[s_ * 9 + q];
-          acc[q].x += t4.x; acc[q].y += t4.y; acc[q].z += t4.z; acc[q].w += t4.w;
+          acc.x += t4.x; acc.y += t4.y; acc.z += t4.z; acc.w += t4.w;
         }
+        L.C[a0 * 9 + q] = acc;
       }
+      __syncthreads();
+      SC_PH(4)
 #pragma unroll
       for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -291,12 +317,13 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
           if (owner) {
             const int node = mycell + (i * g.n[1] + j) * g.n[2] + k;
             float4 t4 = L.tile[node];
-            const float4 c4 = acc[j * 3 + k];
+            const float4 c4 = L.C[s0 * 9 + j * 3 + k];
             t4.x += c4.x; t4.y += c4.y; t4.z += c4.z; t4.w += c4.w;
             L.tile[node] = t4;
           }
           __syncthreads();   // next offset: another cell's target may be this cell's current node
         }
+      SC_PH(5)
     }
     // ---- flush: one global atomic set per touched node
     for (int nidx = tid; nidx < g.vol; nidx += NM_SC_T) {
@@ -322,9 +349,11 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
       }
     }
     pending = pending && !in;
+    SC_PH(6)
     if (single) break;
     __syncthreads();
   }
+  SC_STORE(sc_pass)
 }
 
 // ---------------------------------------------------------------- kernels
@@ -805,6 +834,7 @@ extern "C" int nm_mpm_create(const nm_mpm_cfg* cfg, nm_mpm** out) {
   K.bound = cfg->bound;
   K.bc = cfg->bc;
   K.dbg = getenv("NM_DBG") ? atoi(getenv("NM_DBG")) : 0;
+  K.maxpass = getenv("NM_MAXPASS") ? atoi(getenv("NM_MAXPASS")) : NM_WT_MAXPASS;
   h->nblocks = K.nb * K.nb * K.nb;
   size_t nodes = (size_t)h->nblocks * 64;
   h->gm = h->gv = h->gg = nullptr;
@@ -814,12 +844,12 @@ extern "C" int nm_mpm_create(const nm_mpm_cfg* cfg, nm_mpm** out) {
   NM_HIP_CHECK(hipMalloc(&h->flags, h->nblocks * sizeof(int)));
   NM_HIP_CHECK(hipMalloc(&h->list[0], h->nblocks * sizeof(int)));
   NM_HIP_CHECK(hipMalloc(&h->list[1], h->nblocks * sizeof(int)));
-  NM_HIP_CHECK(hipMalloc(&h->count, 4 * sizeof(int)));
+  NM_HIP_CHECK(hipMalloc(&h->count, 8 * sizeof(int)));
   NM_HIP_CHECK(hipMemset(h->gm, 0, nodes * sizeof(float4)));
   NM_HIP_CHECK(hipMemset(h->gv, 0, nodes * sizeof(float4)));
   NM_HIP_CHECK(hipMemset(h->gg, 0, nodes * sizeof(float4)));
   NM_HIP_CHECK(hipMemset(h->flags, 0, h->nblocks * sizeof(int)));
-  NM_HIP_CHECK(hipMemset(h->count, 0, 4 * sizeof(int)));
+  NM_HIP_CHECK(hipMemset(h->count, 0, 8 * sizeof(int)));
   NM_HIP_CHECK(hipDeviceSynchronize());
   h->cur = 0;
   h->epoch = 0;

@@ -20,12 +20,53 @@ CONFIGS = {
 }
 
 
-def stencil_order(P: np.ndarray, G: int) -> np.ndarray:
+def hilbert_index(cells: np.ndarray, bits: int) -> np.ndarray:
+    """Index of integer 3-D cells along a Hilbert curve of 2^bits cells per axis (Skilling's transpose algorithm):
+    consecutive indices are face-adjacent cells."""
+    X = np.array(cells, dtype=np.int64).copy()
+    n = X.shape[1]
+    M = 1 << (bits - 1)
+    Q = M
+    while Q > 1:
+        P = Q - 1
+        for i in range(n):
+            mask = (X[:, i] & Q) != 0
+            X[mask, 0] ^= P
+            nm = ~mask
+            t = (X[nm, 0] ^ X[nm, i]) & P
+            X[nm, 0] ^= t
+            X[nm, i] ^= t
+        Q >>= 1
+    for i in range(1, n):
+        X[:, i] ^= X[:, i - 1]
+    t = np.zeros(len(X), dtype=np.int64)
+    Q = M
+    while Q > 1:
+        mask = (X[:, n - 1] & Q) != 0
+        t[mask] ^= (Q - 1)
+        Q >>= 1
+    for i in range(n):
+        X[:, i] ^= t
+    idx = np.zeros(len(X), dtype=np.int64)
+    for b in range(bits - 1, -1, -1):
+        for i in range(n):
+            idx = (idx << 1) | ((X[:, i] >> b) & 1)
+    return idx
+
+
+def stencil_order(P: np.ndarray, G: int, curve: str = "hilbert") -> np.ndarray:
     """Permutation that sorts particles by the origin of their 3x3x3 stencil, base = int(x*G - 0.5) (mpm.py:336-339),
-    grouped in 4x4x4 blocks of base cells.  Particles sharing a base touch the same 27 nodes, so the scatter kernels
-    can pre-add them in registers; consecutive lanes then work on neighbouring nodes.  Any order gives the same
-    results — this one is the fast one (a load-time sort like the reference's `sort` option, mpm.py:640-642)."""
+    along a space-filling curve over the base cells.  Particles sharing a base touch the same 27 nodes and stay
+    contiguous; any run of consecutive particles is spatially compact, so the scatter kernels' per-workgroup node
+    tiles stay small.  A Hilbert curve never jumps (a Morton / Z-order curve does at every power-of-two boundary,
+    which leaves a few workgroups with two or three disjoint clusters and makes them the kernel's critical path).
+    Any order gives the same results - this one is the fast one (a load-time sort like the reference's `sort`
+    option, mpm.py:640-642)."""
     base = np.trunc(P.astype(np.float64) * G - 0.5).astype(np.int64)
+    base = np.clip(base, 0, None)
+    if curve == "hilbert":
+        bits = max(1, int(np.ceil(np.log2(G + 2))))
+        return np.argsort(hilbert_index(base, bits), kind="stable")
     blk = base // 4
 
     def spread(v):  # Morton bit spread of a 10-bit integer
@@ -36,8 +77,6 @@ def stencil_order(P: np.ndarray, G: int) -> np.ndarray:
         v = (v | (v << 2)) & 0x09249249
         return v
 
-    # blocks along a Morton (Z-order) curve: any run of consecutive particles stays compact in all three axes, so the
-    # scatter kernels' per-workgroup tiles stay small (row-major block order breaks at every row end)
     morton = (spread(blk[:, 0]) << 2) | (spread(blk[:, 1]) << 1) | spread(blk[:, 2])
     key = morton * 64 + ((base[:, 0] % 4) * 16 + (base[:, 1] % 4) * 4 + base[:, 2] % 4)
     return np.argsort(key, kind="stable")

@@ -1,0 +1,30 @@
+"""-DNM_PHASES build: per-workgroup phase cycles of wg_scatter in the LAST k_p2g / k_g2p_bwd launch of a roll-out."""
+import os, subprocess, sys, ctypes as C
+import numpy as np
+sys.path.insert(0, ".")
+src = "neuma_amd/csrc"
+out = "/tmp/libneuma_phases.so"
+subprocess.run(f"/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -DNM_PHASES -Iinclude -shared "
+               f"{src}/nm_api.hip {src}/nm_mpm.hip {src}/nm_material.hip {src}/nm_bind.hip {src}/nm_raster.hip {src}/nm_rollout.hip -o {out}",
+               shell=True, check=True)
+os.environ["NEUMA_HIP_LIB"] = out
+import torch
+from neuma_amd import _lib, synth
+from neuma_amd.harness import SceneRuntime
+lib = _lib.lib()
+dev = torch.device("cuda", 0)
+rt = SceneRuntime(synth.make_scene("metric", override=dict(K=1000)), dev)
+with torch.no_grad():
+    for _ in range(2):
+        rt.rollout(rt.x0, rt.v0, rt.C0, rt.F0)      # last launch using wg_scatter = k_p2g of substep 20
+torch.cuda.synchronize()
+fn = lib.nm_debug_scatter; fn.argtypes = [C.c_void_p, C.c_int]
+buf = np.zeros(8 * 4096, dtype=np.int64)
+print("rc", fn(buf.ctypes.data, 8 * 4096))
+nwg = (rt.N + 255) // 256
+b = buf.reshape(4096, 8)[:nwg]
+names = ["bbox", "box select", "sort/scan", "contrib write", "cell sums", "9 pushes", "flush+mark", "passes"]
+for i, nm in enumerate(names):
+    print(f"{nm:14s} mean {b[:, i].mean():9.1f} median {np.median(b[:, i]):9.1f} max {b[:, i].max():9.0f}")
+print("total cycles mean", b[:, :7].sum(1).mean(), "max", b[:, :7].sum(1).max())
+print("passes histogram", np.bincount(b[:, 7].astype(int)))
