@@ -37,8 +37,8 @@ struct nm_mpm {
   float4* gv;  // {v.xyz, 0}
   float4* gg;  // adjoint scratch: {vbar.xyz,0} -> {mvbar.xyz, mbar}
   int* flags;
-  int* list[2];
-  int* count;  // [0..1] ping-pong block counters, [2..3] stats
+  int* list[3];   // active-block lists in rotation: previous / current / next substep
+  int* count;     // [0..2] block counters in the same rotation, [4..5] stats
   int cur;
   int epoch;
 };
@@ -151,6 +151,7 @@ struct ScatterLds {
   float4 tile[NM_WT_CAP];    // node sums of the workgroup's bounding box
   int cnt[NM_WT_CAP + 4];    // particles per stencil origin -> exclusive offsets (+ total as sentinel)
   short run_cell[NM_SC_T];   // compacted list of non-empty origin cells (<= one per particle)
+  short ainv[3][NM_SC_T];    // axis compression: compressed coordinate -> grid coordinate
   int red[32];               // block reductions / broadcasts
 };
 
@@ -163,8 +164,12 @@ struct ScatterLds {
 //      cell sums are pushed into the LDS tile one stencil offset at a time: for a FIXED offset distinct cells hit
 //      distinct nodes, so plain ds_read_b128 / ds_write_b128 never conflict; a workgroup barrier separates offsets;
 //   3. every touched node is flushed with one global atomic set.
-// Chunks whose bounding box exceeds the tile (row breaks of the particle order) are processed box by box; after
-// NM_WT_MAXPASS boxes the leftovers use per-particle global atomics, so any order is correct.
+// A chunk whose bounding box exceeds the tile (the particle order left the body and re-entered it elsewhere: two or
+// three compact clusters) first tries AXIS COMPRESSION: per axis, the coordinates no stencil touches are squeezed
+// out (an occupancy array + a block scan give grid coordinate -> compressed coordinate; base, base+1, base+2 stay
+// consecutive, so the stencil arithmetic is unchanged) and the whole chunk is still handled in ONE pass if the
+// compressed box fits.  Only what is left (random particle orders) is processed box by box; after NM_WT_MAXPASS
+// boxes the leftovers use per-particle global atomics, so any order is correct.
 //   contrib(i, j, k) -> float4 contribution of THIS thread's particle to stencil node (i,j,k)
 template <int NCH, class ContribF>
 __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* base, float4* __restrict__ grid, int* flags,
@@ -195,9 +200,53 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
 #pragma unroll
   for (int a = 0; a < 3; ++a) { g.o[a] = lo[a]; g.n[a] = hi[a] - lo[a] + 3; }
   g.vol = g.n[0] * g.n[1] * g.n[2];
-  const bool single = g.vol <= NM_WT_CAP;
+  bool single = g.vol <= NM_WT_CAP;
+  bool cmp = false;          // compressed tile coordinates in use
+  int tb[3] = {base[0] - lo[0], base[1] - lo[1], base[2] - lo[2]};   // tile coordinates of this particle's stencil origin
   bool pending = en;
   if (K.dbg & 4) return;
+  if (!single && !(K.dbg & 32)) {
+    // ---- axis compression (scratch: the contribution buffer, not in use yet)
+    const int Gp = K.Gp, tot = 3 * Gp;
+    short* occ = reinterpret_cast<short*>(L.C);
+    short* amap = occ + ((tot + 7) & ~7);
+    for (int i = tid; i < tot; i += NM_SC_T) occ[i] = 0;
+    __syncthreads();
+    if (en) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { occ[a * Gp + base[a]] = 1; occ[a * Gp + base[a] + 1] = 1; occ[a * Gp + base[a] + 2] = 1; }
+    }
+    __syncthreads();
+    const int E = (tot + NM_SC_T - 1) / NM_SC_T;
+    int sum = 0;
+    for (int e = 0; e < E; ++e) { int idx = tid * E + e; if (idx < tot) sum += occ[idx]; }
+    int wtot;
+    int off = wave_excl_scan_i(sum, lane, wtot);
+    if (lane == 0) L.red[wave] = wtot;
+    __syncthreads();
+    for (int w2 = 0; w2 < wave; ++w2) off += L.red[w2];
+    const int total = L.red[0] + L.red[1] + L.red[2] + L.red[3];
+    for (int e = 0; e < E; ++e) { int idx = tid * E + e; if (idx < tot) { amap[idx] = (short)off; off += occ[idx]; } }
+    __syncthreads();
+    const int st1 = amap[Gp], st2 = amap[2 * Gp];
+    const int cn[3] = {st1, st2 - st1, total - st2};
+    const int cstart[3] = {0, st1, st2};
+    if (cn[0] <= NM_SC_T && cn[1] <= NM_SC_T && cn[2] <= NM_SC_T && cn[0] * cn[1] * cn[2] <= NM_WT_CAP) {
+      for (int idx = tid; idx < tot; idx += NM_SC_T) {
+        if (occ[idx]) { int a = idx >= 2 * Gp ? 2 : (idx >= Gp ? 1 : 0); L.ainv[a][amap[idx] - cstart[a]] = (short)(idx - a * Gp); }
+      }
+      if (en) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) tb[a] = amap[a * Gp + base[a]] - cstart[a];
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { g.o[a] = 0; g.n[a] = cn[a]; }
+      g.vol = cn[0] * cn[1] * cn[2];
+      cmp = true;
+      single = true;
+    }
+    __syncthreads();   // scratch (= contribution buffer) free again, ainv visible
+  }
   if ((K.dbg & 16) && !single) return;
 
   SC_PH(0)
@@ -239,12 +288,14 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
       __syncthreads();
       int anchor[3] = {L.red[8], L.red[9], L.red[10]};
       g = tile_box(K, anchor);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) tb[a] = base[a] - g.o[a];
       __syncthreads();
     }
     SC_PH(1)
     const bool in = pending && (single || tile_holds(g, base));
     const int nyz = g.n[1] * g.n[2];
-    const int ci = in ? ((base[0] - g.o[0]) * g.n[1] + (base[1] - g.o[1])) * g.n[2] + (base[2] - g.o[2]) : 0;
+    const int ci = in ? (tb[0] * g.n[1] + tb[1]) * g.n[2] + tb[2] : 0;
     // ---- counting sort by origin cell (+ compacted list of the non-empty cells)
     for (int i = tid; i < g.vol + 4; i += NM_SC_T) L.cnt[i] = 0;
     for (int i = tid; i < g.vol; i += NM_SC_T) L.tile[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -325,27 +376,41 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
         }
       SC_PH(5)
     }
+    // ---- the blocks this pass touches join the active list (almost always a single flag read per block: k_clear
+    // carried the previous substep's blocks over).  Plain tile: one thread per block of the bounding box (a superset;
+    // blocks that stay empty drop out at the next k_clear).  Compressed tile: thread r stamps the blocks of cell r.
+    if (flags && !(K.dbg & 2)) {
+      if (!cmp) {
+        const int b0 = g.o[0] >> 2, b1 = g.o[1] >> 2, b2 = g.o[2] >> 2;
+        const int m0 = ((g.o[0] + g.n[0] - 1) >> 2) - b0 + 1, m1 = ((g.o[1] + g.n[1] - 1) >> 2) - b1 + 1,
+                  m2 = ((g.o[2] + g.n[2] - 1) >> 2) - b2 + 1;
+        for (int t = tid; t < m0 * m1 * m2; t += NM_SC_T) {
+          const int i = t / (m1 * m2), r = t - i * (m1 * m2);
+          const int j = r / m2, k = r - j * m2;
+          mark_block(((b0 + i) * K.nb + (b1 + j)) * K.nb + (b2 + k), flags, list, count, epoch);
+        }
+      } else if (owner) {
+        const int a_ = mycell / nyz, r_ = mycell - a_ * nyz;
+        const int b_ = r_ / g.n[2], c_ = r_ - b_ * g.n[2];
+        const int o0 = (int)L.ainv[0][a_], o1 = (int)L.ainv[1][b_], o2 = (int)L.ainv[2][c_];
+        for (int i = o0 >> 2; i <= (o0 + 2) >> 2; ++i)
+          for (int j = o1 >> 2; j <= (o1 + 2) >> 2; ++j)
+            for (int k = o2 >> 2; k <= (o2 + 2) >> 2; ++k) mark_block((i * K.nb + j) * K.nb + k, flags, list, count, epoch);
+      }
+    }
     // ---- flush: one global atomic set per touched node
     for (int nidx = tid; nidx < g.vol; nidx += NM_SC_T) {
       const float4 t = L.tile[nidx];
       if (!(K.dbg & 1) && (t.x != 0.f || t.y != 0.f || t.z != 0.f || t.w != 0.f)) {
         int a_ = nidx / nyz, r = nidx - a_ * nyz;
         int b_ = r / g.n[2], c_ = r - b_ * g.n[2];
-        float* dst = (float*)&grid[node_addr(g.o[0] + a_, g.o[1] + b_, g.o[2] + c_, K.nb)];
+        const int x_ = cmp ? (int)L.ainv[0][a_] : g.o[0] + a_, y_ = cmp ? (int)L.ainv[1][b_] : g.o[1] + b_,
+                  z_ = cmp ? (int)L.ainv[2][c_] : g.o[2] + c_;
+        float* dst = (float*)&grid[node_addr(x_, y_, z_, K.nb)];
         unsafeAtomicAdd(dst, t.x);
         unsafeAtomicAdd(dst + 1, t.y);
         unsafeAtomicAdd(dst + 2, t.z);
         if (NCH == 4) unsafeAtomicAdd(dst + 3, t.w);
-      }
-    }
-    if (flags && !(K.dbg & 2)) {
-      int b0 = g.o[0] >> 2, b1 = g.o[1] >> 2, b2 = g.o[2] >> 2;
-      int m0 = ((g.o[0] + g.n[0] - 1) >> 2) - b0 + 1, m1 = ((g.o[1] + g.n[1] - 1) >> 2) - b1 + 1,
-          m2 = ((g.o[2] + g.n[2] - 1) >> 2) - b2 + 1;
-      for (int t = tid; t < m0 * m1 * m2; t += NM_SC_T) {
-        int i = t / (m1 * m2), r = t - i * (m1 * m2);
-        int j = r / m2, k = r - j * m2;
-        mark_block(((b0 + i) * K.nb + (b1 + j)) * K.nb + (b2 + k), flags, list, count, epoch);
       }
     }
     pending = pending && !in;
@@ -357,20 +422,50 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
 }
 
 // ---------------------------------------------------------------- kernels
-// zero the blocks the previous substep touched (all three node arrays) and reset the counter p2g will fill
+// Zero the blocks the previous substep touched (all three node arrays) and CARRY the ones that still held mass over
+// into the new active list, stamped with the new epoch: particles move a fraction of a cell per substep, so p2g finds
+// nearly every block it touches already listed (one flag read) and the returning atomics of mark_block - which would
+// otherwise all hit the same counter in a burst - are left to the few blocks that are genuinely new.  Blocks that
+// lost their mass drop out here.  One returning atomic per wave reserves the list slots.  count_next is reset for the
+// substep after this one (nobody reads it now).
+#define NM_CLEAR_WGS 64
 __global__ void __launch_bounds__(256) k_clear(float4* __restrict__ gm, float4* __restrict__ gv, float4* __restrict__ gg,
-                                               const int* __restrict__ list, const int* __restrict__ count_prev,
-                                               int* __restrict__ count_cur) {
+                                               const int* __restrict__ list_prev, const int* __restrict__ count_prev,
+                                               int* __restrict__ list_now, int* __restrict__ count_now,
+                                               int* __restrict__ count_next, int* __restrict__ flags, int epoch) {
   const int cnt = *count_prev;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nw = gridDim.x * 4, w = blockIdx.x * 4 + wave;
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int li = blockIdx.x * 4 + wave; li < cnt; li += gridDim.x * 4) {
-    int node = (list[li] << 6) + lane;
-    gm[node] = z;
-    gv[node] = z;
-    gg[node] = z;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *count_next = 0;
+  for (int li0 = w; li0 < cnt; li0 += nw * 64) {      // rounds of up to 64 blocks per wave (one keep-bit each)
+    unsigned long long keep = 0ull;
+    int it = 0;
+    for (int li = li0; li < cnt && it < 64; li += nw, ++it) {
+      const int node = (list_prev[li] << 6) + lane;
+      const bool has = gm[node].w > 0.f;
+      gm[node] = z;
+      gv[node] = z;
+      gg[node] = z;
+      if (__ballot(has) != 0ull) keep |= 1ull << it;
+    }
+    const int nkeep = __popcll(keep);
+    if (nkeep == 0) continue;
+    int pos = 0;
+    if (lane == 0) pos = atomicAdd(count_now, nkeep);
+    pos = __shfl(pos, 0, 64);
+    it = 0;
+    for (int li = li0; li < cnt && it < 64; li += nw, ++it) {
+      if ((keep >> it) & 1ull) {
+        if (lane == 0) {
+          const int b = list_prev[li];
+          list_now[pos] = b;
+          flags[b] = epoch;
+        }
+        ++pos;
+      }
+    }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) *count_cur = 0;
 }
 
 // mpm.py:321-371.  One particle per thread, 256 per workgroup.
@@ -842,8 +937,7 @@ extern "C" int nm_mpm_create(const nm_mpm_cfg* cfg, nm_mpm** out) {
   NM_HIP_CHECK(hipMalloc(&h->gv, nodes * sizeof(float4)));
   NM_HIP_CHECK(hipMalloc(&h->gg, nodes * sizeof(float4)));
   NM_HIP_CHECK(hipMalloc(&h->flags, h->nblocks * sizeof(int)));
-  NM_HIP_CHECK(hipMalloc(&h->list[0], h->nblocks * sizeof(int)));
-  NM_HIP_CHECK(hipMalloc(&h->list[1], h->nblocks * sizeof(int)));
+  for (int i = 0; i < 3; ++i) NM_HIP_CHECK(hipMalloc(&h->list[i], h->nblocks * sizeof(int)));
   NM_HIP_CHECK(hipMalloc(&h->count, 8 * sizeof(int)));
   NM_HIP_CHECK(hipMemset(h->gm, 0, nodes * sizeof(float4)));
   NM_HIP_CHECK(hipMemset(h->gv, 0, nodes * sizeof(float4)));
@@ -862,7 +956,7 @@ float nm_mpm_get_dt(const nm_mpm* h) { return h->k.dt; }
 extern "C" int nm_mpm_destroy(nm_mpm* h) {
   if (!h) return NM_OK;
   hipFree(h->gm); hipFree(h->gv); hipFree(h->gg); hipFree(h->flags);
-  hipFree(h->list[0]); hipFree(h->list[1]); hipFree(h->count);
+  hipFree(h->list[0]); hipFree(h->list[1]); hipFree(h->list[2]); hipFree(h->count);
   delete h;
   return NM_OK;
 }
@@ -874,10 +968,10 @@ static const int kSweepGrid = 512;  // workgroups for the active-block sweeps (g
 // grid from the record; p2g / grid_op are still enqueued but return at once unless the record is marked invalid.
 static int mpm_build_grid(nm_mpm* h, int n, const nm_statics* st, const nm_particles* cur, hipStream_t s, void* save = nullptr,
                           const void* restore = nullptr, int cap = 0) {
-  const int prev = h->cur, now = prev ^ 1;
+  const int prev = h->cur, now = (prev + 1) % 3, next = (prev + 2) % 3;
   h->epoch += 1;
-  NM_LAUNCH(k_clear, dim3(kSweepGrid), dim3(256), 0, s, h->gm, h->gv, h->gg, h->list[prev], h->count + prev,
-                     h->count + now);
+  NM_LAUNCH(k_clear, dim3(NM_CLEAR_WGS), dim3(256), 0, s, h->gm, h->gv, h->gg, h->list[prev], h->count + prev, h->list[now],
+                     h->count + now, h->count + next, h->flags, h->epoch);
   NM_LAUNCH_CHECK();
   GridRec none = {nullptr, nullptr, nullptr};
   GridRec srec = save ? gridrec_at(save, cap) : none;
@@ -992,12 +1086,12 @@ extern "C" int nm_mpm_backward_ex(nm_mpm* h, int32_t n, const nm_statics* st, co
 extern "C" int nm_mpm_grid_stats(nm_mpm* h, int32_t* active_blocks, int32_t* nodes_with_mass, void* stream) {
   NM_REQUIRE(h, "null handle");
   hipStream_t s = (hipStream_t)stream;
-  NM_HIP_CHECK(hipMemsetAsync(h->count + 2, 0, 2 * sizeof(int), s));
+  NM_HIP_CHECK(hipMemsetAsync(h->count + 4, 0, 2 * sizeof(int), s));
   NM_LAUNCH(k_grid_stats, dim3(kSweepGrid), dim3(256), 0, s, h->gm, h->list[h->cur], h->count + h->cur,
-                     h->count + 2);
+                     h->count + 4);
   NM_LAUNCH_CHECK();
   int host[2];
-  NM_HIP_CHECK(hipMemcpyAsync(host, h->count + 2, sizeof(host), hipMemcpyDeviceToHost, s));
+  NM_HIP_CHECK(hipMemcpyAsync(host, h->count + 4, sizeof(host), hipMemcpyDeviceToHost, s));
   NM_HIP_CHECK(hipStreamSynchronize(s));
   if (active_blocks) *active_blocks = host[0];
   if (nodes_with_mass) *nodes_with_mass = host[1];
