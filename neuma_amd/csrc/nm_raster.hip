@@ -326,35 +326,67 @@ __global__ void __launch_bounds__(256) k_gather_tiles(int K, const uint32_t* __r
   if (r < K) tiles_sorted[r] = tiles[order[r]];
 }
 
-// One thread per depth RANK: pairs are emitted already ordered by (depth, id), so the (tile, depth) order the
-// compositor needs is obtained by a STABLE sort on the tile id alone (13 key bits instead of 45).
+// Pairs are emitted in depth-rank order, so the (tile, depth) order the compositor needs is obtained by a STABLE sort
+// on the tile id alone (13 key bits instead of 45).  A lane loads the data of one rank; the tile rectangle of each
+// Gaussian is then scanned by a group of 16 lanes (4 Gaussians per wave at a time, 16 rounds): the contributing tiles
+// of a round are compacted with a ballot and written to consecutive slots, i.e. as full 64-byte segments.  (One
+// thread per Gaussian writing its own pairs one at a time cost 4.6x the algorithmic write traffic in partial lines.)
 __global__ void __launch_bounds__(256) k_emit_keys(RK k, int K, const uint32_t* __restrict__ order, const int* __restrict__ radii,
                                                    const float2* __restrict__ xy, const float4* __restrict__ conop,
                                                    const uint32_t* __restrict__ offs, const uint32_t* __restrict__ tiles,
                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-  int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= K) return;
-  const uint32_t i = order[r];
-  if (tiles[i] == 0) return;
-  uint32_t off = (r == 0) ? 0u : offs[r - 1];
-  const uint32_t end = offs[r];
-  float2 p = xy[i];
-  const float4 co = conop[i];
-  int x0, y0, x1, y1;
-  get_rect(k, p.x, p.y, radii[i], x0, y0, x1, y1, k.ty0, k.ty1);
-  const TileCull tc = make_tile_cull(p.x, p.y, co);
-  for (int y = y0; y < y1; ++y)
-    for (int x = x0; x < x1; ++x) {
-      if (!tile_contributes(tc, x, y) || off >= end) continue;  // same predicate as the count in k_preprocess
-      keys[off] = (uint32_t)(y * k.gx + x);
-      vals[off] = i;
-      ++off;
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
+  // ---- this lane's rank
+  uint32_t my_i = 0, my_off = 0, my_end = 0;
+  int rx0 = 0, ry0 = 0, rx1 = 0, ry1 = 0;
+  TileCull my_tc = {0.f, 0.f, 1.f, 0.f, 1.f, 0.f, 0.f, -1.f};
+  if (r < K) {
+    my_i = order[r];
+    if (tiles[my_i] != 0) {
+      my_off = (r == 0) ? 0u : offs[r - 1];
+      my_end = offs[r];
+      const float2 p = xy[my_i];
+      get_rect(k, p.x, p.y, radii[my_i], rx0, ry0, rx1, ry1, k.ty0, k.ty1);
+      my_tc = make_tile_cull(p.x, p.y, conop[my_i]);
     }
-  // belt and braces: should the two passes ever disagree, no slot is left uninitialised - leftovers go to a dummy
-  // tile (id gx*gy) that has a range entry but is never composited
-  for (; off < end; ++off) {
-    keys[off] = (uint32_t)(k.gx * k.gy);
-    vals[off] = i;
+  }
+  // ---- 16 rounds: group g scans the rectangle of the rank held by lane (4 * round + g)
+  for (int round = 0; round < 16; ++round) {
+    const int src = 4 * round + grp;
+    const uint32_t gi = __shfl(my_i, src, 64);
+    uint32_t off = __shfl(my_off, src, 64);
+    const uint32_t end = __shfl(my_end, src, 64);
+    const int x0 = __shfl(rx0, src, 64), y0 = __shfl(ry0, src, 64), x1 = __shfl(rx1, src, 64), y1 = __shfl(ry1, src, 64);
+    TileCull tc;
+    tc.mx = __shfl(my_tc.mx, src, 64); tc.my = __shfl(my_tc.my, src, 64);
+    tc.ca = __shfl(my_tc.ca, src, 64); tc.cb = __shfl(my_tc.cb, src, 64); tc.cc = __shfl(my_tc.cc, src, 64);
+    tc.cb_over_cc = __shfl(my_tc.cb_over_cc, src, 64); tc.cb_over_ca = __shfl(my_tc.cb_over_ca, src, 64);
+    tc.qmax = __shfl(my_tc.qmax, src, 64);
+    const int w = x1 - x0, area = end > off ? w * (y1 - y0) : 0;
+    const int steps = (area + 15) >> 4;
+    for (int st = 0; st < steps; ++st) {            // group-uniform trip count
+      const int t = st * 16 + sub;
+      bool hit = false;
+      int tx = 0, ty = 0;
+      if (t < area) {
+        ty = y0 + t / w; tx = x0 + t - (t / w) * w;
+        hit = tile_contributes(tc, tx, ty);        // same predicate, same inputs as the count in k_preprocess
+      }
+      const uint32_t m16 = (uint32_t)((__ballot(hit) >> (16 * grp)) & 0xffffull);
+      const uint32_t pos = off + (uint32_t)__popc(m16 & ((1u << sub) - 1u));
+      if (hit && pos < end) {
+        keys[pos] = (uint32_t)(ty * k.gx + tx);
+        vals[pos] = gi;
+      }
+      off += (uint32_t)__popc(m16);
+    }
+    // belt and braces: should the two passes ever disagree, no slot is left uninitialised - leftovers go to a dummy
+    // tile (id gx*gy) that has a range entry but is never composited
+    for (uint32_t q = off + (uint32_t)sub; q < end; q += 16u) {
+      keys[q] = (uint32_t)(k.gx * k.gy);
+      vals[q] = gi;
+    }
   }
 }
 
