@@ -1,0 +1,47 @@
+"""Build profiles/<tag>_kernel_stats.{md,csv} from rocprofv3 outputs: --kernel-trace --stats CSV plus two --pmc passes.
+    python tools/make_profile_md.py gpurun_out/p2 r01b "description of the command"
+"""
+import csv, glob, sys, collections, shutil
+root, tag, desc = sys.argv[1], sys.argv[2], sys.argv[3]
+stats = glob.glob(root + "/stats/**/*kernel_stats.csv", recursive=True)[0]
+shutil.copy(stats, f"profiles/{tag}_bench_metric_kernel_stats.csv")
+rows = list(csv.DictReader(open(stats)))
+def short(n):
+    n = n.split("(")[0]
+    n = n.replace("void ", "")
+    if n.startswith("rocprim"):
+        for key in ("radix_sort_onesweep_iteration", "radix_sort_onesweep_global_offsets", "lookback_scan", "radix_sort_block_sort", "transform", "init_lookback"):
+            if key in n: return "rocprim::" + key
+        return "rocprim::kernel"
+    if n.startswith("at::native"):
+        return "torch " + n.split("<")[0].split("::")[-1] + (" " + n.split("at::native::")[2].split("<")[0] if n.count("at::native::") > 1 else "")
+    return n[:60]
+agg = collections.OrderedDict()
+for r in rows:
+    k = short(r["Name"])
+    a = agg.setdefault(k, [0, 0.0])
+    a[0] += int(r["Calls"]); a[1] += float(r["TotalDurationNs"]) / 1e6
+tot = sum(v[1] for v in agg.values())
+def pmc(sub, counter):
+    out = collections.defaultdict(lambda: [0.0, set()])
+    for f in glob.glob(root + f"/{sub}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter: continue
+            k = short(r["Kernel_Name"])
+            out[k][0] += float(r["Counter_Value"]); out[k][1].add(r["Dispatch_Id"])
+    return {k: v[0] / max(len(v[1]), 1) for k, v in out.items()}
+fetch, write = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
+with open(f"profiles/{tag}_bench_metric_kernel_stats.md", "w") as f:
+    f.write(f"# {tag} - rocprofv3 summaries of `bench.py` (metric workload: 100k particles / 128^3 / 200k Gaussians / 1080p, S=20, V=3), 1x MI355X\n\n")
+    f.write(f"## `{desc}`\n\n(kernel time over the whole run incl. warm-up, kernel-selection pass and ground-truth renders; full CSV: {tag}_bench_metric_kernel_stats.csv)\n\n")
+    f.write("| kernel | calls | total ms | avg us | % |\n|---|---:|---:|---:|---:|\n")
+    for k, (c, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+        f.write(f"| {k} | {c} | {ms:.3f} | {1e3 * ms / c:.1f} | {100 * ms / tot:.2f} |\n")
+    f.write(f"\ntotal kernel time {tot:.1f} ms\n\n")
+    f.write("## HBM traffic per launch from PMC (separate passes: `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`), KiB per dispatch\n\n")
+    f.write("FETCH_SIZE is the raw counter; per MI355X_MICROARCH.md (HBM / rocprofv3 section) it under-reports wide coalesced streaming reads on gfx950 by 2x, so `2 x FETCH` is the upper estimate of read traffic.  WRITE_SIZE matches known byte counts.\n\n")
+    f.write("| kernel | FETCH_SIZE KiB | WRITE_SIZE KiB |\n|---|---:|---:|\n")
+    for k in sorted(set(fetch) | set(write)):
+        if k.startswith(("torch", "Cijk", "rocprim", "__amd")): continue
+        f.write(f"| {k} | {fetch.get(k, 0):.0f} | {write.get(k, 0):.0f} |\n")
+print(open(f"profiles/{tag}_bench_metric_kernel_stats.md").read())
