@@ -96,6 +96,61 @@ __global__ void __launch_bounds__(256) k_mfma_bf16(float* out, long long* cyc, i
   if (lane == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
+// fast-math GELU (1-ulp rcp / exp2) and a two-at-a-time version written on float2 vectors (v_pk_*_f32)
+__device__ __forceinline__ void gelu_fast(float x, float& h, float& dh) {
+  const float ax = fabsf(x);
+  const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.4426950408889634f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.0f));
+  float poly = fmaf(t, 1.061405429f, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float half_tail = 0.5f * poly * t * e;
+  float Phi = x >= 0.f ? 1.0f - half_tail : half_tail;
+  h = x * Phi;
+  dh = fmaf(x, 0.3989422804014327f * e, Phi);
+}
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_pk(f2 x, f2& h, f2& dh) {
+  const f2 ax = {fabsf(x.x), fabsf(x.y)};
+  const f2 xx = x * x * (-0.5f * 1.4426950408889634f);
+  const f2 e = {__builtin_amdgcn_exp2f(xx.x), __builtin_amdgcn_exp2f(xx.y)};
+  const f2 den = ax * (0.3275911f * 0.70710678118654752f) + 1.0f;
+  const f2 t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+  f2 poly = t * 1.061405429f + (-1.453152027f);
+  poly = poly * t + 1.421413741f;
+  poly = poly * t + (-0.284496736f);
+  poly = poly * t + 0.254829592f;
+  const f2 ht = poly * t * e * 0.5f;
+  const f2 one_m = 1.0f - ht;
+  f2 Phi = {x.x >= 0.f ? one_m.x : ht.x, x.y >= 0.f ? one_m.y : ht.y};
+  h = x * Phi;
+  dh = x * (e * 0.3989422804014327f) + Phi;
+}
+template <int MODE>
+__global__ void __launch_bounds__(256) k_gelu2(float* out, long long* cyc, int reps) {
+  const int lane = threadIdx.x & 63;
+  float gx = 0.1f * lane, gh = 0.f, gd = 0.f;
+  long long t0 = clock64();
+  for (int r = 0; r < reps; ++r) {
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+      if (MODE == 0) {
+        float h, d;
+        gelu_fast(gx, h, d); gh += h; gd += d; gx += 0.001f;
+        gelu_fast(gx, h, d); gh += h; gd += d; gx += 0.001f;
+      } else {
+        f2 x2 = {gx, gx + 0.001f}, h2, d2;
+        gelu_pk(x2, h2, d2);
+        gh += h2.x + h2.y; gd += d2.x + d2.y; gx += 0.002f;
+      }
+    }
+  }
+  long long t1 = clock64();
+  out[blockIdx.x * 256 + threadIdx.x] = gh + gd;
+  if (lane == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
 // gelu only
 __global__ void __launch_bounds__(256) k_gelu(float* out, long long* cyc, int reps) {
   const int lane = threadIdx.x & 63;
@@ -153,6 +208,10 @@ int main() {
       if (it) report("bf16 mfma + gelu/4", blocks, reps * 64.0, reps * 16.0);
       hipLaunchKernelGGL((k_mfma_bf16<6, 6>), dim3(blocks), dim3(256), 0, 0, out, cyc, reps);
       if (it) report("bf16 mfma + gelu/4 interleaved 1:6", blocks, reps * 64.0, reps * 16.0);
+      hipLaunchKernelGGL((k_gelu2<0>), dim3(blocks), dim3(256), 0, 0, out, cyc, reps);
+      if (it) report("gelu fast (rcp/exp2 1 ulp)", blocks, 0, reps * 16.0);
+      hipLaunchKernelGGL((k_gelu2<1>), dim3(blocks), dim3(256), 0, 0, out, cyc, reps);
+      if (it) report("gelu fast, packed float2", blocks, 0, reps * 16.0);
       hipLaunchKernelGGL(k_gelu, dim3(blocks), dim3(256), 0, 0, out, cyc, reps);
       if (it) report("gelu only", blocks, 0, reps * 16.0);
     }
