@@ -133,13 +133,17 @@ def main():
     # ---- timed region: K frames, HIP events on the dominant kernel only
     lib.nm_prof_enable(1, dom_base.encode())
     sync()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     last = None
-    for _ in range(args.steps):
+    marks[0].record()
+    for it in range(args.steps):
         zero_grads()
         last = rt.frame()
+        marks[it + 1].record()          # per-frame GPU timeline (no host sync inside the timed region)
     sync()
     elapsed = time.perf_counter() - t0
+    per_frame = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     lib.nm_prof_enable(0, None)
     dom = prof_table(lib)
     if world > 1:
@@ -200,6 +204,49 @@ def main():
                     "algorithmic_bytes_per_launch": ab,
                     "note": "latency/VALU-bound kernel at this problem size (see DESIGN.md); HBM fraction reported as the contract asks"}
 
+    # ---- component rates, measured outside the timed region with HIP events on torch's stream
+    rates = None
+    if rank == 0 or world > 1:
+        from neuma_amd.tune import compute_bindings_xyz, compute_bindings_F
+
+        def gpu_ms(fn, reps=3):
+            best = []
+            for _ in range(reps):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); out = fn(); b.record(); torch.cuda.synchronize(dev)
+                best.append(a.elapsed_time(b))
+            return sorted(best)[len(best) // 2], out
+
+        def sim_fwd():
+            with torch.no_grad():
+                return rt.rollout(rt.x0, rt.v0, rt.C0, rt.F0)
+
+        def sim_fwdbwd():
+            zero_grads()
+            o = rt.rollout(rt.x0, rt.v0, rt.C0, rt.F0)
+            (o[0].sum() + o[3].sum()).backward()
+
+        t_sf, o = gpu_ms(sim_fwd)
+        t_sfb, _ = gpu_ms(sim_fwdbwd)
+        with torch.no_grad():
+            m3 = compute_bindings_xyz(o[0], rt.x0, rt.gaussians.get_xyz, rt.bindings)
+            dgr = compute_bindings_F(o[3], rt.bindings)
+
+        def ren_fwd():
+            with torch.no_grad():
+                return rt.pixel_loss(rt.render_view(m3, dgr, 0), rt.gt[0])
+
+        def ren_fwdbwd():
+            mm = m3.clone().requires_grad_(True)
+            rt.pixel_loss(rt.render_view(mm, dgr, 0), rt.gt[0]).backward()
+
+        t_rf, _ = gpu_ms(ren_fwd)
+        t_rfb, _ = gpu_ms(ren_fwdbwd)
+        S_ = rt.S
+        rates = {"substeps_per_s_fwd": round(1e3 * S_ / t_sf, 1), "substeps_per_s_fwdbwd": round(1e3 * S_ / t_sfb, 1),
+                 "renders_per_s_fwd": round(1e3 / t_rf, 1), "renders_per_s_fwdbwd": round(1e3 / t_rfb, 1),
+                 "note": "full-image renders (1 view incl. loss) and whole-particle-set substeps on one GPU"}
+
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
         try:
@@ -225,6 +272,9 @@ def main():
             "cpu_baseline": cpu,
             "kernel_breakdown_ms_per_frame": {k: round(v[1], 3) for k, v in sorted(full.items(), key=lambda kv: -kv[1][1])[:12]},
             "kernel_time_fraction_of_frame": round(total_ms / (1e3 * elapsed / args.steps), 3),
+            "frame_ms_gpu": {"median": round(per_frame[len(per_frame) // 2], 3), "p10": round(per_frame[len(per_frame) // 10], 3),
+                             "p90": round(per_frame[(9 * len(per_frame)) // 10], 3)},
+            "rates": rates,
             "loss": float(last.loss),
         }
         print(json.dumps(out))
