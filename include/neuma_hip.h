@@ -205,6 +205,20 @@ int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cfg, const n
  * The backward (B^T g) is the same call on the transposed CSR. */
 int nm_spmm_csr(int32_t rows, int32_t D, const int32_t* rowptr, const int32_t* col,
                 const float* val, const float* in, float* out, void* stream);
+/* Binding construction (data preparation): gaussian_binding_with_clip_v1 / gaussian_binding,
+ * modules/d3gs/utils/binding_utils.py:199-285 / 123-196.  Particle j binds to Gaussian k iff (x_j - mean_k)^T inv(cov_k)
+ * (x_j - mean_k) <= threshold (= chi2.ppf(confidence, 3)); at most max_particles (<= 16) per Gaussian, the ones with the
+ * smallest distance.  The particles are binned into the uniform grid (origin, cell edge, dims) the caller chooses; a
+ * Gaussian only visits the cells under its ellipsoid's bounding box.  Outputs (caller-allocated): counts (K) = kept per
+ * Gaussian, n_inside (K, may be NULL) = qualifying before the clip, cols (K x max_particles, ascending, -1 padded),
+ * pvals (same shape, may be NULL) = their Mahalanobis distances.  Every kept particle has weight 1/counts[k]
+ * (softmax of -ones, binding_utils.py:259-269).  No dense K x N matrix is ever formed. */
+size_t nm_bind_build_workspace(int32_t n_particles, int32_t ncells);
+int nm_bind_build(int32_t K, int32_t N, const float* means, const float* cov6, const float* particles,
+                  const float* grid_origin, float cell, const int32_t* grid_dims, float threshold,
+                  int32_t max_particles, int32_t* counts, int32_t* n_inside, int32_t* cols, float* pvals,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
 /* deform_cov_by_F, modules/d3gs/utils/simulation_utils.py:25-48. */
 int nm_cov_deform(int32_t k, const float* cov6, const float* F, float* out_cov6, void* stream);
 /* Fused per-frame binding: means3D = k_prev + B (p_cur - p_prev);  F_k = B F;  cov' = F_k cov F_k^T

@@ -1,0 +1,82 @@
+"""GPU parity: binding construction (nm_bind_build, neuma_amd/binding.py) against the dense fp64 oracle
+(binding_utils.py:199-285)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import binding as ob
+from gpu_util import dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(K, N, seed, scale=0.05):
+    rng = np.random.default_rng(seed)
+    particles = rng.random((N, 3)).astype(np.float32)
+    means = (0.1 + 0.8 * rng.random((K, 3))).astype(np.float32)
+    from scipy.spatial.transform import Rotation
+    R = Rotation.random(K, random_state=seed).as_matrix()
+    sig = rng.uniform(0.4, 1.6, size=(K, 3)) * scale            # anisotropy up to 4:1 (fp32 inverse stays accurate)
+    S = R @ (sig[:, :, None] ** 2 * np.eye(3)) @ R.transpose(0, 2, 1)
+    cov6 = np.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1).astype(np.float32)
+    return means, cov6, particles
+
+
+@pytest.mark.parametrize("K,N,maxp,seed", [(400, 6000, 10, 0), (257, 3000, 4, 1), (64, 40000, 16, 2), (50, 10, 10, 3)])
+def test_binding_matches_dense_oracle(K, N, maxp, seed):
+    from neuma_amd.binding import build_bindings
+    means, cov6, particles = _scene(K, N, seed)
+    W, p, thr = ob.weight_matrix(means, cov6, particles, 0.95, maxp)
+    t = lambda a: torch.tensor(a, device=dev())
+    counts, inside, cols, pv = build_bindings(t(means), t(cov6), t(particles), 0.95, maxp, return_distances=True)
+    counts, inside, cols, pv = counts.cpu().numpy(), inside.cpu().numpy(), cols.cpu().numpy(), pv.cpu().numpy()
+    tol = 5e-5 * thr                                  # fp32 evaluation of p against the fp64 oracle
+    checked_exact = 0
+    for k in range(K):
+        sel = cols[k, :counts[k]]
+        assert np.all(cols[k, counts[k]:] == -1) and np.all(np.diff(sel) > 0)              # ascending, padded
+        assert np.allclose(pv[k, :counts[k]], p[k, sel], rtol=5e-5, atol=1e-6)
+        assert np.all(p[k, sel] <= thr + tol)                                              # nothing outside the ellipsoid
+        n_in_lo, n_in_hi = int((p[k] <= thr - tol).sum()), int((p[k] <= thr + tol).sum())
+        assert n_in_lo <= inside[k] <= n_in_hi
+        assert counts[k] == min(inside[k], maxp)
+        ref = np.nonzero(W[k])[0]
+        srt = np.sort(p[k])
+        borderline = (n_in_lo != n_in_hi) or (len(ref) == maxp and N > maxp and srt[maxp] - srt[maxp - 1] < tol)
+        if not borderline:
+            assert np.array_equal(sel, ref), k
+            checked_exact += 1
+        else:                                        # the kept set may differ only by candidates within tolerance
+            assert len(sel) >= min(n_in_lo, maxp) and (len(sel) == 0 or p[k, sel].max() <= srt[min(maxp, N) - 1] + tol)
+    assert checked_exact > 0.8 * K
+
+
+def test_binding_python_api_and_prepare(tmp_path):
+    from neuma_amd import io as nio
+    from neuma_amd.binding import gaussian_binding, gaussian_binding_with_clip_v1, prepare_bindings
+    from neuma_amd.render.gaussian_model import GaussianModel
+    rng = np.random.default_rng(5)
+    K, N = 300, 5000
+    d = dev()
+    g = GaussianModel(0)
+    q = rng.normal(size=(K, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    xyz = (0.1 + 0.8 * rng.random((K, 3))).astype(np.float32)
+    xyz[:5] += 5.0                                    # five Gaussians far away from every particle
+    g.set_params(torch.tensor(xyz, device=d), torch.zeros(K, 1, 3, device=d), torch.zeros(K, 0, 3, device=d),
+                 torch.tensor(np.log(rng.uniform(0.01, 0.04, size=(K, 3))).astype(np.float32), device=d),
+                 torch.tensor(q.astype(np.float32), device=d), torch.zeros(K, 1, device=d))
+    particles = torch.tensor(rng.random((N, 3)).astype(np.float32), device=d)
+    with pytest.raises(AssertionError):
+        gaussian_binding_with_clip_v1(g, particles, 0.95, 10)          # binding_utils.py:281 assert weight.sum() != 0
+    flags = gaussian_binding(g, particles, 0.95, 10)
+    assert flags.size() == (K, N) and int((torch.bincount(flags.indices()[0], minlength=K) == 0).sum()) >= 5
+    pts, B, n_p = prepare_bindings(g, particles, 0.95, 10, save_dir=tmp_path)
+    assert pts.shape[0] >= N + 5 and B.size() == (K, pts.shape[0]) and int(n_p.min()) >= 1 and int(n_p.max()) <= 10
+    Wd = B.to_dense()
+    assert torch.allclose(Wd.sum(1), torch.ones(K, device=d), atol=1e-5)                    # rows are convex weights
+    W, p, thr = ob.weight_matrix(g.get_xyz.cpu().numpy(), g.get_covariance().cpu().numpy(), pts.cpu().numpy(), 0.95, 10)
+    agree = (np.abs(Wd.cpu().numpy() - W).max(1) < 1e-6).mean()
+    assert agree > 0.95
+    b2, n2 = nio.load_bindings(tmp_path / "bindings.pt")
+    assert (b2.K, b2.N) == (K, pts.shape[0]) and torch.equal(n2.long(), n_p.cpu().long())
+    assert np.allclose(nio.load_particles_ply(tmp_path / "particles.ply"), pts.cpu().numpy())
