@@ -12,6 +12,11 @@ and modules/tune/scheduler/__init__.py:
   * LoRA-only checkpoints `{epoch:04d}_lora.pt` = {'elasticity', 'plasticity', 'loss'} at epoch 1, every 10th and the
     last, newest `num_lora_ckpts` kept (470-480); resume reloads the newest one with strict=False (299-309).
 
+Stage A, `optimize_init_velocity` (finetune.py:63-231): one global initial velocity (a 3-vector broadcast to every
+particle, neuma_dataset.py:107-131) fitted by the same BPTT loop with RAdam + scheduler and the x-z prior
+`lambda_reg * (mean|v_x| + mean|v_z|) / 2` switched on after 10 % of the epochs (207-214); result exported as `init.pt`
+= {'init_x', 'init_v'} (neuma_dataset.py:115-118).
+
 Everything numeric runs in the HIP kernels (neuma_amd.rollout / neuma_amd.tune / neuma_amd.render); this file is host
 control flow only.
 """
@@ -202,3 +207,65 @@ def finetune_constitutive(rt, gt_frames: List[List[torch.Tensor]], cfg: Optional
         if c["warmup_step"] == 0 or epoch > c["warmup_step"]:                   # finetune.py:482-484
             e_sch.step(); p_sch.step()
     return losses
+
+
+VELOCITY_CFG = dict(   # experiments/configs/*/finetune-*.yaml `velocity:` block (sizes reduced by the caller)
+    num_epochs=100, num_frames=5, lr=0.1, scheduler=dict(type="cos", max_steps=100, learning_rate_alpha=0.05),
+    lambda_reg=None, reg_all=False, pixel_loss="l2",
+)
+
+
+def optimize_init_velocity(rt, gt_frames: List[List[torch.Tensor]], cfg: Optional[Dict] = None, tune_root: Optional[Path] = None,
+                           views: Optional[Sequence[int]] = None, log=None):
+    """finetune.py:63-231 on a SceneRuntime.  gt_frames[f-1][i] = ground-truth image of frame f for views[i].
+    Returns (init_v (3,) tensor, per-epoch rgb losses); rt.v0 is set to the broadcast result."""
+    from .tune import l1_loss, l2_loss
+    c = dict(VELOCITY_CFG)
+    c.update(cfg or {})
+    views = list(range(rt.V)) if views is None else list(views)
+    if tune_root is not None and (Path(tune_root) / "init.pt").exists():          # finetune.py:76-85
+        d = torch.load(Path(tune_root) / "init.pt", map_location="cpu")
+        rt.x0 = d["init_x"].to(rt.device).float().contiguous()
+        rt.v0 = d["init_v"].to(rt.device).float().contiguous()
+        return rt.v0.mean(0), []
+    pixel_loss = {"l1": l1_loss, "l2": l2_loss}[c["pixel_loss"]]
+    init_v = torch.nn.Parameter(torch.zeros(3, device=rt.device))                 # neuma_dataset.py:128-131
+    opt = RAdam([init_v], lr=c["lr"])
+    sch = fetch_scheduler(c["scheduler"]).get_scheduler(opt, c["lr"])
+    losses = []
+    nframes = int(c["num_frames"])
+    for epoch in range(1, int(c["num_epochs"]) + 1):
+        opt.zero_grad(set_to_none=True)
+        x, C, F = rt.x0, rt.C0, rt.F0
+        v = init_v.unsqueeze(0).expand(rt.N, -1) + 0.0                            # finetune.py:148
+        de_prev = ((x - rt.center) / rt.size).clone().detach()
+        g_prev = rt.gaussians.get_xyz.clone().detach()
+        loss_rgb = torch.zeros((), device=rt.device)
+        for cur_step in range(1, nframes + 1):
+            x, v, C, F = rt.rollout(x, v, C, F, step0=(cur_step - 1) * rt.S)
+            de_x = (x - rt.center) / rt.size
+            means3D = compute_bindings_xyz(de_x, de_prev, g_prev, rt.bindings)
+            dg = compute_bindings_F(F, rt.bindings)
+            for i, vi in enumerate(views):
+                loss_rgb = loss_rgb + pixel_loss(rt.render_view(means3D, dg, vi), gt_frames[cur_step - 1][i])
+            de_prev, g_prev = de_x.clone().detach(), means3D.clone().detach()
+        if c["lambda_reg"] is not None and epoch > int(0.1 * c["num_epochs"]):    # finetune.py:207-214
+            if c["reg_all"]:
+                loss_reg = c["lambda_reg"] * init_v.abs().mean()
+            else:
+                loss_reg = c["lambda_reg"] * (init_v[0].abs() + init_v[2].abs()) / 2.0
+        else:
+            loss_reg = torch.zeros_like(loss_rgb)
+        (loss_rgb + loss_reg).backward()
+        opt.step()
+        losses.append(float(loss_rgb))
+        if log is not None:
+            log(f"[Epoch {epoch}/{c['num_epochs']} | L rgb: {losses[-1]:.4e}, reg: {float(loss_reg):.4e} | "
+                f"lr: {opt.param_groups[0]['lr']:.4f} | init_v: {init_v.detach().cpu().tolist()}]")
+        sch.step()
+    init_v.requires_grad_(False)
+    rt.v0 = init_v.detach().unsqueeze(0).expand(rt.N, -1).contiguous()
+    if tune_root is not None:                                                     # neuma_dataset.py:115-118
+        Path(tune_root).mkdir(parents=True, exist_ok=True)
+        torch.save({"init_x": rt.x0.cpu(), "init_v": rt.v0.cpu()}, Path(tune_root) / "init.pt")
+    return init_v.detach(), losses

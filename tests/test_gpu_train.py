@@ -14,7 +14,8 @@ def test_finetune_recovers_towards_ground_truth_and_checkpoints(tmp_path):
     scene = synth.make_scene("tiny", override=dict(S=10, V=2))
     frames = 3
     # a pre-stretched body, so the constitutive response (not gravity) drives the first 30 substeps
-    F0 = torch.diag(torch.tensor([1.12, 0.92, 1.0])).to(dev())
+    torch.manual_seed(0)
+    F0 = torch.diag(torch.tensor([1.3, 0.75, 1.0])).to(dev())
     # ground-truth video from a "true" material = the same nets with different LoRA factors
     true = SceneRuntime(scene, dev(), fused=True)
     true.F0 = F0.repeat(true.N, 1, 1).contiguous()
@@ -55,21 +56,26 @@ def test_bptt_gradient_is_a_descent_direction_with_first_order_accuracy():
 
     * reference setting (covariances pushed forward by F, a path the reference deliberately leaves non-differentiable,
       tune/utils.py:353-373): the gradient is a descent direction;
-    * rest covariances (every dependence on theta goes through differentiable operators): a small step of -eps*g lowers
-      the loss by eps*|g|^2 to first order (the loss is only piecewise smooth - alpha cut-offs, tile culling - so the
-      check uses a small step and a loose band)."""
+    * rest covariances (every dependence on theta goes through differentiable operators): the central difference of the
+      loss along g equals |g|^2.  The image is only piecewise smooth (alpha >= 1/255 cut-off, tile culling: a footprint
+      edge crossing a pixel moves it by up to 1/255), so the ground truth is made different enough (L ~ 1e-5) for the
+      smooth part to dominate; what remains is a reproducible ~+13 % of edge terms the analytic gradient - like the
+      reference's - does not carry (tools/exp_descent.py: 1.07-1.17 over step sizes 0.2 %-5 %; sim-only and render-only
+      checks in tools/exp_gradcheck.py give 1.000 and 1.00 +- 0.03)."""
     from neuma_amd import synth
     from neuma_amd.harness import SceneRuntime
     from neuma_amd.train import DEFAULT_CFG, simulate_video, video_loss
     scene = synth.make_scene("tiny", override=dict(S=10, V=2))
-    F0 = torch.diag(torch.tensor([1.12, 0.92, 1.0])).to(dev())
+    torch.manual_seed(0)
+    F0 = torch.diag(torch.tensor([1.3, 0.75, 1.0])).to(dev())
     true = SceneRuntime(scene, dev(), fused=True)
     true.F0 = F0.repeat(true.N, 1, 1).contiguous()
     for net in (true.elasticity, true.plasticity):
         for lin in (net.layers[0].fc, net.layers[1].fc, net.final_layer.fc):
-            lin.lora_B.data.mul_(10.0)
+            lin.lora_B.data.mul_(40.0)
     c = dict(DEFAULT_CFG, num_frames=3, decay_steps=2)
-    for deform_cov, frac in ((True, 0.2), (False, 0.004)):
+    for deform_cov in (True, False):
+        torch.manual_seed(0)
         gt = simulate_video(true, 3, deform_cov=deform_cov)
         rt = SceneRuntime(scene, dev(), fused=True)
         rt.F0 = true.F0.clone()
@@ -78,13 +84,45 @@ def test_bptt_gradient_is_a_descent_direction_with_first_order_accuracy():
         grads = torch.autograd.grad(L0, params)
         g2 = sum(float((g.double() ** 2).sum()) for g in grads)
         assert float(L0) > 0 and g2 > 0 and all(torch.isfinite(g).all() for g in grads)
-        eps = frac * float(L0) / g2
-        with torch.no_grad():
-            for p, g in zip(params, grads):
-                p.sub_(eps * g)
-            L1 = video_loss(rt, gt, c, 1.0, [0, 1], deform_cov=deform_cov)
-        pred = eps * g2
-        assert float(L1) < float(L0)
-        if not deform_cov:
-            ratio = (float(L0) - float(L1)) / pred
-            assert 0.6 < ratio < 1.6, (float(L0), float(L1), pred, ratio)
+
+        def loss_at(step):
+            with torch.no_grad():
+                for p, g in zip(params, grads):
+                    p.add_(step * g)
+                L = float(video_loss(rt, gt, c, 1.0, [0, 1], deform_cov=deform_cov))
+                for p, g in zip(params, grads):
+                    p.sub_(step * g)
+            return L
+
+        if deform_cov:
+            assert loss_at(-0.2 * float(L0) / g2) < float(L0)            # descent direction
+        else:
+            eps = 0.01 * float(L0) / g2                                   # central difference: curvature cancels
+            ratio = (loss_at(eps) - loss_at(-eps)) / (2 * eps * g2)
+            assert float(L0) > 1e-6 and 0.85 < ratio < 1.35, (float(L0), g2, ratio)
+
+
+def test_stage_a_recovers_the_initial_velocity(tmp_path):
+    """optimize_init_velocity (finetune.py:63-231): a global initial velocity is fitted through sim + render BPTT; it
+    moves towards the velocity the ground-truth video was made with, init.pt is exported in the reference's layout and
+    picked up again on the next call."""
+    from neuma_amd import synth
+    from neuma_amd.harness import SceneRuntime
+    from neuma_amd.train import optimize_init_velocity, simulate_video
+    scene = synth.make_scene("tiny", override=dict(S=10, V=2))
+    true = SceneRuntime(scene, dev(), fused=True)
+    v_true = torch.tensor([0.6, -0.5, -0.4], device=dev())
+    true.v0 = v_true.unsqueeze(0).expand(true.N, -1).contiguous()
+    gt = simulate_video(true, 3)
+    rt = SceneRuntime(scene, dev(), fused=True)
+    v_fit, losses = optimize_init_velocity(rt, gt, dict(num_epochs=60, num_frames=3, lr=0.1, lambda_reg=1e-9,
+                                                        scheduler=dict(type="cos", max_steps=60, learning_rate_alpha=0.1)), tmp_path,
+                                           log=print)
+    assert len(losses) == 60 and losses[-1] < 0.5 * losses[0]
+    assert float((v_fit - v_true).norm()) < 0.6 * float(v_true.norm())
+    assert rt.v0.shape == (rt.N, 3) and float((rt.v0 - v_fit).abs().max()) == 0.0
+    d = torch.load(tmp_path / "init.pt")
+    assert set(d) == {"init_x", "init_v"} and d["init_v"].shape == (rt.N, 3)
+    rt2 = SceneRuntime(scene, dev(), fused=True)
+    v2, l2 = optimize_init_velocity(rt2, gt, dict(num_epochs=40), tmp_path)
+    assert l2 == [] and float((rt2.v0 - rt.v0).abs().max()) == 0.0
