@@ -155,6 +155,141 @@ struct ScatterLds {
   int red[32];               // block reductions / broadcasts
 };
 
+// Fallback for a workgroup whose 256 particles neither fit one tile nor compress into one (the particle order left the
+// body several times: up to ~7 disjoint runs of the curve in one chunk): every WAVE scatters its own 64 consecutive
+// particles - a short, compact piece of the order - through a private quarter of the LDS buffers, with the same
+// sort / sum / push / flush sequence as the workgroup pass but 8x8x8-node boxes and wave barriers only, so the four
+// waves work on four different boxes at the same time instead of taking turns at workgroup-wide passes (7 passes at
+// ~20k cycles each made one such workgroup the critical path of the whole launch).
+#define NM_WV_BOX 8
+#define NM_WV_VOL (NM_WV_BOX * NM_WV_BOX * NM_WV_BOX)
+template <int NCH, class ContribF>
+__device__ __forceinline__ void wave_scatter(const MpmK& K, bool en, const int* base, float4* __restrict__ grid, int* flags,
+                                             int* list, int* count, int epoch, ScatterLds& L, ContribF contrib) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4* C = L.C + wave * 64 * 9;
+  float4* tile = L.tile + wave * NM_WV_VOL;
+  int* cnt = L.cnt + wave * (NM_WV_VOL + 1);
+  short* run_cell = L.run_cell + wave * 64;
+  bool pending = en;
+  for (int pass = 0; pass <= K.maxpass; ++pass) {
+    const unsigned long long pm = __ballot(pending);
+    if (pm == 0ull) break;
+    if (pass == K.maxpass) {   // last resort: per-particle global atomics
+      if (pending) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              const float4 c = contrib(i, j, k);
+              float* dst = (float*)&grid[node_addr(base[0] + i, base[1] + j, base[2] + k, K.nb)];
+              unsafeAtomicAdd(dst, c.x);
+              unsafeAtomicAdd(dst + 1, c.y);
+              unsafeAtomicAdd(dst + 2, c.z);
+              if (NCH == 4) unsafeAtomicAdd(dst + 3, c.w);
+            }
+        if (flags) {
+          for (int i = base[0] >> 2; i <= (base[0] + 2) >> 2; ++i)
+            for (int j = base[1] >> 2; j <= (base[1] + 2) >> 2; ++j)
+              for (int k = base[2] >> 2; k <= (base[2] + 2) >> 2; ++k)
+                mark_block((i * K.nb + j) * K.nb + k, flags, list, count, epoch);
+        }
+      }
+      break;
+    }
+    // box anchored at the first pending lane: node origin o = anchor - 1 (clamped), 8 nodes = 6 stencil origins per axis
+    const int first = __ffsll((long long)pm) - 1;
+    int o[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) o[a] = max(0, min(__shfl(base[a], first, 64) - 1, K.Gp - NM_WV_BOX));
+    const int t0 = base[0] - o[0], t1 = base[1] - o[1], t2 = base[2] - o[2];
+    const bool in = pending && t0 >= 0 && t0 + 3 <= NM_WV_BOX && t1 >= 0 && t1 + 3 <= NM_WV_BOX && t2 >= 0 && t2 + 3 <= NM_WV_BOX;
+    const int ci = in ? (t0 * NM_WV_BOX + t1) * NM_WV_BOX + t2 : 0;
+    for (int i = lane; i < NM_WV_VOL + 1; i += 64) cnt[i] = 0;
+    for (int i = lane; i < NM_WV_VOL; i += 64) tile[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __builtin_amdgcn_wave_barrier();
+    const int rank = in ? atomicAdd(&cnt[ci], 1) : 0;
+    __builtin_amdgcn_wave_barrier();
+    // exclusive scan of the 512 cell counts (8 consecutive cells per lane) + list of the non-empty cells
+    int v[NM_WV_VOL / 64], sum = 0, nz = 0;
+#pragma unroll
+    for (int q = 0; q < NM_WV_VOL / 64; ++q) { v[q] = cnt[lane * (NM_WV_VOL / 64) + q]; sum += v[q]; nz += v[q] > 0; }
+    int wtot, nruns;
+    int off = wave_excl_scan_i(sum, lane, wtot);
+    int roff = wave_excl_scan_i(nz, lane, nruns);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < NM_WV_VOL / 64; ++q) {
+      const int c = lane * (NM_WV_VOL / 64) + q;
+      cnt[c] = off;
+      off += v[q];
+      if (v[q] > 0) run_cell[roff++] = (short)c;
+    }
+    if (lane == 63) cnt[NM_WV_VOL] = off;
+    __builtin_amdgcn_wave_barrier();
+    const int slot = in ? cnt[ci] + rank : 0;
+    const bool owner = lane < nruns;             // at most 64 non-empty cells: one per particle
+    const int mycell = owner ? (int)run_cell[lane] : 0;
+    const int s0 = owner ? cnt[mycell] : 0;
+#pragma unroll 1
+    for (int i = 0; i < 3; ++i) {
+      if (in) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) C[slot * 9 + j * 3 + k] = contrib(i, j, k);
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int u = lane; u < nruns * 9; u += 64) {
+        const int r = u / 9, q = u - 9 * r;
+        const int cell = (int)run_cell[r];
+        const int a0 = cnt[cell], a1 = cnt[cell + 1];
+        float4 acc = C[a0 * 9 + q];
+        for (int s_ = a0 + 1; s_ < a1; ++s_) {
+          const float4 t4 = C[s_ * 9 + q];
+          acc.x += t4.x; acc.y += t4.y; acc.z += t4.z; acc.w += t4.w;
+        }
+        C[a0 * 9 + q] = acc;
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          if (owner) {
+            const int node = mycell + (i * NM_WV_BOX + j) * NM_WV_BOX + k;
+            float4 t4 = tile[node];
+            const float4 c4 = C[s0 * 9 + j * 3 + k];
+            t4.x += c4.x; t4.y += c4.y; t4.z += c4.z; t4.w += c4.w;
+            tile[node] = t4;
+          }
+          __builtin_amdgcn_wave_barrier();   // LDS operations of one wave complete in program order
+        }
+    }
+    if (flags && lane < 27) {   // the box spans at most 3 blocks per axis
+      const int bi = (o[0] >> 2) + lane / 9, bj = (o[1] >> 2) + (lane / 3) % 3, bk = (o[2] >> 2) + lane % 3;
+      if (bi <= (o[0] + NM_WV_BOX - 1) >> 2 && bj <= (o[1] + NM_WV_BOX - 1) >> 2 && bk <= (o[2] + NM_WV_BOX - 1) >> 2)
+        mark_block((bi * K.nb + bj) * K.nb + bk, flags, list, count, epoch);
+    }
+    for (int nidx = lane; nidx < NM_WV_VOL; nidx += 64) {
+      const float4 t = tile[nidx];
+      if (t.x != 0.f || t.y != 0.f || t.z != 0.f || t.w != 0.f) {
+        const int a_ = nidx / (NM_WV_BOX * NM_WV_BOX), r = nidx - a_ * (NM_WV_BOX * NM_WV_BOX);
+        const int b_ = r / NM_WV_BOX, c_ = r - b_ * NM_WV_BOX;
+        float* dst = (float*)&grid[node_addr(o[0] + a_, o[1] + b_, o[2] + c_, K.nb)];
+        unsafeAtomicAdd(dst, t.x);
+        unsafeAtomicAdd(dst + 1, t.y);
+        unsafeAtomicAdd(dst + 2, t.z);
+        if (NCH == 4) unsafeAtomicAdd(dst + 3, t.w);
+      }
+    }
+    pending = pending && !in;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // Scatter of the workgroup's 256 particles (one per thread) into `grid` WITHOUT floating-point atomics in LDS
 // (ds_add_f32 retires ~0.33 lanes/clk/CU on gfx950) and without serial per-wave chains:
 //   1. the particles are counting-sorted by stencil origin inside LDS (256 integer LDS atomics + a block scan), so
@@ -168,8 +303,8 @@ struct ScatterLds {
 // three compact clusters) first tries AXIS COMPRESSION: per axis, the coordinates no stencil touches are squeezed
 // out (an occupancy array + a block scan give grid coordinate -> compressed coordinate; base, base+1, base+2 stay
 // consecutive, so the stencil arithmetic is unchanged) and the whole chunk is still handled in ONE pass if the
-// compressed box fits.  Only what is left (random particle orders) is processed box by box; after NM_WT_MAXPASS
-// boxes the leftovers use per-particle global atomics, so any order is correct.
+// compressed box fits.  What is left goes to wave_scatter (each wave scatters its own 64 particles through small
+// private boxes); after NM_WT_MAXPASS boxes the leftovers use per-particle global atomics, so any order is correct.
 //   contrib(i, j, k) -> float4 contribution of THIS thread's particle to stencil node (i,j,k)
 template <int NCH, class ContribF>
 __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* base, float4* __restrict__ grid, int* flags,
@@ -248,6 +383,13 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
     __syncthreads();   // scratch (= contribution buffer) free again, ainv visible
   }
   if ((K.dbg & 16) && !single) return;
+  if (!single && !(K.dbg & 64)) {      // workgroup-uniform: no workgroup barrier is executed past this point
+    SC_PH(0)
+    wave_scatter<NCH>(K, en, base, grid, flags, list, count, epoch, L, contrib);
+    SC_PH(6)
+    SC_STORE(99)
+    return;
+  }
 
   SC_PH(0)
   for (int pass = 0; pass <= K.maxpass; ++pass) {

@@ -192,3 +192,40 @@ def test_grid_cache_per_step_api_matches_plain_backward():
         outs[tag] = [nx, nv, nC, nF] + gc
     for a, b in zip(outs["cached"], outs["plain"]):
         assert rel_max(a, b) < 1e-4
+
+
+def test_rollout_reorders_shuffled_particles_transparently():
+    """NeuMA's data preparation shuffles the particles (tune/utils.py:270-272).  The fused roll-out detects the bad order,
+    runs on a Hilbert-sorted copy and hands results and gradients back in the caller's order: same numbers as the sorted
+    scene, permuted."""
+    rt = _runtime("tiny", fused=True, S=3)
+    N = rt.N
+    torch.manual_seed(3)
+    shuf = torch.randperm(N, device=dev())
+    g = torch.Generator().manual_seed(6)
+    F0 = (torch.eye(3) + 0.05 * torch.randn(N, 3, 3, generator=g)).to(dev())
+    gws = [torch.randn(N, 3, generator=g).to(dev()), torch.randn(N, 3, 3, generator=g).to(dev())]
+    params = rt.parameters()
+
+    def run(perm):
+        ins = [t[perm].clone().requires_grad_(True) for t in (rt.x0, rt.v0, rt.C0, F0)]
+        outs = rt.rollout(*ins)
+        loss = (outs[0] * gws[0][perm]).sum() + (outs[3] * gws[1][perm]).sum()
+        grads = torch.autograd.grad(loss, ins + params)
+        return [o.detach() for o in outs], grads
+
+    ident = torch.arange(N, device=dev())
+    assert rt.sim_fused.order_quality(rt.x0) > 0.8
+    o_ref, g_ref = run(ident)
+    assert rt.sim_fused._perm is False                                   # Hilbert-ordered scene: left alone
+    from neuma_amd.rollout import MPMFusedDiffSim
+    rt.sim_fused = MPMFusedDiffSim(rt.model, rt.elasticity, rt.plasticity, rt.S)
+    assert rt.sim_fused.order_quality(rt.x0[shuf]) < 0.5
+    o_sh, g_sh = run(shuf)
+    assert torch.is_tensor(rt.sim_fused._perm) and rt.sim_fused._perm.numel() == N
+    for a, b in zip(o_sh, o_ref):
+        assert abs_max(a, b[shuf]) < 1e-5 * max(1.0, float(b.abs().max()))
+    for a, b in zip(g_sh[:4], g_ref[:4]):
+        assert rel_max(a, b[shuf]) < 1e-3
+    for a, b in zip(g_sh[4:], g_ref[4:]):
+        assert rel_max(a, b) < 1e-3

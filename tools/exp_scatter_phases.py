@@ -5,7 +5,7 @@ sys.path.insert(0, ".")
 src = "neuma_amd/csrc"
 out = "/tmp/libneuma_phases.so"
 subprocess.run(f"/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -DNM_PHASES -Iinclude -shared "
-               f"{src}/nm_api.hip {src}/nm_mpm.hip {src}/nm_material.hip {src}/nm_bind.hip {src}/nm_raster.hip {src}/nm_rollout.hip -o {out}",
+               f"{src}/nm_api.hip {src}/nm_mpm.hip {src}/nm_material.hip {src}/nm_bind.hip {src}/nm_bindbuild.hip {src}/nm_raster.hip {src}/nm_rollout.hip -o {out}",
                shell=True, check=True)
 os.environ["NEUMA_HIP_LIB"] = out
 import torch
@@ -13,7 +13,7 @@ from neuma_amd import _lib, synth
 from neuma_amd.harness import SceneRuntime
 lib = _lib.lib()
 dev = torch.device("cuda", 0)
-rt = SceneRuntime(synth.make_scene("metric", override=dict(K=1000)), dev)
+rt = SceneRuntime(synth.make_scene(sys.argv[1] if len(sys.argv) > 1 else "metric", override=dict(K=1000)), dev)
 with torch.no_grad():
     for _ in range(2):
         rt.rollout(rt.x0, rt.v0, rt.C0, rt.F0)      # last launch using wg_scatter = k_p2g of substep 20
