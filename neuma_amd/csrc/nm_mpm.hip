@@ -89,8 +89,7 @@ __device__ __forceinline__ void mark_block(int b, int* __restrict__ flags, int* 
 #define NM_SC_T 256      // threads = particles per workgroup
 #define NM_WT_CAP 2048   // tile nodes a workgroup can own (NM_NPT per thread)
 #define NM_NPT (NM_WT_CAP / NM_SC_T)
-#define NM_WT_BOX 12     // edge of the fixed box used when a chunk's bounding box exceeds the tile (12^3 nodes)
-#define NM_WT_MAXPASS 12 // boxes tried per chunk before the leftovers go to direct global atomics
+#define NM_WT_MAXPASS 12 // boxes a wave tries (wave_scatter) before its leftovers go to direct global atomics
 
 #ifdef NM_PHASES
 __device__ long long g_nm_scatter[8 * 4096];
@@ -131,21 +130,6 @@ __device__ __forceinline__ int wave_excl_scan_i(int v, int lane, int& total) {
   total = __shfl(x, 63, 64);
   return x - v;
 }
-__device__ __forceinline__ TileGeom tile_box(const MpmK& K, const int* anchor) {
-  TileGeom g;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    g.o[a] = max(0, min(anchor[a] - 2, K.Gp - NM_WT_BOX));
-    g.n[a] = NM_WT_BOX;
-  }
-  g.vol = NM_WT_BOX * NM_WT_BOX * NM_WT_BOX;
-  return g;
-}
-__device__ __forceinline__ bool tile_holds(const TileGeom& g, const int* b) {
-  return b[0] >= g.o[0] && b[0] + 3 <= g.o[0] + g.n[0] && b[1] >= g.o[1] && b[1] + 3 <= g.o[1] + g.n[1] && b[2] >= g.o[2] &&
-         b[2] + 3 <= g.o[2] + g.n[2];
-}
-
 struct ScatterLds {
   float4 C[NM_SC_T * 9];     // one i-slab (9 stencil nodes) of every particle's contributions, in cell-sorted order
   float4 tile[NM_WT_CAP];    // node sums of the workgroup's bounding box
@@ -382,8 +366,7 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
     }
     __syncthreads();   // scratch (= contribution buffer) free again, ainv visible
   }
-  if ((K.dbg & 16) && !single) return;
-  if (!single && !(K.dbg & 64)) {      // workgroup-uniform: no workgroup barrier is executed past this point
+  if (!single) {      // workgroup-uniform: no workgroup barrier is executed past this point
     SC_PH(0)
     wave_scatter<NCH>(K, en, base, grid, flags, list, count, epoch, L, contrib);
     SC_PH(6)
@@ -392,50 +375,10 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
   }
 
   SC_PH(0)
-  for (int pass = 0; pass <= K.maxpass; ++pass) {
-    sc_pass = pass + 1;
-    if (!single) {
-      if (pass == K.maxpass) {   // last resort: per-particle global atomics for what is still pending
-        if (pending) {
-#pragma unroll
-          for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-#pragma unroll
-              for (int k = 0; k < 3; ++k) {
-                const float4 c = contrib(i, j, k);
-                float* dst = (float*)&grid[node_addr(base[0] + i, base[1] + j, base[2] + k, K.nb)];
-                unsafeAtomicAdd(dst, c.x);
-                unsafeAtomicAdd(dst + 1, c.y);
-                unsafeAtomicAdd(dst + 2, c.z);
-                if (NCH == 4) unsafeAtomicAdd(dst + 3, c.w);
-              }
-          if (flags) {
-            for (int i = base[0] >> 2; i <= (base[0] + 2) >> 2; ++i)
-              for (int j = base[1] >> 2; j <= (base[1] + 2) >> 2; ++j)
-                for (int k = base[2] >> 2; k <= (base[2] + 2) >> 2; ++k)
-                  mark_block((i * K.nb + j) * K.nb + k, flags, list, count, epoch);
-          }
-        }
-        break;
-      }
-      // anchor a box at the pending particle with the lowest thread id
-      int first = wave_min_i(pending ? tid : 0x7fffffff);
-      if (lane == 0) L.red[wave] = first;
-      __syncthreads();
-      first = min(min(L.red[0], L.red[1]), min(L.red[2], L.red[3]));
-      __syncthreads();
-      if (first == 0x7fffffff) break;
-      if (tid == first) { L.red[8] = base[0]; L.red[9] = base[1]; L.red[10] = base[2]; }
-      __syncthreads();
-      int anchor[3] = {L.red[8], L.red[9], L.red[10]};
-      g = tile_box(K, anchor);
-#pragma unroll
-      for (int a = 0; a < 3; ++a) tb[a] = base[a] - g.o[a];
-      __syncthreads();
-    }
+  sc_pass = 1;
+  {   // ---- the single workgroup-wide pass
     SC_PH(1)
-    const bool in = pending && (single || tile_holds(g, base));
+    const bool in = pending;
     const int nyz = g.n[1] * g.n[2];
     const int ci = in ? (tb[0] * g.n[1] + tb[1]) * g.n[2] + tb[2] : 0;
     // ---- counting sort by origin cell (+ compacted list of the non-empty cells)
@@ -555,10 +498,7 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
         if (NCH == 4) unsafeAtomicAdd(dst + 3, t.w);
       }
     }
-    pending = pending && !in;
     SC_PH(6)
-    if (single) break;
-    __syncthreads();
   }
   SC_STORE(sc_pass)
 }
