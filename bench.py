@@ -248,7 +248,7 @@ def main():
                  "note": "full-image renders (1 view incl. loss) and whole-particle-set substeps on one GPU"}
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N=1 only
         try:
             from oracle import cpu_baseline as cbaseline
             cpu = cbaseline.time_frame_sample(scene, rt)
