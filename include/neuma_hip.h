@@ -181,10 +181,15 @@ typedef struct nm_rollout_cfg {
   int32_t substeps;
   float plasticity_alpha;
   int32_t grid_cache_blocks; /* capacity (in 4x4x4-node blocks) of each substep's grid cache record; 0 = no cache */
+  int32_t cache_verified;    /* backward only: the caller has read nm_rollout_cache_status and every record is valid, so the
+                              * (early-exit) fallback launches of p2g / grid_op can be left out altogether */
 } nm_rollout_cfg;
 size_t nm_rollout_workspace(int32_t n, int32_t substeps);
 /* bytes of the optional `gridcache` buffer: substeps records of nm_mpm_gridcache_bytes(grid_cache_blocks) */
 size_t nm_rollout_gridcache_bytes(int32_t substeps, int32_t grid_cache_blocks);
+/* Asynchronous read-back of the S record headers of a grid cache into host memory (pinned recommended): status[t] = number
+ * of cached blocks of substep t, or -1 if that substep outgrew the capacity.  Valid once the stream has passed this point. */
+int nm_rollout_cache_status(const void* gridcache, const nm_rollout_cfg* cfg, int32_t* status_host, void* stream);
 /* gridcache (may be NULL): written by the forward pass, handed unchanged to nm_rollout_backward, which then restores
  * each substep's grid instead of recomputing p2g (see nm_mpm_forward_ex). */
 int nm_rollout_forward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cfg, const nm_statics* st,

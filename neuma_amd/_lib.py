@@ -37,7 +37,8 @@ class nm_raster_cfg(C.Structure):
 
 
 class nm_rollout_cfg(C.Structure):
-    _fields_ = [("substeps", C.c_int32), ("plasticity_alpha", C.c_float), ("grid_cache_blocks", C.c_int32)]
+    _fields_ = [("substeps", C.c_int32), ("plasticity_alpha", C.c_float), ("grid_cache_blocks", C.c_int32),
+                ("cache_verified", C.c_int32)]
 
 
 # name -> (restype, argtypes); kept in one table so tests can check the exports against the header
@@ -89,6 +90,7 @@ SIGNATURES = {
     "nm_lora_merge_bwd": (C.c_int, [_I32, _I32, _I32, _F, _P, _P, _P, _P, _P, _P]),
     "nm_rollout_workspace": (_SZ, [_I32, _I32]),
     "nm_rollout_gridcache_bytes": (_SZ, [_I32, _I32]),
+    "nm_rollout_cache_status": (C.c_int, [_P, C.POINTER(nm_rollout_cfg), _P, _P]),
     "nm_rollout_forward": (C.c_int, [_P, _I32, C.POINTER(nm_rollout_cfg), C.POINTER(nm_statics), C.POINTER(nm_mlp),
                                      C.POINTER(nm_mlp), _P, _P, _P, _SZ, _P]),
     "nm_rollout_backward": (C.c_int, [_P, _I32, C.POINTER(nm_rollout_cfg), C.POINTER(nm_statics), C.POINTER(nm_mlp),

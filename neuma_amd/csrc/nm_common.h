@@ -47,6 +47,9 @@ extern int g_nm_prof_on;
 
 // internal cross-file helpers
 float nm_mpm_get_dt(const nm_mpm* h);
+int nm_mpm_backward_cached(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, const nm_particles* next,
+                           const nm_particles* gnext, nm_particles* gcur, const void* gridrec, int32_t cap_blocks, bool verified,
+                           void* stream);
 int nm_material_bwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* wperm,
                            const float* gout, float* gF, float* wpart, int wmode, const float* trial_C, const int* enabled,
                            float dt, int add_to_gF, void* stream);

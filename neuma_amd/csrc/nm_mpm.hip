@@ -1049,7 +1049,7 @@ static const int kSweepGrid = 512;  // workgroups for the active-block sweeps (g
 // save != null: the forward pass also writes a grid cache record.  restore != null: the reverse sweep restores the
 // grid from the record; p2g / grid_op are still enqueued but return at once unless the record is marked invalid.
 static int mpm_build_grid(nm_mpm* h, int n, const nm_statics* st, const nm_particles* cur, hipStream_t s, void* save = nullptr,
-                          const void* restore = nullptr, int cap = 0) {
+                          const void* restore = nullptr, int cap = 0, bool restore_verified = false) {
   const int prev = h->cur, now = (prev + 1) % 3, next = (prev + 2) % 3;
   h->epoch += 1;
   NM_LAUNCH(k_clear, dim3(NM_CLEAR_WGS), dim3(256), 0, s, h->gm, h->gv, h->gg, h->list[prev], h->count + prev, h->list[now],
@@ -1063,6 +1063,10 @@ static int mpm_build_grid(nm_mpm* h, int n, const nm_statics* st, const nm_parti
     NM_LAUNCH(k_grid_restore, dim3(kSweepGrid), dim3(256), 0, s, h->k, rrec, h->gm, h->gv, h->list[now], h->count + now);
     NM_LAUNCH_CHECK();
     skip = rrec.hdr;
+    if (restore_verified) {   // the host has seen this record's header: it is valid, nothing to fall back to
+      h->cur = now;
+      return NM_OK;
+    }
   }
   if (n > 0) {
     NM_LAUNCH(k_p2g, dim3(nm_div_up(n, NM_SC_T)), dim3(NM_SC_T), 0, s, h->k, n, st->vol, st->rho, st->enabled, cur->x,
@@ -1139,6 +1143,12 @@ extern "C" int nm_mpm_backward(nm_mpm* h, int32_t n, const nm_statics* st, const
 extern "C" int nm_mpm_backward_ex(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur,
                                   const nm_particles* next, const nm_particles* gnext, nm_particles* gcur,
                                   const void* gridrec, int32_t cap_blocks, void* stream) {
+  return nm_mpm_backward_cached(h, n, st, cur, next, gnext, gcur, gridrec, cap_blocks, false, stream);
+}
+
+int nm_mpm_backward_cached(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, const nm_particles* next,
+                           const nm_particles* gnext, nm_particles* gcur, const void* gridrec, int32_t cap_blocks, bool verified,
+                           void* stream) {
   NM_REQUIRE(h, "null handle");
   NM_REQUIRE(!gridrec || cap_blocks > 0, "grid cache record without capacity");
   NM_REQUIRE(n >= 0, "negative particle count");
@@ -1149,7 +1159,7 @@ extern "C" int nm_mpm_backward_ex(nm_mpm* h, int32_t n, const nm_statics* st, co
   NM_REQUIRE(gnext && gnext->x && gnext->v && gnext->C && gnext->F, "null incoming gradients");
   NM_REQUIRE(gcur && gcur->x && gcur->v && gcur->C && gcur->F && gcur->stress, "null outgoing gradients");
   hipStream_t s = (hipStream_t)stream;
-  rc = mpm_build_grid(h, n, st, cur, s, nullptr, gridrec, cap_blocks);  // recompute (mpm.py:312-315) or restore
+  rc = mpm_build_grid(h, n, st, cur, s, nullptr, gridrec, cap_blocks, verified && gridrec != nullptr);  // recompute (mpm.py:312-315) or restore
   if (rc) return rc;
   if (n == 0) return NM_OK;
   const int now = h->cur;

@@ -69,6 +69,14 @@ static inline void* grid_rec(const void* gridcache, const nm_rollout_cfg* cfg, i
   return (char*)const_cast<void*>(gridcache) + (size_t)t * nm_mpm_gridcache_bytes(cfg->grid_cache_blocks);
 }
 
+extern "C" int nm_rollout_cache_status(const void* gridcache, const nm_rollout_cfg* cfg, int32_t* status_host, void* stream) {
+  NM_REQUIRE(gridcache && cfg && status_host, "null pointer");
+  NM_REQUIRE(cfg->substeps >= 1 && cfg->grid_cache_blocks >= 1, "no grid cache configured");
+  NM_HIP_CHECK(hipMemcpy2DAsync(status_host, sizeof(int32_t), gridcache, nm_mpm_gridcache_bytes(cfg->grid_cache_blocks), sizeof(int32_t),
+                                (size_t)cfg->substeps, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return NM_OK;
+}
+
 extern "C" int nm_rollout_forward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cfg, const nm_statics* st, const nm_mlp* we,
                                   const nm_mlp* wp, float* states, void* gridcache, void* workspace, size_t workspace_bytes,
                                   void* stream) {
@@ -136,7 +144,8 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
     gn.x = const_cast<float*>(gin); gn.v = const_cast<float*>(gin) + 3 * N; gn.C = const_cast<float*>(gin) + 6 * N;
     gn.F = w.gFtr; gn.stress = nullptr;
     gc.x = gout; gc.v = gout + 3 * N; gc.C = gout + 6 * N; gc.F = gout + 15 * N; gc.stress = w.gS;
-    rc = nm_mpm_backward_ex(h, n, st, &cur, &nxt, &gn, &gc, grid_rec(gridcache, cfg, t), cfg->grid_cache_blocks, stream);
+    rc = nm_mpm_backward_cached(h, n, st, &cur, &nxt, &gn, &gc, grid_rec(gridcache, cfg, t), cfg->grid_cache_blocks,
+                                cfg->cache_verified != 0, stream);
     if (rc) return rc;
     // elasticity backward: dL/dstress -> dL/dF (added to the sim's dL/dF)
     rc = nm_material_bwd_launch(n, NM_ELASTICITY, 0.f, cur.F, we, w.perm_e, w.gS, gc.F, w.part_e, wmode, nullptr, nullptr, 0.f, 1,

@@ -13,6 +13,7 @@ from . import _lib as L
 from .sim.mpm import MPMModel, MPMStatics
 
 _WSZ = (64 * 13, 64 * 64, 9 * 64)
+_CACHE_STATUS = __import__('os').environ.get('NEUMA_CACHE_STATUS', '1') != '0'
 
 
 class _Rollout(autograd.Function):
@@ -38,7 +39,7 @@ class _Rollout(autograd.Function):
         cache_blocks = int(cache_blocks) if any(ctx.needs_input_grad) else 0
         gc_bytes = int(lib.nm_rollout_gridcache_bytes(S, cache_blocks)) if cache_blocks > 0 else 0
         gcache = torch.empty(gc_bytes, dtype=torch.uint8, device=dev) if gc_bytes > 0 else None
-        cfg = L.nm_rollout_cfg(S, float(alpha), cache_blocks if gcache is not None else 0)
+        cfg = L.nm_rollout_cfg(S, float(alpha), cache_blocks if gcache is not None else 0, 0)
         st = statics.c_struct()
         mle = L.nm_mlp(*[L.ptr(t) for t in we])
         mlp = L.nm_mlp(*[L.ptr(t) for t in wp])
@@ -47,6 +48,14 @@ class _Rollout(autograd.Function):
                 "nm_rollout_forward")
         ctx.model, ctx.statics, ctx.S, ctx.alpha, ctx.n = model, statics, S, float(alpha), n
         ctx.cache_blocks, ctx.gcache = int(cfg.grid_cache_blocks), gcache
+        ctx.cache_status = ctx.cache_event = None
+        if gcache is not None and _CACHE_STATUS:      # asynchronous read-back of the record headers: by the time the backward pass runs the
+            status = torch.empty(S, dtype=torch.int32, pin_memory=True)       # host usually knows that every record is valid
+            L.check(lib.nm_rollout_cache_status(L.ptr(gcache), C.byref(cfg), C.c_void_p(status.data_ptr()), L.stream_ptr(dev)),
+                    "nm_rollout_cache_status")
+            ev = torch.cuda.Event()
+            ev.record()
+            ctx.cache_status, ctx.cache_event = status, ev
         ctx.save_for_backward(states, *we, *wp)
         last = states[S]
         return (last[:3 * n].view(n, 3), last[3 * n:6 * n].view(n, 3), last[6 * n:15 * n].view(n, 3, 3),
@@ -70,8 +79,11 @@ class _Rollout(autograd.Function):
         gwp = torch.empty(sum(_WSZ), dtype=torch.float32, device=dev)
         ws_bytes = int(lib.nm_rollout_workspace(n, S))
         ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
-        cfg = L.nm_rollout_cfg(S, ctx.alpha, ctx.cache_blocks)
         gcache = ctx.gcache
+        verified = 0
+        if gcache is not None and ctx.cache_event is not None and ctx.cache_event.query():
+            verified = int(bool((ctx.cache_status >= 0).all()))
+        cfg = L.nm_rollout_cfg(S, ctx.alpha, ctx.cache_blocks, verified)
         st = ctx.statics.c_struct()
         mle = L.nm_mlp(L.ptr(e0), L.ptr(e1), L.ptr(e2))
         mlp = L.nm_mlp(L.ptr(p0), L.ptr(p1), L.ptr(p2))
