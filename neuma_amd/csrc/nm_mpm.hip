@@ -75,10 +75,23 @@ __device__ __forceinline__ void make_stencil(const MpmK& K, const float* __restr
 
 __device__ __forceinline__ float sel3(const float* a, int i) { return i == 0 ? a[0] : (i == 1 ? a[1] : a[2]); }
 
+#ifdef NM_PHASES
+__device__ int g_nm_markslow[4];
+extern "C" int nm_debug_markslow(int* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nm_markslow), 16) == hipSuccess ? 0 : -2; }
+#endif
 __device__ __forceinline__ void mark_block(int b, int* __restrict__ flags, int* __restrict__ list,
                                            int* __restrict__ count, int epoch) {
+#ifdef NM_PHASES
+  atomicAdd(&g_nm_markslow[0], 1);
+#endif
   if (flags[b] != epoch) {
+#ifdef NM_PHASES
+    atomicAdd(&g_nm_markslow[1], 1);
+#endif
     if (atomicExch(&flags[b], epoch) != epoch) {
+#ifdef NM_PHASES
+      atomicAdd(&g_nm_markslow[2], 1);
+#endif
       int pos = atomicAdd(count, 1);
       list[pos] = b;
     }
@@ -376,6 +389,18 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
 
   SC_PH(0)
   sc_pass = 1;
+  // Block stamps of the bounding box are read NOW, while the memory system is quiet: at the end of the kernel the same
+  // read queues behind every workgroup's atomic flush (10-25k cycles under load).
+  int pre_flag = epoch;
+  if (flags && !cmp) {
+    const int b0 = g.o[0] >> 2, b1 = g.o[1] >> 2, b2 = g.o[2] >> 2;
+    const int m1 = ((g.o[1] + g.n[1] - 1) >> 2) - b1 + 1, m2 = ((g.o[2] + g.n[2] - 1) >> 2) - b2 + 1;
+    const int nblk = (((g.o[0] + g.n[0] - 1) >> 2) - b0 + 1) * m1 * m2;
+    if (tid < nblk) {
+      const int i = tid / (m1 * m2), r = tid - i * (m1 * m2);
+      pre_flag = flags[((b0 + i) * K.nb + (b1 + r / m2)) * K.nb + (b2 + r % m2)];
+    }
+  }
   {   // ---- the single workgroup-wide pass
     SC_PH(1)
     const bool in = pending;
@@ -421,6 +446,14 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
     const bool owner = tid < nruns;                   // thread r owns non-empty cell r
     const int mycell = owner ? (int)L.run_cell[tid] : 0;
     const int s0 = owner ? L.cnt[mycell] : 0;
+    if (flags && cmp && owner && !(K.dbg & 2)) {   // compressed tile: thread r stamps the blocks of cell r, early (see above)
+      const int a_ = mycell / nyz, r_ = mycell - a_ * nyz;
+      const int b_ = r_ / g.n[2], c_ = r_ - b_ * g.n[2];
+      const int o0 = (int)L.ainv[0][a_], o1 = (int)L.ainv[1][b_], o2 = (int)L.ainv[2][c_];
+      for (int i = o0 >> 2; i <= (o0 + 2) >> 2; ++i)
+        for (int j = o1 >> 2; j <= (o1 + 2) >> 2; ++j)
+          for (int k = o2 >> 2; k <= (o2 + 2) >> 2; ++k) mark_block((i * K.nb + j) * K.nb + k, flags, list, count, epoch);
+    }
 #pragma unroll 1
     for (int i = 0; i < 3; ++i) {
       if (in) {
@@ -461,29 +494,38 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
         }
       SC_PH(5)
     }
-    // ---- the blocks this pass touches join the active list (almost always a single flag read per block: k_clear
-    // carried the previous substep's blocks over).  Plain tile: one thread per block of the bounding box (a superset;
-    // blocks that stay empty drop out at the next k_clear).  Compressed tile: thread r stamps the blocks of cell r.
-    if (flags && !(K.dbg & 2)) {
+    // ---- the blocks that receive something join the active list (almost always a single flag read per block: k_clear
+    // carried the previous substep's blocks over).  Plain tile: a pass over the tile records in LDS which blocks of the
+    // bounding box hold a non-zero node and one thread per such block stamps it - an untouched block stamped here would
+    // hold no mass, drop out at the next k_clear and take the atomic path again every substep.  Compressed tile: thread r
+    // stamps the blocks of cell r.  Then the flush: one global atomic set per touched node.
+    const bool mark = flags != nullptr && !(K.dbg & 2);
+    if (mark) {
       if (!cmp) {
         const int b0 = g.o[0] >> 2, b1 = g.o[1] >> 2, b2 = g.o[2] >> 2;
-        const int m0 = ((g.o[0] + g.n[0] - 1) >> 2) - b0 + 1, m1 = ((g.o[1] + g.n[1] - 1) >> 2) - b1 + 1,
-                  m2 = ((g.o[2] + g.n[2] - 1) >> 2) - b2 + 1;
-        for (int t = tid; t < m0 * m1 * m2; t += NM_SC_T) {
+        const int m1 = ((g.o[1] + g.n[1] - 1) >> 2) - b1 + 1, m2 = ((g.o[2] + g.n[2] - 1) >> 2) - b2 + 1;
+        const int nblk = (((g.o[0] + g.n[0] - 1) >> 2) - b0 + 1) * m1 * m2;
+        int* touched = L.cnt;                     // free after the slab loop
+        for (int t = tid; t < nblk; t += NM_SC_T) touched[t] = 0;
+        __syncthreads();
+        for (int nidx = tid; nidx < g.vol; nidx += NM_SC_T) {
+          const float4 t = L.tile[nidx];
+          if (t.x != 0.f || t.y != 0.f || t.z != 0.f || t.w != 0.f) {
+            const int a_ = nidx / nyz, r = nidx - a_ * nyz;
+            const int b_ = r / g.n[2], c_ = r - b_ * g.n[2];
+            touched[((((g.o[0] + a_) >> 2) - b0) * m1 + (((g.o[1] + b_) >> 2) - b1)) * m2 + (((g.o[2] + c_) >> 2) - b2)] = 1;
+          }
+        }
+        __syncthreads();
+        for (int t = tid; t < nblk; t += NM_SC_T) {
+          if (touched[t] == 0 || (t == tid && pre_flag == epoch)) continue;     // already stamped when we looked
           const int i = t / (m1 * m2), r = t - i * (m1 * m2);
           const int j = r / m2, k = r - j * m2;
           mark_block(((b0 + i) * K.nb + (b1 + j)) * K.nb + (b2 + k), flags, list, count, epoch);
         }
-      } else if (owner) {
-        const int a_ = mycell / nyz, r_ = mycell - a_ * nyz;
-        const int b_ = r_ / g.n[2], c_ = r_ - b_ * g.n[2];
-        const int o0 = (int)L.ainv[0][a_], o1 = (int)L.ainv[1][b_], o2 = (int)L.ainv[2][c_];
-        for (int i = o0 >> 2; i <= (o0 + 2) >> 2; ++i)
-          for (int j = o1 >> 2; j <= (o1 + 2) >> 2; ++j)
-            for (int k = o2 >> 2; k <= (o2 + 2) >> 2; ++k) mark_block((i * K.nb + j) * K.nb + k, flags, list, count, epoch);
       }
     }
-    // ---- flush: one global atomic set per touched node
+    // the atomics go last: nothing waits for them, they drain while other workgroups compute
     for (int nidx = tid; nidx < g.vol; nidx += NM_SC_T) {
       const float4 t = L.tile[nidx];
       if (!(K.dbg & 1) && (t.x != 0.f || t.y != 0.f || t.z != 0.f || t.w != 0.f)) {

@@ -18,6 +18,9 @@ with torch.no_grad():
     for _ in range(2):
         rt.rollout(rt.x0, rt.v0, rt.C0, rt.F0)      # last launch using wg_scatter = k_p2g of substep 20
 torch.cuda.synchronize()
+ms = (C.c_int * 4)()
+lib.nm_debug_markslow(ms)
+print("mark_block calls / flag misses / new blocks over the whole run (2 x 20 substeps):", list(ms)[:3], "active blocks", rt.model.grid_stats())
 fn = lib.nm_debug_scatter; fn.argtypes = [C.c_void_p, C.c_int]
 buf = np.zeros(8 * 4096, dtype=np.int64)
 print("rc", fn(buf.ctypes.data, 8 * 4096))
@@ -28,3 +31,6 @@ for i, nm in enumerate(names):
     print(f"{nm:14s} mean {b[:, i].mean():9.1f} median {np.median(b[:, i]):9.1f} max {b[:, i].max():9.0f}")
 print("total cycles mean", b[:, :7].sum(1).mean(), "max", b[:, :7].sum(1).max())
 print("passes histogram", np.bincount(b[:, 7].astype(int)))
+tot = b[:, :7].sum(1)
+for w in np.argsort(-tot)[:6]:
+    print("wg", int(w), "total", int(tot[w]), "phases", b[w, :7].astype(int).tolist(), "mode/passes", int(b[w, 7]))
