@@ -84,6 +84,49 @@ def test_unsorted_particles_take_the_fallback_path_with_same_result():
     assert all(torch.isfinite(t).all() for t in g)
 
 
+@pytest.mark.parametrize("nclusters", [1, 2, 3, 8, 24])
+def test_scatter_modes_on_chunks_made_of_disjoint_clusters(nclusters):
+    """Every 256-particle workgroup chunk is made of `nclusters` compact clusters far apart from each other: 1 -> plain
+    tile, 2-3 -> axis-compressed tile, 8 -> per-wave boxes, 24 -> per-wave boxes with several passes (+ leftovers through
+    global atomics).  Forward grid, next state and the gradients (g2p adjoint scatter uses the same code) vs the oracle."""
+    G = 64
+    const = om.MPMConstant(num_grids=G, dt=1e-3, bound=1, gravity=(0.0, -9.8, 0.0), eps=6e-7, bc="noslip")
+    g = torch.Generator().manual_seed(nclusters)
+    nchunks, per = 6, 256 // nclusters
+    centers = 0.15 + 0.7 * torch.rand(nchunks * nclusters, 3, generator=g, dtype=torch.float64)
+    xs = []
+    for c in range(nchunks):
+        for k in range(nclusters):
+            xs.append(centers[c * nclusters + k] + (1.5 / G) * (torch.rand(per, 3, generator=g, dtype=torch.float64) - 0.5))
+        if per * nclusters < 256:      # pad the chunk to 256 so that chunks stay aligned with workgroups
+            xs.append(centers[c * nclusters] + (1.5 / G) * (torch.rand(256 - per * nclusters, 3, generator=g, dtype=torch.float64) - 0.5))
+    x = torch.cat(xs)
+    N = x.shape[0]
+    v = torch.randn(N, 3, generator=g, dtype=torch.float64)
+    C = torch.randn(N, 3, 3, generator=g, dtype=torch.float64)
+    F = torch.eye(3, dtype=torch.float64)[None] + 0.05 * torch.randn(N, 3, 3, generator=g, dtype=torch.float64)
+    S = 20.0 * torch.randn(N, 3, 3, generator=g, dtype=torch.float64)
+    vol = torch.full((N,), (const.dx / 2) ** 3, dtype=torch.float64)
+    rho = torch.full((N,), 1000.0, dtype=torch.float64)
+    clip = torch.full((N,), 0.1, dtype=torch.float64)
+    en = torch.ones(N, dtype=torch.int32)
+    model = build_model(const, dev())
+    st = build_statics(model, vol, rho, clip, en, dev())
+    ins, outs = _gpu_step(model, st, x, v, C, F, S)
+    xi, vi, Ci, Fi, Si = [t.detach().cpu().double().requires_grad_(True) for t in ins]
+    (ox, ov, oC, oF), (gmv, gm, gv) = om.step(const, vol, rho, clip, en, xi, vi, Ci, Fi, Si, return_grid=True)
+    mv, m, vg = model.grid_export()
+    assert rel_max(m, gm) < 2e-6 and rel_max(mv, gmv) < 5e-6
+    assert abs_max(outs[0], ox) < 5e-7 and rel_max(outs[1], ov) < 2e-5 and rel_max(outs[2], oC) < 5e-5
+    w = [torch.randn(o.shape, generator=g, dtype=torch.float64) for o in outs]
+    go = torch.autograd.grad(sum((o * wi).sum() for o, wi in zip((ox, ov, oC, oF), w)), [xi, vi, Ci, Fi, Si])
+    gg = torch.autograd.grad(sum((o * wi.float().to(dev())).sum() for o, wi in zip(outs, w)), ins)
+    for a, b in zip(gg, go):
+        assert rel_max(a, b) < 2e-3
+    nb, nm = model.grid_stats()
+    assert nm == int((gm > 0).sum())
+
+
 def test_in_place_forward_sim_and_extra():
     from neuma_amd.sim import MPMForwardSim, MPMExtraSim
     const, vol, rho, clip, en, x, v, C, F, S = mpm_case(N=2048, G=32, disabled=False)
