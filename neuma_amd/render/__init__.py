@@ -84,7 +84,7 @@ class _RasterizeGaussians(autograd.Function):
         cp = None if colors_precomp is None else colors_precomp.detach().float().contiguous()
         M = 0 if sh is None else sh.size(1)
         H, W = cfg.image_height, cfg.image_width
-        radii = torch.zeros(K, dtype=torch.int32, device=dev)
+        radii = torch.empty(K, dtype=torch.int32, device=dev)            # k_preprocess writes every entry
         geom_bytes = int(lib.nm_raster_geom_bytes(K))
         geom = torch.empty(geom_bytes, dtype=torch.uint8, device=dev)
         num = C.c_int64(0)
@@ -97,7 +97,9 @@ class _RasterizeGaussians(autograd.Function):
         binning = torch.empty(bin_bytes, dtype=torch.uint8, device=dev)
         imgbuf = torch.empty(img_bytes, dtype=torch.uint8, device=dev)
         scratch = torch.empty(scr_bytes, dtype=torch.uint8, device=dev)
-        color = torch.zeros(3, H, W, dtype=torch.float32, device=dev)
+        full = cfg.tile_y1 <= cfg.tile_y0 or (cfg.tile_y0 == 0 and cfg.tile_y1 * 16 >= H)
+        # a full-image render writes every pixel; a stripe leaves the rows outside it untouched (zero)
+        color = (torch.empty if full else torch.zeros)(3, H, W, dtype=torch.float32, device=dev)
         L.check(lib.nm_raster_render(C.byref(cfg), K, D, L.ptr(geom), L.ptr(binning), bin_bytes, L.ptr(scratch), scr_bytes,
                                      L.ptr(imgbuf), img_bytes, L.ptr(color), stream), "nm_raster_render")
         del scratch
