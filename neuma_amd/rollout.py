@@ -11,6 +11,7 @@ from torch import Tensor
 
 from . import _lib as L
 from .sim.mpm import MPMModel, MPMStatics
+from .sim.order import ParticleOrder, hilbert_index_torch  # noqa: F401 (re-exported)
 
 _WSZ = (64 * 13, 64 * 64, 9 * 64)
 _CACHE_STATUS = __import__('os').environ.get('NEUMA_CACHE_STATUS', '1') != '0'
@@ -100,39 +101,6 @@ class _Rollout(autograd.Function):
                 gwp[:a].view(64, 13), gwp[a:b].view(64, 64), gwp[b:].view(9, 64))
 
 
-def hilbert_index_torch(cells: Tensor, bits: int) -> Tensor:
-    """Device version of synth.hilbert_index (Skilling's transpose algorithm) on an (N,3) int64 tensor."""
-    X = [cells[:, 0].clone(), cells[:, 1].clone(), cells[:, 2].clone()]
-    Q = 1 << (bits - 1)
-    while Q > 1:
-        P = Q - 1
-        for i in range(3):
-            hit = (X[i] & Q) != 0
-            t = (X[0] ^ X[i]) & P
-            x0_hit = X[0] ^ P
-            x0_miss = X[0] ^ t
-            xi_miss = X[i] ^ t
-            if i == 0:
-                X[0] = torch.where(hit, x0_hit, X[0])          # t == 0 for i == 0
-            else:
-                X[i] = torch.where(hit, X[i], xi_miss)
-                X[0] = torch.where(hit, x0_hit, x0_miss)
-        Q >>= 1
-    X[1] = X[1] ^ X[0]
-    X[2] = X[2] ^ X[1]
-    t = torch.zeros_like(X[0])
-    Q = 1 << (bits - 1)
-    while Q > 1:
-        t = torch.where((X[2] & Q) != 0, t ^ (Q - 1), t)
-        Q >>= 1
-    X = [x ^ t for x in X]
-    idx = torch.zeros_like(X[0])
-    for b in range(bits - 1, -1, -1):
-        for i in range(3):
-            idx = (idx << 1) | ((X[i] >> b) & 1)
-    return idx
-
-
 class MPMFusedDiffSim(nn.Module):
     """sim(statics, x, v, C, F) -> (x, v, C, F) after `substeps` substeps, constitutive nets included.
 
@@ -152,40 +120,23 @@ class MPMFusedDiffSim(nn.Module):
         # consecutive particles have adjacent stencil origins; below 80 % the roll-out runs on a Hilbert-sorted copy
         # (inputs gathered, outputs scattered back - plain differentiable indexing, so callers never see the order).
         # True / False force it.  The permutation is fixed at the first call (particles move a fraction of a cell per step).
-        self.reorder = reorder
-        self._perm = None          # None: undecided; False: not needed; tensor: permutation
-        self._inv = None
-        self._statics_cache = None
+        self.order = ParticleOrder(int(model.constant.num_grids), reorder)
 
-    # -- particle order ------------------------------------------------------------------------------------------
+    @property
+    def reorder(self):
+        return self.order.mode
+
+    @reorder.setter
+    def reorder(self, mode):
+        self.order.mode = mode
+        self.order.perm = None
+
+    @property
+    def _perm(self):
+        return self.order.perm
+
     def order_quality(self, x: Tensor) -> float:
-        G = int(self.model.constant.num_grids)
-        base = torch.trunc(x.detach() * G - 0.5).clamp_(min=0).long()
-        d = (base[1:] - base[:-1]).abs().max(dim=1).values
-        return float((d <= 1).float().mean()) if d.numel() else 1.0
-
-    def _decide_order(self, x: Tensor) -> None:
-        want = self.reorder
-        if want == "auto":
-            want = self.order_quality(x) < 0.8
-        if not want:
-            self._perm = False
-            return
-        G = int(self.model.constant.num_grids)
-        bits = max(1, (G + 2 - 1).bit_length())
-        base = torch.trunc(x.detach() * G - 0.5).clamp_(min=0).long()
-        self._perm = torch.argsort(hilbert_index_torch(base, bits), stable=True)
-        self._inv = torch.empty_like(self._perm)
-        self._inv[self._perm] = torch.arange(self._perm.numel(), device=self._perm.device)
-
-    def _permuted_statics(self, statics: MPMStatics) -> MPMStatics:
-        key = tuple((t.data_ptr(), t._version) for t in (statics.vol, statics.rho, statics.clip_bound, statics.enabled))
-        if self._statics_cache is None or self._statics_cache[0] != key:
-            st = MPMStatics()
-            st.vol, st.rho = statics.vol[self._perm].contiguous(), statics.rho[self._perm].contiguous()
-            st.clip_bound, st.enabled = statics.clip_bound[self._perm].contiguous(), statics.enabled[self._perm].contiguous()
-            self._statics_cache = (key, st)
-        return self._statics_cache[1]
+        return self.order.quality(x)
 
     def grid_cache_blocks(self) -> int:
         return int(self._cache_blocks or 0)
@@ -193,11 +144,9 @@ class MPMFusedDiffSim(nn.Module):
     def forward(self, statics: MPMStatics, x: Tensor, v: Tensor, C_: Tensor, F: Tensor):
         e = self.elasticity.effective_weights()
         p = self.plasticity.effective_weights()
-        if self._perm is None or (self._perm is not False and self._perm.numel() != x.shape[0]):
-            self._decide_order(x)
-        if self._perm is not False:
-            pm, inv = self._perm, self._inv
-            out = _Rollout.apply(self.model, self._permuted_statics(statics), self.substeps, self.plasticity.alpha,
+        if self.order.active(x):
+            pm, inv = self.order.perm, self.order.inv
+            out = _Rollout.apply(self.model, self.order.statics(statics), self.substeps, self.plasticity.alpha,
                                  self.grid_cache_blocks(), x[pm], v[pm], C_[pm], F[pm], *e, *p)
             out = tuple(o[inv] for o in out)
         else:

@@ -9,6 +9,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from .mpm import MPMModel, MPMState, MPMStatics
+from .order import ParticleOrder
 
 
 class MPMSimFunction(autograd.Function):
@@ -44,9 +45,20 @@ class MPMSimFunction(autograd.Function):
 class MPMSim(nn.Module):
     """interface.py:79-93"""
 
-    def __init__(self, model: MPMModel) -> None:
+    def __init__(self, model: MPMModel, reorder="auto") -> None:
         super().__init__()
         self.model = model
+        # not in the reference: shuffled particle sets (what prepare_simulation_data produces) are run on an internally
+        # Hilbert-sorted copy, see order.py; reorder=False switches it off
+        self.order = ParticleOrder(int(model.constant.num_grids), reorder)
+
+    def _apply(self, statics: MPMStatics, state_curr: MPMState, state_next: MPMState, x, v, C, F, stress):
+        if self.order.active(x):
+            pm, inv = self.order.perm, self.order.inv
+            out = MPMSimFunction.apply(self.model, self.order.statics(statics), state_curr, state_next, x[pm], v[pm], C[pm], F[pm],
+                                       stress[pm])
+            return tuple(o[inv] for o in out)
+        return MPMSimFunction.apply(self.model, statics, state_curr, state_next, x, v, C, F, stress)
 
     def state(self, x: Tensor, v: Tensor, C: Tensor, F: Tensor, stress: Tensor, state: Optional[MPMState] = None) -> MPMState:
         model = self.model
@@ -64,14 +76,14 @@ class MPMDiffSim(MPMSim):
         shape = x.size(0)
         state_curr = self.model.state(shape)
         state_next = self.model.state(shape)
-        return MPMSimFunction.apply(self.model, statics, state_curr, state_next, x, v, C, F, stress)
+        return self._apply(statics, state_curr, state_next, x, v, C, F, stress)
 
 
 class MPMCacheDiffSim(MPMSim):
     """interface.py:108-123"""
 
-    def __init__(self, model: MPMModel, num_steps: int) -> None:
-        super().__init__(model)
+    def __init__(self, model: MPMModel, num_steps: int, reorder="auto") -> None:
+        super().__init__(model, reorder)
         self.curr_states = [None for _ in range(num_steps)]
         self.next_states = [None for _ in range(num_steps)]
 
@@ -81,7 +93,7 @@ class MPMCacheDiffSim(MPMSim):
             self.curr_states[step] = self.model.state(shape)
         if self.next_states[step] is None:
             self.next_states[step] = self.model.state(shape)
-        return MPMSimFunction.apply(self.model, statics, self.curr_states[step], self.next_states[step], x, v, C, F, stress)
+        return self._apply(statics, self.curr_states[step], self.next_states[step], x, v, C, F, stress)
 
 
 class MPMForwardSim(MPMSim):

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 def _gpu_step(model, st, x, v, C, F, S, sim=None):
     from neuma_amd.sim import MPMDiffSim
-    sim = sim or MPMDiffSim(model)
+    sim = sim or MPMDiffSim(model, reorder=False)       # the kernels see the particles in exactly the order given here
     ins = [t.float().to(dev()).requires_grad_(True) for t in (x, v, C, F, S)]
     outs = sim(st, *ins)
     return ins, outs
@@ -125,6 +125,31 @@ def test_scatter_modes_on_chunks_made_of_disjoint_clusters(nclusters):
         assert rel_max(a, b) < 2e-3
     nb, nm = model.grid_stats()
     assert nm == int((gm > 0).sum())
+
+
+def test_per_operator_sims_reorder_shuffled_particles_transparently():
+    """MPMDiffSim / MPMCacheDiffSim (what finetune.py drives, on particles prepare_simulation_data has shuffled) run on an
+    internally Hilbert-sorted copy: same outputs and gradients, in the caller's order, as with re-ordering switched off."""
+    from neuma_amd.sim import MPMCacheDiffSim, MPMDiffSim
+    const, vol, rho, clip, en, x, v, C, F, S = mpm_case(N=6000, G=32, near_wall=False)
+    perm = torch.randperm(x.shape[0], generator=torch.Generator().manual_seed(9))
+    x, v, C, F, S, en = x[perm], v[perm], C[perm], F[perm], S[perm], en[perm].contiguous()
+    model = build_model(const, dev())
+    st = build_statics(model, vol, rho, clip, en, dev())
+    ref_in, ref_out = _gpu_step(model, st, x, v, C, F, S)                       # reorder=False
+    w = [torch.randn(o.shape, generator=torch.Generator().manual_seed(1)).to(dev()) for o in ref_out]
+    g_ref = torch.autograd.grad(sum((o * wi).sum() for o, wi in zip(ref_out, w)), ref_in)
+    for sim, args in ((MPMDiffSim(model), ()), (MPMCacheDiffSim(model, 4), (2,))):
+        ins = [t.float().to(dev()).requires_grad_(True) for t in (x, v, C, F, S)]
+        outs = sim(st, *args, *ins)
+        assert torch.is_tensor(sim.order.perm)                                   # shuffled input: permutation in use
+        for a, b in zip(outs, ref_out):
+            assert abs_max(a, b) < 1e-5 * max(1.0, float(b.abs().max()))
+        g = torch.autograd.grad(sum((o * wi).sum() for o, wi in zip(outs, w)), ins)
+        for a, b in zip(g, g_ref):
+            assert rel_max(a, b) < 1e-3
+    e = (en != 0).to(dev())
+    assert torch.equal(outs[0][~e], ins[0][~e])                                  # disabled particles pass through, in place
 
 
 def test_in_place_forward_sim_and_extra():
