@@ -100,7 +100,20 @@ class MPMForwardSim(MPMSim):
     """interface.py:126-135 (in place: state is both current and next)"""
 
     def forward(self, statics: MPMStatics, state: MPMState):
-        self.model.forward(statics, state, state, None)
+        x, v, C, F, stress = state.to_torch()
+        if self.order.active(x):
+            # shuffled particles: step an internally sorted copy and write the result back into the caller's buffers
+            pm, inv = self.order.perm, self.order.inv
+            ps = getattr(self, "_sorted_state", None)
+            if ps is None or ps.particle.x.shape[0] != x.shape[0]:
+                ps = self._sorted_state = self.model.state(x.shape[0])
+            for dst, src in zip(ps.to_torch(), (x, v, C, F, stress)):
+                torch.index_select(src.detach(), 0, pm, out=dst)
+            self.model.forward(self.order.statics(statics), ps, ps, None)
+            for dst, src in zip((x, v, C, F), ps.to_torch()[:4]):
+                torch.index_select(src, 0, inv, out=dst.detach())
+        else:
+            self.model.forward(statics, state, state, None)
         x_next, v_next, C_next, F_next, _ = state.to_torch()
         return x_next, v_next, C_next, F_next
 

@@ -152,6 +152,31 @@ def test_per_operator_sims_reorder_shuffled_particles_transparently():
     assert torch.equal(outs[0][~e], ins[0][~e])                                  # disabled particles pass through, in place
 
 
+def test_forward_sim_reorders_shuffled_particles_in_place():
+    """MPMForwardSim (inference path, in place on the caller's state): shuffled particles are stepped on a sorted internal
+    copy and written back into the same buffers."""
+    from neuma_amd.sim import MPMForwardSim
+    const, vol, rho, clip, en, x, v, C, F, S = mpm_case(N=5000, G=32, near_wall=False)
+    perm = torch.randperm(x.shape[0], generator=torch.Generator().manual_seed(11))
+    x, v, C, F, S, en = x[perm], v[perm], C[perm], F[perm], S[perm], en[perm].contiguous()
+    model = build_model(const, dev())
+    st = build_statics(model, vol, rho, clip, en, dev())
+    res = {}
+    for tag, reorder in (("plain", False), ("sorted", "auto")):
+        sim = MPMForwardSim(model, reorder=reorder)
+        state = model.state(x.shape[0])
+        state.from_torch(x=x.float().to(dev()), v=v.float().to(dev()), C=C.float().to(dev()), F=F.float().to(dev()),
+                         stress=S.float().to(dev()))
+        held = state.to_torch()[0]                       # a handle the caller keeps: must see the update
+        for _ in range(3):
+            outs = sim(st, state)
+        assert outs[0].data_ptr() == held.data_ptr()
+        assert torch.is_tensor(sim.order.perm) == (reorder == "auto")
+        res[tag] = [o.clone() for o in outs]
+    for a, b in zip(res["sorted"], res["plain"]):
+        assert abs_max(a, b) < 2e-5 * max(1.0, float(b.abs().max()))
+
+
 def test_in_place_forward_sim_and_extra():
     from neuma_amd.sim import MPMForwardSim, MPMExtraSim
     const, vol, rho, clip, en, x, v, C, F, S = mpm_case(N=2048, G=32, disabled=False)
