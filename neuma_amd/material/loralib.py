@@ -80,7 +80,19 @@ class LinearLoRA(nn.Linear):
     def effective_weight(self) -> torch.Tensor:
         if self.r > 0 and not self.merged:
             if self.weight.is_cuda:
-                return _LoraMerge.apply(self.weight, self.lora_B, self.lora_A, self.scaling)
+                # A roll-out asks for the merged weight once per substep and net while the parameters only change at the
+                # optimiser step: the merged tensor (and its autograd node) is reused until a parameter is modified
+                # (version counters), the grad mode changes, or a backward pass has consumed the node.
+                key = (self.weight._version, self.lora_A._version, self.lora_B._version, torch.is_grad_enabled(),
+                       self.lora_A.requires_grad, self.lora_B.requires_grad, self.weight.requires_grad)
+                cached = getattr(self, "_eff_cache", None)
+                if cached is not None and cached[0] == key:
+                    return cached[1]
+                w = _LoraMerge.apply(self.weight, self.lora_B, self.lora_A, self.scaling)
+                self._eff_cache = (key, w)
+                if w.grad_fn is not None:
+                    w.grad_fn.register_hook(lambda *_: setattr(self, "_eff_cache", None))
+                return w
             return self.weight + (self.lora_B @ self.lora_A) * self.scaling      # host tensors (CPU-side unit tests)
         return self.weight
 
