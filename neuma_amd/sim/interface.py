@@ -18,9 +18,11 @@ class MPMSimFunction(autograd.Function):
     @staticmethod
     def forward(ctx, model: MPMModel, statics: MPMStatics, state_curr: MPMState, state_next: MPMState,
                 x: Tensor, v: Tensor, C: Tensor, F: Tensor, stress: Tensor):
-        tape = None
+        # the reference passes a Warp tape here; ours carries the substep's grid cache record when a backward pass can follow
+        tape = model.new_tape() if any(ctx.needs_input_grad) else None
         state_curr.from_torch(x=x, v=v, C=C, F=F, stress=stress)
         model.forward(statics, state_curr, state_next, tape)
+        model._size_cache()
         x_next, v_next, C_next, F_next, _ = state_next.to_torch()
         ctx.model = model
         ctx.tape = tape

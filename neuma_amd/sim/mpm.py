@@ -174,6 +174,16 @@ class MPMState(State):
             p.stress_grad = self._prep(grad_stress)
 
 
+class GridTape(object):
+    """What the `tape` positional of MPMModel.forward / backward carries here: one grid cache record (the substep's
+    touched grid blocks, nm_mpm_forward_ex) instead of Warp's operation tape, so that the backward pass restores the
+    grid instead of re-running p2g (mpm.py:312-315)."""
+
+    def __init__(self, cap_blocks: int, device) -> None:
+        self.cap = int(cap_blocks)
+        self.buf = torch.empty(int(L.lib().nm_mpm_gridcache_bytes(self.cap)), dtype=torch.uint8, device=device)
+
+
 class MPMModel(Model):
     """mpm.py:245-319.  Owns the (sparse-blocked) grid through an nm_mpm handle."""
 
@@ -186,6 +196,25 @@ class MPMModel(Model):
         self.requires_grad = requires_grad
         self.bc = bc
         self._handle = None
+        # grid cache of the per-operator differentiable path: "auto" sizes the per-substep record from the first substep
+        # (x1.5 + 64 blocks, one host sync); an int fixes the capacity; 0 / None = recompute like the reference
+        self.grid_cache = "auto"
+        self._cache_blocks = None
+
+    def new_tape(self):
+        """A fresh GridTape for one differentiable substep (None while the capacity is not known yet / cache disabled)."""
+        if self.grid_cache in (0, None, False):
+            return None
+        if self.grid_cache != "auto":
+            return GridTape(int(self.grid_cache), self.device)
+        if self._cache_blocks is None:
+            return None
+        return GridTape(self._cache_blocks, self.device)
+
+    def _size_cache(self) -> None:
+        if self.grid_cache == "auto" and self._cache_blocks is None:
+            blocks, _ = self.grid_stats()
+            self._cache_blocks = int(1.5 * blocks) + 64
 
     # -- handle management
     def handle(self):
@@ -215,14 +244,18 @@ class MPMModel(Model):
 
     # -- operators
     def forward(self, statics: MPMStatics, state_curr: MPMState, state_next: MPMState, tape=None) -> None:
-        """mpm.py:279-297.  `tape` is accepted for signature parity; nothing is recorded (the backward
-        pass recomputes the grid exactly like mpm.py:312-315)."""
+        """mpm.py:279-297.  `tape`: None (nothing is recorded; the backward pass recomputes the grid exactly like
+        mpm.py:312-315) or a GridTape from new_tape() (the substep's touched grid blocks are saved into it)."""
         n = state_curr.particle.x.shape[0]
         st = statics.c_struct()
         cur = state_curr.particle.c_struct()
         nxt = state_next.particle.c_struct()
-        L.check(L.lib().nm_mpm_forward(self.handle(), n, C.byref(st), C.byref(cur), C.byref(nxt), self._stream()),
-                "nm_mpm_forward")
+        if isinstance(tape, GridTape):
+            L.check(L.lib().nm_mpm_forward_ex(self.handle(), n, C.byref(st), C.byref(cur), C.byref(nxt), L.ptr(tape.buf), tape.cap,
+                                              self._stream()), "nm_mpm_forward_ex")
+        else:
+            L.check(L.lib().nm_mpm_forward(self.handle(), n, C.byref(st), C.byref(cur), C.byref(nxt), self._stream()),
+                    "nm_mpm_forward")
 
     def backward(self, statics: MPMStatics, state_curr: MPMState, state_next: MPMState, tape=None) -> None:
         """mpm.py:299-319.  Reads state_next.particle.*_grad, writes state_curr.particle.*_grad."""
@@ -241,8 +274,12 @@ class MPMModel(Model):
         cur, nxt = pc.c_struct(), pn.c_struct()
         gn = L.nm_particles(L.ptr(pn.x_grad), L.ptr(pn.v_grad), L.ptr(pn.C_grad), L.ptr(pn.F_grad), None)
         gc = pc.c_struct_grad()
-        L.check(L.lib().nm_mpm_backward(self.handle(), n, C.byref(st), C.byref(cur), C.byref(nxt), C.byref(gn),
-                                        C.byref(gc), self._stream()), "nm_mpm_backward")
+        if isinstance(tape, GridTape):
+            L.check(L.lib().nm_mpm_backward_ex(self.handle(), n, C.byref(st), C.byref(cur), C.byref(nxt), C.byref(gn), C.byref(gc),
+                                               L.ptr(tape.buf), tape.cap, self._stream()), "nm_mpm_backward_ex")
+        else:
+            L.check(L.lib().nm_mpm_backward(self.handle(), n, C.byref(st), C.byref(cur), C.byref(nxt), C.byref(gn),
+                                            C.byref(gc), self._stream()), "nm_mpm_backward")
 
     def forward_extra(self, statics, state, statics_extra, state_extra) -> None:
         """mpm.py:260-277."""

@@ -244,3 +244,25 @@ def test_error_paths():
     model_cpu = MPMModelBuilder().parse_cfg(cfg).finalize("cpu")
     with pytest.raises(NeumaHipError):
         model_cpu.forward(model_cpu.statics(4), model_cpu.state(4), model_cpu.state(4))
+
+
+def test_per_operator_grid_tape_matches_recompute():
+    """MPMSimFunction carries a grid cache record in the `tape` slot: gradients equal the reference-style recompute, also
+    when the record overflows (capacity 1 block -> transparent fallback)."""
+    from neuma_amd.sim import MPMCacheDiffSim
+    const, vol, rho, clip, en, x, v, C, F, S = mpm_case(N=4096, G=32)
+    res = {}
+    for tag, cache in (("recompute", 0), ("auto", "auto"), ("overflow", 1)):
+        model = build_model(const, dev())
+        model.grid_cache = cache
+        st = build_statics(model, vol, rho, clip, en, dev())
+        sim = MPMCacheDiffSim(model, 3, reorder=False)
+        ins = [t.float().to(dev()).requires_grad_(True) for t in (x, v, C, F, S)]
+        a = sim(st, 0, *ins)
+        b = sim(st, 1, a[0], a[1], a[2], a[3], ins[4])          # second substep: the auto capacity is known by now
+        if cache == "auto":
+            assert model._cache_blocks == int(1.5 * model.grid_stats()[0]) + 64 or model._cache_blocks > 64
+        res[tag] = torch.autograd.grad(b[0].sum() + (b[3] * b[3]).sum() + b[1].sum(), ins)
+    for tag in ("auto", "overflow"):
+        for g, r in zip(res[tag], res["recompute"]):
+            assert rel_max(g, r) < 2e-4, tag
