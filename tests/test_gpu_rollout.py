@@ -229,3 +229,27 @@ def test_rollout_reorders_shuffled_particles_transparently():
         assert rel_max(a, b[shuf]) < 1e-3
     for a, b in zip(g_sh[4:], g_ref[4:]):
         assert rel_max(a, b) < 1e-3
+
+
+def test_long_rollout_keeps_the_active_block_list_consistent():
+    """600 substeps: the ball falls, hits the floor and deforms, so grid blocks enter and leave the active list all the time
+    (k_clear carry-over, three-list rotation, new-block stamping).  At every checkpoint the engine's bookkeeping must agree
+    with a dense export of the grid: every node with mass lies in a listed block, the counts match, nothing is NaN, and the
+    total grid mass equals the particle mass."""
+    rt = _runtime("tiny", fused=True, S=50)
+    G = int(rt.model.constant.num_grids)
+    x, v, C, F = rt.x0, rt.v0, rt.C0, rt.F0
+    pm = float(rt.statics.vol[0] * rt.statics.rho[0]) * rt.N
+    hit_floor = False
+    with torch.no_grad():
+        for chunk in range(12):
+            x, v, C, F = rt.rollout(x, v, C, F)
+            assert all(torch.isfinite(t).all() for t in (x, v, C, F))
+            mv, m, vg = rt.model.grid_export()
+            blocks, nodes = rt.model.grid_stats()
+            assert nodes == int((m > 0).sum())
+            bm = m.reshape(G // 4, 4, G // 4, 4, G // 4, 4).amax(dim=(1, 3, 5)) > 0
+            assert int(bm.sum()) <= blocks <= 3 * int(bm.sum()) + 64      # listed blocks cover the massive ones, no runaway growth
+            assert abs(float(m.double().sum()) - pm) < 1e-4 * pm
+            hit_floor = hit_floor or float(x[:, 1].min()) < 2.5 / G
+    assert hit_floor, "the scenario is meant to include wall contact"
