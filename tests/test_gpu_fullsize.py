@@ -49,15 +49,16 @@ def test_step_is_invariant_under_particle_order_at_100k(rt):
     C = (0.5 * torch.randn(N, 3, 3, generator=g)).to(dev())
     F = (torch.eye(3) + 0.05 * torch.randn(N, 3, 3, generator=g)).to(dev())
     S = (100.0 * torch.randn(N, 3, 3, generator=g)).to(dev())
-    sim = MPMDiffSim(rt.model)
     with torch.no_grad():
-        a = sim(rt.statics, rt.x0, v, C, F, S)
+        a = MPMDiffSim(rt.model, reorder=False)(rt.statics, rt.x0, v, C, F, S)
         a = [t.clone() for t in a]
         perm = torch.randperm(N, generator=g).to(dev())
-        b = sim(rt.statics, rt.x0[perm].contiguous(), v[perm].contiguous(), C[perm].contiguous(), F[perm].contiguous(),
-                S[perm].contiguous())
-    for x, y, tol in zip(a, b, [5e-7, 2e-5, 5e-5, 5e-6]):
-        assert abs_max(x[perm], y) < tol * max(1.0, float(x.abs().max()))
+        shuffled = [t[perm].contiguous() for t in (rt.x0, v, C, F, S)]
+        # once through the kernels' own fall-back paths (per-wave boxes, global atomics), once through the transparent re-ordering
+        for reorder in (False, "auto"):
+            b = MPMDiffSim(rt.model, reorder=reorder)(rt.statics, *shuffled)
+            for x, y, tol in zip(a, b, [5e-7, 2e-5, 5e-5, 5e-6]):
+                assert abs_max(x[perm], y) < tol * max(1.0, float(x.abs().max())), reorder
 
 
 def test_constitutive_nets_are_frame_indifferent_at_100k(rt):
@@ -125,3 +126,58 @@ def test_fused_rollout_matches_per_operator_path_at_100k(rt):
         rt.S = old
         rt.sim_fused.substeps = old
         rt.fused = True
+
+
+def test_million_particles_on_a_256_grid():
+    """BASELINE config 5 (1M particles in four balls, 256^3 grid): mass / momentum conservation of p2g, bookkeeping of the
+    active blocks, and a fused roll-out forward + backward that stays finite and agrees with the per-operator path."""
+    from neuma_amd import synth
+    from neuma_amd.harness import make_material_cfg
+    from neuma_amd.material import InvariantFullMetaElasticity, InvariantFullMetaPlasticity
+    from neuma_amd.rollout import MPMFusedDiffSim
+    from neuma_amd.sim import MPMDiffSim, MPMModelBuilder, MPMStatics
+    G = 256
+    x0 = synth.ball_particles(1_000_000, G, ((0.3, 0.5, 0.3), (0.7, 0.5, 0.3), (0.3, 0.5, 0.7), (0.7, 0.5, 0.7)), 0)
+    N = x0.shape[0]
+    d = dev()
+    model = MPMModelBuilder().parse_cfg(dict(gravity=[0.0, -9.8, 0.0], bc="noslip", num_grids=G, dt=5e-4, bound=1, eps=6e-7)).finalize(d)
+    st = MPMStatics()
+    st.init(N, d)
+    st.vol.fill_((0.5 / G) ** 3); st.rho.fill_(1000.0); st.clip_bound.fill_(0.1); st.enabled.fill_(1)
+    x = torch.tensor(x0, device=d)
+    g = torch.Generator().manual_seed(0)
+    v = torch.randn(N, 3, generator=g).to(d)
+    zero = torch.zeros(N, 3, 3, device=d)
+    F = torch.eye(3, device=d).repeat(N, 1, 1)
+    with torch.no_grad():
+        MPMDiffSim(model)(st, x, v, zero, F, zero)
+    mv, m, vg = model.grid_export()
+    pm = float(st.vol[0] * st.rho[0])
+    assert abs(float(m.double().sum()) - pm * N) < 1e-5 * pm * N
+    assert float((mv.double().sum((0, 1, 2)) - pm * v.double().sum(0)).abs().max()) < 1e-4 * pm * N
+    blocks, nodes = model.grid_stats()
+    assert nodes == int((m > 0).sum()) and 120_000 < nodes < 190_000           # SURVEY 8d: T = 148 813 for one ball of 1M
+    w = synth.load_base_weights("jelly")
+    E, P = InvariantFullMetaElasticity(make_material_cfg()).to(d), InvariantFullMetaPlasticity(make_material_cfg()).to(d)
+    for net, tag in ((E, "e"), (P, "p")):
+        net.layers[0].fc.weight.data.copy_(torch.tensor(w[tag][0]))
+        net.layers[1].fc.weight.data.copy_(torch.tensor(w[tag][1]))
+        net.final_layer.fc.weight.data.copy_(torch.tensor(w[tag][2]))
+        net.init_lora_layers(r=16, lora_alpha=16)
+        net.freeze_all_except_lora()
+    sim = MPMFusedDiffSim(model, E, P, 2)
+    v0 = torch.tensor([[0.0, -0.5, 0.0]], device=d).expand(N, 3).contiguous()
+    xin = x.clone().requires_grad_(True)
+    out = sim(st, xin, v0, zero, F)
+    out = sim(st, *out)                         # second call: grid cache in use
+    loss = out[0].sum() + (out[3] ** 2).sum()
+    grads = torch.autograd.grad(loss, [xin] + [p for p in list(E.parameters()) + list(P.parameters()) if p.requires_grad])
+    assert all(torch.isfinite(t).all() for t in out) and all(torch.isfinite(t).all() for t in grads)
+    with torch.no_grad():
+        sims = MPMDiffSim(model)
+        xs, vs, Cs, Fs = x, v0, zero, F
+        for _ in range(4):
+            stress = E(Fs)
+            xs, vs, Cs, Fs = sims(st, xs, vs, Cs, Fs, stress)
+            Fs = P(Fs)
+    assert abs_max(out[0], xs) < 5e-6 and abs_max(out[3], Fs) < 1e-5
