@@ -109,6 +109,7 @@ DEFAULT_CFG = dict(   # experiments/configs/synthetic/finetune-bb.yaml:61-107 (s
     plasticity_scheduler=dict(type="cos", max_steps=1000, learning_rate_alpha=0.025),
     warmup_step=0, decay_init=0.5, decay_final=1.0, decay_steps=80, lambda_max_decay=0.33,
     num_epochs=1000, num_frames=400, exclude_steps=(), num_lora_ckpts=3, resume=False,
+    overlap_render=False,   # not in the reference: render frame f on a second stream while frame f+1 simulates (see video_loss)
 )
 
 
@@ -131,31 +132,63 @@ def simulate_video(rt, num_frames: int, views: Optional[Sequence[int]] = None, d
     return out
 
 
-def video_loss(rt, gt_frames, c, decay_rate: float, views: Sequence[int], deform_cov: bool = True) -> torch.Tensor:
+def video_loss(rt, gt_frames, c, decay_rate: float, views: Sequence[int], deform_cov: bool = True,
+               overlap_render: bool = False) -> torch.Tensor:
     """One epoch's forward pass (finetune.py:334-392): roll the simulation out frame by frame from the initial state,
     bind + render the requested views of every frame, accumulate the decayed pixel loss.
     NB (reference semantics, tune/utils.py:353-373): the covariance push-forward by F is not differentiable, so the
     gradient of this loss deliberately omits the d(image)/dF path; deform_cov=False renders with the rest covariances
-    (what the reference does for its first frame), which makes the returned gradient the exact one."""
+    (what the reference does for its first frame), which makes the returned gradient the exact one.
+    overlap_render: binding + rendering + loss of frame f are enqueued on a second HIP stream, so they execute while the
+    (latency-bound) simulation of frame f+1 runs on the main stream; autograd replays the same stream assignment in the
+    backward pass.  Results are identical; only the schedule changes."""
     nframes = int(c["num_frames"])
     x, v, C, F = rt.x0, rt.v0, rt.C0, rt.F0
     de_prev = ((x - rt.center) / rt.size).clone().detach()
     g_prev = rt.gaussians.get_xyz.clone().detach()
-    loss_rgb = torch.zeros((), device=rt.device)
+    main = torch.cuda.current_stream(rt.device) if overlap_render else None
+    side = None
+    if overlap_render:
+        side = getattr(rt, "_render_stream", None)
+        if side is None:
+            side = rt._render_stream = torch.cuda.Stream(device=rt.device)
+    terms = []
     for cur_step in range(1, nframes + 1):
         x, v, C, F = rt.rollout(x, v, C, F, step0=(cur_step - 1) * rt.S)      # `substeps` substeps (362-364)
         if cur_step in c["exclude_steps"]:
             continue                                                          # finetune.py:371-372
-        de_x = (x - rt.center) / rt.size
-        means3D = compute_bindings_xyz(de_x, de_prev, g_prev, rt.bindings)
-        dg = compute_bindings_F(F, rt.bindings) if deform_cov else None
         w = decay_rate ** ((cur_step - 1) // c["decay_steps"])
-        for i, vi in enumerate(views):
-            render = rt.render_view(means3D, dg, vi)
-            loss_rgb = loss_rgb + w * rt.pixel_loss(render, gt_frames[cur_step - 1][i])
-        de_prev = de_x.clone().detach()
-        g_prev = means3D.clone().detach()
+        if overlap_render:
+            side.wait_stream(main)
+            for t in (x, F):
+                t.record_stream(side)                                         # read on `side` after `main` moves on
+        with torch.cuda.stream(side) if overlap_render else _nullcontext():
+            de_x = (x - rt.center) / rt.size
+            means3D = compute_bindings_xyz(de_x, de_prev, g_prev, rt.bindings)
+            dg = compute_bindings_F(F, rt.bindings) if deform_cov else None
+            lf = torch.zeros((), device=rt.device)
+            for i, vi in enumerate(views):
+                render = rt.render_view(means3D, dg, vi)
+                lf = lf + w * rt.pixel_loss(render, gt_frames[cur_step - 1][i])
+            terms.append(lf)
+            de_prev = de_x.clone().detach()
+            g_prev = means3D.clone().detach()
+    if overlap_render:
+        main.wait_stream(side)
+        for t in terms:
+            t.record_stream(main)
+    loss_rgb = torch.zeros((), device=rt.device)
+    for t in terms:
+        loss_rgb = loss_rgb + t
     return loss_rgb
+
+
+class _nullcontext(object):
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
 
 
 def finetune_constitutive(rt, gt_frames: List[List[torch.Tensor]], cfg: Optional[Dict] = None, tune_root: Optional[Path] = None,
@@ -187,7 +220,7 @@ def finetune_constitutive(rt, gt_frames: List[List[torch.Tensor]], cfg: Optional
                 for g in opt.param_groups:
                     g["lr"] = lr * float(epoch) / c["warmup_step"]
         decay_rate = rollout_decay_rate(c, epoch)
-        loss_rgb = video_loss(rt, gt_frames, c, decay_rate, views)
+        loss_rgb = video_loss(rt, gt_frames, c, decay_rate, views, overlap_render=bool(c.get("overlap_render", False)))
         e_opt.zero_grad(set_to_none=True); p_opt.zero_grad(set_to_none=True)
         loss_rgb.backward()
         e_gn = clip_grad_norm_(E.parameters(), max_norm=c["elasticity_grad_max_norm"], error_if_nonfinite=True)

@@ -126,3 +126,34 @@ def test_stage_a_recovers_the_initial_velocity(tmp_path):
     rt2 = SceneRuntime(scene, dev(), fused=True)
     v2, l2 = optimize_init_velocity(rt2, gt, dict(num_epochs=40), tmp_path)
     assert l2 == [] and float((rt2.v0 - rt.v0).abs().max()) == 0.0
+
+
+def test_render_on_a_second_stream_changes_the_schedule_not_the_result():
+    """video_loss(overlap_render=True): binding + render + loss of frame f run on a second HIP stream while frame f+1
+    simulates; loss and gradients equal the single-stream epoch."""
+    from neuma_amd import synth
+    from neuma_amd.harness import SceneRuntime
+    from neuma_amd.train import DEFAULT_CFG, simulate_video, video_loss
+    torch.manual_seed(0)
+    scene = synth.make_scene("tiny", override=dict(S=6, V=2))
+    true = SceneRuntime(scene, dev(), fused=True)
+    true.F0 = torch.diag(torch.tensor([1.25, 0.8, 1.0])).to(dev()).repeat(true.N, 1, 1).contiguous()
+    for net in (true.elasticity, true.plasticity):
+        for lin in (net.layers[0].fc, net.layers[1].fc, net.final_layer.fc):
+            lin.lora_B.data.mul_(30.0)
+    gt = simulate_video(true, 4)
+    torch.manual_seed(0)
+    rt = SceneRuntime(scene, dev(), fused=True)
+    rt.F0 = true.F0.clone()
+    c = dict(DEFAULT_CFG, num_frames=4, decay_steps=2, exclude_steps=(3,))
+    res = {}
+    for overlap in (False, True):
+        for p in rt.parameters():
+            p.grad = None
+        L = video_loss(rt, gt, c, 0.7, [0, 1], overlap_render=overlap)
+        L.backward()
+        torch.cuda.synchronize()
+        res[overlap] = (float(L), torch.cat([p.grad.reshape(-1) for p in rt.parameters()]).clone())
+    assert res[False][0] > 1e-7
+    assert abs(res[True][0] - res[False][0]) < 1e-4 * res[False][0]
+    assert float((res[True][1] - res[False][1]).norm()) < 1e-3 * float(res[False][1].norm())
