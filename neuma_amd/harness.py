@@ -86,8 +86,8 @@ class SceneRuntime(object):
                  rank: int = 0, world: int = 1, group=None):
         self.scene, self.device, self.fused = scene, torch.device(device), fused
         self.rank, self.world, self.group = rank, world, group
-        # single GPU: the V views of a frame alternate between HIP streams so that one view's binning (small sort / scan
-        # kernels) runs under another view's compositing kernel - same results, ~9 % shorter frame
+        # the render jobs of a frame (views, or view stripes on several GPUs) go round-robin over HIP streams so that one job's
+        # binning (small sort / scan kernels) runs under another job's compositing kernel - same results, ~9 % shorter frame
         self.overlap_views = os.environ.get("NEUMA_OVERLAP_VIEWS", "1") != "0"
         self.num_view_streams = int(os.environ.get("NEUMA_VIEW_STREAMS", "0")) or None      # default: one stream per view
         cfg = scene.cfg
@@ -193,37 +193,42 @@ class SceneRuntime(object):
         means3D = merge_grad_across_ranks(means3D, self.group)
         loss = torch.zeros((), device=self.device)
         H = self.scene.cfg["H"]
-        if self.world == 1 and getattr(self, "overlap_views", False) and self.V > 1:
-            # views alternate between two streams: the binning of view v+1 (sorts, scans: small latency-bound kernels)
-            # executes under the compositing kernel of view v
+        # render jobs of this rank: whole views on one GPU, (view, tile-row stripe) pieces when the frame is split
+        if self.world == 1:
+            jobs = [(vi, None) for vi in range(self.V)]                         # :378-389
+        else:
+            jobs = [(vi, (r0, r1)) for (vi, r0, r1) in stripe_plan(self.V, self.tile_rows, self.world, self.rank)]
+
+        def job_loss(vi, rows):
+            if rows is None:
+                return weight * self.pixel_loss(self.render_view(means3D, deform_grad, vi), self.gt[vi])
+            render = self.render_view(means3D, deform_grad, vi, tile_rows=rows)
+            y0, y1 = rows[0] * 16, min(H, rows[1] * 16)
+            # partial sums of the mean over the full image: the ranks' losses add up to the 1-GPU loss
+            return weight * pixel_loss_rows(render, self.gt[vi], 0 if self.pixel_loss is l1_loss else 1, y0, y1)
+
+        if getattr(self, "overlap_views", False) and len(jobs) > 1:
+            # the jobs go round-robin over HIP streams: one job's binning (sorts, scans: small latency-bound kernels)
+            # executes under another job's compositing kernel; autograd replays the assignment in the backward pass
             main = torch.cuda.current_stream(self.device)
             if not hasattr(self, "_view_streams"):
                 self._view_streams = [torch.cuda.Stream(device=self.device) for _ in range(int(self.num_view_streams or self.V))]
             terms = []
-            for vi in range(self.V):
-                s = self._view_streams[vi % len(self._view_streams)]
+            for k, (vi, rows) in enumerate(jobs):
+                s = self._view_streams[k % len(self._view_streams)]
                 s.wait_stream(main)
                 for t in (means3D, deform_grad):
                     t.record_stream(s)
                 with torch.cuda.stream(s):
-                    render = self.render_view(means3D, deform_grad, vi)
-                    terms.append(weight * self.pixel_loss(render, self.gt[vi]))
+                    terms.append(job_loss(vi, rows))
             for s in self._view_streams:
                 main.wait_stream(s)
             for t in terms:
                 t.record_stream(main)
                 loss = loss + t
-        elif self.world == 1:
-            for vi in range(self.V):                                            # :378-389
-                render = self.render_view(means3D, deform_grad, vi)
-                loss = loss + weight * self.pixel_loss(render, self.gt[vi])
         else:
-            for (vi, r0, r1) in stripe_plan(self.V, self.tile_rows, self.world, self.rank):
-                render = self.render_view(means3D, deform_grad, vi, tile_rows=(r0, r1))
-                y0, y1 = r0 * 16, min(H, r1 * 16)
-                # partial sums of the mean over the full image: the ranks' losses add up to the 1-GPU loss
-                part = pixel_loss_rows(render, self.gt[vi], 0 if self.pixel_loss is l1_loss else 1, y0, y1)
-                loss = loss + weight * part
+            for vi, rows in jobs:
+                loss = loss + job_loss(vi, rows)
         if backward:
             loss.backward()
         return FrameResult(loss.detach(), x.detach(), F.detach())
