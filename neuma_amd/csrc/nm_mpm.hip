@@ -29,6 +29,13 @@ struct MpmK {
   int maxpass;  // NM_DBG experiment switches (0 in production)
 };
 
+// experiment switches (tools/exp_*.py) exist only in -DNM_PHASES builds; in the shipped library they fold to constants
+#ifdef NM_PHASES
+#define NM_DBG_BIT(K, bit) (((K).dbg & (bit)) != 0)
+#else
+#define NM_DBG_BIT(K, bit) false
+#endif
+
 struct nm_mpm {
   nm_mpm_cfg cfg;
   MpmK k;
@@ -336,8 +343,8 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
   bool cmp = false;          // compressed tile coordinates in use
   int tb[3] = {base[0] - lo[0], base[1] - lo[1], base[2] - lo[2]};   // tile coordinates of this particle's stencil origin
   bool pending = en;
-  if (K.dbg & 4) return;
-  if (!single && !(K.dbg & 32)) {
+  if (NM_DBG_BIT(K, 4)) return;
+  if (!single && !NM_DBG_BIT(K, 32)) {
     // ---- axis compression (scratch: the contribution buffer, not in use yet)
     const int Gp = K.Gp, tot = 3 * Gp;
     short* occ = reinterpret_cast<short*>(L.C);
@@ -446,7 +453,7 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
     const bool owner = tid < nruns;                   // thread r owns non-empty cell r
     const int mycell = owner ? (int)L.run_cell[tid] : 0;
     const int s0 = owner ? L.cnt[mycell] : 0;
-    if (flags && cmp && owner && !(K.dbg & 2)) {   // compressed tile: thread r stamps the blocks of cell r, early (see above)
+    if (flags && cmp && owner && !NM_DBG_BIT(K, 2)) {   // compressed tile: thread r stamps the blocks of cell r, early (see above)
       const int a_ = mycell / nyz, r_ = mycell - a_ * nyz;
       const int b_ = r_ / g.n[2], c_ = r_ - b_ * g.n[2];
       const int o0 = (int)L.ainv[0][a_], o1 = (int)L.ainv[1][b_], o2 = (int)L.ainv[2][c_];
@@ -499,7 +506,7 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
     // bounding box hold a non-zero node and one thread per such block stamps it - an untouched block stamped here would
     // hold no mass, drop out at the next k_clear and take the atomic path again every substep.  Compressed tile: thread r
     // stamps the blocks of cell r.  Then the flush: one global atomic set per touched node.
-    const bool mark = flags != nullptr && !(K.dbg & 2);
+    const bool mark = flags != nullptr && !NM_DBG_BIT(K, 2);
     if (mark) {
       if (!cmp) {
         const int b0 = g.o[0] >> 2, b1 = g.o[1] >> 2, b2 = g.o[2] >> 2;
@@ -528,7 +535,7 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
     // the atomics go last: nothing waits for them, they drain while other workgroups compute
     for (int nidx = tid; nidx < g.vol; nidx += NM_SC_T) {
       const float4 t = L.tile[nidx];
-      if (!(K.dbg & 1) && (t.x != 0.f || t.y != 0.f || t.z != 0.f || t.w != 0.f)) {
+      if (!NM_DBG_BIT(K, 1) && (t.x != 0.f || t.y != 0.f || t.z != 0.f || t.w != 0.f)) {
         int a_ = nidx / nyz, r = nidx - a_ * nyz;
         int b_ = r / g.n[2], c_ = r - b_ * g.n[2];
         const int x_ = cmp ? (int)L.ainv[0][a_] : g.o[0] + a_, y_ = cmp ? (int)L.ainv[1][b_] : g.o[1] + b_,
@@ -1052,8 +1059,13 @@ extern "C" int nm_mpm_create(const nm_mpm_cfg* cfg, nm_mpm** out) {
   for (int a = 0; a < 3; ++a) K.gdt[a] = cfg->gravity[a] * cfg->dt;
   K.bound = cfg->bound;
   K.bc = cfg->bc;
+#ifdef NM_PHASES
   K.dbg = getenv("NM_DBG") ? atoi(getenv("NM_DBG")) : 0;
   K.maxpass = getenv("NM_MAXPASS") ? atoi(getenv("NM_MAXPASS")) : NM_WT_MAXPASS;
+#else
+  K.dbg = 0;
+  K.maxpass = NM_WT_MAXPASS;
+#endif
   h->nblocks = K.nb * K.nb * K.nb;
   size_t nodes = (size_t)h->nblocks * 64;
   h->gm = h->gv = h->gg = nullptr;
