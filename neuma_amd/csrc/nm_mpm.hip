@@ -477,10 +477,19 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
         const int r = u / 9, q = u - 9 * r;
         const int cell = (int)L.run_cell[r];
         const int a0 = L.cnt[cell], a1 = L.cnt[cell + 1];
+        // members are read eight at a time with clamped addresses and 0/1 weights: eight independent LDS reads in flight
+        // instead of a chain of dependent ones (the loop is LDS-latency bound, ~8 members per cell)
         float4 acc = L.C[a0 * 9 + q];
-        for (int s_ = a0 + 1; s_ < a1; ++s_) {
-          const float4 t4 = L.C[s_ * 9 + q];
-          acc.x += t4.x; acc.y += t4.y; acc.z += t4.z; acc.w += t4.w;
+        for (int s_ = a0 + 1; s_ < a1; s_ += 8) {
+          float4 t4[8];
+#pragma unroll
+          for (int m = 0; m < 8; ++m) t4[m] = L.C[min(s_ + m, a1 - 1) * 9 + q];
+#pragma unroll
+          for (int m = 0; m < 8; ++m) {
+            const float wgt = s_ + m < a1 ? 1.f : 0.f;
+            acc.x = fmaf(wgt, t4[m].x, acc.x); acc.y = fmaf(wgt, t4[m].y, acc.y);
+            acc.z = fmaf(wgt, t4[m].z, acc.z); acc.w = fmaf(wgt, t4[m].w, acc.w);
+          }
         }
         L.C[a0 * 9 + q] = acc;
       }
@@ -583,6 +592,9 @@ __global__ void __launch_bounds__(256) k_clear(float4* __restrict__ gm, float4* 
     const int nkeep = __popcll(keep);
     if (nkeep == 0) continue;
     int pos = 0;
+#ifdef NM_PHASES
+    if (lane == 0) atomicAdd(&g_nm_markslow[3], nkeep);
+#endif
     if (lane == 0) pos = atomicAdd(count_now, nkeep);
     pos = __shfl(pos, 0, 64);
     it = 0;

@@ -14,13 +14,14 @@ from neuma_amd.harness import SceneRuntime
 lib = _lib.lib()
 dev = torch.device("cuda", 0)
 rt = SceneRuntime(synth.make_scene(sys.argv[1] if len(sys.argv) > 1 else "metric", override=dict(K=1000)), dev)
-with torch.no_grad():
-    for _ in range(2):
-        rt.rollout(rt.x0, rt.v0, rt.C0, rt.F0)      # last launch using wg_scatter = k_p2g of substep 20
-torch.cuda.synchronize()
 ms = (C.c_int * 4)()
-lib.nm_debug_markslow(ms)
-print("mark_block calls / flag misses / new blocks over the whole run (2 x 20 substeps):", list(ms)[:3], "active blocks", rt.model.grid_stats())
+with torch.no_grad():
+    for it in range(3):
+        rt.rollout(rt.x0, rt.v0, rt.C0, rt.F0)      # last launch using wg_scatter = k_p2g of substep 20
+        torch.cuda.synchronize()
+        lib.nm_debug_markslow(ms)
+        print("after rollout", it, "cumulative mark_block calls / flag misses / new blocks / carried:", list(ms)[:4])
+print("active blocks", rt.model.grid_stats())
 fn = lib.nm_debug_scatter; fn.argtypes = [C.c_void_p, C.c_int]
 buf = np.zeros(8 * 4096, dtype=np.int64)
 print("rc", fn(buf.ctypes.data, 8 * 4096))
