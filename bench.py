@@ -67,6 +67,18 @@ def main():
     ap.add_argument("--per-op", action="store_true", help="use the per-operator drop-in path instead of the fused roll-out")
     args = ap.parse_args()
 
+    # the shared library is a build artefact: build it if this checkout does not have it (rank 0 builds, the others wait)
+    libpath = ROOT / "neuma_amd" / "lib" / "libneuma_hip.so"
+    if not libpath.exists() and not os.environ.get("NEUMA_HIP_LIB"):
+        if int(os.environ.get("RANK", "0")) == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        else:
+            for _ in range(600):
+                if libpath.exists():
+                    break
+                time.sleep(1.0)
+
     import torch
     import torch.distributed as dist
     from neuma_amd import synth, _lib
