@@ -57,6 +57,31 @@ def algorithmic_bytes(kernel: str, rt, D: float) -> float:
     return table.get(base, 0.0)
 
 
+def kernel_rooflines(full, rt, D):
+    """Per-kernel roofline figures of the profiled frame (HIP-event durations of every launch; the views of the frame run
+    on concurrent streams, so the render-side durations include some overlap): algorithmic bytes or flops per launch over
+    the mean launch duration, against 8 TB/s HBM or the 157.3 TFLOP/s f32-MFMA peak."""
+    by = {}
+    for name, (calls, ms) in full.items():
+        b = name.split("<")[0]
+        c0, m0 = by.get(b, (0, 0.0))
+        by[b] = (c0 + calls, m0 + ms)
+    out = []
+    for b, (calls, ms) in sorted(by.items(), key=lambda kv: -kv[1][1])[:12]:
+        avg_s = ms / calls / 1e3
+        if b in ("k_material_fwd", "k_material_bwd"):
+            fl = (11008.0 if b == "k_material_fwd" else 3 * 11008.0) * rt.N
+            out.append({"kernel": b, "bound": "mfma", "achieved": round(fl / avg_s / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s",
+                        "frac": round(fl / avg_s / 1e12 / 157.3, 4), "avg_us": round(avg_s * 1e6, 1), "launches": calls})
+        else:
+            ab = algorithmic_bytes(b, rt, D)
+            if ab <= 0:
+                continue
+            out.append({"kernel": b, "bound": "hbm", "achieved": round(ab / avg_s / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(ab / avg_s / 1e9 / 8000.0, 4), "avg_us": round(avg_s * 1e6, 1), "launches": calls})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -284,6 +309,7 @@ def main():
             "cpu_baseline": cpu,
             "kernel_breakdown_ms_per_frame": {k: round(v[1], 3) for k, v in sorted(full.items(), key=lambda kv: -kv[1][1])[:12]},
             "kernel_time_fraction_of_frame": round(total_ms / (1e3 * elapsed / args.steps), 3),
+            "kernel_rooflines": kernel_rooflines(full, rt, D),
             "frame_ms_gpu": {"median": round(per_frame[len(per_frame) // 2], 3), "p10": round(per_frame[len(per_frame) // 10], 3),
                              "p90": round(per_frame[(9 * len(per_frame)) // 10], 3)},
             "rates": rates,
