@@ -7,7 +7,7 @@ from neuma_amd import synth
 from neuma_amd.harness import SceneRuntime
 from neuma_amd.tune import compute_bindings_xyz, compute_bindings_F
 dev = torch.device("cuda", 0)
-rt = SceneRuntime(synth.make_scene("metric"), dev)
+rt = SceneRuntime(synth.make_scene(sys.argv[1] if len(sys.argv) > 1 else "metric"), dev)
 rt.make_ground_truth()
 import os
 if os.environ.get("NOCACHE"):
