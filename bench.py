@@ -214,6 +214,11 @@ def main():
     except Exception as e:  # accounting only
         print(f"[bench] pair count unavailable: {e}", file=sys.stderr)
 
+    pmc = {}
+    try:        # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json, tools/make_profile_md.py)
+        pmc = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text()).get("kernels", {})
+    except Exception:
+        pass
     roof = None
     if dom:
         calls = sum(v[0] for v in dom.values())
@@ -292,6 +297,9 @@ def main():
         except Exception as e:
             print(f"[bench] cpu baseline unavailable: {e}", file=sys.stderr)
 
+    if roof is not None and roof["kernel"].split("<")[0] in pmc and args.workload == "metric" and world == 1:
+        roof["traffic"] = pmc[roof["kernel"].split("<")[0]]["hbm_bytes_per_launch"]
+        roof["traffic_source"] = "profiles/pmc_traffic.json: rocprofv3 PMC passes of this workload (2 x FETCH_SIZE + WRITE_SIZE per launch)"
     if rank == 0:
         cfg = scene.cfg
         total_ms = sum(v[1] for v in full.values()) or 1.0
