@@ -10,8 +10,9 @@ pixel loss, then the full backward sweep (the settings NeuMA ships for its 1080p
 experiments/configs/realworld/finetune-burger.yaml:109-113).  Synthetic data (neuma_amd/synth.py), real shipped
 constitutive weights + LoRA r=16.  Inputs are resident in HBM before the timed region.
 
-Multi-GPU: strong scaling of the same frame — simulation replicated, the V x tile-row render stripes split
-across ranks, one RCCL all-reduce of dL/dmeans3D per frame (neuma_amd/harness.py).
+Multi-GPU: strong scaling of the same frame — the V x tile-row render stripes split across ranks, one RCCL all-reduce
+of dL/dmeans3D per frame; the simulation replicated, or (--shard-sim, default from 100k particles per rank)
+particle-sharded with two block all-reduces per substep (neuma_amd/harness.py, neuma_amd/sim/shard.py).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -39,7 +40,7 @@ def prof_table(lib):
 def algorithmic_bytes(kernel: str, rt, D: float) -> float:
     """Compulsory HBM bytes of ONE launch of `kernel` (formulas stated in DESIGN.md §Kernels)."""
     cfg = rt.scene.cfg
-    N, K, W, H = rt.N, rt.K, cfg["W"], cfg["H"]
+    N, K, W, H = rt.n_local, rt.K, cfg["W"], cfg["H"]   # simulation kernels see this rank's particles
     T = rt.touched_nodes
     base = kernel.split("<")[0]
     table = {
@@ -70,7 +71,7 @@ def kernel_rooflines(full, rt, D):
     for b, (calls, ms) in sorted(by.items(), key=lambda kv: -kv[1][1])[:12]:
         avg_s = ms / calls / 1e3
         if b in ("k_material_fwd", "k_material_bwd"):
-            fl = (11008.0 if b == "k_material_fwd" else 3 * 11008.0) * rt.N
+            fl = (11008.0 if b == "k_material_fwd" else 3 * 11008.0) * rt.n_local
             out.append({"kernel": b, "bound": "mfma", "achieved": round(fl / avg_s / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s",
                         "frac": round(fl / avg_s / 1e12 / 157.3, 4), "avg_us": round(avg_s * 1e6, 1), "launches": calls})
         else:
@@ -90,6 +91,10 @@ def main():
     ap.add_argument("--workload", default="metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-op", action="store_true", help="use the per-operator drop-in path instead of the fused roll-out")
+    ap.add_argument("--shard-sim", choices=("auto", "on", "off"), default="auto",
+                    help="N > 1: particle-sharded simulation (neuma_amd/sim/shard.py) instead of a replicated one; "
+                         "auto = on from 100k particles per rank (the 1M-particle stress workload), where a substep "
+                         "outlasts its two block all-reduces")
     args = ap.parse_args()
 
     # the shared library is a build artefact: build it if this checkout does not have it (rank 0 builds, the others wait)
@@ -128,11 +133,14 @@ def main():
     lib = _lib.lib()
 
     scene = synth.make_scene(args.workload)
-    rt = SceneRuntime(scene, dev, fused=not args.per_op, rank=rank, world=world)
+    shard_sim = world > 1 and (args.shard_sim == "on" or
+                               (args.shard_sim == "auto" and scene.x0.shape[0] // world >= 100_000))
+    rt = SceneRuntime(scene, dev, fused=not args.per_op, rank=rank, world=world, shard_sim=shard_sim,
+                      group=dist.group.WORLD if world > 1 else None)
     rt.make_ground_truth()
     # touched grid nodes of the initial state (roofline accounting) and (Gaussian, tile) pairs per view
     with torch.no_grad():
-        rt.rollout(rt.x0, rt.v0, rt.C0, rt.F0)
+        rt.rollout(rt.x0[rt.rows], rt.v0[rt.rows], rt.C0[rt.rows], rt.F0[rt.rows])
         _, rt.touched_nodes = rt.model.grid_stats()
 
     def sync():
@@ -229,7 +237,7 @@ def main():
         if base in ("k_material_fwd", "k_material_bwd"):
             # MFMA-bound: 2*(13*64 + 64*64 + 64*9) = 11 008 flop per particle per net forward; the backward recomputes
             # the forward and adds data-gradient and weight-gradient GEMMs of the same size (3x)
-            flops = (11008.0 if base == "k_material_fwd" else 3 * 11008.0) * rt.N
+            flops = (11008.0 if base == "k_material_fwd" else 3 * 11008.0) * rt.n_local
             achieved = flops / avg_s / 1e12 if avg_s > 0 else 0.0
             roof = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 3), "peak": 157.3, "unit": "TFLOP/s",
                     "frac": round(achieved / 157.3, 5), "traffic": None, "launches": calls, "avg_us": round(avg_s * 1e6, 2),
@@ -259,20 +267,22 @@ def main():
                 best.append(a.elapsed_time(b))
             return sorted(best)[len(best) // 2], out
 
+        rw = rt.rows       # all particles, or this rank's range when the simulation is sharded
+
         def sim_fwd():
             with torch.no_grad():
-                return rt.rollout(rt.x0, rt.v0, rt.C0, rt.F0)
+                return rt.rollout(rt.x0[rw], rt.v0[rw], rt.C0[rw], rt.F0[rw])
 
         def sim_fwdbwd():
             zero_grads()
-            o = rt.rollout(rt.x0, rt.v0, rt.C0, rt.F0)
+            o = rt.rollout(rt.x0[rw], rt.v0[rw], rt.C0[rw], rt.F0[rw])
             (o[0].sum() + o[3].sum()).backward()
 
         t_sf, o = gpu_ms(sim_fwd)
         t_sfb, _ = gpu_ms(sim_fwdbwd)
         with torch.no_grad():
-            m3 = compute_bindings_xyz(o[0], rt.x0, rt.gaussians.get_xyz, rt.bindings)
-            dgr = compute_bindings_F(o[3], rt.bindings)
+            m3 = compute_bindings_xyz(rt.all_rows(o[0]), rt.x0, rt.gaussians.get_xyz, rt.bindings)
+            dgr = compute_bindings_F(rt.all_rows(o[3]), rt.bindings)
 
         def ren_fwd():
             with torch.no_grad():
@@ -310,8 +320,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {cfg['N']} particles / {cfg['G']}^3 grid / {cfg['K']} Gaussians / "
                                    f"{cfg['W']}x{cfg['H']}", "substeps_per_frame": cfg["S"], "views_per_frame": cfg["V"],
-                       "sh_degree": cfg["sh"], "material": cfg["mat"] + "_0300 + LoRA r16", "path": "per-op" if args.per_op else "fused-rollout",
-                       "parallelism": "replicated sim + render stripes" if world > 1 else "single GPU",
+                       "sh_degree": cfg["sh"], "material": cfg["mat"] + "_0300 + LoRA r16", "path": "per-op" if (args.per_op or shard_sim) else "fused-rollout",
+                       "parallelism": (("particle-sharded sim" if shard_sim else "replicated sim") + " + render stripes") if world > 1 else "single GPU",
                        "touched_grid_nodes": int(rt.touched_nodes), "gaussian_tile_pairs_per_view": int(D)},
             "roofline": roof,
             "cpu_baseline": cpu,

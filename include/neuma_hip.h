@@ -118,6 +118,44 @@ int nm_mpm_forward_extra(nm_mpm* h, int32_t n, const nm_statics* st, const nm_pa
                          int32_t n_extra, const nm_statics* st_extra, nm_particles* extra,
                          void* stream);
 
+/* Particle-sharded substep (no reference counterpart - the reference is single-device).  Every rank
+ * owns a fixed subset of the particles and a full grid handle; a grid node receives contributions from several ranks
+ * only inside 4x4x4-node blocks that more than one rank touches.  The substep of mpm.py:279-297 / 299-319 is split
+ * at the two points where those blocks have to be summed over the ranks, and the caller runs the collectives
+ * (RCCL through torch.distributed) in between:
+ *
+ *   forward : nm_mpm_p2g                                     clear + scatter of the rank's particles (mpm.py:281-290)
+ *             nm_mpm_active_list -> all-gather               the rank's touched-block list: out[0] = count, out[1..cap] = ids
+ *             nm_mpm_shared_blocks                           blocks listed by >= 2 ranks, in an order all ranks agree on
+ *             nm_mpm_blocks_pack(0) -> all-reduce(sum) -> nm_mpm_blocks_unpack(0)     {mv, m} of those blocks
+ *             nm_mpm_forward_finish                          grid_op + g2p (mpm.py:291-297), writes the grid cache record
+ *   backward: nm_mpm_backward_begin                          restore the grid from the record + scatter of the g2p adjoint
+ *             nm_mpm_blocks_pack(1) -> all-reduce(sum) -> nm_mpm_blocks_unpack(1)     adjoint of the node velocities
+ *             nm_mpm_backward_finish                         grid_op adjoint + p2g adjoint
+ *
+ * `shared` (device, int32[2 + 2*cap_shared], caller-owned, kept per substep for the backward): [0] number of shared
+ * blocks, [1] status bits, [2..] block ids, [2+cap_shared..] 1 where this rank lists the block itself.  Status bits
+ * (also OR-ed into *status, a device int32 the caller polls): 1 = some rank's list exceeded `cap`, 2 = more than
+ * cap_shared shared blocks, 4 = the grid cache record overflowed (nm_mpm_forward_finish).  Any bit means the results
+ * of that substep are incomplete: the caller must raise, enlarge the capacity and redo the roll-out.
+ * pack writes cap_shared*64 float4 (zeros for blocks the rank does not list and for the unused tail), so the
+ * all-reduce has a fixed size and needs no host synchronisation. */
+int nm_mpm_p2g(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, void* stream);
+int nm_mpm_active_list(nm_mpm* h, int32_t* out, int32_t cap, void* stream);
+size_t nm_mpm_shared_workspace(int32_t world, int32_t cap);
+int nm_mpm_shared_blocks(nm_mpm* h, const int32_t* gathered, int32_t world, int32_t cap, int32_t* shared,
+                         int32_t cap_shared, int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
+int nm_mpm_blocks_pack(nm_mpm* h, int32_t which, const int32_t* shared, int32_t cap_shared, float* buf, void* stream);
+int nm_mpm_blocks_unpack(nm_mpm* h, int32_t which, const int32_t* shared, int32_t cap_shared, const float* buf,
+                         void* stream);
+int nm_mpm_forward_finish(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, nm_particles* next,
+                          void* gridrec, int32_t cap_blocks, int32_t* status, void* stream);
+int nm_mpm_backward_begin(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, const nm_particles* next,
+                          const nm_particles* gnext, nm_particles* gcur, const void* gridrec, int32_t cap_blocks,
+                          void* stream);
+int nm_mpm_backward_finish(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, nm_particles* gcur,
+                           void* stream);
+
 /* Introspection for tests / roofline accounting: number of touched 4x4x4-node blocks and nodes with
  * mass > 0 after the last p2g.  Synchronises the stream. */
 int nm_mpm_grid_stats(nm_mpm* h, int32_t* active_blocks, int32_t* nodes_with_mass, void* stream);

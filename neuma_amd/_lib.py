@@ -62,6 +62,17 @@ SIGNATURES = {
                                   C.POINTER(nm_particles), C.POINTER(nm_particles), _P]),
     "nm_mpm_forward_extra": (C.c_int, [_P, _I32, C.POINTER(nm_statics), C.POINTER(nm_particles), _I32,
                                        C.POINTER(nm_statics), C.POINTER(nm_particles), _P]),
+    "nm_mpm_p2g": (C.c_int, [_P, _I32, C.POINTER(nm_statics), C.POINTER(nm_particles), _P]),
+    "nm_mpm_active_list": (C.c_int, [_P, _P, _I32, _P]),
+    "nm_mpm_shared_workspace": (_SZ, [_I32, _I32]),
+    "nm_mpm_shared_blocks": (C.c_int, [_P, _P, _I32, _I32, _P, _I32, _P, _P, _SZ, _P]),
+    "nm_mpm_blocks_pack": (C.c_int, [_P, _I32, _P, _I32, _P, _P]),
+    "nm_mpm_blocks_unpack": (C.c_int, [_P, _I32, _P, _I32, _P, _P]),
+    "nm_mpm_forward_finish": (C.c_int, [_P, _I32, C.POINTER(nm_statics), C.POINTER(nm_particles), C.POINTER(nm_particles), _P, _I32,
+                                        _P, _P]),
+    "nm_mpm_backward_begin": (C.c_int, [_P, _I32, C.POINTER(nm_statics), C.POINTER(nm_particles), C.POINTER(nm_particles),
+                                        C.POINTER(nm_particles), C.POINTER(nm_particles), _P, _I32, _P]),
+    "nm_mpm_backward_finish": (C.c_int, [_P, _I32, C.POINTER(nm_statics), C.POINTER(nm_particles), C.POINTER(nm_particles), _P]),
     "nm_mpm_grid_stats": (C.c_int, [_P, C.POINTER(_I32), C.POINTER(_I32), _P]),
     "nm_mpm_grid_export": (C.c_int, [_P, _P, _P, _P, _P]),
     "nm_svd3_fwd": (C.c_int, [_I32, _P, _P, _P, _P, _P]),

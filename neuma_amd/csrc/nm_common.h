@@ -47,6 +47,16 @@ extern int g_nm_prof_on;
 
 // internal cross-file helpers
 float nm_mpm_get_dt(const nm_mpm* h);
+struct nm_mpm_view {   // what nm_shard.hip needs to see of a grid handle (valid until the next scatter)
+  float4* gm;          // {mv.xyz, m} per node, 64 nodes per block
+  float4* gg;          // adjoint scratch per node
+  int* flags;          // per block: == epoch when the block is in the current active list
+  int* list;           // current active-block list
+  int* count;          // its length (device)
+  int epoch, nblocks;
+};
+nm_mpm_view nm_mpm_get_view(nm_mpm* h);
+int nm_mpm_shared_counters(nm_mpm* h, int** cnt, int** pos);   // [nblocks] each: 0 / INT_MAX between exchanges
 int nm_mpm_backward_cached(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, const nm_particles* next,
                            const nm_particles* gnext, nm_particles* gcur, const void* gridrec, int32_t cap_blocks, bool verified,
                            void* stream);

@@ -48,6 +48,8 @@ struct nm_mpm {
   int* count;     // [0..2] block counters in the same rotation, [4..5] stats
   int cur;
   int epoch;
+  int* sh_cnt;    // sharded runs only (nm_shard.hip): per-block rank counter / first position, allocated on first use
+  int* sh_pos;
 };
 
 __device__ __forceinline__ int node_addr(int i, int j, int k, int nb) {
@@ -704,12 +706,15 @@ static inline GridRec gridrec_at(void* base, int cap) {
 // mpm.py:373-429 on the active blocks only; optionally saves the pre-grid-op node values into a cache record
 __global__ void __launch_bounds__(256) k_grid_op(MpmK K, const float4* __restrict__ gm, float4* __restrict__ gv,
                                                  const int* __restrict__ list, const int* __restrict__ count, GridRec rec,
-                                                 int cap, const int* __restrict__ skip_hdr) {
+                                                 int cap, const int* __restrict__ skip_hdr, int* __restrict__ status) {
   if (skip_hdr && *skip_hdr >= 0) return;
   const int cnt = *count;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool save = rec.hdr != nullptr && cnt <= cap;
-  if (rec.hdr && blockIdx.x == 0 && threadIdx.x == 0) rec.hdr[0] = save ? cnt : -1;
+  if (rec.hdr && blockIdx.x == 0 && threadIdx.x == 0) {
+    rec.hdr[0] = save ? cnt : -1;
+    if (!save && status) atomicOr(status, 4);   // sharded substeps cannot fall back to a recompute: tell the caller
+  }
   for (int li = blockIdx.x * 4 + wave; li < cnt; li += gridDim.x * 4) {
     int b = list[li];
     int i, j, k;
@@ -1095,6 +1100,7 @@ extern "C" int nm_mpm_create(const nm_mpm_cfg* cfg, nm_mpm** out) {
   NM_HIP_CHECK(hipDeviceSynchronize());
   h->cur = 0;
   h->epoch = 0;
+  h->sh_cnt = h->sh_pos = nullptr;
   *out = h;
   return NM_OK;
 }
@@ -1105,6 +1111,8 @@ extern "C" int nm_mpm_destroy(nm_mpm* h) {
   if (!h) return NM_OK;
   hipFree(h->gm); hipFree(h->gv); hipFree(h->gg); hipFree(h->flags);
   hipFree(h->list[0]); hipFree(h->list[1]); hipFree(h->list[2]); hipFree(h->count);
+  if (h->sh_cnt) hipFree(h->sh_cnt);
+  if (h->sh_pos) hipFree(h->sh_pos);
   delete h;
   return NM_OK;
 }
@@ -1139,7 +1147,8 @@ static int mpm_build_grid(nm_mpm* h, int n, const nm_statics* st, const nm_parti
                        cur->v, cur->C, cur->stress, h->gm, h->flags, h->list[now], h->count + now, h->epoch, skip);
     NM_LAUNCH_CHECK();
   }
-  NM_LAUNCH(k_grid_op, dim3(kSweepGrid), dim3(256), 0, s, h->k, h->gm, h->gv, h->list[now], h->count + now, srec, cap, skip);
+  NM_LAUNCH(k_grid_op, dim3(kSweepGrid), dim3(256), 0, s, h->k, h->gm, h->gv, h->list[now], h->count + now, srec, cap, skip,
+            (int*)nullptr);
   NM_LAUNCH_CHECK();
   h->cur = now;
   return NM_OK;
@@ -1236,6 +1245,117 @@ int nm_mpm_backward_cached(nm_mpm* h, int32_t n, const nm_statics* st, const nm_
   NM_LAUNCH(k_grid_op_bwd, dim3(kSweepGrid), dim3(256), 0, s, h->k, h->gm, h->gg, h->list[now], h->count + now);
   NM_LAUNCH_CHECK();
   NM_LAUNCH(k_p2g_bwd, dim3(nwg), dim3(256), 0, s, h->k, n, st->vol, st->rho, st->enabled, cur->x, cur->v, cur->C,
+                     cur->stress, h->gg, gcur->x, gcur->v, gcur->C, gcur->stress);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}
+
+// ---------------------------------------------------------------- particle-sharded substep: the same launches, cut at the
+// two points where the caller sums the blocks that several ranks touch (nm_shard.hip has the exchange kernels)
+nm_mpm_view nm_mpm_get_view(nm_mpm* h) {
+  nm_mpm_view v;
+  v.gm = h->gm; v.gg = h->gg; v.flags = h->flags; v.list = h->list[h->cur]; v.count = h->count + h->cur;
+  v.epoch = h->epoch; v.nblocks = h->nblocks;
+  return v;
+}
+
+__global__ void k_shared_init(int* __restrict__ cnt, int* __restrict__ pos, int nblocks) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nblocks) { cnt[i] = 0; pos[i] = 0x7fffffff; }
+}
+
+int nm_mpm_shared_counters(nm_mpm* h, int** cnt, int** pos) {
+  if (!h->sh_cnt) {
+    NM_HIP_CHECK(hipMalloc(&h->sh_cnt, h->nblocks * sizeof(int)));
+    NM_HIP_CHECK(hipMalloc(&h->sh_pos, h->nblocks * sizeof(int)));
+    NM_LAUNCH(k_shared_init, dim3(nm_div_up(h->nblocks, 256)), dim3(256), 0, (hipStream_t)0, h->sh_cnt, h->sh_pos, h->nblocks);
+    NM_LAUNCH_CHECK();
+    NM_HIP_CHECK(hipDeviceSynchronize());
+  }
+  *cnt = h->sh_cnt;
+  *pos = h->sh_pos;
+  return NM_OK;
+}
+
+extern "C" int nm_mpm_p2g(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, void* stream) {
+  NM_REQUIRE(h, "null handle");
+  NM_REQUIRE(n >= 0, "negative particle count");
+  if (n > 0) {
+    int rc = check_particles(st, cur, true);
+    if (rc) return rc;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int prev = h->cur, now = (prev + 1) % 3, next = (prev + 2) % 3;
+  h->epoch += 1;
+  NM_LAUNCH(k_clear, dim3(NM_CLEAR_WGS), dim3(256), 0, s, h->gm, h->gv, h->gg, h->list[prev], h->count + prev, h->list[now],
+                     h->count + now, h->count + next, h->flags, h->epoch);
+  NM_LAUNCH_CHECK();
+  if (n > 0) {   // a rank without particles still takes part in the exchange with an empty list
+    NM_LAUNCH(k_p2g, dim3(nm_div_up(n, NM_SC_T)), dim3(NM_SC_T), 0, s, h->k, n, st->vol, st->rho, st->enabled, cur->x,
+                       cur->v, cur->C, cur->stress, h->gm, h->flags, h->list[now], h->count + now, h->epoch, (const int*)nullptr);
+    NM_LAUNCH_CHECK();
+  }
+  h->cur = now;
+  return NM_OK;
+}
+
+extern "C" int nm_mpm_forward_finish(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, nm_particles* next,
+                                     void* gridrec, int32_t cap_blocks, int32_t* status, void* stream) {
+  NM_REQUIRE(h, "null handle");
+  NM_REQUIRE(!gridrec || cap_blocks > 0, "grid cache record without capacity");
+  NM_REQUIRE(n >= 0, "negative particle count");
+  hipStream_t s = (hipStream_t)stream;
+  const int now = h->cur;
+  GridRec none = {nullptr, nullptr, nullptr};
+  NM_LAUNCH(k_grid_op, dim3(kSweepGrid), dim3(256), 0, s, h->k, h->gm, h->gv, h->list[now], h->count + now,
+                     gridrec ? gridrec_at(gridrec, cap_blocks) : none, cap_blocks, (const int*)nullptr, (int*)status);
+  NM_LAUNCH_CHECK();
+  if (n == 0) return NM_OK;
+  int rc = check_particles(st, cur, true);
+  if (rc) return rc;
+  rc = check_particles(st, next, false);
+  if (rc) return rc;
+  NM_LAUNCH(k_g2p, dim3(nm_div_up(n, 256)), dim3(256), 0, s, h->k, n, st->clip_bound, st->enabled, cur->x, cur->v, cur->C,
+                     cur->F, h->gv, next->x, next->v, next->C, next->F);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}
+
+extern "C" int nm_mpm_backward_begin(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, const nm_particles* next,
+                                     const nm_particles* gnext, nm_particles* gcur, const void* gridrec, int32_t cap_blocks,
+                                     void* stream) {
+  NM_REQUIRE(h, "null handle");
+  NM_REQUIRE(gridrec && cap_blocks > 0, "the sharded reverse sweep needs the substep's grid cache record");
+  NM_REQUIRE(n >= 0, "negative particle count");
+  hipStream_t s = (hipStream_t)stream;
+  // restore {mv, m}, v and the block list of the forward substep (they already hold the sums over the ranks)
+  int rc = mpm_build_grid(h, 0, st, cur, s, nullptr, gridrec, cap_blocks, true);
+  if (rc) return rc;
+  if (n == 0) return NM_OK;
+  rc = check_particles(st, cur, true);
+  if (rc) return rc;
+  NM_REQUIRE(next && next->v && next->C, "next state (v, C) required");
+  NM_REQUIRE(gnext && gnext->x && gnext->v && gnext->C && gnext->F, "null incoming gradients");
+  NM_REQUIRE(gcur && gcur->x && gcur->v && gcur->C && gcur->F && gcur->stress, "null outgoing gradients");
+  NM_LAUNCH(k_g2p_bwd, dim3(nm_div_up(n, NM_SC_T)), dim3(NM_SC_T), 0, s, h->k, n, st->clip_bound, st->enabled, cur->x, cur->F,
+                     next->v, next->C, gnext->x, gnext->v, gnext->C, gnext->F, h->gv, h->gg, gcur->x, gcur->F);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}
+
+extern "C" int nm_mpm_backward_finish(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, nm_particles* gcur,
+                                      void* stream) {
+  NM_REQUIRE(h, "null handle");
+  NM_REQUIRE(n >= 0, "negative particle count");
+  hipStream_t s = (hipStream_t)stream;
+  const int now = h->cur;
+  NM_LAUNCH(k_grid_op_bwd, dim3(kSweepGrid), dim3(256), 0, s, h->k, h->gm, h->gg, h->list[now], h->count + now);
+  NM_LAUNCH_CHECK();
+  if (n == 0) return NM_OK;
+  int rc = check_particles(st, cur, true);
+  if (rc) return rc;
+  NM_REQUIRE(gcur && gcur->x && gcur->v && gcur->C && gcur->F && gcur->stress, "null outgoing gradients");
+  NM_LAUNCH(k_p2g_bwd, dim3(nm_div_up(n, 256)), dim3(256), 0, s, h->k, n, st->vol, st->rho, st->enabled, cur->x, cur->v, cur->C,
                      cur->stress, h->gg, gcur->x, gcur->v, gcur->C, gcur->stress);
   NM_LAUNCH_CHECK();
   return NM_OK;

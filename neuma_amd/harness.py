@@ -6,10 +6,13 @@ loop) and render.py:304-332 for one video frame:
     de_x = denormalize(x); means3D = g_prev + B (de_x - de_x_prev); F_k = B F               (373-376)
     for view: render = diff_rasterization(...); loss += decay * pixel_loss(render, gt)      (378-389)
     loss.backward()                                                                        (413-414)
-Multi-GPU (torch.distributed over RCCL): the simulation is replicated (a 100k-particle substep is shorter than
-one xGMI collective); the V views x tile rows of a frame are split into contiguous stripes, one
+Multi-GPU (torch.distributed over RCCL): the V views x tile rows of a frame are split into contiguous stripes, one
 per rank; each rank back-propagates its stripes to dL/dmeans3D and ONE all-reduce (sum, K x 3 fp32) per frame
-merges them before the binding transpose.
+merges them before the binding transpose.  The simulation is either replicated (default: a 100k-particle substep is
+shorter than one xGMI collective) or, with shard_sim=True, particle-sharded (sim/shard.py): each rank
+steps its contiguous range of the particle list and the ranks all-reduce the grid blocks their ranges share, twice
+per substep; positions and deformation gradients are all-gathered once per frame for the bindings, and the LoRA
+gradients are summed over the ranks after the backward pass.
 """
 import os
 from dataclasses import dataclass
@@ -83,9 +86,12 @@ class SceneRuntime(object):
 
     def __init__(self, scene: synth.Scene, device, lora_r: int = 16, lora_alpha: int = 16, fused: bool = True,
                  bc: str = "noslip", gravity=(0.0, -9.8, 0.0), pixel_loss: str = "l2", white_bg: bool = True,
-                 rank: int = 0, world: int = 1, group=None):
+                 rank: int = 0, world: int = 1, group=None, shard_sim: bool = False):
         self.scene, self.device, self.fused = scene, torch.device(device), fused
         self.rank, self.world, self.group = rank, world, group
+        self.shard_sim = bool(shard_sim) and world > 1
+        if self.shard_sim:
+            self.fused = False          # the exchange sits between the phases of a substep: per-operator path
         # the render jobs of a frame (views, or view stripes on several GPUs) go round-robin over HIP streams so that one job's
         # binning (small sort / scan kernels) runs under another job's compositing kernel - same results, ~9 % shorter frame
         self.overlap_views = os.environ.get("NEUMA_OVERLAP_VIEWS", "1") != "0"
@@ -96,14 +102,21 @@ class SceneRuntime(object):
         self.model = MPMModelBuilder().parse_cfg(sim_cfg).finalize(self.device, requires_grad=True)
         N = scene.x0.shape[0]
         self.N = N
-        st = MPMStatics()
-        st.init(N, self.device)
-        st.vol.fill_(scene.vol); st.rho.fill_(1000.0); st.clip_bound.fill_(0.1); st.enabled.fill_(1)
-        self.statics = st
         self.x0 = torch.tensor(scene.x0, device=self.device)
         self.v0 = torch.tensor(scene.v0, device=self.device)
         self.C0 = torch.zeros(N, 3, 3, device=self.device)
         self.F0 = torch.eye(3, device=self.device).repeat(N, 1, 1)
+        # the particle rows this rank simulates: all of them, or its contiguous range of the (Hilbert-ordered) list
+        self.rows = slice(0, N)
+        if self.shard_sim:
+            from .sim.shard import shard_range
+            self.rows = slice(*shard_range(N, world, rank))
+            self.model.shard(group)
+        n_local = self.n_local = self.rows.stop - self.rows.start
+        st = MPMStatics()
+        st.init(n_local, self.device)
+        st.vol.fill_(scene.vol); st.rho.fill_(1000.0); st.clip_bound.fill_(0.1); st.enabled.fill_(1)
+        self.statics = st
         # constitutive nets: shipped checkpoint + LoRA (finetune.py:295-313)
         w = synth.load_base_weights(cfg["mat"])
         mcfg = make_material_cfg()
@@ -174,23 +187,37 @@ class SceneRuntime(object):
         self.fused = False
         S = self.S
         self.S = steps
-        x, v, C, F = self.rollout(x, v, C, F, step0=2048)
+        x, v, C, F = self.rollout(x[self.rows], v[self.rows], C[self.rows], F[self.rows], step0=2048)
+        x, F = self.all_rows(x), self.all_rows(F)
         self.S, self.fused = S, was
         means3D = compute_bindings_xyz(x, self.x0, self.gaussians.get_xyz, self.bindings)
         dg = compute_bindings_F(F, self.bindings)
         for vi in range(self.V):
             self.gt[vi] = self.render_view(means3D, dg, vi).detach().clone()
 
+    def all_rows(self, t: torch.Tensor, differentiable: bool = False) -> torch.Tensor:
+        """This rank's particle rows -> all particles (identity unless the simulation is sharded).  The gradient that
+        comes back through it is already summed over the ranks (merge_grad_across_ranks sits downstream)."""
+        if not self.shard_sim:
+            return t
+        from .sim.shard import gather_rows
+        return gather_rows(t if differentiable else t.detach(), self.N, self.group, grad_is_summed=True)
+
     # ---- one frame, forward + backward
     def frame(self, weight: float = 1.0, backward: bool = True) -> FrameResult:
-        x, v, C, F = self.x0, self.v0, self.C0, self.F0
+        rows = self.rows
+        x, v, C, F = self.x0[rows], self.v0[rows], self.C0[rows], self.F0[rows]
         de_x_prev = (self.x0 - self.center) / self.size
         g_prev = self.gaussians.get_xyz
         x, v, C, F = self.rollout(x, v, C, F)
+        if self.shard_sim:
+            self.model.exchange.check()                                       # every substep's exchange was complete
+            x, F = self.all_rows(x, differentiable=True), self.all_rows(F)    # the bindings need every particle
         de_x = (x - self.center) / self.size                                  # finetune.py:373
         means3D = compute_bindings_xyz(de_x, de_x_prev, g_prev, self.bindings)  # :375
         deform_grad = compute_bindings_F(F, self.bindings)                      # :376
-        means3D = merge_grad_across_ranks(means3D, self.group)
+        if self.world > 1:          # a single-rank runtime inside a multi-rank job (tests) must not join the collective
+            means3D = merge_grad_across_ranks(means3D, self.group)
         loss = torch.zeros((), device=self.device)
         H = self.scene.cfg["H"]
         # render jobs of this rank: whole views on one GPU, (view, tile-row stripe) pieces when the frame is split
@@ -231,4 +258,7 @@ class SceneRuntime(object):
                 loss = loss + job_loss(vi, rows)
         if backward:
             loss.backward()
+            if self.shard_sim:
+                from .sim.shard import reduce_param_grads
+                reduce_param_grads(self.parameters(), self.group)             # each rank saw only its particles
         return FrameResult(loss.detach(), x.detach(), F.detach())

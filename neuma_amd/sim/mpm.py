@@ -200,9 +200,20 @@ class MPMModel(Model):
         # (x1.5 + 64 blocks, one host sync); an int fixes the capacity; 0 / None = recompute like the reference
         self.grid_cache = "auto"
         self._cache_blocks = None
+        self.exchange = None        # set by shard(): this model steps one rank's share of the particles
+
+    def shard(self, group=None, cap=None, cap_shared=None):
+        """Make this model one rank of a particle-sharded simulation (sim/shard.py): every forward / backward sums the
+        grid blocks it shares with other ranks over `group`.  Capacities default to 1.5x what the first substep needs."""
+        from .shard import GridExchange
+        self.exchange = GridExchange(self, group, cap, cap_shared)
+        return self.exchange
 
     def new_tape(self):
         """A fresh GridTape for one differentiable substep (None while the capacity is not known yet / cache disabled)."""
+        if self.exchange is not None:
+            from .shard import ShardTape
+            return ShardTape(self.exchange.generation)
         if self.grid_cache in (0, None, False):
             return None
         if self.grid_cache != "auto":
@@ -212,7 +223,7 @@ class MPMModel(Model):
         return GridTape(self._cache_blocks, self.device)
 
     def _size_cache(self) -> None:
-        if self.grid_cache == "auto" and self._cache_blocks is None:
+        if self.exchange is None and self.grid_cache == "auto" and self._cache_blocks is None:
             blocks, _ = self.grid_stats()
             self._cache_blocks = int(1.5 * blocks) + 64
 
@@ -246,6 +257,8 @@ class MPMModel(Model):
     def forward(self, statics: MPMStatics, state_curr: MPMState, state_next: MPMState, tape=None) -> None:
         """mpm.py:279-297.  `tape`: None (nothing is recorded; the backward pass recomputes the grid exactly like
         mpm.py:312-315) or a GridTape from new_tape() (the substep's touched grid blocks are saved into it)."""
+        if self.exchange is not None:
+            return self.exchange.forward(statics, state_curr, state_next, tape)
         n = state_curr.particle.x.shape[0]
         st = statics.c_struct()
         cur = state_curr.particle.c_struct()
@@ -274,6 +287,8 @@ class MPMModel(Model):
         cur, nxt = pc.c_struct(), pn.c_struct()
         gn = L.nm_particles(L.ptr(pn.x_grad), L.ptr(pn.v_grad), L.ptr(pn.C_grad), L.ptr(pn.F_grad), None)
         gc = pc.c_struct_grad()
+        if self.exchange is not None:
+            return self.exchange.backward(statics, state_curr, state_next, gn, gc, tape)
         if isinstance(tape, GridTape):
             L.check(L.lib().nm_mpm_backward_ex(self.handle(), n, C.byref(st), C.byref(cur), C.byref(nxt), C.byref(gn), C.byref(gc),
                                                L.ptr(tape.buf), tape.cap, self._stream()), "nm_mpm_backward_ex")
@@ -283,6 +298,8 @@ class MPMModel(Model):
 
     def forward_extra(self, statics, state, statics_extra, state_extra) -> None:
         """mpm.py:260-277."""
+        if self.exchange is not None:
+            raise L.NeumaHipError("forward_extra is not available on a sharded model (gather the particles to one rank)")
         n, ne = state.particle.x.shape[0], state_extra.particle.x.shape[0]
         st, ste = statics.c_struct(), statics_extra.c_struct()
         cur, ext = state.particle.c_struct(), state_extra.particle.c_struct()

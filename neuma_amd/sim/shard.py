@@ -1,0 +1,232 @@
+"""Particle-sharded simulation: one process per GPU, every rank steps a fixed subset of the particles.
+
+No reference counterpart (the reference is single-device).  Ownership is by particle, not by region:
+rank r keeps a contiguous range of the (Hilbert-ordered) particle list for the whole roll-out, so nothing migrates and
+autograd needs no routing.  Each rank scatters its own particles into its own block-sparse grid; the only data-path
+collective of a substep is an all-reduce (sum) over the 4x4x4-node blocks that MORE than one rank touches - the
+overlap of the ranks' halos - once for {mv, m} in the forward pass and once for the adjoint of the node velocities in
+the backward pass (include/neuma_hip.h, "Particle-sharded substep"; kernels in csrc/nm_shard.hip).
+
+    model.shard(group)          every MPMModel.forward / backward on this model is now the sharded substep
+    shard_range(N, world, r)    the particle rows rank r owns
+    gather_rows(t, N, group)    local rows -> all rows (differentiable; the rasterizer needs every particle)
+    reduce_param_grads(params)  sum the LoRA gradients of the ranks after loss.backward()
+"""
+import ctypes as C
+from typing import Iterable, Optional, Tuple
+
+import torch
+
+from .. import _lib as L
+
+
+def shard_range(num_particles: int, world: int, rank: int) -> Tuple[int, int]:
+    """Rows [lo, hi) of the particle list that `rank` owns: contiguous, sizes differ by at most one."""
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside world of {world}")
+    return (num_particles * rank) // world, (num_particles * (rank + 1)) // world
+
+
+def size_with_slack(count: int) -> int:
+    """Capacity chosen from an observed count: 1.5x + 64 (the same rule as the grid cache)."""
+    return int(1.5 * int(count)) + 64
+
+
+STATUS_TEXT = {1: "a rank touched more grid blocks than the list capacity `cap`",
+               2: "more blocks are shared between ranks than `cap_shared`",
+               4: "a substep touched more blocks than its grid cache record holds"}
+
+
+def explain_status(bits: int) -> str:
+    return "; ".join(text for bit, text in STATUS_TEXT.items() if bits & bit)
+
+
+class ShardTape(object):
+    """`tape` of a sharded substep: the grid cache record plus the list of blocks that were summed over the ranks.
+    Filled by MPMModel.forward, consumed by MPMModel.backward."""
+
+    def __init__(self, generation: int) -> None:
+        self.generation = generation
+        self.cap = 0
+        self.buf: Optional[torch.Tensor] = None
+        self.shared: Optional[torch.Tensor] = None
+
+
+class GridExchange(object):
+    """Per-model state of the sharded substep: capacities, exchange buffers, the status word."""
+
+    def __init__(self, model, group=None, cap: Optional[int] = None, cap_shared: Optional[int] = None) -> None:
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            raise L.NeumaHipError("model.shard() needs an initialised torch.distributed process group")
+        self.model, self.group = model, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.cap = int(cap) if cap else None                    # blocks per rank list / grid cache record
+        self.cap_shared = int(cap_shared) if cap_shared else None
+        self.device = model.device
+        self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.generation = 0
+        self._mine = self._gathered = self._ws = self._buf = self._scratch_shared = None
+
+    # -- sizing (first substep only: two host reads + two tiny collectives)
+    def _ensure_sized(self) -> None:
+        import torch.distributed as dist
+        lib, h, s = L.lib(), self.model.handle(), self.model._stream()
+        if self.cap is None:
+            nblocks = (int(self.model.constant.num_grids) + 2 + 3) // 4
+            probe = torch.empty(1 + nblocks ** 3, dtype=torch.int32, device=self.device)
+            L.check(lib.nm_mpm_active_list(h, L.ptr(probe), nblocks ** 3, s), "nm_mpm_active_list")
+            count = probe[:1].clone()
+            dist.all_reduce(count, op=dist.ReduceOp.MAX, group=self.group)
+            self.cap = size_with_slack(int(count.item()))
+        if self._gathered is None:
+            self._mine = torch.empty(1 + self.cap, dtype=torch.int32, device=self.device)
+            self._gathered = torch.empty(self.world, 1 + self.cap, dtype=torch.int32, device=self.device)
+            nbytes = int(lib.nm_mpm_shared_workspace(self.world, self.cap))
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        if self.cap_shared is None:
+            upper = max(1, (self.world * self.cap) // 2)          # a shared block is in at least two lists
+            probe = torch.zeros(2 + 2 * upper, dtype=torch.int32, device=self.device)
+            self._find_shared(probe, upper, None)
+            self.cap_shared = size_with_slack(int(probe[0].item()))
+        if self._buf is None:
+            self._buf = torch.empty(self.cap_shared * 64 * 4, dtype=torch.float32, device=self.device)
+            self._scratch_shared = self.new_shared()
+
+    def new_shared(self) -> torch.Tensor:
+        return torch.empty(2 + 2 * self.cap_shared, dtype=torch.int32, device=self.device)
+
+    # -- the exchange
+    def _find_shared(self, shared: torch.Tensor, cap_shared: int, status) -> None:
+        import torch.distributed as dist
+        lib, h, s = L.lib(), self.model.handle(), self.model._stream()
+        L.check(lib.nm_mpm_active_list(h, L.ptr(self._mine), self.cap, s), "nm_mpm_active_list")
+        dist.all_gather_into_tensor(self._gathered.view(-1), self._mine, group=self.group)
+        L.check(lib.nm_mpm_shared_blocks(h, L.ptr(self._gathered), self.world, self.cap, L.ptr(shared), cap_shared,
+                                         L.ptr(status), L.ptr(self._ws), self._ws.numel(), s), "nm_mpm_shared_blocks")
+
+    def find_shared(self, shared: torch.Tensor) -> None:
+        self._find_shared(shared, self.cap_shared, self.status)
+
+    def sum_blocks(self, which: int, shared: torch.Tensor) -> None:
+        """All-reduce the shared blocks of {mv, m} (which = 0) or of the grid adjoint (which = 1)."""
+        import torch.distributed as dist
+        lib, h, s = L.lib(), self.model.handle(), self.model._stream()
+        L.check(lib.nm_mpm_blocks_pack(h, which, L.ptr(shared), self.cap_shared, L.ptr(self._buf), s), "nm_mpm_blocks_pack")
+        dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=self.group)
+        L.check(lib.nm_mpm_blocks_unpack(h, which, L.ptr(shared), self.cap_shared, L.ptr(self._buf), s), "nm_mpm_blocks_unpack")
+
+    # -- status
+    def check(self) -> None:
+        """Raise if any substep since the last check exceeded a capacity (one host read).  Called once per backward
+        pass by MPMModel.backward and by the frame driver after the forward roll-out."""
+        bits = int(self.status.item())
+        self.generation += 1
+        if bits:
+            self.status.zero_()
+            raise L.NeumaHipError(f"sharded substep incomplete ({explain_status(bits)}): cap={self.cap}, "
+                                  f"cap_shared={self.cap_shared}; re-create the exchange with larger capacities")
+
+    # -- the substep (called by MPMModel.forward / backward)
+    def forward(self, statics, state_curr, state_next, tape) -> None:
+        lib, model = L.lib(), self.model
+        h, s = model.handle(), model._stream()
+        n = state_curr.particle.x.shape[0]
+        st = statics.c_struct()
+        cur, nxt = state_curr.particle.c_struct(), state_next.particle.c_struct()
+        L.check(lib.nm_mpm_p2g(h, n, C.byref(st), C.byref(cur), s), "nm_mpm_p2g")
+        self._ensure_sized()
+        record = None
+        if isinstance(tape, ShardTape):
+            tape.cap = self.cap
+            tape.buf = torch.empty(int(lib.nm_mpm_gridcache_bytes(self.cap)), dtype=torch.uint8, device=self.device)
+            tape.shared = self.new_shared()
+            tape.generation = self.generation
+            shared, record = tape.shared, tape.buf
+        elif tape is None:
+            shared = self._scratch_shared
+        else:
+            raise L.NeumaHipError("a sharded MPMModel takes the tape from model.new_tape() (or None)")
+        self.find_shared(shared)
+        self.sum_blocks(0, shared)
+        L.check(lib.nm_mpm_forward_finish(h, n, C.byref(st), C.byref(cur), C.byref(nxt), L.ptr(record), self.cap,
+                                          L.ptr(self.status), s), "nm_mpm_forward_finish")
+
+    def backward(self, statics, state_curr, state_next, gnext, gcur, tape) -> None:
+        if not isinstance(tape, ShardTape) or tape.buf is None:
+            raise L.NeumaHipError("the sharded reverse sweep needs the ShardTape its forward substep filled "
+                                  "(model.new_tape()); there is no recompute fallback across ranks")
+        if tape.generation == self.generation:
+            self.check()                # first substep of this reverse sweep: were all forward substeps complete?
+        lib, model = L.lib(), self.model
+        h, s = model.handle(), model._stream()
+        n = state_curr.particle.x.shape[0]
+        st = statics.c_struct()
+        cur, nxt = state_curr.particle.c_struct(), state_next.particle.c_struct()
+        L.check(lib.nm_mpm_backward_begin(h, n, C.byref(st), C.byref(cur), C.byref(nxt), C.byref(gnext), C.byref(gcur),
+                                          L.ptr(tape.buf), tape.cap, s), "nm_mpm_backward_begin")
+        self.sum_blocks(1, tape.shared)
+        L.check(lib.nm_mpm_backward_finish(h, n, C.byref(st), C.byref(cur), C.byref(gcur), s), "nm_mpm_backward_finish")
+
+
+# ---------------------------------------------------------------- particle rows <-> all rows
+class _GatherRows(torch.autograd.Function):
+    """Forward: all-gather the ranks' row blocks into the full (N, ...) tensor.  Backward: this rank's rows of the
+    incoming gradient (`summed` = the gradient is already the same on every rank, e.g. behind merge_grad_across_ranks)
+    or of its all-reduced sum."""
+
+    @staticmethod
+    def forward(ctx, local, num_rows: int, group, summed: bool):
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        lo, hi = shard_range(num_rows, world, rank)
+        if local.shape[0] != hi - lo:
+            raise L.NeumaHipError(f"rank {rank} owns rows [{lo},{hi}) but holds {local.shape[0]}")
+        chunk = -(-num_rows // world)
+        tail = local.shape[1:]
+        padded = local.new_zeros((chunk,) + tail)
+        padded[:hi - lo] = local
+        out = local.new_empty((world * chunk,) + tail)
+        dist.all_gather_into_tensor(out, padded, group=group)
+        ctx.meta = (group, lo, hi, summed)
+        if chunk * world == num_rows:
+            return out
+        pieces = [out[r * chunk:r * chunk + (shard_range(num_rows, world, r)[1] - shard_range(num_rows, world, r)[0])]
+                  for r in range(world)]
+        return torch.cat(pieces, 0)
+
+    @staticmethod
+    def backward(ctx, grad):
+        import torch.distributed as dist
+        group, lo, hi, summed = ctx.meta
+        if not summed:
+            grad = grad.contiguous().clone()
+            dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
+        return grad[lo:hi].contiguous(), None, None, None
+
+
+def gather_rows(local: torch.Tensor, num_rows: int, group=None, grad_is_summed: bool = False) -> torch.Tensor:
+    return _GatherRows.apply(local.contiguous(), num_rows, group, grad_is_summed)
+
+
+def reduce_param_grads(params: Iterable[torch.nn.Parameter], group=None) -> None:
+    """Sum the parameter gradients over the ranks (each rank holds the contribution of its particles) - the one
+    collective a data-parallel trainer adds after loss.backward().  One flat all-reduce."""
+    import torch.distributed as dist
+    if dist.get_world_size(group) == 1:
+        return
+    grads = []
+    for p in params:
+        if not p.requires_grad:
+            continue
+        if p.grad is None:                       # e.g. a rank without particles: it still takes part with zeros
+            p.grad = torch.zeros_like(p)
+        grads.append(p.grad)
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()

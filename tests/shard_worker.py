@@ -1,0 +1,146 @@
+"""Rank body of the particle-sharded tests (spawned by test_gpu_shard.py / test_shard_cpu.py; not a test module).
+
+GPU cases run `world` processes on cuda:0 with the gloo backend: the box has one GPU, and what is checked is the
+exchange logic (which blocks are summed, in which order, forward and backward), which does not depend on the transport.
+Every rank also runs the unsharded model on all particles and compares its own rows against it."""
+import os
+
+import torch
+
+
+def _init(rank, world, port):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dist
+
+
+def _err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
+
+
+def gpu_substeps(rank, world, port, q, steps=3, cap_shared=None):
+    """`steps` chained substeps with given stresses: sharded rows vs the unsharded model, states and gradients."""
+    try:
+        dist = _init(rank, world, port)
+        from gpu_util import mpm_case, build_model, build_statics
+        from neuma_amd.sim import MPMDiffSim
+        from neuma_amd.sim.shard import shard_range, gather_rows
+        dev = torch.device("cuda", 0)
+        const, vol, rho, clip, en, x, v, C, F, S = mpm_case(N=6000, G=32, seed=3)
+        N = x.shape[0]
+        lo, hi = shard_range(N, world, rank)
+        g = torch.Generator().manual_seed(11)
+        wts = [torch.randn(t.shape, generator=g).to(dev) for t in (x, v, C, F)]
+
+        def run(model, statics, rows, gather):
+            leaves = [t[rows].float().to(dev).requires_grad_(True) for t in (x, v, C, F)]
+            stresses = [(S[rows] * (1.0 + 0.25 * k)).float().to(dev).requires_grad_(True) for k in range(steps)]
+            sim = MPMDiffSim(model, reorder=False)
+            state = leaves
+            for k in range(steps):
+                state = sim(statics, *state, stresses[k])
+            full = [gather(t) for t in state]
+            loss = sum((w * t).sum() for w, t in zip(wts, full))
+            loss.backward()
+            return [t.detach() for t in full], [t.grad for t in leaves + stresses]
+
+        ref_model = build_model(const, dev)
+        ref_out, ref_grad = run(ref_model, build_statics(ref_model, vol, rho, clip, en, dev), slice(0, N), lambda t: t)
+
+        model = build_model(const, dev)
+        ex = model.shard(None, cap_shared=cap_shared)
+        rows = slice(lo, hi)
+        st = build_statics(model, vol[rows], rho[rows], clip[rows], en[rows], dev)
+        out, grad = run(model, st, rows, lambda t: gather_rows(t, N, None, grad_is_summed=True))
+        ex.check()
+        res = {"rank": rank, "cap": ex.cap, "cap_shared": ex.cap_shared}
+        res["out_err"] = [_err(a, b) for a, b in zip(out, ref_out)]
+        res["out_abs"] = [float((a - b).abs().max()) for a, b in zip(out, ref_out)]
+        res["grad_err"] = [_err(a, b[rows]) for a, b in zip(grad, ref_grad)]
+        # how many blocks were actually exchanged in a substep (forward-only call uses the scratch list)
+        with torch.no_grad():
+            sim = MPMDiffSim(model, reorder=False)
+            sim(st, *[t[rows].float().to(dev) for t in (x, v, C, F)], S[rows].float().to(dev))
+        res["shared_blocks"] = int(ex._scratch_shared[0])
+        res["status"] = int(ex.status.item())
+        q.put(res)
+        dist.destroy_process_group()
+    except Exception as e:      # report instead of leaving the parent waiting on the queue
+        import traceback
+        q.put({"rank": rank, "error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()})
+
+
+def gpu_frame(rank, world, port, q, name="tiny"):
+    """One frame of the driver (materials + roll-out + bindings + render + loss, forward and backward): sharded
+    simulation on `world` ranks vs the single-process frame."""
+    try:
+        dist = _init(rank, world, port)
+        from neuma_amd import synth
+        from neuma_amd.harness import SceneRuntime
+        dev = torch.device("cuda", 0)
+        scene = synth.make_scene(name)
+        ref = SceneRuntime(scene, dev, fused=False)
+        ref.make_ground_truth()
+        rt = SceneRuntime(scene, dev, rank=rank, world=world, shard_sim=True)
+        rt.gt = ref.gt
+        for run in (ref, rt):
+            # a material that is visibly wrong for the ground truth, so that the LoRA gradients are a signal and not the
+            # rounding residue of a sum that cancels; and the initial velocities as leaves (per-particle gradients)
+            with torch.no_grad():
+                for p in run.parameters():
+                    if p.shape[0] in (64, 9):       # the lora_B factors
+                        p.mul_(-4.0)
+            run.v0.requires_grad_(True)
+        r0 = ref.frame()
+        ref_grads = [p.grad.clone() for p in ref.parameters()]
+        r1 = rt.frame()
+        tot = r1.loss.clone()
+        dist.all_reduce(tot)
+        grads = [p.grad for p in rt.parameters()]
+        res = {"rank": rank, "loss": float(tot), "ref_loss": float(r0.loss),
+               "x_err": _err(r1.x, r0.x), "F_err": _err(r1.F, r0.F),
+               "v0_err": _err(rt.v0.grad[rt.rows], ref.v0.grad[rt.rows]), "v0_mag": float(ref.v0.grad.abs().max()),
+               "grad_err": [_err(a, b) for a, b in zip(grads, ref_grads)],
+               "grad_mag": [float(b.abs().max()) for b in ref_grads]}
+        q.put(res)
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put({"rank": rank, "error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()})
+
+
+def cpu_rows(rank, world, port, q):
+    """Host-side pieces on CPU tensors: row ownership, gather_rows forward / backward, parameter-gradient reduction."""
+    try:
+        dist = _init(rank, world, port)
+        from neuma_amd.sim.shard import shard_range, gather_rows, reduce_param_grads
+        N = 11                                      # not divisible by the world size: exercises the padding
+        torch.manual_seed(0)
+        full = torch.randn(N, 3)
+        lo, hi = shard_range(N, world, rank)
+        local = full[lo:hi].clone().requires_grad_(True)
+        w = torch.randn(N, 3)
+        out = gather_rows(local, N, None, grad_is_summed=True)
+        ok_fwd = bool(torch.equal(out, full))
+        (out * w).sum().backward()
+        ok_bwd = bool(torch.allclose(local.grad, w[lo:hi]))
+        local2 = full[lo:hi].clone().requires_grad_(True)
+        out2 = gather_rows(local2, N, None, grad_is_summed=False)
+        (out2 * w * (rank + 1)).sum().backward()   # rank-dependent partial losses: gradients must be summed
+        scale = sum(r + 1 for r in range(world))
+        ok_sum = bool(torch.allclose(local2.grad, w[lo:hi] * scale))
+        p = torch.nn.Parameter(torch.ones(4))
+        p2 = torch.nn.Parameter(torch.ones(2, 2))
+        p.grad = torch.full((4,), float(rank + 1))
+        if rank == 0:
+            p2.grad = torch.ones(2, 2)              # the other rank has no gradient for p2 yet
+        reduce_param_grads([p, p2])
+        ok_par = bool(torch.allclose(p.grad, torch.full((4,), float(scale))) and torch.allclose(p2.grad, torch.ones(2, 2)))
+        q.put({"rank": rank, "ok": [ok_fwd, ok_bwd, ok_sum, ok_par]})
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put({"rank": rank, "error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()})
