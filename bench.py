@@ -135,6 +135,11 @@ def main():
     scene = synth.make_scene(args.workload)
     shard_sim = world > 1 and (args.shard_sim == "on" or
                                (args.shard_sim == "auto" and scene.x0.shape[0] // world >= 100_000))
+    if world == 1 and args.shard_sim == "on" and os.environ.get("NEUMA_SHARD_FORCE") == "1":
+        # overhead measurement on one GPU: a one-rank RCCL group, every collective of the sharded substep is issued
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        shard_sim = True
     rt = SceneRuntime(scene, dev, fused=not args.per_op, rank=rank, world=world, shard_sim=shard_sim,
                       group=dist.group.WORLD if world > 1 else None)
     rt.make_ground_truth()
@@ -333,9 +338,17 @@ def main():
             "rates": rates,
             "loss": float(last.loss),
         }
-        print(json.dumps(out))
-    if world > 1:
+    else:
+        out = None
+    if dist.is_initialized():
+        dist.barrier()
         dist.destroy_process_group()
+    if out is not None:
+        # RCCL writes its version banner to the C stdout buffer; push it out first so that the JSON is the last line
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

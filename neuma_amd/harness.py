@@ -89,7 +89,8 @@ class SceneRuntime(object):
                  rank: int = 0, world: int = 1, group=None, shard_sim: bool = False):
         self.scene, self.device, self.fused = scene, torch.device(device), fused
         self.rank, self.world, self.group = rank, world, group
-        self.shard_sim = bool(shard_sim) and world > 1
+        # (NEUMA_SHARD_FORCE=1: keep the exchange machinery on with a single rank, to measure its overhead on one GPU)
+        self.shard_sim = bool(shard_sim) and (world > 1 or os.environ.get("NEUMA_SHARD_FORCE") == "1")
         if self.shard_sim:
             self.fused = False          # the exchange sits between the phases of a substep: per-operator path
         # the render jobs of a frame (views, or view stripes on several GPUs) go round-robin over HIP streams so that one job's
@@ -211,7 +212,7 @@ class SceneRuntime(object):
         g_prev = self.gaussians.get_xyz
         x, v, C, F = self.rollout(x, v, C, F)
         if self.shard_sim:
-            self.model.exchange.check()                                       # every substep's exchange was complete
+            self.model.exchange.defer_check()                                 # checked once, at the end of the frame
             x, F = self.all_rows(x, differentiable=True), self.all_rows(F)    # the bindings need every particle
         de_x = (x - self.center) / self.size                                  # finetune.py:373
         means3D = compute_bindings_xyz(de_x, de_x_prev, g_prev, self.bindings)  # :375
@@ -261,4 +262,6 @@ class SceneRuntime(object):
             if self.shard_sim:
                 from .sim.shard import reduce_param_grads
                 reduce_param_grads(self.parameters(), self.group)             # each rank saw only its particles
+        if self.shard_sim:
+            self.model.exchange.check()      # raises if a substep's block exchange was incomplete (capacity exceeded)
         return FrameResult(loss.detach(), x.detach(), F.detach())

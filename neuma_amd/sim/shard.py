@@ -127,6 +127,11 @@ class GridExchange(object):
             raise L.NeumaHipError(f"sharded substep incomplete ({explain_status(bits)}): cap={self.cap}, "
                                   f"cap_shared={self.cap_shared}; re-create the exchange with larger capacities")
 
+    def defer_check(self) -> None:
+        """The caller promises to call check() itself before it uses any result of the substeps recorded so far (the
+        frame driver does so once, after the backward pass, instead of stalling the GPU between the two sweeps)."""
+        self.generation += 1
+
     # -- the substep (called by MPMModel.forward / backward)
     def forward(self, statics, state_curr, state_next, tape) -> None:
         lib, model = L.lib(), self.model
