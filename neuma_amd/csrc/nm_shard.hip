@@ -14,6 +14,7 @@
 // Blocks that only one rank touches never leave that rank: it alone gathers from them.
 #include "nm_common.h"
 #include <limits.h>
+#include <stdlib.h>
 #include <rocprim/rocprim.hpp>
 
 struct SharedWs {
@@ -102,6 +103,66 @@ __global__ void k_shared_finish(const int* __restrict__ gathered, int total, int
   if (i < total && gathered_entry(gathered, i, cap, nblocks, b)) { cnt[b] = 0; pos[b] = INT_MAX; }   // ready for the next call
 }
 
+// The same three steps in ONE launch of one 1024-thread workgroup, for the usual case of short lists (a 100k-particle
+// body covers ~400 blocks, 1M particles ~3400): mark with global atomics, then an ordered compaction by block scan over
+// chunks of 1024 entries, then the reset.  Saves four launches per substep on a path that is launch-latency bound.
+#define NM_SHARED_FUSED_MAX 32768
+__global__ void __launch_bounds__(1024) k_shared_fused(const int* __restrict__ gathered, int total, int world, int cap, int nblocks,
+                                                       int* __restrict__ cnt, int* __restrict__ pos, int* __restrict__ shared,
+                                                       int cap_shared, const int* __restrict__ flags, int epoch,
+                                                       int* __restrict__ status) {
+  __shared__ int wave_sum[16];
+  __shared__ int running;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid == 0) running = 0;
+  for (int i = tid; i < total; i += 1024) {
+    int b;
+    if (gathered_entry(gathered, i, cap, nblocks, b)) {
+      atomicAdd(&cnt[b], 1);
+      atomicMin(&pos[b], i);
+    }
+  }
+  __threadfence();
+  __syncthreads();
+  for (int base = 0; base < total; base += 1024) {
+    const int i = base + tid;
+    int b = 0;
+    bool s = false;
+    if (i < total && gathered_entry(gathered, i, cap, nblocks, b))
+      s = __hip_atomic_load(&pos[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == i &&
+          __hip_atomic_load(&cnt[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 2;
+    const unsigned long long m = __ballot(s);
+    if (lane == 0) wave_sum[wave] = __popcll(m);
+    __syncthreads();
+    int before = running, all = 0;
+    for (int w = 0; w < 16; ++w) {
+      if (w < wave) before += wave_sum[w];
+      all += wave_sum[w];
+    }
+    const int idx = before + __popcll(m & ((1ull << lane) - 1ull));
+    if (s && idx < cap_shared) {
+      shared[2 + idx] = b;
+      shared[2 + cap_shared + idx] = flags[b] == epoch ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid == 0) running += all;
+    __syncthreads();
+  }
+  for (int i = tid; i < total; i += 1024) {
+    int b;
+    if (gathered_entry(gathered, i, cap, nblocks, b)) { cnt[b] = 0; pos[b] = INT_MAX; }
+  }
+  if (tid == 0) {
+    const int np = running;
+    int bits = np > cap_shared ? 2 : 0;
+    for (int r = 0; r < world; ++r)
+      if (gathered[r * (1 + cap)] > cap) bits |= 1;
+    shared[0] = min(np, cap_shared);
+    shared[1] = bits;
+    if (bits && status) atomicOr(status, bits);
+  }
+}
+
 extern "C" int nm_mpm_active_list(nm_mpm* h, int32_t* out, int32_t cap, void* stream) {
   NM_REQUIRE(h && out, "null handle / output");
   NM_REQUIRE(cap > 0, "list capacity must be positive");
@@ -124,6 +185,13 @@ extern "C" int nm_mpm_shared_blocks(nm_mpm* h, const int32_t* gathered, int32_t 
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   const int total = world * (1 + cap);
+  static const int fused_max = getenv("NM_SHARED_FUSED_MAX") ? atoi(getenv("NM_SHARED_FUSED_MAX")) : NM_SHARED_FUSED_MAX;
+  if (total <= fused_max) {
+    NM_LAUNCH(k_shared_fused, dim3(1), dim3(1024), 0, s, gathered, total, world, cap, v.nblocks, cnt, pos, shared, cap_shared,
+                       v.flags, v.epoch, status);
+    NM_LAUNCH_CHECK();
+    return NM_OK;
+  }
   const dim3 grid(nm_div_up(total, 256)), block(256);
   NM_LAUNCH(k_shared_mark, grid, block, 0, s, gathered, total, cap, v.nblocks, cnt, pos);
   NM_LAUNCH_CHECK();

@@ -133,7 +133,11 @@ class SceneRuntime(object):
                 net.init_lora_layers(r=lora_r, lora_alpha=lora_alpha)
                 net.freeze_all_except_lora()
                 for lin in (net.layers[0].fc, net.layers[1].fc, net.final_layer.fc):
-                    lin.lora_B.data.copy_(0.01 * torch.randn(lin.lora_B.shape, generator=g))   # non-zero B
+                    # lora_A ~ kaiming_uniform (a = sqrt 5, i.e. U(+-1/sqrt(fan_in))) and a non-zero lora_B, both
+                    # from the seeded generator so that every runtime / rank builds the same adaptor
+                    bound = 1.0 / (lin.lora_A.shape[1] ** 0.5)
+                    lin.lora_A.data.copy_((2.0 * torch.rand(lin.lora_A.shape, generator=g) - 1.0) * bound)
+                    lin.lora_B.data.copy_(0.01 * torch.randn(lin.lora_B.shape, generator=g))
         self.sim_cached = MPMCacheDiffSim(self.model, 4096)
         self.sim_fused = MPMFusedDiffSim(self.model, self.elasticity, self.plasticity, self.S)
         # Gaussians

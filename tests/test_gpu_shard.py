@@ -36,9 +36,11 @@ def _run(target, world, *args, timeout=600):
     return sorted(res, key=lambda r: r["rank"])
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_substeps_match_the_unsharded_model(world):
-    res = _run(shard_worker.gpu_substeps, world)
+@pytest.mark.parametrize("world,cap", [(2, None), (3, None), (2, 20000)])
+def test_sharded_substeps_match_the_unsharded_model(world, cap):
+    """cap=None: capacities sized from the first substep, short lists -> the one-launch shared-list kernel;
+    cap=20000: 2 x 20001 gathered entries -> the multi-kernel (rocPRIM select) path."""
+    res = _run(shard_worker.gpu_substeps, world, 3, None, cap)
     for r in res:
         assert r["shared_blocks"] > 0, "the ranks' particle ranges must overlap in some grid blocks for this test to mean anything"
         assert r["status"] == 0
@@ -65,6 +67,6 @@ def test_sharded_frame_matches_the_single_process_frame():
     for r in res:
         assert abs(r["loss"] - r["ref_loss"]) <= 1e-3 * abs(r["ref_loss"]) + 1e-9, r
         assert r["x_err"] < 1e-5 and r["F_err"] < 1e-5, r
-        assert r["v0_err"] < 2e-3, r
-        for e, m in zip(r["grad_err"], r["grad_mag"]):
-            assert e < 5e-3 or m < 1e-12, r
+        # render gradients of this small scene carry ~1e-3 of atomics-order noise even between two unsharded runs
+        assert r["v0_err"] < 5e-3, r
+        assert max(r["grad_err"]) < 2e-3 and min(r["grad_mag"]) > 1e-9, r
