@@ -14,7 +14,6 @@
 // Blocks that only one rank touches never leave that rank: it alone gathers from them.
 #include "nm_common.h"
 #include <limits.h>
-#include <stdlib.h>
 #include <rocprim/rocprim.hpp>
 
 struct SharedWs {
@@ -185,8 +184,7 @@ extern "C" int nm_mpm_shared_blocks(nm_mpm* h, const int32_t* gathered, int32_t 
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   const int total = world * (1 + cap);
-  static const int fused_max = getenv("NM_SHARED_FUSED_MAX") ? atoi(getenv("NM_SHARED_FUSED_MAX")) : NM_SHARED_FUSED_MAX;
-  if (total <= fused_max) {
+  if (total <= NM_SHARED_FUSED_MAX) {
     NM_LAUNCH(k_shared_fused, dim3(1), dim3(1024), 0, s, gathered, total, world, cap, v.nblocks, cnt, pos, shared, cap_shared,
                        v.flags, v.epoch, status);
     NM_LAUNCH_CHECK();

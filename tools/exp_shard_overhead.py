@@ -12,11 +12,12 @@ from neuma_amd import synth
 from neuma_amd.harness import SceneRuntime
 
 name = sys.argv[1] if len(sys.argv) > 1 else "metric"
+npart = int(sys.argv[2]) if len(sys.argv) > 2 else None       # e.g. 12500: what one of 8 ranks would hold
 dev = torch.device("cuda", 0)
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29544")
 os.environ["NEUMA_SHARD_FORCE"] = "1"
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-scene = synth.make_scene(name)
+scene = synth.make_scene(name, override=dict(N=npart, K=1000) if npart else None)
 for shard in (False, True, False, True):
     rt = SceneRuntime(scene, dev, fused=False, shard_sim=shard)
     rw = rt.rows
@@ -42,5 +43,5 @@ for shard in (False, True, False, True):
             fn()
         torch.cuda.synchronize()
         out.append(1e6 * (time.perf_counter() - t0) / reps / rt.S)
-    print(f"{name} shard={shard}: {out[0]:.1f} us/substep fwd, {out[1]:.1f} us/substep fwd+bwd", flush=True)
+    print(f"{name} N={rt.N} shard={shard}: {out[0]:.1f} us/substep fwd, {out[1]:.1f} us/substep fwd+bwd", flush=True)
 dist.destroy_process_group()
