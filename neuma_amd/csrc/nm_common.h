@@ -57,14 +57,6 @@ struct nm_mpm_view {   // what nm_shard.hip needs to see of a grid handle (valid
 };
 nm_mpm_view nm_mpm_get_view(nm_mpm* h);
 int nm_mpm_shared_counters(nm_mpm* h, int** cnt, int** pos);   // [nblocks] each: 0 / INT_MAX between exchanges
-int nm_mpm_backward_cached(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, const nm_particles* next,
-                           const nm_particles* gnext, nm_particles* gcur, const void* gridrec, int32_t cap_blocks, bool verified,
-                           void* stream);
-int nm_material_bwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* wperm,
-                           const float* gout, float* gF, float* wpart, int wmode, const float* trial_C, const int* enabled,
-                           float dt, int add_to_gF, void* stream);
-int nm_material_fwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* wperm, float* out,
-                           void* stream);
 int nm_material_prepare(const nm_mlp* w, float* wperm, void* stream);   // weights -> MFMA operand order, once per roll-out
 size_t nm_material_prepared_floats();
 int nm_material_wgrad_reduce(const float* wpart, int32_t n, float* gw0, float* gw1, float* gw2, int accumulate, void* stream);

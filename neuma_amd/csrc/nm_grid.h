@@ -1,0 +1,188 @@
+// Block-sparse grid pieces shared by the MPM kernels (nm_mpm.hip) and the constitutive kernels (nm_material.hip), which in
+// a roll-out perform the grid housekeeping of the following MPM substep in their prologue (GridPrologue below).
+#pragma once
+#include "nm_common.h"
+
+struct MpmK {
+  int G, Gp, nb;
+  float dt, dx, inv_dx, eps;
+  float gdt[3];
+  int bound, bc;
+  int dbg;
+  int maxpass;  // NM_DBG experiment switches (0 in production)
+};
+
+__device__ __forceinline__ void block_coords(int b, int nb, int lane, int& i, int& j, int& k) {
+  int bi = b / (nb * nb), r = b - bi * nb * nb;
+  int bj = r / nb, bk = r - bj * nb;
+  i = (bi << 2) | (lane >> 4);
+  j = (bj << 2) | ((lane >> 2) & 3);
+  k = (bk << 2) | (lane & 3);
+}
+
+// velocity before / after the boundary condition; returns the per-component pass mask
+__device__ __forceinline__ void grid_velocity(const MpmK& K, int i, int j, int k, const float4& a, float u[3], float mask[3]) {
+  if (a.w > 0.f) {  // mpm.py:382-385 / 411-414
+    float inv = 1.f / (a.w + K.eps);
+    u[0] = a.x * inv + K.gdt[0];
+    u[1] = a.y * inv + K.gdt[1];
+    u[2] = a.z * inv + K.gdt[2];
+  } else {
+    u[0] = K.gdt[0]; u[1] = K.gdt[1]; u[2] = K.gdt[2];
+  }
+  const int idx[3] = {i, j, k};
+  bool hit[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+    hit[c] = (idx[c] < K.bound && u[c] < 0.f) || (idx[c] >= K.G - K.bound && u[c] > 0.f);
+  if (K.bc == 0) {  // noslip: any hit zeroes the whole vector (sequential tests, mpm.py:416-427)
+    float m = (hit[0] || hit[1] || hit[2]) ? 0.f : 1.f;
+    mask[0] = mask[1] = mask[2] = m;
+  } else {          // freeslip: only that component (mpm.py:387-398)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) mask[c] = hit[c] ? 0.f : 1.f;
+  }
+}
+
+// A grid cache record (optional, one per substep of a roll-out): the active-block list and the scattered node values
+// {mv, m} of those blocks, so that the reverse sweep restores the grid instead of re-running p2g.
+//   int hdr[4]  (hdr[0] = number of blocks, -1 = record invalid because the substep touched more than `cap` blocks)
+//   int list[cap]   float4 gm[cap * 64]
+struct GridRec {
+  int* hdr;
+  int* list;
+  float4* gm;
+};
+
+// Zero the blocks the previous substep touched (all three node arrays) and CARRY the ones that still held mass over
+// into the new active list, stamped with the new epoch: particles move a fraction of a cell per substep, so p2g finds
+// nearly every block it touches already listed (one flag read) and the returning atomics of mark_block - which would
+// otherwise all hit the same counter in a burst - are left to the few blocks that are genuinely new.  Blocks that
+// lost their mass drop out here.  One returning atomic per wave reserves the list slots.  count_next is reset for the
+// substep after this one (nobody reads it now).  Called by workgroups wg = 0..nwg-1 of 256 threads.
+#define NM_CLEAR_WGS 64
+__device__ __forceinline__ void grid_clear_carry(float4* __restrict__ gm, float4* __restrict__ gv, float4* __restrict__ gg,
+                                                 const int* __restrict__ list_prev, const int* __restrict__ count_prev,
+                                                 int* __restrict__ list_now, int* __restrict__ count_now,
+                                                 int* __restrict__ count_next, int* __restrict__ flags, int epoch, int wg, int nwg) {
+  const int cnt = *count_prev;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nw = nwg * 4, w = wg * 4 + wave;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (wg == 0 && threadIdx.x == 0) *count_next = 0;
+  for (int li0 = w; li0 < cnt; li0 += nw * 64) {      // rounds of up to 64 blocks per wave (one keep-bit each)
+    unsigned long long keep = 0ull;
+    int it = 0;
+    for (int li = li0; li < cnt && it < 64; li += nw, ++it) {
+      const int node = (list_prev[li] << 6) + lane;
+      const bool has = gm[node].w > 0.f;
+      gm[node] = z;
+      gv[node] = z;
+      gg[node] = z;
+      if (__ballot(has) != 0ull) keep |= 1ull << it;
+    }
+    const int nkeep = __popcll(keep);
+    if (nkeep == 0) continue;
+    int pos = 0;
+    if (lane == 0) pos = atomicAdd(count_now, nkeep);
+    pos = __shfl(pos, 0, 64);
+    it = 0;
+    for (int li = li0; li < cnt && it < 64; li += nw, ++it) {
+      if ((keep >> it) & 1ull) {
+        if (lane == 0) {
+          const int b = list_prev[li];
+          list_now[pos] = b;
+          flags[b] = epoch;
+        }
+        ++pos;
+      }
+    }
+  }
+}
+
+// reverse sweep: rebuild {mv, m}, the post-grid-op velocities and the active list from a cache record
+__device__ __forceinline__ void grid_restore(const MpmK& K, const GridRec& rec, float4* __restrict__ gm, float4* __restrict__ gv,
+                                             int* __restrict__ list, int* __restrict__ count, int wg, int nwg) {
+  const int cnt = rec.hdr[0];
+  if (cnt < 0) return;   // invalid record: the p2g / grid_op launches that follow do the work
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (wg == 0 && threadIdx.x == 0) *count = cnt;
+  for (int li = wg * 4 + wave; li < cnt; li += nwg * 4) {
+    int b = rec.list[li];
+    int i, j, k;
+    block_coords(b, K.nb, lane, i, j, k);
+    int node = (b << 6) + lane;
+    float4 a = rec.gm[(li << 6) + lane];
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < K.G && j < K.G && k < K.G) {
+      float u[3], mk[3];
+      grid_velocity(K, i, j, k, a, u, mk);
+      out.x = u[0] * mk[0]; out.y = u[1] * mk[1]; out.z = u[2] * mk[2];
+    }
+    gm[node] = a;
+    gv[node] = out;
+    if (lane == 0) list[li] = b;
+  }
+}
+
+// Grid housekeeping a constitutive kernel of the fused roll-out performs before its own work, so that the substep does
+// not pay separate launches for it (each ~8 us of launch + dependent-load latency for ~1 MB of traffic):
+//   mode 1 (forward, in front of p2g): grid_clear_carry.
+//   mode 2 (verified reverse sweep, in front of the g2p adjoint): restore the substep's record AND zero what the
+//           previous substep of the sweep left behind, in one pass without ordering between workgroups: a block of the
+//           previous list that is also in the record (flags[b] == epoch - stamped by the previous substep's
+//           k_grid_op_bwd, which knows the next record) only has its adjoint scratch zeroed, because its {mv, m} and v
+//           are being overwritten by whichever workgroup restores it; a block that left the list is zeroed entirely.
+struct GridPrologue {
+  int mode;   // 0 = none
+  MpmK K;
+  float4 *gm, *gv, *gg;
+  const int *list_prev, *count_prev;
+  int *list_now, *count_now, *count_next;
+  int* flags;
+  int epoch;
+  GridRec rec;
+};
+
+__device__ __forceinline__ void grid_prologue(const GridPrologue& g, int wg, int nwg_all) {
+  if (g.mode == 0) return;
+  const int nwg = min(nwg_all, NM_CLEAR_WGS);
+  if (g.mode == 1) {
+    if (wg < nwg) grid_clear_carry(g.gm, g.gv, g.gg, g.list_prev, g.count_prev, g.list_now, g.count_now, g.count_next, g.flags,
+                                   g.epoch, wg, nwg);
+    return;
+  }
+  // mode 2: the first nwg workgroups sweep the previous list, the next nwg restore the record (a launch with fewer
+  // than 2*nwg workgroups lets every workgroup do a share of both)
+  const bool split = nwg_all >= 2 * nwg;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (!split || wg < nwg) {
+    const int sn = split ? nwg : nwg_all;
+    const int cnt = *g.count_prev;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (wg == 0 && threadIdx.x == 0) *g.count_next = 0;
+    for (int li = wg * 4 + wave; li < cnt; li += sn * 4) {
+      const int b = g.list_prev[li];
+      const int node = (b << 6) + lane;
+      g.gg[node] = z;
+      if (g.flags[b] != g.epoch) { g.gm[node] = z; g.gv[node] = z; }
+    }
+  }
+  if (!split) grid_restore(g.K, g.rec, g.gm, g.gv, g.list_now, g.count_now, wg, nwg_all);
+  else if (wg >= nwg && wg < 2 * nwg) grid_restore(g.K, g.rec, g.gm, g.gv, g.list_now, g.count_now, wg - nwg, nwg);
+}
+
+// ---- internal cross-file entry points of the fused roll-out (nm_rollout.hip)
+int nm_mpm_prologue_forward(nm_mpm* h, GridPrologue* g);
+int nm_mpm_prologue_backward(nm_mpm* h, const void* gridrec, int cap, GridPrologue* g);
+int nm_mpm_forward_prepared(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, nm_particles* next, void* gridrec,
+                            int32_t cap_blocks, void* stream);
+int nm_mpm_backward_cached(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, const nm_particles* next,
+                           const nm_particles* gnext, nm_particles* gcur, const void* gridrec, int32_t cap_blocks, bool verified,
+                           bool prepared, const void* stamp_rec, void* stream);
+// pro: grid housekeeping performed in the kernel's prologue (NULL = none)
+int nm_material_bwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* wperm,
+                           const float* gout, float* gF, float* wpart, int wmode, const float* trial_C, const int* enabled,
+                           float dt, int add_to_gF, const GridPrologue* pro, void* stream);
+int nm_material_fwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* wperm, float* out,
+                           const GridPrologue* pro, void* stream);

@@ -14,6 +14,7 @@
 // layouts, and forms the weight gradients as MFMA outer products over the particle index through two
 // small LDS transposes; per-workgroup partial sums are reduced by a second tiny kernel (deterministic).
 #include "nm_common.h"
+#include "nm_grid.h"
 #include <cstddef>
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -327,7 +328,7 @@ template <int KIND>
 __global__ void __launch_bounds__(256) k_material_fwd(int n, int q, float alpha, const float* __restrict__ F,
                                                       const float* __restrict__ w0, const float* __restrict__ w1,
                                                       const float* __restrict__ w2, const float* __restrict__ wperm,
-                                                      float* __restrict__ out) {
+                                                      float* __restrict__ out, GridPrologue pro) {
   __shared__ __attribute__((aligned(16))) float sP[NM_PERM_FWD];
   float *sP0 = sP, *sP1 = sP + 16 * 64, *sP2 = sP + 16 * 64 + 64 * 64;
   // per-wave buffers (features 64x17, outputs 64x9); before the main loop the same memory holds the raw weights
@@ -336,6 +337,7 @@ __global__ void __launch_bounds__(256) k_material_fwd(int n, int q, float alpha,
   float (*sZ)[64 * 17] = reinterpret_cast<float (*)[64 * 17]>(sBuf);
   float (*sY)[64 * 9] = reinterpret_cast<float (*)[64 * 9]>(sBuf + 4 * 64 * 17);
   NM_PH_DECL
+  grid_prologue(pro, blockIdx.x, gridDim.x);   // roll-out: the clear of the MPM substep that follows (nm_grid.h)
   if (wperm) {
     stage_permuted<NM_PERM_FWD>(wperm, sP);
   } else {
@@ -416,15 +418,17 @@ __global__ void __launch_bounds__(256) k_material_fwd(int n, int q, float alpha,
 
 // internal (fused roll-out): wperm != NULL -> weights come pre-permuted from nm_material_prepare
 int nm_material_fwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* wperm, float* out,
-                           void* stream) {
+                           const GridPrologue* pro, void* stream) {
   int grid, q;
   nm_wave_quota(n, grid, q);
   hipStream_t s = (hipStream_t)stream;
   const float *w0 = w ? w->w0 : nullptr, *w1 = w ? w->w1 : nullptr, *w2 = w ? w->w2 : nullptr;
+  GridPrologue gp;
+  if (pro) gp = *pro; else { memset(&gp, 0, sizeof(gp)); }
   if (kind == NM_ELASTICITY)
-    NM_LAUNCH(k_material_fwd<NM_ELASTICITY>, dim3(grid), dim3(256), 0, s, n, q, alpha, F, w0, w1, w2, wperm, out);
+    NM_LAUNCH(k_material_fwd<NM_ELASTICITY>, dim3(grid), dim3(256), 0, s, n, q, alpha, F, w0, w1, w2, wperm, out, gp);
   else
-    NM_LAUNCH(k_material_fwd<NM_PLASTICITY>, dim3(grid), dim3(256), 0, s, n, q, alpha, F, w0, w1, w2, wperm, out);
+    NM_LAUNCH(k_material_fwd<NM_PLASTICITY>, dim3(grid), dim3(256), 0, s, n, q, alpha, F, w0, w1, w2, wperm, out, gp);
   NM_LAUNCH_CHECK();
   return NM_OK;
 }
@@ -441,7 +445,7 @@ extern "C" int nm_material_fwd(int32_t n, int32_t kind, float alpha, const float
   NM_REQUIRE(kind == NM_ELASTICITY || kind == NM_PLASTICITY, "kind must be NM_ELASTICITY or NM_PLASTICITY");
   if (n == 0) return NM_OK;
   NM_REQUIRE(F && out && w && w->w0 && w->w1 && w->w2, "null pointer");
-  return nm_material_fwd_launch(n, kind, alpha, F, w, nullptr, out, stream);
+  return nm_material_fwd_launch(n, kind, alpha, F, w, nullptr, out, nullptr, stream);
 }
 
 // ---------------------------------------------------------------- backward
@@ -468,10 +472,11 @@ __global__ void __launch_bounds__(256, 1) k_material_bwd(int n, int q, float alp
                                                          const float* __restrict__ w0, const float* __restrict__ w1,
                                                          const float* __restrict__ w2, const float* __restrict__ wperm,
                                                          const float* __restrict__ gout, float* __restrict__ gF,
-                                                         float* __restrict__ wpart, int want_w, BwdFuse fz) {
+                                                         float* __restrict__ wpart, int want_w, BwdFuse fz, GridPrologue pro) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   BwdLds& L = *reinterpret_cast<BwdLds*>(smem_raw);
   NM_PH_DECL
+  grid_prologue(pro, blockIdx.x, gridDim.x);   // roll-out: grid restore + clear of the MPM adjoint that follows (nm_grid.h)
   if (wperm) {
     static_assert(offsetof(BwdLds, Z) == NM_PERM_ALL * sizeof(float), "P0..Q2 must be contiguous in operand order");
     stage_permuted<NM_PERM_ALL>(wperm, L.P0);
@@ -781,8 +786,10 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
 // 1: write this launch's per-workgroup partial sums to wpart, 2: add them to wpart.
 int nm_material_bwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* wperm,
                            const float* gout, float* gF, float* wpart, int wmode, const float* trial_C, const int* enabled,
-                           float dt, int add_to_gF, void* stream) {
+                           float dt, int add_to_gF, const GridPrologue* pro, void* stream) {
   BwdFuse fz = {trial_C, enabled, dt, add_to_gF};
+  GridPrologue gp;
+  if (pro) gp = *pro; else { memset(&gp, 0, sizeof(gp)); }
   hipStream_t s = (hipStream_t)stream;
   int grid, q;
   nm_wave_quota(n, grid, q);
@@ -797,10 +804,10 @@ int nm_material_bwd_launch(int32_t n, int32_t kind, float alpha, const float* F,
   const float *w0 = w ? w->w0 : nullptr, *w1 = w ? w->w1 : nullptr, *w2 = w ? w->w2 : nullptr;
   if (kind == NM_ELASTICITY)
     NM_LAUNCH(k_material_bwd<NM_ELASTICITY>, dim3(grid), dim3(256), sizeof(BwdLds), s, n, q, alpha, F, w0, w1, w2, wperm,
-                       gout, gF, wpart, wmode, fz);
+                       gout, gF, wpart, wmode, fz, gp);
   else
     NM_LAUNCH(k_material_bwd<NM_PLASTICITY>, dim3(grid), dim3(256), sizeof(BwdLds), s, n, q, alpha, F, w0, w1, w2, wperm,
-                       gout, gF, wpart, wmode, fz);
+                       gout, gF, wpart, wmode, fz, gp);
   NM_LAUNCH_CHECK();
   return NM_OK;
 }
@@ -849,7 +856,7 @@ extern "C" int nm_material_bwd_ex(int32_t n, int32_t kind, float alpha, const fl
     return NM_ERR_WORKSPACE;
   }
   int rc = nm_material_bwd_launch(n, kind, alpha, F, w, nullptr, gout, gF, (float*)workspace, want_w, nullptr, nullptr, 0.f, 0,
-                                  stream);
+                                  nullptr, stream);
   if (rc) return rc;
   if (want_w) return nm_material_wgrad_reduce((const float*)workspace, n, gw0, gw1, gw2, accumulate, stream);
   return NM_OK;

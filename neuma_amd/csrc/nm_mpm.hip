@@ -17,17 +17,9 @@
 //   * stencil nodes with an index >= G (reference: out-of-bounds access when x > 1-1.5dx) land in
 //     padding blocks whose velocity is defined as zero.
 #include "nm_common.h"
+#include "nm_grid.h"
 #include <stdlib.h>
 
-
-struct MpmK {
-  int G, Gp, nb;
-  float dt, dx, inv_dx, eps;
-  float gdt[3];
-  int bound, bc;
-  int dbg;
-  int maxpass;  // NM_DBG experiment switches (0 in production)
-};
 
 // experiment switches (tools/exp_*.py) exist only in -DNM_PHASES builds; in the shipped library they fold to constants
 #ifdef NM_PHASES
@@ -564,53 +556,11 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
 }
 
 // ---------------------------------------------------------------- kernels
-// Zero the blocks the previous substep touched (all three node arrays) and CARRY the ones that still held mass over
-// into the new active list, stamped with the new epoch: particles move a fraction of a cell per substep, so p2g finds
-// nearly every block it touches already listed (one flag read) and the returning atomics of mark_block - which would
-// otherwise all hit the same counter in a burst - are left to the few blocks that are genuinely new.  Blocks that
-// lost their mass drop out here.  One returning atomic per wave reserves the list slots.  count_next is reset for the
-// substep after this one (nobody reads it now).
-#define NM_CLEAR_WGS 64
 __global__ void __launch_bounds__(256) k_clear(float4* __restrict__ gm, float4* __restrict__ gv, float4* __restrict__ gg,
                                                const int* __restrict__ list_prev, const int* __restrict__ count_prev,
                                                int* __restrict__ list_now, int* __restrict__ count_now,
                                                int* __restrict__ count_next, int* __restrict__ flags, int epoch) {
-  const int cnt = *count_prev;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int nw = gridDim.x * 4, w = blockIdx.x * 4 + wave;
-  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (blockIdx.x == 0 && threadIdx.x == 0) *count_next = 0;
-  for (int li0 = w; li0 < cnt; li0 += nw * 64) {      // rounds of up to 64 blocks per wave (one keep-bit each)
-    unsigned long long keep = 0ull;
-    int it = 0;
-    for (int li = li0; li < cnt && it < 64; li += nw, ++it) {
-      const int node = (list_prev[li] << 6) + lane;
-      const bool has = gm[node].w > 0.f;
-      gm[node] = z;
-      gv[node] = z;
-      gg[node] = z;
-      if (__ballot(has) != 0ull) keep |= 1ull << it;
-    }
-    const int nkeep = __popcll(keep);
-    if (nkeep == 0) continue;
-    int pos = 0;
-#ifdef NM_PHASES
-    if (lane == 0) atomicAdd(&g_nm_markslow[3], nkeep);
-#endif
-    if (lane == 0) pos = atomicAdd(count_now, nkeep);
-    pos = __shfl(pos, 0, 64);
-    it = 0;
-    for (int li = li0; li < cnt && it < 64; li += nw, ++it) {
-      if ((keep >> it) & 1ull) {
-        if (lane == 0) {
-          const int b = list_prev[li];
-          list_now[pos] = b;
-          flags[b] = epoch;
-        }
-        ++pos;
-      }
-    }
-  }
+  grid_clear_carry(gm, gv, gg, list_prev, count_prev, list_now, count_now, count_next, flags, epoch, blockIdx.x, gridDim.x);
 }
 
 // mpm.py:321-371.  One particle per thread, 256 per workgroup.
@@ -651,47 +601,6 @@ __global__ void __launch_bounds__(NM_SC_T) k_p2g(MpmK K, int n, const float* __r
   wg_scatter<4>(K, en, st.b, gm, flags, list, count, epoch, L, contrib);
 }
 
-__device__ __forceinline__ void block_coords(int b, int nb, int lane, int& i, int& j, int& k) {
-  int bi = b / (nb * nb), r = b - bi * nb * nb;
-  int bj = r / nb, bk = r - bj * nb;
-  i = (bi << 2) | (lane >> 4);
-  j = (bj << 2) | ((lane >> 2) & 3);
-  k = (bk << 2) | (lane & 3);
-}
-
-// velocity before / after the boundary condition; returns the per-component pass mask
-__device__ __forceinline__ void grid_velocity(const MpmK& K, int i, int j, int k, const float4& a, float u[3], float mask[3]) {
-  if (a.w > 0.f) {  // mpm.py:382-385 / 411-414
-    float inv = 1.f / (a.w + K.eps);
-    u[0] = a.x * inv + K.gdt[0];
-    u[1] = a.y * inv + K.gdt[1];
-    u[2] = a.z * inv + K.gdt[2];
-  } else {
-    u[0] = K.gdt[0]; u[1] = K.gdt[1]; u[2] = K.gdt[2];
-  }
-  const int idx[3] = {i, j, k};
-  bool hit[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c)
-    hit[c] = (idx[c] < K.bound && u[c] < 0.f) || (idx[c] >= K.G - K.bound && u[c] > 0.f);
-  if (K.bc == 0) {  // noslip: any hit zeroes the whole vector (sequential tests, mpm.py:416-427)
-    float m = (hit[0] || hit[1] || hit[2]) ? 0.f : 1.f;
-    mask[0] = mask[1] = mask[2] = m;
-  } else {          // freeslip: only that component (mpm.py:387-398)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) mask[c] = hit[c] ? 0.f : 1.f;
-  }
-}
-
-// A grid cache record (optional, one per substep of a roll-out): the active-block list and the scattered node values
-// {mv, m} of those blocks, so that the reverse sweep restores the grid instead of re-running p2g.
-//   int hdr[4]  (hdr[0] = number of blocks, -1 = record invalid because the substep touched more than `cap` blocks)
-//   int list[cap]   float4 gm[cap * 64]
-struct GridRec {
-  int* hdr;
-  int* list;
-  float4* gm;
-};
 static inline size_t gridrec_list_bytes(int cap) { return ((size_t)cap * sizeof(int) + 255) & ~(size_t)255; }
 static inline size_t gridrec_bytes(int cap) { return 256 + gridrec_list_bytes(cap) + (size_t)cap * 64 * sizeof(float4); }
 static inline GridRec gridrec_at(void* base, int cap) {
@@ -735,36 +644,23 @@ __global__ void __launch_bounds__(256) k_grid_op(MpmK K, const float4* __restric
   }
 }
 
-// reverse sweep: rebuild {mv, m}, the post-grid-op velocities and the active list from a cache record
 __global__ void __launch_bounds__(256) k_grid_restore(MpmK K, GridRec rec, float4* __restrict__ gm, float4* __restrict__ gv,
                                                       int* __restrict__ list, int* __restrict__ count) {
-  const int cnt = rec.hdr[0];
-  if (cnt < 0) return;   // invalid record: the p2g / grid_op launches that follow do the work
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *count = cnt;
-  for (int li = blockIdx.x * 4 + wave; li < cnt; li += gridDim.x * 4) {
-    int b = rec.list[li];
-    int i, j, k;
-    block_coords(b, K.nb, lane, i, j, k);
-    int node = (b << 6) + lane;
-    float4 a = rec.gm[(li << 6) + lane];
-    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < K.G && j < K.G && k < K.G) {
-      float u[3], mk[3];
-      grid_velocity(K, i, j, k, a, u, mk);
-      out.x = u[0] * mk[0]; out.y = u[1] * mk[1]; out.z = u[2] * mk[2];
-    }
-    gm[node] = a;
-    gv[node] = out;
-    if (lane == 0) list[li] = b;
-  }
+  grid_restore(K, rec, gm, gv, list, count, blockIdx.x, gridDim.x);
 }
 
 // adjoint of grid_op: gg {vbar} -> {mvbar, mbar}
+// stamp != null (verified reverse sweep of a roll-out): also marks the blocks of the NEXT record of the sweep with the
+// epoch its restore will run under, which is what lets that restore share one pass with the clear (GridPrologue mode 2)
 __global__ void __launch_bounds__(256) k_grid_op_bwd(MpmK K, const float4* __restrict__ gm, float4* __restrict__ gg,
-                                                     const int* __restrict__ list, const int* __restrict__ count) {
+                                                     const int* __restrict__ list, const int* __restrict__ count,
+                                                     GridRec stamp, int stamp_epoch, int* __restrict__ flags) {
   const int cnt = *count;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (stamp.hdr) {
+    const int sc = stamp.hdr[0];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < sc; i += gridDim.x * blockDim.x) flags[stamp.list[i]] = stamp_epoch;
+  }
   for (int li = blockIdx.x * 4 + wave; li < cnt; li += gridDim.x * 4) {
     int b = list[li];
     int i, j, k;
@@ -1122,13 +1018,23 @@ static const int kSweepGrid = 512;  // workgroups for the active-block sweeps (g
 // clear + p2g + grid_op (shared by forward, backward-recompute and forward_extra).
 // save != null: the forward pass also writes a grid cache record.  restore != null: the reverse sweep restores the
 // grid from the record; p2g / grid_op are still enqueued but return at once unless the record is marked invalid.
-static int mpm_build_grid(nm_mpm* h, int n, const nm_statics* st, const nm_particles* cur, hipStream_t s, void* save = nullptr,
-                          const void* restore = nullptr, int cap = 0, bool restore_verified = false) {
-  const int prev = h->cur, now = (prev + 1) % 3, next = (prev + 2) % 3;
+static void mpm_rotate(nm_mpm* h, int& prev, int& now, int& next) {
+  prev = h->cur; now = (prev + 1) % 3; next = (prev + 2) % 3;
   h->epoch += 1;
-  NM_LAUNCH(k_clear, dim3(NM_CLEAR_WGS), dim3(256), 0, s, h->gm, h->gv, h->gg, h->list[prev], h->count + prev, h->list[now],
-                     h->count + now, h->count + next, h->flags, h->epoch);
-  NM_LAUNCH_CHECK();
+  h->cur = now;
+}
+
+static int mpm_build_grid(nm_mpm* h, int n, const nm_statics* st, const nm_particles* cur, hipStream_t s, void* save = nullptr,
+                          const void* restore = nullptr, int cap = 0, bool restore_verified = false, bool precleared = false) {
+  int prev, now, next;
+  if (precleared) {   // a GridPrologue (nm_mpm_prologue_forward) has rotated the lists and cleared the grid already
+    now = h->cur;
+  } else {
+    mpm_rotate(h, prev, now, next);
+    NM_LAUNCH(k_clear, dim3(NM_CLEAR_WGS), dim3(256), 0, s, h->gm, h->gv, h->gg, h->list[prev], h->count + prev, h->list[now],
+                       h->count + now, h->count + next, h->flags, h->epoch);
+    NM_LAUNCH_CHECK();
+  }
   GridRec none = {nullptr, nullptr, nullptr};
   GridRec srec = save ? gridrec_at(save, cap) : none;
   const int* skip = nullptr;
@@ -1137,10 +1043,7 @@ static int mpm_build_grid(nm_mpm* h, int n, const nm_statics* st, const nm_parti
     NM_LAUNCH(k_grid_restore, dim3(kSweepGrid), dim3(256), 0, s, h->k, rrec, h->gm, h->gv, h->list[now], h->count + now);
     NM_LAUNCH_CHECK();
     skip = rrec.hdr;
-    if (restore_verified) {   // the host has seen this record's header: it is valid, nothing to fall back to
-      h->cur = now;
-      return NM_OK;
-    }
+    if (restore_verified) return NM_OK;   // the host has seen this record's header: it is valid, nothing to fall back to
   }
   if (n > 0) {
     NM_LAUNCH(k_p2g, dim3(nm_div_up(n, NM_SC_T)), dim3(NM_SC_T), 0, s, h->k, n, st->vol, st->rho, st->enabled, cur->x,
@@ -1150,7 +1053,27 @@ static int mpm_build_grid(nm_mpm* h, int n, const nm_statics* st, const nm_parti
   NM_LAUNCH(k_grid_op, dim3(kSweepGrid), dim3(256), 0, s, h->k, h->gm, h->gv, h->list[now], h->count + now, srec, cap, skip,
             (int*)nullptr);
   NM_LAUNCH_CHECK();
-  h->cur = now;
+  return NM_OK;
+}
+
+// ---- roll-out only: the clear / restore of a substep rides in the prologue of the constitutive kernel in front of it
+int nm_mpm_prologue_forward(nm_mpm* h, GridPrologue* g) {
+  int prev, now, next;
+  mpm_rotate(h, prev, now, next);
+  g->mode = 1;
+  g->K = h->k;
+  g->gm = h->gm; g->gv = h->gv; g->gg = h->gg;
+  g->list_prev = h->list[prev]; g->count_prev = h->count + prev;
+  g->list_now = h->list[now]; g->count_now = h->count + now; g->count_next = h->count + next;
+  g->flags = h->flags; g->epoch = h->epoch;
+  g->rec.hdr = nullptr; g->rec.list = nullptr; g->rec.gm = nullptr;
+  return NM_OK;
+}
+int nm_mpm_prologue_backward(nm_mpm* h, const void* gridrec, int cap, GridPrologue* g) {
+  NM_REQUIRE(gridrec && cap > 0, "prologue restore needs a grid cache record");
+  nm_mpm_prologue_forward(h, g);
+  g->mode = 2;
+  g->rec = gridrec_at(const_cast<void*>(gridrec), cap);
   return NM_OK;
 }
 
@@ -1168,8 +1091,8 @@ extern "C" int nm_mpm_forward(nm_mpm* h, int32_t n, const nm_statics* st, const 
   return nm_mpm_forward_ex(h, n, st, cur, next, nullptr, 0, stream);
 }
 
-extern "C" int nm_mpm_forward_ex(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, nm_particles* next,
-                                 void* gridrec, int32_t cap_blocks, void* stream) {
+static int mpm_forward_impl(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, nm_particles* next,
+                            void* gridrec, int32_t cap_blocks, bool precleared, void* stream) {
   NM_REQUIRE(h, "null handle");
   NM_REQUIRE(!gridrec || cap_blocks > 0, "grid cache record without capacity");
   NM_REQUIRE(n >= 0, "negative particle count");
@@ -1179,14 +1102,23 @@ extern "C" int nm_mpm_forward_ex(nm_mpm* h, int32_t n, const nm_statics* st, con
   rc = check_particles(st, next, false);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  rc = mpm_build_grid(h, n, st, cur, s, gridrec, nullptr, cap_blocks);
+  rc = mpm_build_grid(h, n, st, cur, s, gridrec, nullptr, cap_blocks, false, precleared);
   if (rc) return rc;
-  if (n > 0) {
-    NM_LAUNCH(k_g2p, dim3(nm_div_up(n, 256)), dim3(256), 0, s, h->k, n, st->clip_bound, st->enabled, cur->x,
-                       cur->v, cur->C, cur->F, h->gv, next->x, next->v, next->C, next->F);
-    NM_LAUNCH_CHECK();
-  }
+  NM_LAUNCH(k_g2p, dim3(nm_div_up(n, 256)), dim3(256), 0, s, h->k, n, st->clip_bound, st->enabled, cur->x,
+                     cur->v, cur->C, cur->F, h->gv, next->x, next->v, next->C, next->F);
+  NM_LAUNCH_CHECK();
   return NM_OK;
+}
+
+extern "C" int nm_mpm_forward_ex(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, nm_particles* next,
+                                 void* gridrec, int32_t cap_blocks, void* stream) {
+  return mpm_forward_impl(h, n, st, cur, next, gridrec, cap_blocks, false, stream);
+}
+
+// roll-out: the grid was cleared by a GridPrologue (nm_mpm_prologue_forward) in the kernel launched just before
+int nm_mpm_forward_prepared(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, nm_particles* next, void* gridrec,
+                            int32_t cap_blocks, void* stream) {
+  return mpm_forward_impl(h, n, st, cur, next, gridrec, cap_blocks, true, stream);
 }
 
 extern "C" int nm_mpm_forward_extra(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, int32_t n_extra,
@@ -1218,12 +1150,15 @@ extern "C" int nm_mpm_backward(nm_mpm* h, int32_t n, const nm_statics* st, const
 extern "C" int nm_mpm_backward_ex(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur,
                                   const nm_particles* next, const nm_particles* gnext, nm_particles* gcur,
                                   const void* gridrec, int32_t cap_blocks, void* stream) {
-  return nm_mpm_backward_cached(h, n, st, cur, next, gnext, gcur, gridrec, cap_blocks, false, stream);
+  return nm_mpm_backward_cached(h, n, st, cur, next, gnext, gcur, gridrec, cap_blocks, false, false, nullptr, stream);
 }
 
+// verified: the host has seen the record's header (valid) - no fall-back launches.  prepared: a GridPrologue
+// (nm_mpm_prologue_backward) restored the grid in the kernel launched just before.  stamp_rec: record of the substep the
+// sweep visits next; its blocks get flagged for that substep's prologue.
 int nm_mpm_backward_cached(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, const nm_particles* next,
                            const nm_particles* gnext, nm_particles* gcur, const void* gridrec, int32_t cap_blocks, bool verified,
-                           void* stream) {
+                           bool prepared, const void* stamp_rec, void* stream) {
   NM_REQUIRE(h, "null handle");
   NM_REQUIRE(!gridrec || cap_blocks > 0, "grid cache record without capacity");
   NM_REQUIRE(n >= 0, "negative particle count");
@@ -1234,15 +1169,19 @@ int nm_mpm_backward_cached(nm_mpm* h, int32_t n, const nm_statics* st, const nm_
   NM_REQUIRE(gnext && gnext->x && gnext->v && gnext->C && gnext->F, "null incoming gradients");
   NM_REQUIRE(gcur && gcur->x && gcur->v && gcur->C && gcur->F && gcur->stress, "null outgoing gradients");
   hipStream_t s = (hipStream_t)stream;
-  rc = mpm_build_grid(h, n, st, cur, s, nullptr, gridrec, cap_blocks, verified && gridrec != nullptr);  // recompute (mpm.py:312-315) or restore
-  if (rc) return rc;
-  if (n == 0) return NM_OK;
+  if (!prepared) {
+    rc = mpm_build_grid(h, n, st, cur, s, nullptr, gridrec, cap_blocks, verified && gridrec != nullptr);  // recompute (mpm.py:312-315) or restore
+    if (rc) return rc;
+  }
   const int now = h->cur;
   const int nwg = nm_div_up(n, 256);
   NM_LAUNCH(k_g2p_bwd, dim3(nm_div_up(n, NM_SC_T)), dim3(NM_SC_T), 0, s, h->k, n, st->clip_bound, st->enabled, cur->x, cur->F, next->v,
                      next->C, gnext->x, gnext->v, gnext->C, gnext->F, h->gv, h->gg, gcur->x, gcur->F);
   NM_LAUNCH_CHECK();
-  NM_LAUNCH(k_grid_op_bwd, dim3(kSweepGrid), dim3(256), 0, s, h->k, h->gm, h->gg, h->list[now], h->count + now);
+  GridRec stamp = {nullptr, nullptr, nullptr};
+  if (stamp_rec) stamp = gridrec_at(const_cast<void*>(stamp_rec), cap_blocks);
+  NM_LAUNCH(k_grid_op_bwd, dim3(kSweepGrid), dim3(256), 0, s, h->k, h->gm, h->gg, h->list[now], h->count + now, stamp,
+                     h->epoch + 1, h->flags);
   NM_LAUNCH_CHECK();
   NM_LAUNCH(k_p2g_bwd, dim3(nwg), dim3(256), 0, s, h->k, n, st->vol, st->rho, st->enabled, cur->x, cur->v, cur->C,
                      cur->stress, h->gg, gcur->x, gcur->v, gcur->C, gcur->stress);
@@ -1349,7 +1288,9 @@ extern "C" int nm_mpm_backward_finish(nm_mpm* h, int32_t n, const nm_statics* st
   NM_REQUIRE(n >= 0, "negative particle count");
   hipStream_t s = (hipStream_t)stream;
   const int now = h->cur;
-  NM_LAUNCH(k_grid_op_bwd, dim3(kSweepGrid), dim3(256), 0, s, h->k, h->gm, h->gg, h->list[now], h->count + now);
+  GridRec nostamp = {nullptr, nullptr, nullptr};
+  NM_LAUNCH(k_grid_op_bwd, dim3(kSweepGrid), dim3(256), 0, s, h->k, h->gm, h->gg, h->list[now], h->count + now, nostamp, 0,
+                     h->flags);
   NM_LAUNCH_CHECK();
   if (n == 0) return NM_OK;
   int rc = check_particles(st, cur, true);

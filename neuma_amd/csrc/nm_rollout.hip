@@ -4,6 +4,7 @@
 // kept (132 B/particle), plus - optionally - each substep's touched grid blocks (the grid cache, see nm_mpm_forward_ex);
 // the trial deformation gradient and every MLP activation are recomputed.
 #include "nm_common.h"
+#include "nm_grid.h"
 
 #define NM_WTOT_ (64 * 13 + 64 * 64 + 9 * 64)
 
@@ -94,13 +95,17 @@ extern "C" int nm_rollout_forward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cf
   if (rc) return rc;
   for (int t = 0; t < cfg->substeps; ++t) {
     nm_particles cur = rec(states, n, t), nxt = rec(states, n, t + 1);
-    rc = nm_material_fwd_launch(n, NM_ELASTICITY, 0.f, cur.F, we, w.perm_e, cur.stress, stream);  // finetune.py:362
+    // the elasticity kernel also clears the grid for the substep that follows it (GridPrologue mode 1, nm_grid.h)
+    GridPrologue pro;
+    rc = nm_mpm_prologue_forward(h, &pro);
+    if (rc) return rc;
+    rc = nm_material_fwd_launch(n, NM_ELASTICITY, 0.f, cur.F, we, w.perm_e, cur.stress, &pro, stream);  // finetune.py:362
     if (rc) return rc;
     nm_particles out = nxt;
     out.F = w.ftrial;
-    rc = nm_mpm_forward_ex(h, n, st, &cur, &out, grid_rec(gridcache, cfg, t), cfg->grid_cache_blocks, stream);  // finetune.py:363
+    rc = nm_mpm_forward_prepared(h, n, st, &cur, &out, grid_rec(gridcache, cfg, t), cfg->grid_cache_blocks, stream);  // finetune.py:363
     if (rc) return rc;
-    rc = nm_material_fwd_launch(n, NM_PLASTICITY, cfg->plasticity_alpha, w.ftrial, wp, w.perm_p, nxt.F, stream);  // finetune.py:364
+    rc = nm_material_fwd_launch(n, NM_PLASTICITY, cfg->plasticity_alpha, w.ftrial, wp, w.perm_p, nxt.F, nullptr, stream);  // finetune.py:364
     if (rc) return rc;
   }
   return NM_OK;
@@ -136,8 +141,18 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
     float* gout = (t == 0) ? gstate_first : ((gin == w.ga) ? w.gb : w.ga);
     // plasticity backward on the trial F of this step (recomputed in-kernel from the checkpoints): dL/dF_{t+1} -> dL/dFtrial
     const int wmode = (t == cfg->substeps - 1) ? 1 : 2;   // first visit writes the partials, later ones add
+    // verified sweep: from the second substep on, the plasticity kernel also restores the grid of this substep and clears
+    // what the previous one left (GridPrologue mode 2; the block flags it relies on were set by that substep's
+    // k_grid_op_bwd).  The first substep of the sweep, and unverified sweeps, use the stand-alone launches.
+    const bool verified = cfg->cache_verified != 0 && gridcache != nullptr && cfg->grid_cache_blocks > 0;
+    const bool prepared = verified && t < cfg->substeps - 1;
+    GridPrologue pro;
+    if (prepared) {
+      rc = nm_mpm_prologue_backward(h, grid_rec(gridcache, cfg, t), cfg->grid_cache_blocks, &pro);
+      if (rc) return rc;
+    }
     rc = nm_material_bwd_launch(n, NM_PLASTICITY, cfg->plasticity_alpha, cur.F, wp, w.perm_p, gin + 15 * N, w.gFtr, w.part_p, wmode,
-                                nxt.C, st->enabled, nm_mpm_get_dt(h), 0, stream);
+                                nxt.C, st->enabled, nm_mpm_get_dt(h), 0, prepared ? &pro : nullptr, stream);
     if (rc) return rc;
     // sim backward (stress of this step was checkpointed by the forward pass)
     nm_particles gn, gc;
@@ -145,11 +160,12 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
     gn.F = w.gFtr; gn.stress = nullptr;
     gc.x = gout; gc.v = gout + 3 * N; gc.C = gout + 6 * N; gc.F = gout + 15 * N; gc.stress = w.gS;
     rc = nm_mpm_backward_cached(h, n, st, &cur, &nxt, &gn, &gc, grid_rec(gridcache, cfg, t), cfg->grid_cache_blocks,
-                                cfg->cache_verified != 0, stream);
+                                cfg->cache_verified != 0, prepared, (verified && t > 0) ? grid_rec(gridcache, cfg, t - 1) : nullptr,
+                                stream);
     if (rc) return rc;
     // elasticity backward: dL/dstress -> dL/dF (added to the sim's dL/dF)
     rc = nm_material_bwd_launch(n, NM_ELASTICITY, 0.f, cur.F, we, w.perm_e, w.gS, gc.F, w.part_e, wmode, nullptr, nullptr, 0.f, 1,
-                                stream);
+                                nullptr, stream);
     if (rc) return rc;
     gin = gout;
   }

@@ -133,16 +133,29 @@ def test_grid_cache_restores_the_same_grid_as_the_recompute():
     blocks, _ = (rt.rollout(rt.x0, rt.v0, rt.C0, F0), rt.model.grid_stats())[1]
     assert blocks > 1
     res = {}
-    for tag, cap in (("off", 0), ("ample", 4 * blocks), ("overflow", 1), ("auto", None)):
+    import neuma_amd.rollout as ro
+    # "verified": the record headers have reached the host before the backward pass starts, so the reverse sweep runs
+    # without fall-back launches and, from its second substep on, restores the grid inside the plasticity kernel
+    # (GridPrologue mode 2); "unverified": header read-back switched off, every substep keeps the guarded launches
+    for tag, cap in (("off", 0), ("ample", 4 * blocks), ("verified", 4 * blocks), ("unverified", 4 * blocks), ("overflow", 1),
+                     ("auto", None)):
         rt.sim_fused._cache_blocks = cap
         if cap is None:      # auto: the first call sizes the cache, the second one uses it
             rt.rollout(rt.x0, rt.v0, rt.C0, F0)
             assert rt.sim_fused.grid_cache_blocks() == int(1.5 * blocks) + 64
         ins = [t.clone().requires_grad_(True) for t in (rt.x0, rt.v0, rt.C0, F0)]
-        outs = rt.rollout(*ins)
+        was = ro._CACHE_STATUS
+        ro._CACHE_STATUS = tag != "unverified"
+        try:
+            outs = rt.rollout(*ins)
+        finally:
+            ro._CACHE_STATUS = was
         loss = sum((o * w.to(dev())).sum() for o, w in zip(outs, gws))
+        if tag == "verified":
+            torch.cuda.synchronize()
+            assert outs[0].grad_fn is not None
         res[tag] = torch.autograd.grad(loss, ins + params)
-    for tag in ("ample", "overflow", "auto"):
+    for tag in ("ample", "verified", "unverified", "overflow", "auto"):
         for a, b in zip(res[tag], res["off"]):
             assert torch.isfinite(a).all()
             assert rel_max(a, b) < 2e-4, tag
