@@ -135,6 +135,7 @@ __device__ __forceinline__ void grid_restore(const MpmK& K, const GridRec& rec, 
 //           are being overwritten by whichever workgroup restores it; a block that left the list is zeroed entirely.
 struct GridPrologue {
   int mode;   // 0 = none
+  int mat_grid;   // set by the constitutive launcher: workgroups that carry particles (the rest only run the prologue)
   MpmK K;
   float4 *gm, *gv, *gg;
   const int *list_prev, *count_prev;

@@ -34,6 +34,22 @@ extern "C" int nm_debug_phases(long long* out, int n) {
 #define NM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 #define NM_BWD_GRID 256   // workgroups of the constitutive kernels = CUs
+// A GridPrologue runs on NM_PRO_WGS extra workgroups (blockIdx >= pro.mat_grid) when the constitutive work leaves that many
+// CUs idle - at 100k particles it fills 224 of 256 - so that its dependent-load chain delays nobody; otherwise the first
+// workgroups do it before their own particles.  Evaluates to true for a workgroup that has nothing else to do.
+#define NM_PRO_WGS 32
+#define NM_PROLOGUE_SPLIT(pro) material_prologue(pro)
+__device__ __forceinline__ bool material_prologue(const GridPrologue& pro) {
+  if (pro.mode == 0) return false;
+  const int mat = pro.mat_grid;
+  if ((int)gridDim.x > mat) {
+    if ((int)blockIdx.x < mat) return false;
+    grid_prologue(pro, blockIdx.x - mat, gridDim.x - mat);
+    return true;
+  }
+  grid_prologue(pro, blockIdx.x, gridDim.x);
+  return false;
+}
 #define NM_W0 (64 * 13)
 #define NM_W1 (64 * 64)
 #define NM_W2 (9 * 64)
@@ -337,7 +353,8 @@ __global__ void __launch_bounds__(256) k_material_fwd(int n, int q, float alpha,
   float (*sZ)[64 * 17] = reinterpret_cast<float (*)[64 * 17]>(sBuf);
   float (*sY)[64 * 9] = reinterpret_cast<float (*)[64 * 9]>(sBuf + 4 * 64 * 17);
   NM_PH_DECL
-  grid_prologue(pro, blockIdx.x, gridDim.x);   // roll-out: the clear of the MPM substep that follows (nm_grid.h)
+  // roll-out: the clear of the MPM substep that follows (nm_grid.h) - on workgroups of its own when CUs are to spare
+  if (NM_PROLOGUE_SPLIT(pro)) return;
   if (wperm) {
     stage_permuted<NM_PERM_FWD>(wperm, sP);
   } else {
@@ -425,10 +442,12 @@ int nm_material_fwd_launch(int32_t n, int32_t kind, float alpha, const float* F,
   const float *w0 = w ? w->w0 : nullptr, *w1 = w ? w->w1 : nullptr, *w2 = w ? w->w2 : nullptr;
   GridPrologue gp;
   if (pro) gp = *pro; else { memset(&gp, 0, sizeof(gp)); }
+  gp.mat_grid = grid;
+  const int launch = (pro && grid + NM_PRO_WGS <= NM_BWD_GRID) ? grid + NM_PRO_WGS : grid;
   if (kind == NM_ELASTICITY)
-    NM_LAUNCH(k_material_fwd<NM_ELASTICITY>, dim3(grid), dim3(256), 0, s, n, q, alpha, F, w0, w1, w2, wperm, out, gp);
+    NM_LAUNCH(k_material_fwd<NM_ELASTICITY>, dim3(launch), dim3(256), 0, s, n, q, alpha, F, w0, w1, w2, wperm, out, gp);
   else
-    NM_LAUNCH(k_material_fwd<NM_PLASTICITY>, dim3(grid), dim3(256), 0, s, n, q, alpha, F, w0, w1, w2, wperm, out, gp);
+    NM_LAUNCH(k_material_fwd<NM_PLASTICITY>, dim3(launch), dim3(256), 0, s, n, q, alpha, F, w0, w1, w2, wperm, out, gp);
   NM_LAUNCH_CHECK();
   return NM_OK;
 }
@@ -476,7 +495,8 @@ __global__ void __launch_bounds__(256, 1) k_material_bwd(int n, int q, float alp
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   BwdLds& L = *reinterpret_cast<BwdLds*>(smem_raw);
   NM_PH_DECL
-  grid_prologue(pro, blockIdx.x, gridDim.x);   // roll-out: grid restore + clear of the MPM adjoint that follows (nm_grid.h)
+  // roll-out: grid restore + clear of the MPM adjoint that follows (nm_grid.h) - on workgroups of its own when CUs are to spare
+  if (NM_PROLOGUE_SPLIT(pro)) return;
   if (wperm) {
     static_assert(offsetof(BwdLds, Z) == NM_PERM_ALL * sizeof(float), "P0..Q2 must be contiguous in operand order");
     stage_permuted<NM_PERM_ALL>(wperm, L.P0);
@@ -793,6 +813,8 @@ int nm_material_bwd_launch(int32_t n, int32_t kind, float alpha, const float* F,
   hipStream_t s = (hipStream_t)stream;
   int grid, q;
   nm_wave_quota(n, grid, q);
+  gp.mat_grid = grid;
+  const int launch = (pro && grid + NM_PRO_WGS <= NM_BWD_GRID) ? grid + NM_PRO_WGS : grid;
   static bool attr_set = false;
   if (!attr_set) {
     NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd<NM_ELASTICITY>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -803,10 +825,10 @@ int nm_material_bwd_launch(int32_t n, int32_t kind, float alpha, const float* F,
   }
   const float *w0 = w ? w->w0 : nullptr, *w1 = w ? w->w1 : nullptr, *w2 = w ? w->w2 : nullptr;
   if (kind == NM_ELASTICITY)
-    NM_LAUNCH(k_material_bwd<NM_ELASTICITY>, dim3(grid), dim3(256), sizeof(BwdLds), s, n, q, alpha, F, w0, w1, w2, wperm,
+    NM_LAUNCH(k_material_bwd<NM_ELASTICITY>, dim3(launch), dim3(256), sizeof(BwdLds), s, n, q, alpha, F, w0, w1, w2, wperm,
                        gout, gF, wpart, wmode, fz, gp);
   else
-    NM_LAUNCH(k_material_bwd<NM_PLASTICITY>, dim3(grid), dim3(256), sizeof(BwdLds), s, n, q, alpha, F, w0, w1, w2, wperm,
+    NM_LAUNCH(k_material_bwd<NM_PLASTICITY>, dim3(launch), dim3(256), sizeof(BwdLds), s, n, q, alpha, F, w0, w1, w2, wperm,
                        gout, gF, wpart, wmode, fz, gp);
   NM_LAUNCH_CHECK();
   return NM_OK;
