@@ -44,6 +44,114 @@ __device__ __forceinline__ void grid_velocity(const MpmK& K, int i, int j, int k
   }
 }
 
+__device__ __forceinline__ int node_addr(int i, int j, int k, int nb) {
+  return ((((i >> 2) * nb + (j >> 2)) * nb + (k >> 2)) << 6) | ((i & 3) << 4) | ((j & 3) << 2) | (k & 3);
+}
+
+struct Stencil {
+  int b[3];
+  float f[3];
+  float w[3][3];   // w[axis][i]
+  float dw[3][3];  // d w[axis][i] / d f
+};
+
+__device__ __forceinline__ void make_stencil(const MpmK& K, const float* __restrict__ xp, Stencil& s) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float px = xp[a] * K.inv_dx;
+    int b = (int)(px - 0.5f);  // C cast: truncation toward zero (mpm.py:337-339)
+    b = max(0, min(b, K.Gp - 3));
+    float f = px - (float)b;
+    s.b[a] = b;
+    s.f[a] = f;
+    float wa = 1.5f - f, wb = f - 1.0f, wc = f - 0.5f;
+    s.w[a][0] = wa * wa * 0.5f;
+    s.w[a][1] = 0.75f - wb * wb;
+    s.w[a][2] = wc * wc * 0.5f;
+    s.dw[a][0] = -wa;
+    s.dw[a][1] = -2.f * wb;
+    s.dw[a][2] = wc;
+  }
+}
+
+__device__ __forceinline__ float sel3(const float* a, int i) { return i == 0 ? a[0] : (i == 1 ? a[1] : a[2]); }
+
+
+// mpm.py:432-498 for one particle: gather v and C' from the 27 stencil nodes, advance x (clamped), return the trial
+// deformation gradient (I + dt C') F in Fo.  Disabled particles pass their state through (mpm.py:443-444).  UNROLL: all 27
+// gathers in flight (for callers that run one wave per SIMD); otherwise nine per trip, which keeps k_g2p at 4+ waves/SIMD.
+template <bool UNROLL>
+__device__ __forceinline__ void g2p_particle(const MpmK& K, int p, const float* __restrict__ clip, const int* __restrict__ enabled,
+                                             const float* x, const float* v, const float* C, const float* F,
+                                             const float4* __restrict__ gv, float* xn, float* vn, float* Cn, M3& Fo) {
+  if (enabled[p] == 0) {
+    Fo = m3_load(F + 9 * p);
+    if (xn != x) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { xn[3 * p + a] = x[3 * p + a]; vn[3 * p + a] = v[3 * p + a]; }
+#pragma unroll
+      for (int a = 0; a < 9; ++a) Cn[9 * p + a] = C[9 * p + a];
+    }
+    return;
+  }
+  float xp[3] = {x[3 * p], x[3 * p + 1], x[3 * p + 2]};
+  Stencil st;
+  make_stencil(K, xp, st);
+  float nv[3] = {0.f, 0.f, 0.f};
+  M3 nC = m3_zero();
+  const float kap = 4.0f * K.inv_dx * K.inv_dx;
+  auto slab = [&](int i) {
+    float d0 = ((float)i - st.f[0]) * K.dx;
+    const float w0i = sel3(st.w[0], i);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float d1 = ((float)j - st.f[1]) * K.dx;
+      float wij = w0i * st.w[1][j];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float d2 = ((float)k - st.f[2]) * K.dx;
+        float w = wij * st.w[2][k];
+        float4 g = gv[node_addr(st.b[0] + i, st.b[1] + j, st.b[2] + k, K.nb)];
+        nv[0] += w * g.x; nv[1] += w * g.y; nv[2] += w * g.z;
+        float kw = kap * w;  // mpm.py:479: (4 w inv_dx^2) outer(v, dpos)
+        nC.m[0] += kw * g.x * d0; nC.m[1] += kw * g.x * d1; nC.m[2] += kw * g.x * d2;
+        nC.m[3] += kw * g.y * d0; nC.m[4] += kw * g.y * d1; nC.m[5] += kw * g.y * d2;
+        nC.m[6] += kw * g.z * d0; nC.m[7] += kw * g.z * d1; nC.m[8] += kw * g.z * d2;
+      }
+    }
+  };
+  if (UNROLL) {
+    slab(0); slab(1); slab(2);
+  } else {
+#pragma unroll 1
+    for (int i = 0; i < 3; ++i) slab(i);
+  }
+  M3 Fp = m3_load(F + 9 * p);
+  M3 T = nC;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) T.m[i] *= K.dt;
+  T.m[0] += 1.f; T.m[4] += 1.f; T.m[8] += 1.f;
+  Fo = m3_mul(T, Fp);  // mpm.py:489
+  float bnd = clip[p] * K.dx;
+  float lo = 0.0f + bnd, hi = 1.0f - bnd;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float t = xp[a] + K.dt * nv[a];
+    xn[3 * p + a] = fminf(fmaxf(t, lo), hi);  // wp.clamp, mpm.py:491-497
+    vn[3 * p + a] = nv[a];
+  }
+  m3_store(Cn + 9 * p, nC);
+}
+
+// g2p of the substep fused into the plasticity kernel that consumes its trial F (roll-out forward): gv == NULL -> off
+struct G2pFuse {
+  const float4* gv;
+  MpmK K;
+  const float *clip; const int* enabled;
+  const float *x, *v, *C, *F;
+  float *xn, *vn, *Cn;
+};
+
 // A grid cache record (optional, one per substep of a roll-out): the active-block list and the scattered node values
 // {mv, m} of those blocks, so that the reverse sweep restores the grid instead of re-running p2g.
 //   int hdr[4]  (hdr[0] = number of blocks, -1 = record invalid because the substep touched more than `cap` blocks)
@@ -186,4 +294,8 @@ int nm_material_bwd_launch(int32_t n, int32_t kind, float alpha, const float* F,
                            const float* gout, float* gF, float* wpart, int wmode, const float* trial_C, const int* enabled,
                            float dt, int add_to_gF, const GridPrologue* pro, void* stream);
 int nm_material_fwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* wperm, float* out,
-                           const GridPrologue* pro, void* stream);
+                           const GridPrologue* pro, const G2pFuse* g2p, void* stream);
+// g2p fused into the next constitutive kernel (roll-out forward): fills the descriptor / runs the substep without its g2p
+int nm_mpm_g2p_fuse(nm_mpm* h, const nm_statics* st, const nm_particles* cur, nm_particles* next, G2pFuse* f);
+int nm_mpm_forward_prepared_nog2p(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, void* gridrec,
+                                  int32_t cap_blocks, void* stream);

@@ -344,7 +344,7 @@ template <int KIND>
 __global__ void __launch_bounds__(256) k_material_fwd(int n, int q, float alpha, const float* __restrict__ F,
                                                       const float* __restrict__ w0, const float* __restrict__ w1,
                                                       const float* __restrict__ w2, const float* __restrict__ wperm,
-                                                      float* __restrict__ out, GridPrologue pro) {
+                                                      float* __restrict__ out, GridPrologue pro, G2pFuse gf) {
   __shared__ __attribute__((aligned(16))) float sP[NM_PERM_FWD];
   float *sP0 = sP, *sP1 = sP + 16 * 64, *sP2 = sP + 16 * 64 + 64 * 64;
   // per-wave buffers (features 64x17, outputs 64x9); before the main loop the same memory holds the raw weights
@@ -375,7 +375,12 @@ __global__ void __launch_bounds__(256) k_material_fwd(int n, int q, float alpha,
     const int p = c0 + lane;
     const bool valid = p < pend;
     const int ntile = (min(64, pend - c0) + 15) >> 4;
-    M3 Fp = valid ? m3_load(F + 9 * p) : m3_ident();
+    M3 Fp = m3_ident();
+    if (gf.gv) {     // roll-out: this kernel performs the substep's g2p and takes the trial F straight from it
+      if (valid) g2p_particle<true>(gf.K, p, gf.clip, gf.enabled, gf.x, gf.v, gf.C, gf.F, gf.gv, gf.xn, gf.vn, gf.Cn, Fp);
+    } else if (valid) {
+      Fp = m3_load(F + 9 * p);
+    }
     M3 R, U, V;
     float z[13], s[3];
     nm_features(Fp, z, R, U, V, s);
@@ -435,19 +440,21 @@ __global__ void __launch_bounds__(256) k_material_fwd(int n, int q, float alpha,
 
 // internal (fused roll-out): wperm != NULL -> weights come pre-permuted from nm_material_prepare
 int nm_material_fwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* wperm, float* out,
-                           const GridPrologue* pro, void* stream) {
+                           const GridPrologue* pro, const G2pFuse* g2p, void* stream) {
   int grid, q;
   nm_wave_quota(n, grid, q);
   hipStream_t s = (hipStream_t)stream;
   const float *w0 = w ? w->w0 : nullptr, *w1 = w ? w->w1 : nullptr, *w2 = w ? w->w2 : nullptr;
   GridPrologue gp;
   if (pro) gp = *pro; else { memset(&gp, 0, sizeof(gp)); }
+  G2pFuse gf;
+  if (g2p) gf = *g2p; else { memset(&gf, 0, sizeof(gf)); }
   gp.mat_grid = grid;
   const int launch = (pro && grid + NM_PRO_WGS <= NM_BWD_GRID) ? grid + NM_PRO_WGS : grid;
   if (kind == NM_ELASTICITY)
-    NM_LAUNCH(k_material_fwd<NM_ELASTICITY>, dim3(launch), dim3(256), 0, s, n, q, alpha, F, w0, w1, w2, wperm, out, gp);
+    NM_LAUNCH(k_material_fwd<NM_ELASTICITY>, dim3(launch), dim3(256), 0, s, n, q, alpha, F, w0, w1, w2, wperm, out, gp, gf);
   else
-    NM_LAUNCH(k_material_fwd<NM_PLASTICITY>, dim3(launch), dim3(256), 0, s, n, q, alpha, F, w0, w1, w2, wperm, out, gp);
+    NM_LAUNCH(k_material_fwd<NM_PLASTICITY>, dim3(launch), dim3(256), 0, s, n, q, alpha, F, w0, w1, w2, wperm, out, gp, gf);
   NM_LAUNCH_CHECK();
   return NM_OK;
 }
@@ -464,7 +471,7 @@ extern "C" int nm_material_fwd(int32_t n, int32_t kind, float alpha, const float
   NM_REQUIRE(kind == NM_ELASTICITY || kind == NM_PLASTICITY, "kind must be NM_ELASTICITY or NM_PLASTICITY");
   if (n == 0) return NM_OK;
   NM_REQUIRE(F && out && w && w->w0 && w->w1 && w->w2, "null pointer");
-  return nm_material_fwd_launch(n, kind, alpha, F, w, nullptr, out, nullptr, stream);
+  return nm_material_fwd_launch(n, kind, alpha, F, w, nullptr, out, nullptr, nullptr, stream);
 }
 
 // ---------------------------------------------------------------- backward

@@ -44,38 +44,6 @@ struct nm_mpm {
   int* sh_pos;
 };
 
-__device__ __forceinline__ int node_addr(int i, int j, int k, int nb) {
-  return ((((i >> 2) * nb + (j >> 2)) * nb + (k >> 2)) << 6) | ((i & 3) << 4) | ((j & 3) << 2) | (k & 3);
-}
-
-struct Stencil {
-  int b[3];
-  float f[3];
-  float w[3][3];   // w[axis][i]
-  float dw[3][3];  // d w[axis][i] / d f
-};
-
-__device__ __forceinline__ void make_stencil(const MpmK& K, const float* __restrict__ xp, Stencil& s) {
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    float px = xp[a] * K.inv_dx;
-    int b = (int)(px - 0.5f);  // C cast: truncation toward zero (mpm.py:337-339)
-    b = max(0, min(b, K.Gp - 3));
-    float f = px - (float)b;
-    s.b[a] = b;
-    s.f[a] = f;
-    float wa = 1.5f - f, wb = f - 1.0f, wc = f - 0.5f;
-    s.w[a][0] = wa * wa * 0.5f;
-    s.w[a][1] = 0.75f - wb * wb;
-    s.w[a][2] = wc * wc * 0.5f;
-    s.dw[a][0] = -wa;
-    s.dw[a][1] = -2.f * wb;
-    s.dw[a][2] = wc;
-  }
-}
-
-__device__ __forceinline__ float sel3(const float* a, int i) { return i == 0 ? a[0] : (i == 1 ? a[1] : a[2]); }
-
 #ifdef NM_PHASES
 __device__ int g_nm_markslow[4];
 extern "C" int nm_debug_markslow(int* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nm_markslow), 16) == hipSuccess ? 0 : -2; }
@@ -683,64 +651,15 @@ __global__ void __launch_bounds__(256) k_grid_op_bwd(MpmK K, const float4* __res
   }
 }
 
-// mpm.py:432-498
+// mpm.py:432-498 (body: g2p_particle, nm_grid.h)
 __global__ void __launch_bounds__(256, 4) k_g2p(MpmK K, int n, const float* __restrict__ clip, const int* __restrict__ enabled,
                                              const float* x, const float* v, const float* C, const float* F,
                                              const float4* __restrict__ gv, float* xn, float* vn, float* Cn, float* Fn) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
-  if (enabled[p] == 0) {  // reference skips the particle (mpm.py:443-444); pass the state through
-    if (xn != x) {
-#pragma unroll
-      for (int a = 0; a < 3; ++a) { xn[3 * p + a] = x[3 * p + a]; vn[3 * p + a] = v[3 * p + a]; }
-#pragma unroll
-      for (int a = 0; a < 9; ++a) { Cn[9 * p + a] = C[9 * p + a]; Fn[9 * p + a] = F[9 * p + a]; }
-    }
-    return;
-  }
-  float xp[3] = {x[3 * p], x[3 * p + 1], x[3 * p + 2]};
-  Stencil st;
-  make_stencil(K, xp, st);
-  float nv[3] = {0.f, 0.f, 0.f};
-  M3 nC = m3_zero();
-  const float kap = 4.0f * K.inv_dx * K.inv_dx;
-#pragma unroll 1
-  for (int i = 0; i < 3; ++i) {  // rolled: nine gathers in flight per trip keeps the kernel at 4+ waves/SIMD
-    float d0 = ((float)i - st.f[0]) * K.dx;
-    const float w0i = sel3(st.w[0], i);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      float d1 = ((float)j - st.f[1]) * K.dx;
-      float wij = w0i * st.w[1][j];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        float d2 = ((float)k - st.f[2]) * K.dx;
-        float w = wij * st.w[2][k];
-        float4 g = gv[node_addr(st.b[0] + i, st.b[1] + j, st.b[2] + k, K.nb)];
-        nv[0] += w * g.x; nv[1] += w * g.y; nv[2] += w * g.z;
-        float kw = kap * w;  // mpm.py:479: (4 w inv_dx^2) outer(v, dpos)
-        nC.m[0] += kw * g.x * d0; nC.m[1] += kw * g.x * d1; nC.m[2] += kw * g.x * d2;
-        nC.m[3] += kw * g.y * d0; nC.m[4] += kw * g.y * d1; nC.m[5] += kw * g.y * d2;
-        nC.m[6] += kw * g.z * d0; nC.m[7] += kw * g.z * d1; nC.m[8] += kw * g.z * d2;
-      }
-    }
-  }
-  M3 Fp = m3_load(F + 9 * p);
-  M3 T = nC;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) T.m[i] *= K.dt;
-  T.m[0] += 1.f; T.m[4] += 1.f; T.m[8] += 1.f;
-  M3 Fo = m3_mul(T, Fp);  // mpm.py:489
-  float bnd = clip[p] * K.dx;
-  float lo = 0.0f + bnd, hi = 1.0f - bnd;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    float t = xp[a] + K.dt * nv[a];
-    xn[3 * p + a] = fminf(fmaxf(t, lo), hi);  // wp.clamp, mpm.py:491-497
-    vn[3 * p + a] = nv[a];
-  }
-  m3_store(Cn + 9 * p, nC);
-  m3_store(Fn + 9 * p, Fo);
+  M3 Fo;
+  g2p_particle<false>(K, p, clip, enabled, x, v, C, F, gv, xn, vn, Cn, Fo);
+  if (enabled[p] != 0 || Fn != F) m3_store(Fn + 9 * p, Fo);
 }
 
 // adjoint of g2p: writes gx (direct part), gF; scatters vbar into gg (same wave-tile scheme as p2g)
@@ -1099,11 +1018,14 @@ static int mpm_forward_impl(nm_mpm* h, int32_t n, const nm_statics* st, const nm
   if (n == 0) return NM_OK;  // empty input: nothing to scatter or gather
   int rc = check_particles(st, cur, true);
   if (rc) return rc;
-  rc = check_particles(st, next, false);
-  if (rc) return rc;
+  if (next) {
+    rc = check_particles(st, next, false);
+    if (rc) return rc;
+  }
   hipStream_t s = (hipStream_t)stream;
   rc = mpm_build_grid(h, n, st, cur, s, gridrec, nullptr, cap_blocks, false, precleared);
   if (rc) return rc;
+  if (!next) return NM_OK;   // g2p is performed by the caller's next kernel (nm_mpm_g2p_fuse)
   NM_LAUNCH(k_g2p, dim3(nm_div_up(n, 256)), dim3(256), 0, s, h->k, n, st->clip_bound, st->enabled, cur->x,
                      cur->v, cur->C, cur->F, h->gv, next->x, next->v, next->C, next->F);
   NM_LAUNCH_CHECK();
@@ -1119,6 +1041,21 @@ extern "C" int nm_mpm_forward_ex(nm_mpm* h, int32_t n, const nm_statics* st, con
 int nm_mpm_forward_prepared(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, nm_particles* next, void* gridrec,
                             int32_t cap_blocks, void* stream) {
   return mpm_forward_impl(h, n, st, cur, next, gridrec, cap_blocks, true, stream);
+}
+
+int nm_mpm_forward_prepared_nog2p(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, void* gridrec,
+                                  int32_t cap_blocks, void* stream) {
+  return mpm_forward_impl(h, n, st, cur, nullptr, gridrec, cap_blocks, true, stream);
+}
+int nm_mpm_g2p_fuse(nm_mpm* h, const nm_statics* st, const nm_particles* cur, nm_particles* next, G2pFuse* f) {
+  int rc = check_particles(st, cur, true);
+  if (rc) return rc;
+  NM_REQUIRE(next && next->x && next->v && next->C, "null next state");
+  f->gv = h->gv; f->K = h->k;
+  f->clip = st->clip_bound; f->enabled = st->enabled;
+  f->x = cur->x; f->v = cur->v; f->C = cur->C; f->F = cur->F;
+  f->xn = next->x; f->vn = next->v; f->Cn = next->C;
+  return NM_OK;
 }
 
 extern "C" int nm_mpm_forward_extra(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, int32_t n_extra,

@@ -99,13 +99,16 @@ extern "C" int nm_rollout_forward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cf
     GridPrologue pro;
     rc = nm_mpm_prologue_forward(h, &pro);
     if (rc) return rc;
-    rc = nm_material_fwd_launch(n, NM_ELASTICITY, 0.f, cur.F, we, w.perm_e, cur.stress, &pro, stream);  // finetune.py:362
+    rc = nm_material_fwd_launch(n, NM_ELASTICITY, 0.f, cur.F, we, w.perm_e, cur.stress, &pro, nullptr, stream);  // finetune.py:362
     if (rc) return rc;
-    nm_particles out = nxt;
-    out.F = w.ftrial;
-    rc = nm_mpm_forward_prepared(h, n, st, &cur, &out, grid_rec(gridcache, cfg, t), cfg->grid_cache_blocks, stream);  // finetune.py:363
+    // p2g + grid update here; the substep's g2p runs inside the plasticity kernel, which consumes its trial F from
+    // registers (the reverse sweep recomputes the trial F from the checkpointed C', so it is never stored)
+    rc = nm_mpm_forward_prepared_nog2p(h, n, st, &cur, grid_rec(gridcache, cfg, t), cfg->grid_cache_blocks, stream);  // finetune.py:363
     if (rc) return rc;
-    rc = nm_material_fwd_launch(n, NM_PLASTICITY, cfg->plasticity_alpha, w.ftrial, wp, w.perm_p, nxt.F, nullptr, stream);  // finetune.py:364
+    G2pFuse g2p;
+    rc = nm_mpm_g2p_fuse(h, st, &cur, &nxt, &g2p);
+    if (rc) return rc;
+    rc = nm_material_fwd_launch(n, NM_PLASTICITY, cfg->plasticity_alpha, nullptr, wp, w.perm_p, nxt.F, nullptr, &g2p, stream);  // finetune.py:364
     if (rc) return rc;
   }
   return NM_OK;
