@@ -206,6 +206,22 @@ int nm_lora_merge(int32_t out_f, int32_t in_f, int32_t r, float scaling, const f
 int nm_lora_merge_bwd(int32_t out_f, int32_t in_f, int32_t r, float scaling, const float* gW, const float* B,
                       const float* A, float* gB, float* gA, void* stream);
 
+/* The same for up to NM_LORA_MAX_LAYERS layers in ONE launch each way (a constitutive net has three; per-layer launches
+ * of these tiny matrices are pure launch latency).  merge: o0 = W + scaling * B A.  merge_bwd: W holds dL/dW_eff,
+ * o0 = dL/dB, o1 = dL/dA. */
+#define NM_LORA_MAX_LAYERS 4
+typedef struct nm_lora_layer {
+  int32_t out_f, in_f, r;
+  float scaling;
+  const float* W;
+  const float* B;
+  const float* A;
+  float* o0;
+  float* o1;
+} nm_lora_layer;
+int nm_lora_merge_layers(int32_t n, const nm_lora_layer* layers, void* stream);
+int nm_lora_merge_layers_bwd(int32_t n, const nm_lora_layer* layers, void* stream);
+
 /* ------------------------------------------------------------------ fused roll-out (experiments/finetune.py:360-364) */
 
 /* S substeps of   stress = E(F); (x,v,C,F) = sim(x,v,C,F,stress); F = P(F)   (finetune.py:362-364,

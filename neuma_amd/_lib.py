@@ -36,6 +36,11 @@ class nm_raster_cfg(C.Structure):
                 ("prefiltered", C.c_int32), ("debug", C.c_int32), ("tile_y0", C.c_int32), ("tile_y1", C.c_int32)]
 
 
+class nm_lora_layer(C.Structure):
+    _fields_ = [("out_f", C.c_int32), ("in_f", C.c_int32), ("r", C.c_int32), ("scaling", C.c_float), ("W", C.c_void_p),
+                ("B", C.c_void_p), ("A", C.c_void_p), ("o0", C.c_void_p), ("o1", C.c_void_p)]
+
+
 class nm_rollout_cfg(C.Structure):
     _fields_ = [("substeps", C.c_int32), ("plasticity_alpha", C.c_float), ("grid_cache_blocks", C.c_int32),
                 ("cache_verified", C.c_int32)]
@@ -99,6 +104,8 @@ SIGNATURES = {
     "nm_pixel_loss": (C.c_int, [_I32, _F, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
     "nm_lora_merge": (C.c_int, [_I32, _I32, _I32, _F, _P, _P, _P, _P, _P]),
     "nm_lora_merge_bwd": (C.c_int, [_I32, _I32, _I32, _F, _P, _P, _P, _P, _P, _P]),
+    "nm_lora_merge_layers": (C.c_int, [_I32, C.POINTER(nm_lora_layer), _P]),
+    "nm_lora_merge_layers_bwd": (C.c_int, [_I32, C.POINTER(nm_lora_layer), _P]),
     "nm_rollout_workspace": (_SZ, [_I32, _I32]),
     "nm_rollout_gridcache_bytes": (_SZ, [_I32, _I32]),
     "nm_rollout_cache_status": (C.c_int, [_P, C.POINTER(nm_rollout_cfg), _P, _P]),

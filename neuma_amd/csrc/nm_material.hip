@@ -942,3 +942,69 @@ extern "C" int nm_lora_merge_bwd(int32_t out_f, int32_t in_f, int32_t r, float s
   NM_LAUNCH_CHECK();
   return NM_OK;
 }
+
+// ---- all layers of a net in one launch (blockIdx.y = layer)
+struct LoraJobs {
+  nm_lora_layer l[NM_LORA_MAX_LAYERS];
+};
+__global__ void __launch_bounds__(256) k_lora_merge_layers(LoraJobs jobs) {
+  const nm_lora_layer& L = jobs.l[blockIdx.y];
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= L.out_f * L.in_f) return;
+  const int o = e / L.in_f, i = e - o * L.in_f;
+  float acc = 0.f;
+  for (int k = 0; k < L.r; ++k) acc = fmaf(L.B[o * L.r + k], L.A[k * L.in_f + i], acc);
+  L.o0[e] = fmaf(L.scaling, acc, L.W[e]);
+}
+__global__ void __launch_bounds__(256) k_lora_merge_layers_bwd(LoraJobs jobs) {
+  const nm_lora_layer& L = jobs.l[blockIdx.y];
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < L.out_f * L.r) {          // gB[o][k] = s * sum_i gW[o][i] A[k][i]
+    const int o = e / L.r, k = e - o * L.r;
+    float acc = 0.f;
+    for (int i = 0; i < L.in_f; ++i) acc = fmaf(L.W[o * L.in_f + i], L.A[k * L.in_f + i], acc);
+    L.o0[e] = L.scaling * acc;
+    return;
+  }
+  e -= L.out_f * L.r;
+  if (e < L.r * L.in_f) {           // gA[k][i] = s * sum_o B[o][k] gW[o][i]
+    const int k = e / L.in_f, i = e - k * L.in_f;
+    float acc = 0.f;
+    for (int o = 0; o < L.out_f; ++o) acc = fmaf(L.B[o * L.r + k], L.W[o * L.in_f + i], acc);
+    L.o1[e] = L.scaling * acc;
+  }
+}
+
+static int lora_jobs(int32_t n, const nm_lora_layer* layers, bool bwd, LoraJobs* jobs, int* blocks) {
+  NM_REQUIRE(layers && n >= 1 && n <= NM_LORA_MAX_LAYERS, "1..NM_LORA_MAX_LAYERS layers");
+  memset(jobs, 0, sizeof(*jobs));
+  int64_t most = 0;
+  for (int i = 0; i < n; ++i) {
+    const nm_lora_layer& L = layers[i];
+    NM_REQUIRE(L.out_f > 0 && L.in_f > 0 && L.r > 0, "bad LoRA shape");
+    NM_REQUIRE(L.W && L.B && L.A && L.o0 && (!bwd || L.o1), "null pointer");
+    jobs->l[i] = L;
+    const int64_t work = bwd ? (int64_t)(L.out_f + L.in_f) * L.r : (int64_t)L.out_f * L.in_f;
+    most = work > most ? work : most;
+  }
+  *blocks = nm_div_up(most, 256);
+  return NM_OK;
+}
+extern "C" int nm_lora_merge_layers(int32_t n, const nm_lora_layer* layers, void* stream) {
+  LoraJobs jobs;
+  int blocks;
+  int rc = lora_jobs(n, layers, false, &jobs, &blocks);
+  if (rc) return rc;
+  NM_LAUNCH(k_lora_merge_layers, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, jobs);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}
+extern "C" int nm_lora_merge_layers_bwd(int32_t n, const nm_lora_layer* layers, void* stream) {
+  LoraJobs jobs;
+  int blocks;
+  int rc = lora_jobs(n, layers, true, &jobs, &blocks);
+  if (rc) return rc;
+  NM_LAUNCH(k_lora_merge_layers_bwd, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, jobs);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}

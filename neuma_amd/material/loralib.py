@@ -40,6 +40,67 @@ class _LoraMerge(torch.autograd.Function):
         return (g if ctx.needs_input_grad[0] else None), gB, gA, None
 
 
+class _LoraMergeLayers(torch.autograd.Function):
+    """The effective weights of several LinearLoRA layers (one constitutive net) with ONE launch in each direction
+    (nm_lora_merge_layers / nm_lora_merge_layers_bwd).  Inputs: scalings, then W, B, A per layer."""
+
+    @staticmethod
+    def forward(ctx, scalings, *wba):
+        import ctypes as C
+        from .. import _lib as L
+        n = len(scalings)
+        prep = [t.detach().contiguous().float() for t in wba]
+        outs = [torch.empty_like(prep[3 * i]) for i in range(n)]
+        jobs = (L.nm_lora_layer * n)()
+        for i in range(n):
+            W, B, A = prep[3 * i:3 * i + 3]
+            jobs[i] = L.nm_lora_layer(W.shape[0], W.shape[1], B.shape[1], float(scalings[i]), L.ptr(W), L.ptr(B), L.ptr(A),
+                                      L.ptr(outs[i]), None)
+        L.check(L.lib().nm_lora_merge_layers(n, jobs, L.stream_ptr(prep[0].device)), "nm_lora_merge_layers")
+        ctx.save_for_backward(*[prep[3 * i + k] for i in range(n) for k in (1, 2)])
+        ctx.scalings = [float(s) for s in scalings]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        import ctypes as C
+        from .. import _lib as L
+        n = len(ctx.scalings)
+        BA = ctx.saved_tensors
+        gs = [(g if g is not None else None) for g in gs]
+        jobs = (L.nm_lora_layer * n)()
+        gB, gA, gW = [], [], []
+        for i in range(n):
+            B, A = BA[2 * i], BA[2 * i + 1]
+            g = gs[i].contiguous().float() if gs[i] is not None else torch.zeros(B.shape[0], A.shape[1], device=B.device)
+            gW.append(g)
+            gB.append(torch.empty_like(B)); gA.append(torch.empty_like(A))
+            jobs[i] = L.nm_lora_layer(g.shape[0], g.shape[1], B.shape[1], ctx.scalings[i], L.ptr(g), L.ptr(B), L.ptr(A),
+                                      L.ptr(gB[i]), L.ptr(gA[i]))
+        L.check(L.lib().nm_lora_merge_layers_bwd(n, jobs, L.stream_ptr(BA[0].device)), "nm_lora_merge_layers_bwd")
+        out = [None]
+        for i in range(n):
+            out += [gW[i] if ctx.needs_input_grad[1 + 3 * i] else None, gB[i], gA[i]]
+        return tuple(out)
+
+
+def merged_weights(layers, owner) -> tuple:
+    """Effective weights of `layers` (LinearLoRA modules, unmerged, on the GPU) through _LoraMergeLayers, cached on
+    `owner` under the same rules as LinearLoRA.effective_weight: reused until a parameter changes (version counters),
+    the grad mode changes, or a backward pass has consumed the node."""
+    key = tuple(v for l in layers for v in (l.weight._version, l.lora_A._version, l.lora_B._version, l.lora_A.requires_grad,
+                                            l.lora_B.requires_grad, l.weight.requires_grad)) + (torch.is_grad_enabled(),)
+    cached = getattr(owner, "_eff_cache", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    flat = [t for l in layers for t in (l.weight, l.lora_B, l.lora_A)]
+    ws = _LoraMergeLayers.apply([l.scaling for l in layers], *flat)
+    owner._eff_cache = (key, ws)
+    if ws[0].grad_fn is not None:
+        ws[0].grad_fn.register_hook(lambda *_: setattr(owner, "_eff_cache", None))
+    return ws
+
+
 class LinearLoRA(nn.Linear):
     def __init__(self, in_features: int, out_features: int, r: int = 0, lora_alpha: int = 1, lora_dropout: float = 0.,
                  merge_weights: bool = True, **kwargs):

@@ -15,7 +15,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from .. import _lib as L
-from .loralib import LinearLoRA, mark_only_lora_as_trainable, lora_state_dict, replace_with_linear_lora
+from .loralib import LinearLoRA, mark_only_lora_as_trainable, lora_state_dict, merged_weights, replace_with_linear_lora
 
 NM_ELASTICITY, NM_PLASTICITY = 0, 1
 
@@ -116,6 +116,9 @@ class _InvariantFullMeta(nn.Module):
         return lora_state_dict(self, bias)
 
     def effective_weights(self):
+        fcs = (self.layers[0].fc, self.layers[1].fc, self.final_layer.fc)
+        if all(isinstance(fc, LinearLoRA) and fc.r > 0 and not fc.merged and fc.weight.is_cuda for fc in fcs):
+            return merged_weights(fcs, self)       # the three layers' merges (and their adjoints) in one launch each
         return (self.layers[0].effective_weight(), self.layers[1].effective_weight(), self.final_layer.effective_weight())
 
     def _alpha(self) -> float:
