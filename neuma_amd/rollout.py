@@ -17,6 +17,17 @@ _WSZ = (64 * 13, 64 * 64, 9 * 64)
 _CACHE_STATUS = __import__('os').environ.get('NEUMA_CACHE_STATUS', '1') != '0'
 
 
+_ZEROS = {}
+
+
+def _zeros(count: int, device) -> torch.Tensor:
+    """A cached read-only zero vector (stands in for a gradient autograd did not produce)."""
+    key = (count, str(device))
+    if key not in _ZEROS:
+        _ZEROS[key] = torch.zeros(count, dtype=torch.float32, device=device)
+    return _ZEROS[key]
+
+
 class _Rollout(autograd.Function):
 
     @staticmethod
@@ -27,11 +38,8 @@ class _Rollout(autograd.Function):
         n = x.size(0)
         S = int(substeps)
         states = torch.empty(S + 1, 33 * n, dtype=torch.float32, device=dev)   # x|v|C|F|stress per record
-        rec0 = states[0]
-        rec0[:3 * n].copy_(x.detach().float().reshape(-1))
-        rec0[3 * n:6 * n].copy_(v.detach().float().reshape(-1))
-        rec0[6 * n:15 * n].copy_(C_.detach().float().reshape(-1))
-        rec0[15 * n:24 * n].copy_(F.detach().float().reshape(-1))
+        # record 0 = the inputs, packed x|v|C|F by one concatenation kernel
+        torch.cat([t.detach().float().reshape(-1) for t in (x, v, C_, F)], out=states[0][:24 * n])
         we = [t.detach().float().contiguous() for t in (e0, e1, e2)]
         wp = [t.detach().float().contiguous() for t in (p0, p1, p2)]
         ws_bytes = int(lib.nm_rollout_workspace(n, S))
@@ -68,13 +76,11 @@ class _Rollout(autograd.Function):
         states, e0, e1, e2, p0, p1, p2 = ctx.saved_tensors
         dev = states.device
         n, S = ctx.n, ctx.S
-        glast = torch.empty(24 * n, dtype=torch.float32, device=dev)
-        for sl, g, cnt in ((slice(0, 3 * n), gx, 3 * n), (slice(3 * n, 6 * n), gv, 3 * n), (slice(6 * n, 15 * n), gC, 9 * n),
-                           (slice(15 * n, 24 * n), gF, 9 * n)):
-            if g is None:
-                glast[sl].zero_()
-            else:
-                glast[sl].copy_(g.float().reshape(-1))
+        # incoming gradients packed x|v|C|F by one concatenation kernel (absent ones are zeros, kept per size)
+        parts = []
+        for g, cnt in ((gx, 3 * n), (gv, 3 * n), (gC, 9 * n), (gF, 9 * n)):
+            parts.append(g.float().reshape(-1) if g is not None else _zeros(cnt, dev))
+        glast = torch.cat(parts)
         gfirst = torch.empty(24 * n, dtype=torch.float32, device=dev)
         gwe = torch.empty(sum(_WSZ), dtype=torch.float32, device=dev)
         gwp = torch.empty(sum(_WSZ), dtype=torch.float32, device=dev)

@@ -171,7 +171,7 @@ def diff_rasterization(x: Tensor, deform_grad: Optional[Tensor], gaussians, view
         cov3D_deformed = deform_cov_by_F(cov3D_precomp.reshape(-1, 6), tensor_F)
     else:
         cov3D_deformed = cov3D_precomp
-    means2D = torch.zeros_like(means3D, requires_grad=True) + 0
+    means2D = torch.zeros_like(means3D, requires_grad=True)     # (the reference adds 0 to make it a non-leaf it can retain_grad on)
     rasterizer = get_rasterizer(view_cam, sh_degree, debug=False, bg_color=background_color, tile_rows=tile_rows)
     if force_mask_data:
         rendered_image, _ = rasterizer(means3D=means3D, means2D=means2D, shs=None,

@@ -1,0 +1,39 @@
+"""Kernel sequence of one steady-state frame from a rocprofv3 --kernel-trace CSV, with run-length compression, to spot
+glue kernels (fills, copies, elementwise) on the frame's critical path.   python tools/exp_frame_seq.py <dir>"""
+import csv
+import glob
+import sys
+
+f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
+rows = []
+for r in csv.DictReader(open(f)):
+    n = r["Kernel_Name"].split("(")[0].replace("void ", "")
+    if "at::native" in n:
+        n = "torch:" + n.split("at::native::")[-1].split("<")[0][:40] + "|" + (n.split("at::native::")[1].split("<")[0][:30] if n.count("at::native::") > 1 else "")
+    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n[:70], r.get("Queue_Id", "")))
+rows.sort()
+marks = [i for i, r in enumerate(rows) if r[2].startswith("k_lora_merge_layers") and not r[2].startswith("k_lora_merge_layers_bwd")]
+# frame = from an elasticity merge (every second merge launch) to the next
+# a frame = from one elasticity merge (every second merge launch) to the next, with renders in between; take the last one
+seq = None
+for a, b in zip(marks[-2::-2][1:], marks[-2::-2]):
+    if any(r[2].startswith("k_render_bwd") for r in rows[a:b]):
+        seq = rows[a:b]
+        break
+if seq is None:
+    raise SystemExit("no frame found")
+print("frame span %.3f ms, %d kernels, busy %.3f ms" % ((seq[-1][1] - seq[0][0]) / 1e6, len(seq), sum(r[1] - r[0] for r in seq) / 1e6))
+out = []
+for r in seq:
+    d = (r[1] - r[0]) / 1e3
+    if out and out[-1][0] == r[2]:
+        out[-1][1] += 1; out[-1][2] += d
+    else:
+        out.append([r[2], 1, d])
+glue = 0.0
+for n, c, d in out:
+    tag = ""
+    if n.startswith(("torch:", "__amd_rocclr")):
+        glue += d; tag = "   <-- glue"
+    print(f"{c:4d} x {n:70s} {d:9.1f} us{tag}")
+print("glue kernels: %.1f us" % glue)
