@@ -468,6 +468,16 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float x) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
 }
+// x + x(lane ^ 16) and x + x(lane ^ 32) on every lane with the gfx950 row / half swaps (two VALU instructions each) instead
+// of ds_bpermute, whose LDS round trip sat on the dependent path of every evaluated (pixel, Gaussian) pair
+__device__ __forceinline__ float add_xor16(float x) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float add_xor32(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 // Sum 8 per-lane values over the 64 lanes of a wave with a folding butterfly: every step halves the number of
 // live values per lane (lanes split on one index bit keep one half and hand the other half to their partner), so
 // the whole reduction costs 4+2+1 DPP exchanges inside a row plus 3 single-value steps instead of 8 full
@@ -488,18 +498,14 @@ __device__ __forceinline__ float wave_fold8(const float* v, int lane) {
   float keep = b2 ? c[1] : c[0], send = b2 ? c[0] : c[1];
   float d = keep + dpp_mov<0x124>(send);  // row_ror:4 — partner has bit 2 flipped, bits 0,1 equal
   d += dpp_mov<0x128>(d);                 // row_ror:8 == lane ^ 8 within the row of 16
-  d += __shfl_xor(d, 16, 64);
-  d += __shfl_xor(d, 32, 64);
-  return d;
+  return add_xor32(add_xor16(d));
 }
 __device__ __forceinline__ float wave_sum_dpp(float x) {
   x += dpp_mov<0xB1>(x);
   x += dpp_mov<0x4E>(x);
   x += dpp_mov<0x141>(x);  // row_half_mirror
   x += dpp_mov<0x140>(x);  // row_mirror
-  x += __shfl_xor(x, 16, 64);
-  x += __shfl_xor(x, 32, 64);
-  return x;
+  return add_xor32(add_xor16(x));
 }
 
 #define NM_NG 9  // per-Gaussian reduced quantities: ndc-mean(2) conic(3) colour(3) | opacity(1)
