@@ -609,8 +609,13 @@ __global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, const uint2* __rest
         g[4] = -0.5f * gdy * dy * dL_dG;       // d/d conic.z
         gop = G * dL_dalpha;                   // d/d opacity
       }
+#if defined(NM_RB_VARIANT) && NM_RB_VARIANT == 1
+      float tot = g[0] + g[1] + g[2] + g[3] + g[4] + g[5] + g[6] + g[7];   // experiment: no cross-lane reduction
+      if (tot == 12345.f) my_acc[j * NM_NG + slot] += tot;
+#else
       float tot = wave_fold8(g, lane);
       if (lane < 8) my_acc[j * NM_NG + slot] += tot;
+#endif
       if (WITH_OPACITY) {
         float to = wave_sum_dpp(gop);
         if (lane == 0) my_acc[j * NM_NG + 8] += to;
