@@ -508,6 +508,9 @@ __device__ __forceinline__ float wave_sum_dpp(float x) {
   return add_xor32(add_xor16(x));
 }
 
+#ifndef NM_RB_BATCH
+#define NM_RB_BATCH 128
+#endif
 #define NM_NG 9  // per-Gaussian reduced quantities: ndc-mean(2) conic(3) colour(3) | opacity(1)
 // slot order inside an accumulator row: [0..7] = values of wave_fold8 order, [8] = opacity
 //   v[0]=d/dndc.x v[1]=d/dndc.y v[2]=d/dconic.x v[3]=d/dconic.y v[4]=d/dconic.z v[5..7]=d/drgb
@@ -518,11 +521,13 @@ __global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, const uint2* __rest
                                                        const float4* __restrict__ conop, const float* __restrict__ final_T,
                                                        const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
                                                        float* __restrict__ acc /* (K, 9) */) {
-  __shared__ uint32_t s_id[NM_TPB];
-  __shared__ float2 s_xy[NM_TPB];
-  __shared__ float4 s_co[NM_TPB];
-  __shared__ float s_rgb[NM_TPB * 3];
-  __shared__ float s_acc[4][NM_TPB * NM_NG];   // one private table per wave: plain stores, no LDS atomics
+  // Gaussians are staged NM_RB_BATCH at a time: the four per-wave tables are what limits the number of resident tiles
+  // (LDS), and this loop lives on latency hiding - 128 per batch = 23 KB per tile = 6 waves per SIMD instead of 3
+  __shared__ uint32_t s_id[NM_RB_BATCH];
+  __shared__ float2 s_xy[NM_RB_BATCH];
+  __shared__ float4 s_co[NM_RB_BATCH];
+  __shared__ float s_rgb[NM_RB_BATCH * 3];
+  __shared__ float s_acc[4][NM_RB_BATCH * NM_NG];   // one private table per wave: plain stores, no LDS atomics
   const int tile_x = blockIdx.x, tile_y = blockIdx.y + k.ty0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = tile_x * NM_TILE + (tid & 15), py = tile_y * NM_TILE + (tid >> 4);
@@ -530,7 +535,7 @@ __global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, const uint2* __rest
   const float fxp = (float)px, fyp = (float)py;
   const uint2 range = ranges[tile_y * k.gx + tile_x];
   int todo = (int)(range.y - range.x);
-  const int rounds = (todo + NM_TPB - 1) / NM_TPB;
+  const int rounds = (todo + NM_RB_BATCH - 1) / NM_RB_BATCH;
   const size_t pix = (size_t)py * k.W + px, hw = (size_t)k.H * k.W;
   const float T_final = inside ? final_T[pix] : 0.f;
   float T = T_final;
@@ -544,7 +549,7 @@ __global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, const uint2* __rest
   float* my_acc = s_acc[wave];
   // lane l < 8 owns fold slot value index:
   const int slot = 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1);
-  for (int i = lane; i < NM_TPB * NM_NG; i += 64) my_acc[i] = 0.f;
+  for (int i = lane; i < NM_RB_BATCH * NM_NG; i += 64) my_acc[i] = 0.f;
   // Gaussians behind every pixel's last contributor (the forward pass stopped compositing there) cannot
   // contribute: the wave skips them before doing any arithmetic, the tile skips whole batches of them
   uint32_t wave_last = last_contributor;
@@ -554,12 +559,12 @@ __global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, const uint2* __rest
   if (lane == 0) s_last[wave] = wave_last;
   __syncthreads();
   const uint32_t tile_last = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
-  for (int rd = 0; rd < rounds; ++rd, todo -= NM_TPB) {
-    // this batch covers list positions [todo - NM_TPB, todo): skip it entirely if all of them are >= tile_last
-    if ((uint32_t)max(todo - NM_TPB, 0) >= tile_last) { contributor -= (uint32_t)min(NM_TPB, todo); continue; }
+  for (int rd = 0; rd < rounds; ++rd, todo -= NM_RB_BATCH) {
+    // this batch covers list positions [todo - NM_RB_BATCH, todo): skip it entirely if all of them are >= tile_last
+    if ((uint32_t)max(todo - NM_RB_BATCH, 0) >= tile_last) { contributor -= (uint32_t)min(NM_RB_BATCH, todo); continue; }
     __syncthreads();
-    int prog = rd * NM_TPB + tid;
-    if (range.x + prog < range.y) {
+    int prog = rd * NM_RB_BATCH + tid;
+    if (tid < NM_RB_BATCH && range.x + prog < range.y) {
       uint32_t id = plist[range.y - prog - 1];  // back to front
       s_id[tid] = id;
       s_xy[tid] = xy[id];
@@ -567,7 +572,7 @@ __global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, const uint2* __rest
       s_rgb[3 * tid] = rgb[3 * id]; s_rgb[3 * tid + 1] = rgb[3 * id + 1]; s_rgb[3 * tid + 2] = rgb[3 * id + 2];
     }
     __syncthreads();
-    const int nb = min(NM_TPB, todo);
+    const int nb = min(NM_RB_BATCH, todo);
     for (int j = 0; j < nb; ++j) {
       contributor--;
       if (contributor >= wave_last) continue;   // wave-uniform

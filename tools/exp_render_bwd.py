@@ -3,12 +3,13 @@ kernel compiled in (-DNM_RB_VARIANT=n).   python tools/exp_render_bwd.py [varian
 import os, subprocess, sys, ctypes as C
 sys.path.insert(0, ".")
 variant = sys.argv[1] if len(sys.argv) > 1 else None
+extra = sys.argv[2] if len(sys.argv) > 2 else ""       # e.g. -DNM_RB_BATCH=64
 if variant:
     src = "neuma_amd/csrc"
     out = f"/tmp/libneuma_rb{variant}.so"
     files = " ".join(f"{src}/{f}" for f in ("nm_api.hip", "nm_mpm.hip", "nm_shard.hip", "nm_material.hip", "nm_bind.hip", "nm_bindbuild.hip",
                                              "nm_raster.hip", "nm_rollout.hip"))
-    subprocess.run(f"/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -DNM_RB_VARIANT={variant} -Iinclude "
+    subprocess.run(f"/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -DNM_RB_VARIANT={variant} {extra} -Iinclude "
                    f"-shared {files} -o {out}", shell=True, check=True)
     os.environ["NEUMA_HIP_LIB"] = out
 import torch
@@ -39,4 +40,4 @@ lib.nm_prof_report(buf, len(buf))
 for line in buf.value.decode().splitlines():
     name, calls, ms = line.rsplit(" ", 2)
     if "render" in name or "preprocess" in name or "emit" in name:
-        print(f"variant {variant}: {name:36s} {1e3 * float(ms) / int(calls):8.1f} us")
+        print(f"variant {variant} {extra}: {name:36s} {1e3 * float(ms) / int(calls):8.1f} us")
