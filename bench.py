@@ -37,6 +37,10 @@ def prof_table(lib):
     return out
 
 
+# algorithmic flop per particle and launch of the constitutive kernels (see the roofline block in main)
+MATERIAL_FLOPS = {"k_material_fwd": 11008.0, "k_material_bwd": 3 * 11008.0, "k_material_bwd_pair": 6 * 11008.0}
+
+
 def algorithmic_bytes(kernel: str, rt, D: float) -> float:
     """Compulsory HBM bytes of ONE launch of `kernel` (formulas stated in DESIGN.md §Kernels)."""
     cfg = rt.scene.cfg
@@ -50,6 +54,7 @@ def algorithmic_bytes(kernel: str, rt, D: float) -> float:
         "k_preprocess_bwd": (4 * (3 + 6) + 12 * (cfg["sh"] + 1) ** 2) * K + 36.0 * K + 12.0 * K,
         "k_material_fwd": 72.0 * N,
         "k_material_bwd": 108.0 * N,
+        "k_material_bwd_pair": 216.0 * N,
         "k_p2g": 124.0 * N + 16.0 * T,
         "k_g2p": 64.0 * N + 16.0 * T + 96.0 * N,
         "k_g2p_bwd": 192.0 * N + 32.0 * T,
@@ -70,8 +75,8 @@ def kernel_rooflines(full, rt, D):
     out = []
     for b, (calls, ms) in sorted(by.items(), key=lambda kv: -kv[1][1])[:12]:
         avg_s = ms / calls / 1e3
-        if b in ("k_material_fwd", "k_material_bwd"):
-            fl = (11008.0 if b == "k_material_fwd" else 3 * 11008.0) * rt.n_local
+        if b in MATERIAL_FLOPS:
+            fl = MATERIAL_FLOPS[b] * rt.n_local
             out.append({"kernel": b, "bound": "mfma", "achieved": round(fl / avg_s / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s",
                         "frac": round(fl / avg_s / 1e12 / 157.3, 4), "avg_us": round(avg_s * 1e6, 1), "launches": calls})
         else:
@@ -239,10 +244,11 @@ def main():
         name = dom_base + ("<*>" if any("<" in k for k in dom) else "")
         avg_s = ms / calls / 1e3
         base = dom_base
-        if base in ("k_material_fwd", "k_material_bwd"):
+        if base in MATERIAL_FLOPS:
             # MFMA-bound: 2*(13*64 + 64*64 + 64*9) = 11 008 flop per particle per net forward; the backward recomputes
-            # the forward and adds data-gradient and weight-gradient GEMMs of the same size (3x)
-            flops = (11008.0 if base == "k_material_fwd" else 3 * 11008.0) * rt.n_local
+            # the forward and adds data-gradient and weight-gradient GEMMs of the same size (3x); the pair kernel of the
+            # reverse sweep runs two nets' backward passes per launch
+            flops = MATERIAL_FLOPS[base] * rt.n_local
             achieved = flops / avg_s / 1e12 if avg_s > 0 else 0.0
             roof = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 3), "peak": 157.3, "unit": "TFLOP/s",
                     "frac": round(achieved / 157.3, 5), "traffic": None, "launches": calls, "avg_us": round(avg_s * 1e6, 2),

@@ -493,17 +493,26 @@ struct BwdLds {
   float TB[4][64 * 17];
 };
 
+struct BwdArgs {
+  int n, q;
+  float alpha;
+  const float *F, *w0, *w1, *w2, *wperm, *gout;
+  float *gF, *wpart;
+  int want_w;
+  BwdFuse fz;
+};
+
 template <int KIND>
-__global__ void __launch_bounds__(256, 1) k_material_bwd(int n, int q, float alpha, const float* __restrict__ F,
-                                                         const float* __restrict__ w0, const float* __restrict__ w1,
-                                                         const float* __restrict__ w2, const float* __restrict__ wperm,
-                                                         const float* __restrict__ gout, float* __restrict__ gF,
-                                                         float* __restrict__ wpart, int want_w, BwdFuse fz, GridPrologue pro) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+__device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_raw) {
+  const int n = a.n, q = a.q, want_w = a.want_w;
+  const float alpha = a.alpha;
+  const float* __restrict__ F = a.F;
+  const float *__restrict__ w0 = a.w0, *__restrict__ w1 = a.w1, *__restrict__ w2 = a.w2, *__restrict__ wperm = a.wperm;
+  const float* __restrict__ gout = a.gout;
+  float *__restrict__ gF = a.gF, *__restrict__ wpart = a.wpart;
+  const BwdFuse fz = a.fz;
   BwdLds& L = *reinterpret_cast<BwdLds*>(smem_raw);
   NM_PH_DECL
-  // roll-out: grid restore + clear of the MPM adjoint that follows (nm_grid.h) - on workgroups of its own when CUs are to spare
-  if (NM_PROLOGUE_SPLIT(pro)) return;
   if (wperm) {
     static_assert(offsetof(BwdLds, Z) == NM_PERM_ALL * sizeof(float), "P0..Q2 must be contiguous in operand order");
     stage_permuted<NM_PERM_ALL>(wperm, L.P0);
@@ -744,7 +753,7 @@ __global__ void __launch_bounds__(256, 1) k_material_bwd(int n, int q, float alp
   }
   NM_PH_STORE
 
-  if (!want_w) return;
+  if (!want_w) return;   // (workgroup-uniform)
   // combine the four waves' weight-gradient accumulators: every wave stores its own copy in plain (out,in) layout to a
   // private LDS region (the weights and per-wave buffers are dead by now), then the workgroup sums the four copies.
   // (LDS float atomics would serialise here: ds_add_f32 sustains ~0.3 lanes/clk/CU on gfx950, i.e. ~70k cycles for the
@@ -780,6 +789,27 @@ __global__ void __launch_bounds__(256, 1) k_material_bwd(int n, int q, float alp
   }
 }
 
+template <int KIND>
+__global__ void __launch_bounds__(256, 1) k_material_bwd(BwdArgs a, GridPrologue pro) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  // roll-out: grid restore + clear of the MPM adjoint that follows (nm_grid.h) - on workgroups of its own when CUs are to spare
+  if (NM_PROLOGUE_SPLIT(pro)) return;
+  material_bwd_body<KIND>(a, smem_raw);
+}
+
+// Roll-out reverse sweep: the elasticity adjoint of substep t and the plasticity adjoint of substep t-1 in ONE launch.  The
+// second only needs the first's dL/dF of the same particle (a wave owns the same particles in both), so the pair saves a
+// launch boundary - and k_material_bwd's boundaries are expensive: its waves own a SIMD's whole register file, so the
+// neighbouring kernels cannot overlap its ramp-up / drain (~5 us).  `pro` is the grid prologue of substep t-1.
+__global__ void __launch_bounds__(256, 1) k_material_bwd_pair(BwdArgs e, BwdArgs p, GridPrologue pro) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (NM_PROLOGUE_SPLIT(pro)) return;
+  material_bwd_body<NM_ELASTICITY>(e, smem_raw);
+  __threadfence_block();     // dL/dF written by this workgroup's lanes is read back by the same lanes below
+  __syncthreads();
+  material_bwd_body<NM_PLASTICITY>(p, smem_raw);
+}
+
 // sum the per-workgroup partials: a workgroup owns 64 consecutive weights, its four waves each sum a quarter of the
 // partials (coalesced 256 B rows) and combine through LDS — deterministic, ~86 workgroups instead of 22 serial ones
 __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ wpart, int nparts, float* __restrict__ g0,
@@ -811,10 +841,32 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
 
 // internal (also used by the fused roll-out): launch the backward kernel only.  wmode 0: no weight gradients,
 // 1: write this launch's per-workgroup partial sums to wpart, 2: add them to wpart.
+static int bwd_attr_once() {
+  static bool attr_set = false;
+  if (!attr_set) {
+    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd<NM_ELASTICITY>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)sizeof(BwdLds)));
+    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd<NM_PLASTICITY>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)sizeof(BwdLds)));
+    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd_pair, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)sizeof(BwdLds)));
+    attr_set = true;
+  }
+  return NM_OK;
+}
+static BwdArgs bwd_args(int32_t n, int q, float alpha, const float* F, const nm_mlp* w, const float* wperm, const float* gout,
+                        float* gF, float* wpart, int wmode, const float* trial_C, const int* enabled, float dt, int add_to_gF) {
+  BwdArgs a;
+  a.n = n; a.q = q; a.alpha = alpha; a.F = F;
+  a.w0 = w ? w->w0 : nullptr; a.w1 = w ? w->w1 : nullptr; a.w2 = w ? w->w2 : nullptr;
+  a.wperm = wperm; a.gout = gout; a.gF = gF; a.wpart = wpart; a.want_w = wmode;
+  a.fz.trial_C = trial_C; a.fz.enabled = enabled; a.fz.dt = dt; a.fz.add_to_gF = add_to_gF;
+  return a;
+}
+
 int nm_material_bwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* wperm,
                            const float* gout, float* gF, float* wpart, int wmode, const float* trial_C, const int* enabled,
                            float dt, int add_to_gF, const GridPrologue* pro, void* stream) {
-  BwdFuse fz = {trial_C, enabled, dt, add_to_gF};
   GridPrologue gp;
   if (pro) gp = *pro; else { memset(&gp, 0, sizeof(gp)); }
   hipStream_t s = (hipStream_t)stream;
@@ -822,21 +874,35 @@ int nm_material_bwd_launch(int32_t n, int32_t kind, float alpha, const float* F,
   nm_wave_quota(n, grid, q);
   gp.mat_grid = grid;
   const int launch = (pro && grid + NM_PRO_WGS <= NM_BWD_GRID) ? grid + NM_PRO_WGS : grid;
-  static bool attr_set = false;
-  if (!attr_set) {
-    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd<NM_ELASTICITY>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)sizeof(BwdLds)));
-    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd<NM_PLASTICITY>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)sizeof(BwdLds)));
-    attr_set = true;
-  }
-  const float *w0 = w ? w->w0 : nullptr, *w1 = w ? w->w1 : nullptr, *w2 = w ? w->w2 : nullptr;
+  int rc = bwd_attr_once();
+  if (rc) return rc;
+  BwdArgs a = bwd_args(n, q, alpha, F, w, wperm, gout, gF, wpart, wmode, trial_C, enabled, dt, add_to_gF);
   if (kind == NM_ELASTICITY)
-    NM_LAUNCH(k_material_bwd<NM_ELASTICITY>, dim3(launch), dim3(256), sizeof(BwdLds), s, n, q, alpha, F, w0, w1, w2, wperm,
-                       gout, gF, wpart, wmode, fz, gp);
+    NM_LAUNCH(k_material_bwd<NM_ELASTICITY>, dim3(launch), dim3(256), sizeof(BwdLds), s, a, gp);
   else
-    NM_LAUNCH(k_material_bwd<NM_PLASTICITY>, dim3(launch), dim3(256), sizeof(BwdLds), s, n, q, alpha, F, w0, w1, w2, wperm,
-                       gout, gF, wpart, wmode, fz, gp);
+    NM_LAUNCH(k_material_bwd<NM_PLASTICITY>, dim3(launch), dim3(256), sizeof(BwdLds), s, a, gp);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}
+
+// roll-out reverse sweep: elasticity adjoint (dL/dstress gS -> += gF) of one substep, then the plasticity adjoint of the
+// substep before it (dL/dF = that gF -> gFtrial), one launch (k_material_bwd_pair)
+int nm_material_bwd_pair_launch(int32_t n, const float* F_e, const nm_mlp* we, const float* wperm_e, const float* gS, float* gF,
+                                float* wpart_e, int wmode_e, float alpha_p, const float* F_p, const nm_mlp* wp,
+                                const float* wperm_p, float* gFtrial, float* wpart_p, int wmode_p, const float* trial_C,
+                                const int* enabled, float dt, const GridPrologue* pro, void* stream) {
+  GridPrologue gp;
+  if (pro) gp = *pro; else { memset(&gp, 0, sizeof(gp)); }
+  hipStream_t s = (hipStream_t)stream;
+  int grid, q;
+  nm_wave_quota(n, grid, q);
+  gp.mat_grid = grid;
+  const int launch = (pro && grid + NM_PRO_WGS <= NM_BWD_GRID) ? grid + NM_PRO_WGS : grid;
+  int rc = bwd_attr_once();
+  if (rc) return rc;
+  BwdArgs e = bwd_args(n, q, 0.f, F_e, we, wperm_e, gS, gF, wpart_e, wmode_e, nullptr, nullptr, 0.f, 1);
+  BwdArgs p = bwd_args(n, q, alpha_p, F_p, wp, wperm_p, gF, gFtrial, wpart_p, wmode_p, trial_C, enabled, dt, 0);
+  NM_LAUNCH(k_material_bwd_pair, dim3(launch), dim3(256), sizeof(BwdLds), s, e, p, gp);
   NM_LAUNCH_CHECK();
   return NM_OK;
 }

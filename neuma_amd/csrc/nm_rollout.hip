@@ -139,37 +139,51 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
   if (rc) return rc;
   rc = nm_material_prepare(wp, w.perm_p, stream);
   if (rc) return rc;
+  const bool verified = cfg->cache_verified != 0 && gridcache != nullptr && cfg->grid_cache_blocks > 0;
+  const float dt = nm_mpm_get_dt(h);
+  bool restored = false;   // the grid of the substep about to be visited was restored by the previous launch's prologue
   for (int t = cfg->substeps - 1; t >= 0; --t) {
     nm_particles cur = rec(states_m, n, t), nxt = rec(states_m, n, t + 1);
     float* gout = (t == 0) ? gstate_first : ((gin == w.ga) ? w.gb : w.ga);
-    // plasticity backward on the trial F of this step (recomputed in-kernel from the checkpoints): dL/dF_{t+1} -> dL/dFtrial
     const int wmode = (t == cfg->substeps - 1) ? 1 : 2;   // first visit writes the partials, later ones add
-    // verified sweep: from the second substep on, the plasticity kernel also restores the grid of this substep and clears
-    // what the previous one left (GridPrologue mode 2; the block flags it relies on were set by that substep's
-    // k_grid_op_bwd).  The first substep of the sweep, and unverified sweeps, use the stand-alone launches.
-    const bool verified = cfg->cache_verified != 0 && gridcache != nullptr && cfg->grid_cache_blocks > 0;
-    const bool prepared = verified && t < cfg->substeps - 1;
-    GridPrologue pro;
-    if (prepared) {
-      rc = nm_mpm_prologue_backward(h, grid_rec(gridcache, cfg, t), cfg->grid_cache_blocks, &pro);
+    if (t == cfg->substeps - 1) {
+      // plasticity backward on the trial F of the last substep (recomputed in-kernel from the checkpoints):
+      // dL/dF_{t+1} -> dL/dFtrial.  For every earlier substep it rides in the pair launch at the end of this loop body.
+      rc = nm_material_bwd_launch(n, NM_PLASTICITY, cfg->plasticity_alpha, cur.F, wp, w.perm_p, gin + 15 * N, w.gFtr, w.part_p, wmode,
+                                  nxt.C, st->enabled, dt, 0, nullptr, stream);
       if (rc) return rc;
     }
-    rc = nm_material_bwd_launch(n, NM_PLASTICITY, cfg->plasticity_alpha, cur.F, wp, w.perm_p, gin + 15 * N, w.gFtr, w.part_p, wmode,
-                                nxt.C, st->enabled, nm_mpm_get_dt(h), 0, prepared ? &pro : nullptr, stream);
-    if (rc) return rc;
-    // sim backward (stress of this step was checkpointed by the forward pass)
+    // sim backward (stress of this step was checkpointed by the forward pass).  Verified sweep: from the second substep
+    // on the grid has been restored by the prologue of the preceding constitutive launch (GridPrologue mode 2; the block
+    // flags it relies on were set by the previous substep's k_grid_op_bwd); otherwise the stand-alone launches do it.
     nm_particles gn, gc;
     gn.x = const_cast<float*>(gin); gn.v = const_cast<float*>(gin) + 3 * N; gn.C = const_cast<float*>(gin) + 6 * N;
     gn.F = w.gFtr; gn.stress = nullptr;
     gc.x = gout; gc.v = gout + 3 * N; gc.C = gout + 6 * N; gc.F = gout + 15 * N; gc.stress = w.gS;
     rc = nm_mpm_backward_cached(h, n, st, &cur, &nxt, &gn, &gc, grid_rec(gridcache, cfg, t), cfg->grid_cache_blocks,
-                                cfg->cache_verified != 0, prepared, (verified && t > 0) ? grid_rec(gridcache, cfg, t - 1) : nullptr,
+                                cfg->cache_verified != 0, restored, (verified && t > 0) ? grid_rec(gridcache, cfg, t - 1) : nullptr,
                                 stream);
     if (rc) return rc;
-    // elasticity backward: dL/dstress -> dL/dF (added to the sim's dL/dF)
-    rc = nm_material_bwd_launch(n, NM_ELASTICITY, 0.f, cur.F, we, w.perm_e, w.gS, gc.F, w.part_e, wmode, nullptr, nullptr, 0.f, 1,
-                                nullptr, stream);
-    if (rc) return rc;
+    restored = false;
+    if (t == 0) {
+      // elasticity backward: dL/dstress -> dL/dF (added to the sim's dL/dF)
+      rc = nm_material_bwd_launch(n, NM_ELASTICITY, 0.f, cur.F, we, w.perm_e, w.gS, gc.F, w.part_e, wmode, nullptr, nullptr, 0.f, 1,
+                                  nullptr, stream);
+      if (rc) return rc;
+    } else {
+      // elasticity backward of this substep and plasticity backward of the previous one (its input dL/dF_t is exactly
+      // what the elasticity part leaves in gc.F) in one launch, which also carries the grid prologue of substep t-1
+      nm_particles prev = rec(states_m, n, t - 1);
+      GridPrologue pro;
+      if (verified) {
+        rc = nm_mpm_prologue_backward(h, grid_rec(gridcache, cfg, t - 1), cfg->grid_cache_blocks, &pro);
+        if (rc) return rc;
+        restored = true;
+      }
+      rc = nm_material_bwd_pair_launch(n, cur.F, we, w.perm_e, w.gS, gc.F, w.part_e, wmode, cfg->plasticity_alpha, prev.F, wp,
+                                       w.perm_p, w.gFtr, w.part_p, 2, cur.C, st->enabled, dt, verified ? &pro : nullptr, stream);
+      if (rc) return rc;
+    }
     gin = gout;
   }
   // one deterministic reduction per net for the whole roll-out
