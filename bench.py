@@ -189,6 +189,9 @@ def main():
     lib.nm_prof_enable(1, dom_base.encode())
     sync()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    import gc
+    gc.collect()
+    gc.disable()            # no collector pauses inside the timed region (a gen-2 pass costs milliseconds with this many tensors alive)
     t0 = time.perf_counter()
     last = None
     marks[0].record()
@@ -198,6 +201,7 @@ def main():
         marks[it + 1].record()          # per-frame GPU timeline (no host sync inside the timed region)
     sync()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     per_frame = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     lib.nm_prof_enable(0, None)
     dom = prof_table(lib)
