@@ -180,3 +180,35 @@ def test_lora_merge_kernel_matches_loralib_expression():
         assert rel_max(gB, rB) < 1e-5 and rel_max(gA, rA) < 1e-5
         lin.eval()       # merged path: plain weight, loralib.py:199-214
         assert abs_max(lin.effective_weight(), ref) < 1e-6
+
+
+def test_lora_merge_of_a_whole_net_in_one_launch():
+    """nm_lora_merge_layers / nm_lora_merge_layers_bwd (the three layers of a constitutive net per launch) against the
+    per-layer expression W + (B @ A) * scaling and its autograd; the merged tuple is reused until a parameter changes."""
+    from neuma_amd.material import InvariantFullMetaElasticity
+    cfg = dict(layer_widths=[64, 64], norm=None, nonlinearity="gelu", no_bias=True, normalize_input=True, alpha=1e-3)
+    torch.manual_seed(1)
+    net = InvariantFullMetaElasticity(cfg).to(dev())
+    net.init_lora_layers(16, 16)
+    net.freeze_all_except_lora()
+    fcs = (net.layers[0].fc, net.layers[1].fc, net.final_layer.fc)
+    for fc in fcs:
+        fc.lora_B.data.normal_(0, 0.1)
+    ws = net.effective_weights()
+    assert net.effective_weights() is ws                        # cached
+    gs = [torch.randn_like(w) for w in ws]
+    params = [p for fc in fcs for p in (fc.lora_B, fc.lora_A)]
+    grads = torch.autograd.grad(sum((w * g).sum() for w, g in zip(ws, gs)), params)
+    k = 0
+    for fc, w, g in zip(fcs, ws, gs):
+        rB = fc.lora_B.detach().double().cpu().requires_grad_(True)
+        rA = fc.lora_A.detach().double().cpu().requires_grad_(True)
+        ref = fc.weight.detach().double().cpu() + (rB @ rA) * fc.scaling
+        assert abs_max(w, ref) < 1e-6
+        eB, eA = torch.autograd.grad((ref * g.double().cpu()).sum(), [rB, rA])
+        assert rel_max(grads[k], eB) < 1e-5 and rel_max(grads[k + 1], eA) < 1e-5
+        k += 2
+    with torch.no_grad():
+        fcs[1].lora_A.mul_(2.0)
+    ws2 = net.effective_weights()
+    assert ws2 is not ws and abs_max(ws2[0], ws[0]) == 0.0 and abs_max(ws2[1], ws[1]) > 0.0
