@@ -324,6 +324,13 @@ int nm_raster_preprocess(const nm_raster_cfg* cfg, int32_t k, int32_t m, const f
                          const float* shs, const float* colors_precomp, const float* opacities,
                          const float* cov3D, int32_t* radii, void* geom, size_t geom_bytes,
                          int64_t* num_rendered, void* stream);
+/* The same without the synchronisation: num_rendered must be PINNED host memory; it is zeroed at once and its value
+ * arrives in stream order (wait for the stream or an event recorded after the call before reading it).  Lets a caller
+ * enqueue stage 1 of several views before it blocks on the first count. */
+int nm_raster_preprocess_async(const nm_raster_cfg* cfg, int32_t k, int32_t m, const float* means3D,
+                               const float* shs, const float* colors_precomp, const float* opacities,
+                               const float* cov3D, int32_t* radii, void* geom, size_t geom_bytes,
+                               int64_t* num_rendered, void* stream);
 /* Stage 2: key emit, (tile, depth) sort, tile ranges, front-to-back composite -> out_color (3,H,W).
  * Rows outside the cfg tile stripe are left untouched. */
 int nm_raster_render(const nm_raster_cfg* cfg, int32_t k, int64_t num_rendered, const void* geom,

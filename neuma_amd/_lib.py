@@ -97,6 +97,7 @@ SIGNATURES = {
     "nm_raster_image_bytes": (_SZ, [C.POINTER(nm_raster_cfg)]),
     "nm_raster_preprocess": (C.c_int, [C.POINTER(nm_raster_cfg), _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _SZ,
                                        C.POINTER(_I64), _P]),
+    "nm_raster_preprocess_async": (C.c_int, [C.POINTER(nm_raster_cfg), _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _P]),
     "nm_raster_render": (C.c_int, [C.POINTER(nm_raster_cfg), _I32, _I64, _P, _P, _SZ, _P, _SZ, _P, _SZ, _P, _P]),
     "nm_raster_bwd_workspace": (_SZ, [_I32]),
     "nm_raster_backward": (C.c_int, [C.POINTER(nm_raster_cfg), _I32, _I32, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P,

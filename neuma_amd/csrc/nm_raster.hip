@@ -791,7 +791,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(RK k, int K, const float
 }
 
 // ---------------------------------------------------------------- host API
-extern "C" int nm_raster_preprocess(const nm_raster_cfg* cfg, int32_t K, int32_t m, const float* means3D, const float* shs,
+static int raster_preprocess_impl(bool wait, const nm_raster_cfg* cfg, int32_t K, int32_t m, const float* means3D, const float* shs,
                                     const float* colors_precomp, const float* opacities, const float* cov3D, int32_t* radii,
                                     void* geom, size_t geom_bytes, int64_t* num_rendered, void* stream) {
   RK k;
@@ -816,11 +816,26 @@ extern "C" int nm_raster_preprocess(const nm_raster_cfg* cfg, int32_t K, int32_t
   NM_LAUNCH_CHECK();
   size_t tb = g.scan_bytes;
   NM_HIP_CHECK(rocprim::inclusive_scan(g.scan_tmp, tb, g.tiles_sorted, g.offs, (size_t)K, rocprim::plus<uint32_t>(), s));
+  if (!wait) {   // num_rendered is pinned host memory (pre-zeroed by the caller's *num_rendered = 0 above): low 32 bits arrive later
+    NM_HIP_CHECK(hipMemcpyAsync(num_rendered, g.offs + (K - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    return NM_OK;
+  }
   uint32_t total = 0;
   NM_HIP_CHECK(hipMemcpyAsync(&total, g.offs + (K - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   NM_HIP_CHECK(hipStreamSynchronize(s));
   *num_rendered = (int64_t)total;
   return NM_OK;
+}
+
+extern "C" int nm_raster_preprocess(const nm_raster_cfg* cfg, int32_t K, int32_t m, const float* means3D, const float* shs,
+                                    const float* colors_precomp, const float* opacities, const float* cov3D, int32_t* radii,
+                                    void* geom, size_t geom_bytes, int64_t* num_rendered, void* stream) {
+  return raster_preprocess_impl(true, cfg, K, m, means3D, shs, colors_precomp, opacities, cov3D, radii, geom, geom_bytes, num_rendered, stream);
+}
+extern "C" int nm_raster_preprocess_async(const nm_raster_cfg* cfg, int32_t K, int32_t m, const float* means3D, const float* shs,
+                                    const float* colors_precomp, const float* opacities, const float* cov3D, int32_t* radii,
+                                    void* geom, size_t geom_bytes, int64_t* num_rendered, void* stream) {
+  return raster_preprocess_impl(false, cfg, K, m, means3D, shs, colors_precomp, opacities, cov3D, radii, geom, geom_bytes, num_rendered, stream);
 }
 
 extern "C" int nm_raster_render(const nm_raster_cfg* cfg, int32_t K, int64_t D, const void* geom, void* binning,

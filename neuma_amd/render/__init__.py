@@ -68,29 +68,80 @@ def build_cov3D(scales: Tensor, rotations: Tensor, scale_modifier: float = 1.0) 
     return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], -1)
 
 
+class PreparedRaster(object):
+    """Stage 1 of a rasterization (preprocess, depth order, tile counts) that has been enqueued but whose pair count has
+    not been read yet (nm_raster_preprocess_async).  A caller with several views prepares all of them, then rasterizes:
+    the host blocks on the first count only after every view's stage 1 is in flight (harness.SceneRuntime.frame)."""
+
+    def __init__(self, cam, inputs, radii, geom, geom_bytes, count, event):
+        self.cam, self.inputs, self.radii, self.geom, self.geom_bytes, self.count, self.event = \
+            cam, inputs, radii, geom, geom_bytes, count, event
+
+    def matches(self, cam, m3, sh, cp, op, cv) -> bool:
+        def same(a, b):
+            return (a is None and b is None) or (a is not None and b is not None and a.data_ptr() == b.data_ptr()
+                                                  and a.shape == b.shape and a._version == b._version)
+        return cam is self.cam and all(same(a, b) for a, b in zip(self.inputs, (m3, sh, cp, op, cv)))
+
+    def num_rendered(self) -> int:
+        self.event.synchronize()
+        return int(self.count.item())
+
+
+def _raster_inputs(means3D, shs, colors_precomp, opacities, cov3D):
+    m3 = means3D.detach().float().contiguous()
+    op = opacities.detach().float().contiguous()
+    cv = cov3D.detach().float().contiguous()
+    sh = None if shs is None else shs.detach().float().contiguous()
+    cp = None if colors_precomp is None else colors_precomp.detach().float().contiguous()
+    return m3, sh, cp, op, cv
+
+
+def prepare_rasterization(rasterizer, means3D, opacities, shs=None, colors_precomp=None, cov3D_precomp=None) -> PreparedRaster:
+    """Enqueue stage 1 for `rasterizer` (a GaussianRasterizer) on the current stream; pass the result to
+    rasterizer(..., prepared=...) with the SAME tensors."""
+    lib = L.lib()
+    cam = rasterizer._cam
+    m3, sh, cp, op, cv = _raster_inputs(means3D, shs, colors_precomp, opacities, cov3D_precomp)
+    dev = m3.device
+    K = m3.size(0)
+    M = 0 if sh is None else sh.size(1)
+    radii = torch.empty(K, dtype=torch.int32, device=dev)
+    geom_bytes = int(lib.nm_raster_geom_bytes(K))
+    geom = torch.empty(geom_bytes, dtype=torch.uint8, device=dev)
+    count = torch.zeros(1, dtype=torch.int64, pin_memory=True)
+    L.check(lib.nm_raster_preprocess_async(C.byref(cam.cfg), K, M, L.ptr(m3), L.ptr(sh), L.ptr(cp), L.ptr(op), L.ptr(cv),
+                                           L.ptr(radii), L.ptr(geom), geom_bytes, C.c_void_p(count.data_ptr()), L.stream_ptr(dev)),
+            "nm_raster_preprocess_async")
+    ev = torch.cuda.Event()
+    ev.record()
+    return PreparedRaster(cam, (m3, sh, cp, op, cv), radii, geom, geom_bytes, count, ev)
+
+
 class _RasterizeGaussians(autograd.Function):
 
     @staticmethod
-    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, cov3D, cam: RasterCamera):
+    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, cov3D, cam: RasterCamera, prepared=None):
         lib = L.lib()
         dev = means3D.device
         stream = L.stream_ptr(dev)
         cfg = cam.cfg
         K = means3D.size(0)
-        m3 = means3D.detach().float().contiguous()
-        op = opacities.detach().float().contiguous()
-        cv = cov3D.detach().float().contiguous()
-        sh = None if shs is None else shs.detach().float().contiguous()
-        cp = None if colors_precomp is None else colors_precomp.detach().float().contiguous()
+        m3, sh, cp, op, cv = _raster_inputs(means3D, shs, colors_precomp, opacities, cov3D)
         M = 0 if sh is None else sh.size(1)
         H, W = cfg.image_height, cfg.image_width
-        radii = torch.empty(K, dtype=torch.int32, device=dev)            # k_preprocess writes every entry
-        geom_bytes = int(lib.nm_raster_geom_bytes(K))
-        geom = torch.empty(geom_bytes, dtype=torch.uint8, device=dev)
-        num = C.c_int64(0)
-        L.check(lib.nm_raster_preprocess(C.byref(cfg), K, M, L.ptr(m3), L.ptr(sh), L.ptr(cp), L.ptr(op), L.ptr(cv), L.ptr(radii),
-                                         L.ptr(geom), geom_bytes, C.byref(num), stream), "nm_raster_preprocess")
-        D = int(num.value)
+        if prepared is not None and prepared.matches(cam, m3, sh, cp, op, cv):
+            radii, geom, D = prepared.radii, prepared.geom, prepared.num_rendered()
+            if geom.device == dev:
+                geom.record_stream(torch.cuda.current_stream(dev)); radii.record_stream(torch.cuda.current_stream(dev))
+        else:
+            radii = torch.empty(K, dtype=torch.int32, device=dev)            # k_preprocess writes every entry
+            geom_bytes = int(lib.nm_raster_geom_bytes(K))
+            geom = torch.empty(geom_bytes, dtype=torch.uint8, device=dev)
+            num = C.c_int64(0)
+            L.check(lib.nm_raster_preprocess(C.byref(cfg), K, M, L.ptr(m3), L.ptr(sh), L.ptr(cp), L.ptr(op), L.ptr(cv), L.ptr(radii),
+                                             L.ptr(geom), geom_bytes, C.byref(num), stream), "nm_raster_preprocess")
+            D = int(num.value)
         bin_bytes = int(lib.nm_raster_binning_bytes(D, C.byref(cfg)))
         img_bytes = int(lib.nm_raster_image_bytes(C.byref(cfg)))
         scr_bytes = int(lib.nm_raster_scratch_bytes(D))
@@ -133,7 +184,7 @@ class _RasterizeGaussians(autograd.Function):
                                        L.ptr(binning), L.ptr(imgbuf), L.ptr(g), L.ptr(dmeans3D), L.ptr(dmeans2D), L.ptr(dcov),
                                        L.ptr(dop), L.ptr(dsh), L.ptr(dcol), L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
                 "nm_raster_backward")
-        return dmeans3D, dmeans2D, dsh, dcol, dop, dcov, None
+        return dmeans3D, dmeans2D, dsh, dcol, dop, dcov, None, None
 
 
 class GaussianRasterizer(nn.Module):
@@ -148,7 +199,7 @@ class GaussianRasterizer(nn.Module):
         return (hom @ s.viewmatrix.to(positions))[:, 2] > 0.2
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None):
+                cov3D_precomp=None, prepared=None):
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
@@ -158,7 +209,7 @@ class GaussianRasterizer(nn.Module):
             cov3D_precomp = build_cov3D(scales, rotations, self._cam.settings.scale_modifier)
         if means2D is None:
             means2D = torch.zeros_like(means3D)
-        return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, cov3D_precomp, self._cam)
+        return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, cov3D_precomp, self._cam, prepared)
 
 
 def get_rasterizer(viewpoint_camera, active_sh_degree: int, debug, bg_color: Tensor, scaling_modifier=1.0,
