@@ -22,7 +22,18 @@ for a, b in zip(marks[-2::-2][1:], marks[-2::-2]):
         break
 if seq is None:
     raise SystemExit("no frame found")
-print("frame span %.3f ms, %d kernels, busy %.3f ms" % ((seq[-1][1] - seq[0][0]) / 1e6, len(seq), sum(r[1] - r[0] for r in seq) / 1e6))
+cover, end = 0, seq[0][0]
+idle = []
+for r in seq:                       # union of the kernel intervals (kernels of different streams overlap)
+    if r[0] > end:
+        idle.append(((r[0] - end) / 1e3, r[2]))
+        end = r[0]
+    if r[1] > end:
+        cover += r[1] - end
+        end = r[1]
+print("frame span %.3f ms, %d kernels, kernel time summed %.3f ms, GPU busy (union) %.3f ms" %
+      ((seq[-1][1] - seq[0][0]) / 1e6, len(seq), sum(r[1] - r[0] for r in seq) / 1e6, cover / 1e6))
+print("largest idle gaps (us, before kernel):", sorted(idle, reverse=True)[:12])
 out = []
 for r in seq:
     d = (r[1] - r[0]) / 1e3
