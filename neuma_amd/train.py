@@ -29,6 +29,7 @@ import torch
 from torch.nn.utils import clip_grad_norm_
 from torch.optim import RAdam, lr_scheduler
 
+from .render import deform_cov_by_F
 from .tune import compute_bindings_xyz, compute_bindings_F
 
 
@@ -167,8 +168,11 @@ def video_loss(rt, gt_frames, c, decay_rate: float, views: Sequence[int], deform
             means3D = compute_bindings_xyz(de_x, de_prev, g_prev, rt.bindings)
             dg = compute_bindings_F(F, rt.bindings) if deform_cov else None
             lf = torch.zeros((), device=rt.device)
+            # covariance push-forward once per frame; stage 1 of every view is enqueued before the first pair-count read-back
+            cov = deform_cov_by_F(rt._cov, dg) if dg is not None else rt._cov
+            preps = [rt.prepare_view(means3D.detach(), cov, vi) for vi in views]
             for i, vi in enumerate(views):
-                render = rt.render_view(means3D, dg, vi)
+                render = rt.render_view(means3D, None, vi, cov=cov, prepared=preps[i])
                 lf = lf + w * rt.pixel_loss(render, gt_frames[cur_step - 1][i])
             terms.append(lf)
             de_prev = de_x.clone().detach()
