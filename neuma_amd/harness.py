@@ -18,9 +18,7 @@ import os
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
 
-import numpy as np
 import torch
-import torch.nn as nn
 
 from . import synth
 from .material import InvariantFullMetaElasticity, InvariantFullMetaPlasticity

@@ -46,7 +46,6 @@ class _LoraMergeLayers(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, scalings, *wba):
-        import ctypes as C
         from .. import _lib as L
         n = len(scalings)
         prep = [t.detach().contiguous().float() for t in wba]
@@ -63,7 +62,6 @@ class _LoraMergeLayers(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gs):
-        import ctypes as C
         from .. import _lib as L
         n = len(ctx.scalings)
         BA = ctx.saved_tensors
