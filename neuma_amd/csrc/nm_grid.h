@@ -80,10 +80,14 @@ __device__ __forceinline__ float sel3(const float* a, int i) { return i == 0 ? a
 // mpm.py:432-498 for one particle: gather v and C' from the 27 stencil nodes, advance x (clamped), return the trial
 // deformation gradient (I + dt C') F in Fo.  Disabled particles pass their state through (mpm.py:443-444).  UNROLL: all 27
 // gathers in flight (for callers that run one wave per SIMD); otherwise nine per trip, which keeps k_g2p at 4+ waves/SIMD.
-template <bool UNROLL>
+// FILL (passive extra sets, mpm.py:260-277): a stencil node in a block the scattering particles did not touch reads what the
+// reference's dense grid_op sweep leaves there - BC(g dt) of an empty node (mpm.py:384-385 / 413-414) - instead of the
+// block-sparse grid's zero; `flags[block] == epoch` marks the blocks this substep built.
+template <bool UNROLL, bool FILL = false>
 __device__ __forceinline__ void g2p_particle(const MpmK& K, int p, const float* __restrict__ clip, const int* __restrict__ enabled,
                                              const float* x, const float* v, const float* C, const float* F,
-                                             const float4* __restrict__ gv, float* xn, float* vn, float* Cn, M3& Fo) {
+                                             const float4* __restrict__ gv, float* xn, float* vn, float* Cn, M3& Fo,
+                                             const int* __restrict__ flags = nullptr, int epoch = 0) {
   if (enabled[p] == 0) {
     Fo = m3_load(F + 9 * p);
     if (xn != x) {
@@ -111,7 +115,16 @@ __device__ __forceinline__ void g2p_particle(const MpmK& K, int p, const float* 
       for (int k = 0; k < 3; ++k) {
         float d2 = ((float)k - st.f[2]) * K.dx;
         float w = wij * st.w[2][k];
-        float4 g = gv[node_addr(st.b[0] + i, st.b[1] + j, st.b[2] + k, K.nb)];
+        const int ni = st.b[0] + i, nj = st.b[1] + j, nk = st.b[2] + k;
+        float4 g = gv[node_addr(ni, nj, nk, K.nb)];
+        if (FILL) {
+          if (ni < K.G && nj < K.G && nk < K.G && flags[((ni >> 2) * K.nb + (nj >> 2)) * K.nb + (nk >> 2)] != epoch) {
+            const float4 empty = {0.f, 0.f, 0.f, 0.f};
+            float u[3], mk[3];
+            grid_velocity(K, ni, nj, nk, empty, u, mk);
+            g.x = u[0] * mk[0]; g.y = u[1] * mk[1]; g.z = u[2] * mk[2];
+          }
+        }
         nv[0] += w * g.x; nv[1] += w * g.y; nv[2] += w * g.z;
         float kw = kap * w;  // mpm.py:479: (4 w inv_dx^2) outer(v, dpos)
         nC.m[0] += kw * g.x * d0; nC.m[1] += kw * g.x * d1; nC.m[2] += kw * g.x * d2;

@@ -662,6 +662,17 @@ __global__ void __launch_bounds__(256, 4) k_g2p(MpmK K, int n, const float* __re
   if (enabled[p] != 0 || Fn != F) m3_store(Fn + 9 * p, Fo);
 }
 
+// g2p onto a passive particle set (MPMModel.forward_extra, mpm.py:260-277): in place, untouched blocks read as BC(g dt)
+__global__ void __launch_bounds__(256, 4) k_g2p_extra(MpmK K, int n, const float* __restrict__ clip, const int* __restrict__ enabled,
+                                                   float* x, float* v, float* C, float* F, const float4* __restrict__ gv,
+                                                   const int* __restrict__ flags, int epoch) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  M3 Fo;
+  g2p_particle<false, true>(K, p, clip, enabled, x, v, C, F, gv, x, v, C, Fo, flags, epoch);
+  if (enabled[p] != 0) m3_store(F + 9 * p, Fo);
+}
+
 // adjoint of g2p: writes gx (direct part), gF; scatters vbar into gg (same wave-tile scheme as p2g)
 struct G2pBwdP {  // per-particle quantities of the g2p adjoint
   Stencil st;
@@ -860,14 +871,22 @@ __global__ void k_grid_stats(const float4* __restrict__ gm, const int* __restric
   if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = cnt;
 }
 
+// dense (G,G,G) view of the block-sparse grid, as the reference's arrays read after grid_op: blocks the last substep did
+// not touch hold m = mv = 0 and v = BC(g dt) (the dense sweep of mpm.py:373-429 visits every node)
 __global__ void k_grid_export(MpmK K, const float4* __restrict__ gm, const float4* __restrict__ gv, float* mv, float* m,
-                              float* v) {
+                              float* v, const int* __restrict__ flags, int epoch) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   int G = K.G;
   if (t >= G * G * G) return;
   int i = t / (G * G), r = t - i * G * G, j = r / G, k = r - j * G;
   int a = node_addr(i, j, k, K.nb);
   float4 q = gm[a], u = gv[a];
+  if (flags[((i >> 2) * K.nb + (j >> 2)) * K.nb + (k >> 2)] != epoch) {
+    q = make_float4(0.f, 0.f, 0.f, 0.f);
+    float w[3], mk[3];
+    grid_velocity(K, i, j, k, q, w, mk);
+    u = make_float4(w[0] * mk[0], w[1] * mk[1], w[2] * mk[2], 0.f);
+  }
   if (mv) { mv[3 * t] = q.x; mv[3 * t + 1] = q.y; mv[3 * t + 2] = q.z; }
   if (m) m[t] = q.w;
   if (v) { v[3 * t] = u.x; v[3 * t + 1] = u.y; v[3 * t + 2] = u.z; }
@@ -1071,9 +1090,8 @@ extern "C" int nm_mpm_forward_extra(nm_mpm* h, int32_t n, const nm_statics* st, 
   rc = mpm_build_grid(h, n, st, cur, s);
   if (rc) return rc;
   if (n_extra > 0) {
-    NM_LAUNCH(k_g2p, dim3(nm_div_up(n_extra, 256)), dim3(256), 0, s, h->k, n_extra, st_extra->clip_bound,
-                       st_extra->enabled, extra->x, extra->v, extra->C, extra->F, h->gv, extra->x, extra->v, extra->C,
-                       extra->F);
+    NM_LAUNCH(k_g2p_extra, dim3(nm_div_up(n_extra, 256)), dim3(256), 0, s, h->k, n_extra, st_extra->clip_bound,
+                          st_extra->enabled, extra->x, extra->v, extra->C, extra->F, h->gv, h->flags, h->epoch);
     NM_LAUNCH_CHECK();
   }
   return NM_OK;
@@ -1258,7 +1276,7 @@ extern "C" int nm_mpm_grid_export(nm_mpm* h, float* mv, float* m, float* v, void
   NM_REQUIRE(h, "null handle");
   int G = h->k.G;
   NM_LAUNCH(k_grid_export, dim3(nm_div_up((int64_t)G * G * G, 256)), dim3(256), 0, (hipStream_t)stream, h->k,
-                     h->gm, h->gv, mv, m, v);
+                     h->gm, h->gv, mv, m, v, h->flags, h->epoch);
   NM_LAUNCH_CHECK();
   return NM_OK;
 }

@@ -359,10 +359,18 @@ class MPMModelBuilder(ModelBuilder):
         return MPMModel(self.build_constant(), device, requires_grad, bc=bc)
 
 
+def _per_particle(values, counts, dtype, device) -> Tensor:
+    """Expand one value per group to one value per particle (group g owns counts[g] consecutive particles)."""
+    vals = torch.as_tensor(np.asarray(values, dtype=np.float64), dtype=dtype)
+    return torch.repeat_interleave(vals, torch.as_tensor(list(counts), dtype=torch.long)).to(device)
+
+
 @dataclass
 class MPMInitData(object):
-    """mpm.py:554-692 (the trimesh / PLY loading of get_pcd is replaced by an .npz / ndarray path:
-    asset preprocessing is out of scope)."""
+    """One body of particles as the initializers consume it - field names of mpm.py:554-574 (rho, clip_bound, span,
+    num_particles, vol, pos, lin_vel, ang_vel, center, ind_vel, bounds, size).  Particle positions come from an ndarray or
+    from the `<name>.npz` cache (p_x, vol) the reference itself writes (mpm.py:653); sampling a mesh / PLY with trimesh is
+    asset preprocessing and out of scope."""
 
     rho: float
     clip_bound: float
@@ -379,66 +387,74 @@ class MPMInitData(object):
 
     def __post_init__(self) -> None:
         if self.center is None:
-            self.center = self.pos.mean(0)
+            self.center = self.pos.mean(0)          # rotation centre of ang_vel defaults to the centroid
 
     @staticmethod
     def alignment(min_bound_1, max_bound_1, min_bound_2, max_bound_2):
-        """mpm.py:576-594"""
-        center_1 = (min_bound_1 + max_bound_1) / 2
-        center_2 = (min_bound_2 + max_bound_2) / 2
-        scale_factor = (max_bound_2 - min_bound_2) / (max_bound_1 - min_bound_1)
-        translation = center_2 - center_1 * scale_factor
-        return scale_factor, translation
+        """Per-axis affine map p -> p * scale + shift taking box 1 onto box 2 (mpm.py:576-594). Returns (scale, shift)."""
+        lo1, hi1, lo2, hi2 = (np.asarray(b, dtype=np.float64) for b in (min_bound_1, max_bound_1, min_bound_2, max_bound_2))
+        scale = (hi2 - lo2) / (hi1 - lo1)
+        shift = 0.5 * (lo2 + hi2) - 0.5 * (lo1 + hi1) * scale
+        return scale, shift
 
     @classmethod
     def get(cls, cfg) -> 'MPMInitData':
+        """From a `particle_data` config node (rho, clip_bound, span, shape.{name, asset_root, sort, ori_bounds, sim_bounds})."""
         shape = _cfg_req(cfg, "shape")
-        kwargs = cls.get_pcd(_cfg_req(shape, "name"), _cfg_get(shape, "asset_root"), _cfg_get(shape, "sort"),
-                             _cfg_get(shape, "ori_bounds"), _cfg_get(shape, "sim_bounds"))
-        return cls(rho=_cfg_req(cfg, "rho"), clip_bound=_cfg_req(cfg, "clip_bound"), span=tuple(_cfg_req(cfg, "span")), **kwargs)
+        body = cls.get_pcd(_cfg_req(shape, "name"), _cfg_get(shape, "asset_root"), _cfg_get(shape, "sort"),
+                           _cfg_get(shape, "ori_bounds"), _cfg_get(shape, "sim_bounds"))
+        return cls(rho=_cfg_req(cfg, "rho"), clip_bound=_cfg_req(cfg, "clip_bound"), span=tuple(_cfg_req(cfg, "span")), **body)
 
     @classmethod
     def get_pcd(cls, name, asset_root, sort=None, ori_bounds=None, sim_bounds=None) -> dict:
-        """mpm.py:607-677, reading the cached `<name>.npz` (p_x, vol) the reference itself writes at :653."""
+        """Counterpart of mpm.py:607-677 for the cached form of an asset."""
         assert ori_bounds is not None, "ori_bounds must be provided for pcd shape."
         assert sim_bounds is not None, "sim_bounds must be provided for pcd shape."
-        ori_bounds, sim_bounds = np.array(ori_bounds, dtype=np.float64), np.array(sim_bounds, dtype=np.float64)
-        path = Path(asset_root if asset_root is not None else ".") / f"{name}.npz"
-        if not path.is_file():
-            raise FileNotFoundError(f"{path}: particle cache not found (mesh/PLY sampling is out of scope here)")
-        file = np.load(path)
-        return cls.from_points(file['p_x'], float(file['vol']), ori_bounds, sim_bounds, sort)
+        cache = Path(asset_root if asset_root is not None else ".") / f"{name}.npz"
+        if not cache.is_file():
+            raise FileNotFoundError(f"{cache}: particle cache not found (mesh/PLY sampling is out of scope here)")
+        with np.load(cache) as file:
+            return cls.from_points(file['p_x'], float(file['vol']), ori_bounds, sim_bounds, sort)
 
     @classmethod
     def from_points(cls, p_x: np.ndarray, vol: float, ori_bounds, sim_bounds, sort=None) -> dict:
-        p_x = np.array(p_x, dtype=np.float64).copy()
+        """Map raw points and their per-particle volume from `ori_bounds` into the unit-cube box `sim_bounds`."""
+        pts = np.array(p_x, dtype=np.float64).reshape(-1, 3)
         if sort is not None:
-            p_x = p_x[np.argsort(-p_x[:, sort], kind="stable")]
-        size, center = cls.alignment(np.asarray(ori_bounds[0]), np.asarray(ori_bounds[1]),
-                                     np.asarray(sim_bounds[0]), np.asarray(sim_bounds[1]))
-        vol = vol * np.prod(size)
-        p_x = np.ascontiguousarray((p_x * size + center).reshape(-1, 3))
-        assert p_x.min() >= 0.0 and p_x.max() <= 1.0        # mpm.py:673-675
-        return dict(num_particles=p_x.shape[0], vol=vol, pos=p_x, center=center, size=size)
+            pts = pts[np.argsort(-pts[:, sort], kind="stable")]            # descending along axis `sort`
+        ori, sim = np.asarray(ori_bounds, dtype=np.float64), np.asarray(sim_bounds, dtype=np.float64)
+        scale, shift = cls.alignment(ori[0], ori[1], sim[0], sim[1])
+        pts = np.ascontiguousarray(pts * scale + shift)
+        if pts.min() < 0.0 or pts.max() > 1.0:                              # same condition as the asserts of mpm.py:673-675
+            raise AssertionError("particles leave the unit cube after mapping ori_bounds -> sim_bounds")
+        return dict(num_particles=pts.shape[0], vol=vol * float(np.prod(scale)), pos=pts, center=shift, size=scale)
 
     def set_lin_vel(self, value) -> None:
         self.lin_vel = np.array(value)
 
     def zero_lin_vel(self) -> None:
-        self.set_lin_vel(np.zeros_like(self.lin_vel))
+        self.lin_vel = np.zeros_like(self.lin_vel)
 
     def set_ang_vel(self, value) -> None:
         self.ang_vel = np.array(value)
 
     def zero_ang_vel(self) -> None:
-        self.set_ang_vel(np.zeros_like(self.ang_vel))
+        self.ang_vel = np.zeros_like(self.ang_vel)
 
     def set_ind_vel(self, ind_vel) -> None:
         self.ind_vel = np.array(ind_vel)
 
+    def velocities(self) -> np.ndarray:
+        """Initial particle velocities: the individual ones if given, else rigid motion lin_vel + ang_vel x (pos - center)."""
+        if self.ind_vel is not None:
+            return np.asarray(self.ind_vel, dtype=np.float64)
+        arm = np.asarray(self.pos, dtype=np.float64) - np.asarray(self.center, dtype=np.float64)
+        return np.asarray(self.lin_vel, dtype=np.float64) + np.cross(np.asarray(self.ang_vel, dtype=np.float64), arm)
+
 
 class MPMStateInitializer(StateInitializer):
-    """mpm.py:695-735"""
+    """Builds the initial MPMState of all added bodies, concatenated in the order added (interface of mpm.py:695-735):
+    finalize() -> (state, sections)."""
 
     StateType = MPMState
     ModelType = MPMModel
@@ -451,26 +467,18 @@ class MPMStateInitializer(StateInitializer):
         self.groups.append(group)
 
     def finalize(self):
-        pos_groups, vel_groups, sections = [], [], []
-        for group in self.groups:
-            pos = group.pos.copy()
-            if group.ind_vel is None:
-                vel = group.lin_vel.copy() + np.cross(group.ang_vel.copy(), pos - group.center)
-            else:
-                vel = group.ind_vel.copy()
-            pos_groups.append(pos)
-            vel_groups.append(vel)
-            sections.append(group.num_particles)
-        pos_groups = np.concatenate(pos_groups, axis=0)
-        vel_groups = np.concatenate(vel_groups, axis=0)
-        state_0 = super().finalize(shape=pos_groups.shape[0], requires_grad=False)
-        state_0.particle.x.copy_(torch.as_tensor(pos_groups, dtype=torch.float32))
-        state_0.particle.v.copy_(torch.as_tensor(vel_groups, dtype=torch.float32))
-        return state_0, sections
+        sections = [int(g.num_particles) for g in self.groups]
+        state = super().finalize(shape=sum(sections), requires_grad=False)
+        x = np.concatenate([np.asarray(g.pos, dtype=np.float64) for g in self.groups], axis=0)
+        v = np.concatenate([g.velocities() for g in self.groups], axis=0)
+        state.particle.x.copy_(torch.from_numpy(x).to(torch.float32))
+        state.particle.v.copy_(torch.from_numpy(v).to(torch.float32))
+        return state, sections
 
 
 class MPMStaticsInitializer(StaticsInitializer):
-    """mpm.py:738-776"""
+    """Per-particle constants of all added bodies (interface of mpm.py:738-776): finalize() -> statics;
+    update(statics, step) re-evaluates `enabled` from each body's span."""
 
     StaticsType = MPMStatics
     ModelType = MPMModel
@@ -480,22 +488,23 @@ class MPMStaticsInitializer(StaticsInitializer):
         self.groups = []
         self.sections, self.vols, self.rhos, self.clip_bounds, self.spans = [], [], [], [], []
 
-    def update(self, statics, step: int = 0) -> None:
-        statics.update_enabled(self.sections, self.spans, step=step)
-
     def add_group(self, group: MPMInitData) -> None:
         self.groups.append(group)
 
+    def update(self, statics, step: int = 0) -> None:
+        statics.update_enabled(self.sections, self.spans, step=step)
+
     def finalize(self):
-        for group in self.groups:
-            self.sections.append(group.num_particles)
-            self.vols.append(group.vol)
-            self.rhos.append(group.rho)
-            self.clip_bounds.append(group.clip_bound)
-            self.spans.append(group.span)
+        new = self.groups[len(self.sections):]          # bodies not tabulated yet (finalize may follow further add_group calls)
+        self.sections += [int(g.num_particles) for g in new]
+        self.vols += [g.vol for g in new]
+        self.rhos += [g.rho for g in new]
+        self.clip_bounds += [g.clip_bound for g in new]
+        self.spans += [tuple(g.span) for g in new]
         statics = super().finalize(shape=sum(self.sections))
-        statics.update_vol(self.sections, self.vols)
-        statics.update_rho(self.sections, self.rhos)
-        statics.update_clip_bound(self.sections, self.clip_bounds)
+        dev = statics.vol.device
+        statics.vol.copy_(_per_particle(self.vols, self.sections, torch.float32, dev))
+        statics.rho.copy_(_per_particle(self.rhos, self.sections, torch.float32, dev))
+        statics.clip_bound.copy_(_per_particle(self.clip_bounds, self.sections, torch.float32, dev))
         self.update(statics, step=0)
         return statics

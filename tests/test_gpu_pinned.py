@@ -1,0 +1,146 @@
+"""GPU parity against fixtures produced by EXECUTING the reference's own kernel code (tests/golden/gen_mpm_golden.py):
+MPM substep + adjoints, in-place forward roll-out with span enabling, passive extra set, SVD det/sign rule,
+deform_cov_by_F.  Everything goes through the C ABI (libneuma_hip.so).  fp32 tolerances of DESIGN.md §2."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mpm as om
+from gpu_util import dev, build_model, build_statics
+
+pytestmark = pytest.mark.gpu
+
+STEP_TAGS = ["n64_g16_noslip", "n64_g16_freeslip", "n2048_g32_noslip", "n2048_g32_freeslip"]
+GRAD_TAGS = ["n64_g16_noslip", "n64_g16_freeslip", "n384_g16_noslip", "n384_g16_freeslip"]
+GRAVITY = (0.0, float(np.float32(-9.8)), 0.0)
+
+
+def _case(z, bc):
+    const = om.MPMConstant(num_grids=int(z["in_G"]), dt=float(z["in_dt"]), bound=1, gravity=GRAVITY, eps=6e-7, bc=bc)
+    t = lambda k: torch.from_numpy(z["in_" + k])  # noqa: E731
+    model = build_model(const, dev())
+    st = build_statics(model, t("vol"), t("rho"), t("clip_bound"), torch.from_numpy(z["in_enabled"]), dev())
+    ins = [t(k).float().to(dev()) for k in ["x", "v", "C", "F", "stress"]]
+    return const, model, st, ins
+
+
+@pytest.mark.parametrize("reorder", [False, "auto"])
+@pytest.mark.parametrize("tag", STEP_TAGS)
+def test_substep_vs_reference_run(golden_dir, tag, reorder):
+    from neuma_amd.sim import MPMDiffSim
+    z = np.load(golden_dir / f"mpm_step_{tag}.npz")
+    const, model, st, ins = _case(z, tag.split("_")[-1])
+    outs = MPMDiffSim(model, reorder=reorder)(st, *ins)
+    e = z["in_enabled"] != 0
+    for ref_key, tol in [("f64", dict(x=5e-7, v=2e-5, C=5e-5, F=5e-6)), ("f32", dict(x=5e-7, v=2e-5, C=1e-4, F=5e-6))]:
+        for name, got in zip(["x", "v", "C", "F"], outs):
+            ref = z[f"{ref_key}_{name}"][e].astype(np.float64)
+            scale = max(1.0, np.abs(ref).max()) if name in ("v", "C") else 1.0
+            err = np.abs(got.detach().cpu().double().numpy()[e] - ref).max()
+            assert err <= tol[name] * scale, (ref_key, name, err)
+    if reorder is False:
+        mv, m, gv = (a.cpu().double().numpy() for a in model.grid_export())
+        assert np.abs(m - z["f64_m"]).max() <= 2e-6 * z["f64_m"].max()
+        assert np.abs(mv - z["f64_mv"]).max() <= 5e-6 * np.abs(z["f64_mv"]).max()
+        w = z["f64_m"][..., None]
+        assert np.abs(gv * m[..., None] - z["f64_gv"] * w).max() <= 2e-5 * np.abs(z["f64_gv"] * w).max()
+        # untouched nodes: the reference's dense sweep leaves v = BC(g dt) there; the block-sparse grid must export the same
+        un = z["f64_m"] == 0
+        assert np.abs(gv[un] - z["f64_gv"][un]).max() <= 1e-9
+
+
+@pytest.mark.parametrize("tag", GRAD_TAGS)
+def test_adjoints_vs_central_differences_of_the_reference(golden_dir, tag):
+    from neuma_amd.sim import MPMDiffSim
+    z = np.load(golden_dir / f"mpm_grad_{tag}.npz")
+    const, model, st, ins = _case(z, tag.split("_")[-1])
+    ins = [t.requires_grad_(True) for t in ins]
+    outs = MPMDiffSim(model, reorder=False)(st, *ins)
+    e = torch.from_numpy(z["in_enabled"] != 0).to(dev())
+    W = [torch.from_numpy(z["W_" + k]).float().to(dev()) for k in ["x", "v", "C", "F"]]
+    L = sum((w[e] * o[e]).sum() for w, o in zip(W, outs))
+    grads = torch.autograd.grad(L, ins)
+    for name, g in zip(["x", "v", "C", "F", "stress"], grads):
+        gd = g.double().cpu()
+        for d, fd in zip(z["dir_" + name], z["fd_" + name]):
+            d = torch.from_numpy(d)
+            an = float((gd * d).sum())
+            # fp32 error budget of an inner product: relative to |g|.|d| rather than to the (possibly cancelling) result
+            budget = 2e-3 * abs(fd) + 2e-6 * float(gd.abs().mul(d.abs()).sum())
+            assert abs(an - fd) <= budget, (name, an, fd)
+
+
+def _stress(F, mu, lam):
+    J = torch.linalg.det(F)
+    I = torch.eye(3, dtype=F.dtype, device=F.device)
+    return mu * (F @ F.transpose(1, 2) - I) + lam * torch.log(J)[:, None, None] * I
+
+
+def test_inplace_forward_rollout_spans_and_extra_vs_reference_run(golden_dir):
+    """render.py:304-310 order on the mirrored classes: from_torch(stress) -> MPMForwardSim (in place) ->
+    statics_initializer.update(statics, step); MPMExtraSim at steps 3 and 9."""
+    from neuma_amd.sim import MPMModelBuilder, MPMInitData, MPMStateInitializer, MPMStaticsInitializer, MPMForwardSim, MPMExtraSim
+    z = np.load(golden_dir / "mpm_rollout.npz")
+    cfg = dict(gravity=[0.0, -9.8, 0.0], bc="noslip", num_grids=int(z["G"]), dt=float(z["dt"]), bound=1, eps=6e-7)
+    model = MPMModelBuilder().parse_cfg(cfg).finalize(dev(), requires_grad=False)
+    sec = [int(s) for s in z["sections"]]
+    x0, v0 = z["x0"], z["v0"]
+    si, sti = MPMStateInitializer(model), MPMStaticsInitializer(model)
+    off = 0
+    for n, span in zip(sec, z["spans"]):
+        g = MPMInitData(rho=float(z["rho"][off]), clip_bound=float(z["clip_bound"][off]), span=(int(span[0]), int(span[1])),
+                        num_particles=n, vol=float(z["vol"][off]), pos=x0[off:off + n])
+        g.set_ind_vel(v0[off:off + n])
+        si.add_group(g); sti.add_group(g)
+        off += n
+    state, sections = si.finalize()
+    statics = sti.finalize()
+    assert np.array_equal(statics.enabled.cpu().numpy(), z["enabled0"])
+    sim, extra = MPMForwardSim(model, reorder=False), MPMExtraSim(model, reorder=False)
+    ne = z["xe0"].shape[0]
+    st_e = model.statics(ne)
+    st_e.enabled.fill_(1); st_e.clip_bound.fill_(0.1)
+    state_e = model.state(ne)
+    state_e.particle.x.copy_(torch.from_numpy(z["xe0"]).float())
+    tol = {1: dict(x=5e-7, v=2e-5, C=2e-4, F=5e-6), 5: dict(x=2e-6, v=5e-5, C=1e-3, F=1e-5), 12: dict(x=5e-6, v=1e-4, C=2e-3, F=2e-5)}
+    for step in range(1, 13):
+        F = state.particle.F
+        state.from_torch(stress=_stress(F.double(), float(z["mu"]), float(z["lam"])).float())
+        if step in (3, 9):
+            xe = extra(statics, state, st_e, state_e)
+            assert np.abs(xe.cpu().double().numpy() - z[f"f64_xe_{step}"]).max() < 2e-6
+        x, v, C, Fn = sim(statics, state)
+        sti.update(statics, step)
+        if step in tol:
+            assert np.array_equal(statics.enabled.cpu().numpy(), z[f"f64_enabled_{step}"])
+            for name, got in zip(["x", "v", "C", "F"], (x, v, C, Fn)):
+                ref = z[f"f64_{name}_{step}"]
+                scale = max(1.0, np.abs(ref).max()) if name in ("v", "C") else 1.0
+                err = np.abs(got.cpu().double().numpy() - ref).max()
+                assert err <= tol[step][name] * scale, (step, name, err)
+
+
+def test_svd_vs_reference_sign_rule(golden_dir):
+    from neuma_amd.svd import SVD
+    z = np.load(golden_dir / "svd_rule.npz")
+    A = torch.from_numpy(z["A"]).float().to(dev())
+    U, s, Vh = (t.double().cpu() for t in SVD()(A))
+    rU, rs, rVh = (torch.from_numpy(z[f"numpy_f64_{k}"]) for k in ["U", "sigma", "Vh"])
+    assert (s - rs).abs().max() < 2e-6
+    assert (torch.linalg.det(U) - 1).abs().max() < 1e-5 and (torch.linalg.det(Vh) - 1).abs().max() < 1e-5
+    assert (U @ torch.diag_embed(s) @ Vh - torch.from_numpy(z["A"])).abs().max() < 5e-6
+    distinct = ((rs[:, 0] - rs[:, 1]).abs() > 1e-2) & ((rs[:, 1] - rs[:, 2].abs()).abs() > 1e-2)
+    assert int(distinct.sum()) > 60
+    assert ((U @ Vh) - (rU @ rVh))[distinct].abs().max() < 2e-5
+    for i in range(3):      # rank-one pieces u_i v_i^T are sign-invariant: same factors up to the joint column flips
+        P = U[:, :, i, None] * Vh[:, None, i, :]
+        rP = rU[:, :, i, None] * rVh[:, None, i, :]
+        assert (P - rP)[distinct].abs().max() < 2e-4
+
+
+def test_cov_deform_vs_reference_run(golden_dir):
+    from neuma_amd.render import deform_cov_by_F
+    z = np.load(golden_dir / "cov_deform.npz")
+    out = deform_cov_by_F(torch.from_numpy(z["cov6"]).float().to(dev()), torch.from_numpy(z["F"]).float().to(dev()))
+    ref = z["f64_out"]
+    assert np.abs(out.cpu().double().numpy() - ref).max() <= 5e-7 * np.abs(ref).max()

@@ -86,6 +86,36 @@ def test_builder_and_initializers_on_cpu():
     assert float(st.rho[150]) == 500.0 and abs(float(st.vol[0]) - kw["vol"]) < 1e-12
 
 
+def test_initializers_match_the_reference_run(golden_dir):
+    """mpm_init.npz was produced by running the reference's MPMStateInitializer / MPMStaticsInitializer / update_enabled /
+    alignment / builder themselves (tests/golden/gen_mpm_golden.py, gen_init)."""
+    from neuma_amd.sim import MPMModelBuilder, MPMInitData, MPMStateInitializer, MPMStaticsInitializer
+    z = np.load(golden_dir / "mpm_init.npz")
+    model = MPMModelBuilder().parse_cfg(dict(gravity=[0.0, -9.8, 0.0], bc="noslip", num_grids=8, dt=1e-3, bound=1, eps=6e-7)).finalize("cpu")
+    c = model.constant
+    assert np.allclose([c.num_grids, c.dt, c.bound, c.dx, c.inv_dx, c.eps, *np.asarray(c.gravity)], z["constant"], rtol=1e-7, atol=0)
+    si, sti = MPMStateInitializer(model), MPMStaticsInitializer(model)
+    for i in range(3):
+        rho, clip, s0, s1, vol, *vel = z[f"spec_{i}"]
+        g = MPMInitData(rho=float(rho), clip_bound=float(clip), span=(int(s0), int(s1)), num_particles=len(z[f"pos_{i}"]), vol=float(vol),
+                        pos=z[f"pos_{i}"], lin_vel=np.array(vel[:3]), ang_vel=np.array(vel[3:]))
+        if i == 1:
+            g.set_ind_vel(z["ind_vel_1"])
+        si.add_group(g); sti.add_group(g)
+    state, sections = si.finalize()
+    st = sti.finalize()
+    assert sections == list(z["sections"])
+    for name in ["x", "v", "C", "F"]:
+        assert np.array_equal(getattr(state.particle, name).numpy(), z[name]), name      # fp32 cast of the same fp64 values
+    for name in ["vol", "rho", "clip_bound"]:
+        assert np.array_equal(getattr(st, name).numpy(), z[name]), name
+    for step in [0, 2, 3, 4, 5, 999, 1000]:
+        sti.update(st, step)
+        assert np.array_equal(st.enabled.numpy(), z[f"enabled_{step}"]), step
+    s, t = MPMInitData.alignment(np.array([-1.0, -2.0, 0.0]), np.array([1.0, 2.0, 4.0]), np.array([0.3, 0.3, 0.3]), np.array([0.7, 0.6, 0.5]))
+    assert np.allclose(s, z["align_scale"], rtol=1e-15) and np.allclose(t, z["align_trans"], rtol=1e-15, atol=1e-16)
+
+
 def test_synth_scene_is_deterministic_and_in_bounds():
     from neuma_amd import synth
     a, b = synth.make_scene("tiny"), synth.make_scene("tiny")
