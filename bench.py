@@ -2,7 +2,8 @@
 """Benchmark of the hot path: simulated + rendered frames/s, forward + backward.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: launched as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`, or plainly
+     as `python bench.py --gpus N`, which starts its own N ranks through torch.distributed.run on 127.0.0.1)
 
 One "step" = one video frame of the BASELINE.json metric workload: 100k particles / 128^3 grid / 200k Gaussians /
 1920x1080, S = 20 MPM substeps (each: elasticity net -> p2g/grid/g2p -> plasticity net) + V = 3 view renders +
@@ -91,9 +92,12 @@ def kernel_rooflines(full, rt, D):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)       # >= 200 timed frames after 20 warm-up (~2 s)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="metric")
+    ap.add_argument("--state", choices=("rest", "deformed", "impact"), default="rest",
+                    help="state each timed frame starts from: rest (SURVEY §8d generator), deformed (F = I + 0.05 N(0,1)), "
+                         "impact (post-floor-contact checkpoint) - see SceneRuntime.set_start_state")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-op", action="store_true", help="use the per-operator drop-in path instead of the fused roll-out")
     ap.add_argument("--shard-sim", choices=("auto", "on", "off"), default="auto",
@@ -101,6 +105,17 @@ def main():
                          "auto = on from 100k particles per rank (the 1M-particle stress workload), where a substep "
                          "outlasts its two block all-reduces")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")))
 
     # the shared library is a build artefact: build it if this checkout does not have it (rank 0 builds, the others wait)
     libpath = ROOT / "neuma_amd" / "lib" / "libneuma_hip.so"
@@ -122,15 +137,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     ndev = torch.cuda.device_count()
-    local = local % max(ndev, 1)          # NEUMA_DIST_BACKEND=gloo dry runs put several ranks on one GPU
+    local = local % max(ndev, 1)          # dry runs put several ranks on one GPU (gloo: RCCL refuses two ranks per device)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    backend = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("NEUMA_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        backend = os.environ.get("NEUMA_DIST_BACKEND", "nccl" if ndev >= world else "gloo")   # "nccl" is RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -147,10 +161,12 @@ def main():
         shard_sim = True
     rt = SceneRuntime(scene, dev, fused=not args.per_op, rank=rank, world=world, shard_sim=shard_sim,
                       group=dist.group.WORLD if world > 1 else None)
+    if args.state != "rest":
+        rt.set_start_state(args.state)
     rt.make_ground_truth()
     # touched grid nodes of the initial state (roofline accounting) and (Gaussian, tile) pairs per view
     with torch.no_grad():
-        rt.rollout(rt.x0[rt.rows], rt.v0[rt.rows], rt.C0[rt.rows], rt.F0[rt.rows])
+        rt.rollout(*(t[rt.rows] for t in rt.start))
         _, rt.touched_nodes = rt.model.grid_stats()
 
     def sync():
@@ -217,7 +233,7 @@ def main():
         from neuma_amd.tune import compute_bindings_xyz, compute_bindings_F
         from neuma_amd.render import _RasterizeGaussians
         with torch.no_grad():
-            m3 = compute_bindings_xyz(last.x, rt.x0, rt.gaussians.get_xyz, rt.bindings)
+            m3 = compute_bindings_xyz(last.x, rt.start[0], rt.g_start, rt.bindings)
             dg = compute_bindings_F(last.F, rt.bindings)
             from neuma_amd.render import deform_cov_by_F, get_rasterizer
             cov = deform_cov_by_F(rt._cov, dg)
@@ -286,17 +302,17 @@ def main():
 
         def sim_fwd():
             with torch.no_grad():
-                return rt.rollout(rt.x0[rw], rt.v0[rw], rt.C0[rw], rt.F0[rw])
+                return rt.rollout(*(t[rw] for t in rt.start))
 
         def sim_fwdbwd():
             zero_grads()
-            o = rt.rollout(rt.x0[rw], rt.v0[rw], rt.C0[rw], rt.F0[rw])
+            o = rt.rollout(*(t[rw] for t in rt.start))
             (o[0].sum() + o[3].sum()).backward()
 
         t_sf, o = gpu_ms(sim_fwd)
         t_sfb, _ = gpu_ms(sim_fwdbwd)
         with torch.no_grad():
-            m3 = compute_bindings_xyz(rt.all_rows(o[0]), rt.x0, rt.gaussians.get_xyz, rt.bindings)
+            m3 = compute_bindings_xyz(rt.all_rows(o[0]), rt.start[0], rt.g_start, rt.bindings)
             dgr = compute_bindings_F(rt.all_rows(o[3]), rt.bindings)
 
         def ren_fwd():
@@ -325,6 +341,11 @@ def main():
     if roof is not None and roof["kernel"].split("<")[0] in pmc and args.workload == "metric" and world == 1:
         roof["traffic"] = pmc[roof["kernel"].split("<")[0]]["hbm_bytes_per_launch"]
         roof["traffic_source"] = "profiles/pmc_traffic.json: rocprofv3 PMC passes of this workload (2 x FETCH_SIZE + WRITE_SIZE per launch)"
+    devices = [f"rank {rank}: cuda:{local} {torch.cuda.get_device_name(dev)}"]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, devices[0])
+        devices = gathered
     if rank == 0:
         cfg = scene.cfg
         total_ms = sum(v[1] for v in full.values()) or 1.0
@@ -337,7 +358,11 @@ def main():
                                    f"{cfg['W']}x{cfg['H']}", "substeps_per_frame": cfg["S"], "views_per_frame": cfg["V"],
                        "sh_degree": cfg["sh"], "material": cfg["mat"] + "_0300 + LoRA r16", "path": "per-op" if (args.per_op or shard_sim) else "fused-rollout",
                        "parallelism": (("particle-sharded sim" if shard_sim else "replicated sim") + " + render stripes") if world > 1 else "single GPU",
+                       "start_state": rt.state_kind,
                        "touched_grid_nodes": int(rt.touched_nodes), "gaussian_tile_pairs_per_view": int(D)},
+            "world": world, "backend": ({"nccl": "rccl"}.get(backend, backend) if world > 1 else None),
+            "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
+            "devices": devices,
             "roofline": roof,
             "cpu_baseline": cpu,
             "kernel_breakdown_ms_per_frame": {k: round(v[1], 3) for k, v in sorted(full.items(), key=lambda kv: -kv[1][1])[:12]},

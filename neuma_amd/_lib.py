@@ -146,16 +146,46 @@ def check(rc: int, what: str = ""):
 
 
 def stream_ptr(device=None) -> int:
+    """The caller's current HIP stream on `device`.  Also makes `device` the current HIP device of this thread: the
+    library launches on whatever device is current (kernel launches carry a stream handle, and a stream belongs to one
+    device), so an operator called on tensors of cuda:N while another device is current would otherwise fault."""
     import torch
+    if device is not None:
+        dev = torch.device(device)
+        if dev.type == "cuda" and dev.index is not None and dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
     return torch.cuda.current_stream(device).cuda_stream
 
 
-def ptr(t):
-    """Device pointer of a contiguous fp32/int32 CUDA(HIP) tensor, or None."""
+_OK_DTYPES = None
+
+
+def ptr(t, dtype=None):
+    """Device pointer of a contiguous fp32 / int32 / uint8 (opaque buffer) HIP tensor, or None.  `dtype`: required dtype."""
+    global _OK_DTYPES
     if t is None:
         return None
     if not t.is_cuda:
         raise NeumaHipError("neuma_amd operators need tensors on the GPU (no CPU path)")
     if not t.is_contiguous():
         raise NeumaHipError("tensor must be contiguous")
+    if _OK_DTYPES is None:
+        import torch
+        _OK_DTYPES = (torch.float32, torch.int32, torch.uint8)
+    if t.dtype not in _OK_DTYPES or (dtype is not None and t.dtype != dtype):
+        raise NeumaHipError(f"tensor dtype {t.dtype} not accepted here (the C ABI takes float32 / int32 arrays"
+                            f"{'' if dtype is None else ', this argument ' + str(dtype)})")
     return t.data_ptr()
+
+
+def same_device(*tensors):
+    """All non-None operands of one call must live on one device; returns it."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise NeumaHipError(f"operands on different devices: {dev} and {t.device}")
+    return dev

@@ -65,6 +65,9 @@ static inline int nm_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b
 
 // ---------------------------------------------------------------- 3x3 helpers (host+device, row-major)
 #define NM_HD __host__ __device__ __forceinline__
+// torch.nan_to_num(x, nan=0, posinf=0, neginf=0) for one value (NaN fails the comparison, +-Inf exceed FLT_MAX)
+__device__ __forceinline__ float nm_finite_or_zero(float v) { return fabsf(v) <= 3.402823466e+38f ? v : 0.f; }
+
 struct M3 {
   float m[9];
   NM_HD float& operator()(int r, int c) { return m[r * 3 + c]; }

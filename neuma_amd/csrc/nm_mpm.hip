@@ -770,7 +770,9 @@ __global__ void __launch_bounds__(NM_SC_T) k_g2p_bwd(MpmK K, int n, const float*
   }
   if (p < n) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a) gx[3 * p + a] = q.xbar[a];
+    for (int a = 0; a < 3; ++a) gx[3 * p + a] = q.xbar[a];   // completed (and sanitised) by k_p2g_bwd
+#pragma unroll
+    for (int a = 0; a < 9; ++a) q.Fbar.m[a] = nm_finite_or_zero(q.Fbar.m[a]);   // interface.py:65-74
     m3_store(gF + 9 * p, q.Fbar);
   }
   // (2) scatter of the node-velocity adjoint
@@ -786,7 +788,9 @@ __global__ void __launch_bounds__(NM_SC_T) k_g2p_bwd(MpmK K, int n, const float*
   wg_scatter<3>(K, active, q.st.b, gg, nullptr, nullptr, nullptr, 0, L, contrib);
 }
 
-// adjoint of p2g: gathers {mvbar, mbar}; writes gv, gC, gS and adds to gx
+// adjoint of p2g: gathers {mvbar, mbar}; writes gv, gC, gS and adds to gx.  These are the substep's returned gradients:
+// non-finite values become zeros here, per substep, exactly where interface.py:65-74 applies nan_to_num_ - so that the
+// fused roll-out (which never surfaces per-substep gradients to torch) behaves like the per-operator path.
 __global__ void __launch_bounds__(256, 2) k_p2g_bwd(MpmK K, int n, const float* __restrict__ vol, const float* __restrict__ rho,
                                                  const int* __restrict__ enabled, const float* __restrict__ x,
                                                  const float* __restrict__ v, const float* __restrict__ C,
@@ -797,7 +801,7 @@ __global__ void __launch_bounds__(256, 2) k_p2g_bwd(MpmK K, int n, const float* 
   if (p >= n) return;
   if (enabled[p] == 0) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a) gvp[3 * p + a] = 0.f;
+    for (int a = 0; a < 3; ++a) { gvp[3 * p + a] = 0.f; gx[3 * p + a] = nm_finite_or_zero(gx[3 * p + a]); }
     m3_store(gC + 9 * p, m3_zero());
     m3_store(gS + 9 * p, m3_zero());
     return;
@@ -849,15 +853,15 @@ __global__ void __launch_bounds__(256, 2) k_p2g_bwd(MpmK K, int n, const float* 
   }
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    gx[3 * p + a] += xb[a];
-    gvp[3 * p + a] = pm * vb[a];
+    gx[3 * p + a] = nm_finite_or_zero(gx[3 * p + a] + xb[a]);
+    gvp[3 * p + a] = nm_finite_or_zero(pm * vb[a]);
   }
   M3 o;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) o.m[i] = pm * Ab.m[i];
+  for (int i = 0; i < 9; ++i) o.m[i] = nm_finite_or_zero(pm * Ab.m[i]);
   m3_store(gC + 9 * p, o);
 #pragma unroll
-  for (int i = 0; i < 9; ++i) o.m[i] = ks * Ab.m[i];
+  for (int i = 0; i < 9; ++i) o.m[i] = nm_finite_or_zero(ks * Ab.m[i]);
   m3_store(gS + 9 * p, o);
 }
 

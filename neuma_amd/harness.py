@@ -160,6 +160,58 @@ class SceneRuntime(object):
         self.gt: List[Optional[torch.Tensor]] = [None] * self.V
         self.center = torch.zeros(3, device=self.device)
         self.size = torch.ones(3, device=self.device)
+        # the state every frame() starts from (default: the rest state) and the Gaussian centres that belong to it
+        self._start = None
+        self._g_start = None
+        self.state_kind = "rest"
+
+    @property
+    def start(self):
+        return (self.x0, self.v0, self.C0, self.F0) if self._start is None else self._start
+
+    @property
+    def g_start(self):
+        return self.gaussians.get_xyz if self._g_start is None else self._g_start
+
+    @torch.no_grad()
+    def set_start_state(self, kind: str = "rest", seed: int = 3, max_steps: int = 4000):
+        """Choose the state the timed frame starts from.
+        rest      x0, v0, C = 0, F = I (the SURVEY §8d generator: free fall, F stays ~ I - the best case for the Jacobi SVD)
+        deformed  rest positions with F = I + 0.05 N(0,1): every particle needs the full SVD sweeps, stresses are large
+        impact    forward-simulate (no autograd) until the body has hit the floor and rebounded into a compressed state:
+                  real contact, wall boundary conditions active, spatially varying F
+        The Gaussians move with the particles: g_start = g_0 + B (x_start - x_0) (tune/utils.py:424-448)."""
+        if kind == "rest":
+            self._start = self._g_start = None
+            self.state_kind = kind
+            return self.start
+        elif kind == "deformed":
+            g = torch.Generator().manual_seed(seed)
+            F = self.F0 + (0.05 * torch.randn(self.F0.shape, generator=g)).to(self.device)
+            self._start = (self.x0, self.v0, self.C0, F.contiguous())
+        elif kind == "impact":
+            if self.shard_sim:
+                raise ValueError("start state 'impact' is prepared on an unsharded runtime")
+            x, v, C, F = self.x0, self.v0, self.C0, self.F0
+            was, S = self.fused, self.S
+            self.fused, self.S = False, 1
+            dx = 1.0 / self.scene.cfg["G"]
+            hit = None
+            for it in range(max_steps):
+                x, v, C, F = self.rollout(x, v, C, F, step0=3000)
+                if it % 20 == 19:
+                    if hit is None and float(x[:, 1].min()) < 2.5 * dx:
+                        hit = it
+                    # keep going until the bulk is clearly compressed (mean vertical stretch below 0.97) or 400 steps after contact
+                    if hit is not None and (float(F[:, 1, 1].mean()) < 0.97 or it > hit + 400):
+                        break
+            self.fused, self.S = was, S
+            self._start = tuple(t.contiguous() for t in (x, v, C, F))
+        else:
+            raise ValueError(f"unknown start state {kind!r}")
+        self.state_kind = kind
+        self._g_start = compute_bindings_xyz(self.start[0], self.x0, self.gaussians.get_xyz, self.bindings).detach()
+        return self.start
 
     # ---- pieces
     def parameters(self):
@@ -191,8 +243,8 @@ class SceneRuntime(object):
     def make_ground_truth(self, perturb: float = 0.02, steps: int = 5, seed: int = 2):
         """GT image per view = render of the state after a few perturbed substeps."""
         g = torch.Generator().manual_seed(seed)
-        v = self.v0 + (perturb * torch.randn(self.v0.shape, generator=g)).to(self.device)
-        x, C, F = self.x0, self.C0, self.F0
+        x, v, C, F = self.start
+        v = v + (perturb * torch.randn(self.v0.shape, generator=g)).to(self.device)
         was = self.fused
         self.fused = False
         S = self.S
@@ -200,7 +252,7 @@ class SceneRuntime(object):
         x, v, C, F = self.rollout(x[self.rows], v[self.rows], C[self.rows], F[self.rows], step0=2048)
         x, F = self.all_rows(x), self.all_rows(F)
         self.S, self.fused = S, was
-        means3D = compute_bindings_xyz(x, self.x0, self.gaussians.get_xyz, self.bindings)
+        means3D = compute_bindings_xyz(x, self.start[0], self.g_start, self.bindings)
         dg = compute_bindings_F(F, self.bindings)
         for vi in range(self.V):
             self.gt[vi] = self.render_view(means3D, dg, vi).detach().clone()
@@ -216,9 +268,9 @@ class SceneRuntime(object):
     # ---- one frame, forward + backward
     def frame(self, weight: float = 1.0, backward: bool = True) -> FrameResult:
         rows = self.rows
-        x, v, C, F = self.x0[rows], self.v0[rows], self.C0[rows], self.F0[rows]
-        de_x_prev = (self.x0 - self.center) / self.size
-        g_prev = self.gaussians.get_xyz
+        x, v, C, F = (t[rows] for t in self.start)
+        de_x_prev = (self.start[0] - self.center) / self.size
+        g_prev = self.g_start
         x, v, C, F = self.rollout(x, v, C, F)
         if self.shard_sim:
             self.model.exchange.defer_check()                                 # checked once, at the end of the frame

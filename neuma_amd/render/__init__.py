@@ -217,7 +217,12 @@ def get_rasterizer(viewpoint_camera, active_sh_degree: int, debug, bg_color: Ten
     """gaussian_renderer/__init__.py:92-119 (viewpoint_camera: anything with FoVx, FoVy, image_height, image_width,
     world_view_transform, full_proj_transform, camera_center — Camera / PhysCamera / MiniCam of cameras.py)."""
     cached = getattr(viewpoint_camera, "_nm_raster_cache", None)
-    key = (int(active_sh_degree), float(scaling_modifier), tile_rows, bg_color.data_ptr())
+    # the marshalled camera is reused only while nothing it was built from has changed: tensors are identified by storage
+    # AND version counter, so an in-place update of a transform / the background (viewer-style camera reuse) rebuilds it
+    tensors = (viewpoint_camera.world_view_transform, viewpoint_camera.full_proj_transform, viewpoint_camera.camera_center, bg_color)
+    key = (int(active_sh_degree), float(scaling_modifier), tile_rows, bool(debug), float(viewpoint_camera.FoVx),
+           float(viewpoint_camera.FoVy), int(viewpoint_camera.image_height), int(viewpoint_camera.image_width)) + \
+        tuple((t.data_ptr(), t._version) for t in tensors)
     if cached is not None and cached[0] == key:
         return cached[1]
     raster_settings = GaussianRasterizationSettings(

@@ -72,7 +72,9 @@ class MPMStatics(object):
         self._fill(self.enabled, sections, [1 if (span[0] <= step < span[1]) else 0 for span in spans])
 
     def c_struct(self) -> L.nm_statics:
-        return L.nm_statics(L.ptr(self.vol), L.ptr(self.rho), L.ptr(self.clip_bound), L.ptr(self.enabled))
+        L.same_device(self.vol, self.rho, self.clip_bound, self.enabled)
+        return L.nm_statics(L.ptr(self.vol, torch.float32), L.ptr(self.rho, torch.float32), L.ptr(self.clip_bound, torch.float32),
+                            L.ptr(self.enabled, torch.int32))
 
 
 class MPMParticleData(object):
@@ -98,7 +100,9 @@ class MPMParticleData(object):
                 g.zero_()
 
     def c_struct(self) -> L.nm_particles:
-        return L.nm_particles(L.ptr(self.x), L.ptr(self.v), L.ptr(self.C), L.ptr(self.F), L.ptr(self.stress))
+        L.same_device(self.x, self.v, self.C, self.F, self.stress)
+        f32 = torch.float32
+        return L.nm_particles(L.ptr(self.x, f32), L.ptr(self.v, f32), L.ptr(self.C, f32), L.ptr(self.F, f32), L.ptr(self.stress, f32))
 
     def c_struct_grad(self) -> L.nm_particles:
         return L.nm_particles(L.ptr(self.x_grad), L.ptr(self.v_grad), L.ptr(self.C_grad), L.ptr(self.F_grad),

@@ -8,9 +8,14 @@ and modules/tune/scheduler/__init__.py:
     weight of frame f = rate ** ((f - 1) // decay_steps)                                   (finetune.py:353-358, 388);
   * previous particle / kernel positions are re-detached every rendered frame (391-392), frames listed in
     `exclude_steps` skip rendering AND the prev-state update (371-372);
-  * one loss.backward() per epoch, clip_grad_norm_(error_if_nonfinite=True) per net, then the optimiser steps (413-427);
+  * one loss.backward() per epoch, clip_grad_norm_(error_if_nonfinite=True) per net, then the optimiser steps (413-427).
+    The reference loop never zeroes the LoRA gradients between epochs (no zero_grad anywhere in 331-484; only stage A
+    zeroes, :138), so `.grad` ACCUMULATES over the epochs before every clip + RAdam step.  That is reproduced by default
+    (`accumulate_grads_like_reference=True`); set it to False for the conventional zero-per-epoch loop;
   * LoRA-only checkpoints `{epoch:04d}_lora.pt` = {'elasticity', 'plasticity', 'loss'} at epoch 1, every 10th and the
-    last, newest `num_lora_ckpts` kept (470-480); resume reloads the newest one with strict=False (299-309).
+    last, newest `num_lora_ckpts` kept (470-480, natural sort); resume reloads the newest one with strict=False (299-309;
+    the reference picks it with a lexicographic sort, which is the same file below 10 000 epochs - here the epoch number
+    decides in both places).
 
 Stage A, `optimize_init_velocity` (finetune.py:63-231): one global initial velocity (a 3-vector broadcast to every
 particle, neuma_dataset.py:107-131) fitted by the same BPTT loop with RAdam + scheduler and the x-z prior
@@ -109,7 +114,8 @@ DEFAULT_CFG = dict(   # experiments/configs/synthetic/finetune-bb.yaml:61-107 (s
     plasticity_lr=0.0008, plasticity_wd=0.0, plasticity_grad_max_norm=1.0,
     plasticity_scheduler=dict(type="cos", max_steps=1000, learning_rate_alpha=0.025),
     warmup_step=0, decay_init=0.5, decay_final=1.0, decay_steps=80, lambda_max_decay=0.33,
-    num_epochs=1000, num_frames=400, exclude_steps=(), num_lora_ckpts=3, resume=False,
+    num_epochs=1000, num_frames=400, exclude_steps=(), steps=None, num_lora_ckpts=3, resume=False,
+    accumulate_grads_like_reference=True,   # finetune.py:331-484 has no zero_grad: gradients add up across epochs
     overlap_render=False,   # not in the reference: render frame f on a second stream while frame f+1 simulates (see video_loss)
 )
 
@@ -144,6 +150,8 @@ def video_loss(rt, gt_frames, c, decay_rate: float, views: Sequence[int], deform
     (latency-bound) simulation of frame f+1 runs on the main stream; autograd replays the same stream assignment in the
     backward pass.  Results are identical; only the schedule changes."""
     nframes = int(c["num_frames"])
+    # dataset frame ids of the roll-out steps (dataset.steps, finetune.py:369): `exclude_steps` lists FRAME IDS
+    frame_ids = list(c["steps"]) if c.get("steps") is not None else list(range(nframes + 1))
     x, v, C, F = rt.x0, rt.v0, rt.C0, rt.F0
     de_prev = ((x - rt.center) / rt.size).clone().detach()
     g_prev = rt.gaussians.get_xyz.clone().detach()
@@ -156,8 +164,8 @@ def video_loss(rt, gt_frames, c, decay_rate: float, views: Sequence[int], deform
     terms = []
     for cur_step in range(1, nframes + 1):
         x, v, C, F = rt.rollout(x, v, C, F, step0=(cur_step - 1) * rt.S)      # `substeps` substeps (362-364)
-        if cur_step in c["exclude_steps"]:
-            continue                                                          # finetune.py:371-372
+        if frame_ids[cur_step] in c["exclude_steps"]:
+            continue                                                          # finetune.py:369-372
         w = decay_rate ** ((cur_step - 1) // c["decay_steps"])
         if overlap_render:
             side.wait_stream(main)
@@ -195,6 +203,14 @@ class _nullcontext(object):
         return False
 
 
+def lora_checkpoints(tune_root: Path) -> List[Path]:
+    """`*_lora.pt` files of a run, oldest first by epoch number (natsorted in finetune.py:478)."""
+    def epoch_of(p: Path):
+        head = p.stem.split("_")[0]
+        return (int(head) if head.isdigit() else -1, p.name)
+    return sorted(Path(tune_root).glob("*_lora.pt"), key=epoch_of)
+
+
 def finetune_constitutive(rt, gt_frames: List[List[torch.Tensor]], cfg: Optional[Dict] = None, tune_root: Optional[Path] = None,
                           views: Optional[Sequence[int]] = None, log=None) -> List[float]:
     """finetune.py:234-488 on a SceneRuntime.  gt_frames[f-1][i] = ground-truth image of frame f for views[i].
@@ -207,7 +223,7 @@ def finetune_constitutive(rt, gt_frames: List[List[torch.Tensor]], cfg: Optional
         tune_root = Path(tune_root)
         tune_root.mkdir(parents=True, exist_ok=True)
         if c["resume"]:                                                          # finetune.py:299-309
-            prev = sorted(tune_root.glob("*_lora.pt"))
+            prev = lora_checkpoints(tune_root)
             if prev:
                 ck = torch.load(prev[-1], map_location=rt.device)
                 E.load_state_dict(ck["elasticity"], strict=False)
@@ -225,7 +241,8 @@ def finetune_constitutive(rt, gt_frames: List[List[torch.Tensor]], cfg: Optional
                     g["lr"] = lr * float(epoch) / c["warmup_step"]
         decay_rate = rollout_decay_rate(c, epoch)
         loss_rgb = video_loss(rt, gt_frames, c, decay_rate, views, overlap_render=bool(c.get("overlap_render", False)))
-        e_opt.zero_grad(set_to_none=True); p_opt.zero_grad(set_to_none=True)
+        if not c["accumulate_grads_like_reference"]:
+            e_opt.zero_grad(set_to_none=True); p_opt.zero_grad(set_to_none=True)
         loss_rgb.backward()
         e_gn = clip_grad_norm_(E.parameters(), max_norm=c["elasticity_grad_max_norm"], error_if_nonfinite=True)
         e_opt.step()
@@ -238,7 +255,7 @@ def finetune_constitutive(rt, gt_frames: List[List[torch.Tensor]], cfg: Optional
         if tune_root is not None and (epoch == 1 or epoch % 10 == 0 or epoch == c["num_epochs"]):   # finetune.py:470-480
             torch.save({"elasticity": E.lora_state_dict(), "plasticity": P.lora_state_dict(), "loss": losses[-1]},
                        tune_root / f"{epoch:04d}_lora.pt")
-            files = sorted(tune_root.glob("*_lora.pt"))
+            files = lora_checkpoints(tune_root)
             if len(files) > c["num_lora_ckpts"]:
                 files[0].unlink()
         if c["warmup_step"] == 0 or epoch > c["warmup_step"]:                   # finetune.py:482-484

@@ -74,6 +74,41 @@ def test_fused_rollout_equals_per_operator_path_and_oracle():
             k += 2
 
 
+def test_nonfinite_substep_gradients_are_zeroed_like_the_per_operator_path():
+    """interface.py:65-74 sanitises the gradients EVERY substep returns.  An Inf / NaN arriving in dL/dx, dL/dv of the last
+    state poisons the grid adjoint of the last substep; the per-operator path zeroes what comes out of that substep and the
+    earlier substeps continue with finite values - the fused node must do the same inside (not only at its boundary)."""
+    S = 3
+    rt = _runtime("tiny", fused=True, S=S)
+    params = rt.parameters()
+    torch.manual_seed(1)
+    gws = [torch.randn(rt.N, 3), torch.randn(rt.N, 3), torch.randn(rt.N, 3, 3), torch.randn(rt.N, 3, 3)]
+    gws[0][rt.N // 3, 1] = float("inf")
+    gws[1][rt.N // 2, 0] = float("nan")
+    g = torch.Generator().manual_seed(4)
+    F0 = (torch.eye(3) + 0.05 * torch.randn(rt.N, 3, 3, generator=g)).to(dev())
+    res = {}
+    for fused in (True, False):
+        rt.fused = fused
+        ins = [t.clone().requires_grad_(True) for t in (rt.x0, rt.v0, rt.C0, F0)]
+        outs = rt.rollout(*ins)
+        torch.autograd.backward(outs, [w.to(dev()) for w in gws], inputs=ins + params)
+        res[fused] = [t.grad.clone() for t in ins + params]
+    poisoned = 0
+    for a, b in zip(res[True], res[False]):
+        assert torch.isfinite(a).all() and torch.isfinite(b).all()
+        assert rel_max(a, b) < 2e-3
+    # the poison really did reach neighbours: some particles' input gradients were zeroed in both paths
+    clean = [w.clone() for w in gws]
+    clean[0][rt.N // 3, 1] = 0.0
+    clean[1][rt.N // 2, 0] = 0.0
+    rt.fused = True
+    ins = [t.clone().requires_grad_(True) for t in (rt.x0, rt.v0, rt.C0, F0)]
+    torch.autograd.backward(rt.rollout(*ins), [w.to(dev()) for w in clean], inputs=ins)
+    poisoned = int(((ins[1].grad != 0).any(1) & (res[True][1] == 0).all(1)).sum())
+    assert poisoned > 1
+
+
 def test_frame_forward_backward_finite_and_consistent():
     rt = _runtime("tiny", fused=True)
     rt.make_ground_truth()

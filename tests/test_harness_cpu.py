@@ -194,3 +194,66 @@ def test_lr_schedulers_match_reference_curves(golden_dir):
     assert rollout_decay_rate(c, 0) == 0.5 and rollout_decay_rate(c, 1000) == 1.0      # finetune.py:353-358
     assert abs(rollout_decay_rate(c, 165) - (0.5 + 0.5 * (165 / 0.33 / 1000))) < 1e-12
     assert rollout_decay_rate(dict(c, lambda_max_decay=0), 3) == 1.0
+
+
+def test_finetune_loop_accumulates_gradients_like_the_reference(tmp_path, monkeypatch):
+    """experiments/finetune.py:331-484 never zeroes the LoRA gradients: `.grad` adds up over the epochs before clip + RAdam.
+    Host control flow only - the video loss is replaced by a closed-form function of the LoRA parameters."""
+    from types import SimpleNamespace
+    from torch.optim import RAdam
+    from torch.nn.utils import clip_grad_norm_
+    from neuma_amd import train
+    from neuma_amd.material import InvariantFullMetaElasticity, InvariantFullMetaPlasticity
+    cfg = dict(layer_widths=[64, 64], norm=None, nonlinearity="gelu", no_bias=True, normalize_input=True, alpha=1e-3)
+
+    def nets():
+        torch.manual_seed(3)
+        E, P = InvariantFullMetaElasticity(cfg), InvariantFullMetaPlasticity(cfg)
+        for n in (E, P):
+            n.init_lora_layers(16, 16)
+            for lin in (n.layers[0].fc, n.layers[1].fc, n.final_layer.fc):
+                lin.lora_B.data.normal_(0, 0.01)
+        return E, P
+
+    def fake_loss(rt, gt, c, decay, views, **kw):
+        return sum(((p - 0.01 * (i + 1)) ** 2).sum() * decay for i, p in enumerate(rt.parameters_()))
+
+    monkeypatch.setattr(train, "video_loss", fake_loss)
+    c = dict(num_epochs=4, num_frames=1, elasticity_lr=0.01, plasticity_lr=0.01, elasticity_grad_max_norm=50.0,
+             plasticity_grad_max_norm=50.0, elasticity_scheduler=dict(type="cos", max_steps=4, learning_rate_alpha=0.1),
+             plasticity_scheduler=dict(type="cos", max_steps=4, learning_rate_alpha=0.1))
+    out = {}
+    for acc in (True, False):
+        E, P = nets()
+        rt = SimpleNamespace(elasticity=E, plasticity=P, V=1, device="cpu")
+        rt.parameters_ = lambda E=E, P=P: [p for n in (E, P) for p in n.parameters() if p.requires_grad]
+        train.finetune_constitutive(rt, None, dict(c, accumulate_grads_like_reference=acc), tune_root=tmp_path / str(acc))
+        out[acc] = [p.detach().clone() for p in rt.parameters_()]
+        # hand-rolled loop with the same optimiser settings
+        E2, P2 = nets()
+        E2.freeze_all_except_lora(); P2.freeze_all_except_lora()
+        ps = [p for n in (E2, P2) for p in n.parameters() if p.requires_grad]
+        eo = RAdam([p for p in E2.parameters() if p.requires_grad], lr=0.01)
+        po = RAdam([p for p in P2.parameters() if p.requires_grad], lr=0.01)
+        es = train.fetch_scheduler(c["elasticity_scheduler"]).get_scheduler(eo, 0.01)
+        psch = train.fetch_scheduler(c["plasticity_scheduler"]).get_scheduler(po, 0.01)
+        for epoch in range(1, 5):
+            decay = train.rollout_decay_rate(dict(train.DEFAULT_CFG, **c), epoch)
+            if not acc:
+                eo.zero_grad(); po.zero_grad()
+            sum(((p - 0.01 * (i + 1)) ** 2).sum() * decay for i, p in enumerate(ps)).backward()
+            clip_grad_norm_(E2.parameters(), 50.0); eo.step()
+            clip_grad_norm_(P2.parameters(), 50.0); po.step()
+            es.step(); psch.step()
+        for a, b in zip(out[acc], ps):
+            assert torch.allclose(a, b, atol=1e-7), acc
+    assert any(not torch.allclose(a, b, atol=1e-6) for a, b in zip(out[True], out[False]))      # the two behaviours do differ
+    names = sorted(p.name for p in (tmp_path / "True").glob("*_lora.pt"))
+    assert names == ["0001_lora.pt", "0004_lora.pt"]
+
+
+def test_checkpoint_order_is_by_epoch_number(tmp_path):
+    from neuma_amd.train import lora_checkpoints
+    for e in (9990, 10000, 1, 10):
+        (tmp_path / f"{e:04d}_lora.pt").write_bytes(b"")
+    assert [p.name for p in lora_checkpoints(tmp_path)] == ["0001_lora.pt", "0010_lora.pt", "9990_lora.pt", "10000_lora.pt"]
