@@ -192,9 +192,9 @@ def make_scene(name: str, seed: int = 0, nbind: int = 8, override: Optional[dict
 
 
 def load_base_weights(material: str, root=None):
-    """Shipped NeuMA checkpoints as plain arrays (tests/golden/base_models.npz, converted from
-    experiments/base_models/*.pt by tests/golden/gen_material_golden.py)."""
+    """Shipped NeuMA checkpoints as plain arrays: package data neuma_amd/data/base_models.npz (the three
+    experiments/base_models/*_0300.pt files converted by tests/golden/gen_material_golden.py)."""
     from pathlib import Path
-    p = Path(root) if root else Path(__file__).resolve().parent.parent / "tests" / "golden" / "base_models.npz"
+    p = Path(root) if root else Path(__file__).resolve().parent / "data" / "base_models.npz"
     z = np.load(p)
     return {t: [z[f"{material}_{t}_w{i}"] for i in range(3)] for t in "ep"}

@@ -1,129 +1,166 @@
-"""Oracle (TEST INFRASTRUCTURE ONLY) — CPU baseline timing for bench.py's `cpu_baseline` leg.
+"""CPU baseline for bench.py (TEST INFRASTRUCTURE, see oracle/__init__.py): one sim+render frame, forward + backward, through
+the C++/OpenMP restatement of the reference algorithm (oracle/c/neuma_ref.cpp: dense grid, three MPM kernels with the
+reference's recompute in the backward pass, per-particle nets, per-pixel tile rasterizer), on ALL host cores.
 
-The reference's own CPU path cannot be timed (warp-lang is absent; diff_gaussian_rasterization has no CPU
-implementation), so the reported baseline is this oracle — a PyTorch-CPU *port* of the reference
-algorithm — timed on the GPU box's host cores on a BOUNDED SAMPLE of the bench workload:
+It is a "CPU restatement of the reference algorithm", not the reference measured: the reference's own CPU path is Warp's
+CPU device, and warp-lang is not installed here / never reaches the GPU box; diff_gaussian_rasterization has no CPU path at
+all.  The restatement is validated against fixtures produced by executing the reference's code
+(tests/test_oracle_cref.py).
 
-  sim     one full substep (elasticity net -> dense-grid p2g / grid_op / g2p -> plasticity net), forward and
-          backward, on ALL particles of the workload                                  -> t_substep
-  render  per-Gaussian preprocess of ALL Gaussians for one view, then front-to-back compositing + backward for
-          three sampled 16-pixel tile rows (1/4, 1/2, 3/4 of the image height), each tile evaluated densely over
-          the Gaussians whose tile rectangle covers it                                -> t_view ~ t_pre + gy * mean(t_row)
-
-  frames/s (estimated) = 1 / (S * t_substep + V * t_view)
-
-kind = "port", cores = torch.get_num_threads().  Never used as a fallback by the product.
+Operator order of one frame (finetune.py:331-414):
+    S x [stress = E(F); x,v,C,F = sim(...); F = P(F)] -> de_x -> means3D = g_prev + B (x - x_prev), F_k = B F, cov' = F_k cov F_k^T
+    -> V x [render, loss += l2(render, gt)] -> backward through all of it (LoRA-merged weights: dL/dW_eff of both nets)
 """
 import math
+import os
 import time
 
-import torch
+import numpy as np
 
-from . import material as omat
-from . import mpm as om
-from . import raster as orr
+from . import cref
 
 
-def _composite_tile(pp, idx_sorted, tx, ty, W, H, bg):
-    """Dense front-to-back composite of one 16x16 tile over the (depth-sorted) Gaussians covering it."""
-    rminx, rminy, rmaxx, rmaxy = pp["rect"]
-    sel = idx_sorted[(rminx[idx_sorted] <= tx) & (rmaxx[idx_sorted] > tx) & (rminy[idx_sorted] <= ty) & (rmaxy[idx_sorted] > ty)]
-    y0, x0 = ty * 16, tx * 16
-    py, px = torch.meshgrid(torch.arange(y0, min(H, y0 + 16)), torch.arange(x0, min(W, x0 + 16)), indexing="ij")
-    px, py = px.reshape(-1), py.reshape(-1)
-    if sel.numel() == 0:
-        return bg[None].expand(px.numel(), 3), 0
-    xy, con, op, rgb = pp["xy"][sel], pp["conic"][sel], pp["opacity"][sel], pp["rgb"][sel]
-    dt = xy.dtype
-    dx = xy[None, :, 0] - px[:, None].to(dt)
-    dy = xy[None, :, 1] - py[:, None].to(dt)
-    power = -0.5 * (con[None, :, 0] * dx * dx + con[None, :, 2] * dy * dy) - con[None, :, 1] * dx * dy
-    a_raw = op[None] * torch.exp(torch.clamp_max(power, 0.0))
-    alpha = a_raw + (torch.clamp_max(a_raw, 0.99) - a_raw).detach()
-    contrib = (power <= 0) & (alpha.detach() >= 1.0 / 255.0)
-    a_eff = torch.where(contrib, alpha, torch.zeros_like(alpha))
-    T_after = torch.cumprod(1.0 - a_eff, dim=1)
-    stop = contrib & (T_after.detach() < 1e-4)
-    keep = contrib & (torch.cumsum(stop.to(torch.int32), dim=1) == 0)
-    T_before = torch.cat([torch.ones_like(T_after[:, :1]), T_after[:, :-1]], 1)
-    wgt = torch.where(keep, alpha * T_before, torch.zeros_like(alpha))
-    T_fin = torch.prod(torch.where(keep, 1.0 - alpha, torch.ones_like(alpha)), dim=1)
-    return wgt @ rgb + T_fin[:, None] * bg[None], int(sel.numel())
+def _build_cov6(logscale, rot):
+    q = rot / np.linalg.norm(rot, axis=1, keepdims=True)
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y)], -1),
+                  np.stack([2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x)], -1),
+                  np.stack([2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], -1)], -2)
+    L = R * np.exp(logscale)[:, None, :]
+    S = L @ np.swapaxes(L, 1, 2)
+    return np.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], -1).astype(np.float32)
 
 
-def time_frame_sample(scene, rt=None, max_seconds: float = 60.0):
-    """Returns the `cpu_baseline` JSON object."""
+class CpuScene:
+    """Host arrays of a synthetic scene in the layouts the C library takes."""
+
+    def __init__(self, scene, weights):
+        cfg = scene.cfg
+        self.cfg = cfg
+        self.N, self.K = scene.x0.shape[0], scene.g_xyz.shape[0]
+        self.sim = cref.sim_cfg(cfg["G"], cfg["dt"], 1, (0.0, -9.8, 0.0), 6e-7, "noslip")
+        self.grid = cref.Grid(cfg["G"])
+        N = self.N
+        self.vol = np.full(N, scene.vol, np.float32); self.rho = np.full(N, 1000.0, np.float32)
+        self.clip = np.full(N, 0.1, np.float32); self.en = np.ones(N, np.int32)
+        self.x0 = scene.x0.astype(np.float32); self.v0 = scene.v0.astype(np.float32)
+        self.We = [np.ascontiguousarray(w, np.float32) for w in weights["e"]]
+        self.Wp = [np.ascontiguousarray(w, np.float32) for w in weights["p"]]
+        nb = scene.bind_idx.shape[1]
+        self.rowptr = (nb * np.arange(self.K + 1)).astype(np.int32)
+        self.col = np.ascontiguousarray(scene.bind_idx.reshape(-1), np.int32)
+        self.val = np.ascontiguousarray(scene.bind_w.reshape(-1), np.float32)
+        self.cov6 = _build_cov6(scene.g_logscale.astype(np.float64), scene.g_rot.astype(np.float64))
+        self.opac = (1.0 / (1.0 + np.exp(-scene.g_opacity_logit.astype(np.float64)))).astype(np.float32).reshape(-1)
+        self.shs = scene.g_sh.astype(np.float32)
+        self.g_xyz = scene.g_xyz.astype(np.float32)
+        from neuma_amd import synth          # host-side data generator only (numpy): cameras of the workload
+        self.cams = []
+        for c in synth.ring_cameras(cfg["V"], cfg["W"], cfg["H"]):
+            self.cams.append(cref.camera(c.image_height, c.image_width, math.tan(c.FoVx / 2), math.tan(c.FoVy / 2), (1.0, 1.0, 1.0),
+                                         c.world_view_transform.numpy(), c.full_proj_transform.numpy(), cfg["sh"],
+                                         c.camera_center.numpy()))
+
+
+def run_frame(cs: CpuScene, substeps=None, views=None, gt=None, timings=None):
+    """One frame forward + backward.  Returns (loss, dL/dW_e, dL/dW_p, images).  `timings` (dict) receives phase seconds."""
+    S = cs.cfg["S"] if substeps is None else substeps
+    V = list(range(cs.cfg["V"])) if views is None else list(views)
+    N = cs.N
+    tm = timings if timings is not None else {}
+    t0 = time.perf_counter()
+    x, v = cs.x0, cs.v0
+    Cm = np.zeros((N, 3, 3), np.float32)
+    F = np.tile(np.eye(3, dtype=np.float32), (N, 1, 1))
+    tape = []
+    for _ in range(S):                                                   # finetune.py:362-364
+        stress = cref.material_forward(0, 0.0, F, cs.We)
+        xn, vn, Cn, Ft = cref.mpm_forward(cs.sim, cs.grid, cs.vol, cs.rho, cs.clip, cs.en, x, v, Cm, F, stress)
+        Fn = cref.material_forward(1, 1e-3, Ft, cs.Wp)
+        tape.append((x, v, Cm, F, stress, vn, Cn, Ft))
+        x, v, Cm, F = xn, vn, Cn, Fn
+    tm["sim_fwd"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    means3D = cref.spmm(cs.rowptr, cs.col, cs.val, x - cs.x0, base=cs.g_xyz)     # tune/utils.py:424-448
+    Fk = cref.spmm(cs.rowptr, cs.col, cs.val, F).reshape(-1, 3, 3)               # :451-472
+    cov = cref.cov_deform(cs.cov6, Fk)                                          # simulation_utils.py:25-48
+    tm["bind"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    loss, gmeans, images = 0.0, np.zeros((cs.K, 3), np.float32), []
+    pairs = 0
+    for vi in V:
+        r = cref.Raster(cs.cams[vi], means3D, cs.opac, cov, shs=cs.shs)
+        pairs += r.pairs
+        target = gt[vi] if gt is not None else np.ones_like(r.image)
+        lv, gimg = cref.pixel_loss("l2", r.image, target)
+        loss += lv
+        gmeans += r.backward(gimg)["means3D"]
+        images.append(r.image)
+        r.close()
+    tm["render_fwdbwd"] = time.perf_counter() - t0
+    tm["pairs"] = pairs
+    t0 = time.perf_counter()
+    gx = cref.spmm_t(cs.rowptr, cs.col, cs.val, gmeans, N)                      # cov' is not differentiated (tune/utils.py:373)
+    gv = np.zeros((N, 3), np.float32); gC = np.zeros((N, 3, 3), np.float32); gF = np.zeros((N, 3, 3), np.float32)
+    gWe = [np.zeros_like(w) for w in cs.We]; gWp = [np.zeros_like(w) for w in cs.Wp]
+    for (x_, v_, C_, F_, stress, vn, Cn, Ft) in reversed(tape):
+        gFt, gw = cref.material_backward(1, 1e-3, Ft, cs.Wp, gF)
+        for a, b in zip(gWp, gw):
+            a += b
+        gx, gv, gC, gFs, gS = cref.mpm_backward(cs.sim, cs.grid, cs.vol, cs.rho, cs.clip, cs.en, x_, v_, C_, F_, stress, vn, Cn,
+                                                gx, gv, gC, gFt)
+        for g in (gx, gv, gC, gFs, gS):
+            np.nan_to_num(g, copy=False, nan=0.0, posinf=0.0, neginf=0.0)      # interface.py:65-74
+        gFe, gw = cref.material_backward(0, 0.0, F_, cs.We, gS)
+        for a, b in zip(gWe, gw):
+            a += b
+        gF = gFs + gFe
+    tm["sim_bwd"] = time.perf_counter() - t0
+    return loss, gWe, gWp, images
+
+
+def time_frame_sample(scene, rt=None, max_seconds: float = 30.0):
+    """The `cpu_baseline` JSON object of bench.py: the workload's frame on all host cores (bounded sample when a whole frame
+    would take longer than ~max_seconds), plus the mandatory un-sampled BouncyBall (bb) frame of SURVEY.md §8d."""
+    from neuma_amd import synth          # data generator (host numpy) - not a compute path
+    cores = os.cpu_count() or 1
+    cref.set_threads(cores)
     cfg = scene.cfg
-    torch.manual_seed(0)
-    # many tiny ops: more than ~16 intra-op threads only adds overhead on a 128/256-core host
-    torch.set_num_threads(min(16, torch.get_num_threads()))
-    from neuma_amd import synth          # data generator only (host numpy) — not a compute path
-    w = synth.load_base_weights(cfg["mat"])
-    We = [torch.tensor(a) for a in w["e"]]
-    Wp = [torch.tensor(a) for a in w["p"]]
-    N, G = scene.x0.shape[0], cfg["G"]
-    const = om.MPMConstant(G, cfg["dt"], 1, (0.0, -9.8, 0.0), 6e-7, "noslip")
-    x = torch.tensor(scene.x0).requires_grad_(True)
-    v = torch.tensor(scene.v0).requires_grad_(True)
-    C = torch.zeros(N, 3, 3, requires_grad=True)
-    F = (torch.eye(3).repeat(N, 1, 1) + 0.01 * torch.randn(N, 3, 3)).requires_grad_(True)
-    vol = torch.full((N,), scene.vol); rho = torch.full((N,), 1000.0); clip = torch.full((N,), 0.1)
-    en = torch.ones(N, dtype=torch.int32)
-    Weg = [t.clone().requires_grad_(True) for t in We]
-    Wpg = [t.clone().requires_grad_(True) for t in Wp]
-
-    def substep():
-        stress = omat.elasticity(F, Weg)
-        xn, vn, Cn, Fn = om.step(const, vol, rho, clip, en, x, v, C, F, stress)
-        Fn = omat.plasticity(Fn, Wpg, 1e-3)
-        loss = xn.sum() + vn.sum() + Cn.sum() + Fn.sum()
-        torch.autograd.grad(loss, [x, v, C, F] + Weg + Wpg)
-
-    substep()  # warm-up (allocator, thread pool)
+    out = {"unit": "frames/s", "cores": cref.threads(), "kind": "port",
+           "label": "CPU restatement of the reference algorithm (C++/OpenMP, dense grid, 3 MPM kernels + recompute, per-pixel rasterizer)"}
+    # ---- BouncyBall: whole frame, un-sampled
+    bb = synth.make_scene("bb")
+    cb = CpuScene(bb, synth.load_base_weights(bb.cfg["mat"]))
+    run_frame(cb)                                            # warm-up (thread pool, page faults)
     t0 = time.perf_counter()
     reps = 0
-    while reps < 2 and time.perf_counter() - t0 < max_seconds / 3:
-        substep()
+    while reps < 3 or (time.perf_counter() - t0 < 2.0 and reps < 20):
+        run_frame(cb)
         reps += 1
-    t_sub = (time.perf_counter() - t0) / max(reps, 1)
-
-    # ---- render sample
-    W, H = cfg["W"], cfg["H"]
-    cam = synth.ring_cameras(cfg["V"], W, H)[0]
-    s = orr.Settings(H, W, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), torch.ones(3), 1.0, cam.world_view_transform,
-                     cam.full_proj_transform, cfg["sh"], cam.camera_center)
-    means = torch.tensor(scene.g_xyz).requires_grad_(True)
-    cov = orr.build_cov3D(torch.exp(torch.tensor(scene.g_logscale)), torch.tensor(scene.g_rot))
-    op = torch.sigmoid(torch.tensor(scene.g_opacity_logit))
-    shs = torch.tensor(scene.g_sh)
-    t0 = time.perf_counter()
-    pp = orr.preprocess(s, means, cov, op, shs=shs)
-    vis = torch.nonzero(pp["visible"]).reshape(-1)
-    order = torch.argsort(pp["depth"].detach()[vis], stable=True)
-    idx_sorted = vis[order]
-    t_pre = time.perf_counter() - t0
-    gx, gy = (W + 15) // 16, (H + 15) // 16
-    rows = sorted(set([gy // 4, gy // 2, (3 * gy) // 4]))
-    t_rows, pairs = [], 0
-    bg = torch.ones(3)
-    budget = time.perf_counter() + max_seconds / 2
-    for ty in rows:
-        t0 = time.perf_counter()
-        loss = torch.zeros(())
-        for tx in range(gx):
-            img, npair = _composite_tile(pp, idx_sorted, tx, ty, W, H, bg)
-            pairs += npair
-            loss = loss + (img * img).sum()
-        (g,) = torch.autograd.grad(loss, means, retain_graph=True)
-        t_rows.append(time.perf_counter() - t0)
-        if time.perf_counter() > budget:
-            break
-    t_row = sum(t_rows) / len(t_rows)
-    t_view = 2.0 * t_pre + gy * t_row            # preprocess forward + (about as much) backward
+    t_bb = (time.perf_counter() - t0) / reps
+    out["bb"] = {"value": round(1.0 / t_bb, 4), "unit": "frames/s", "sample": f"whole bb frame (8k particles / 64^3 / 16k Gaussians / 256^2, "
+                 f"S=1, V=1), mean of {reps} runs", "ms_per_frame": round(1e3 * t_bb, 2)}
+    # ---- the benchmarked workload
+    cs = CpuScene(scene, synth.load_base_weights(cfg["mat"]))
     S, V = cfg["S"], cfg["V"]
-    fps = 1.0 / (S * t_sub + V * t_view)
-    return {"value": round(fps, 6), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"torch-CPU oracle: {reps} full substep(s) fwd+bwd on all {N} particles (t={t_sub:.3f}s each, dense {G}^3 grid) + "
-                      f"preprocess of all {scene.g_xyz.shape[0]} Gaussians (t={t_pre:.3f}s) + composite fwd+bwd of {len(t_rows)} of {gy} tile rows "
-                      f"(mean t={t_row:.3f}s/row, {pairs} pairs); frame estimated as S*t_sub + V*(2*t_pre + {gy}*t_row) with S={S}, V={V}",
-            "t_substep_s": round(t_sub, 4), "t_view_s": round(t_view, 4)}
+    tm = {}
+    t0 = time.perf_counter()
+    run_frame(cs, substeps=1, views=[0], timings=tm)         # minimal sample: 1 substep + binding + 1 view, fwd + bwd
+    t_sub = tm["sim_fwd"] + tm["sim_bwd"]
+    t_view = tm["render_fwdbwd"]
+    est = S * t_sub + V * t_view + tm["bind"]
+    if est <= max_seconds:
+        tm = {}
+        t0 = time.perf_counter()
+        run_frame(cs, timings=tm)
+        t_frame = time.perf_counter() - t0
+        sample = (f"whole frame un-sampled: {S} substeps + {V} views fwd+bwd on {cs.N} particles / {cfg['G']}^3 dense grid / {cs.K} Gaussians / "
+                  f"{cfg['W']}x{cfg['H']} ({tm['pairs']} (Gaussian,tile) pairs): sim fwd {tm['sim_fwd']:.2f}s, render fwd+bwd {tm['render_fwdbwd']:.2f}s, "
+                  f"sim bwd {tm['sim_bwd']:.2f}s")
+    else:
+        t_frame = est
+        sample = (f"sampled: 1 of {S} substeps fwd+bwd ({t_sub:.2f}s) + binding ({tm['bind']:.2f}s) + 1 of {V} views fwd+bwd ({t_view:.2f}s, "
+                  f"{tm['pairs']} pairs) on {cs.N} particles / {cfg['G']}^3 dense grid / {cs.K} Gaussians / {cfg['W']}x{cfg['H']}; "
+                  f"frame = S*t_sub + V*t_view + t_bind")
+    out.update(value=round(1.0 / t_frame, 5), sample=sample, s_per_frame=round(t_frame, 3))
+    return out

@@ -10,7 +10,8 @@ modules/nclaw/warp/svd.py:76-92.  Everything else (MLPBlock, LinearLoRA, invaria
 is the reference's code, executed in fp64 on CPU.
 
 Outputs (data only — inputs and expected outputs):
-    tests/golden/base_models.npz              the three shipped checkpoints as plain arrays
+    tests/golden/base_models.npz              the three shipped checkpoints as plain arrays (+ the same file as package
+                                              data neuma_amd/data/base_models.npz, which synth / bench load)
     tests/golden/material_<name>.npz          F, LoRA A/B, stress, F_p, and autograd gradients
     tests/golden/camera_sh_golden.npz         view/proj matrices, SH evaluations, l1/l2 loss values
     tests/golden/scheduler_golden.npz         learning-rate curves of the reference's cosine / exponential schedulers
@@ -153,6 +154,7 @@ def main():
             out["Fp_lora_merged"] = P(F).numpy()
         np.savez_compressed(OUT / f"material_{name}.npz", **out)
     np.savez_compressed(OUT / "base_models.npz", **base)
+    np.savez_compressed(OUT.parent.parent / "neuma_amd" / "data" / "base_models.npz", **base)
 
     # ---- camera / SH / loss conventions (pure torch/numpy reference modules, loaded by file path)
     import importlib.util
