@@ -18,6 +18,7 @@ import os
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
 
+import numpy as np
 import torch
 
 from . import synth
@@ -83,7 +84,7 @@ class SceneRuntime(object):
     cameras and ground-truth images."""
 
     def __init__(self, scene: synth.Scene, device, lora_r: int = 16, lora_alpha: int = 16, fused: bool = True,
-                 bc: str = "noslip", gravity=(0.0, -9.8, 0.0), pixel_loss: str = "l2", white_bg: bool = True,
+                 bc: str = "noslip", gravity=(0.0, -9.8, 0.0), pixel_loss: str = "l2", white_bg: Optional[bool] = None,
                  rank: int = 0, world: int = 1, group=None, shard_sim: bool = False):
         self.scene, self.device, self.fused = scene, torch.device(device), fused
         self.rank, self.world, self.group = rank, world, group
@@ -153,6 +154,8 @@ class SceneRuntime(object):
         ind = torch.stack([rows, torch.tensor(scene.bind_idx.reshape(-1))], 0)
         self.bindings = Bindings(ind, torch.tensor(scene.bind_w.reshape(-1)), (K, N), self.device)
         self.K = K
+        if white_bg is None:        # synthetic scenes render on white, the real-world ones (burger) on black
+            white_bg = cfg.get("bg", "white") == "white"
         self.background = (torch.ones(3) if white_bg else torch.zeros(3)).to(self.device)
         self.cameras = synth.ring_cameras(self.V, cfg["W"], cfg["H"], device=self.device)
         self.pixel_loss = PIXEL_LOSSES[pixel_loss]
@@ -227,16 +230,26 @@ class SceneRuntime(object):
             F = self.plasticity(F)
         return x, v, C, F
 
-    def render_view(self, means3D, deform_grad, view: int, tile_rows=None, cov=None, prepared=None):
+    def camera_at(self, view: int, step=None):
+        """Camera of view index `view` at dataset frame `step` (synthetic scenes: static cameras, `step` is ignored)."""
+        return self.cameras[view]
+
+    def render_view(self, means3D, deform_grad, view: int, tile_rows=None, cov=None, prepared=None, step=None):
         """cov: covariances already pushed forward by the deformation gradients (deform_grad is then ignored)."""
-        return diff_rasterization(means3D, deform_grad if cov is None else None, None, self.cameras[view], self.background,
+        if getattr(self, "force_mask_data", False):       # silhouette supervision: constant colour 1 (tune/utils.py:390-404)
+            return diff_rasterization(means3D, deform_grad if cov is None else None, None, self.camera_at(view, step), self.background,
+                                      gaussians_active_sh=self.gaussians.active_sh_degree, guassians_cov=self._cov if cov is None else cov,
+                                      gaussians_opa=self._opacity, gaussians_shs=self._shs, force_mask_data=True, tile_rows=tile_rows)
+        return diff_rasterization(means3D, deform_grad if cov is None else None, None, self.camera_at(view, step), self.background,
                                   gaussians_active_sh=self.gaussians.active_sh_degree,
                                   guassians_cov=self._cov if cov is None else cov,
                                   gaussians_opa=self._opacity, gaussians_shs=self._shs, tile_rows=tile_rows, prepared=prepared)
 
-    def prepare_view(self, means3D, cov, view: int, tile_rows=None):
+    def prepare_view(self, means3D, cov, view: int, tile_rows=None, step=None):
         from .tune import prepare_view
-        return prepare_view(means3D, cov, self.cameras[view], self.background, self.gaussians.active_sh_degree, self._opacity,
+        if getattr(self, "force_mask_data", False):
+            return None
+        return prepare_view(means3D, cov, self.camera_at(view, step), self.background, self.gaussians.active_sh_degree, self._opacity,
                             self._shs, tile_rows=tile_rows)
 
     @torch.no_grad()
@@ -336,3 +349,85 @@ class SceneRuntime(object):
         if self.shard_sim:
             self.model.exchange.check()      # raises if a substep's block exchange was incomplete (capacity exceeded)
         return FrameResult(loss.detach(), x.detach(), F.detach())
+
+
+class DiskRuntime(SceneRuntime):
+    """The same runtime assembled from a NeuMA experiment on disk instead of a synthetic scene: what
+    experiments/finetune.py:491-663 builds before it enters the two training stages.
+
+        dataset     dataset.VideoDataset (cameras + ground-truth images per (view, frame id), init_x / init_v)
+        gaussians   GaussianModel from <assets>/<sim_data_name>/kernels.ply
+        bindings    tune.Bindings from bindings.pt
+        init_data   MPMInitData of the particle set (positions in simulation space, vol, rho, clip_bound, size, center)
+        nets        InvariantFullMetaElasticity / Plasticity with the base checkpoint loaded (LoRA is added by the trainer)
+    `views`: names of the dataset views used for the loss (cfg.constitution.views / cfg.velocity.views)."""
+
+    def __init__(self, sim_cfg, dataset, gaussians, bindings, init_data, elasticity, plasticity, background, device, substeps: int,
+                 views, scaling_modifier: float = 1.0, pixel_loss: str = "l2", fused: bool = True, eps: Optional[float] = 6e-7):
+        from types import SimpleNamespace
+        self.device = torch.device(device)
+        self.fused, self.rank, self.world, self.group, self.shard_sim = fused, 0, 1, None, False
+        self.overlap_views = os.environ.get("NEUMA_OVERLAP_VIEWS", "1") != "0"
+        self.num_view_streams = None
+        self.dataset = dataset
+        self.view_names = sorted(views)                                          # finetune.py:262
+        self.S, self.V = int(substeps), len(self.view_names)
+        sim_cfg = dict(sim_cfg)
+        if eps is not None:
+            sim_cfg["eps"] = eps                                                 # finetune.py:105 / 270: cfg.sim.eps = EPS
+        self.model = MPMModelBuilder().parse_cfg(sim_cfg).finalize(self.device, requires_grad=True)
+        N = int(init_data.pos.shape[0])
+        self.N = self.n_local = N
+        self.rows = slice(0, N)
+        first = dataset.getCameras(self.view_names[0], dataset.steps[0])
+        self.scene = SimpleNamespace(name="disk", cfg=dict(N=N, G=int(sim_cfg["num_grids"]), K=int(gaussians.get_xyz.shape[0]),
+                                                            W=first.image_width, H=first.image_height, dt=float(sim_cfg["dt"]), S=self.S,
+                                                            V=self.V, sh=gaussians.active_sh_degree, mat="checkpoint"))
+        self.x0 = dataset.get_init_x.to(self.device).float().contiguous()
+        self.v0 = dataset.get_init_v.detach().to(self.device).float().contiguous()
+        self.C0 = torch.zeros(N, 3, 3, device=self.device)
+        self.F0 = torch.eye(3, device=self.device).repeat(N, 1, 1)
+        from .sim import MPMStaticsInitializer
+        self.statics_initializer = MPMStaticsInitializer(self.model)
+        self.statics_initializer.add_group(init_data)
+        self.statics = self.statics_initializer.finalize()
+        self.init_data = init_data
+        self.elasticity, self.plasticity = elasticity.to(self.device), plasticity.to(self.device)
+        self.sim_cached = MPMCacheDiffSim(self.model, 1 << 16)
+        self._sim_fused = None
+        self.gaussians = gaussians
+        self._opacity = gaussians.get_opacity.contiguous()
+        self._shs = gaussians.get_features.contiguous()
+        self._cov = gaussians.get_covariance(scaling_modifier)
+        self.bindings = Bindings.of(bindings)
+        self.K = int(gaussians.get_xyz.shape[0])
+        self.background = background.to(self.device)
+        self.cameras = [dataset.getCameras(v, dataset.steps[0]) for v in self.view_names]
+        self.pixel_loss = PIXEL_LOSSES[pixel_loss]
+        self.tile_rows = (first.image_height + 15) // 16
+        self.gt = [None] * self.V
+        # de-normalisation of particle positions (nclaw/utils.py:110-118): (x - center) / size
+        self.center = torch.as_tensor(np.asarray(init_data.center), dtype=torch.float32, device=self.device)
+        self.size = torch.as_tensor(np.asarray(init_data.size), dtype=torch.float32, device=self.device)
+        self._start = self._g_start = None
+        self.state_kind = "rest"
+
+    @property
+    def sim_fused(self):
+        # built on first use: the trainer adds the LoRA layers to the nets after this runtime exists
+        if self._sim_fused is None or self._sim_fused.substeps != self.S:
+            self._sim_fused = MPMFusedDiffSim(self.model, self.elasticity, self.plasticity, self.S)
+        return self._sim_fused
+
+    def camera_at(self, view: int, step=None):
+        if step is None:
+            return self.cameras[view]
+        return self.dataset.getCameras(self.view_names[view], step)
+
+    def ground_truth(self, num_frames: int):
+        """gt[f-1][i] = image of view i at the f-th frame AFTER the first one (finetune.py:369, 386)."""
+        out = []
+        for f in range(1, num_frames + 1):
+            step = self.dataset.steps[f]
+            out.append([self.dataset.getCameras(v, step).original_image.to(self.device) for v in self.view_names])
+        return out

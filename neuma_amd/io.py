@@ -32,53 +32,116 @@ _PLY_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short":
               "double": "f8", "float64": "f8"}
 
 
+def _ply_header(f, path):
+    """Parse a PLY header from the open binary file `f` (positioned at the start); returns (format, elements) with
+    elements = [{'name', 'count', 'props': [(dtype | 'list', name, (count type, item type) | None)]}] and leaves `f` at the data."""
+    if f.readline().strip() != b"ply":
+        raise ValueError(f"{path}: not a PLY file")
+    fmt, elements, cur = None, [], None
+    while True:
+        line = f.readline()
+        if not line:
+            raise ValueError(f"{path}: unterminated PLY header")
+        tok = line.decode("ascii", "replace").split()
+        if not tok or tok[0] in ("comment", "obj_info"):
+            continue
+        if tok[0] == "format":
+            fmt = tok[1]
+        elif tok[0] == "element":
+            cur = {"name": tok[1], "count": int(tok[2]), "props": []}
+            elements.append(cur)
+        elif tok[0] == "property":
+            if tok[1] == "list":
+                cur["props"].append(("list", tok[-1], (tok[2], tok[3])))
+            else:
+                if tok[1] not in _PLY_TYPES:
+                    raise ValueError(f"{path}: unknown PLY type {tok[1]}")
+                cur["props"].append((_PLY_TYPES[tok[1]], tok[2], None))
+        elif tok[0] == "end_header":
+            break
+    if fmt not in ("ascii", "binary_little_endian", "binary_big_endian"):
+        raise ValueError(f"{path}: unsupported PLY format {fmt}")
+    if not elements or elements[0]["name"] != "vertex":
+        raise ValueError(f"{path}: first element must be `vertex`")
+    if any(p[0] == "list" for p in elements[0]["props"]):
+        raise ValueError(f"{path}: list properties in the vertex element are not supported")
+    return fmt, elements
+
+
+def _ply_vertex_block(f, path, fmt, el) -> Dict[str, np.ndarray]:
+    n = el["count"]
+    if fmt == "ascii":
+        rows = [f.readline().split() for _ in range(n)]
+        cols = list(zip(*rows)) if n else [[] for _ in el["props"]]
+        return {name: np.asarray(col, dtype=np.float64).astype(t) for (t, name, _), col in zip(el["props"], cols)}
+    end = "<" if fmt == "binary_little_endian" else ">"
+    dt = np.dtype([(name, end + t) for t, name, _ in el["props"]])
+    raw = f.read(dt.itemsize * n)
+    if len(raw) != dt.itemsize * n:
+        raise ValueError(f"{path}: truncated vertex data ({len(raw)} of {dt.itemsize * n} bytes)")
+    arr = np.frombuffer(raw, dtype=dt, count=n)
+    return {name: np.ascontiguousarray(arr[name]).astype(arr[name].dtype.newbyteorder("=")) for _, name, _ in el["props"]}
+
+
 def read_ply_vertices(path) -> Dict[str, np.ndarray]:
     """Properties of the `vertex` element of a PLY file (ascii, binary_little_endian or binary_big_endian) as a dict of
     1-D arrays, in file order.  Other elements (faces ...) are ignored; list properties inside `vertex` are rejected."""
     with open(path, "rb") as f:
-        if f.readline().strip() != b"ply":
-            raise ValueError(f"{path}: not a PLY file")
-        fmt, elements, cur = None, [], None
-        while True:
-            line = f.readline()
-            if not line:
-                raise ValueError(f"{path}: unterminated PLY header")
-            tok = line.decode("ascii", "replace").split()
-            if not tok or tok[0] in ("comment", "obj_info"):
-                continue
-            if tok[0] == "format":
-                fmt = tok[1]
-            elif tok[0] == "element":
-                cur = {"name": tok[1], "count": int(tok[2]), "props": []}
-                elements.append(cur)
-            elif tok[0] == "property":
-                if tok[1] == "list":
-                    cur["props"].append(("list", tok[-1], (tok[2], tok[3])))
-                else:
-                    if tok[1] not in _PLY_TYPES:
-                        raise ValueError(f"{path}: unknown PLY type {tok[1]}")
-                    cur["props"].append((_PLY_TYPES[tok[1]], tok[2], None))
-            elif tok[0] == "end_header":
-                break
-        if fmt not in ("ascii", "binary_little_endian", "binary_big_endian"):
-            raise ValueError(f"{path}: unsupported PLY format {fmt}")
-        if not elements or elements[0]["name"] != "vertex":
-            raise ValueError(f"{path}: first element must be `vertex`")
-        el = elements[0]
-        if any(p[0] == "list" for p in el["props"]):
-            raise ValueError(f"{path}: list properties in the vertex element are not supported")
-        n = el["count"]
+        fmt, elements = _ply_header(f, path)
+        return _ply_vertex_block(f, path, fmt, elements[0])
+
+
+def read_ply_mesh(path):
+    """(vertices (n,3) float64, triangles (m,3) int64) of a PLY mesh: `vertex` element followed by a `face` element with one
+    list property; polygons are fan-triangulated."""
+    with open(path, "rb") as f:
+        fmt, elements = _ply_header(f, path)
+        v = _ply_vertex_block(f, path, fmt, elements[0])
+        verts = np.stack((v["x"], v["y"], v["z"]), axis=1).astype(np.float64)
+        face = next((e for e in elements[1:2] if e["name"] == "face"), None)
+        if face is None or len(face["props"]) < 1 or face["props"][0][0] != "list":
+            raise ValueError(f"{path}: no `face` element right after `vertex`")
+        tris = []
         if fmt == "ascii":
-            rows = [f.readline().split() for _ in range(n)]
-            cols = list(zip(*rows)) if n else [[] for _ in el["props"]]
-            return {name: np.asarray(col, dtype=np.float64).astype(t) for (t, name, _), col in zip(el["props"], cols)}
-        end = "<" if fmt == "binary_little_endian" else ">"
-        dt = np.dtype([(name, end + t) for t, name, _ in el["props"]])
-        raw = f.read(dt.itemsize * n)
-        if len(raw) != dt.itemsize * n:
-            raise ValueError(f"{path}: truncated vertex data ({len(raw)} of {dt.itemsize * n} bytes)")
-        arr = np.frombuffer(raw, dtype=dt, count=n)
-        return {name: np.ascontiguousarray(arr[name]).astype(arr[name].dtype.newbyteorder("=")) for _, name, _ in el["props"]}
+            for _ in range(face["count"]):
+                tok = f.readline().split()
+                k = int(tok[0])
+                idx = [int(t) for t in tok[1:1 + k]]
+                tris += [(idx[0], idx[i], idx[i + 1]) for i in range(1, k - 1)]
+        else:
+            end = "<" if fmt == "binary_little_endian" else ">"
+            ct, it = (np.dtype(end + _PLY_TYPES[t]) for t in face["props"][0][2])
+            extra = sum(np.dtype(p[0]).itemsize for p in face["props"][1:])       # fixed-size properties after the list
+            for _ in range(face["count"]):
+                k = int(np.frombuffer(f.read(ct.itemsize), dtype=ct)[0])
+                idx = np.frombuffer(f.read(it.itemsize * k), dtype=it).astype(np.int64)
+                if extra:
+                    f.read(extra)
+                tris += [(idx[0], idx[i], idx[i + 1]) for i in range(1, k - 1)]
+        return verts, np.asarray(tris, dtype=np.int64).reshape(-1, 3)
+
+
+def read_obj_mesh(path):
+    """(vertices, triangles) of a Wavefront OBJ (v / f records; polygons fan-triangulated, negative indices supported)."""
+    verts, tris = [], []
+    with open(path) as f:
+        for line in f:
+            tok = line.split()
+            if not tok:
+                continue
+            if tok[0] == "v":
+                verts.append([float(t) for t in tok[1:4]])
+            elif tok[0] == "f":
+                idx = [int(t.split("/")[0]) for t in tok[1:]]
+                idx = [i - 1 if i > 0 else len(verts) + i for i in idx]
+                tris += [(idx[0], idx[i], idx[i + 1]) for i in range(1, len(idx) - 1)]
+    return np.asarray(verts, dtype=np.float64), np.asarray(tris, dtype=np.int64).reshape(-1, 3)
+
+
+def mesh_volume(verts: np.ndarray, tris: np.ndarray) -> float:
+    """Signed volume of a closed triangle mesh (sum of tetrahedra against the origin), what trimesh's `mesh.volume` returns."""
+    a, b, c = verts[tris[:, 0]], verts[tris[:, 1]], verts[tris[:, 2]]
+    return float(np.einsum("ij,ij->i", a, np.cross(b, c)).sum() / 6.0)
 
 
 def write_ply_vertices(path, names: Sequence[str], data: np.ndarray) -> None:
@@ -291,8 +354,26 @@ def read_colmap_cameras_bin(path) -> Dict[int, Dict]:
     return out
 
 
+def _load_masked_image(image_path: str, extension: str, white_background: bool, read_mask_only: bool) -> np.ndarray:
+    """dataset_readers.py:338-352: RealCapture frames come with a binary mask under dynamic_masks/<same name>.png; either the
+    mask itself is the image (read_mask_only: 3 equal channels) or the photo is composited onto the background through it."""
+    from PIL import Image
+    mask_path = image_path.replace("/dynamics/", "/dynamic_masks/").replace(extension, ".png")
+    mask = np.array(Image.open(mask_path))
+    if mask.ndim == 3:
+        mask = mask[:, :, 0]
+    if read_mask_only:
+        return (np.repeat(mask[:, :, None], 3, axis=-1) / 255.0).astype(np.float32)
+    im = np.array(Image.open(image_path).convert("RGB")) / 255.0
+    m = mask[:, :, None] / 255.0
+    bg = np.ones(3) if white_background else np.zeros(3)
+    arr = np.array((im * m + bg * (1 - m)) * 255.0, dtype=np.uint8)           # the reference quantises back to 8 bit here
+    return (arr / 255.0).astype(np.float32)
+
+
 def read_realcapture_cameras(path, white_background: bool, extension: str = ".jpg", width: int = 1920, height: int = 1080,
-                             init_frame=None, exclude_steps=(-1,), used_views=None, load_images: bool = False) -> Dict:
+                             init_frame=None, exclude_steps=(-1,), used_views=None, load_images: bool = False,
+                             read_mask_only: bool = False) -> Dict:
     """dataset_readers.py:282-372.  Intrinsics come from COLMAP camera 1, rescaled from the 4752x2672 capture size; NB the
     reference assigns FovY from fx/height and FovX from fy/width (:309-310) - kept."""
     intr = read_colmap_cameras_bin(os.path.join(path, "sparse/0", "cameras.bin"))
@@ -309,7 +390,11 @@ def read_realcapture_cameras(path, white_background: bool, extension: str = ".jp
         T = np.array(calib[view]["tvecs"], dtype=np.float64).reshape(3)
         for step in steps_used:
             img_path = os.path.join(path, f"./dynamics/{view}_{step}{extension}")
-            image = _load_image(img_path, white_background) if load_images else None
+            image = None
+            if load_images:
+                has_mask = os.path.exists(img_path.replace("/dynamics/", "/dynamic_masks/").replace(extension, ".png"))
+                image = _load_masked_image(img_path, extension, white_background, read_mask_only) if (has_mask or read_mask_only) \
+                    else _load_image(img_path, white_background)
             infos.append(CameraInfo(idx, R, T, FovY, FovX, img_path, width, height, view, step, image))
             idx += 1
     return {"cam_infos": infos, "views": views, "steps": steps}

@@ -1,0 +1,53 @@
+"""Asset preparation that sits in front of both drivers: counterpart of `prepare_simulation_data`
+(/root/reference/modules/tune/utils.py:211-320).  From a reconstructed 3DGS `point_cloud.ply` and a particle point cloud
+it writes, into experiments/assets/<sim_data_name>/:
+    kernels.ply     Gaussians with opacity > opacity_thres (property order of gaussian_model.py:189-220)
+    particles.ply   the simulated particles: the given ones (randomly permuted, every `downsample_factor`-th kept) plus the
+                    centres of the Gaussians no particle fell into
+    bindings.pt     sparse (K x N) binding weights + per-Gaussian particle counts
+The O(K N) Mahalanobis loop of binding_utils.py runs as the grid-hashed HIP search of neuma_amd.binding.
+Sampling particles out of a mesh (uniform / volumetric / surface, tune/utils.py:49-200; `VolumeSampling` is a prebuilt ELF)
+is asset preprocessing outside the hot path: pass `particles_path`, or place particles.ply in the asset folder."""
+from pathlib import Path
+from typing import Optional
+
+import torch
+
+from . import io as nio
+from .binding import prepare_bindings
+
+
+@torch.no_grad()
+def prepare_simulation_data(save_dir: Path, kernels_path: Path, particles_path: Optional[Path] = None, mesh_path: Optional[Path] = None,
+                            mesh_sample_mode: str = "volumetric", mesh_sample_resolution: int = 30, sh_degree: int = 3,
+                            opacity_thres: float = 0.02, particles_downsample_factor: int = 3, confidence: float = 0.95,
+                            max_particles: int = 10, device="cuda") -> None:
+    save_dir = Path(save_dir)
+    done = all((save_dir / n).is_file() for n in ("kernels.ply", "particles.ply", "bindings.pt"))
+    print("===================================")
+    if done:
+        print("Data already prepared. Skipping data preparation.\n")
+        print("===================================\n")
+        return
+    print("Start preparing data for simulation.\n")
+    save_dir.mkdir(parents=True, exist_ok=True)
+    gaussians = nio.load_gaussians_ply(kernels_path, sh_degree, device=device)
+    retain = (gaussians.get_opacity.squeeze(-1) > opacity_thres).cpu().numpy()
+    print(f"Gaussians after pruning low opacity kernels: {int(retain.sum())}")
+    gaussians = nio.load_gaussians_ply(kernels_path, sh_degree, device=device, mask=retain)
+    nio.save_gaussians_ply(gaussians, save_dir / "kernels.ply")
+    if particles_path is not None:
+        print(f"Extracting particles from pcd file [{particles_path}] ...")
+        particles = nio.load_particles_ply(particles_path)
+    elif mesh_path is not None:
+        raise NotImplementedError(
+            f"sampling particles from a mesh ({mesh_sample_mode}, resolution {mesh_sample_resolution}) is asset preprocessing "
+            "outside this engine: sample the mesh with the reference's tools and pass particle_data.particles_path")
+    else:
+        raise ValueError("Either 'particles_path' or 'mesh_path' must be provided.")
+    particles = torch.as_tensor(particles, dtype=torch.float32, device=device)
+    particles, B, n_particles = prepare_bindings(gaussians, particles, confidence=confidence, max_particles=max_particles,
+                                                 particles_downsample_factor=int(particles_downsample_factor), save_dir=save_dir)
+    print(f"COO:  {tuple(B.indices().shape)}")
+    print("\nData preparation done.")
+    print("===================================\n")

@@ -411,14 +411,34 @@ class MPMInitData(object):
 
     @classmethod
     def get_pcd(cls, name, asset_root, sort=None, ori_bounds=None, sim_bounds=None) -> dict:
-        """Counterpart of mpm.py:607-677 for the cached form of an asset."""
+        """Counterpart of mpm.py:607-677: the `<name>.npz` cache (p_x, vol) if present, else `<name>.ply` (a point cloud; sorted
+        descending along `sort`), whose per-particle volume is the volume of the single `mesh.*` file next to it divided by
+        the particle count, or of the points' convex hull when there is no such mesh; the cache is then written, as the
+        reference does.  (trimesh is replaced by the PLY / OBJ readers of neuma_amd.io and scipy's ConvexHull.)"""
         assert ori_bounds is not None, "ori_bounds must be provided for pcd shape."
         assert sim_bounds is not None, "sim_bounds must be provided for pcd shape."
-        cache = Path(asset_root if asset_root is not None else ".") / f"{name}.npz"
-        if not cache.is_file():
-            raise FileNotFoundError(f"{cache}: particle cache not found (mesh/PLY sampling is out of scope here)")
-        with np.load(cache) as file:
-            return cls.from_points(file['p_x'], float(file['vol']), ori_bounds, sim_bounds, sort)
+        root = Path(asset_root) if asset_root is not None else Path("experiments") / "assets"
+        cache = root / f"{name}.npz"
+        if cache.is_file():
+            with np.load(cache) as file:
+                return cls.from_points(file['p_x'], float(file['vol']), ori_bounds, sim_bounds, None)
+        pcd_path = root / f"{name}.ply"
+        if not pcd_path.is_file():
+            raise FileNotFoundError(f"neither {cache} nor {pcd_path} exists")
+        from .. import io as nio
+        p_x = nio.load_particles_ply(pcd_path)
+        if sort is not None:
+            p_x = p_x[np.argsort(-p_x[:, sort], kind="stable")]
+        meshes = sorted(pcd_path.parent.glob("mesh.*"))
+        if len(meshes) == 1:
+            reader = nio.read_obj_mesh if meshes[0].suffix.lower() == ".obj" else nio.read_ply_mesh
+            vol = abs(nio.mesh_volume(*reader(meshes[0]))) / p_x.shape[0]
+        else:
+            from scipy.spatial import ConvexHull
+            vol = float(ConvexHull(p_x).volume) / p_x.shape[0]
+            print('  WARNING: mesh file not found, using convex hull volume.')
+        np.savez(cache, p_x=p_x, vol=vol)
+        return cls.from_points(p_x, float(vol), ori_bounds, sim_bounds, None)
 
     @classmethod
     def from_points(cls, p_x: np.ndarray, vol: float, ori_bounds, sim_bounds, sort=None) -> dict:

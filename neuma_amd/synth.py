@@ -13,7 +13,7 @@ CONFIGS = {
     "bb":     dict(N=8_000,     G=64,  K=16_000,  W=256,  H=256,  dt=1e-3, S=1,  V=1, sh=3, mat="jelly"),
     "jd":     dict(N=50_000,    G=128, K=100_000, W=800,  H=800,  dt=1e-3, S=1,  V=1, sh=3, mat="jelly"),
     "sf":     dict(N=100_000,   G=128, K=100_000, W=800,  H=800,  dt=5e-4, S=1,  V=1, sh=3, mat="sand"),
-    "burger": dict(N=80_000,    G=128, K=200_000, W=1920, H=1080, dt=5e-4, S=20, V=3, sh=0, mat="jelly"),
+    "burger": dict(N=80_000,    G=128, K=200_000, W=1920, H=1080, dt=5e-4, S=20, V=3, sh=0, mat="jelly", bg="black"),
     "metric": dict(N=100_000,   G=128, K=200_000, W=1920, H=1080, dt=5e-4, S=20, V=3, sh=3, mat="jelly"),
     "stress": dict(N=1_000_000, G=256, K=500_000, W=1920, H=1080, dt=5e-4, S=1,  V=1, sh=3, mat="jelly"),
     "tiny":   dict(N=2_000,     G=32,  K=3_000,   W=128,  H=96,   dt=1e-3, S=2,  V=2, sh=3, mat="jelly"),

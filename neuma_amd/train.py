@@ -178,9 +178,10 @@ def video_loss(rt, gt_frames, c, decay_rate: float, views: Sequence[int], deform
             lf = torch.zeros((), device=rt.device)
             # covariance push-forward once per frame; stage 1 of every view is enqueued before the first pair-count read-back
             cov = deform_cov_by_F(rt._cov, dg) if dg is not None else rt._cov
-            preps = [rt.prepare_view(means3D.detach(), cov, vi) for vi in views]
+            fid = frame_ids[cur_step]
+            preps = [rt.prepare_view(means3D.detach(), cov, vi, step=fid) for vi in views]
             for i, vi in enumerate(views):
-                render = rt.render_view(means3D, None, vi, cov=cov, prepared=preps[i])
+                render = rt.render_view(means3D, None, vi, cov=cov, prepared=preps[i], step=fid)
                 lf = lf + w * rt.pixel_loss(render, gt_frames[cur_step - 1][i])
             terms.append(lf)
             de_prev = de_x.clone().detach()
@@ -265,7 +266,7 @@ def finetune_constitutive(rt, gt_frames: List[List[torch.Tensor]], cfg: Optional
 
 VELOCITY_CFG = dict(   # experiments/configs/*/finetune-*.yaml `velocity:` block (sizes reduced by the caller)
     num_epochs=100, num_frames=5, lr=0.1, scheduler=dict(type="cos", max_steps=100, learning_rate_alpha=0.05),
-    lambda_reg=None, reg_all=False, pixel_loss="l2",
+    lambda_reg=None, reg_all=False, pixel_loss="l2", steps=None,
 )
 
 
@@ -288,6 +289,7 @@ def optimize_init_velocity(rt, gt_frames: List[List[torch.Tensor]], cfg: Optiona
     sch = fetch_scheduler(c["scheduler"]).get_scheduler(opt, c["lr"])
     losses = []
     nframes = int(c["num_frames"])
+    frame_ids = list(c["steps"]) if c.get("steps") is not None else list(range(nframes + 1))     # dataset.steps, finetune.py:155
     for epoch in range(1, int(c["num_epochs"]) + 1):
         opt.zero_grad(set_to_none=True)
         x, C, F = rt.x0, rt.C0, rt.F0
@@ -301,7 +303,7 @@ def optimize_init_velocity(rt, gt_frames: List[List[torch.Tensor]], cfg: Optiona
             means3D = compute_bindings_xyz(de_x, de_prev, g_prev, rt.bindings)
             dg = compute_bindings_F(F, rt.bindings)
             for i, vi in enumerate(views):
-                loss_rgb = loss_rgb + pixel_loss(rt.render_view(means3D, dg, vi), gt_frames[cur_step - 1][i])
+                loss_rgb = loss_rgb + pixel_loss(rt.render_view(means3D, dg, vi, step=frame_ids[cur_step]), gt_frames[cur_step - 1][i])
             de_prev, g_prev = de_x.clone().detach(), means3D.clone().detach()
         if c["lambda_reg"] is not None and epoch > int(0.1 * c["num_epochs"]):    # finetune.py:207-214
             if c["reg_all"]:

@@ -123,15 +123,28 @@ def time_frame_sample(scene, rt=None, max_seconds: float = 30.0):
     """The `cpu_baseline` JSON object of bench.py: the workload's frame on all host cores (bounded sample when a whole frame
     would take longer than ~max_seconds), plus the mandatory un-sampled BouncyBall (bb) frame of SURVEY.md §8d."""
     from neuma_amd import synth          # data generator (host numpy) - not a compute path
-    cores = os.cpu_count() or 1
-    cref.set_threads(cores)
+    host = os.cpu_count() or 1
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else host
     cfg = scene.cfg
-    out = {"unit": "frames/s", "cores": cref.threads(), "kind": "port",
-           "label": "CPU restatement of the reference algorithm (C++/OpenMP, dense grid, 3 MPM kernels + recompute, per-pixel rasterizer)"}
     # ---- BouncyBall: whole frame, un-sampled
     bb = synth.make_scene("bb")
     cb = CpuScene(bb, synth.load_base_weights(bb.cfg["mat"]))
+    # thread count: all usable cores is not automatically the fastest (cgroup CPU quotas, NUMA, 27 atomics per particle on a
+    # shared grid) - time the bb frame at every power of two up to the usable count and keep the best for everything below
+    cand = sorted({min(usable, 1 << k) for k in range(0, 11)} | {usable})
+    cref.set_threads(cand[-1])
     run_frame(cb)                                            # warm-up (thread pool, page faults)
+    sweep = {}
+    for n in cand:
+        cref.set_threads(n)
+        t0 = time.perf_counter()
+        run_frame(cb)
+        sweep[n] = time.perf_counter() - t0
+    best = min(sweep, key=sweep.get)
+    cref.set_threads(best)
+    out = {"unit": "frames/s", "cores": best, "host_cpus": host, "usable_cpus": usable, "kind": "port",
+           "thread_sweep_bb_ms": {str(k): round(1e3 * v, 1) for k, v in sweep.items()},
+           "label": "CPU restatement of the reference algorithm (C++/OpenMP, dense grid, 3 MPM kernels + recompute, per-pixel rasterizer)"}
     t0 = time.perf_counter()
     reps = 0
     while reps < 3 or (time.perf_counter() - t0 < 2.0 and reps < 20):
@@ -143,12 +156,21 @@ def time_frame_sample(scene, rt=None, max_seconds: float = 30.0):
     # ---- the benchmarked workload
     cs = CpuScene(scene, synth.load_base_weights(cfg["mat"]))
     S, V = cfg["S"], cfg["V"]
-    tm = {}
-    t0 = time.perf_counter()
-    run_frame(cs, substeps=1, views=[0], timings=tm)         # minimal sample: 1 substep + binding + 1 view, fwd + bwd
+    # minimal sample (1 substep + binding + 1 view, fwd + bwd) at the bb-optimal thread count and at (half of) all usable
+    # cores: a 100k-particle scene can use more threads than the 8k-particle one
+    trials = {}
+    for n in sorted({best, usable, max(1, usable // 2)}):
+        cref.set_threads(n)
+        tmn = {}
+        run_frame(cs, substeps=1, views=[0], timings=tmn)
+        trials[n] = (S * (tmn["sim_fwd"] + tmn["sim_bwd"]) + V * tmn["render_fwdbwd"] + tmn["bind"], tmn)
+    nbest = min(trials, key=lambda k: trials[k][0])
+    cref.set_threads(nbest)
+    est, tm = trials[nbest]
+    out["cores"] = nbest
+    out["thread_trials_frame_s"] = {str(k): round(v[0], 2) for k, v in trials.items()}
     t_sub = tm["sim_fwd"] + tm["sim_bwd"]
     t_view = tm["render_fwdbwd"]
-    est = S * t_sub + V * t_view + tm["bind"]
     if est <= max_seconds:
         tm = {}
         t0 = time.perf_counter()

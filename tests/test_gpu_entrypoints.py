@@ -1,0 +1,152 @@
+"""GPU: the config-driven entry points (`python -m neuma_amd.finetune`, `python -m neuma_amd.render`) on a tiny experiment
+written to disk in the reference's layout - YAML in the schema of experiments/configs/synthetic/finetune-bb.yaml, a
+NeuMASynthetic dataset (data_dynamic.json + RGBA frames), a 3DGS point_cloud.ply, a particle cloud, a base checkpoint - with
+asset preparation (opacity pruning, binding construction), stage A, stage B, checkpoint rotation, resume and the forward
+renderer.  Counterpart of experiments/finetune.py:491-663 and render.py:109-347."""
+import json
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from gpu_util import dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_experiment(tmp_path, frames=3):
+    from PIL import Image
+    from neuma_amd import io as nio, synth
+    from neuma_amd.config import load_config
+    from neuma_amd.dataset import VideoDataset
+    from neuma_amd.finetune import particle_init_data, setup
+    from neuma_amd.harness import DiskRuntime
+    from neuma_amd.render.gaussian_model import GaussianModel
+    from neuma_amd.train import simulate_video
+    d = dev()
+    scene = synth.make_scene("tiny")
+    W, H = scene.cfg["W"], scene.cfg["H"]
+    raw = tmp_path / "raw"
+    raw.mkdir()
+    # reconstructed kernels (with a few nearly transparent ones that preparation must prune) and the particle cloud
+    gm = GaussianModel(scene.cfg["sh"])
+    sh = torch.tensor(scene.g_sh)
+    op = torch.tensor(scene.g_opacity_logit).clone()
+    op[:50] = -8.0                                              # sigmoid(-8) < opacity_thres
+    gm.set_params(torch.tensor(scene.g_xyz), sh[:, :1].contiguous(), sh[:, 1:].contiguous(), torch.tensor(scene.g_logscale),
+                  torch.tensor(scene.g_rot), op)
+    nio.save_gaussians_ply(gm, raw / "point_cloud.ply")
+    nio.save_particles_ply(raw / "pcd.ply", scene.x0)
+    w = synth.load_base_weights("jelly")
+    keys = ("layers.0.fc.weight", "layers.1.fc.weight", "final_layer.fc.weight")
+    torch.save({t: {k: torch.tensor(a) for k, a in zip(keys, w[s])} for t, s in (("elasticity", "e"), ("plasticity", "p"))},
+               raw / "jelly_0300.pt")
+    data = tmp_path / "dataset"
+    (data / "data_dynamic").mkdir(parents=True)
+    cams = synth.ring_cameras(2, W, H)
+    entries = []
+    for vi, cam in enumerate(cams):
+        c2w = np.linalg.inv(cam.world_view_transform.double().numpy().T)
+        c2w[:3, 1:3] *= -1
+        fx, fy = nio.fov2focal(cam.FoVx, W), nio.fov2focal(cam.FoVy, H)
+        for step in range(frames + 1):
+            entries.append({"file_path": f"./data_dynamic/r_{vi}_{step:03d}.png", "c2w": c2w[:3].tolist(),
+                            "intrinsic": [[fx, 0, W / 2], [0, fy, H / 2], [0, 0, 1]]})
+            Image.fromarray(np.full((H, W, 4), 255, dtype=np.uint8), "RGBA").save(data / entries[-1]["file_path"])
+    (data / "data_dynamic.json").write_text(json.dumps(entries))
+    net = dict(layer_widths=[64, 64], norm=None, nonlinearity="gelu", no_bias=True, normalize_input=True)
+    sched = dict(type="cos", max_steps=4, learning_rate_alpha=0.1)
+    cfg = dict(gpu=0, seed=42, debug=False, debug_views=["r_0"], resume=False, overwrite=False, root=str(tmp_path / "logs"),
+               assets_root=str(tmp_path / "assets"), sim_data_name="tinyball", name="tinyball-v1", pretrained_ckpt=str(raw / "jelly_0300.pt"),
+               gaussian=dict(sh_degree=3, opacity_thres=0.02, confidence=0.95, max_particles=10, kernels_path=str(raw / "point_cloud.ply")),
+               video_data=dict(eval=False, camera_type="NeuMASynthetic",
+                               data=dict(path=str(data), transformsfile="data_dynamic.json", white_background=True, exclude_steps=[-1],
+                                         used_views=["r_0", "r_1"]), camera=dict(resolution=1, data_device="cpu")),
+               sim=dict(gravity=[0.0, -9.8, 0.0], bc="noslip", num_grids=32, dt=1e-3, bound=1, eps=0.0, skip_frame=1),
+               particle_data=dict(shape=dict(asset_root=None, sort=None, ori_bounds=[[0.0, 0.0, 0.0], [1.0, 1.0, 1.0]],
+                                             sim_bounds=[[0.0, 0.0, 0.0], [1.0, 1.0, 1.0]]), rho=1000.0, clip_bound=0.1,
+                                  particles_path=str(raw / "pcd.ply"), downsample_factor=1),
+               constitution=dict(elasticity=dict(net), plasticity=dict(net, alpha=1e-3), elasticity_lr=0.02, elasticity_wd=0.0,
+                                 elasticity_grad_max_norm=1.0, elasticity_scheduler=sched, plasticity_lr=0.002, plasticity_wd=0.0,
+                                 plasticity_grad_max_norm=1.0, plasticity_scheduler=sched, warmup_step=0, decay_init=0.5, decay_final=1.0,
+                                 decay_steps=2, lambda_max_decay=0.33, lora=dict(r=16, alpha=16), num_epochs=2, substeps=4,
+                                 num_frames=frames, views=["r_0", "r_1"], num_lora_ckpts=3),
+               velocity=dict(num_epochs=3, num_frames=2, substeps=4, lambda_reg=0.005, views=["r_0"], lr=0.2, scheduler=sched))
+    path = tmp_path / "finetune-tiny.yaml"
+    path.write_text(yaml.safe_dump(cfg, sort_keys=False))
+    # ---- ground-truth video: prepare the assets exactly as the driver will, then roll a "true" material out and overwrite
+    #      the placeholder frames
+    c = load_config(path)
+    env = setup(c, d)
+    init_data = particle_init_data(c, frames * 4)
+    ds = env["dataset"]
+    ds.set_init_x_and_v(init_x=init_data.pos, init_v=np.tile(np.array([[0.3, -0.6, 0.1]], np.float32), (init_data.pos.shape[0], 1)))
+    E, P = env["elasticity"], env["plasticity"]
+    for n in (E, P):
+        n.init_lora_layers(16, 16)
+        for lin in (n.layers[0].fc, n.layers[1].fc, n.final_layer.fc):
+            lin.lora_B.data.normal_(0, 0.05)
+    rt = DiskRuntime(c.sim, ds, env["gaussians"], env["bindings"], init_data, E.to(d), P.to(d), torch.ones(3, device=d), d, 4, ["r_0", "r_1"])
+    video = simulate_video(rt, frames)
+    first = [rt.render_view(rt.gaussians.get_xyz, None, vi, cov=rt._cov) for vi in range(2)]
+    for step, imgs in enumerate([first] + video):
+        for vi, img in enumerate(imgs):
+            a = (img.clamp(0, 1) * 255 + 0.5).to(torch.uint8).permute(1, 2, 0).cpu().numpy()
+            Image.fromarray(np.concatenate([a, np.full((H, W, 1), 255, np.uint8)], -1), "RGBA").save(data / f"data_dynamic/r_{vi}_{step:03d}.png")
+    return path, scene
+
+
+def test_finetune_and_render_entry_points(tmp_path):
+    from neuma_amd import io as nio
+    from neuma_amd.config import load_config
+    from neuma_amd.evaluate import main as render_main
+    from neuma_amd.finetune import finetune, main as finetune_main
+    path, scene = _write_experiment(tmp_path)
+    assets = tmp_path / "assets" / "tinyball"
+    # asset preparation happened through the reference's rules
+    K = nio.load_gaussians_ply(assets / "kernels.ply", 3).get_xyz.shape[0]
+    assert K == scene.g_xyz.shape[0] - 50                                   # 50 transparent kernels pruned
+    B, n_p = nio.load_bindings(assets / "bindings.pt")
+    N = nio.load_particles_ply(assets / "particles.ply").shape[0]
+    assert N >= scene.x0.shape[0] and B.size == (K, N) and float(n_p.min()) >= 1 and float(n_p.max()) <= 10
+    assert (assets / "particles.npz").exists()                              # MPMInitData cache written like the reference's
+    # ---- the whole driver through its command line
+    finetune_main(["-c", str(path)])
+    exp = tmp_path / "logs" / "tinyball-v1"
+    tune = exp / "finetune"
+    saved = yaml.safe_load((exp / "config.yaml").read_text())
+    assert saved["particle_data"]["span"] == [0, 12] and saved["particle_data"]["shape"]["name"] == "tinyball/particles"
+    init = torch.load(tune / "init.pt")
+    assert set(init) == {"init_x", "init_v"} and init["init_v"].shape == (N, 3)
+    v_fit = init["init_v"][0]
+    assert torch.isfinite(v_fit).all() and float(v_fit.abs().max()) > 0 and float((init["init_v"] - v_fit).abs().max()) == 0
+    assert sorted(p.name for p in tune.glob("*_lora.pt")) == ["0001_lora.pt", "0002_lora.pt"]
+    ck = torch.load(tune / "0002_lora.pt")
+    assert set(ck) == {"elasticity", "plasticity", "loss"} and np.isfinite(ck["loss"])
+    assert sorted(ck["elasticity"]) == sorted(f"{p}.fc.lora_{ab}" for p in ("layers.0", "layers.1", "final_layer") for ab in "AB")
+    # ---- an existing experiment is refused unless resume / overwrite; resume reuses init.pt and the newest adaptor
+    with pytest.raises(FileExistsError):
+        finetune(load_config(path))
+    cfg = load_config(path)
+    cfg.resume = True
+    cfg.constitution.num_epochs = 1
+    logs = []
+    losses = finetune(cfg, log=logs.append)
+    assert any("Loading initial velocity from checkpoint" in l for l in logs)
+    assert len(losses) == 1 and abs(losses[0] - ck["loss"]) < 0.5 * ck["loss"] + 1e-9
+    # ---- forward renderer with the fine-tuned adaptor
+    render_main(["-c", str(path), "-vn", "check", "-es", "5", "-l", "0002_lora.pt", "-dv", "r_0", "-sp", "run", "--result_root",
+                 str(tmp_path / "results")])
+    out = tmp_path / "results" / "tinyball-v1"
+    imgs = sorted(p.name for p in (out / "images_check").glob("*.png"))
+    assert imgs == [f"r_0_{i:03d}.png" for i in range(6)]
+    assert sorted(p.name for p in (out / "states_run").glob("*.ply")) == [f"{i:03d}.ply" for i in range(1, 6)]
+    from PIL import Image
+    a0 = np.array(Image.open(out / "images_check" / "r_0_000.png")).astype(np.float64)
+    gt0 = np.array(Image.open(tmp_path / "dataset" / "data_dynamic" / "r_0_000.png").convert("RGB")).astype(np.float64)
+    assert np.abs(a0 - gt0).max() <= 1.0                                      # first frame = un-deformed kernels = the GT's first frame
+    a5 = np.array(Image.open(out / "images_check" / "r_0_005.png")).astype(np.float64)
+    assert np.abs(a5 - a0).max() > 5                                          # the body moved
+    x5 = nio.load_particles_ply(out / "states_run" / "005.ply")
+    assert x5.shape == (N, 3) and np.isfinite(x5).all()

@@ -90,6 +90,8 @@ def test_nonfinite_substep_gradients_are_zeroed_like_the_per_operator_path():
     res = {}
     for fused in (True, False):
         rt.fused = fused
+        for p in params:
+            p.grad = None
         ins = [t.clone().requires_grad_(True) for t in (rt.x0, rt.v0, rt.C0, F0)]
         outs = rt.rollout(*ins)
         torch.autograd.backward(outs, [w.to(dev()) for w in gws], inputs=ins + params)
@@ -98,15 +100,17 @@ def test_nonfinite_substep_gradients_are_zeroed_like_the_per_operator_path():
     for a, b in zip(res[True], res[False]):
         assert torch.isfinite(a).all() and torch.isfinite(b).all()
         assert rel_max(a, b) < 2e-3
-    # the poison really did reach neighbours: some particles' input gradients were zeroed in both paths
+    # the poison really did reach the neighbours of the two particles through the grid adjoint: against a run with the two
+    # entries replaced by zeros, the gradients of more than those two particles differ
     clean = [w.clone() for w in gws]
     clean[0][rt.N // 3, 1] = 0.0
     clean[1][rt.N // 2, 0] = 0.0
     rt.fused = True
     ins = [t.clone().requires_grad_(True) for t in (rt.x0, rt.v0, rt.C0, F0)]
     torch.autograd.backward(rt.rollout(*ins), [w.to(dev()) for w in clean], inputs=ins)
-    poisoned = int(((ins[1].grad != 0).any(1) & (res[True][1] == 0).all(1)).sum())
-    assert poisoned > 1
+    diff = (res[True][1] - ins[1].grad).abs().amax(1)
+    poisoned = int((diff > 1e-3 * float(ins[1].grad.abs().max())).sum())
+    assert poisoned > 2
 
 
 def test_frame_forward_backward_finite_and_consistent():
