@@ -109,14 +109,14 @@ def test_finetune_and_render_entry_points(tmp_path):
     assert K == scene.g_xyz.shape[0] - 50                                   # 50 transparent kernels pruned
     B, n_p = nio.load_bindings(assets / "bindings.pt")
     N = nio.load_particles_ply(assets / "particles.ply").shape[0]
-    assert N >= scene.x0.shape[0] and B.size == (K, N) and float(n_p.min()) >= 1 and float(n_p.max()) <= 10
+    assert N >= scene.x0.shape[0] and (B.K, B.N) == (K, N) and float(n_p.min()) >= 1 and float(n_p.max()) <= 10
     assert (assets / "particles.npz").exists()                              # MPMInitData cache written like the reference's
     # ---- the whole driver through its command line
     finetune_main(["-c", str(path)])
     exp = tmp_path / "logs" / "tinyball-v1"
     tune = exp / "finetune"
     saved = yaml.safe_load((exp / "config.yaml").read_text())
-    assert saved["particle_data"]["span"] == [0, 12] and saved["particle_data"]["shape"]["name"] == "tinyball/particles"
+    assert saved["name"] == "tinyball-v1" and saved["constitution"]["lora"] == {"r": 16, "alpha": 16}      # finetune.py:529
     init = torch.load(tune / "init.pt")
     assert set(init) == {"init_x", "init_v"} and init["init_v"].shape == (N, 3)
     v_fit = init["init_v"][0]
@@ -136,17 +136,17 @@ def test_finetune_and_render_entry_points(tmp_path):
     assert any("Loading initial velocity from checkpoint" in l for l in logs)
     assert len(losses) == 1 and abs(losses[0] - ck["loss"]) < 0.5 * ck["loss"] + 1e-9
     # ---- forward renderer with the fine-tuned adaptor
-    render_main(["-c", str(path), "-vn", "check", "-es", "5", "-l", "0002_lora.pt", "-dv", "r_0", "-sp", "run", "--result_root",
-                 str(tmp_path / "results")])
+    render_main(["-c", str(path), "-vn", "check", "-es", "30", "-dt", "0.004", "-l", "0002_lora.pt", "-dv", "r_0", "-sp", "run",
+                 "--result_root", str(tmp_path / "results")])
     out = tmp_path / "results" / "tinyball-v1"
     imgs = sorted(p.name for p in (out / "images_check").glob("*.png"))
-    assert imgs == [f"r_0_{i:03d}.png" for i in range(6)]
-    assert sorted(p.name for p in (out / "states_run").glob("*.ply")) == [f"{i:03d}.ply" for i in range(1, 6)]
+    assert imgs == [f"r_0_{i:03d}.png" for i in range(31)]
+    assert sorted(p.name for p in (out / "states_run").glob("*.ply")) == [f"{i:03d}.ply" for i in range(1, 31)]
     from PIL import Image
     a0 = np.array(Image.open(out / "images_check" / "r_0_000.png")).astype(np.float64)
     gt0 = np.array(Image.open(tmp_path / "dataset" / "data_dynamic" / "r_0_000.png").convert("RGB")).astype(np.float64)
     assert np.abs(a0 - gt0).max() <= 1.0                                      # first frame = un-deformed kernels = the GT's first frame
-    a5 = np.array(Image.open(out / "images_check" / "r_0_005.png")).astype(np.float64)
-    assert np.abs(a5 - a0).max() > 5                                          # the body moved
-    x5 = nio.load_particles_ply(out / "states_run" / "005.ply")
-    assert x5.shape == (N, 3) and np.isfinite(x5).all()
+    a30 = np.array(Image.open(out / "images_check" / "r_0_030.png")).astype(np.float64)
+    assert np.abs(a30 - a0).max() > 5                                         # the body fell (0.12 s of gravity)
+    x30 = nio.load_particles_ply(out / "states_run" / "030.ply")
+    assert x30.shape == (N, 3) and np.isfinite(x30).all() and x30[:, 1].mean() < nio.load_particles_ply(assets / "particles.ply")[:, 1].mean() - 0.03
