@@ -231,24 +231,13 @@ def main():
     D = 0.0
     try:
         from neuma_amd.tune import compute_bindings_xyz, compute_bindings_F
-        from neuma_amd.render import _RasterizeGaussians
         with torch.no_grad():
             m3 = compute_bindings_xyz(last.x, rt.start[0], rt.g_start, rt.bindings)
             dg = compute_bindings_F(last.F, rt.bindings)
-            from neuma_amd.render import deform_cov_by_F, get_rasterizer
+            from neuma_amd.render import deform_cov_by_F, get_rasterizer, count_tile_pairs
             cov = deform_cov_by_F(rt._cov, dg)
             rast = get_rasterizer(rt.cameras[0], rt.gaussians.active_sh_degree, False, rt.background)
-            import ctypes as C
-            K = rt.K
-            radii = torch.zeros(K, dtype=torch.int32, device=dev)
-            gb = int(lib.nm_raster_geom_bytes(K))
-            geom = torch.empty(gb, dtype=torch.uint8, device=dev)
-            num = C.c_int64(0)
-            cfgc = rast._cam.cfg
-            lib.nm_raster_preprocess(C.byref(cfgc), K, rt._shs.size(1), _lib.ptr(m3.contiguous()), _lib.ptr(rt._shs), None,
-                                     _lib.ptr(rt._opacity), _lib.ptr(cov), _lib.ptr(radii), _lib.ptr(geom), gb, C.byref(num),
-                                     _lib.stream_ptr(dev))
-            D = float(num.value)
+            D = float(count_tile_pairs(rast, m3.contiguous(), rt._opacity, shs=rt._shs, cov3D_precomp=cov))
     except Exception as e:  # accounting only
         print(f"[bench] pair count unavailable: {e}", file=sys.stderr)
 

@@ -308,43 +308,35 @@ typedef struct nm_raster_cfg {
   int32_t tile_y1;
 } nm_raster_cfg;
 
-/* Byte sizes of the caller-allocated buffers.  geom / binning / image are state kept for the backward
- * pass (the geomBuffer / binningBuffer / imgBuffer tensors of the reference extension); scratch is only
- * live during nm_raster_render (sort double-buffers) and may be dropped right after. */
-size_t nm_raster_geom_bytes(int32_t k);
-size_t nm_raster_binning_bytes(int64_t num_rendered, const nm_raster_cfg* cfg);
-size_t nm_raster_scratch_bytes(int64_t num_rendered);
-size_t nm_raster_image_bytes(const nm_raster_cfg* cfg);
+/* One caller-allocated state buffer per rendered view replaces the geomBuffer / binningBuffer / imgBuffer tensors of the
+ * reference extension (diff_gaussian_rasterization rasterize_points.cu, called from gaussian_renderer/__init__.py:103-119);
+ * it is what the backward pass needs and nothing else.  cap_pairs = capacity, in (Gaussian, 64x64-pixel bin) pairs, of the
+ * depth-sorted bin lists inside it (a Gaussian of the usual size touches 1-4 bins; 8 * k is a generous first guess). */
+size_t nm_raster_state_bytes(const nm_raster_cfg* cfg, int32_t k, int64_t cap_pairs);
 
-/* Stage 1 (GaussianRasterizer.forward, first half: preprocess + tile counts + scan).
- * shs (K,M,3) or colors_precomp (K,3): exactly one non-NULL.  cov3D (K,6) required.
- * Writes radii (K) and *num_rendered (host) = number of (Gaussian,tile) pairs.  Synchronises `stream`
- * once to read that count (the reference extension does the same). */
-int nm_raster_preprocess(const nm_raster_cfg* cfg, int32_t k, int32_t m, const float* means3D,
-                         const float* shs, const float* colors_precomp, const float* opacities,
-                         const float* cov3D, int32_t* radii, void* geom, size_t geom_bytes,
-                         int64_t* num_rendered, void* stream);
-/* The same without the synchronisation: num_rendered must be PINNED host memory; it is zeroed at once and its value
- * arrives in stream order (wait for the stream or an event recorded after the call before reading it).  Lets a caller
- * enqueue stage 1 of several views before it blocks on the first count. */
-int nm_raster_preprocess_async(const nm_raster_cfg* cfg, int32_t k, int32_t m, const float* means3D,
-                               const float* shs, const float* colors_precomp, const float* opacities,
-                               const float* cov3D, int32_t* radii, void* geom, size_t geom_bytes,
-                               int64_t* num_rendered, void* stream);
-/* Stage 2: key emit, (tile, depth) sort, tile ranges, front-to-back composite -> out_color (3,H,W).
- * Rows outside the cfg tile stripe are left untouched. */
-int nm_raster_render(const nm_raster_cfg* cfg, int32_t k, int64_t num_rendered, const void* geom,
-                     void* binning, size_t binning_bytes, void* scratch, size_t scratch_bytes,
-                     void* image, size_t image_bytes, float* out_color, void* stream);
+/* GaussianRasterizer.forward: preprocess, binning into (bin, depth slab) cells, per-cell LDS depth sort, per-tile
+ * streaming composite -> out_color (3,H,W) and radii (K).  shs (K,M,3) or colors_precomp (K,3): exactly one non-NULL.
+ * cov3D (K,6) required.  Rows outside the cfg tile stripe are left untouched.  Entirely asynchronous on `stream` (the
+ * reference extension synchronises once per view to size its sort buffers).
+ * status_host: NULL, or PINNED host memory of two zero-initialised int64 that receive, in stream order, {number of
+ * pairs binned, overflow flag}.  overflow != 0: cap_pairs was too small, the image is incomplete - re-run with a state
+ * buffer of capacity >= the reported number of pairs. */
+int nm_raster_forward(const nm_raster_cfg* cfg, int32_t k, int32_t m, const float* means3D,
+                      const float* shs, const float* colors_precomp, const float* opacities,
+                      const float* cov3D, int32_t* radii, void* state, size_t state_bytes, int64_t cap_pairs,
+                      float* out_color, int64_t* status_host, void* stream);
+/* Exact number of (Gaussian, 16x16 tile) pairs of the view held in `state` - the `num_rendered` the reference extension
+ * returns.  Statistics (byte accounting); synchronises `stream`. */
+int nm_raster_count_pairs(const nm_raster_cfg* cfg, int32_t k, void* state, int64_t cap_pairs,
+                          int64_t* pairs_out, void* stream);
 /* GaussianRasterizer.backward.  dL_dcolor (3,H,W) in; outputs (any may be NULL except dL_dmeans3D):
  * dL_dmeans3D (K,3), dL_dmeans2D (K,3; screen-space mean gradient as the reference returns it),
  * dL_dcov3D (K,6), dL_dopacity (K,1), dL_dshs (K,M,3) or dL_dcolors (K,3).
- * workspace: device scratch of nm_raster_bwd_workspace(k) bytes. */
+ * state / cap_pairs: as passed to nm_raster_forward.  workspace: device scratch of nm_raster_bwd_workspace(k) bytes. */
 size_t nm_raster_bwd_workspace(int32_t k);
-int nm_raster_backward(const nm_raster_cfg* cfg, int32_t k, int32_t m, int64_t num_rendered,
-                       const float* means3D, const float* shs, const float* colors_precomp,
-                       const float* opacities, const float* cov3D, const void* geom,
-                       const void* binning, const void* image, const float* dL_dcolor,
+int nm_raster_backward(const nm_raster_cfg* cfg, int32_t k, int32_t m, const float* means3D,
+                       const float* shs, const float* colors_precomp, const float* opacities,
+                       const float* cov3D, const void* state, int64_t cap_pairs, const float* dL_dcolor,
                        float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcov3D, float* dL_dopacity,
                        float* dL_dshs, float* dL_dcolors, void* workspace, size_t workspace_bytes,
                        void* stream);

@@ -91,17 +91,12 @@ SIGNATURES = {
     "nm_bind_build": (C.c_int, [_I32, _I32, _P, _P, _P, C.POINTER(C.c_float), _F, C.POINTER(_I32), _F, _I32, _P, _P, _P, _P, _P, _SZ,
                                 _P]),
     "nm_bind_frame": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "nm_raster_geom_bytes": (_SZ, [_I32]),
-    "nm_raster_binning_bytes": (_SZ, [_I64, C.POINTER(nm_raster_cfg)]),
-    "nm_raster_scratch_bytes": (_SZ, [_I64]),
-    "nm_raster_image_bytes": (_SZ, [C.POINTER(nm_raster_cfg)]),
-    "nm_raster_preprocess": (C.c_int, [C.POINTER(nm_raster_cfg), _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _SZ,
-                                       C.POINTER(_I64), _P]),
-    "nm_raster_preprocess_async": (C.c_int, [C.POINTER(nm_raster_cfg), _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _P]),
-    "nm_raster_render": (C.c_int, [C.POINTER(nm_raster_cfg), _I32, _I64, _P, _P, _SZ, _P, _SZ, _P, _SZ, _P, _P]),
+    "nm_raster_state_bytes": (_SZ, [C.POINTER(nm_raster_cfg), _I32, _I64]),
+    "nm_raster_forward": (C.c_int, [C.POINTER(nm_raster_cfg), _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _SZ, _I64, _P, _P, _P]),
+    "nm_raster_count_pairs": (C.c_int, [C.POINTER(nm_raster_cfg), _I32, _P, _I64, _P, _P]),
     "nm_raster_bwd_workspace": (_SZ, [_I32]),
-    "nm_raster_backward": (C.c_int, [C.POINTER(nm_raster_cfg), _I32, _I32, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                                     _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "nm_raster_backward": (C.c_int, [C.POINTER(nm_raster_cfg), _I32, _I32, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P,
+                                     _SZ, _P]),
     "nm_pixel_loss": (C.c_int, [_I32, _F, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
     "nm_lora_merge": (C.c_int, [_I32, _I32, _I32, _F, _P, _P, _P, _P, _P]),
     "nm_lora_merge_bwd": (C.c_int, [_I32, _I32, _I32, _F, _P, _P, _P, _P, _P, _P]),

@@ -10,11 +10,15 @@
 //     gradients over its 64 lanes with DPP row operations (no LDS traffic), waves combine through
 //     ds_add_f32 into a per-batch LDS table, and one thread per Gaussian flushes the tile total with global
 //     atomics (one set per (tile, Gaussian) pair instead of one per (pixel, Gaussian));
-//   * (tile, depth) ordering: Gaussians are depth-sorted once (K keys), pairs are emitted in that order and a STABLE
-//     rocPRIM radix sort on the log2(tiles) tile bits alone finishes the job (2 passes over D instead of 6 over 64-bit keys).
+//   * (tile, depth) ordering without any global sort and without a host round trip: Gaussians are binned (integer global
+//     atomics, ~3 per Gaussian) into cells = (64x64-pixel bin, one of 64 depth slabs between the view's nearest and farthest
+//     visible Gaussian); every cell is sorted by (depth, index) in LDS by its own workgroup (bitonic network), which makes a
+//     bin's cells, read in slab order, one depth-sorted list.  A 16x16 tile streams the list of its bin front to back in
+//     batches of 256 candidates, keeps the ones that can reach one of its pixels (exact conic test) with an order-
+//     preserving ballot compaction into LDS, composites them, and stops at saturation - on a dense scene that is after
+//     ~5 % of the list, so the Gaussians behind an opaque surface are never duplicated per tile, sorted per tile or
+//     read again.  The backward pass walks the same list in reverse from the last contributor.
 #include "nm_common.h"
-
-#include <rocprim/rocprim.hpp>
 
 #define NM_TILE 16
 #define NM_TPB 256
@@ -46,89 +50,47 @@ static int make_rk(const nm_raster_cfg* c, int m, RK& k) {
   return NM_OK;
 }
 
-// ---------------------------------------------------------------- buffer carving
+// ---------------------------------------------------------------- state buffer (caller-owned, kept for the backward pass)
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-struct Geom {
-  float2* xy; float* depth; float4* conop; float* rgb; uint32_t* clamped; uint32_t* tiles; uint32_t* offs; int* rad;
-  uint32_t* order;                                 // Gaussian ids sorted by (depth, id); culled ones last
-  uint32_t *dkey_in, *dkey_out, *dval_in, *tiles_sorted;
-  void* scan_tmp; size_t scan_bytes; void* dsort_tmp; size_t dsort_bytes; size_t total;
+#define NM_BT 4      // a bin is NM_BT x NM_BT tiles (64 x 64 pixels)
+#define NM_NS 64     // depth slabs per bin
+#define NM_CELL_LDS 2048   // pairs a cell's workgroup sorts in LDS (bigger cells: same network on global memory)
+
+struct State {
+  uint32_t* hdr;       // [0] zmin bits [1] zmax bits [2] pairs binned (may exceed cap) [3] overflow flag [4..5] exact pair count (stats)
+  float2* xy; float* depth; float4* conop; float* rgb; uint32_t* clamped; int* rad;
+  uint32_t* cnt;       // per cell: count, then fill cursor
+  uint32_t* off;       // per cell: exclusive offsets (ncell + 1)
+  unsigned long long* pairs;   // (depth bits << 32 | Gaussian id), cell-major; cap entries
+  float* final_T; uint32_t* n_contrib;
+  int nbx, nby, ncell;
+  size_t total;
 };
-static size_t scan_temp_bytes(int k) {
-  size_t b = 0;
-  (void)rocprim::inclusive_scan(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)(k > 0 ? k : 1),
-                                rocprim::plus<uint32_t>());
-  return b;
-}
-static size_t dsort_temp_bytes(int k) {
-  size_t b = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                  (size_t)(k > 0 ? k : 1), 0u, 32u);
-  return b;
-}
-static Geom carve_geom(void* base, int k) {
-  Geom g; char* p = (char*)base; size_t o = 0; size_t K = (size_t)(k > 0 ? k : 1);
-  g.xy = (float2*)(p + o); o += al256(K * sizeof(float2));
-  g.depth = (float*)(p + o); o += al256(K * sizeof(float));
-  g.conop = (float4*)(p + o); o += al256(K * sizeof(float4));
-  g.rgb = (float*)(p + o); o += al256(K * 3 * sizeof(float));
-  g.clamped = (uint32_t*)(p + o); o += al256(K * sizeof(uint32_t));
-  g.tiles = (uint32_t*)(p + o); o += al256(K * sizeof(uint32_t));
-  g.offs = (uint32_t*)(p + o); o += al256(K * sizeof(uint32_t));
-  g.rad = (int*)(p + o); o += al256(K * sizeof(int));
-  g.order = (uint32_t*)(p + o); o += al256(K * sizeof(uint32_t));
-  g.dkey_in = (uint32_t*)(p + o); o += al256(K * sizeof(uint32_t));
-  g.dkey_out = (uint32_t*)(p + o); o += al256(K * sizeof(uint32_t));
-  g.dval_in = (uint32_t*)(p + o); o += al256(K * sizeof(uint32_t));
-  g.tiles_sorted = (uint32_t*)(p + o); o += al256(K * sizeof(uint32_t));
-  g.scan_bytes = scan_temp_bytes(k);
-  g.scan_tmp = (void*)(p + o); o += al256(g.scan_bytes);
-  g.dsort_bytes = dsort_temp_bytes(k);
-  g.dsort_tmp = (void*)(p + o); o += al256(g.dsort_bytes);
-  g.total = o;
-  return g;
-}
-struct Binning { uint32_t* point_list; uint2* ranges; size_t total; };
-static Binning carve_binning(void* base, int64_t D, int ntiles) {
-  Binning b; char* p = (char*)base; size_t o = 0; size_t n = (size_t)(D > 0 ? D : 1);
-  b.point_list = (uint32_t*)(p + o); o += al256(n * sizeof(uint32_t));
-  b.ranges = (uint2*)(p + o); o += al256((size_t)(ntiles + 1) * sizeof(uint2));   // + one never-rendered dummy tile
-  b.total = o;
-  return b;
-}
-struct Scratch { uint32_t* keys_in; uint32_t* keys_out; uint32_t* vals_in; void* sort_tmp; size_t sort_bytes; size_t total; };
-static Scratch carve_scratch(void* base, int64_t D) {
-  Scratch s; char* p = (char*)base; size_t o = 0; size_t n = (size_t)(D > 0 ? D : 1);
-  s.keys_in = (uint32_t*)(p + o); o += al256(n * sizeof(uint32_t));
-  s.keys_out = (uint32_t*)(p + o); o += al256(n * sizeof(uint32_t));
-  s.vals_in = (uint32_t*)(p + o); o += al256(n * sizeof(uint32_t));
-  size_t b = 0, b16 = 0;     // the buffers are sized for 32-bit keys; 16-bit keys (<= 65535 tiles) use a prefix of them
-  (void)rocprim::radix_sort_pairs(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                  (uint32_t*)nullptr, n, 0u, 32u);
-  (void)rocprim::radix_sort_pairs(nullptr, b16, (uint16_t*)nullptr, (uint16_t*)nullptr, (uint32_t*)nullptr,
-                                  (uint32_t*)nullptr, n, 0u, 16u);
-  s.sort_bytes = b > b16 ? b : b16;
-  s.sort_tmp = (void*)(p + o); o += al256(b);
-  s.total = o;
-  return s;
-}
-struct Img { float* final_T; uint32_t* n_contrib; size_t total; };
-static Img carve_img(void* base, int W, int H) {
-  Img i; char* p = (char*)base; size_t o = 0; size_t n = (size_t)W * H;
-  i.final_T = (float*)(p + o); o += al256(n * sizeof(float));
-  i.n_contrib = (uint32_t*)(p + o); o += al256(n * sizeof(uint32_t));
-  i.total = o;
-  return i;
+static State carve_state(void* base, int W, int H, int k, int64_t cap) {
+  State t; char* p = (char*)base; size_t o = 0; size_t K = (size_t)(k > 0 ? k : 1), n = (size_t)W * H;
+  const int gx = (W + NM_TILE - 1) / NM_TILE, gy = (H + NM_TILE - 1) / NM_TILE;
+  t.nbx = (gx + NM_BT - 1) / NM_BT; t.nby = (gy + NM_BT - 1) / NM_BT; t.ncell = t.nbx * t.nby * NM_NS;
+  t.hdr = (uint32_t*)(p + o); o += 256;
+  t.xy = (float2*)(p + o); o += al256(K * sizeof(float2));
+  t.depth = (float*)(p + o); o += al256(K * sizeof(float));
+  t.conop = (float4*)(p + o); o += al256(K * sizeof(float4));
+  t.rgb = (float*)(p + o); o += al256(K * 3 * sizeof(float));
+  t.clamped = (uint32_t*)(p + o); o += al256(K * sizeof(uint32_t));
+  t.rad = (int*)(p + o); o += al256(K * sizeof(int));
+  t.cnt = (uint32_t*)(p + o); o += al256(((size_t)t.ncell + 1) * sizeof(uint32_t));
+  t.off = (uint32_t*)(p + o); o += al256(((size_t)t.ncell + 1) * sizeof(uint32_t));
+  t.pairs = (unsigned long long*)(p + o); o += al256((size_t)(cap > 0 ? cap : 1) * sizeof(unsigned long long));
+  t.final_T = (float*)(p + o); o += al256(n * sizeof(float));
+  t.n_contrib = (uint32_t*)(p + o); o += al256(n * sizeof(uint32_t));
+  t.total = o;
+  return t;
 }
 
-extern "C" size_t nm_raster_geom_bytes(int32_t k) { return carve_geom(nullptr, k).total; }
-extern "C" size_t nm_raster_binning_bytes(int64_t D, const nm_raster_cfg* c) {
-  int gx = (c->image_width + NM_TILE - 1) / NM_TILE, gy = (c->image_height + NM_TILE - 1) / NM_TILE;
-  return carve_binning(nullptr, D, gx * gy).total;
+extern "C" size_t nm_raster_state_bytes(const nm_raster_cfg* c, int32_t k, int64_t cap_pairs) {
+  if (!c) return 0;
+  return carve_state(nullptr, c->image_width, c->image_height, k, cap_pairs).total;
 }
-extern "C" size_t nm_raster_scratch_bytes(int64_t D) { return carve_scratch(nullptr, D).total; }
-extern "C" size_t nm_raster_image_bytes(const nm_raster_cfg* c) { return carve_img(nullptr, c->image_width, c->image_height).total; }
 
 // ---------------------------------------------------------------- device helpers
 __device__ __forceinline__ float3 xf43(const float* m, float x, float y, float z) {  // [p,1] * M, first 3 columns
@@ -237,220 +199,292 @@ __device__ __forceinline__ Cov2D compute_cov2d(const RK& k, float mx, float my, 
 }
 
 // ---------------------------------------------------------------- forward kernels
+__global__ void __launch_bounds__(256) k_raster_init(uint32_t* __restrict__ hdr, uint32_t* __restrict__ cnt, int ncell) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= ncell) cnt[i] = 0u;
+  if (i == 0) { hdr[0] = 0x7f800000u; hdr[1] = 0u; hdr[2] = 0u; hdr[3] = 0u; hdr[4] = 0u; hdr[5] = 0u; }
+}
+
 __global__ void __launch_bounds__(256) k_preprocess(RK k, int K, const float* __restrict__ means, const float* __restrict__ shs,
                                                     const float* __restrict__ colors, const float* __restrict__ opac,
                                                     const float* __restrict__ cov3D, int* __restrict__ radii, float2* __restrict__ xy,
                                                     float* __restrict__ depth, float4* __restrict__ conop, float* __restrict__ rgb,
-                                                    uint32_t* __restrict__ clamped, uint32_t* __restrict__ tiles, int* __restrict__ grad_,
-                                                    uint32_t* __restrict__ dkey, uint32_t* __restrict__ dval) {
+                                                    uint32_t* __restrict__ clamped, int* __restrict__ grad_, uint32_t* __restrict__ hdr) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= K) return;
-  radii[i] = 0;
-  grad_[i] = 0;
-  tiles[i] = 0;
-  dkey[i] = 0xFFFFFFFFu;   // culled Gaussians sort last
-  dval[i] = (uint32_t)i;
-  float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
-  float3 pv = xf43(k.view, mx, my, mz);
-  if (!(pv.z > 0.2f)) return;  // near-plane cull
-  float4 ph = xf44(k.proj, mx, my, mz);
-  float pw = 1.0f / (ph.w + 0.0000001f);
-  float ndx = ph.x * pw, ndy = ph.y * pw;
-  float c6[6];
+  // depth range of the visible Gaussians (positive floats order like their bit patterns): one atomic pair per wave
+  uint32_t zlo = 0x7f800000u, zhi = 0u;
+  if (i < K) {
+    radii[i] = 0;
+    grad_[i] = 0;
+  }
+  bool live = i < K;
+  float mx = 0.f, my = 0.f, mz = 0.f, px = 0.f, py = 0.f;
+  float3 pv = make_float3(0.f, 0.f, 0.f);
+  Cov2D cv;
+  float det_inv = 0.f;
+  int r = 0;
+  if (live) {
+    mx = means[3 * i]; my = means[3 * i + 1]; mz = means[3 * i + 2];
+    pv = xf43(k.view, mx, my, mz);
+    live = pv.z > 0.2f;  // near-plane cull
+  }
+  if (live) {
+    float4 ph = xf44(k.proj, mx, my, mz);
+    float pw = 1.0f / (ph.w + 0.0000001f);
+    float ndx = ph.x * pw, ndy = ph.y * pw;
+    float c6[6];
 #pragma unroll
-  for (int a = 0; a < 6; ++a) c6[a] = cov3D[6 * i + a];
-  Cov2D cv = compute_cov2d(k, mx, my, mz, c6);
-  float det = cv.a * cv.c - cv.b * cv.b;
-  if (det == 0.0f) return;
-  float det_inv = 1.f / det;
-  float mid = 0.5f * (cv.a + cv.c);
-  float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
-  int r = (int)ceilf(3.f * sqrtf(lam));
-  float px = ((ndx + 1.0f) * k.W - 1.0f) * 0.5f, py = ((ndy + 1.0f) * k.H - 1.0f) * 0.5f;
-  int x0, y0, x1, y1;
-  get_rect(k, px, py, r, x0, y0, x1, y1, 0, k.gy);
-  if ((x1 - x0) * (y1 - y0) == 0) return;
-  // colour
-  uint32_t cl = 0;
-  float col[3];
-  if (colors) {
-    col[0] = colors[3 * i]; col[1] = colors[3 * i + 1]; col[2] = colors[3 * i + 2];
-  } else {
-    float dx = mx - k.cam[0], dy = my - k.cam[1], dz = mz - k.cam[2];
-    float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
-    float x = dx * inv, y = dy * inv, z = dz * inv;
-    const float* sh = shs + (size_t)i * k.M * 3;
+    for (int a = 0; a < 6; ++a) c6[a] = cov3D[6 * i + a];
+    cv = compute_cov2d(k, mx, my, mz, c6);
+    float det = cv.a * cv.c - cv.b * cv.b;
+    live = det != 0.0f;
+    if (live) {
+      det_inv = 1.f / det;
+      float mid = 0.5f * (cv.a + cv.c);
+      float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+      r = (int)ceilf(3.f * sqrtf(lam));
+      px = ((ndx + 1.0f) * k.W - 1.0f) * 0.5f; py = ((ndy + 1.0f) * k.H - 1.0f) * 0.5f;
+      int x0, y0, x1, y1;
+      get_rect(k, px, py, r, x0, y0, x1, y1, 0, k.gy);
+      live = (x1 - x0) * (y1 - y0) != 0;
+    }
+  }
+  if (live) {
+    // colour
+    uint32_t cl = 0;
+    float col[3];
+    if (colors) {
+      col[0] = colors[3 * i]; col[1] = colors[3 * i + 1]; col[2] = colors[3 * i + 2];
+    } else {
+      float dx = mx - k.cam[0], dy = my - k.cam[1], dz = mz - k.cam[2];
+      float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+      float x = dx * inv, y = dy * inv, z = dz * inv;
+      const float* sh = shs + (size_t)i * k.M * 3;
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      float res = SH_C0 * sh[ch];
-      if (k.deg > 0) {
-        res = res - SH_C1 * y * sh[3 + ch] + SH_C1 * z * sh[6 + ch] - SH_C1 * x * sh[9 + ch];
-        if (k.deg > 1) {
-          float xx = x * x, yy = y * y, zz = z * z, xy_ = x * y, yz = y * z, xz = x * z;
-          res = res + SH_C2[0] * xy_ * sh[12 + ch] + SH_C2[1] * yz * sh[15 + ch] + SH_C2[2] * (2.f * zz - xx - yy) * sh[18 + ch] +
-                SH_C2[3] * xz * sh[21 + ch] + SH_C2[4] * (xx - yy) * sh[24 + ch];
-          if (k.deg > 2) {
-            res = res + SH_C3[0] * y * (3.f * xx - yy) * sh[27 + ch] + SH_C3[1] * xy_ * z * sh[30 + ch] +
-                  SH_C3[2] * y * (4.f * zz - xx - yy) * sh[33 + ch] + SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * sh[36 + ch] +
-                  SH_C3[4] * x * (4.f * zz - xx - yy) * sh[39 + ch] + SH_C3[5] * z * (xx - yy) * sh[42 + ch] +
-                  SH_C3[6] * x * (xx - 3.f * yy) * sh[45 + ch];
+      for (int ch = 0; ch < 3; ++ch) {
+        float res = SH_C0 * sh[ch];
+        if (k.deg > 0) {
+          res = res - SH_C1 * y * sh[3 + ch] + SH_C1 * z * sh[6 + ch] - SH_C1 * x * sh[9 + ch];
+          if (k.deg > 1) {
+            float xx = x * x, yy = y * y, zz = z * z, xy_ = x * y, yz = y * z, xz = x * z;
+            res = res + SH_C2[0] * xy_ * sh[12 + ch] + SH_C2[1] * yz * sh[15 + ch] + SH_C2[2] * (2.f * zz - xx - yy) * sh[18 + ch] +
+                  SH_C2[3] * xz * sh[21 + ch] + SH_C2[4] * (xx - yy) * sh[24 + ch];
+            if (k.deg > 2) {
+              res = res + SH_C3[0] * y * (3.f * xx - yy) * sh[27 + ch] + SH_C3[1] * xy_ * z * sh[30 + ch] +
+                    SH_C3[2] * y * (4.f * zz - xx - yy) * sh[33 + ch] + SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * sh[36 + ch] +
+                    SH_C3[4] * x * (4.f * zz - xx - yy) * sh[39 + ch] + SH_C3[5] * z * (xx - yy) * sh[42 + ch] +
+                    SH_C3[6] * x * (xx - 3.f * yy) * sh[45 + ch];
+            }
           }
         }
+        res += 0.5f;
+        if (res < 0.f) { cl |= (1u << ch); res = 0.f; }
+        col[ch] = res;
       }
-      res += 0.5f;
-      if (res < 0.f) { cl |= (1u << ch); res = 0.f; }
-      col[ch] = res;
     }
+    radii[i] = r;
+    grad_[i] = r;
+    xy[i] = make_float2(px, py);
+    depth[i] = pv.z;
+    conop[i] = make_float4(cv.c * det_inv, -cv.b * det_inv, cv.a * det_inv, opac[i]);
+    rgb[3 * i] = col[0]; rgb[3 * i + 1] = col[1]; rgb[3 * i + 2] = col[2];
+    clamped[i] = cl;
+    zlo = zhi = __float_as_uint(pv.z);
   }
-  int sx0, sy0, sx1, sy1;
-  get_rect(k, px, py, r, sx0, sy0, sx1, sy1, k.ty0, k.ty1);
-  radii[i] = r;
-  grad_[i] = r;
-  xy[i] = make_float2(px, py);
-  depth[i] = pv.z;
-  conop[i] = make_float4(cv.c * det_inv, -cv.b * det_inv, cv.a * det_inv, opac[i]);
-  rgb[3 * i] = col[0]; rgb[3 * i + 1] = col[1]; rgb[3 * i + 2] = col[2];
-  clamped[i] = cl;
-  {
-    const float4 co = make_float4(cv.c * det_inv, -cv.b * det_inv, cv.a * det_inv, opac[i]);
-    const TileCull tc = make_tile_cull(px, py, co);
-    uint32_t cnt = 0;
-    for (int y = sy0; y < sy1; ++y)
-      for (int x = sx0; x < sx1; ++x) cnt += tile_contributes(tc, x, y) ? 1u : 0u;
-    tiles[i] = cnt;
-    if (cnt) dkey[i] = __float_as_uint(pv.z);   // positive floats order like their bit patterns
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    zlo = min(zlo, (uint32_t)__shfl_xor((int)zlo, o, 64));
+    zhi = max(zhi, (uint32_t)__shfl_xor((int)zhi, o, 64));
   }
+  if ((threadIdx.x & 63) == 0 && zhi != 0u) { atomicMin(&hdr[0], zlo); atomicMax(&hdr[1], zhi); }
 }
 
-__global__ void __launch_bounds__(256) k_gather_tiles(int K, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles,
-                                                      uint32_t* __restrict__ tiles_sorted) {
-  int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < K) tiles_sorted[r] = tiles[order[r]];
+// depth slab of a view-space depth: monotone in z, evaluated by the count and the fill pass on identical inputs
+__device__ __forceinline__ int slab_of(float z, uint32_t zmin_bits, uint32_t zmax_bits) {
+#pragma clang fp contract(off)
+  const float zmin = __uint_as_float(zmin_bits), zmax = __uint_as_float(zmax_bits);
+  const float span = zmax - zmin;
+  if (!(span > 0.f)) return 0;
+  const int s = (int)((z - zmin) / span * (float)NM_NS);
+  return min(NM_NS - 1, max(0, s));
 }
 
-// Pairs are emitted in depth-rank order, so the (tile, depth) order the compositor needs is obtained by a STABLE sort
-// on the tile id alone (13 key bits instead of 45).  A lane loads the data of one rank; the tile rectangle of each
-// Gaussian is then scanned by a group of 16 lanes (4 Gaussians per wave at a time, 16 rounds): the contributing tiles
-// of a round are compacted with a ballot and written to consecutive slots, i.e. as full 64-byte segments.  (One
-// thread per Gaussian writing its own pairs one at a time cost 4.6x the algorithmic write traffic in partial lines.)
-template <typename KeyT>
-__global__ void __launch_bounds__(256) k_emit_keys(RK k, int K, const uint32_t* __restrict__ order, const int* __restrict__ radii,
-                                                   const float2* __restrict__ xy, const float4* __restrict__ conop,
-                                                   const uint32_t* __restrict__ offs, const uint32_t* __restrict__ tiles,
-                                                   KeyT* __restrict__ keys, uint32_t* __restrict__ vals) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
-  // ---- this lane's rank
-  uint32_t my_i = 0, my_off = 0, my_end = 0;
-  int rx0 = 0, ry0 = 0, rx1 = 0, ry1 = 0;
-  TileCull my_tc = {0.f, 0.f, 1.f, 0.f, 1.f, 0.f, 0.f, -1.f};
-  if (r < K) {
-    my_i = order[r];
-    if (tiles[my_i] != 0) {
-      my_off = (r == 0) ? 0u : offs[r - 1];
-      my_end = offs[r];
-      const float2 p = xy[my_i];
-      get_rect(k, p.x, p.y, radii[my_i], rx0, ry0, rx1, ry1, k.ty0, k.ty1);
-      my_tc = make_tile_cull(p.x, p.y, conop[my_i]);
-    }
-  }
-  // ---- 16 rounds: group g scans the rectangle of the rank held by lane (4 * round + g)
-  for (int round = 0; round < 16; ++round) {
-    const int src = 4 * round + grp;
-    const uint32_t gi = __shfl(my_i, src, 64);
-    uint32_t off = __shfl(my_off, src, 64);
-    const uint32_t end = __shfl(my_end, src, 64);
-    const int x0 = __shfl(rx0, src, 64), y0 = __shfl(ry0, src, 64), x1 = __shfl(rx1, src, 64), y1 = __shfl(ry1, src, 64);
-    TileCull tc;
-    tc.mx = __shfl(my_tc.mx, src, 64); tc.my = __shfl(my_tc.my, src, 64);
-    tc.ca = __shfl(my_tc.ca, src, 64); tc.cb = __shfl(my_tc.cb, src, 64); tc.cc = __shfl(my_tc.cc, src, 64);
-    tc.cb_over_cc = __shfl(my_tc.cb_over_cc, src, 64); tc.cb_over_ca = __shfl(my_tc.cb_over_ca, src, 64);
-    tc.qmax = __shfl(my_tc.qmax, src, 64);
-    const int w = x1 - x0, area = end > off ? w * (y1 - y0) : 0;
-    const int steps = (area + 15) >> 4;
-    for (int st = 0; st < steps; ++st) {            // group-uniform trip count
-      const int t = st * 16 + sub;
-      bool hit = false;
-      int tx = 0, ty = 0;
-      if (t < area) {
-        ty = y0 + t / w; tx = x0 + t - (t / w) * w;
-        hit = tile_contributes(tc, tx, ty);        // same predicate, same inputs as the count in k_preprocess
+// FILL = false: count the (Gaussian, bin) pairs per cell; FILL = true: write them.  A Gaussian goes into every bin its
+// 3-sigma tile rectangle (clipped to this rank's tile rows) overlaps.
+template <bool FILL>
+__global__ void __launch_bounds__(256) k_bin(RK k, int K, int nbx, const int* __restrict__ radii, const float2* __restrict__ xy,
+                                             const float* __restrict__ depth, const uint32_t* __restrict__ hdr,
+                                             uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
+                                             unsigned long long* __restrict__ pairs, long long cap) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K) return;
+  const int r = radii[i];
+  if (r <= 0) return;
+  const float2 p = xy[i];
+  int x0, y0, x1, y1;
+  get_rect(k, p.x, p.y, r, x0, y0, x1, y1, k.ty0, k.ty1);
+  if ((x1 - x0) * (y1 - y0) == 0) return;
+  const float z = depth[i];
+  const int slab = slab_of(z, hdr[0], hdr[1]);
+  const unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)(uint32_t)i;
+  for (int by = y0 / NM_BT; by <= (y1 - 1) / NM_BT; ++by)
+    for (int bx = x0 / NM_BT; bx <= (x1 - 1) / NM_BT; ++bx) {
+      const int cell = (by * nbx + bx) * NM_NS + slab;
+      const uint32_t at = atomicAdd(&cnt[cell], 1u);
+      if (FILL) {
+        const long long slot = (long long)off[cell] + (long long)at;
+        if (slot < cap) pairs[slot] = key;
       }
-      const uint32_t m16 = (uint32_t)((__ballot(hit) >> (16 * grp)) & 0xffffull);
-      const uint32_t pos = off + (uint32_t)__popc(m16 & ((1u << sub) - 1u));
-      if (hit && pos < end) {
-        keys[pos] = (KeyT)(ty * k.gx + tx);
-        vals[pos] = gi;
+    }
+}
+
+// exclusive scan of the cell counts by ONE workgroup (cells: 32k at 1080p); resets the counters for the fill pass
+__global__ void __launch_bounds__(1024) k_bin_scan(int ncell, uint32_t* __restrict__ cnt, uint32_t* __restrict__ off,
+                                                   uint32_t* __restrict__ hdr, long long cap) {
+  __shared__ uint32_t s_part[1024];
+  const int tid = threadIdx.x;
+  const int per = (ncell + 1023) / 1024;
+  const int lo = min(ncell, tid * per), hi = min(ncell, lo + per);
+  uint32_t sum = 0;
+  for (int c = lo; c < hi; ++c) sum += cnt[c];
+  s_part[tid] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {      // Hillis-Steele inclusive scan of the 1024 partial sums
+    uint32_t v = tid >= d ? s_part[tid - d] : 0u;
+    __syncthreads();
+    s_part[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = tid ? s_part[tid - 1] : 0u;
+  for (int c = lo; c < hi; ++c) {
+    const uint32_t n = cnt[c];
+    off[c] = run;
+    cnt[c] = 0u;
+    run += n;
+  }
+  if (tid == 1023) {
+    off[ncell] = s_part[1023];
+    hdr[2] = s_part[1023];
+    hdr[3] = ((long long)s_part[1023] > cap) ? 1u : 0u;   // pairs beyond the capacity are dropped: the caller must re-run
+  }
+}
+
+// Sort every cell by (depth, index).  All compare-exchanges of this bitonic network put the smaller key at the lower index
+// (each merge starts with a "flip" step i <-> block_end - 1 - i), so positions >= n simply act as +infinity padding.
+template <class Acc>
+__device__ __forceinline__ void bitonic_sort(Acc a, int n, int tid, int nthreads) {
+  int np = 1;
+  while (np < n) np <<= 1;
+  for (int kk = 2; kk <= np; kk <<= 1) {
+    const int half = kk >> 1;
+    for (int t = tid; t < (np >> 1); t += nthreads) {
+      const int blk = t / half, in = t - blk * half;
+      const int i = blk * kk + in, j = blk * kk + kk - 1 - in;
+      if (j < n) { unsigned long long x = a(i), y = a(j); if (x > y) { a(i) = y; a(j) = x; } }
+    }
+    __syncthreads();
+    for (int st = half >> 1; st > 0; st >>= 1) {
+      for (int t = tid; t < (np >> 1); t += nthreads) {
+        const int i = 2 * st * (t / st) + (t % st), j = i + st;
+        if (j < n) { unsigned long long x = a(i), y = a(j); if (x > y) { a(i) = y; a(j) = x; } }
       }
-      off += (uint32_t)__popc(m16);
+      __syncthreads();
     }
-    // belt and braces: should the two passes ever disagree, no slot is left uninitialised - leftovers go to a dummy
-    // tile (id gx*gy) that has a range entry but is never composited
-    for (uint32_t q = off + (uint32_t)sub; q < end; q += 16u) {
-      keys[q] = (KeyT)(k.gx * k.gy);
-      vals[q] = gi;
+  }
+}
+struct LdsAcc { unsigned long long* p; __device__ __forceinline__ unsigned long long& operator()(int i) const { return p[i]; } };
+struct GlobalAcc { volatile unsigned long long* p; __device__ __forceinline__ volatile unsigned long long& operator()(int i) const { return p[i]; } };
+
+__global__ void __launch_bounds__(256) k_cell_sort(int ncell, const uint32_t* __restrict__ off, unsigned long long* __restrict__ pairs,
+                                                   long long cap) {
+  __shared__ unsigned long long s_key[NM_CELL_LDS];
+  const int tid = threadIdx.x;
+  for (int c = blockIdx.x; c < ncell; c += gridDim.x) {
+    const long long lo = off[c];
+    const long long hi = min((long long)off[c + 1], cap);
+    const int n = (int)max(0ll, hi - lo);
+    if (n < 2) continue;
+    if (n <= NM_CELL_LDS) {
+      for (int i = tid; i < n; i += 256) s_key[i] = pairs[lo + i];
+      __syncthreads();
+      bitonic_sort(LdsAcc{s_key}, n, tid, 256);
+      for (int i = tid; i < n; i += 256) pairs[lo + i] = s_key[i];
+      __syncthreads();
+    } else {   // a cell too big for LDS (thousands of Gaussians of one bin in one depth slab): same network in global memory
+      __syncthreads();
+      bitonic_sort(GlobalAcc{pairs + lo}, n, tid, 256);
     }
   }
 }
 
-template <typename KeyT>
-__global__ void __launch_bounds__(256) k_tile_ranges(int64_t D, const KeyT* __restrict__ keys, uint2* __restrict__ ranges) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= D) return;
-  uint32_t t = keys[i];
-  if (i == 0) ranges[t].x = 0;
-  else {
-    uint32_t tp = keys[i - 1];
-    if (t != tp) { ranges[tp].y = (uint32_t)i; ranges[t].x = (uint32_t)i; }
-  }
-  if (i == D - 1) ranges[t].y = (uint32_t)D;
-}
-
-// front-to-back composite of one 16x16 tile (upstream renderCUDA forward)
-__global__ void __launch_bounds__(NM_TPB) k_render(RK k, const uint2* __restrict__ ranges, const uint32_t* __restrict__ plist,
-                                                   const float2* __restrict__ xy, const float* __restrict__ rgb,
-                                                   const float4* __restrict__ conop, float* __restrict__ final_T,
-                                                   uint32_t* __restrict__ n_contrib, float* __restrict__ out) {
+// front-to-back composite of one 16x16 tile (upstream renderCUDA forward) over the depth-sorted list of the tile's bin
+__global__ void __launch_bounds__(NM_TPB) k_render(RK k, int nbx, const uint32_t* __restrict__ off,
+                                                   const unsigned long long* __restrict__ pairs, long long cap,
+                                                   const int* __restrict__ radii, const float2* __restrict__ xy,
+                                                   const float* __restrict__ rgb, const float4* __restrict__ conop,
+                                                   float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                                                   float* __restrict__ out) {
   __shared__ float2 s_xy[NM_TPB];
   __shared__ float4 s_co[NM_TPB];
   __shared__ float s_rgb[NM_TPB * 3];
+  __shared__ uint32_t s_pos[NM_TPB];
+  __shared__ int s_wcnt[4];
   const int tile_x = blockIdx.x, tile_y = blockIdx.y + k.ty0;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = tile_x * NM_TILE + (tid & 15), py = tile_y * NM_TILE + (tid >> 4);
   const bool inside = px < k.W && py < k.H;
   const float fxp = (float)px, fyp = (float)py;
-  const uint2 range = ranges[tile_y * k.gx + tile_x];
-  int todo = (int)(range.y - range.x);
-  const int rounds = (todo + NM_TPB - 1) / NM_TPB;
+  const int bin = (tile_y / NM_BT) * nbx + tile_x / NM_BT;
+  const long long lo = off[bin * NM_NS];
+  const long long hi = min((long long)off[(bin + 1) * NM_NS], cap);
   bool done = !inside;
   float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
-  uint32_t contributor = 0, last = 0;
-  for (int rd = 0; rd < rounds; ++rd, todo -= NM_TPB) {
+  uint32_t last = 0;
+  for (long long base = lo; base < hi; base += NM_TPB) {
     if (__syncthreads_count(done) == NM_TPB) break;
-    int prog = rd * NM_TPB + tid;
-    if (range.x + prog < range.y) {
-      uint32_t id = plist[range.x + prog];
-      s_xy[tid] = xy[id];
-      s_co[tid] = conop[id];
-      s_rgb[3 * tid] = rgb[3 * id]; s_rgb[3 * tid + 1] = rgb[3 * id + 1]; s_rgb[3 * tid + 2] = rgb[3 * id + 2];
+    // ---- 256 candidates: which of them can reach a pixel of this tile?
+    const long long c = base + tid;
+    bool hit = false;
+    uint32_t id = 0;
+    float2 p = make_float2(0.f, 0.f);
+    float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < hi) {
+      id = (uint32_t)pairs[c];
+      p = xy[id];
+      co = conop[id];
+      int x0, y0, x1, y1;
+      get_rect(k, p.x, p.y, radii[id], x0, y0, x1, y1, k.ty0, k.ty1);
+      hit = tile_x >= x0 && tile_x < x1 && tile_y >= y0 && tile_y < y1 && tile_contributes(make_tile_cull(p.x, p.y, co), tile_x, tile_y);
+    }
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) s_wcnt[wave] = __popcll(m);
+    __syncthreads();
+    int before = 0, nb = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const int n = s_wcnt[w]; before += w < wave ? n : 0; nb += n; }
+    if (hit) {
+      const int slot = before + __popcll(m & ((1ull << lane) - 1ull));
+      s_xy[slot] = p;
+      s_co[slot] = co;
+      s_rgb[3 * slot] = rgb[3 * id]; s_rgb[3 * slot + 1] = rgb[3 * id + 1]; s_rgb[3 * slot + 2] = rgb[3 * id + 2];
+      s_pos[slot] = (uint32_t)(c - lo) + 1u;     // 1-based position in the bin's list
     }
     __syncthreads();
-    const int nb = min(NM_TPB, todo);
+    // ---- composite the survivors, in list (= depth) order
     for (int j = 0; !done && j < nb; ++j) {
-      contributor++;
-      float2 p = s_xy[j];
-      float4 co = s_co[j];
-      float dx = p.x - fxp, dy = p.y - fyp;
-      float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+      float2 q = s_xy[j];
+      float4 cj = s_co[j];
+      float dx = q.x - fxp, dy = q.y - fyp;
+      float power = -0.5f * (cj.x * dx * dx + cj.z * dy * dy) - cj.y * dx * dy;
       if (power > 0.f) continue;
-      float alpha = fminf(0.99f, co.w * __expf(power));
+      float alpha = fminf(0.99f, cj.w * __expf(power));
       if (alpha < 1.0f / 255.0f) continue;
       float test_T = T * (1.f - alpha);
       if (test_T < 0.0001f) { done = true; continue; }
       float w = alpha * T;
       C0 += s_rgb[3 * j] * w; C1 += s_rgb[3 * j + 1] * w; C2 += s_rgb[3 * j + 2] * w;
       T = test_T;
-      last = contributor;
+      last = s_pos[j];
     }
   }
   if (inside) {
@@ -461,6 +495,25 @@ __global__ void __launch_bounds__(NM_TPB) k_render(RK k, const uint2* __restrict
     out[hw + pix] = C1 + T * k.bg[1];
     out[2 * hw + pix] = C2 + T * k.bg[2];
   }
+}
+
+// exact number of (Gaussian, tile) pairs of the view (what the reference's duplicateWithKeys would emit after the conic
+// test): statistics for the byte accounting, not on the render path
+__global__ void __launch_bounds__(256) k_count_pairs(RK k, int K, const int* __restrict__ radii, const float2* __restrict__ xy,
+                                                     const float4* __restrict__ conop, unsigned long long* __restrict__ total) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long cnt = 0;
+  if (i < K && radii[i] > 0) {
+    const float2 p = xy[i];
+    int x0, y0, x1, y1;
+    get_rect(k, p.x, p.y, radii[i], x0, y0, x1, y1, k.ty0, k.ty1);
+    const TileCull tc = make_tile_cull(p.x, p.y, conop[i]);
+    for (int y = y0; y < y1; ++y)
+      for (int x = x0; x < x1; ++x) cnt += tile_contributes(tc, x, y) ? 1ull : 0ull;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += (unsigned long long)__shfl_xor((long long)cnt, o, 64);
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(total, cnt);
 }
 
 // ---------------------------------------------------------------- backward kernels
@@ -516,31 +569,33 @@ __device__ __forceinline__ float wave_sum_dpp(float x) {
 //   v[0]=d/dndc.x v[1]=d/dndc.y v[2]=d/dconic.x v[3]=d/dconic.y v[4]=d/dconic.z v[5..7]=d/drgb
 
 template <bool WITH_OPACITY>
-__global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, const uint2* __restrict__ ranges, const uint32_t* __restrict__ plist,
+__global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, int nbx, const uint32_t* __restrict__ off,
+                                                       const unsigned long long* __restrict__ pairs, const int* __restrict__ radii,
                                                        const float2* __restrict__ xy, const float* __restrict__ rgb,
                                                        const float4* __restrict__ conop, const float* __restrict__ final_T,
                                                        const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
                                                        float* __restrict__ acc /* (K, 9) */) {
-  // Gaussians are staged NM_RB_BATCH at a time: the four per-wave tables are what limits the number of resident tiles
-  // (LDS), and this loop lives on latency hiding - 128 per batch = 23 KB per tile = 6 waves per SIMD instead of 3
+  // candidates of the bin's list are tested NM_RB_BATCH at a time (back to front, starting at the tile's last contributor);
+  // the survivors are staged in LDS.  The four per-wave tables are what limits the number of resident tiles (LDS), and
+  // this loop lives on latency hiding - 128 per batch = 23 KB per tile = 6 waves per SIMD instead of 3
   __shared__ uint32_t s_id[NM_RB_BATCH];
+  __shared__ uint32_t s_pos[NM_RB_BATCH];
   __shared__ float2 s_xy[NM_RB_BATCH];
   __shared__ float4 s_co[NM_RB_BATCH];
   __shared__ float s_rgb[NM_RB_BATCH * 3];
   __shared__ float s_acc[4][NM_RB_BATCH * NM_NG];   // one private table per wave: plain stores, no LDS atomics
+  __shared__ int s_wcnt[4];
   const int tile_x = blockIdx.x, tile_y = blockIdx.y + k.ty0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = tile_x * NM_TILE + (tid & 15), py = tile_y * NM_TILE + (tid >> 4);
   const bool inside = px < k.W && py < k.H;
   const float fxp = (float)px, fyp = (float)py;
-  const uint2 range = ranges[tile_y * k.gx + tile_x];
-  int todo = (int)(range.y - range.x);
-  const int rounds = (todo + NM_RB_BATCH - 1) / NM_RB_BATCH;
+  const int bin = (tile_y / NM_BT) * nbx + tile_x / NM_BT;
+  const long long lo = off[bin * NM_NS];
   const size_t pix = (size_t)py * k.W + px, hw = (size_t)k.H * k.W;
   const float T_final = inside ? final_T[pix] : 0.f;
   float T = T_final;
-  uint32_t contributor = (uint32_t)todo;
-  const uint32_t last_contributor = inside ? n_contrib[pix] : 0u;
+  const uint32_t last_contributor = inside ? n_contrib[pix] : 0u;      // 1-based position in the bin's list, 0 = none
   float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f;
   if (inside) { dp0 = dL_dpix[pix]; dp1 = dL_dpix[hw + pix]; dp2 = dL_dpix[2 * hw + pix]; }
   const float bg_dot = k.bg[0] * dp0 + k.bg[1] * dp1 + k.bg[2] * dp2;
@@ -559,24 +614,41 @@ __global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, const uint2* __rest
   if (lane == 0) s_last[wave] = wave_last;
   __syncthreads();
   const uint32_t tile_last = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
-  for (int rd = 0; rd < rounds; ++rd, todo -= NM_RB_BATCH) {
-    // this batch covers list positions [todo - NM_RB_BATCH, todo): skip it entirely if all of them are >= tile_last
-    if ((uint32_t)max(todo - NM_RB_BATCH, 0) >= tile_last) { contributor -= (uint32_t)min(NM_RB_BATCH, todo); continue; }
+  for (long long top = lo + (long long)tile_last; top > lo; top -= NM_RB_BATCH) {
     __syncthreads();
-    int prog = rd * NM_RB_BATCH + tid;
-    if (tid < NM_RB_BATCH && range.x + prog < range.y) {
-      uint32_t id = plist[range.y - prog - 1];  // back to front
-      s_id[tid] = id;
-      s_xy[tid] = xy[id];
-      s_co[tid] = conop[id];
-      s_rgb[3 * tid] = rgb[3 * id]; s_rgb[3 * tid + 1] = rgb[3 * id + 1]; s_rgb[3 * tid + 2] = rgb[3 * id + 2];
+    // ---- candidates top-1, top-2, ... (back to front): which of them can reach a pixel of this tile?
+    const long long c = top - 1 - tid;
+    bool hit = false;
+    uint32_t id = 0;
+    float2 cp = make_float2(0.f, 0.f);
+    float4 cc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < NM_RB_BATCH && c >= lo) {
+      id = (uint32_t)pairs[c];
+      cp = xy[id];
+      cc = conop[id];
+      int x0, y0, x1, y1;
+      get_rect(k, cp.x, cp.y, radii[id], x0, y0, x1, y1, k.ty0, k.ty1);
+      hit = tile_x >= x0 && tile_x < x1 && tile_y >= y0 && tile_y < y1 && tile_contributes(make_tile_cull(cp.x, cp.y, cc), tile_x, tile_y);
+    }
+    const unsigned long long hm = __ballot(hit);
+    if (lane == 0) s_wcnt[wave] = __popcll(hm);
+    __syncthreads();
+    int before = 0, nb = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const int n = s_wcnt[w]; before += w < wave ? n : 0; nb += n; }
+    if (hit) {
+      const int slot = before + __popcll(hm & ((1ull << lane) - 1ull));
+      s_id[slot] = id;
+      s_pos[slot] = (uint32_t)(c - lo) + 1u;
+      s_xy[slot] = cp;
+      s_co[slot] = cc;
+      s_rgb[3 * slot] = rgb[3 * id]; s_rgb[3 * slot + 1] = rgb[3 * id + 1]; s_rgb[3 * slot + 2] = rgb[3 * id + 2];
     }
     __syncthreads();
-    const int nb = min(NM_RB_BATCH, todo);
     for (int j = 0; j < nb; ++j) {
-      contributor--;
-      if (contributor >= wave_last) continue;   // wave-uniform
-      bool act = contributor < last_contributor;
+      const uint32_t pos = s_pos[j];
+      if (pos > wave_last) continue;            // wave-uniform: behind every pixel's last contributor
+      bool act = pos <= last_contributor;
       float2 p = s_xy[j];
       float4 co = s_co[j];
       float dx = p.x - fxp, dy = p.y - fyp;
@@ -791,130 +863,104 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(RK k, int K, const float
 }
 
 // ---------------------------------------------------------------- host API
-static int raster_preprocess_impl(bool wait, const nm_raster_cfg* cfg, int32_t K, int32_t m, const float* means3D, const float* shs,
-                                    const float* colors_precomp, const float* opacities, const float* cov3D, int32_t* radii,
-                                    void* geom, size_t geom_bytes, int64_t* num_rendered, void* stream) {
+// One view, forward: 6 launches, no host synchronisation.  status_host (optional, pinned host memory, 2 x int64): receives
+// {pairs binned, overflow flag} by an asynchronous copy at the end - overflow != 0 means cap_pairs was too small and the image
+// is incomplete (the caller re-runs with a capacity >= pairs).
+extern "C" int nm_raster_forward(const nm_raster_cfg* cfg, int32_t K, int32_t m, const float* means3D, const float* shs,
+                                 const float* colors_precomp, const float* opacities, const float* cov3D, int32_t* radii,
+                                 void* state, size_t state_bytes, int64_t cap_pairs, float* out_color, int64_t* status_host,
+                                 void* stream) {
   RK k;
   int rc = make_rk(cfg, m, k);
   if (rc) return rc;
-  NM_REQUIRE(K >= 0 && num_rendered, "bad arguments");
-  *num_rendered = 0;
-  if (K == 0) return NM_OK;
-  NM_REQUIRE((shs != nullptr) != (colors_precomp != nullptr), "provide exactly one of shs / colors_precomp");
+  NM_REQUIRE(K >= 0 && cap_pairs >= 0 && out_color && state, "bad arguments");
+  NM_REQUIRE(K == 0 || (shs != nullptr) != (colors_precomp != nullptr), "provide exactly one of shs / colors_precomp");
   NM_REQUIRE(!shs || m >= (cfg->sh_degree + 1) * (cfg->sh_degree + 1), "shs has too few coefficients for sh_degree");
-  NM_REQUIRE(means3D && opacities && cov3D && radii && geom, "null pointer");
-  Geom g = carve_geom(geom, K);
-  if (geom_bytes < g.total) { nm_set_error("geom buffer too small: need %zu got %zu", g.total, geom_bytes); return NM_ERR_WORKSPACE; }
+  NM_REQUIRE(K == 0 || (means3D && opacities && cov3D && radii), "null pointer");
+  State t = carve_state(state, k.W, k.H, K, cap_pairs);
+  if (state_bytes < t.total) { nm_set_error("raster state buffer too small: need %zu got %zu", t.total, state_bytes); return NM_ERR_WORKSPACE; }
   hipStream_t s = (hipStream_t)stream;
-  NM_LAUNCH(k_preprocess, dim3(nm_div_up(K, 256)), dim3(256), 0, s, k, K, means3D, shs, colors_precomp, opacities, cov3D,
-                     radii, g.xy, g.depth, g.conop, g.rgb, g.clamped, g.tiles, g.rad, g.dkey_in, g.dval_in);
+  NM_LAUNCH(k_raster_init, dim3(nm_div_up(t.ncell + 1, 256)), dim3(256), 0, s, t.hdr, t.cnt, t.ncell);
   NM_LAUNCH_CHECK();
-  // depth order of the Gaussians (stable: ties keep index order), then tile counts / offsets in that order
-  size_t db = g.dsort_bytes;
-  NM_HIP_CHECK(rocprim::radix_sort_pairs(g.dsort_tmp, db, g.dkey_in, g.dkey_out, g.dval_in, g.order, (size_t)K, 0u, 32u, s));
-  NM_LAUNCH(k_gather_tiles, dim3(nm_div_up(K, 256)), dim3(256), 0, s, K, g.order, g.tiles, g.tiles_sorted);
-  NM_LAUNCH_CHECK();
-  size_t tb = g.scan_bytes;
-  NM_HIP_CHECK(rocprim::inclusive_scan(g.scan_tmp, tb, g.tiles_sorted, g.offs, (size_t)K, rocprim::plus<uint32_t>(), s));
-  if (!wait) {   // num_rendered is pinned host memory (pre-zeroed by the caller's *num_rendered = 0 above): low 32 bits arrive later
-    NM_HIP_CHECK(hipMemcpyAsync(num_rendered, g.offs + (K - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    return NM_OK;
+  if (K > 0) {
+    NM_LAUNCH(k_preprocess, dim3(nm_div_up(K, 256)), dim3(256), 0, s, k, K, means3D, shs, colors_precomp, opacities, cov3D, radii,
+              t.xy, t.depth, t.conop, t.rgb, t.clamped, t.rad, t.hdr);
+    NM_LAUNCH_CHECK();
+    NM_LAUNCH(k_bin<false>, dim3(nm_div_up(K, 256)), dim3(256), 0, s, k, K, t.nbx, (const int*)t.rad, t.xy, t.depth, t.hdr, t.cnt,
+              t.off, t.pairs, (long long)cap_pairs);
+    NM_LAUNCH_CHECK();
   }
-  uint32_t total = 0;
-  NM_HIP_CHECK(hipMemcpyAsync(&total, g.offs + (K - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-  NM_HIP_CHECK(hipStreamSynchronize(s));
-  *num_rendered = (int64_t)total;
+  NM_LAUNCH(k_bin_scan, dim3(1), dim3(1024), 0, s, t.ncell, t.cnt, t.off, t.hdr, (long long)cap_pairs);
+  NM_LAUNCH_CHECK();
+  if (K > 0) {
+    NM_LAUNCH(k_bin<true>, dim3(nm_div_up(K, 256)), dim3(256), 0, s, k, K, t.nbx, (const int*)t.rad, t.xy, t.depth, t.hdr, t.cnt,
+              t.off, t.pairs, (long long)cap_pairs);
+    NM_LAUNCH_CHECK();
+    NM_LAUNCH(k_cell_sort, dim3(min(t.ncell, 4096)), dim3(256), 0, s, t.ncell, t.off, t.pairs, (long long)cap_pairs);
+    NM_LAUNCH_CHECK();
+  }
+  NM_LAUNCH(k_render, dim3(k.gx, k.ty1 - k.ty0), dim3(NM_TPB), 0, s, k, t.nbx, t.off, t.pairs, (long long)cap_pairs, (const int*)t.rad,
+            t.xy, t.rgb, t.conop, t.final_T, t.n_contrib, out_color);
+  NM_LAUNCH_CHECK();
+  if (status_host) {
+    // hdr[2], hdr[3] are 32-bit: widen on the host side of the copy (two 4-byte copies into the low halves; the caller zeroes the buffer)
+    NM_HIP_CHECK(hipMemcpyAsync(status_host, t.hdr + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    NM_HIP_CHECK(hipMemcpyAsync(status_host + 1, t.hdr + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  }
   return NM_OK;
 }
 
-extern "C" int nm_raster_preprocess(const nm_raster_cfg* cfg, int32_t K, int32_t m, const float* means3D, const float* shs,
-                                    const float* colors_precomp, const float* opacities, const float* cov3D, int32_t* radii,
-                                    void* geom, size_t geom_bytes, int64_t* num_rendered, void* stream) {
-  return raster_preprocess_impl(true, cfg, K, m, means3D, shs, colors_precomp, opacities, cov3D, radii, geom, geom_bytes, num_rendered, stream);
-}
-extern "C" int nm_raster_preprocess_async(const nm_raster_cfg* cfg, int32_t K, int32_t m, const float* means3D, const float* shs,
-                                    const float* colors_precomp, const float* opacities, const float* cov3D, int32_t* radii,
-                                    void* geom, size_t geom_bytes, int64_t* num_rendered, void* stream) {
-  return raster_preprocess_impl(false, cfg, K, m, means3D, shs, colors_precomp, opacities, cov3D, radii, geom, geom_bytes, num_rendered, stream);
-}
-
-extern "C" int nm_raster_render(const nm_raster_cfg* cfg, int32_t K, int64_t D, const void* geom, void* binning,
-                                size_t binning_bytes, void* scratch, size_t scratch_bytes, void* image, size_t image_bytes,
-                                float* out_color, void* stream) {
+// Exact (Gaussian, tile) pair count of the view held in `state` (what the reference's duplicateWithKeys emits after the
+// conic test).  Synchronises the stream: statistics only.
+extern "C" int nm_raster_count_pairs(const nm_raster_cfg* cfg, int32_t K, void* state, int64_t cap_pairs, int64_t* pairs_out,
+                                     void* stream) {
   RK k;
   int rc = make_rk(cfg, 0, k);
   if (rc) return rc;
-  NM_REQUIRE(K >= 0 && D >= 0 && out_color && image && binning, "bad arguments");
+  NM_REQUIRE(K >= 0 && state && pairs_out, "bad arguments");
+  State t = carve_state(state, k.W, k.H, K, cap_pairs);
   hipStream_t s = (hipStream_t)stream;
-  Geom g = carve_geom((void*)geom, K);
-  Binning b = carve_binning(binning, D, k.gx * k.gy);
-  Img im = carve_img(image, k.W, k.H);
-  if (binning_bytes < b.total) { nm_set_error("binning buffer too small: need %zu got %zu", b.total, binning_bytes); return NM_ERR_WORKSPACE; }
-  if (image_bytes < im.total) { nm_set_error("image buffer too small: need %zu got %zu", im.total, image_bytes); return NM_ERR_WORKSPACE; }
-  NM_HIP_CHECK(hipMemsetAsync(b.ranges, 0, ((size_t)k.gx * k.gy + 1) * sizeof(uint2), s));
-  if (D > 0) {
-    NM_REQUIRE(geom && scratch, "null geom/scratch");
-    Scratch sc = carve_scratch(scratch, D);
-    if (scratch_bytes < sc.total) { nm_set_error("scratch buffer too small: need %zu got %zu", sc.total, scratch_bytes); return NM_ERR_WORKSPACE; }
-    int bits = 1;
-    while ((1 << bits) <= k.gx * k.gy) ++bits;   // tile ids 0 .. gx*gy (the last one is the dummy tile)
-    size_t tb = sc.sort_bytes;
-    if (bits <= 16) {      // 16-bit tile keys: a quarter less sort traffic (6 instead of 8 bytes per pair and pass)
-      uint16_t *k_in = (uint16_t*)sc.keys_in, *k_out = (uint16_t*)sc.keys_out;
-      NM_LAUNCH(k_emit_keys<uint16_t>, dim3(nm_div_up(K, 256)), dim3(256), 0, s, k, K, g.order, (const int*)g.rad, g.xy, g.conop,
-                g.offs, g.tiles, k_in, sc.vals_in);
-      NM_LAUNCH_CHECK();
-      NM_HIP_CHECK(rocprim::radix_sort_pairs(sc.sort_tmp, tb, k_in, k_out, sc.vals_in, b.point_list, (size_t)D, 0u, (unsigned)bits, s));
-      NM_LAUNCH(k_tile_ranges<uint16_t>, dim3(nm_div_up(D, 256)), dim3(256), 0, s, D, (const uint16_t*)k_out, b.ranges);
-      NM_LAUNCH_CHECK();
-    } else {
-      NM_LAUNCH(k_emit_keys<uint32_t>, dim3(nm_div_up(K, 256)), dim3(256), 0, s, k, K, g.order, (const int*)g.rad, g.xy, g.conop,
-                g.offs, g.tiles, sc.keys_in, sc.vals_in);
-      NM_LAUNCH_CHECK();
-      NM_HIP_CHECK(rocprim::radix_sort_pairs(sc.sort_tmp, tb, sc.keys_in, sc.keys_out, sc.vals_in, b.point_list, (size_t)D, 0u,
-                                             (unsigned)bits, s));
-      NM_LAUNCH(k_tile_ranges<uint32_t>, dim3(nm_div_up(D, 256)), dim3(256), 0, s, D, (const uint32_t*)sc.keys_out, b.ranges);
-      NM_LAUNCH_CHECK();
-    }
+  unsigned long long* total = (unsigned long long*)(t.hdr + 4);
+  NM_HIP_CHECK(hipMemsetAsync(total, 0, sizeof(unsigned long long), s));
+  if (K > 0) {
+    NM_LAUNCH(k_count_pairs, dim3(nm_div_up(K, 256)), dim3(256), 0, s, k, K, (const int*)t.rad, t.xy, t.conop, total);
+    NM_LAUNCH_CHECK();
   }
-  NM_LAUNCH(k_render, dim3(k.gx, k.ty1 - k.ty0), dim3(NM_TPB), 0, s, k, b.ranges, b.point_list, g.xy, g.rgb, g.conop,
-                     im.final_T, im.n_contrib, out_color);
-  NM_LAUNCH_CHECK();
+  unsigned long long h = 0;
+  NM_HIP_CHECK(hipMemcpyAsync(&h, total, sizeof(h), hipMemcpyDeviceToHost, s));
+  NM_HIP_CHECK(hipStreamSynchronize(s));
+  *pairs_out = (int64_t)h;
   return NM_OK;
 }
 
 extern "C" size_t nm_raster_bwd_workspace(int32_t K) { return al256((size_t)(K > 0 ? K : 1) * NM_NG * sizeof(float)); }
 
-extern "C" int nm_raster_backward(const nm_raster_cfg* cfg, int32_t K, int32_t m, int64_t D, const float* means3D,
-                                  const float* shs, const float* colors_precomp, const float* opacities, const float* cov3D,
-                                  const void* geom, const void* binning, const void* image, const float* dL_dcolor,
-                                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dcov3D, float* dL_dopacity, float* dL_dshs,
-                                  float* dL_dcolors, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int nm_raster_backward(const nm_raster_cfg* cfg, int32_t K, int32_t m, const float* means3D, const float* shs,
+                                  const float* colors_precomp, const float* opacities, const float* cov3D, const void* state,
+                                  int64_t cap_pairs, const float* dL_dcolor, float* dL_dmeans3D, float* dL_dmeans2D,
+                                  float* dL_dcov3D, float* dL_dopacity, float* dL_dshs, float* dL_dcolors, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
   (void)opacities; (void)colors_precomp;
   RK k;
   int rc = make_rk(cfg, m, k);
   if (rc) return rc;
-  NM_REQUIRE(K >= 0 && D >= 0, "bad arguments");
+  NM_REQUIRE(K >= 0 && cap_pairs >= 0, "bad arguments");
   if (K == 0) return NM_OK;
-  NM_REQUIRE(means3D && cov3D && geom && binning && image && dL_dcolor && dL_dmeans3D && workspace, "null pointer");
+  NM_REQUIRE(means3D && cov3D && state && dL_dcolor && dL_dmeans3D && workspace, "null pointer");
   if (workspace_bytes < nm_raster_bwd_workspace(K)) { nm_set_error("raster backward workspace too small"); return NM_ERR_WORKSPACE; }
   hipStream_t s = (hipStream_t)stream;
-  Geom g = carve_geom((void*)geom, K);
-  Binning b = carve_binning((void*)binning, D, k.gx * k.gy);
-  Img im = carve_img((void*)image, k.W, k.H);
+  State t = carve_state((void*)state, k.W, k.H, K, cap_pairs);
   float* acc = (float*)workspace;
   NM_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)K * NM_NG * sizeof(float), s));
-  if (D > 0) {
-    if (dL_dopacity)
-      NM_LAUNCH(k_render_bwd<true>, dim3(k.gx, k.ty1 - k.ty0), dim3(NM_TPB), 0, s, k, b.ranges, b.point_list, g.xy, g.rgb, g.conop,
-                im.final_T, im.n_contrib, dL_dcolor, acc);
-    else
-      NM_LAUNCH(k_render_bwd<false>, dim3(k.gx, k.ty1 - k.ty0), dim3(NM_TPB), 0, s, k, b.ranges, b.point_list, g.xy, g.rgb, g.conop,
-                im.final_T, im.n_contrib, dL_dcolor, acc);
-    NM_LAUNCH_CHECK();
-  }
-  NM_LAUNCH(k_preprocess_bwd, dim3(nm_div_up(K, 256)), dim3(256), 0, s, k, K, means3D, shs, cov3D, (const int*)g.tiles,
-                     g.clamped, acc, dL_dmeans3D, dL_dmeans2D, dL_dcov3D, dL_dopacity, dL_dshs, dL_dcolors, shs ? 1 : 0);
+  if (dL_dopacity)
+    NM_LAUNCH(k_render_bwd<true>, dim3(k.gx, k.ty1 - k.ty0), dim3(NM_TPB), 0, s, k, t.nbx, t.off, t.pairs, (const int*)t.rad, t.xy,
+              t.rgb, t.conop, t.final_T, t.n_contrib, dL_dcolor, acc);
+  else
+    NM_LAUNCH(k_render_bwd<false>, dim3(k.gx, k.ty1 - k.ty0), dim3(NM_TPB), 0, s, k, t.nbx, t.off, t.pairs, (const int*)t.rad, t.xy,
+              t.rgb, t.conop, t.final_T, t.n_contrib, dL_dcolor, acc);
+  NM_LAUNCH_CHECK();
+  NM_LAUNCH(k_preprocess_bwd, dim3(nm_div_up(K, 256)), dim3(256), 0, s, k, K, means3D, shs, cov3D, (const int*)t.rad, t.clamped, acc,
+            dL_dmeans3D, dL_dmeans2D, dL_dcov3D, dL_dopacity, dL_dshs, dL_dcolors, shs ? 1 : 0);
   NM_LAUNCH_CHECK();
   return NM_OK;
 }

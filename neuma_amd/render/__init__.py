@@ -52,6 +52,7 @@ class RasterCamera(object):
         self.settings = settings
         self.tile_rows = tile_rows
         self.cfg = _c_cfg(settings, tile_rows)
+        self.bins = BinCapacity()
 
 
 def build_cov3D(scales: Tensor, rotations: Tensor, scale_modifier: float = 1.0) -> Tensor:
@@ -69,23 +70,12 @@ def build_cov3D(scales: Tensor, rotations: Tensor, scale_modifier: float = 1.0) 
 
 
 class PreparedRaster(object):
-    """Stage 1 of a rasterization (preprocess, depth order, tile counts) that has been enqueued but whose pair count has
-    not been read yet (nm_raster_preprocess_async).  A caller with several views prepares all of them, then rasterizes:
-    the host blocks on the first count only after every view's stage 1 is in flight (harness.SceneRuntime.frame)."""
+    """Kept for callers of the two-stage interface (prepare_rasterization -> rasterizer(..., prepared=...)): the rasterizer
+    no longer has a host round trip between its stages (nm_raster_forward is one asynchronous call), so there is nothing
+    to prepare and this is an empty token."""
 
-    def __init__(self, cam, inputs, radii, geom, geom_bytes, count, event):
-        self.cam, self.inputs, self.radii, self.geom, self.geom_bytes, self.count, self.event = \
-            cam, inputs, radii, geom, geom_bytes, count, event
-
-    def matches(self, cam, m3, sh, cp, op, cv) -> bool:
-        def same(a, b):
-            return (a is None and b is None) or (a is not None and b is not None and a.data_ptr() == b.data_ptr()
-                                                  and a.shape == b.shape and a._version == b._version)
-        return cam is self.cam and all(same(a, b) for a, b in zip(self.inputs, (m3, sh, cp, op, cv)))
-
-    def num_rendered(self) -> int:
-        self.event.synchronize()
-        return int(self.count.item())
+    def matches(self, *a) -> bool:
+        return False
 
 
 def _raster_inputs(means3D, shs, colors_precomp, opacities, cov3D):
@@ -98,24 +88,35 @@ def _raster_inputs(means3D, shs, colors_precomp, opacities, cov3D):
 
 
 def prepare_rasterization(rasterizer, means3D, opacities, shs=None, colors_precomp=None, cov3D_precomp=None) -> PreparedRaster:
-    """Enqueue stage 1 for `rasterizer` (a GaussianRasterizer) on the current stream; pass the result to
-    rasterizer(..., prepared=...) with the SAME tensors."""
-    lib = L.lib()
-    cam = rasterizer._cam
-    m3, sh, cp, op, cv = _raster_inputs(means3D, shs, colors_precomp, opacities, cov3D_precomp)
-    dev = m3.device
-    K = m3.size(0)
-    M = 0 if sh is None else sh.size(1)
-    radii = torch.empty(K, dtype=torch.int32, device=dev)
-    geom_bytes = int(lib.nm_raster_geom_bytes(K))
-    geom = torch.empty(geom_bytes, dtype=torch.uint8, device=dev)
-    count = torch.zeros(1, dtype=torch.int64, pin_memory=True)
-    L.check(lib.nm_raster_preprocess_async(C.byref(cam.cfg), K, M, L.ptr(m3), L.ptr(sh), L.ptr(cp), L.ptr(op), L.ptr(cv),
-                                           L.ptr(radii), L.ptr(geom), geom_bytes, C.c_void_p(count.data_ptr()), L.stream_ptr(dev)),
-            "nm_raster_preprocess_async")
-    ev = torch.cuda.Event()
-    ev.record()
-    return PreparedRaster(cam, (m3, sh, cp, op, cv), radii, geom, geom_bytes, count, ev)
+    return PreparedRaster()
+
+
+class BinCapacity(object):
+    """Capacity policy of the depth-sorted bin lists of one camera (nm_raster_forward's cap_pairs).  The first render with a
+    camera is checked synchronously (and repeated with a larger state buffer if it overflowed); afterwards the capacity is
+    twice the last observed number of pairs and the status of every render is read back asynchronously and examined at the
+    next call - an overflow that slipped through (the scene suddenly needs > 2x the pairs) raises instead of returning a
+    truncated image silently."""
+
+    def __init__(self):
+        self.cap = 0              # 0: not sized yet (first guess 8 K + 4096)
+        self.verified = False     # a synchronously checked render has completed within `cap`
+        self.pending = None       # (pinned status tensor, event) of the last unchecked render
+
+    def check_pending(self):
+        if self.pending is None:
+            return
+        status, ev = self.pending
+        self.pending = None
+        ev.synchronize()
+        pairs, overflow = int(status[0]), int(status[1])
+        self.observe(pairs)
+        if overflow:
+            raise L.NeumaHipError(f"rasterizer bin lists overflowed in the previous render ({pairs} pairs > capacity): the image "
+                                  "was incomplete; the capacity has been raised, repeat the step")
+
+    def observe(self, pairs: int):
+        self.cap = max(self.cap, 2 * pairs + 4096)
 
 
 class _RasterizeGaussians(autograd.Function):
@@ -130,44 +131,46 @@ class _RasterizeGaussians(autograd.Function):
         m3, sh, cp, op, cv = _raster_inputs(means3D, shs, colors_precomp, opacities, cov3D)
         M = 0 if sh is None else sh.size(1)
         H, W = cfg.image_height, cfg.image_width
-        if prepared is not None and prepared.matches(cam, m3, sh, cp, op, cv):
-            radii, geom, D = prepared.radii, prepared.geom, prepared.num_rendered()
-            if geom.device == dev:
-                geom.record_stream(torch.cuda.current_stream(dev)); radii.record_stream(torch.cuda.current_stream(dev))
-        else:
-            radii = torch.empty(K, dtype=torch.int32, device=dev)            # k_preprocess writes every entry
-            geom_bytes = int(lib.nm_raster_geom_bytes(K))
-            geom = torch.empty(geom_bytes, dtype=torch.uint8, device=dev)
-            num = C.c_int64(0)
-            L.check(lib.nm_raster_preprocess(C.byref(cfg), K, M, L.ptr(m3), L.ptr(sh), L.ptr(cp), L.ptr(op), L.ptr(cv), L.ptr(radii),
-                                             L.ptr(geom), geom_bytes, C.byref(num), stream), "nm_raster_preprocess")
-            D = int(num.value)
-        bin_bytes = int(lib.nm_raster_binning_bytes(D, C.byref(cfg)))
-        img_bytes = int(lib.nm_raster_image_bytes(C.byref(cfg)))
-        scr_bytes = int(lib.nm_raster_scratch_bytes(D))
-        binning = torch.empty(bin_bytes, dtype=torch.uint8, device=dev)
-        imgbuf = torch.empty(img_bytes, dtype=torch.uint8, device=dev)
-        scratch = torch.empty(scr_bytes, dtype=torch.uint8, device=dev)
+        bins = cam.bins
+        bins.check_pending()
+        first = not bins.verified
+        if bins.cap == 0:
+            bins.cap = 8 * K + 4096
+        radii = torch.empty(K, dtype=torch.int32, device=dev)            # k_preprocess writes every entry
         full = cfg.tile_y1 <= cfg.tile_y0 or (cfg.tile_y0 == 0 and cfg.tile_y1 * 16 >= H)
         # a full-image render writes every pixel; a stripe leaves the rows outside it untouched (zero)
         color = (torch.empty if full else torch.zeros)(3, H, W, dtype=torch.float32, device=dev)
-        L.check(lib.nm_raster_render(C.byref(cfg), K, D, L.ptr(geom), L.ptr(binning), bin_bytes, L.ptr(scratch), scr_bytes,
-                                     L.ptr(imgbuf), img_bytes, L.ptr(color), stream), "nm_raster_render")
-        del scratch
-        ctx.cam, ctx.K, ctx.M, ctx.D = cam, K, M, D
+        while True:
+            cap = int(bins.cap)
+            state_bytes = int(lib.nm_raster_state_bytes(C.byref(cfg), K, cap))
+            state = torch.empty(state_bytes, dtype=torch.uint8, device=dev)
+            status = torch.zeros(2, dtype=torch.int64, pin_memory=True)
+            L.check(lib.nm_raster_forward(C.byref(cfg), K, M, L.ptr(m3), L.ptr(sh), L.ptr(cp), L.ptr(op), L.ptr(cv), L.ptr(radii),
+                                          L.ptr(state), state_bytes, cap, L.ptr(color), C.c_void_p(status.data_ptr()), stream),
+                    "nm_raster_forward")
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            if not first:
+                bins.pending = (status, ev)
+                break
+            ev.synchronize()                      # first render with this camera: size the lists from what the view needs
+            bins.observe(int(status[0]))
+            if not int(status[1]):
+                bins.verified = True
+                break
+        ctx.cam, ctx.K, ctx.M, ctx.cap = cam, K, M, cap
         ctx.has_sh = sh is not None
-        ctx.save_for_backward(m3, sh if sh is not None else cp, op, cv, geom, binning, imgbuf)
+        ctx.save_for_backward(m3, sh if sh is not None else cp, op, cv, state)
         ctx.mark_non_differentiable(radii)
-        ctx.num_rendered = D
         return color, radii
 
     @staticmethod
     def backward(ctx, grad_color, _grad_radii):
         lib = L.lib()
-        m3, shcol, op, cv, geom, binning, imgbuf = ctx.saved_tensors
+        m3, shcol, op, cv, state = ctx.saved_tensors
         dev = m3.device
         cfg = ctx.cam.cfg
-        K, M, D = ctx.K, ctx.M, ctx.D
+        K, M = ctx.K, ctx.M
         g = grad_color.float().contiguous()
         need = ctx.needs_input_grad  # means3D, means2D, shs, colors, opac, cov3D, cam
         dmeans3D = torch.empty(K, 3, dtype=torch.float32, device=dev)
@@ -180,11 +183,29 @@ class _RasterizeGaussians(autograd.Function):
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         sh = shcol if ctx.has_sh else None
         cp = None if ctx.has_sh else shcol
-        L.check(lib.nm_raster_backward(C.byref(cfg), K, M, D, L.ptr(m3), L.ptr(sh), L.ptr(cp), L.ptr(op), L.ptr(cv), L.ptr(geom),
-                                       L.ptr(binning), L.ptr(imgbuf), L.ptr(g), L.ptr(dmeans3D), L.ptr(dmeans2D), L.ptr(dcov),
-                                       L.ptr(dop), L.ptr(dsh), L.ptr(dcol), L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
-                "nm_raster_backward")
+        L.check(lib.nm_raster_backward(C.byref(cfg), K, M, L.ptr(m3), L.ptr(sh), L.ptr(cp), L.ptr(op), L.ptr(cv), L.ptr(state),
+                                       ctx.cap, L.ptr(g), L.ptr(dmeans3D), L.ptr(dmeans2D), L.ptr(dcov), L.ptr(dop), L.ptr(dsh),
+                                       L.ptr(dcol), L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "nm_raster_backward")
         return dmeans3D, dmeans2D, dsh, dcol, dop, dcov, None, None
+
+
+def count_tile_pairs(rasterizer, means3D, opacities, shs=None, colors_precomp=None, cov3D_precomp=None) -> int:
+    """Exact number of (Gaussian, 16x16 tile) pairs of a view - the reference extension's `num_rendered` (statistics)."""
+    lib = L.lib()
+    cam = rasterizer._cam
+    m3, sh, cp, op, cv = _raster_inputs(means3D, shs, colors_precomp, opacities, cov3D_precomp)
+    dev, K = m3.device, m3.size(0)
+    M = 0 if sh is None else sh.size(1)
+    cap = 8 * K + 4096
+    state_bytes = int(lib.nm_raster_state_bytes(C.byref(cam.cfg), K, cap))
+    state = torch.empty(state_bytes, dtype=torch.uint8, device=dev)
+    radii = torch.empty(K, dtype=torch.int32, device=dev)
+    color = torch.empty(3, cam.cfg.image_height, cam.cfg.image_width, dtype=torch.float32, device=dev)
+    L.check(lib.nm_raster_forward(C.byref(cam.cfg), K, M, L.ptr(m3), L.ptr(sh), L.ptr(cp), L.ptr(op), L.ptr(cv), L.ptr(radii),
+                                  L.ptr(state), state_bytes, cap, L.ptr(color), None, L.stream_ptr(dev)), "nm_raster_forward")
+    out = C.c_int64(0)
+    L.check(lib.nm_raster_count_pairs(C.byref(cam.cfg), K, L.ptr(state), cap, C.byref(out), L.stream_ptr(dev)), "nm_raster_count_pairs")
+    return int(out.value)
 
 
 class GaussianRasterizer(nn.Module):

@@ -160,3 +160,53 @@ def test_pixel_loss_kernel():
         ref = 0.7 * fn(ad, b.cpu().double())
         (gr,) = torch.autograd.grad(ref, ad)
         assert abs(float(loss) - float(ref)) < 1e-6 and abs_max(grad, gr) < 1e-7
+
+
+def test_raster_heavy_depth_cell_and_capacity_growth():
+    """3000 Gaussians at (almost) one depth in one 64x64-pixel bin land in ONE (bin, depth slab) cell - more than a cell's
+    workgroup sorts in LDS (2048), so the global-memory network sorts it; equal depths must come out in index order.
+    Then the same view with a deliberately tiny bin-list capacity: the first render grows it and repeats."""
+    from neuma_amd.render import count_tile_pairs
+    W, H, K = 64, 48, 3000
+    g = torch.Generator().manual_seed(5)
+    fov = math.radians(50.0)
+    fovy = 2 * math.atan(math.tan(fov / 2) * H / W)
+    wv, full, cam = orr.look_at_camera([0.5, 0.5, -1.0], [0.5, 0.5, 0.5], [0, -1, 0], fov, fovy)
+    s = orr.Settings(H, W, math.tan(fov / 2), math.tan(fovy / 2), torch.tensor([0.1, 0.2, 0.3]), 1.0, wv, full, 0, cam)
+    means = torch.empty(K, 3)
+    means[:, :2] = 0.5 + 0.25 * (torch.rand(K, 2, generator=g) - 0.5)
+    means[:, 2] = 0.5                                    # one plane perpendicular to the view axis: view depth 1.5 for all ...
+    means[:40, 2] = torch.linspace(0.2, 0.9, 40)         # ... but for a few that span the depth range (64 slabs)
+    means[100:400, 2] = 0.5                              # exact ties: order by index
+    cov = orr.build_cov3D(torch.full((K, 3), 0.012), torch.randn(K, 4, generator=g), 1.0)
+    op = torch.full((K, 1), 0.02) + 0.03 * torch.rand(K, 1, generator=g)       # faint: hundreds of layers contribute per pixel
+    col = torch.rand(K, 3, generator=g)
+    rast = _gpu_raster(s)
+    m = means.to(dev()).requires_grad_(True)
+    img, radii = rast(means3D=m, means2D=None, opacities=op.to(dev()), colors_precomp=col.to(dev()), cov3D_precomp=cov.to(dev()))
+    sd = orr.Settings(*[(f.double() if torch.is_tensor(f) else f) for f in s])
+    om = means.double().requires_grad_(True)
+    oimg, _, aux = orr.render(sd, om, cov.double(), op.double(), colors_precomp=col.double(), return_aux=True)
+    assert int(aux["n_contrib"].max()) > 150
+    assert abs_max(img, oimg) < 1e-3
+    gw = torch.randn(3, H, W, generator=g)
+    (gm,) = torch.autograd.grad((img * gw.to(dev())).sum(), m)
+    (ogm,) = torch.autograd.grad((oimg * gw.double()).sum(), om)
+    assert rel_max(gm, ogm) < 2e-3
+    # pairs after the exact conic test: a subset of the 3-sigma rectangles the oracle counts
+    pairs = count_tile_pairs(rast, means.to(dev()), op.to(dev()), colors_precomp=col.to(dev()), cov3D_precomp=cov.to(dev()))
+    assert 0.5 * aux["D"] < pairs <= aux["D"]
+    # capacity growth: a fresh camera whose first guess is far too small
+    rast2 = _gpu_raster(s)
+    rast2._cam.bins.cap = 64
+    img2, _ = rast2(means3D=means.to(dev()), means2D=None, opacities=op.to(dev()), colors_precomp=col.to(dev()), cov3D_precomp=cov.to(dev()))
+    assert torch.equal(img2, img.detach()) and rast2._cam.bins.cap > 3000
+    # a later render that overflows is reported at the next call, never silently
+    assert rast2._cam.bins.verified
+    rast2._cam.bins.cap = 64
+    rast2(means3D=means.to(dev()), means2D=None, opacities=op.to(dev()), colors_precomp=col.to(dev()), cov3D_precomp=cov.to(dev()))
+    from neuma_amd import NeumaHipError
+    with pytest.raises(NeumaHipError):
+        rast2(means3D=means.to(dev()), means2D=None, opacities=op.to(dev()), colors_precomp=col.to(dev()), cov3D_precomp=cov.to(dev()))
+    img3, _ = rast2(means3D=means.to(dev()), means2D=None, opacities=op.to(dev()), colors_precomp=col.to(dev()), cov3D_precomp=cov.to(dev()))
+    assert torch.equal(img3, img.detach())
