@@ -11,7 +11,7 @@
 //     ds_add_f32 into a per-batch LDS table, and one thread per Gaussian flushes the tile total with global
 //     atomics (one set per (tile, Gaussian) pair instead of one per (pixel, Gaussian));
 //   * (tile, depth) ordering without any global sort and without a host round trip: Gaussians are binned (integer global
-//     atomics, ~3 per Gaussian) into cells = (64x64-pixel bin, one of 64 depth slabs between the view's nearest and farthest
+//     atomics, ~3 per Gaussian) into cells = (64x64-pixel bin, one of 256 depth slabs between the view's nearest and farthest
 //     visible Gaussian); every cell is sorted by (depth, index) in LDS by its own workgroup (bitonic network), which makes a
 //     bin's cells, read in slab order, one depth-sorted list.  A 16x16 tile streams the list of its bin front to back in
 //     batches of 256 candidates, keeps the ones that can reach one of its pixels (exact conic test) with an order-
@@ -54,15 +54,24 @@ static int make_rk(const nm_raster_cfg* c, int m, RK& k) {
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 #define NM_BT 4      // a bin is NM_BT x NM_BT tiles (64 x 64 pixels)
-#define NM_NS 64     // depth slabs per bin
+#define NM_NS 256    // depth slabs per bin (one thread of a 256-thread workgroup each in the per-bin kernels)
 #define NM_CELL_LDS 2048   // pairs a cell's workgroup sorts in LDS (bigger cells: same network on global memory)
+#define NM_PAD 32          // words between two cell counters (one 128-byte line each)
+
+struct PairLog { uint32_t cell, rank, id, mask; };   // one (Gaussian, bin) pair as the count pass saw it
 
 struct State {
-  uint32_t* hdr;       // [0] zmin bits [1] zmax bits [2] pairs binned (may exceed cap) [3] overflow flag [4..5] exact pair count (stats)
+  uint32_t* hdr;       // [2] pairs binned (may exceed cap) [3] overflow flag [4..5] exact pair count (stats) [6] largest cell
   float2* xy; float* depth; float4* conop; float* rgb; uint32_t* clamped; int* rad;
-  uint32_t* cnt;       // per cell: count, then fill cursor
+  uint32_t* pad;       // per cell, one counter per 128-byte line (NM_PAD words apart): count, then fill cursor.  Neighbouring
+                       // cells are hit by the same burst of atomics; packed they would serialise on one L2 channel
+  uint32_t* cnt;       // per cell: count (compact copy of pad)
   uint32_t* off;       // per cell: exclusive offsets (ncell + 1)
-  unsigned long long* pairs;   // (depth bits << 32 | Gaussian id), cell-major; cap entries
+  uint2* zrange;       // per k_preprocess workgroup: {min, max} depth bits of its visible Gaussians
+  unsigned long long* keys;    // (depth bits << 32 | Gaussian id), cell-major; cap entries
+  uint32_t* vals;              // tile mask of the pair: bit (ty % 4) * 4 + (tx % 4) set iff the Gaussian can reach that tile of the bin
+  PairLog* log;                // the count pass's pair log (cap entries; dead after the fill pass)
+  uint32_t *bin_total, *bin_off;
   float* final_T; uint32_t* n_contrib;
   int nbx, nby, ncell;
   size_t total;
@@ -78,9 +87,16 @@ static State carve_state(void* base, int W, int H, int k, int64_t cap) {
   t.rgb = (float*)(p + o); o += al256(K * 3 * sizeof(float));
   t.clamped = (uint32_t*)(p + o); o += al256(K * sizeof(uint32_t));
   t.rad = (int*)(p + o); o += al256(K * sizeof(int));
+  t.pad = (uint32_t*)(p + o); o += al256((size_t)t.ncell * NM_PAD * sizeof(uint32_t));
   t.cnt = (uint32_t*)(p + o); o += al256(((size_t)t.ncell + 1) * sizeof(uint32_t));
   t.off = (uint32_t*)(p + o); o += al256(((size_t)t.ncell + 1) * sizeof(uint32_t));
-  t.pairs = (unsigned long long*)(p + o); o += al256((size_t)(cap > 0 ? cap : 1) * sizeof(unsigned long long));
+  t.zrange = (uint2*)(p + o); o += al256((K / 256 + 1) * sizeof(uint2));
+  const size_t cp = (size_t)(cap > 0 ? cap : 1);
+  t.keys = (unsigned long long*)(p + o); o += al256(cp * sizeof(unsigned long long));
+  t.vals = (uint32_t*)(p + o); o += al256(cp * sizeof(uint32_t));
+  t.log = (PairLog*)(p + o); o += al256(cp * sizeof(PairLog));
+  t.bin_total = (uint32_t*)(p + o); o += al256(((size_t)t.nbx * t.nby + 1) * sizeof(uint32_t));
+  t.bin_off = (uint32_t*)(p + o); o += al256(((size_t)t.nbx * t.nby + 1) * sizeof(uint32_t));
   t.final_T = (float*)(p + o); o += al256(n * sizeof(float));
   t.n_contrib = (uint32_t*)(p + o); o += al256(n * sizeof(uint32_t));
   t.total = o;
@@ -199,19 +215,15 @@ __device__ __forceinline__ Cov2D compute_cov2d(const RK& k, float mx, float my, 
 }
 
 // ---------------------------------------------------------------- forward kernels
-__global__ void __launch_bounds__(256) k_raster_init(uint32_t* __restrict__ hdr, uint32_t* __restrict__ cnt, int ncell) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i <= ncell) cnt[i] = 0u;
-  if (i == 0) { hdr[0] = 0x7f800000u; hdr[1] = 0u; hdr[2] = 0u; hdr[3] = 0u; hdr[4] = 0u; hdr[5] = 0u; }
-}
-
 __global__ void __launch_bounds__(256) k_preprocess(RK k, int K, const float* __restrict__ means, const float* __restrict__ shs,
                                                     const float* __restrict__ colors, const float* __restrict__ opac,
                                                     const float* __restrict__ cov3D, int* __restrict__ radii, float2* __restrict__ xy,
                                                     float* __restrict__ depth, float4* __restrict__ conop, float* __restrict__ rgb,
-                                                    uint32_t* __restrict__ clamped, int* __restrict__ grad_, uint32_t* __restrict__ hdr) {
+                                                    uint32_t* __restrict__ clamped, int* __restrict__ grad_, uint2* __restrict__ zrange) {
+  __shared__ uint32_t s_lo[4], s_hi[4];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  // depth range of the visible Gaussians (positive floats order like their bit patterns): one atomic pair per wave
+  // depth range of the visible Gaussians (positive floats order like their bit patterns), reduced per workgroup; the
+  // binning kernels fold the per-workgroup ranges themselves (a same-address atomic per wave cost more than this kernel)
   uint32_t zlo = 0x7f800000u, zhi = 0u;
   if (i < K) {
     radii[i] = 0;
@@ -296,12 +308,14 @@ __global__ void __launch_bounds__(256) k_preprocess(RK k, int K, const float* __
     zlo = min(zlo, (uint32_t)__shfl_xor((int)zlo, o, 64));
     zhi = max(zhi, (uint32_t)__shfl_xor((int)zhi, o, 64));
   }
-  if ((threadIdx.x & 63) == 0 && zhi != 0u) { atomicMin(&hdr[0], zlo); atomicMax(&hdr[1], zhi); }
+  if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = zlo; s_hi[threadIdx.x >> 6] = zhi; }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    zrange[blockIdx.x] = make_uint2(min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3])), max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3])));
 }
 
-// depth slab of a view-space depth: monotone in z, evaluated by the count and the fill pass on identical inputs
+// depth slab of a view-space depth: monotone in z
 __device__ __forceinline__ int slab_of(float z, uint32_t zmin_bits, uint32_t zmax_bits) {
-#pragma clang fp contract(off)
   const float zmin = __uint_as_float(zmin_bits), zmax = __uint_as_float(zmax_bits);
   const float span = zmax - zmin;
   if (!(span > 0.f)) return 0;
@@ -309,125 +323,279 @@ __device__ __forceinline__ int slab_of(float z, uint32_t zmin_bits, uint32_t zma
   return min(NM_NS - 1, max(0, s));
 }
 
-// FILL = false: count the (Gaussian, bin) pairs per cell; FILL = true: write them.  A Gaussian goes into every bin its
-// 3-sigma tile rectangle (clipped to this rank's tile rows) overlaps.
-template <bool FILL>
-__global__ void __launch_bounds__(256) k_bin(RK k, int K, int nbx, const int* __restrict__ radii, const float2* __restrict__ xy,
-                                             const float* __restrict__ depth, const uint32_t* __restrict__ hdr,
-                                             uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
-                                             unsigned long long* __restrict__ pairs, long long cap) {
+// Count pass of the binning: one thread per Gaussian.  For every 64x64-pixel bin its 3-sigma tile rectangle (clipped to this
+// rank's tile rows) overlaps, the exact conic test is run on the bin's 16 tiles; a pair with a non-empty tile mask takes a
+// rank in its (bin, depth slab) cell (one integer atomic on the cell's counter) and is appended to the pair log (slots of a
+// wave are reserved with ONE atomic), so that the fill pass needs neither atomics nor tile tests.
+__global__ void __launch_bounds__(256) k_bin_count(RK k, int K, int nbx, const int* __restrict__ radii, const float2* __restrict__ xy,
+                                                   const float* __restrict__ depth, const float4* __restrict__ conop,
+                                                   const uint2* __restrict__ zrange, int nrange, uint32_t* __restrict__ pad,
+                                                   PairLog* __restrict__ log, uint32_t* __restrict__ hdr, long long cap) {
+  __shared__ uint32_t s_lo[4], s_hi[4];
+  const int lane = threadIdx.x & 63;
+  uint32_t zlo = 0x7f800000u, zhi = 0u;
+  for (int q = threadIdx.x; q < nrange; q += 256) { const uint2 z = zrange[q]; zlo = min(zlo, z.x); zhi = max(zhi, z.y); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    zlo = min(zlo, (uint32_t)__shfl_xor((int)zlo, o, 64));
+    zhi = max(zhi, (uint32_t)__shfl_xor((int)zhi, o, 64));
+  }
+  if (lane == 0) { s_lo[threadIdx.x >> 6] = zlo; s_hi[threadIdx.x >> 6] = zhi; }
+  __syncthreads();
+  zlo = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
+  zhi = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= K) return;
-  const int r = radii[i];
-  if (r <= 0) return;
-  const float2 p = xy[i];
-  int x0, y0, x1, y1;
-  get_rect(k, p.x, p.y, r, x0, y0, x1, y1, k.ty0, k.ty1);
-  if ((x1 - x0) * (y1 - y0) == 0) return;
-  const float z = depth[i];
-  const int slab = slab_of(z, hdr[0], hdr[1]);
-  const unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)(uint32_t)i;
-  for (int by = y0 / NM_BT; by <= (y1 - 1) / NM_BT; ++by)
-    for (int bx = x0 / NM_BT; bx <= (x1 - 1) / NM_BT; ++bx) {
-      const int cell = (by * nbx + bx) * NM_NS + slab;
-      const uint32_t at = atomicAdd(&cnt[cell], 1u);
-      if (FILL) {
-        const long long slot = (long long)off[cell] + (long long)at;
-        if (slot < cap) pairs[slot] = key;
+  int x0 = 0, y0 = 0, x1 = 0, y1 = 0, slab = 0;
+  TileCull tc = {0.f, 0.f, 1.f, 0.f, 1.f, 0.f, 0.f, -1.f};
+  bool live = i < K && radii[i] > 0;
+  if (live) {
+    const float2 p = xy[i];
+    get_rect(k, p.x, p.y, radii[i], x0, y0, x1, y1, k.ty0, k.ty1);
+    live = (x1 - x0) * (y1 - y0) != 0;
+    if (live) {
+      tc = make_tile_cull(p.x, p.y, conop[i]);
+      slab = slab_of(depth[i], zlo, zhi);
+    }
+  }
+  const int bx0 = x0 / NM_BT, bx1 = live ? (x1 - 1) / NM_BT : -1, by0 = y0 / NM_BT, by1 = live ? (y1 - 1) / NM_BT : -1;
+  // ---- log slots: one per bin of the rectangle (an upper bound - bins no tile of which passes the conic test leave a dead
+  //      entry), exclusive prefix over the lanes, ONE atomic for the wave
+  const int mine = live ? (bx1 - bx0 + 1) * (by1 - by0 + 1) : 0;
+  int incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
+  const int wave_total = __shfl(incl, 63, 64);
+  uint32_t base = 0;
+  if (lane == 0 && wave_total) base = atomicAdd(&hdr[2], (uint32_t)wave_total);
+  base = (uint32_t)__shfl((int)base, 0, 64);
+  long long at = (long long)base + (incl - mine);
+  for (int by = by0; by <= by1; ++by)
+    for (int bx = bx0; bx <= bx1; ++bx) {
+      uint32_t m = 0;
+      for (int ty = max(y0, by * NM_BT); ty < min(y1, by * NM_BT + NM_BT); ++ty)
+        for (int tx = max(x0, bx * NM_BT); tx < min(x1, bx * NM_BT + NM_BT); ++tx)
+          m |= tile_contributes(tc, tx, ty) ? (1u << ((ty - by * NM_BT) * NM_BT + (tx - bx * NM_BT))) : 0u;
+      PairLog e;
+      e.cell = 0xffffffffu; e.rank = 0u; e.id = (uint32_t)i; e.mask = m;
+      if (m) {
+        e.cell = (uint32_t)((by * nbx + bx) * NM_NS + slab);
+        e.rank = atomicAdd(&pad[(size_t)e.cell * NM_PAD], 1u);
       }
+      if (at < cap) log[at] = e;
+      ++at;
     }
 }
 
-// exclusive scan of the cell counts by ONE workgroup (cells: 32k at 1080p); resets the counters for the fill pass
-__global__ void __launch_bounds__(1024) k_bin_scan(int ncell, uint32_t* __restrict__ cnt, uint32_t* __restrict__ off,
-                                                   uint32_t* __restrict__ hdr, long long cap) {
-  __shared__ uint32_t s_part[1024];
-  const int tid = threadIdx.x;
-  const int per = (ncell + 1023) / 1024;
-  const int lo = min(ncell, tid * per), hi = min(ncell, lo + per);
-  uint32_t sum = 0;
-  for (int c = lo; c < hi; ++c) sum += cnt[c];
-  s_part[tid] = sum;
+// padded counters -> compact array; per-bin totals (one workgroup per bin, one thread per depth slab)
+__global__ void __launch_bounds__(NM_NS) k_bin_compact(int nbin, const uint32_t* __restrict__ pad, uint32_t* __restrict__ cnt,
+                                                       uint32_t* __restrict__ bin_total, uint32_t* __restrict__ hdr) {
+  __shared__ uint32_t s_sum[NM_NS / 64], s_big[NM_NS / 64];
+  const int bin = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = bin * NM_NS + threadIdx.x;
+  const uint32_t n = pad[(size_t)c * NM_PAD];
+  cnt[c] = n;
+  uint32_t sum = n, big = n;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { sum += (uint32_t)__shfl_xor((int)sum, o, 64); big = max(big, (uint32_t)__shfl_xor((int)big, o, 64)); }
+  if (lane == 0) { s_sum[wave] = sum; s_big[wave] = big; }
   __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {      // Hillis-Steele inclusive scan of the 1024 partial sums
-    uint32_t v = tid >= d ? s_part[tid - d] : 0u;
-    __syncthreads();
-    s_part[tid] += v;
-    __syncthreads();
-  }
-  uint32_t run = tid ? s_part[tid - 1] : 0u;
-  for (int c = lo; c < hi; ++c) {
-    const uint32_t n = cnt[c];
-    off[c] = run;
-    cnt[c] = 0u;
-    run += n;
-  }
-  if (tid == 1023) {
-    off[ncell] = s_part[1023];
-    hdr[2] = s_part[1023];
-    hdr[3] = ((long long)s_part[1023] > cap) ? 1u : 0u;   // pairs beyond the capacity are dropped: the caller must re-run
+  if (threadIdx.x == 0) {
+    uint32_t ts = 0, tb = 0;
+    for (int w = 0; w < NM_NS / 64; ++w) { ts += s_sum[w]; tb = max(tb, s_big[w]); }
+    bin_total[bin] = ts;
+    if (tb) atomicMax(&hdr[6], tb);
   }
 }
 
-// Sort every cell by (depth, index).  All compare-exchanges of this bitonic network put the smaller key at the lower index
-// (each merge starts with a "flip" step i <-> block_end - 1 - i), so positions >= n simply act as +infinity padding.
-template <class Acc>
-__device__ __forceinline__ void bitonic_sort(Acc a, int n, int tid, int nthreads) {
+// exclusive scan of the bin totals by one workgroup (510 bins at 1080p)
+__global__ void __launch_bounds__(1024) k_bin_scan(int nbin, const uint32_t* __restrict__ bin_total, uint32_t* __restrict__ bin_off,
+                                                   uint32_t* __restrict__ hdr, long long cap) {
+  __shared__ uint32_t s_w[16];
+  __shared__ uint32_t s_run;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_run = 0u;
+  __syncthreads();
+  for (int base = 0; base < nbin; base += 1024) {
+    const int c = base + tid;
+    const uint32_t n = c < nbin ? bin_total[c] : 0u;
+    uint32_t x = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, o, 64); if (lane >= o) x += y; }
+    if (lane == 63) s_w[wave] = x;
+    __syncthreads();
+    uint32_t before = s_run;
+    for (int w = 0; w < wave; ++w) before += s_w[w];
+    if (c < nbin) bin_off[c] = before + x - n;
+    __syncthreads();
+    if (tid == 1023) s_run = before + x;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    bin_off[nbin] = s_run;
+    // hdr[2] = pairs logged by the count pass (may exceed the capacity: the log and the lists then miss pairs)
+    hdr[3] = ((long long)hdr[2] > cap) ? 1u : 0u;
+  }
+}
+
+// cell offsets: bin offset + exclusive scan over the bin's depth slabs (one workgroup per bin)
+__global__ void __launch_bounds__(NM_NS) k_cell_offsets(int nbin, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ bin_off,
+                                                        uint32_t* __restrict__ off) {
+  __shared__ uint32_t s_w[NM_NS / 64];
+  const int bin = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = bin * NM_NS + threadIdx.x;
+  const uint32_t n = cnt[c];
+  uint32_t x = n;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, o, 64); if (lane >= o) x += y; }
+  if (lane == 63) s_w[wave] = x;
+  __syncthreads();
+  uint32_t before = bin_off[bin];
+  for (int w = 0; w < wave; ++w) before += s_w[w];
+  off[c] = before + x - n;
+  if (bin == nbin - 1 && threadIdx.x == NM_NS - 1) off[c + 1] = bin_off[nbin];
+}
+
+// Fill pass: replay of the pair log - no atomics, no geometry: slot = cell offset + rank
+__global__ void __launch_bounds__(256) k_bin_fill(const uint32_t* __restrict__ hdr, const PairLog* __restrict__ log,
+                                                  const uint32_t* __restrict__ off, const float* __restrict__ depth,
+                                                  unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals, long long cap) {
+  const long long n = min((long long)hdr[2], cap);
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+    const PairLog q = log[e];
+    if (q.cell == 0xffffffffu) continue;     // dead entry: no tile of that bin passed the conic test
+    const long long slot = (long long)off[q.cell] + q.rank;
+    if (slot < cap) {
+      keys[slot] = ((unsigned long long)__float_as_uint(depth[q.id]) << 32) | (unsigned long long)q.id;
+      vals[slot] = q.mask;
+    }
+  }
+}
+
+// Sort every cell by (depth, index), the tile masks riding along.  All compare-exchanges of this bitonic network put the
+// smaller key at the lower index (each merge starts with a "flip" step i <-> block_end - 1 - i), so positions >= n act as
+// +infinity padding and no power-of-two padding is stored.  SYNC: barrier among the NT cooperating threads.
+template <int NT, class KeyP, class ValP, class Sync>
+__device__ __forceinline__ void bitonic_sort_kv(KeyP key, ValP val, int n, int t, Sync sync) {
   int np = 1;
   while (np < n) np <<= 1;
   for (int kk = 2; kk <= np; kk <<= 1) {
     const int half = kk >> 1;
-    for (int t = tid; t < (np >> 1); t += nthreads) {
-      const int blk = t / half, in = t - blk * half;
+    for (int q = t; q < (np >> 1); q += NT) {
+      const int blk = q / half, in = q - blk * half;
       const int i = blk * kk + in, j = blk * kk + kk - 1 - in;
-      if (j < n) { unsigned long long x = a(i), y = a(j); if (x > y) { a(i) = y; a(j) = x; } }
+      if (j < n) {
+        const unsigned long long x = key[i], y = key[j];
+        if (x > y) { key[i] = y; key[j] = x; const uint32_t u = val[i]; val[i] = val[j]; val[j] = u; }
+      }
     }
-    __syncthreads();
+    sync();
     for (int st = half >> 1; st > 0; st >>= 1) {
-      for (int t = tid; t < (np >> 1); t += nthreads) {
-        const int i = 2 * st * (t / st) + (t % st), j = i + st;
-        if (j < n) { unsigned long long x = a(i), y = a(j); if (x > y) { a(i) = y; a(j) = x; } }
+      for (int q = t; q < (np >> 1); q += NT) {
+        const int i = 2 * st * (q / st) + (q % st), j = i + st;
+        if (j < n) {
+          const unsigned long long x = key[i], y = key[j];
+          if (x > y) { key[i] = y; key[j] = x; const uint32_t u = val[i]; val[i] = val[j]; val[j] = u; }
+        }
+      }
+      sync();
+    }
+  }
+}
+
+#define NM_CELL_WAVE 512   // cells up to this size are sorted by ONE wave (four cells per workgroup at a time, no block barriers)
+
+// Rank sort of a cell held in LDS by NT cooperating threads: every element counts the keys smaller than its own (keys are
+// unique: they end in the Gaussian index) - n broadcast reads per thread, no barrier, no data-dependent control flow - and
+// goes straight to its final place in global memory.  O(n^2) compares, but for the few hundred pairs of a typical cell this
+// is several times faster than a sorting network, whose ~log^2 n dependent LDS round trips dominate.
+template <int NT, int PER>
+__device__ __forceinline__ void rank_sort_to_global(const unsigned long long* s_key, const uint32_t* s_val, int n, int t,
+                                                    unsigned long long* __restrict__ gkey, uint32_t* __restrict__ gval) {
+  unsigned long long mine[PER];
+  int rank[PER];
+#pragma unroll
+  for (int e = 0; e < PER; ++e) { const int i = t + NT * e; mine[e] = i < n ? s_key[i] : ~0ull; rank[e] = 0; }
+  for (int j = 0; j < n; ++j) {
+    const unsigned long long kj = s_key[j];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) rank[e] += kj < mine[e] ? 1 : 0;
+  }
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {
+    const int i = t + NT * e;
+    if (i < n) { gkey[rank[e]] = mine[e]; gval[rank[e]] = s_val[i]; }
+  }
+}
+
+// A workgroup takes four consecutive cells.  All four small: each wave sorts its own in a private LDS slice.  Otherwise the
+// four are sorted one after the other by the whole workgroup (rank sort in LDS up to NM_CELL_LDS pairs; beyond that a bitonic
+// network directly on global memory).
+__global__ void __launch_bounds__(256) k_cell_sort(int ncell, const uint32_t* __restrict__ off, unsigned long long* __restrict__ keys,
+                                                   uint32_t* __restrict__ vals, long long cap, const uint32_t* __restrict__ hdr) {
+  if (hdr[3]) return;    // overflow: the lists are incomplete (some slots never written) and are not used
+  __shared__ unsigned long long s_key[NM_CELL_LDS];
+  __shared__ uint32_t s_val[NM_CELL_LDS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c0 = blockIdx.x * 4; c0 < ncell; c0 += gridDim.x * 4) {
+    long long lo[4];
+    int n[4], biggest = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = min(c0 + q, ncell - 1);
+      lo[q] = off[c];
+      n[q] = (c0 + q < ncell) ? (int)max(0ll, min((long long)off[c + 1], cap) - lo[q]) : 0;
+      biggest = max(biggest, n[q]);
+    }
+    if (biggest < 2) continue;
+    if (biggest <= NM_CELL_WAVE) {
+      unsigned long long* wk = s_key + wave * NM_CELL_WAVE;
+      uint32_t* wv = s_val + wave * NM_CELL_WAVE;
+      int m = 0;
+      long long l = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (q == wave) { m = n[q]; l = lo[q]; }
+      if (m > 1) {
+        for (int i = lane; i < m; i += 64) { wk[i] = keys[l + i]; wv[i] = vals[l + i]; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (m <= 128) rank_sort_to_global<64, 2>(wk, wv, m, lane, keys + l, vals + l);
+        else if (m <= 256) rank_sort_to_global<64, 4>(wk, wv, m, lane, keys + l, vals + l);
+        else rank_sort_to_global<64, 8>(wk, wv, m, lane, keys + l, vals + l);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else {
+      auto bsync = [] { __syncthreads(); };
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = n[q];
+        if (m < 2) continue;        // workgroup-uniform
+        __syncthreads();
+        if (m <= NM_CELL_LDS) {
+          for (int i = tid; i < m; i += 256) { s_key[i] = keys[lo[q] + i]; s_val[i] = vals[lo[q] + i]; }
+          __syncthreads();
+          rank_sort_to_global<256, 8>(s_key, s_val, m, tid, keys + lo[q], vals + lo[q]);
+        } else {   // thousands of Gaussians of one bin in one depth slab: a sorting network on global memory
+          bitonic_sort_kv<256>((volatile unsigned long long*)(keys + lo[q]), (volatile uint32_t*)(vals + lo[q]), m, tid, bsync);
+        }
       }
       __syncthreads();
     }
   }
 }
-struct LdsAcc { unsigned long long* p; __device__ __forceinline__ unsigned long long& operator()(int i) const { return p[i]; } };
-struct GlobalAcc { volatile unsigned long long* p; __device__ __forceinline__ volatile unsigned long long& operator()(int i) const { return p[i]; } };
 
-__global__ void __launch_bounds__(256) k_cell_sort(int ncell, const uint32_t* __restrict__ off, unsigned long long* __restrict__ pairs,
-                                                   long long cap) {
-  __shared__ unsigned long long s_key[NM_CELL_LDS];
-  const int tid = threadIdx.x;
-  for (int c = blockIdx.x; c < ncell; c += gridDim.x) {
-    const long long lo = off[c];
-    const long long hi = min((long long)off[c + 1], cap);
-    const int n = (int)max(0ll, hi - lo);
-    if (n < 2) continue;
-    if (n <= NM_CELL_LDS) {
-      for (int i = tid; i < n; i += 256) s_key[i] = pairs[lo + i];
-      __syncthreads();
-      bitonic_sort(LdsAcc{s_key}, n, tid, 256);
-      for (int i = tid; i < n; i += 256) pairs[lo + i] = s_key[i];
-      __syncthreads();
-    } else {   // a cell too big for LDS (thousands of Gaussians of one bin in one depth slab): same network in global memory
-      __syncthreads();
-      bitonic_sort(GlobalAcc{pairs + lo}, n, tid, 256);
-    }
-  }
-}
-
+#define NM_SCAN 4096   // candidates a tile examines per round (16 per thread: four 16-byte loads of their tile masks)
 // front-to-back composite of one 16x16 tile (upstream renderCUDA forward) over the depth-sorted list of the tile's bin
 __global__ void __launch_bounds__(NM_TPB) k_render(RK k, int nbx, const uint32_t* __restrict__ off,
-                                                   const unsigned long long* __restrict__ pairs, long long cap,
-                                                   const int* __restrict__ radii, const float2* __restrict__ xy,
-                                                   const float* __restrict__ rgb, const float4* __restrict__ conop,
-                                                   float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                   float* __restrict__ out) {
+                                                   const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                   long long cap, const uint32_t* __restrict__ hdr, const float2* __restrict__ xy,
+                                                   const float* __restrict__ rgb,
+                                                   const float4* __restrict__ conop, float* __restrict__ final_T,
+                                                   uint32_t* __restrict__ n_contrib, float* __restrict__ out) {
+  __shared__ uint32_t s_hit[NM_SCAN];      // 1-based list positions of the candidates that touch this tile, in list order
   __shared__ float2 s_xy[NM_TPB];
   __shared__ float4 s_co[NM_TPB];
   __shared__ float s_rgb[NM_TPB * 3];
-  __shared__ uint32_t s_pos[NM_TPB];
   __shared__ int s_wcnt[4];
   const int tile_x = blockIdx.x, tile_y = blockIdx.y + k.ty0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -435,56 +603,68 @@ __global__ void __launch_bounds__(NM_TPB) k_render(RK k, int nbx, const uint32_t
   const bool inside = px < k.W && py < k.H;
   const float fxp = (float)px, fyp = (float)py;
   const int bin = (tile_y / NM_BT) * nbx + tile_x / NM_BT;
+  const uint32_t bit = 1u << ((tile_y % NM_BT) * NM_BT + tile_x % NM_BT);
   const long long lo = off[bin * NM_NS];
-  const long long hi = min((long long)off[(bin + 1) * NM_NS], cap);
+  // capacity overflow (hdr[3]): slots of the lists were never written - render the background only, the caller re-runs
+  const long long hi = hdr[3] ? lo : min((long long)off[(bin + 1) * NM_NS], cap);
   bool done = !inside;
   float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
   uint32_t last = 0;
-  for (long long base = lo; base < hi; base += NM_TPB) {
+  for (long long base = lo & ~3ll; base < hi; base += NM_SCAN) {     // rounds start 16-byte aligned; positions < lo are masked out
     if (__syncthreads_count(done) == NM_TPB) break;
-    // ---- 256 candidates: which of them can reach a pixel of this tile?
-    const long long c = base + tid;
-    bool hit = false;
-    uint32_t id = 0;
-    float2 p = make_float2(0.f, 0.f);
-    float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < hi) {
-      id = (uint32_t)pairs[c];
-      p = xy[id];
-      co = conop[id];
-      int x0, y0, x1, y1;
-      get_rect(k, p.x, p.y, radii[id], x0, y0, x1, y1, k.ty0, k.ty1);
-      hit = tile_x >= x0 && tile_x < x1 && tile_y >= y0 && tile_y < y1 && tile_contributes(make_tile_cull(p.x, p.y, co), tile_x, tile_y);
-    }
-    const unsigned long long m = __ballot(hit);
-    if (lane == 0) s_wcnt[wave] = __popcll(m);
-    __syncthreads();
-    int before = 0, nb = 0;
+    // ---- NM_SCAN candidates: which of them touch this tile (bit of their tile mask)?
+    const long long c = base + 16 * tid;
+    uint32_t m16 = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { const int n = s_wcnt[w]; before += w < wave ? n : 0; nb += n; }
-    if (hit) {
-      const int slot = before + __popcll(m & ((1ull << lane) - 1ull));
-      s_xy[slot] = p;
-      s_co[slot] = co;
-      s_rgb[3 * slot] = rgb[3 * id]; s_rgb[3 * slot + 1] = rgb[3 * id + 1]; s_rgb[3 * slot + 2] = rgb[3 * id + 2];
-      s_pos[slot] = (uint32_t)(c - lo) + 1u;     // 1-based position in the bin's list
+    for (int v4 = 0; v4 < 4; ++v4) {
+      const long long p = c + 4 * v4;
+      if (p < hi) {                      // the array is padded to 256 bytes: a 16-byte load at an aligned p < cap stays inside
+        const uint4 v = *(const uint4*)(vals + p);
+        const uint32_t b4 = ((v.x & bit) ? 1u : 0u) | ((v.y & bit) ? 2u : 0u) | ((v.z & bit) ? 4u : 0u) | ((v.w & bit) ? 8u : 0u);
+        uint32_t ok = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ok |= (p + q >= lo && p + q < hi) ? (1u << q) : 0u;
+        m16 |= (b4 & ok) << (4 * v4);
+      }
     }
+    const int mine = __popc(m16);
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
+    if (lane == 63) s_wcnt[wave] = incl;
     __syncthreads();
-    // ---- composite the survivors, in list (= depth) order
-    for (int j = 0; !done && j < nb; ++j) {
-      float2 q = s_xy[j];
-      float4 cj = s_co[j];
-      float dx = q.x - fxp, dy = q.y - fyp;
-      float power = -0.5f * (cj.x * dx * dx + cj.z * dy * dy) - cj.y * dx * dy;
-      if (power > 0.f) continue;
-      float alpha = fminf(0.99f, cj.w * __expf(power));
-      if (alpha < 1.0f / 255.0f) continue;
-      float test_T = T * (1.f - alpha);
-      if (test_T < 0.0001f) { done = true; continue; }
-      float w = alpha * T;
-      C0 += s_rgb[3 * j] * w; C1 += s_rgb[3 * j + 1] * w; C2 += s_rgb[3 * j + 2] * w;
-      T = test_T;
-      last = s_pos[j];
+    int before = 0, nh = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const int n = s_wcnt[w]; before += w < wave ? n : 0; nh += n; }
+    int slot = before + incl - mine;
+    for (uint32_t mm = m16; mm; mm &= mm - 1u) s_hit[slot++] = (uint32_t)(c + (__ffs((int)mm) - 1) - lo) + 1u;
+    __syncthreads();
+    // ---- composite the survivors, in list (= depth) order, NM_TPB at a time
+    for (int h0 = 0; h0 < nh; h0 += NM_TPB) {
+      if (h0 > 0 && __syncthreads_count(done) == NM_TPB) break;
+      const int nb = min(NM_TPB, nh - h0);
+      if (tid < nb) {
+        const uint32_t id = (uint32_t)keys[lo + s_hit[h0 + tid] - 1];
+        s_xy[tid] = xy[id];
+        s_co[tid] = conop[id];
+        s_rgb[3 * tid] = rgb[3 * id]; s_rgb[3 * tid + 1] = rgb[3 * id + 1]; s_rgb[3 * tid + 2] = rgb[3 * id + 2];
+      }
+      __syncthreads();
+      for (int j = 0; !done && j < nb; ++j) {
+        float2 q = s_xy[j];
+        float4 cj = s_co[j];
+        float dx = q.x - fxp, dy = q.y - fyp;
+        float power = -0.5f * (cj.x * dx * dx + cj.z * dy * dy) - cj.y * dx * dy;
+        if (power > 0.f) continue;
+        float alpha = fminf(0.99f, cj.w * __expf(power));
+        if (alpha < 1.0f / 255.0f) continue;
+        float test_T = T * (1.f - alpha);
+        if (test_T < 0.0001f) { done = true; continue; }
+        float w = alpha * T;
+        C0 += s_rgb[3 * j] * w; C1 += s_rgb[3 * j + 1] * w; C2 += s_rgb[3 * j + 2] * w;
+        T = test_T;
+        last = s_hit[h0 + j];
+      }
     }
   }
   if (inside) {
@@ -564,20 +744,22 @@ __device__ __forceinline__ float wave_sum_dpp(float x) {
 #ifndef NM_RB_BATCH
 #define NM_RB_BATCH 128
 #endif
+#define NM_RB_SCAN 2048
 #define NM_NG 9  // per-Gaussian reduced quantities: ndc-mean(2) conic(3) colour(3) | opacity(1)
 // slot order inside an accumulator row: [0..7] = values of wave_fold8 order, [8] = opacity
 //   v[0]=d/dndc.x v[1]=d/dndc.y v[2]=d/dconic.x v[3]=d/dconic.y v[4]=d/dconic.z v[5..7]=d/drgb
 
 template <bool WITH_OPACITY>
 __global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, int nbx, const uint32_t* __restrict__ off,
-                                                       const unsigned long long* __restrict__ pairs, const int* __restrict__ radii,
+                                                       const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                        const float2* __restrict__ xy, const float* __restrict__ rgb,
                                                        const float4* __restrict__ conop, const float* __restrict__ final_T,
                                                        const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
                                                        float* __restrict__ acc /* (K, 9) */) {
-  // candidates of the bin's list are tested NM_RB_BATCH at a time (back to front, starting at the tile's last contributor);
-  // the survivors are staged in LDS.  The four per-wave tables are what limits the number of resident tiles (LDS), and
-  // this loop lives on latency hiding - 128 per batch = 23 KB per tile = 6 waves per SIMD instead of 3
+  // the bin's list is examined NM_RB_SCAN candidates at a time, back to front from the tile's last contributor (tile-mask bit
+  // test); the survivors are staged in LDS NM_RB_BATCH at a time.  The four per-wave tables are what limits the number of
+  // resident tiles (LDS), and this loop lives on latency hiding - 128 per batch = 25 KB per tile = 6 waves per SIMD
+  __shared__ uint32_t s_hit[NM_RB_SCAN];
   __shared__ uint32_t s_id[NM_RB_BATCH];
   __shared__ uint32_t s_pos[NM_RB_BATCH];
   __shared__ float2 s_xy[NM_RB_BATCH];
@@ -591,6 +773,7 @@ __global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, int nbx, const uint
   const bool inside = px < k.W && py < k.H;
   const float fxp = (float)px, fyp = (float)py;
   const int bin = (tile_y / NM_BT) * nbx + tile_x / NM_BT;
+  const uint32_t bit = 1u << ((tile_y % NM_BT) * NM_BT + tile_x % NM_BT);
   const long long lo = off[bin * NM_NS];
   const size_t pix = (size_t)py * k.W + px, hw = (size_t)k.H * k.W;
   const float T_final = inside ? final_T[pix] : 0.f;
@@ -614,35 +797,40 @@ __global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, int nbx, const uint
   if (lane == 0) s_last[wave] = wave_last;
   __syncthreads();
   const uint32_t tile_last = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
-  for (long long top = lo + (long long)tile_last; top > lo; top -= NM_RB_BATCH) {
+  for (long long top = lo + (long long)tile_last; top > lo; top -= NM_RB_SCAN) {
     __syncthreads();
-    // ---- candidates top-1, top-2, ... (back to front): which of them can reach a pixel of this tile?
-    const long long c = top - 1 - tid;
-    bool hit = false;
-    uint32_t id = 0;
-    float2 cp = make_float2(0.f, 0.f);
-    float4 cc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < NM_RB_BATCH && c >= lo) {
-      id = (uint32_t)pairs[c];
-      cp = xy[id];
-      cc = conop[id];
-      int x0, y0, x1, y1;
-      get_rect(k, cp.x, cp.y, radii[id], x0, y0, x1, y1, k.ty0, k.ty1);
-      hit = tile_x >= x0 && tile_x < x1 && tile_y >= y0 && tile_y < y1 && tile_contributes(make_tile_cull(cp.x, cp.y, cc), tile_x, tile_y);
-    }
-    const unsigned long long hm = __ballot(hit);
-    if (lane == 0) s_wcnt[wave] = __popcll(hm);
-    __syncthreads();
-    int before = 0, nb = 0;
+    // ---- candidates top-1, top-2, ... (back to front): which of them touch this tile?  Thread t < 128 looks at four.
+    const long long c = top - 1 - 16 * tid;     // this thread's candidates: c, c-1, ..., c-15
+    uint32_t m16 = 0;
+    if (tid < NM_RB_SCAN / 16) {
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { const int n = s_wcnt[w]; before += w < wave ? n : 0; nb += n; }
-    if (hit) {
-      const int slot = before + __popcll(hm & ((1ull << lane) - 1ull));
-      s_id[slot] = id;
-      s_pos[slot] = (uint32_t)(c - lo) + 1u;
-      s_xy[slot] = cp;
-      s_co[slot] = cc;
-      s_rgb[3 * slot] = rgb[3 * id]; s_rgb[3 * slot + 1] = rgb[3 * id + 1]; s_rgb[3 * slot + 2] = rgb[3 * id + 2];
+      for (int q = 0; q < 16; ++q)
+        if (c - q >= lo && (vals[c - q] & bit)) m16 |= 1u << q;
+    }
+    const int mine = __popc(m16);
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
+    if (lane == 63) s_wcnt[wave] = incl;
+    __syncthreads();
+    int before = 0, nh = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const int n = s_wcnt[w]; before += w < wave ? n : 0; nh += n; }
+    {
+      int hslot = before + incl - mine;
+      for (uint32_t mm = m16; mm; mm &= mm - 1u) s_hit[hslot++] = (uint32_t)(c - (__ffs((int)mm) - 1) - lo) + 1u;   // 1-based, descending
+    }
+    for (int h0 = 0; h0 < nh; h0 += NM_RB_BATCH) {
+    __syncthreads();
+    const int nb = min(NM_RB_BATCH, nh - h0);
+    if (tid < nb) {
+      const uint32_t pos = s_hit[h0 + tid];
+      const uint32_t id = (uint32_t)keys[lo + pos - 1];
+      s_id[tid] = id;
+      s_pos[tid] = pos;
+      s_xy[tid] = xy[id];
+      s_co[tid] = conop[id];
+      s_rgb[3 * tid] = rgb[3 * id]; s_rgb[3 * tid + 1] = rgb[3 * id + 1]; s_rgb[3 * tid + 2] = rgb[3 * id + 2];
     }
     __syncthreads();
     for (int j = 0; j < nb; ++j) {
@@ -712,6 +900,7 @@ __global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, int nbx, const uint
     }
     __syncthreads();
     for (int i = lane; i < nb * NM_NG; i += 64) my_acc[i] = 0.f;
+    }
   }
 }
 
@@ -880,32 +1069,41 @@ extern "C" int nm_raster_forward(const nm_raster_cfg* cfg, int32_t K, int32_t m,
   State t = carve_state(state, k.W, k.H, K, cap_pairs);
   if (state_bytes < t.total) { nm_set_error("raster state buffer too small: need %zu got %zu", t.total, state_bytes); return NM_ERR_WORKSPACE; }
   hipStream_t s = (hipStream_t)stream;
-  NM_LAUNCH(k_raster_init, dim3(nm_div_up(t.ncell + 1, 256)), dim3(256), 0, s, t.hdr, t.cnt, t.ncell);
-  NM_LAUNCH_CHECK();
+  const int nrange = nm_div_up(K, 256);
+  NM_HIP_CHECK(hipMemsetAsync(t.hdr, 0, 256, s));
+  NM_HIP_CHECK(hipMemsetAsync(t.pad, 0, (size_t)t.ncell * NM_PAD * sizeof(uint32_t), s));
   if (K > 0) {
-    NM_LAUNCH(k_preprocess, dim3(nm_div_up(K, 256)), dim3(256), 0, s, k, K, means3D, shs, colors_precomp, opacities, cov3D, radii,
-              t.xy, t.depth, t.conop, t.rgb, t.clamped, t.rad, t.hdr);
+    NM_LAUNCH(k_preprocess, dim3(nrange), dim3(256), 0, s, k, K, means3D, shs, colors_precomp, opacities, cov3D, radii,
+              t.xy, t.depth, t.conop, t.rgb, t.clamped, t.rad, t.zrange);
     NM_LAUNCH_CHECK();
-    NM_LAUNCH(k_bin<false>, dim3(nm_div_up(K, 256)), dim3(256), 0, s, k, K, t.nbx, (const int*)t.rad, t.xy, t.depth, t.hdr, t.cnt,
-              t.off, t.pairs, (long long)cap_pairs);
+    NM_LAUNCH(k_bin_count, dim3(nrange), dim3(256), 0, s, k, K, t.nbx, (const int*)t.rad, t.xy, t.depth, t.conop, t.zrange, nrange,
+              t.pad, t.log, t.hdr, (long long)cap_pairs);
     NM_LAUNCH_CHECK();
   }
-  NM_LAUNCH(k_bin_scan, dim3(1), dim3(1024), 0, s, t.ncell, t.cnt, t.off, t.hdr, (long long)cap_pairs);
+  const int nbin = t.nbx * t.nby;
+  NM_LAUNCH(k_bin_compact, dim3(nbin), dim3(NM_NS), 0, s, nbin, (const uint32_t*)t.pad, t.cnt, t.bin_total, t.hdr);
+  NM_LAUNCH_CHECK();
+  NM_LAUNCH(k_bin_scan, dim3(1), dim3(1024), 0, s, nbin, (const uint32_t*)t.bin_total, t.bin_off, t.hdr, (long long)cap_pairs);
+  NM_LAUNCH_CHECK();
+  NM_LAUNCH(k_cell_offsets, dim3(nbin), dim3(NM_NS), 0, s, nbin, (const uint32_t*)t.cnt, (const uint32_t*)t.bin_off, t.off);
   NM_LAUNCH_CHECK();
   if (K > 0) {
-    NM_LAUNCH(k_bin<true>, dim3(nm_div_up(K, 256)), dim3(256), 0, s, k, K, t.nbx, (const int*)t.rad, t.xy, t.depth, t.hdr, t.cnt,
-              t.off, t.pairs, (long long)cap_pairs);
+    NM_LAUNCH(k_bin_fill, dim3(min(2048, nm_div_up((int)min((int64_t)cap_pairs, (int64_t)K * 64), 256) + 1)), dim3(256), 0, s,
+              (const uint32_t*)t.hdr, (const PairLog*)t.log, (const uint32_t*)t.off, (const float*)t.depth, t.keys, t.vals,
+              (long long)cap_pairs);
     NM_LAUNCH_CHECK();
-    NM_LAUNCH(k_cell_sort, dim3(min(t.ncell, 4096)), dim3(256), 0, s, t.ncell, t.off, t.pairs, (long long)cap_pairs);
+    NM_LAUNCH(k_cell_sort, dim3(min(nm_div_up(t.ncell, 4), 8192)), dim3(256), 0, s, t.ncell, (const uint32_t*)t.off, t.keys, t.vals,
+              (long long)cap_pairs, (const uint32_t*)t.hdr);
     NM_LAUNCH_CHECK();
   }
-  NM_LAUNCH(k_render, dim3(k.gx, k.ty1 - k.ty0), dim3(NM_TPB), 0, s, k, t.nbx, t.off, t.pairs, (long long)cap_pairs, (const int*)t.rad,
-            t.xy, t.rgb, t.conop, t.final_T, t.n_contrib, out_color);
+  NM_LAUNCH(k_render, dim3(k.gx, k.ty1 - k.ty0), dim3(NM_TPB), 0, s, k, t.nbx, (const uint32_t*)t.off, (const unsigned long long*)t.keys,
+            (const uint32_t*)t.vals, (long long)cap_pairs, (const uint32_t*)t.hdr, t.xy, t.rgb, t.conop, t.final_T, t.n_contrib, out_color);
   NM_LAUNCH_CHECK();
   if (status_host) {
-    // hdr[2], hdr[3] are 32-bit: widen on the host side of the copy (two 4-byte copies into the low halves; the caller zeroes the buffer)
+    // hdr[2], hdr[3] are 32-bit: widen on the host side of the copy (4-byte copies into the low halves; the caller zeroes the buffer)
     NM_HIP_CHECK(hipMemcpyAsync(status_host, t.hdr + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     NM_HIP_CHECK(hipMemcpyAsync(status_host + 1, t.hdr + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (getenv("NM_RASTER_DEBUG")) NM_HIP_CHECK(hipMemcpyAsync((char*)(status_host + 1) + 4, t.hdr + 6, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   }
   return NM_OK;
 }
@@ -933,6 +1131,20 @@ extern "C" int nm_raster_count_pairs(const nm_raster_cfg* cfg, int32_t K, void* 
   return NM_OK;
 }
 
+// debugging aid: copies the per-cell pair counts of `state` to host memory (ncell_out receives the number of cells)
+extern "C" int nm_debug_raster_cells(const nm_raster_cfg* cfg, int32_t K, void* state, int64_t cap_pairs, uint32_t* counts_host,
+                                     int32_t max_cells, int32_t* ncell_out, void* stream) {
+  RK k;
+  int rc = make_rk(cfg, 0, k);
+  if (rc) return rc;
+  State t = carve_state(state, k.W, k.H, K, cap_pairs);
+  *ncell_out = t.ncell;
+  NM_HIP_CHECK(hipMemcpyAsync(counts_host, t.cnt, sizeof(uint32_t) * (size_t)(t.ncell < max_cells ? t.ncell : max_cells), hipMemcpyDeviceToHost,
+                              (hipStream_t)stream));
+  NM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  return NM_OK;
+}
+
 extern "C" size_t nm_raster_bwd_workspace(int32_t K) { return al256((size_t)(K > 0 ? K : 1) * NM_NG * sizeof(float)); }
 
 extern "C" int nm_raster_backward(const nm_raster_cfg* cfg, int32_t K, int32_t m, const float* means3D, const float* shs,
@@ -953,11 +1165,11 @@ extern "C" int nm_raster_backward(const nm_raster_cfg* cfg, int32_t K, int32_t m
   float* acc = (float*)workspace;
   NM_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)K * NM_NG * sizeof(float), s));
   if (dL_dopacity)
-    NM_LAUNCH(k_render_bwd<true>, dim3(k.gx, k.ty1 - k.ty0), dim3(NM_TPB), 0, s, k, t.nbx, t.off, t.pairs, (const int*)t.rad, t.xy,
-              t.rgb, t.conop, t.final_T, t.n_contrib, dL_dcolor, acc);
+    NM_LAUNCH(k_render_bwd<true>, dim3(k.gx, k.ty1 - k.ty0), dim3(NM_TPB), 0, s, k, t.nbx, (const uint32_t*)t.off,
+              (const unsigned long long*)t.keys, (const uint32_t*)t.vals, t.xy, t.rgb, t.conop, t.final_T, t.n_contrib, dL_dcolor, acc);
   else
-    NM_LAUNCH(k_render_bwd<false>, dim3(k.gx, k.ty1 - k.ty0), dim3(NM_TPB), 0, s, k, t.nbx, t.off, t.pairs, (const int*)t.rad, t.xy,
-              t.rgb, t.conop, t.final_T, t.n_contrib, dL_dcolor, acc);
+    NM_LAUNCH(k_render_bwd<false>, dim3(k.gx, k.ty1 - k.ty0), dim3(NM_TPB), 0, s, k, t.nbx, (const uint32_t*)t.off,
+              (const unsigned long long*)t.keys, (const uint32_t*)t.vals, t.xy, t.rgb, t.conop, t.final_T, t.n_contrib, dL_dcolor, acc);
   NM_LAUNCH_CHECK();
   NM_LAUNCH(k_preprocess_bwd, dim3(nm_div_up(K, 256)), dim3(256), 0, s, k, K, means3D, shs, cov3D, (const int*)t.rad, t.clamped, acc,
             dL_dmeans3D, dL_dmeans2D, dL_dcov3D, dL_dopacity, dL_dshs, dL_dcolors, shs ? 1 : 0);
