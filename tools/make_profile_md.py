@@ -44,6 +44,40 @@ with open(f"profiles/{tag}_bench_metric_kernel_stats.md", "w") as f:
     for k in sorted(set(fetch) | set(write)):
         if k.startswith(("torch", "Cijk", "rocprim", "__amd")): continue
         f.write(f"| {k} | {fetch.get(k, 0):.0f} | {write.get(k, 0):.0f} |\n")
+# ---- MFMA / issue counters (one more pass: --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU
+#      SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU)
+mf = {}
+for f in glob.glob(root + "/mfma/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        d = mf.setdefault(k, collections.defaultdict(float))
+        d[r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Counter_Name"] == "SQ_BUSY_CYCLES":
+            d["_n"] += 1
+            d["_ns"] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+mfma_json = {}
+if mf:
+    with open(f"profiles/{tag}_bench_metric_kernel_stats.md", "a") as f:
+        f.write("\n## Matrix-pipe and issue counters (separate pass: `--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 "
+                "SQ_INSTS_VALU SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU`), per dispatch\n\n")
+        f.write("MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES / (dispatch duration x ~2.4 GHz x 1024 SIMDs... the counter sums the busy cycles of "
+                "all SIMDs): reported here against the kernel's own duration x 1024 SIMDs at the clock implied by SQ_BUSY_CYCLES.  "
+                "MOPS_F32 x 512 = f32 MFMA flops (one MOPS unit = 512 flop).  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count quad-cycles "
+                "summed over waves.\n\n")
+        f.write("| kernel | dispatches | avg us | MFMA busy cycles | MFMA flops (MOPS x 512) | achieved f32 MFMA TFLOP/s | MFMA busy % of SIMD-cycles | "
+                "VALU insts | wait-LDS / wave-cycles | wait-inst-any / wave-cycles | active-VALU / wave-cycles |\n|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|\n")
+        for k, d in sorted(mf.items(), key=lambda kv: -kv[1]["_ns"]):
+            if k.startswith(("torch", "Cijk", "rocprim", "__amd")) or d["_n"] == 0:
+                continue
+            n = d["_n"]; us = d["_ns"] / n / 1e3
+            busy = d["SQ_VALU_MFMA_BUSY_CYCLES"] / n
+            flops = d["SQ_INSTS_VALU_MFMA_MOPS_F32"] / n * 512.0
+            simd_cycles = us * 1e-6 * 2.4e9 * 1024.0
+            wc = max(d["SQ_WAVE_CYCLES"], 1.0)
+            f.write(f"| {k} | {int(n)} | {us:.1f} | {busy:.3g} | {flops:.3g} | {flops / (us * 1e-6) / 1e12:.1f} | {100 * busy / simd_cycles:.1f} | "
+                    f"{d['SQ_INSTS_VALU'] / n:.3g} | {d['SQ_WAIT_INST_LDS'] / wc:.3f} | {d['SQ_WAIT_INST_ANY'] / wc:.3f} | {d['SQ_ACTIVE_INST_VALU'] / wc:.3f} |\n")
+            mfma_json[k.split("<")[0]] = {"avg_us": round(us, 1), "mfma_busy_cycles": busy, "mfma_flops": flops,
+                                          "mfma_busy_pct_of_simd_cycles": round(100 * busy / simd_cycles, 2)}
 import json
 traffic = {}
 for k in sorted(set(fetch) | set(write)):
@@ -58,5 +92,5 @@ for base, t in traffic.items():
     t["hbm_bytes_per_launch"] = int((2.0 * t["fetch_kib"] + t["write_kib"]) * 1024)
 json.dump({"source": f"profiles/{tag}_bench_metric_kernel_stats.md (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)",
            "correction": "bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB counters; FETCH under-reports wide coalesced reads by 2x on gfx950)",
-           "kernels": traffic}, open("profiles/pmc_traffic.json", "w"), indent=1)
+           "kernels": traffic, "mfma": mfma_json}, open("profiles/pmc_traffic.json", "w"), indent=1)
 print(open(f"profiles/{tag}_bench_metric_kernel_stats.md").read())
