@@ -194,10 +194,15 @@ int nm_material_bwd(int32_t n, int32_t kind, float alpha, const float* F, const 
                     const float* gout, float* gF, float* gw0, float* gw1, float* gw2,
                     void* workspace, size_t workspace_bytes, void* stream);
 
-/* Same, with accumulate != 0 adding into gw0/gw1/gw2 instead of overwriting (BPTT over substeps). */
+/* Same with flags: NM_BWD_ACCUMULATE adds into gw0/gw1/gw2 instead of overwriting (BPTT over substeps);
+ * NM_BWD_POLAR_ADJOINT replaces the reference's SVD adjoint - warp's adj_svd3 behind warp/svd.py:41-57, whose denominators
+ * 1/(s_j^2 - s_i^2) are clamped at 1e-6 and which therefore returns ~0 for the rotation path where two singular values
+ * coincide (F = I) - by the exact derivative of the polar rotation.  nm_material_bwd == flags 0 == the reference's gradient. */
+#define NM_BWD_ACCUMULATE 1
+#define NM_BWD_POLAR_ADJOINT 2
 int nm_material_bwd_ex(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w,
                        const float* gout, float* gF, float* gw0, float* gw1, float* gw2,
-                       int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
+                       int32_t flags, void* workspace, size_t workspace_bytes, void* stream);
 
 /* LinearLoRA merge, modules/nclaw/material/loralib.py:209-213: Weff (out,in) = W + scaling * B (out,r) @ A (r,in), and its
  * adjoint gB = scaling * gW A^T, gA = scaling * B^T gW (what autograd derives from loralib.py:216-224). */
@@ -237,7 +242,10 @@ typedef struct nm_rollout_cfg {
   int32_t grid_cache_blocks; /* capacity (in 4x4x4-node blocks) of each substep's grid cache record; 0 = no cache */
   int32_t cache_verified;    /* backward only: the caller has read nm_rollout_cache_status and every record is valid, so the
                               * (early-exit) fallback launches of p2g / grid_op can be left out altogether */
+  int32_t svd_adjoint;       /* backward only: NM_SVD_ADJOINT_REFERENCE (0, clamped like warp's adj_svd3) or NM_SVD_ADJOINT_POLAR */
 } nm_rollout_cfg;
+#define NM_SVD_ADJOINT_REFERENCE 0
+#define NM_SVD_ADJOINT_POLAR 1
 size_t nm_rollout_workspace(int32_t n, int32_t substeps);
 /* bytes of the optional `gridcache` buffer: substeps records of nm_mpm_gridcache_bytes(grid_cache_blocks) */
 size_t nm_rollout_gridcache_bytes(int32_t substeps, int32_t grid_cache_blocks);

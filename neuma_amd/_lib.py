@@ -43,7 +43,7 @@ class nm_lora_layer(C.Structure):
 
 class nm_rollout_cfg(C.Structure):
     _fields_ = [("substeps", C.c_int32), ("plasticity_alpha", C.c_float), ("grid_cache_blocks", C.c_int32),
-                ("cache_verified", C.c_int32)]
+                ("cache_verified", C.c_int32), ("svd_adjoint", C.c_int32)]
 
 
 # name -> (restype, argtypes); kept in one table so tests can check the exports against the header
@@ -112,6 +112,9 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+SVD_ADJOINT = {"reference": 0, "polar": 1}      # NM_SVD_ADJOINT_* / (NM_BWD_POLAR_ADJOINT = 2 for nm_material_bwd_ex)
 
 
 class NeumaHipError(RuntimeError):

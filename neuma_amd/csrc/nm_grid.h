@@ -305,11 +305,11 @@ int nm_mpm_backward_cached(nm_mpm* h, int32_t n, const nm_statics* st, const nm_
 // pro: grid housekeeping performed in the kernel's prologue (NULL = none)
 int nm_material_bwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* wperm,
                            const float* gout, float* gF, float* wpart, int wmode, const float* trial_C, const int* enabled,
-                           float dt, int add_to_gF, const GridPrologue* pro, void* stream);
+                           float dt, int flags /* bit 0: gF += ; bit 1: polar SVD adjoint */, const GridPrologue* pro, void* stream);
 int nm_material_bwd_pair_launch(int32_t n, const float* F_e, const nm_mlp* we, const float* wperm_e, const float* gS, float* gF,
                                 float* wpart_e, int wmode_e, float alpha_p, const float* F_p, const nm_mlp* wp,
                                 const float* wperm_p, float* gFtrial, float* wpart_p, int wmode_p, const float* trial_C,
-                                const int* enabled, float dt, const GridPrologue* pro, void* stream);
+                                const int* enabled, float dt, int polar, const GridPrologue* pro, void* stream);
 int nm_material_fwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* wperm, float* out,
                            const GridPrologue* pro, const G2pFuse* g2p, void* stream);
 // g2p fused into the next constitutive kernel (roll-out forward): fills the descriptor / runs the substep without its g2p

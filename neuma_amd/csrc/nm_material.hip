@@ -481,6 +481,7 @@ struct BwdFuse {
   const int* enabled;
   float dt;
   int add_to_gF;          // gF += result instead of gF = result
+  int polar;              // 0: the reference's SVD adjoint (denominators clamped like warp's adj_svd3); 1: exact polar derivative
 };
 struct BwdLds {
   float P0[16 * 64], P1[64 * 64], P2[16 * 64];
@@ -717,7 +718,12 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
 #pragma unroll
       for (int i = 0; i < 9; ++i) { Rb.m[i] = alpha * gX.m[i]; Fb.m[i] = go.m[i]; }
     }
-    // sigma path + rotation path, both in the singular basis:  U [diag(sbar) + (At - At^T)/(s_i + s_j)] V^T
+    // sigma path + rotation path, both in the singular basis:  U [diag(sbar) + k_rc (At - At^T)_rc] V^T.
+    // R = U V^T only: Ubar = Rbar V, Vbar = Rbar^T U, so U^T Ubar = At and V^T Vbar = At^T, and the general SVD adjoint
+    // (E_ab = 1 / min(s_b^2 - s_a^2, -1e-6) for a < b, as warp's adj_svd3 clamps it) collapses to
+    //   k_ab = (s_b - s_a) E_ab      - the reference's result: equals 1 / (s_a + s_b) away from the clamp and drops to
+    //                                  1e6 (s_a - s_b) -> 0 where two singular values (nearly) coincide, e.g. at F = I;
+    //   k_ab = 1 / (s_a + s_b)       - fz.polar: the exact derivative of the polar rotation (opt-in).
     M3 At = m3_mul(m3_mul_tn(U, Rb), V);
     M3 inner;
 #pragma unroll
@@ -725,9 +731,16 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         if (r == c) { inner.m[4 * r] = zbv[r]; continue; }
-        float den = s[r] + s[c];
-        den = fabsf(den) < 1e-6f ? copysignf(1e-6f, den) : den;
-        inner.m[3 * r + c] = (At.m[3 * r + c] - At.m[3 * c + r]) / den;
+        float kf;
+        if (fz.polar) {
+          float den = s[r] + s[c];
+          den = fabsf(den) < 1e-6f ? copysignf(1e-6f, den) : den;
+          kf = 1.f / den;
+        } else {
+          const int a = r < c ? r : c, b = r < c ? c : r;
+          kf = (s[b] - s[a]) / fminf(s[b] * s[b] - s[a] * s[a], -1e-6f);
+        }
+        inner.m[3 * r + c] = (At.m[3 * r + c] - At.m[3 * c + r]) * kf;
       }
     M3 t = m3_mul_nt(m3_mul(U, inner), V);
     // G = F^T F:  F (Gbar + Gbar^T) ; det:  zbar12 * cof(F)
@@ -855,12 +868,12 @@ static int bwd_attr_once() {
   return NM_OK;
 }
 static BwdArgs bwd_args(int32_t n, int q, float alpha, const float* F, const nm_mlp* w, const float* wperm, const float* gout,
-                        float* gF, float* wpart, int wmode, const float* trial_C, const int* enabled, float dt, int add_to_gF) {
+                        float* gF, float* wpart, int wmode, const float* trial_C, const int* enabled, float dt, int flags) {
   BwdArgs a;
   a.n = n; a.q = q; a.alpha = alpha; a.F = F;
   a.w0 = w ? w->w0 : nullptr; a.w1 = w ? w->w1 : nullptr; a.w2 = w ? w->w2 : nullptr;
   a.wperm = wperm; a.gout = gout; a.gF = gF; a.wpart = wpart; a.want_w = wmode;
-  a.fz.trial_C = trial_C; a.fz.enabled = enabled; a.fz.dt = dt; a.fz.add_to_gF = add_to_gF;
+  a.fz.trial_C = trial_C; a.fz.enabled = enabled; a.fz.dt = dt; a.fz.add_to_gF = flags & 1; a.fz.polar = (flags >> 1) & 1;
   return a;
 }
 
@@ -890,7 +903,7 @@ int nm_material_bwd_launch(int32_t n, int32_t kind, float alpha, const float* F,
 int nm_material_bwd_pair_launch(int32_t n, const float* F_e, const nm_mlp* we, const float* wperm_e, const float* gS, float* gF,
                                 float* wpart_e, int wmode_e, float alpha_p, const float* F_p, const nm_mlp* wp,
                                 const float* wperm_p, float* gFtrial, float* wpart_p, int wmode_p, const float* trial_C,
-                                const int* enabled, float dt, const GridPrologue* pro, void* stream) {
+                                const int* enabled, float dt, int polar, const GridPrologue* pro, void* stream) {
   GridPrologue gp;
   if (pro) gp = *pro; else { memset(&gp, 0, sizeof(gp)); }
   hipStream_t s = (hipStream_t)stream;
@@ -900,8 +913,8 @@ int nm_material_bwd_pair_launch(int32_t n, const float* F_e, const nm_mlp* we, c
   const int launch = (pro && grid + NM_PRO_WGS <= NM_BWD_GRID) ? grid + NM_PRO_WGS : grid;
   int rc = bwd_attr_once();
   if (rc) return rc;
-  BwdArgs e = bwd_args(n, q, 0.f, F_e, we, wperm_e, gS, gF, wpart_e, wmode_e, nullptr, nullptr, 0.f, 1);
-  BwdArgs p = bwd_args(n, q, alpha_p, F_p, wp, wperm_p, gF, gFtrial, wpart_p, wmode_p, trial_C, enabled, dt, 0);
+  BwdArgs e = bwd_args(n, q, 0.f, F_e, we, wperm_e, gS, gF, wpart_e, wmode_e, nullptr, nullptr, 0.f, 1 | (polar ? 2 : 0));
+  BwdArgs p = bwd_args(n, q, alpha_p, F_p, wp, wperm_p, gF, gFtrial, wpart_p, wmode_p, trial_C, enabled, dt, polar ? 2 : 0);
   NM_LAUNCH(k_material_bwd_pair, dim3(launch), dim3(256), sizeof(BwdLds), s, e, p, gp);
   NM_LAUNCH_CHECK();
   return NM_OK;
@@ -927,10 +940,12 @@ extern "C" int nm_material_bwd(int32_t n, int32_t kind, float alpha, const float
   return nm_material_bwd_ex(n, kind, alpha, F, w, gout, gF, gw0, gw1, gw2, 0, workspace, workspace_bytes, stream);
 }
 
-// accumulate != 0: gw* += sum over particles (used by the fused roll-out, one call per substep)
+// flags: NM_BWD_ACCUMULATE (gw* += sum over particles instead of =), NM_BWD_POLAR_ADJOINT (exact polar derivative instead of
+// the reference's clamped SVD adjoint)
 extern "C" int nm_material_bwd_ex(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* gout,
-                                  float* gF, float* gw0, float* gw1, float* gw2, int32_t accumulate, void* workspace,
+                                  float* gF, float* gw0, float* gw1, float* gw2, int32_t flags, void* workspace,
                                   size_t workspace_bytes, void* stream) {
+  const int accumulate = flags & NM_BWD_ACCUMULATE;
   NM_REQUIRE(n >= 0, "negative n");
   NM_REQUIRE(kind == NM_ELASTICITY || kind == NM_PLASTICITY, "kind must be NM_ELASTICITY or NM_PLASTICITY");
   const int want_w = (gw0 && gw1 && gw2) ? 1 : 0;
@@ -950,8 +965,8 @@ extern "C" int nm_material_bwd_ex(int32_t n, int32_t kind, float alpha, const fl
                  workspace_bytes);
     return NM_ERR_WORKSPACE;
   }
-  int rc = nm_material_bwd_launch(n, kind, alpha, F, w, nullptr, gout, gF, (float*)workspace, want_w, nullptr, nullptr, 0.f, 0,
-                                  nullptr, stream);
+  int rc = nm_material_bwd_launch(n, kind, alpha, F, w, nullptr, gout, gF, (float*)workspace, want_w, nullptr, nullptr, 0.f,
+                                  (flags & NM_BWD_POLAR_ADJOINT) ? 2 : 0, nullptr, stream);
   if (rc) return rc;
   if (want_w) return nm_material_wgrad_reduce((const float*)workspace, n, gw0, gw1, gw2, accumulate, stream);
   return NM_OK;

@@ -140,6 +140,7 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
   rc = nm_material_prepare(wp, w.perm_p, stream);
   if (rc) return rc;
   const bool verified = cfg->cache_verified != 0 && gridcache != nullptr && cfg->grid_cache_blocks > 0;
+  const int polar = cfg->svd_adjoint == NM_SVD_ADJOINT_POLAR ? 1 : 0;
   const float dt = nm_mpm_get_dt(h);
   bool restored = false;   // the grid of the substep about to be visited was restored by the previous launch's prologue
   for (int t = cfg->substeps - 1; t >= 0; --t) {
@@ -150,7 +151,7 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
       // plasticity backward on the trial F of the last substep (recomputed in-kernel from the checkpoints):
       // dL/dF_{t+1} -> dL/dFtrial.  For every earlier substep it rides in the pair launch at the end of this loop body.
       rc = nm_material_bwd_launch(n, NM_PLASTICITY, cfg->plasticity_alpha, cur.F, wp, w.perm_p, gin + 15 * N, w.gFtr, w.part_p, wmode,
-                                  nxt.C, st->enabled, dt, 0, nullptr, stream);
+                                  nxt.C, st->enabled, dt, polar ? 2 : 0, nullptr, stream);
       if (rc) return rc;
     }
     // sim backward (stress of this step was checkpointed by the forward pass).  Verified sweep: from the second substep
@@ -167,8 +168,8 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
     restored = false;
     if (t == 0) {
       // elasticity backward: dL/dstress -> dL/dF (added to the sim's dL/dF)
-      rc = nm_material_bwd_launch(n, NM_ELASTICITY, 0.f, cur.F, we, w.perm_e, w.gS, gc.F, w.part_e, wmode, nullptr, nullptr, 0.f, 1,
-                                  nullptr, stream);
+      rc = nm_material_bwd_launch(n, NM_ELASTICITY, 0.f, cur.F, we, w.perm_e, w.gS, gc.F, w.part_e, wmode, nullptr, nullptr, 0.f,
+                                  1 | (polar ? 2 : 0), nullptr, stream);
       if (rc) return rc;
     } else {
       // elasticity backward of this substep and plasticity backward of the previous one (its input dL/dF_t is exactly
@@ -181,7 +182,7 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
         restored = true;
       }
       rc = nm_material_bwd_pair_launch(n, cur.F, we, w.perm_e, w.gS, gc.F, w.part_e, wmode, cfg->plasticity_alpha, prev.F, wp,
-                                       w.perm_p, w.gFtr, w.part_p, 2, cur.C, st->enabled, dt, verified ? &pro : nullptr, stream);
+                                       w.perm_p, w.gFtr, w.part_p, 2, cur.C, st->enabled, dt, polar, verified ? &pro : nullptr, stream);
       if (rc) return rc;
     }
     gin = gout;

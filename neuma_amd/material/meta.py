@@ -30,7 +30,7 @@ class MaterialFunction(autograd.Function):
     """(F, W0, W1, W2) -> out, through nm_material_fwd / nm_material_bwd."""
 
     @staticmethod
-    def forward(ctx, F: Tensor, w0: Tensor, w1: Tensor, w2: Tensor, kind: int, alpha: float):
+    def forward(ctx, F: Tensor, w0: Tensor, w1: Tensor, w2: Tensor, kind: int, alpha: float, svd_adjoint: int = 0):
         Fc = F.detach().float().contiguous()
         w = [t.detach().float().contiguous() for t in (w0, w1, w2)]
         n = Fc.size(0)
@@ -40,6 +40,7 @@ class MaterialFunction(autograd.Function):
                 "nm_material_fwd")
         ctx.save_for_backward(Fc, *w)
         ctx.kind, ctx.alpha = kind, float(alpha)
+        ctx.flags = 2 if svd_adjoint else 0          # NM_BWD_POLAR_ADJOINT
         ctx.need_w = any(ctx.needs_input_grad[1:4])
         return out
 
@@ -55,13 +56,13 @@ class MaterialFunction(autograd.Function):
             gw0, gw1, gw2 = torch.empty_like(w0), torch.empty_like(w1), torch.empty_like(w2)
             nbytes = int(lib.nm_material_bwd_workspace(n))
             ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=Fc.device)
-            L.check(lib.nm_material_bwd(n, ctx.kind, ctx.alpha, L.ptr(Fc), C.byref(mlp), L.ptr(g), L.ptr(gF), L.ptr(gw0),
-                                        L.ptr(gw1), L.ptr(gw2), L.ptr(ws), nbytes, L.stream_ptr(Fc.device)), "nm_material_bwd")
+            L.check(lib.nm_material_bwd_ex(n, ctx.kind, ctx.alpha, L.ptr(Fc), C.byref(mlp), L.ptr(g), L.ptr(gF), L.ptr(gw0),
+                                           L.ptr(gw1), L.ptr(gw2), ctx.flags, L.ptr(ws), nbytes, L.stream_ptr(Fc.device)), "nm_material_bwd_ex")
         else:
             gw0 = gw1 = gw2 = None
-            L.check(lib.nm_material_bwd(n, ctx.kind, ctx.alpha, L.ptr(Fc), C.byref(mlp), L.ptr(g), L.ptr(gF), None, None, None,
-                                        None, 0, L.stream_ptr(Fc.device)), "nm_material_bwd")
-        return gF, gw0, gw1, gw2, None, None
+            L.check(lib.nm_material_bwd_ex(n, ctx.kind, ctx.alpha, L.ptr(Fc), C.byref(mlp), L.ptr(g), L.ptr(gF), None, None, None,
+                                           ctx.flags, None, 0, L.stream_ptr(Fc.device)), "nm_material_bwd_ex")
+        return gF, gw0, gw1, gw2, None, None, None
 
 
 class MLPBlock(nn.Module):
@@ -126,7 +127,8 @@ class _InvariantFullMeta(nn.Module):
 
     def forward(self, F: Tensor) -> Tensor:
         w0, w1, w2 = self.effective_weights()
-        return MaterialFunction.apply(F, w0, w1, w2, self.KIND, self._alpha())
+        # svd_adjoint (attribute, "reference" by default): see rollout.MPMFusedDiffSim
+        return MaterialFunction.apply(F, w0, w1, w2, self.KIND, self._alpha(), L.SVD_ADJOINT[getattr(self, "svd_adjoint", "reference")])
 
 
 class InvariantFullMetaElasticity(_InvariantFullMeta):

@@ -31,7 +31,7 @@ def _zeros(count: int, device) -> torch.Tensor:
 class _Rollout(autograd.Function):
 
     @staticmethod
-    def forward(ctx, model: MPMModel, statics: MPMStatics, substeps: int, alpha: float, cache_blocks: int,
+    def forward(ctx, model: MPMModel, statics: MPMStatics, substeps: int, alpha: float, cache_blocks: int, svd_adjoint: int,
                 x, v, C_, F, e0, e1, e2, p0, p1, p2):
         lib = L.lib()
         dev = x.device
@@ -48,7 +48,7 @@ class _Rollout(autograd.Function):
         cache_blocks = int(cache_blocks) if any(ctx.needs_input_grad) else 0
         gc_bytes = int(lib.nm_rollout_gridcache_bytes(S, cache_blocks)) if cache_blocks > 0 else 0
         gcache = torch.empty(gc_bytes, dtype=torch.uint8, device=dev) if gc_bytes > 0 else None
-        cfg = L.nm_rollout_cfg(S, float(alpha), cache_blocks if gcache is not None else 0, 0)
+        cfg = L.nm_rollout_cfg(S, float(alpha), cache_blocks if gcache is not None else 0, 0, int(svd_adjoint))
         st = statics.c_struct()
         mle = L.nm_mlp(*[L.ptr(t) for t in we])
         mlp = L.nm_mlp(*[L.ptr(t) for t in wp])
@@ -56,6 +56,7 @@ class _Rollout(autograd.Function):
                                        L.ptr(gcache) if gcache is not None else None, L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
                 "nm_rollout_forward")
         ctx.model, ctx.statics, ctx.S, ctx.alpha, ctx.n = model, statics, S, float(alpha), n
+        ctx.svd_adjoint = int(svd_adjoint)
         ctx.cache_blocks, ctx.gcache = int(cfg.grid_cache_blocks), gcache
         ctx.cache_status = ctx.cache_event = None
         if gcache is not None and _CACHE_STATUS:      # asynchronous read-back of the record headers: by the time the backward pass runs the
@@ -90,7 +91,7 @@ class _Rollout(autograd.Function):
         verified = 0
         if gcache is not None and ctx.cache_event is not None and ctx.cache_event.query():
             verified = int(bool((ctx.cache_status >= 0).all()))
-        cfg = L.nm_rollout_cfg(S, ctx.alpha, ctx.cache_blocks, verified)
+        cfg = L.nm_rollout_cfg(S, ctx.alpha, ctx.cache_blocks, verified, ctx.svd_adjoint)
         st = ctx.statics.c_struct()
         mle = L.nm_mlp(L.ptr(e0), L.ptr(e1), L.ptr(e2))
         mlp = L.nm_mlp(L.ptr(p0), L.ptr(p1), L.ptr(p2))
@@ -100,7 +101,7 @@ class _Rollout(autograd.Function):
         ctx.gcache = None
         torch.nan_to_num_(gfirst, 0.0, 0.0, 0.0)   # interface.py:65-74 at the boundary of the fused node
         a, b = _WSZ[0], _WSZ[0] + _WSZ[1]
-        return (None, None, None, None, None,
+        return (None, None, None, None, None, None,
                 gfirst[:3 * n].view(n, 3), gfirst[3 * n:6 * n].view(n, 3), gfirst[6 * n:15 * n].view(n, 3, 3),
                 gfirst[15 * n:].view(n, 3, 3),
                 gwe[:a].view(64, 13), gwe[a:b].view(64, 64), gwe[b:].view(9, 64),
@@ -116,8 +117,16 @@ class MPMFusedDiffSim(nn.Module):
     own.  An int fixes the capacity in 4x4x4-node blocks; 0 / None disables the cache (the reference's behaviour)."""
 
     def __init__(self, model: MPMModel, elasticity: nn.Module, plasticity: nn.Module, substeps: int, grid_cache="auto",
-                 reorder="auto") -> None:
+                 reorder="auto", svd_adjoint: str = "reference") -> None:
         super().__init__()
+        # svd_adjoint: how dL/dF flows through R = U V^T of the constitutive nets in the reverse sweep.
+        #   "reference" (default)  the reference's gradient: warp's adj_svd3 behind warp/svd.py:41-57, whose 1/(s_j^2 - s_i^2) is
+        #                          clamped at 1e-6 - the rotation path vanishes where singular values coincide (F = I, the state every
+        #                          roll-out starts from) and is the exact polar derivative elsewhere;
+        #   "polar"                the exact derivative U [(A - A^T) / (s_i + s_j)] V^T everywhere (an improvement, not parity).
+        if svd_adjoint not in L.SVD_ADJOINT:
+            raise ValueError(f"svd_adjoint must be one of {sorted(L.SVD_ADJOINT)}")
+        self.svd_adjoint = svd_adjoint
         self.model, self.elasticity, self.plasticity, self.substeps = model, elasticity, plasticity, int(substeps)
         self.grid_cache = grid_cache
         self._cache_blocks = None if grid_cache == "auto" else int(grid_cache or 0)
@@ -153,11 +162,11 @@ class MPMFusedDiffSim(nn.Module):
         if self.order.active(x):
             pm, inv = self.order.perm, self.order.inv
             out = _Rollout.apply(self.model, self.order.statics(statics), self.substeps, self.plasticity.alpha,
-                                 self.grid_cache_blocks(), x[pm], v[pm], C_[pm], F[pm], *e, *p)
+                                 self.grid_cache_blocks(), L.SVD_ADJOINT[self.svd_adjoint], x[pm], v[pm], C_[pm], F[pm], *e, *p)
             out = tuple(o[inv] for o in out)
         else:
-            out = _Rollout.apply(self.model, statics, self.substeps, self.plasticity.alpha, self.grid_cache_blocks(), x, v, C_, F,
-                                 *e, *p)
+            out = _Rollout.apply(self.model, statics, self.substeps, self.plasticity.alpha, self.grid_cache_blocks(),
+                                 L.SVD_ADJOINT[self.svd_adjoint], x, v, C_, F, *e, *p)
         if self._cache_blocks is None:      # first roll-out: size the cache from what the scene touches
             blocks, _ = self.model.grid_stats()
             self._cache_blocks = int(1.5 * blocks) + 64

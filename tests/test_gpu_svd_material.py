@@ -212,3 +212,110 @@ def test_lora_merge_of_a_whole_net_in_one_launch():
         fcs[1].lora_A.mul_(2.0)
     ws2 = net.effective_weights()
     assert ws2 is not ws and abs_max(ws2[0], ws[0]) == 0.0 and abs_max(ws2[1], ws[1]) > 0.0
+
+
+def _operator_chain_grad(F, W, gout, kind, alpha=1e-3):
+    """dL/dF of L = <net(F), gout> composed the way the reference composes it (meta.py:196-221 / 468-489): the stand-alone
+    `SVD` operator - whose adjoint is the clamped one of warp's adj_svd3, pinned against oracle.material.svd3_adjoint in
+    test_svd_* above - followed by plain torch ops (fp64).  At coinciding singular values the factors U, V are only defined
+    up to a rotation of the degenerate plane and the gradient depends on that choice (the sigma - 1 features are fed to
+    different weights), so the comparison must use the SAME factors: the fused kernel and the operator share nm_svd3."""
+    from neuma_amd.svd import SVD
+    F = F.float().to(dev()).requires_grad_(True)
+    U, s, Vh = SVD()(F)
+    Fd, U, s, Vh = F.double(), U.double(), s.double(), Vh.double()
+    R = U @ Vh
+    I = torch.eye(3, dtype=torch.float64, device=dev())
+    z = torch.cat([s - 1.0, (Fd.transpose(1, 2) @ Fd - I).reshape(-1, 9), torch.linalg.det(Fd).unsqueeze(1) - 1.0], 1)
+    h = z
+    for i, w in enumerate(W):
+        h = h @ w.to(dev()).T
+        if i < 2:
+            h = torch.nn.functional.gelu(h)
+    X = h.reshape(-1, 3, 3)
+    X = 0.5 * (X + X.transpose(1, 2))
+    out = R @ X @ Fd.transpose(1, 2) if kind == "e" else Fd + alpha * (R @ X)
+    (out * gout.to(dev())).sum().backward()
+    return F.grad.double().cpu()
+
+
+def test_svd_adjoint_modes_reference_is_the_clamped_adjoint_polar_is_opt_in(golden_dir):
+    """The constitutive backward's default is the reference's gradient INCLUDING its behaviour where singular values
+    coincide - per operator and inside the fused roll-out; "polar" is the opt-in exact derivative.  The clamp
+    (|s_j^2 - s_i^2| < 1e-6) only bites at (fp32-)exact coincidences.  Rows: exactly I; diag(a, a, b) and diag(a, b, b) -
+    two equal singular values with a non-zero network output, where the reference's rotation path drops that pair and
+    the polar derivative does not; generic."""
+    g, E, P = _nets("jelly", golden_dir, lora=False)
+    b = np.load(golden_dir / "base_models.npz")
+    gen = torch.Generator().manual_seed(11)
+    N = 600
+    F = torch.eye(3, dtype=torch.float64).repeat(N, 1, 1)
+    ab = 0.8 + 0.5 * torch.rand(200, 2, generator=gen, dtype=torch.float64)
+    F[200:300] = torch.diag_embed(torch.stack([ab[:100, 0], ab[:100, 0], ab[:100, 1]], 1))
+    F[300:400] = torch.diag_embed(torch.stack([ab[100:, 0], ab[100:, 1], ab[100:, 1]], 1))
+    F[400:] += 0.08 * torch.randn(200, 3, 3, generator=gen, dtype=torch.float64)
+    F = F.float().double()                                     # the values the GPU sees
+    gout = torch.randn(N, 3, 3, generator=gen, dtype=torch.float64)
+    for net, t in ((E, "e"), (P, "p")):
+        W = [torch.tensor(b[f"jelly_{t}_w{i}"]).double() for i in range(3)]
+        ref = _operator_chain_grad(F, W, gout, t)
+        res = {}
+        for mode in ("reference", "polar"):
+            net.svd_adjoint = mode
+            Fg = F.float().to(dev()).requires_grad_(True)
+            (net(Fg) * gout.float().to(dev())).sum().backward()
+            res[mode] = Fg.grad.double().cpu()
+            assert torch.isfinite(res[mode]).all()
+        net.svd_adjoint = "reference"
+        scale = float(ref.abs().max())
+        # default mode == the reference's operator chain: F = I and generic rows to fp32 accuracy ...
+        keep = torch.ones(N, dtype=torch.bool); keep[200:400] = False
+        assert float((res["reference"][keep] - ref[keep]).abs().max()) <= 2e-3 * scale
+        # ... and on rows with two coinciding singular values up to what the clamp itself amplifies: the operator evaluates
+        # E (U^T Ubar - ...) s_j + s_i E (V^T Vbar - ...) with E = -1e6 there, i.e. 1e6 x the fp32 rounding difference of two
+        # quantities that are equal in exact arithmetic (the fused kernel factors (s_j - s_i) out and gets an exact zero)
+        tied_err = float((res["reference"][200:400] - ref[200:400]).abs().max())
+        assert tied_err <= 5e-2 * scale
+        print(f"[{t}] tied rows: |fused reference - operator chain| max {tied_err:.3g}, |polar - reference| max "
+              f"{float((res['polar'][200:400] - res['reference'][200:400]).abs().max()):.3g}, scale {scale:.3g}")
+        # generic rows: the clamp is inactive, the exact polar derivative is the same thing
+        assert float((res["polar"][400:] - ref[400:]).abs().max()) <= 2e-3 * scale
+        # two coinciding singular values: the reference drops that pair's rotation term, the polar derivative does not
+        assert float((res["polar"][200:400] - res["reference"][200:400]).abs().max()) > max(3.0 * tied_err, (1e-2 if t == "e" else 1e-5) * scale)
+
+
+def test_fused_rollout_svd_adjoint_default_matches_per_operator_reference_mode():
+    """The fused roll-out and the per-operator path take the same adjoint mode.  Away from coinciding singular values both
+    modes are the same function, so all four results agree; starting at F = I (free fall keeps every F within ~1e-6 of I:
+    inside the clamp, where the reference's gradient is 1e6 x rounding noise and differs between any two evaluation
+    orders) only the noise-free "polar" mode can be compared between the two paths - "reference" must merely stay finite."""
+    from neuma_amd import synth
+    from neuma_amd.harness import SceneRuntime
+    rt = SceneRuntime(synth.make_scene("tiny", override=dict(S=3)), dev(), fused=True)
+    assert rt.sim_fused.svd_adjoint == "reference"
+    params = rt.parameters()
+    gws = [torch.randn(rt.N, 3, generator=torch.Generator().manual_seed(i)).to(dev()) for i in range(2)]
+    gen = torch.Generator().manual_seed(4)
+    F_generic = (torch.eye(3) + 0.05 * torch.randn(rt.N, 3, 3, generator=gen)).to(dev())
+    for F0, label in ((F_generic, "generic"), (rt.F0, "identity")):
+        res = {}
+        for mode in ("reference", "polar"):
+            rt.sim_fused.svd_adjoint = mode
+            rt.elasticity.svd_adjoint = rt.plasticity.svd_adjoint = mode
+            for fused in (True, False):
+                rt.fused = fused
+                for p in params:
+                    p.grad = None
+                ins = [t.clone().requires_grad_(True) for t in (rt.x0, rt.v0)]
+                out = rt.rollout(ins[0], ins[1], rt.C0, F0)
+                ((out[0] * gws[0]).sum() + (out[1] * gws[1]).sum()).backward()
+                res[(mode, fused)] = [t.grad.clone() for t in ins + params]
+                assert all(torch.isfinite(t).all() for t in res[(mode, fused)])
+        for a, b_ in zip(res[("polar", True)], res[("polar", False)]):
+            assert rel_max(a, b_) < 5e-3, label
+        if label == "generic":
+            for a, b_ in zip(res[("reference", True)], res[("reference", False)]):
+                assert rel_max(a, b_) < 5e-3
+            for a, b_ in zip(res[("reference", True)], res[("polar", True)]):
+                assert rel_max(a, b_) < 5e-3
+    rt.sim_fused.svd_adjoint = "reference"
