@@ -41,6 +41,58 @@ def explain_status(bits: int) -> str:
     return "; ".join(text for bit, text in STATUS_TEXT.items() if bits & bit)
 
 
+def shared_blocks_host(gathered, cap: int, nblocks: int, cap_shared: int, rank: Optional[int] = None):
+    """Host statement of the rule nm_mpm_shared_blocks implements on the device (csrc/nm_shard.hip) - the specification the
+    kernels are tested against, and what the CPU (gloo) tests run the exchange bookkeeping with.
+
+    gathered: int array (world, 1 + cap), row r = [count_r, id_0 .. id_{cap-1}] as all-gathered from the ranks.  An entry
+    counts if it lies inside the rank's (capacity-clipped) count and names a block in [0, nblocks).  A block is SHARED if
+    at least two entries name it; the shared list orders the blocks by the first position at which they appear in the
+    flattened gathered array.  Every rank evaluates the same rule on the same array, hence the same list in the same
+    order everywhere, with no coordination.  Returns (ids (n,), mine (n,) bool: `rank` lists the block itself, bits) with
+    bits = 1 if some rank's count exceeds cap, | 2 if more than cap_shared blocks are shared (the list is then cut)."""
+    import numpy as np
+    g = np.asarray(gathered).reshape(-1, 1 + cap)
+    world = g.shape[0]
+    first, count, lists = {}, {}, []
+    bits = 0
+    for r in range(world):
+        n = int(g[r, 0])
+        if n > cap:
+            bits |= 1
+        ids = [int(b) for b in g[r, 1:1 + min(n, cap)] if 0 <= int(b) < nblocks]
+        lists.append(set(ids))
+        for j, b in enumerate(g[r, 1:1 + min(n, cap)]):
+            b = int(b)
+            if not 0 <= b < nblocks:
+                continue
+            count[b] = count.get(b, 0) + 1
+            first.setdefault(b, r * (1 + cap) + 1 + j)
+    shared = sorted((b for b in count if count[b] >= 2), key=lambda b: first[b])
+    if len(shared) > cap_shared:
+        bits |= 2
+        shared = shared[:cap_shared]
+    mine = [rank is not None and b in lists[rank] for b in shared]
+    return np.asarray(shared, dtype=np.int32), np.asarray(mine, dtype=bool), bits
+
+
+def exchange_blocks_host(values, shared_ids, mine, all_reduce):
+    """Host statement of nm_mpm_blocks_pack -> all-reduce -> nm_mpm_blocks_unpack.  values: (nblocks, 64, 4) float array of
+    this rank's block contents, modified in place: blocks of `shared_ids` this rank lists (`mine`) are replaced by the sum
+    over the ranks; the rank contributes zeros for shared blocks it does not list and never touches any other block.
+    all_reduce: callable summing a float array over the ranks in place (dist.all_reduce on a tensor view)."""
+    import numpy as np
+    buf = np.zeros((len(shared_ids), 64, 4), dtype=values.dtype)
+    for i, (b, m) in enumerate(zip(shared_ids, mine)):
+        if m:
+            buf[i] = values[b]
+    all_reduce(buf)
+    for i, (b, m) in enumerate(zip(shared_ids, mine)):
+        if m:
+            values[b] = buf[i]
+    return values
+
+
 class ShardTape(object):
     """`tape` of a sharded substep: the grid cache record plus the list of blocks that were summed over the ranks.
     Filled by MPMModel.forward, consumed by MPMModel.backward."""

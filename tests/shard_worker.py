@@ -169,3 +169,68 @@ def cpu_rows(rank, world, port, q):
     except Exception as e:
         import traceback
         q.put({"rank": rank, "error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()})
+
+
+def cpu_exchange(rank, world, port, q):
+    """The shared-block rule and the pack / all-reduce / unpack bookkeeping of the sharded substep, on the host over gloo:
+    every rank evaluates the rule on the all-gathered lists and must arrive at the same shared list, and after the exchange
+    every block holds the dense (single-rank) sum on exactly the ranks that list it."""
+    try:
+        import numpy as np
+        dist = _init(rank, world, port)
+        from neuma_amd.sim.shard import shared_blocks_host, exchange_blocks_host
+        nblocks, cap, cap_shared = 200, 24, 16
+        rng = np.random.default_rng(7)
+        # overlapping block sets: rank r lists a window of a shuffled block order, plus an out-of-range id and duplicates of nothing
+        order = rng.permutation(nblocks)
+        lists = [order[8 * r: 8 * r + 14].tolist() for r in range(world)]
+        lists[0] = lists[0] + [nblocks + 5]                      # an invalid id must be ignored
+        mine_list = lists[rank]
+        row = np.full(1 + cap, -1, np.int32)
+        row[0] = len(mine_list); row[1:1 + len(mine_list)] = mine_list
+        t = torch.from_numpy(row.copy())
+        gathered = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        g = torch.stack(gathered).numpy()
+        ids, mine, bits = shared_blocks_host(g, cap, nblocks, cap_shared, rank)
+        # (1) the same list in the same order on every rank
+        mine_ids = torch.full((cap_shared,), -1, dtype=torch.int64); mine_ids[:len(ids)] = torch.from_numpy(ids.astype(np.int64))
+        all_ids = [torch.empty_like(mine_ids) for _ in range(world)]
+        dist.all_gather(all_ids, mine_ids)
+        ok_same = all(bool(torch.equal(a, all_ids[0])) for a in all_ids)
+        # (2) it is what the definition says: blocks in >= 2 valid lists, ordered by first appearance in rank order
+        valid = [[b for b in l if 0 <= b < nblocks] for l in lists]
+        want = []
+        for r in range(world):
+            for b in valid[r]:
+                if b not in want and sum(b in v for v in valid) >= 2:
+                    want.append(b)
+        ok_rule = ids.tolist() == want[:cap_shared] and bits == (2 if len(want) > cap_shared else 0)
+        ok_mine = all(bool(m) == (int(b) in valid[rank]) for b, m in zip(ids, mine))
+        # (3) pack / all-reduce / unpack: block values = (rank + 1) where the rank lists the block
+        vals = np.zeros((nblocks, 64, 4), np.float32)
+        for b in valid[rank]:
+            vals[b] = rank + 1.0 + 0.001 * b
+        before = vals.copy()
+
+        def allreduce(buf):
+            tb = torch.from_numpy(buf)
+            dist.all_reduce(tb)
+
+        exchange_blocks_host(vals, ids, mine, allreduce)
+        ok_sum = True
+        for b in range(nblocks):
+            listed = [r for r in range(world) if b in valid[r]]
+            if b in ids.tolist() and rank in listed:
+                ok_sum &= bool(np.allclose(vals[b], sum(r + 1.0 + 0.001 * b for r in listed)))
+            else:
+                ok_sum &= bool(np.array_equal(vals[b], before[b]))       # untouched: unshared, or not listed by this rank
+        # (4) capacity overflow is reported identically everywhere
+        _, _, bits_small = shared_blocks_host(g, cap, nblocks, 2, rank)
+        g_over = g.copy(); g_over[0, 0] = cap + 3
+        _, _, bits_over = shared_blocks_host(g_over, cap, nblocks, cap_shared, rank)
+        q.put({"rank": rank, "ok": [ok_same, ok_rule, ok_mine, ok_sum, bits_small & 2 == 2, bits_over & 1 == 1], "n_shared": len(ids)})
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put({"rank": rank, "error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()})

@@ -70,3 +70,39 @@ def test_sharded_frame_matches_the_single_process_frame():
         # render gradients of this small scene carry ~1e-3 of atomics-order noise even between two unsharded runs
         assert r["v0_err"] < 5e-3, r
         assert max(r["grad_err"]) < 2e-3 and min(r["grad_mag"]) > 1e-9, r
+
+
+@pytest.mark.parametrize("world,cap", [(2, 300), (3, 12000)])
+def test_device_shared_block_rule_equals_the_host_statement(world, cap):
+    """nm_mpm_shared_blocks (one-workgroup path for short lists, mark / flag / select / finish path for long ones) against
+    neuma_amd.sim.shard.shared_blocks_host - the statement of the rule the CPU (gloo) tests run the exchange with."""
+    import ctypes as C
+    import numpy as np
+    from neuma_amd import _lib as L
+    from neuma_amd.sim import MPMModelBuilder
+    from neuma_amd.sim.shard import shared_blocks_host
+    d = torch.device("cuda", 0)
+    model = MPMModelBuilder().parse_cfg(dict(gravity=[0.0, -9.8, 0.0], bc="noslip", num_grids=128, dt=1e-3, bound=1, eps=6e-7)).finalize(d)
+    nblocks = ((128 + 2 + 3) // 4) ** 3
+    rng = np.random.default_rng(world)
+    g = np.full((world, 1 + cap), -1, np.int32)
+    pool = rng.permutation(nblocks)[: int(1.4 * cap)]
+    for r in range(world):
+        n = cap - 7 * r
+        g[r, 0] = n
+        g[r, 1:1 + n] = rng.permutation(pool)[:n]
+    g[0, 5] = nblocks + 11                                   # invalid id: ignored
+    g[world - 1, 0] = cap + 4                                # a rank that overflowed its list: status bit 1
+    for cap_shared in (cap, 40):
+        ids, _, bits = shared_blocks_host(g, cap, nblocks, cap_shared)
+        lib = L.lib()
+        gathered = torch.from_numpy(g).to(d)
+        shared = torch.zeros(2 + 2 * cap_shared, dtype=torch.int32, device=d)
+        status = torch.zeros(1, dtype=torch.int32, device=d)
+        ws = torch.empty(int(lib.nm_mpm_shared_workspace(world, cap)), dtype=torch.uint8, device=d)
+        for _ in range(2):                                   # twice: the per-block counters must be left reset
+            L.check(lib.nm_mpm_shared_blocks(model.handle(), L.ptr(gathered), world, cap, L.ptr(shared), cap_shared, L.ptr(status),
+                                             L.ptr(ws), ws.numel(), L.stream_ptr(d)), "nm_mpm_shared_blocks")
+            out = shared.cpu().numpy()
+            assert int(out[0]) == len(ids) and int(out[1]) == bits and int(status.item()) == bits
+            assert np.array_equal(out[2:2 + len(ids)], ids)

@@ -30,3 +30,37 @@ def test_two_rank_gloo_gather_rows_and_param_grads():
     for r in res:
         assert "error" not in r, r
         assert all(r["ok"]), r
+
+
+def _run(target, world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ps = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = [q.get(timeout=180) for _ in ps]
+    [p.join(30) for p in ps]
+    return res
+
+
+def test_shared_block_rule_and_exchange_bookkeeping_over_gloo():
+    """world_size 2 and 3: the ordering rule of nm_mpm_shared_blocks and the pack / all-reduce / unpack bookkeeping, on the host."""
+    for world in (2, 3):
+        res = _run(shard_worker.cpu_exchange, world)
+        for r in res:
+            assert "error" not in r, r
+            assert all(r["ok"]), r
+            assert r["n_shared"] >= 4
+
+
+def test_stripe_plan_covers_every_tile_row_once():
+    from neuma_amd.harness import stripe_plan
+    for V, rows, world in [(3, 68, 2), (3, 68, 8), (1, 16, 4), (3, 68, 3), (2, 5, 7)]:
+        seen = {}
+        for r in range(world):
+            for (v, a, b) in stripe_plan(V, rows, world, r):
+                assert 0 <= a < b <= rows
+                for y in range(a, b):
+                    assert (v, y) not in seen
+                    seen[(v, y)] = r
+        assert len(seen) == V * rows
