@@ -241,9 +241,10 @@ def main():
     except Exception as e:  # accounting only
         print(f"[bench] pair count unavailable: {e}", file=sys.stderr)
 
-    pmc = {}
-    try:        # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json, tools/make_profile_md.py)
-        pmc = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text()).get("kernels", {})
+    pmc, pmc_mfma = {}, {}
+    try:        # HBM bytes per launch and matrix-pipe counters from the committed PMC passes (profiles/pmc_traffic.json, tools/make_profile_md.py)
+        _p = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
+        pmc, pmc_mfma = _p.get("kernels", {}), _p.get("mfma", {})
     except Exception:
         pass
     roof = None
@@ -330,6 +331,11 @@ def main():
     if roof is not None and roof["kernel"].split("<")[0] in pmc and args.workload == "metric" and world == 1:
         roof["traffic"] = pmc[roof["kernel"].split("<")[0]]["hbm_bytes_per_launch"]
         roof["traffic_source"] = "profiles/pmc_traffic.json: rocprofv3 PMC passes of this workload (2 x FETCH_SIZE + WRITE_SIZE per launch)"
+    if roof is not None and roof["kernel"].split("<")[0] in pmc_mfma and args.workload == "metric" and world == 1:
+        m = pmc_mfma[roof["kernel"].split("<")[0]]
+        roof["mfma_busy_pct_of_simd_cycles"] = m["mfma_busy_pct_of_simd_cycles"]      # SQ_VALU_MFMA_BUSY_CYCLES / (duration x 2.4 GHz x 1024 SIMDs)
+        roof["mfma_flops_counted"] = m["mfma_flops"]                                  # SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 per launch
+        roof["counter_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 ... pass of this workload)"
     devices = [f"rank {rank}: cuda:{local} {torch.cuda.get_device_name(dev)}"]
     if world > 1:
         gathered = [None] * world
