@@ -234,7 +234,7 @@ class SceneRuntime(object):
         """Camera of view index `view` at dataset frame `step` (synthetic scenes: static cameras, `step` is ignored)."""
         return self.cameras[view]
 
-    def render_view(self, means3D, deform_grad, view: int, tile_rows=None, cov=None, prepared=None, step=None):
+    def render_view(self, means3D, deform_grad, view: int, tile_rows=None, cov=None, step=None):
         """cov: covariances already pushed forward by the deformation gradients (deform_grad is then ignored)."""
         if getattr(self, "force_mask_data", False):       # silhouette supervision: constant colour 1 (tune/utils.py:390-404)
             return diff_rasterization(means3D, deform_grad if cov is None else None, None, self.camera_at(view, step), self.background,
@@ -243,14 +243,7 @@ class SceneRuntime(object):
         return diff_rasterization(means3D, deform_grad if cov is None else None, None, self.camera_at(view, step), self.background,
                                   gaussians_active_sh=self.gaussians.active_sh_degree,
                                   guassians_cov=self._cov if cov is None else cov,
-                                  gaussians_opa=self._opacity, gaussians_shs=self._shs, tile_rows=tile_rows, prepared=prepared)
-
-    def prepare_view(self, means3D, cov, view: int, tile_rows=None, step=None):
-        from .tune import prepare_view
-        if getattr(self, "force_mask_data", False):
-            return None
-        return prepare_view(means3D, cov, self.camera_at(view, step), self.background, self.gaussians.active_sh_degree, self._opacity,
-                            self._shs, tile_rows=tile_rows)
+                                  gaussians_opa=self._opacity, gaussians_shs=self._shs, tile_rows=tile_rows)
 
     @torch.no_grad()
     def make_ground_truth(self, perturb: float = 0.02, steps: int = 5, seed: int = 2):
@@ -305,34 +298,28 @@ class SceneRuntime(object):
         from .render import deform_cov_by_F
         cov = deform_cov_by_F(self._cov, deform_grad)
 
-        def job_loss(vi, rows, prep=None):
+        def job_loss(vi, rows):
             if rows is None:
-                return weight * self.pixel_loss(self.render_view(means3D, None, vi, cov=cov, prepared=prep), self.gt[vi])
-            render = self.render_view(means3D, None, vi, tile_rows=rows, cov=cov, prepared=prep)
+                return weight * self.pixel_loss(self.render_view(means3D, None, vi, cov=cov), self.gt[vi])
+            render = self.render_view(means3D, None, vi, tile_rows=rows, cov=cov)
             y0, y1 = rows[0] * 16, min(H, rows[1] * 16)
             # partial sums of the mean over the full image: the ranks' losses add up to the 1-GPU loss
             return weight * pixel_loss_rows(render, self.gt[vi], 0 if self.pixel_loss is l1_loss else 1, y0, y1)
 
         if getattr(self, "overlap_views", False) and len(jobs) > 1:
-            # the jobs go round-robin over HIP streams: one job's binning (sorts, scans: small latency-bound kernels)
-            # executes under another job's compositing kernel; autograd replays the assignment in the backward pass.
-            # Stage 1 of every job (preprocess, depth order, tile counts) is enqueued before the host blocks on the first
-            # pair count, so the read-backs do not serialise the views.
+            # the jobs go round-robin over HIP streams: one job's binning (counts, scans, cell sorts: small latency-bound
+            # kernels) executes under another job's compositing kernel; autograd replays the assignment in the backward pass.
             main = torch.cuda.current_stream(self.device)
             if not hasattr(self, "_view_streams"):
                 self._view_streams = [torch.cuda.Stream(device=self.device) for _ in range(int(self.num_view_streams or self.V))]
             streams = [self._view_streams[k % len(self._view_streams)] for k in range(len(jobs))]
-            preps = []
+            terms = []
             for s, (vi, rows) in zip(streams, jobs):
                 s.wait_stream(main)
                 for t in (means3D, cov):
                     t.record_stream(s)
                 with torch.cuda.stream(s):
-                    preps.append(self.prepare_view(means3D.detach(), cov, vi, tile_rows=rows))
-            terms = []
-            for s, (vi, rows), prep in zip(streams, jobs, preps):
-                with torch.cuda.stream(s):
-                    terms.append(job_loss(vi, rows, prep))
+                    terms.append(job_loss(vi, rows))
             for s in self._view_streams:
                 main.wait_stream(s)
             for t in terms:

@@ -69,15 +69,6 @@ def build_cov3D(scales: Tensor, rotations: Tensor, scale_modifier: float = 1.0) 
     return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], -1)
 
 
-class PreparedRaster(object):
-    """Kept for callers of the two-stage interface (prepare_rasterization -> rasterizer(..., prepared=...)): the rasterizer
-    no longer has a host round trip between its stages (nm_raster_forward is one asynchronous call), so there is nothing
-    to prepare and this is an empty token."""
-
-    def matches(self, *a) -> bool:
-        return False
-
-
 def _raster_inputs(means3D, shs, colors_precomp, opacities, cov3D):
     m3 = means3D.detach().float().contiguous()
     op = opacities.detach().float().contiguous()
@@ -85,10 +76,6 @@ def _raster_inputs(means3D, shs, colors_precomp, opacities, cov3D):
     sh = None if shs is None else shs.detach().float().contiguous()
     cp = None if colors_precomp is None else colors_precomp.detach().float().contiguous()
     return m3, sh, cp, op, cv
-
-
-def prepare_rasterization(rasterizer, means3D, opacities, shs=None, colors_precomp=None, cov3D_precomp=None) -> PreparedRaster:
-    return PreparedRaster()
 
 
 class BinCapacity(object):
@@ -122,7 +109,7 @@ class BinCapacity(object):
 class _RasterizeGaussians(autograd.Function):
 
     @staticmethod
-    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, cov3D, cam: RasterCamera, prepared=None):
+    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, cov3D, cam: RasterCamera):
         lib = L.lib()
         dev = means3D.device
         stream = L.stream_ptr(dev)
@@ -186,7 +173,7 @@ class _RasterizeGaussians(autograd.Function):
         L.check(lib.nm_raster_backward(C.byref(cfg), K, M, L.ptr(m3), L.ptr(sh), L.ptr(cp), L.ptr(op), L.ptr(cv), L.ptr(state),
                                        ctx.cap, L.ptr(g), L.ptr(dmeans3D), L.ptr(dmeans2D), L.ptr(dcov), L.ptr(dop), L.ptr(dsh),
                                        L.ptr(dcol), L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "nm_raster_backward")
-        return dmeans3D, dmeans2D, dsh, dcol, dop, dcov, None, None
+        return dmeans3D, dmeans2D, dsh, dcol, dop, dcov, None
 
 
 def count_tile_pairs(rasterizer, means3D, opacities, shs=None, colors_precomp=None, cov3D_precomp=None) -> int:
@@ -220,7 +207,7 @@ class GaussianRasterizer(nn.Module):
         return (hom @ s.viewmatrix.to(positions))[:, 2] > 0.2
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None, prepared=None):
+                cov3D_precomp=None):
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
@@ -230,7 +217,7 @@ class GaussianRasterizer(nn.Module):
             cov3D_precomp = build_cov3D(scales, rotations, self._cam.settings.scale_modifier)
         if means2D is None:
             means2D = torch.zeros_like(means3D)
-        return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, cov3D_precomp, self._cam, prepared)
+        return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, cov3D_precomp, self._cam)
 
 
 def get_rasterizer(viewpoint_camera, active_sh_degree: int, debug, bg_color: Tensor, scaling_modifier=1.0,

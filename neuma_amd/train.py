@@ -176,12 +176,11 @@ def video_loss(rt, gt_frames, c, decay_rate: float, views: Sequence[int], deform
             means3D = compute_bindings_xyz(de_x, de_prev, g_prev, rt.bindings)
             dg = compute_bindings_F(F, rt.bindings) if deform_cov else None
             lf = torch.zeros((), device=rt.device)
-            # covariance push-forward once per frame; stage 1 of every view is enqueued before the first pair-count read-back
+            # covariance push-forward once per frame, not per view
             cov = deform_cov_by_F(rt._cov, dg) if dg is not None else rt._cov
             fid = frame_ids[cur_step]
-            preps = [rt.prepare_view(means3D.detach(), cov, vi, step=fid) for vi in views]
             for i, vi in enumerate(views):
-                render = rt.render_view(means3D, None, vi, cov=cov, prepared=preps[i], step=fid)
+                render = rt.render_view(means3D, None, vi, cov=cov, step=fid)
                 lf = lf + w * rt.pixel_loss(render, gt_frames[cur_step - 1][i])
             terms.append(lf)
             de_prev = de_x.clone().detach()

@@ -152,7 +152,7 @@ def diff_rasterization(x: Tensor, deform_grad: Optional[Tensor], gaussians, view
                        gaussians_active_sh: Optional[int] = None, guassians_cov: Optional[Tensor] = None,
                        gaussians_opa: Optional[Tensor] = None, gaussians_shs: Optional[Tensor] = None,
                        scaling_modifier: Optional[float] = 1., force_mask_data: Optional[bool] = False,
-                       tile_rows=None, prepared=None) -> Tensor:
+                       tile_rows=None) -> Tensor:
     """tune/utils.py:323-421 (argument names kept, including the reference's `guassians_cov` spelling)."""
     means3D = x
     if gaussians is not None:
@@ -179,21 +179,8 @@ def diff_rasterization(x: Tensor, deform_grad: Optional[Tensor], gaussians, view
                                        opacities=opacity, scales=None, rotations=None, cov3D_precomp=cov3D_deformed)
     else:
         rendered_image, _ = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=None,
-                                       opacities=opacity, scales=None, rotations=None, cov3D_precomp=cov3D_deformed,
-                                       prepared=prepared)
+                                       opacities=opacity, scales=None, rotations=None, cov3D_precomp=cov3D_deformed)
     return rendered_image
-
-
-def prepare_view(x: Tensor, cov3D: Tensor, view_cam, background_color: Tensor, gaussians_active_sh: int, gaussians_opa: Tensor,
-                 gaussians_shs: Tensor, tile_rows=None, scaling_modifier: float = 1.0):
-    """Stage 1 of diff_rasterization (no counterpart in the reference): enqueue the preprocess / depth order / tile counts of one
-    view without waiting for the pair count.  Call it for every view of a frame first, then diff_rasterization(x, None, None,
-    view_cam, ..., guassians_cov=cov3D, prepared=<result>) with the same tensors: the host then blocks on the first count
-    while the other views' stage 1 is already running."""
-    from .render import prepare_rasterization
-    rasterizer = get_rasterizer(view_cam, gaussians_active_sh, debug=False, bg_color=background_color,
-                                scaling_modifier=scaling_modifier, tile_rows=tile_rows)
-    return prepare_rasterization(rasterizer, x, gaussians_opa, shs=gaussians_shs, cov3D_precomp=cov3D)
 
 
 def preprocess_for_rasterization(obj_gaussians: List, obj_deform_grad: List[Tensor], obj_kernels_prev: List[Tensor],
