@@ -84,6 +84,41 @@ __device__ __forceinline__ void nm_gelu_both(float x, float& h, float& dh) {
   dh = fmaf(x, p, P);
 }
 
+// Two GELU value / derivative pairs with packed fp32 arithmetic.  Measured on gfx950 with one wave per SIMD
+// (tools/ubench_valu.hip): a plain VALU instruction issues every 5.3 cycles, v_rcp / v_exp every 9, and a v_pk_fma_f32 /
+// v_pk_mul_f32 every 6.2 - two results for little more than the price of one.  The constitutive kernels are issue-bound
+// (their duration is the sum of their instructions' issue costs), so a pair of pairs drops from ~2 x 92 to ~132 cycles.
+// Same polynomial as nm_phi with 0.5 folded into the coefficients (exact), and
+// Phi = 0.5 + copysign(0.5 - half_tail, x) instead of the select (|difference| <= 1 ulp of 0.5).
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void nm_gelu_both2(const f2 x, f2& h, f2& dh) {
+  const float k = -0.5f * 1.4426950408889634f, c = 0.3275911f * 0.70710678118654752f;
+  f2 u = x * x;
+  u = u * (f2){k, k};
+  f2 t, e;
+  t[0] = fmaf(c, fabsf(x[0]), 1.0f);
+  t[1] = fmaf(c, fabsf(x[1]), 1.0f);
+  e[0] = __builtin_amdgcn_exp2f(u[0]);
+  e[1] = __builtin_amdgcn_exp2f(u[1]);
+  t[0] = __builtin_amdgcn_rcpf(t[0]);
+  t[1] = __builtin_amdgcn_rcpf(t[1]);
+  const float c1 = 0.5f * 1.061405429f, c2 = 0.5f * -1.453152027f, c3 = 0.5f * 1.421413741f, c4 = 0.5f * -0.284496736f,
+              c5 = 0.5f * 0.254829592f;
+  f2 poly = __builtin_elementwise_fma(t, (f2){c1, c1}, (f2){c2, c2});
+  poly = __builtin_elementwise_fma(poly, t, (f2){c3, c3});
+  poly = __builtin_elementwise_fma(poly, t, (f2){c4, c4});
+  poly = __builtin_elementwise_fma(poly, t, (f2){c5, c5});
+  const f2 half_tail = poly * t * e;                       // 0.5 erfc(|x| / sqrt2)
+  const f2 q = (f2){0.5f, 0.5f} - half_tail;
+  f2 r;
+  r[0] = __builtin_copysignf(q[0], x[0]);
+  r[1] = __builtin_copysignf(q[1], x[1]);
+  const f2 P = r + (f2){0.5f, 0.5f};
+  const f2 phi = e * (f2){0.3989422804014327f, 0.3989422804014327f};
+  h = x * P;
+  dh = __builtin_elementwise_fma(x, phi, P);
+}
+
 // ---------------------------------------------------------------- standalone SVD operator
 __global__ void __launch_bounds__(256) k_svd_fwd(int n, const float* __restrict__ F, float* __restrict__ U,
                                                  float* __restrict__ sig, float* __restrict__ Vh) {
@@ -270,60 +305,118 @@ __device__ __forceinline__ void nm_features(const M3& F, float z[13], M3& R, M3&
   z[12] = m3_det(F) - 1.f;
 }
 
+// MFMA chains whose A operands (weights in operand order, one 64-float row per MFMA) stream from LDS.  A wave is alone
+// on its SIMD, so nobody hides an LDS round trip for it: the compiler's own schedule (4 reads, wait, 8 MFMAs, 4 reads,
+// wait ...) exposed one LDS latency per 8 MFMAs (29 % of the wave's cycles were spent waiting, SQ_WAIT_INST_ANY in
+// profiles/r02a).  Here the reads of group g+1 are issued BEFORE the MFMAs of group g (sched_barrier keeps the compiler
+// from sinking them back), and the first group of a chain is fetched by the caller ahead of the phase in front of it.
+// LDS instructions issued between MFMAs cost nothing (the matrix pipe is busy 32 cycles per MFMA); VALU work does not
+// hide, so everything that can be an LDS access in the shadow of a chain is placed there (`mid`).
+#define NM_SB() __builtin_amdgcn_sched_barrier(0)
+template <int G>
+struct AGroup {
+  float a[G];
+};
+template <int G>
+__device__ __forceinline__ void a_fetch(AGroup<G>& o, const float* __restrict__ base, int lane, int grp) {
+#pragma unroll
+  for (int i = 0; i < G; ++i) o.a[i] = base[(grp * G + i) * 64 + lane];
+}
+struct NoMid {
+  __device__ __forceinline__ void operator()() const {}
+};
+// NOPS MFMAs: op -> acc[op & AM] += A(row op) x b[op >> BS];  mid() runs in the shadow of the first group
+template <int NOPS, int G, int AM, int BS, class MID = NoMid>
+__device__ __forceinline__ void a_chain(AGroup<G>& cur, const float* __restrict__ base, int lane, const float* b, f4* acc,
+                                        MID mid = MID()) {
+  static_assert(NOPS % G == 0, "whole groups");
+#pragma unroll
+  for (int g = 0; g < NOPS / G; ++g) {
+    AGroup<G> nxt;
+    if (g + 1 < NOPS / G) a_fetch<G>(nxt, base, lane, g + 1);
+    NM_SB();
+    if (g == 0) mid();
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+      const int op = g * G + i;
+      acc[op & AM] = NM_MFMA(cur.a[i], b[op >> BS], acc[op & AM]);
+    }
+    NM_SB();
+    if (g + 1 < NOPS / G) cur = nxt;
+  }
+}
+
 // three-layer MLP on one 16-particle column tile; B operand of layer 0 comes from zrow (LDS, [particle][17]).
-// WITH_GRAD additionally keeps the hidden activations and GELU derivatives for the backward pass.
+// `first` holds the first A group of layer 0 (a_fetch<8>(first, P0, lane, 0), issued by the caller ahead of time).
+// WITH_GRAD (reverse sweep): keeps the GELU derivatives, and the hidden activations go to LDS transposed
+// ([feature][16 particles + pad], th1 / th2) in the shadow of the next layer's MFMAs - the weight-gradient products read
+// them from there much later, so neither the writes nor the reads are ever waited for.
 struct MlpFwd {
-  f4 h1[4], h2[4], g1[4], g2[4];
+  f4 g1[4], g2[4];
   f4 y;
 };
 template <bool WITH_GRAD>
 __device__ __forceinline__ void mlp_forward_tile(const float* __restrict__ P0, const float* __restrict__ P1,
                                                  const float* __restrict__ P2, const float* zin /* 4 B operands of layer 0 */,
-                                                 int lane, MlpFwd& o) {
+                                                 int lane, AGroup<8>& first, MlpFwd& o, float* th1 = nullptr, float* th2 = nullptr) {
   const f4 zero = {0.f, 0.f, 0.f, 0.f};
+  const int j = lane & 15, g = lane >> 4;
   f4 a1[4] = {zero, zero, zero, zero};
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    float b = zin[ks];
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt) a1[rt] = NM_MFMA(P0[(ks * 4 + rt) * 64 + lane], b, a1[rt]);
-  }
+  a_chain<16, 8, 3, 2>(first, P0, lane, zin, a1);
+  AGroup<8> w1g;
+  a_fetch<8>(w1g, P1, lane, 0);      // in flight under the GELUs
+  NM_SB();
+  float hb[16];
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float h, dh;
-      nm_gelu_both(a1[rt][r], h, dh);
-      o.h1[rt][r] = h;
-      if (WITH_GRAD) o.g1[rt][r] = dh;
+    for (int pr = 0; pr < 2; ++pr) {
+      f2 h, dh;
+      nm_gelu_both2((f2){a1[rt][2 * pr], a1[rt][2 * pr + 1]}, h, dh);
+      hb[4 * rt + 2 * pr] = h[0];
+      hb[4 * rt + 2 * pr + 1] = h[1];
+      if (WITH_GRAD) {
+        o.g1[rt][2 * pr] = dh[0];
+        o.g1[rt][2 * pr + 1] = dh[1];
+      }
     }
   f4 a2[4] = {zero, zero, zero, zero};
+  a_chain<64, 8, 3, 2>(w1g, P1, lane, hb, a2, [&]() {
+    if (WITH_GRAD && th1) {
 #pragma unroll
-  for (int rtp = 0; rtp < 4; ++rtp)
+      for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      float b = o.h1[rtp][reg];
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) a2[rt] = NM_MFMA(P1[((rtp * 4 + reg) * 4 + rt) * 64 + lane], b, a2[rt]);
+        for (int r = 0; r < 4; ++r) th1[(16 * rt + 4 * g + r) * 17 + j] = hb[4 * rt + r];
+      __builtin_amdgcn_wave_barrier();   // (other lanes read these words: keep the compiler from reordering around them)
     }
+  });
+  AGroup<8> w2g;
+  a_fetch<8>(w2g, P2, lane, 0);
+  NM_SB();
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float h, dh;
-      nm_gelu_both(a2[rt][r], h, dh);
-      o.h2[rt][r] = h;
-      if (WITH_GRAD) o.g2[rt][r] = dh;
+    for (int pr = 0; pr < 2; ++pr) {
+      f2 h, dh;
+      nm_gelu_both2((f2){a2[rt][2 * pr], a2[rt][2 * pr + 1]}, h, dh);
+      hb[4 * rt + 2 * pr] = h[0];
+      hb[4 * rt + 2 * pr + 1] = h[1];
+      if (WITH_GRAD) {
+        o.g2[rt][2 * pr] = dh[0];
+        o.g2[rt][2 * pr + 1] = dh[1];
+      }
     }
-  f4 ya = zero, yb = zero;
+  f4 yy[2] = {zero, zero};
+  a_chain<16, 8, 1, 0>(w2g, P2, lane, hb, yy, [&]() {
+    if (WITH_GRAD && th2) {
 #pragma unroll
-  for (int rtp = 0; rtp < 4; ++rtp)
+      for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-    for (int reg = 0; reg < 4; reg += 2) {
-      ya = NM_MFMA(P2[(rtp * 4 + reg) * 64 + lane], o.h2[rtp][reg], ya);
-      yb = NM_MFMA(P2[(rtp * 4 + reg + 1) * 64 + lane], o.h2[rtp][reg + 1], yb);
+        for (int r = 0; r < 4; ++r) th2[(16 * rt + 4 * g + r) * 17 + j] = hb[4 * rt + r];
+      __builtin_amdgcn_wave_barrier();
     }
-  o.y = ya + yb;
+  });
+  o.y = yy[0] + yy[1];
 }
 
 // ---------------------------------------------------------------- forward
@@ -401,7 +494,9 @@ __global__ void __launch_bounds__(256) k_material_fwd(int n, int q, float alpha,
     for (int ct = 0; ct < 4; ++ct) {
       if (ct < ntile) {     // wave-uniform
         MlpFwd m;
-        mlp_forward_tile<false>(sP0, sP1, sP2, zin[ct], lane, m);
+        AGroup<8> first;
+        a_fetch<8>(first, sP0, lane, 0);
+        mlp_forward_tile<false>(sP0, sP1, sP2, zin[ct], lane, first, m);
         yv[ct] = m.y;
       } else {
         yv[ct] = (f4){0.f, 0.f, 0.f, 0.f};
@@ -490,8 +585,9 @@ struct BwdLds {
   float GY[4][64 * 13];   // ybar     [particle][13] (rows 9..12 zero)
   float Y[4][64 * 9];     // forward y
   float GZ[4][64 * 13];   // zbar     [particle][13]
-  float TA[4][64 * 17];   // [feature][16 particles + pad]
-  float TB[4][64 * 17];
+  float TA[4][64 * 17];   // [feature][16 particles + pad]: pre2bar
+  float TB[4][64 * 17];   //   h2, then pre1bar
+  float TC[4][64 * 17];   //   h1
 };
 
 struct BwdArgs {
@@ -535,6 +631,7 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
   float* gzb = L.GZ[wave];
   float* ta = L.TA[wave];
   float* tb = L.TB[wave];
+  float* tc = L.TC[wave];
   const f4 zero = {0.f, 0.f, 0.f, 0.f};
   f4 gW1[4][4], gW0[4], gW2[4];
 #pragma unroll
@@ -581,11 +678,22 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
 
 #pragma unroll 1
     for (int ct = 0; ct < ntile; ++ct) {
+      // Order of the phases: every LDS operand is written at least one MFMA chain before it is read, and the first
+      // operands of a phase are fetched before the chain in front of it starts - no LDS round trip is waited for.
+      //   forward recompute (h1 -> TC under layer 1, h2 -> TB under layer 2)
+      //   (b) h2bar = W2^T ybar, pre2bar = h2bar * gelu'(pre2)        [fetch (a)]
+      //   (a) W2bar += ybar h2^T            (TB)                      [pre2bar -> TA ; fetch (d)]
+      //   (d) h1bar = W1^T pre2bar, pre1bar = h1bar * gelu'(pre1)      [fetch (c)]
+      //   (c) W1bar += pre2bar h1^T         (TA, TC)                  [pre1bar -> TB ; fetch (f)]
+      //   (f) zbar = W0^T pre1bar                                      [fetch (e)]
+      //   (e) W0bar += pre1bar z^T          (TB, Z)
       MlpFwd m;
       float zin[4];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) zin[ks] = zb[(ct * 16 + j) * 17 + 4 * ks + g];
-      mlp_forward_tile<true>(L.P0, L.P1, L.P2, zin, lane, m);
+      AGroup<8> first;
+      a_fetch<8>(first, L.P0, lane, 0);
+      mlp_forward_tile<true>(L.P0, L.P1, L.P2, zin, lane, first, m, want_w ? tc : nullptr, want_w ? tb : nullptr);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int row = 4 * g + r;
@@ -593,104 +701,139 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
       }
       NM_PH(2)
       const float* gyt = gyb + ct * 16 * 13;  // [particle][13]
-      // (a) W2bar += ybar h2^T : A[yrow][particle], B[particle][h2 idx] via TB = h2 [feature][particle]
+      // ---- (b)
+      f4 d2[4] = {zero, zero, zero, zero};
+      float w2a[2], w2b[2][4];     // (a): A = ybar [yrow][particle], B = h2 [particle][feature] via TB
+      {
+        AGroup<4> q2g;
+        a_fetch<4>(q2g, L.Q2, lane, 0);
+        float b[3];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) b[ks] = gyt[j * 13 + 4 * ks + g];
+        if (want_w) {
+          w2a[0] = j < 9 ? gyt[g * 13 + j] : 0.f;
+#pragma unroll
+          for (int ctp = 0; ctp < 4; ++ctp) w2b[0][ctp] = tb[(16 * ctp + j) * 17 + g];
+        }
+        a_chain<12, 4, 3, 2>(q2g, L.Q2, lane, b, d2);
+      }
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) d2[rt] *= m.g2[rt];      // (vector form: packs into v_pk_mul_f32)
+      NM_PH(4)
+      AGroup<8> q1g;
+      a_fetch<8>(q1g, L.Q1, lane, 0);
+      NM_SB();
+      // ---- (a)
       if (want_w) {
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) tb[(16 * rt + 4 * g + r) * 17 + j] = m.h2[rt][r];
+          for (int r = 0; r < 4; ++r) ta[(16 * rt + 4 * g + r) * 17 + j] = d2[rt][r];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          float a = j < 9 ? gyt[(4 * ks + g) * 13 + j] : 0.f;
+          const int c = ks & 1, nx = c ^ 1;
+          if (ks < 3) {
+            w2a[nx] = j < 9 ? gyt[(4 * (ks + 1) + g) * 13 + j] : 0.f;
 #pragma unroll
-          for (int ctp = 0; ctp < 4; ++ctp) gW2[ctp] = NM_MFMA(a, tb[(16 * ctp + j) * 17 + 4 * ks + g], gW2[ctp]);
+            for (int ctp = 0; ctp < 4; ++ctp) w2b[nx][ctp] = tb[(16 * ctp + j) * 17 + 4 * (ks + 1) + g];
+          }
+          NM_SB();
+#pragma unroll
+          for (int ctp = 0; ctp < 4; ++ctp) gW2[ctp] = NM_MFMA(w2a[c], w2b[c][ctp], gW2[ctp]);
+          NM_SB();
         }
-        __builtin_amdgcn_wave_barrier();
       }
       NM_PH(3)
-      // (b) h2bar = W2^T ybar ; pre2bar = h2bar * gelu'(pre2)
-      f4 d2[4] = {zero, zero, zero, zero};
+      // ---- (d)
+      f4 d1[4] = {zero, zero, zero, zero};
+      float w1a[2][4], w1b[2][4];  // (c): A = pre2bar via TA, B = h1 via TC
+      {
+        float b[16];
 #pragma unroll
-      for (int ks = 0; ks < 3; ++ks) {
-        float b = gyt[j * 13 + 4 * ks + g];
+        for (int rtp = 0; rtp < 4; ++rtp)
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) d2[rt] = NM_MFMA(L.Q2[(ks * 4 + rt) * 64 + lane], b, d2[rt]);
+          for (int reg = 0; reg < 4; ++reg) b[4 * rtp + reg] = d2[rtp][reg];
+        if (want_w) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            w1b[0][t] = tc[(16 * t + j) * 17 + g];
+            w1a[0][t] = ta[(16 * t + j) * 17 + g];
+          }
+        }
+        a_chain<64, 8, 3, 2>(q1g, L.Q1, lane, b, d1);
       }
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) d2[rt][r] *= m.g2[rt][r];
-      NM_PH(4)
-      // (c) W1bar += pre2bar h1^T
+      for (int rt = 0; rt < 4; ++rt) d1[rt] *= m.g1[rt];
+      NM_PH(6)
+      AGroup<8> q0g;
+      a_fetch<8>(q0g, L.Q0, lane, 0);
+      NM_SB();
+      // ---- (c)
       if (want_w) {
+        // TB (h2) was last read by (a), whose reads were issued long before these writes (one wave: LDS is in order)
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            ta[(16 * rt + 4 * g + r) * 17 + j] = d2[rt][r];
-            tb[(16 * rt + 4 * g + r) * 17 + j] = m.h1[rt][r];
-          }
+          for (int r = 0; r < 4; ++r) tb[(16 * rt + 4 * g + r) * 17 + j] = d1[rt][r];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          float bq[4];
+          const int c = ks & 1, nx = c ^ 1;
+          if (ks < 3) {
 #pragma unroll
-          for (int ctp = 0; ctp < 4; ++ctp) bq[ctp] = tb[(16 * ctp + j) * 17 + 4 * ks + g];
-#pragma unroll
-          for (int rt = 0; rt < 4; ++rt) {
-            float a = ta[(16 * rt + j) * 17 + 4 * ks + g];
-#pragma unroll
-            for (int ctp = 0; ctp < 4; ++ctp) gW1[rt][ctp] = NM_MFMA(a, bq[ctp], gW1[rt][ctp]);
+            for (int t = 0; t < 4; ++t) {
+              w1b[nx][t] = tc[(16 * t + j) * 17 + 4 * (ks + 1) + g];
+              w1a[nx][t] = ta[(16 * t + j) * 17 + 4 * (ks + 1) + g];
+            }
           }
+          NM_SB();
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int ctp = 0; ctp < 4; ++ctp) gW1[rt][ctp] = NM_MFMA(w1a[c][rt], w1b[c][ctp], gW1[rt][ctp]);
+          NM_SB();
         }
-        __builtin_amdgcn_wave_barrier();
       }
       NM_PH(5)
-      // (d) h1bar = W1^T pre2bar ; pre1bar = h1bar * gelu'(pre1)
-      f4 d1[4] = {zero, zero, zero, zero};
+      // ---- (f)
+      f4 dzz[2] = {zero, zero};
+      float w0b[2], w0a[2][4];     // (e): A = pre1bar via TB, B = z [particle][z idx] straight from Z
+      {
+        float b[16];
 #pragma unroll
-      for (int rtp = 0; rtp < 4; ++rtp)
+        for (int rtp = 0; rtp < 4; ++rtp)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          float b = d2[rtp][reg];
+          for (int reg = 0; reg < 4; ++reg) b[4 * rtp + reg] = d1[rtp][reg];
+        if (want_w) {
+          w0b[0] = zb[(ct * 16 + g) * 17 + j];
 #pragma unroll
-          for (int rt = 0; rt < 4; ++rt) d1[rt] = NM_MFMA(L.Q1[((rtp * 4 + reg) * 4 + rt) * 64 + lane], b, d1[rt]);
+          for (int rt = 0; rt < 4; ++rt) w0a[0][rt] = tb[(16 * rt + j) * 17 + g];
         }
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) d1[rt][r] *= m.g1[rt][r];
-      NM_PH(6)
-      // (e) W0bar += pre1bar z^T : B[particle][z idx] straight from zb ([particle][17])
-      if (want_w) {
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) ta[(16 * rt + 4 * g + r) * 17 + j] = d1[rt][r];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          float b = zb[(ct * 16 + 4 * ks + g) * 17 + j];
-#pragma unroll
-          for (int rt = 0; rt < 4; ++rt) gW0[rt] = NM_MFMA(ta[(16 * rt + j) * 17 + 4 * ks + g], b, gW0[rt]);
-        }
-        __builtin_amdgcn_wave_barrier();
+        a_chain<16, 8, 1, 0>(q0g, L.Q0, lane, b, dzz);
       }
-      // (f) zbar = W0^T pre1bar
-      f4 dza = zero, dzb = zero;
-#pragma unroll
-      for (int rtp = 0; rtp < 4; ++rtp)
-#pragma unroll
-        for (int reg = 0; reg < 4; reg += 2) {
-          dza = NM_MFMA(L.Q0[(rtp * 4 + reg) * 64 + lane], d1[rtp][reg], dza);
-          dzb = NM_MFMA(L.Q0[(rtp * 4 + reg + 1) * 64 + lane], d1[rtp][reg + 1], dzb);
-        }
-      dza += dzb;
+      const f4 dza = dzz[0] + dzz[1];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int row = 4 * g + r;
         if (row < 13) gzb[(ct * 16 + j) * 13 + row] = dza[r];
+      }
+      // ---- (e)
+      if (want_w) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int c = ks & 1, nx = c ^ 1;
+          if (ks < 3) {
+            w0b[nx] = zb[(ct * 16 + 4 * (ks + 1) + g) * 17 + j];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) w0a[nx][rt] = tb[(16 * rt + j) * 17 + 4 * (ks + 1) + g];
+          }
+          NM_SB();
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) gW0[rt] = NM_MFMA(w0a[c][rt], w0b[c], gW0[rt]);
+          NM_SB();
+        }
+        // the next tile's forward pass overwrites TC / TB only after two of its own chains: in order behind these reads
       }
     }
     __builtin_amdgcn_wave_barrier();
