@@ -161,3 +161,41 @@ def test_render_on_a_second_stream_changes_the_schedule_not_the_result():
     # same kernels, different interleaving: equal up to the order of fp32 atomics (which can flip a rasterizer cut-off for a pixel)
     assert abs(res[True][0] - res[False][0]) < 2e-3 * res[False][0]
     assert float((res[True][1] - res[False][1]).norm()) < 5e-3 * float(res[False][1].norm())
+
+
+def test_loss_differences_between_equivalent_paths_are_rasterizer_cut_off_events():
+    """Root cause of the loose bounds above.  The p2g scatter sums with fp32 atomics, so two runs (or the fused and the
+    per-operator path) give positions that differ in the last bits; the rasterizer has two hard cut-offs per
+    (pixel, Gaussian) - alpha < 1/255 is skipped, T < 1e-4 ends the pixel (forward.cu semantics) - and a last-bit
+    difference flips one of them for a handful of pixels.  Everything else agrees to rounding.  Shown here on the
+    images themselves: all pixels agree to 2e-6 except a few, and each of those differs by at most one cut-off's
+    worth of colour; with loss ~ 1e-6 those few pixels are the whole 1e-5 ... 1e-3 relative difference.
+    Observed over four runs: 0, 2, 1, 2 pixels of 147 456 differ by 1.87e-4, every other pixel by <= 1.3e-6."""
+    from neuma_amd import synth
+    from neuma_amd.harness import SceneRuntime
+    from neuma_amd.train import simulate_video
+    scene = synth.make_scene("tiny", override=dict(S=10, V=2))
+    rt = SceneRuntime(scene, dev(), fused=True)
+    rt.F0 = torch.diag(torch.tensor([1.3, 0.75, 1.0])).to(dev()).repeat(rt.N, 1, 1).contiguous()
+    vids = []
+    for fused in (True, True, False):
+        rt.fused = fused
+        vids.append(simulate_video(rt, 3))
+    npix = 0
+    worst_round, flips, worst_flip = 0.0, 0, 0.0
+    for other in (vids[1], vids[2]):                    # run-to-run, and fused vs per-operator
+        for fa, fb in zip(vids[0], other):
+            for ia, ib in zip(fa, fb):
+                d = (ia - ib).abs().amax(0)             # per pixel, max over channels
+                big = d > 2e-6
+                npix += d.numel()
+                flips += int(big.sum())
+                if bool(big.any()):
+                    worst_flip = max(worst_flip, float(d[big].max()))
+                if bool((~big).any()):
+                    worst_round = max(worst_round, float(d[~big].max()))
+    print(f"cut-off events: {flips} of {npix} pixels, worst {worst_flip:.3e}; rounding-level worst {worst_round:.3e}")
+    assert worst_round <= 2e-6
+    # one Gaussian at the alpha threshold contributes at most (1/255) * T * colour, colour <~ 1.5 with the SH offset
+    assert worst_flip <= 1.5 / 255 + 1e-6, worst_flip
+    assert flips <= max(8, npix // 2000), (flips, npix)
