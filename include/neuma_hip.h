@@ -333,6 +333,16 @@ int nm_raster_forward(const nm_raster_cfg* cfg, int32_t k, int32_t m, const floa
                       const float* shs, const float* colors_precomp, const float* opacities,
                       const float* cov3D, int32_t* radii, void* state, size_t state_bytes, int64_t cap_pairs,
                       float* out_color, int64_t* status_host, void* stream);
+/* Tuning of the split compositing (process-wide; read by the following nm_raster_forward calls).  A view with fewer than
+ * `busy_tiles` non-empty tiles leaves most of the chip idle; its tiles whose depth-sorted list is longer than a segment
+ * (>= `min_segment` entries, ~4096 segments per view at most) are walked segment by segment on separate workgroups:
+ * always in the reverse sweep (from checkpoints the forward pass leaves in front of every segment), and in the forward
+ * pass for the tiles that still have a barely covered pixel after their first segment, provided the view's candidate
+ * lists hold no more than `forward_budget` entries together (every segment of such a tile is composited, also those
+ * behind the point where its pixels stop).  Same image, same termination rule (forward.cu: stop when T would fall below
+ * 1e-4), same gradients.  Defaults 256 (one tile per CU) / 512 / 2^21; busy_tiles = 0 switches the splitting off,
+ * forward_budget = 0 keeps the forward walk sequential.  min_segment is rounded up to a multiple of 16. */
+int nm_raster_set_split(int32_t busy_tiles, int32_t min_segment, int64_t forward_budget);
 /* Exact number of (Gaussian, 16x16 tile) pairs of the view held in `state` - the `num_rendered` the reference extension
  * returns.  Statistics (byte accounting); synchronises `stream`. */
 int nm_raster_count_pairs(const nm_raster_cfg* cfg, int32_t k, void* state, int64_t cap_pairs,

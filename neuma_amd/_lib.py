@@ -93,6 +93,7 @@ SIGNATURES = {
     "nm_bind_frame": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nm_raster_state_bytes": (_SZ, [C.POINTER(nm_raster_cfg), _I32, _I64]),
     "nm_raster_forward": (C.c_int, [C.POINTER(nm_raster_cfg), _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _SZ, _I64, _P, _P, _P]),
+    "nm_raster_set_split": (C.c_int, [_I32, _I32, _I64]),
     "nm_raster_count_pairs": (C.c_int, [C.POINTER(nm_raster_cfg), _I32, _P, _I64, _P, _P]),
     "nm_raster_bwd_workspace": (_SZ, [_I32]),
     "nm_raster_backward": (C.c_int, [C.POINTER(nm_raster_cfg), _I32, _I32, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P,

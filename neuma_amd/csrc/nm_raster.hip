@@ -57,11 +57,20 @@ static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 #define NM_NS 256    // depth slabs per bin (one thread of a 256-thread workgroup each in the per-bin kernels)
 #define NM_CELL_LDS 2048   // pairs a cell's workgroup sorts in LDS (bigger cells: same network on global memory)
 #define NM_PAD 32          // words between two cell counters (one 128-byte line each)
+#define NM_SPLIT_WORK 8192    // (tile, segment) work items a view may have (its segment records: 36 B per pixel each)
+#define NM_SPLIT_BUSY 256     // a view with this many non-empty tiles (one per CU) fills the chip: no splitting (default of nm_raster_set_split)
+#define NM_SPLIT_MINSEG 512   // shortest segment (list entries; default): ~50-90 us of one workgroup's walk
+#define NM_SPLIT_WGS 4096     // segments aimed at
+#define NM_SPLIT_TAU 0.01f    // a tile is split when, after its first segment, some pixel still has T above this
+#define NM_SPLIT_FWD_MAX (2u << 20)   // forward splitting composites every segment of a split tile, also those behind the
+                                      // point where its pixels stop: only when all candidate lists together are about one
+                                      // chip-load of work (256 CUs x 8 workgroups x 1024 entries)
 
 struct PairLog { uint32_t cell, rank, id, mask; };   // one (Gaussian, bin) pair as the count pass saw it
 
 struct State {
   uint32_t* hdr;       // [2] pairs binned (may exceed cap) [3] overflow flag [4..5] exact pair count (stats) [6] largest cell
+                       // [8] (tile, segment) work items of the split compositing [9] segment length [10] forward splitting allowed
   float2* xy; float* depth; float4* conop; float* rgb; uint32_t* clamped; int* rad;
   uint32_t* pad;       // per cell, one counter per 128-byte line (NM_PAD words apart): count, then fill cursor.  Neighbouring
                        // cells are hit by the same burst of atomics; packed they would serialise on one L2 channel
@@ -73,6 +82,16 @@ struct State {
   PairLog* log;                // the count pass's pair log (cap entries; dead after the fill pass)
   uint32_t *bin_total, *bin_off;
   float* final_T; uint32_t* n_contrib;
+  // split compositing (k_split_plan): tiles of a view that leaves most of the chip idle are composited in list segments
+  uint32_t* tile_rec;  // per tile: index of its first segment record, 0xFFFFFFFF = composited whole by k_render
+  uint32_t* tile_ns;   // per tile: number of segments (the tile owns ns + 1 consecutive work items / records)
+  uint32_t* tile_cnt;  // per tile: segments that have finished (arrival counter of the forward pass)
+  uint32_t* tile_mode; // per tile: 1 = composited in segments (decided by the tile's first segment, k_render_seg stage 0)
+  uint2* work;         // per (tile, segment) work item: {tile index ty * gx + tx, segment}
+  float4* seg_raw;     // per work item and pixel: colour the segment composites from T = 1, and its transmittance (pass 1)
+  float4* seg_fix;     // the same after pass 2: what the segment really contributes (pixels that stop inside / before it)
+  float4* seg_ct;      // checkpoints: (C, T) of the pixel in front of the segment; the tile's extra item ns holds the final (C, T)
+  uint32_t* seg_last;  // per work item and pixel: last contributor inside the segment (1-based list position), 0 = none
   int nbx, nby, ncell;
   size_t total;
 };
@@ -99,6 +118,16 @@ static State carve_state(void* base, int W, int H, int k, int64_t cap) {
   t.bin_off = (uint32_t*)(p + o); o += al256(((size_t)t.nbx * t.nby + 1) * sizeof(uint32_t));
   t.final_T = (float*)(p + o); o += al256(n * sizeof(float));
   t.n_contrib = (uint32_t*)(p + o); o += al256(n * sizeof(uint32_t));
+  const size_t ntile = (size_t)gx * gy;
+  t.tile_rec = (uint32_t*)(p + o); o += al256(ntile * sizeof(uint32_t));
+  t.tile_ns = (uint32_t*)(p + o); o += al256(ntile * sizeof(uint32_t));
+  t.tile_cnt = (uint32_t*)(p + o); o += al256(ntile * sizeof(uint32_t));
+  t.tile_mode = (uint32_t*)(p + o); o += al256(ntile * sizeof(uint32_t));
+  t.work = (uint2*)(p + o); o += al256((size_t)NM_SPLIT_WORK * sizeof(uint2));
+  t.seg_raw = (float4*)(p + o); o += al256((size_t)NM_SPLIT_WORK * NM_TPB * sizeof(float4));
+  t.seg_fix = (float4*)(p + o); o += al256((size_t)NM_SPLIT_WORK * NM_TPB * sizeof(float4));
+  t.seg_ct = (float4*)(p + o); o += al256((size_t)NM_SPLIT_WORK * NM_TPB * sizeof(float4));
+  t.seg_last = (uint32_t*)(p + o); o += al256((size_t)NM_SPLIT_WORK * NM_TPB * sizeof(uint32_t));
   t.total = o;
   return t;
 }
@@ -585,45 +614,39 @@ __global__ void __launch_bounds__(256) k_cell_sort(int ncell, const uint32_t* __
 }
 
 #define NM_SCAN 4096   // candidates a tile examines per round (16 per thread: four 16-byte loads of their tile masks)
-// front-to-back composite of one 16x16 tile (upstream renderCUDA forward) over the depth-sorted list of the tile's bin
-__global__ void __launch_bounds__(NM_TPB) k_render(RK k, int nbx, const uint32_t* __restrict__ off,
-                                                   const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                   long long cap, const uint32_t* __restrict__ hdr, const float2* __restrict__ xy,
-                                                   const float* __restrict__ rgb,
-                                                   const float4* __restrict__ conop, float* __restrict__ final_T,
-                                                   uint32_t* __restrict__ n_contrib, float* __restrict__ out) {
-  __shared__ uint32_t s_hit[NM_SCAN];      // 1-based list positions of the candidates that touch this tile, in list order
-  __shared__ float2 s_xy[NM_TPB];
-  __shared__ float4 s_co[NM_TPB];
-  __shared__ float s_rgb[NM_TPB * 3];
-  __shared__ int s_wcnt[4];
-  const int tile_x = blockIdx.x, tile_y = blockIdx.y + k.ty0;
+struct CompLds {
+  uint32_t hit[NM_SCAN];      // 1-based list positions of the candidates that touch this tile, in list order
+  float2 xy[NM_TPB];
+  float4 co[NM_TPB];
+  float rgb[NM_TPB * 3];
+  int wcnt[4];
+};
+struct Pix {
+  float T, C0, C1, C2;
+  uint32_t last;      // last contributor, 1-based position in the bin's list
+  bool done;          // stopped (T would fall below 1e-4) or not taking part
+};
+// front-to-back composite of one 16x16 tile (upstream renderCUDA forward) over entries [a, b) of the depth-sorted list of
+// the tile's bin (the bin's list starts at lo; positions are counted from there)
+__device__ __forceinline__ void composite_range(CompLds& L, long long lo, long long a, long long b, uint32_t bit,
+                                                const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                const float2* __restrict__ xy, const float* __restrict__ rgb,
+                                                const float4* __restrict__ conop, float fxp, float fyp, Pix& p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int px = tile_x * NM_TILE + (tid & 15), py = tile_y * NM_TILE + (tid >> 4);
-  const bool inside = px < k.W && py < k.H;
-  const float fxp = (float)px, fyp = (float)py;
-  const int bin = (tile_y / NM_BT) * nbx + tile_x / NM_BT;
-  const uint32_t bit = 1u << ((tile_y % NM_BT) * NM_BT + tile_x % NM_BT);
-  const long long lo = off[bin * NM_NS];
-  // capacity overflow (hdr[3]): slots of the lists were never written - render the background only, the caller re-runs
-  const long long hi = hdr[3] ? lo : min((long long)off[(bin + 1) * NM_NS], cap);
-  bool done = !inside;
-  float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
-  uint32_t last = 0;
-  for (long long base = lo & ~3ll; base < hi; base += NM_SCAN) {     // rounds start 16-byte aligned; positions < lo are masked out
-    if (__syncthreads_count(done) == NM_TPB) break;
+  for (long long base = a & ~3ll; base < b; base += NM_SCAN) {     // rounds start 16-byte aligned; positions < a are masked out
+    if (__syncthreads_count(p.done) == NM_TPB) break;
     // ---- NM_SCAN candidates: which of them touch this tile (bit of their tile mask)?
     const long long c = base + 16 * tid;
     uint32_t m16 = 0;
 #pragma unroll
     for (int v4 = 0; v4 < 4; ++v4) {
-      const long long p = c + 4 * v4;
-      if (p < hi) {                      // the array is padded to 256 bytes: a 16-byte load at an aligned p < cap stays inside
-        const uint4 v = *(const uint4*)(vals + p);
+      const long long q0 = c + 4 * v4;
+      if (q0 < b) {                      // the array is padded to 256 bytes: a 16-byte load at an aligned q0 < cap stays inside
+        const uint4 v = *(const uint4*)(vals + q0);
         const uint32_t b4 = ((v.x & bit) ? 1u : 0u) | ((v.y & bit) ? 2u : 0u) | ((v.z & bit) ? 4u : 0u) | ((v.w & bit) ? 8u : 0u);
         uint32_t ok = 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) ok |= (p + q >= lo && p + q < hi) ? (1u << q) : 0u;
+        for (int q = 0; q < 4; ++q) ok |= (q0 + q >= a && q0 + q < b) ? (1u << q) : 0u;
         m16 |= (b4 & ok) << (4 * v4);
       }
     }
@@ -631,50 +654,297 @@ __global__ void __launch_bounds__(NM_TPB) k_render(RK k, int nbx, const uint32_t
     int incl = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
-    if (lane == 63) s_wcnt[wave] = incl;
+    if (lane == 63) L.wcnt[wave] = incl;
     __syncthreads();
     int before = 0, nh = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { const int n = s_wcnt[w]; before += w < wave ? n : 0; nh += n; }
+    for (int w = 0; w < 4; ++w) { const int n = L.wcnt[w]; before += w < wave ? n : 0; nh += n; }
     int slot = before + incl - mine;
-    for (uint32_t mm = m16; mm; mm &= mm - 1u) s_hit[slot++] = (uint32_t)(c + (__ffs((int)mm) - 1) - lo) + 1u;
+    for (uint32_t mm = m16; mm; mm &= mm - 1u) L.hit[slot++] = (uint32_t)(c + (__ffs((int)mm) - 1) - lo) + 1u;
     __syncthreads();
     // ---- composite the survivors, in list (= depth) order, NM_TPB at a time
     for (int h0 = 0; h0 < nh; h0 += NM_TPB) {
-      if (h0 > 0 && __syncthreads_count(done) == NM_TPB) break;
+      if (h0 > 0 && __syncthreads_count(p.done) == NM_TPB) break;
       const int nb = min(NM_TPB, nh - h0);
       if (tid < nb) {
-        const uint32_t id = (uint32_t)keys[lo + s_hit[h0 + tid] - 1];
-        s_xy[tid] = xy[id];
-        s_co[tid] = conop[id];
-        s_rgb[3 * tid] = rgb[3 * id]; s_rgb[3 * tid + 1] = rgb[3 * id + 1]; s_rgb[3 * tid + 2] = rgb[3 * id + 2];
+        const uint32_t id = (uint32_t)keys[lo + L.hit[h0 + tid] - 1];
+        L.xy[tid] = xy[id];
+        L.co[tid] = conop[id];
+        L.rgb[3 * tid] = rgb[3 * id]; L.rgb[3 * tid + 1] = rgb[3 * id + 1]; L.rgb[3 * tid + 2] = rgb[3 * id + 2];
       }
       __syncthreads();
-      for (int j = 0; !done && j < nb; ++j) {
-        float2 q = s_xy[j];
-        float4 cj = s_co[j];
+      for (int j = 0; !p.done && j < nb; ++j) {
+        float2 q = L.xy[j];
+        float4 cj = L.co[j];
         float dx = q.x - fxp, dy = q.y - fyp;
         float power = -0.5f * (cj.x * dx * dx + cj.z * dy * dy) - cj.y * dx * dy;
         if (power > 0.f) continue;
         float alpha = fminf(0.99f, cj.w * __expf(power));
         if (alpha < 1.0f / 255.0f) continue;
-        float test_T = T * (1.f - alpha);
-        if (test_T < 0.0001f) { done = true; continue; }
-        float w = alpha * T;
-        C0 += s_rgb[3 * j] * w; C1 += s_rgb[3 * j + 1] * w; C2 += s_rgb[3 * j + 2] * w;
-        T = test_T;
-        last = s_hit[h0 + j];
+        float test_T = p.T * (1.f - alpha);
+        if (test_T < 0.0001f) { p.done = true; continue; }
+        float w = alpha * p.T;
+        p.C0 += L.rgb[3 * j] * w; p.C1 += L.rgb[3 * j + 1] * w; p.C2 += L.rgb[3 * j + 2] * w;
+        p.T = test_T;
+        p.last = L.hit[h0 + j];
       }
     }
   }
-  if (inside) {
-    size_t pix = (size_t)py * k.W + px, hw = (size_t)k.H * k.W;
-    final_T[pix] = T;
-    n_contrib[pix] = last;
-    out[pix] = C0 + T * k.bg[0];
-    out[hw + pix] = C1 + T * k.bg[1];
-    out[2 * hw + pix] = C2 + T * k.bg[2];
+}
+__device__ __forceinline__ void write_pixel(const RK& k, int px, int py, const Pix& p, float* __restrict__ final_T,
+                                            uint32_t* __restrict__ n_contrib, float* __restrict__ out) {
+  size_t pix = (size_t)py * k.W + px, hw = (size_t)k.H * k.W;
+  final_T[pix] = p.T;
+  n_contrib[pix] = p.last;
+  out[pix] = p.C0 + p.T * k.bg[0];
+  out[hw + pix] = p.C1 + p.T * k.bg[1];
+  out[2 * hw + pix] = p.C2 + p.T * k.bg[2];
+}
+
+__device__ __forceinline__ void render_whole(CompLds& L, const RK& k, int nbx, int tile_x, int tile_y, const uint32_t* __restrict__ off,
+                                             const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                             long long cap, const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ tile_rec,
+                                             const float2* __restrict__ xy, const float* __restrict__ rgb,
+                                             const float4* __restrict__ conop, float* __restrict__ final_T,
+                                             uint32_t* __restrict__ n_contrib, float* __restrict__ out) {
+  if (tile_rec[tile_y * k.gx + tile_x] != 0xFFFFFFFFu) return;      // a candidate of the split compositing (render_seg)
+  const int tid = threadIdx.x;
+  const int px = tile_x * NM_TILE + (tid & 15), py = tile_y * NM_TILE + (tid >> 4);
+  const bool inside = px < k.W && py < k.H;
+  const int bin = (tile_y / NM_BT) * nbx + tile_x / NM_BT;
+  const uint32_t bit = 1u << ((tile_y % NM_BT) * NM_BT + tile_x % NM_BT);
+  const long long lo = off[bin * NM_NS];
+  // capacity overflow (hdr[3]): slots of the lists were never written - render the background only, the caller re-runs
+  const long long hi = hdr[3] ? lo : min((long long)off[(bin + 1) * NM_NS], cap);
+  Pix p = {1.f, 0.f, 0.f, 0.f, 0u, !inside};
+  composite_range(L, lo, lo, hi, bit, keys, vals, xy, rgb, conop, (float)px, (float)py, p);
+  if (inside) write_pixel(k, px, py, p, final_T, n_contrib, out);
+}
+
+// ---- split compositing.  A view whose Gaussians all fall into a few dozen tiles (the single-object scenes: 36-240 busy
+// tiles with 10-70 k overlapping Gaussians each) keeps a few waves per busy tile busy with one long sequential loop
+// each while most of the chip idles, and the loop is longest where it cannot stop early: in tiles on the object's
+// silhouette, whose barely covered pixels never saturate and walk the whole list.  Compositing is associative - a
+// stretch of the list composited from T = 1 gives (C_s, T_s), and the pixel is C_0 + T_0 C_1 + T_0 T_1 C_2 ... - so
+// such a tile's list is cut into segments, one workgroup each:
+//   k_split_plan      candidate tiles (list longer than a segment) of a view with < busy_limit non-empty tiles; on the
+//                     device, no host read-back.  Views that fill the chip are never split.
+//   k_render_seg 0    a candidate tile's first segment.  If every pixel is at T <= NM_SPLIT_TAU afterwards (interior of an
+//                     opaque object: it will stop soon) the same workgroup simply walks on and finishes the tile;
+//                     otherwise the tile is split (tile_mode = 1) and
+//   k_render_seg 1    composites its other segments from T = 1, in parallel;
+//   k_render_fix      with the transmittance in front of a segment known, a pixel passes through it, has stopped before
+//                     it, or stops inside it - then the segment is walked again for those pixels from the true T, so the
+//                     reference's termination rule (stop when T would fall below 1e-4, forward.cu) is kept exactly;
+//                     the tile's last workgroup to finish sums the records.
+// The reverse sweep walks the segments of a split tile in parallel too (k_render_bwd_seg).
+__global__ void __launch_bounds__(1024) k_split_plan(RK k, int nbx, uint32_t busy_limit, uint32_t min_seg, unsigned long long fwd_max,
+                                                     const uint32_t* __restrict__ off, long long cap,
+                                                     uint32_t* __restrict__ hdr, uint32_t* __restrict__ tile_rec,
+                                                     uint32_t* __restrict__ tile_ns, uint32_t* __restrict__ tile_cnt,
+                                                     uint32_t* __restrict__ tile_mode, uint2* __restrict__ work) {
+  __shared__ unsigned long long s_total;
+  __shared__ uint32_t s_busy, s_base, s_scan[1024];
+  const int tid = threadIdx.x, rows = k.ty1 - k.ty0, ntile = k.gx * rows;
+  if (tid == 0) { s_total = 0ull; s_busy = 0u; s_base = 0u; }
+  __syncthreads();
+  auto list_len = [&](int i) -> uint32_t {
+    const int tx = i % k.gx, ty = i / k.gx + k.ty0;
+    const int bin = (ty / NM_BT) * nbx + tx / NM_BT;
+    const long long lo = off[bin * NM_NS], hi = min((long long)off[(bin + 1) * NM_NS], cap);
+    return hi > lo ? (uint32_t)(hi - lo) : 0u;
+  };
+  unsigned long long tot = 0ull; uint32_t busy = 0u;
+  if (!hdr[3])
+    for (int i = tid; i < ntile; i += 1024) { const uint32_t n = list_len(i); tot += n; busy += n ? 1u : 0u; }
+  if (busy) { atomicAdd(&s_total, tot); atomicAdd(&s_busy, busy); }
+  __syncthreads();
+  const bool split = s_busy > 0u && s_busy < busy_limit;
+  uint32_t seg = (uint32_t)((s_total + NM_SPLIT_WGS - 1) / NM_SPLIT_WGS);
+  seg = max(seg, min_seg);
+  seg = (seg + 15u) & ~15u;
+  for (int i0 = 0; i0 < ntile; i0 += 1024) {     // segments per tile, exclusive prefix in tile order
+    const int i = i0 + tid;
+    uint32_t ns = 0u;
+    if (split && i < ntile) { const uint32_t n = list_len(i); ns = n > seg ? (n + seg - 1) / seg : 0u; }
+    const uint32_t items = ns ? ns + 1u : 0u;      // one more record for the pixel's final (C, T)
+    s_scan[tid] = items;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const uint32_t v = tid >= o ? s_scan[tid - o] : 0u;
+      __syncthreads();
+      s_scan[tid] += v;
+      __syncthreads();
+    }
+    const uint32_t rec = s_base + s_scan[tid] - items;
+    if (i < ntile) {
+      const int t = (i / k.gx + k.ty0) * k.gx + i % k.gx;
+      const bool ok = ns > 0u && rec + items <= NM_SPLIT_WORK;    // (holds by construction of seg; kept as a guard)
+      tile_rec[t] = ok ? rec : 0xFFFFFFFFu;
+      tile_ns[t] = ok ? ns : 0u;
+      tile_cnt[t] = 0u;
+      tile_mode[t] = 0u;
+      if (ok) for (uint32_t q = 0; q <= ns; ++q) work[rec + q] = make_uint2((uint32_t)t, q);
+    }
+    __syncthreads();
+    if (tid == 1023) s_base += s_scan[1023];
+    __syncthreads();
   }
+  if (tid == 0) { hdr[8] = min(s_base, (uint32_t)NM_SPLIT_WORK); hdr[9] = seg; hdr[10] = s_total <= fwd_max ? 1u : 0u; }
+}
+
+// pass 1 (two launches: stage 0 = first segments, which decide; stage 1 = the other segments of the split tiles)
+__device__ __forceinline__ void render_seg(CompLds& L, const RK& k, int nbx, int stage, uint32_t w, uint32_t* __restrict__ tile_mode,
+                                           const uint32_t* __restrict__ tile_ns, const uint32_t* __restrict__ off,
+                                           const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                           long long cap, const uint32_t* __restrict__ hdr, const uint2* __restrict__ work,
+                                           float4* __restrict__ seg_raw, uint32_t* __restrict__ seg_last,
+                                           float4* __restrict__ seg_ct,
+                                           const float2* __restrict__ xy, const float* __restrict__ rgb,
+                                           const float4* __restrict__ conop, float* __restrict__ final_T,
+                                           uint32_t* __restrict__ n_contrib, float* __restrict__ out) {
+  if (w >= hdr[8]) return;
+  const uint2 wk = work[w];
+  const uint32_t ns = tile_ns[wk.x];
+  if (stage == 0 ? wk.y != 0u : (wk.y == 0u || wk.y >= ns || tile_mode[wk.x] != 1u)) return;
+  const int tile_x = wk.x % k.gx, tile_y = wk.x / k.gx;
+  const long long seg = hdr[9];
+  const int tid = threadIdx.x;
+  const int px = tile_x * NM_TILE + (tid & 15), py = tile_y * NM_TILE + (tid >> 4);
+  const bool inside = px < k.W && py < k.H;
+  const float fxp = (float)px, fyp = (float)py;
+  const int bin = (tile_y / NM_BT) * nbx + tile_x / NM_BT;
+  const uint32_t bit = 1u << ((tile_y % NM_BT) * NM_BT + tile_x % NM_BT);
+  const long long lo = off[bin * NM_NS], hi = min((long long)off[(bin + 1) * NM_NS], cap);
+  const long long a = lo + seg * wk.y, b = min(hi, a + seg);
+  Pix p = {1.f, 0.f, 0.f, 0.f, 0u, !inside};
+  composite_range(L, lo, a, b, bit, keys, vals, xy, rgb, conop, fxp, fyp, p);
+  if (stage == 0) {
+    const bool far = __syncthreads_or(!p.done && p.T > NM_SPLIT_TAU);
+    if (!(far && hdr[10])) {
+      // nobody is far from stopping (or the view's lists are too much speculative work): this workgroup walks on, segment by
+      // segment, leaving a checkpoint (C, T) in front of each - the reverse sweep starts its parallel walks from them
+      seg_ct[(size_t)w * NM_TPB + tid] = make_float4(0.f, 0.f, 0.f, 1.f);
+      for (uint32_t sg = 1; sg < ns; ++sg) {
+        if (__syncthreads_and(p.done)) break;
+        seg_ct[(size_t)(w + sg) * NM_TPB + tid] = make_float4(p.C0, p.C1, p.C2, p.T);
+        const long long a2 = lo + seg * sg, b2 = min(hi, a2 + seg);
+        composite_range(L, lo, a2, b2, bit, keys, vals, xy, rgb, conop, fxp, fyp, p);
+      }
+      seg_ct[(size_t)(w + ns) * NM_TPB + tid] = make_float4(p.C0, p.C1, p.C2, p.T);
+      if (inside) write_pixel(k, px, py, p, final_T, n_contrib, out);
+      return;
+    }
+    if (tid == 0) tile_mode[wk.x] = 1u;
+  }
+  // transmittance < 0: the segment stopped by itself (its own T would have fallen below 1e-4) - the pixel ends in it or earlier
+  seg_raw[(size_t)w * NM_TPB + tid] = make_float4(p.C0, p.C1, p.C2, (p.done && inside) ? -1.f : p.T);
+  seg_last[(size_t)w * NM_TPB + tid] = p.last;
+}
+// one launch, 1-D grid: workgroups [0, ntile) = the tiles that are composited whole (stage 0 only), the others = the work
+// items of the split compositing - the two kinds run side by side
+__global__ void __launch_bounds__(NM_TPB) k_render(RK k, int nbx, int stage, int ntile, uint32_t* __restrict__ tile_mode,
+                                                   const uint32_t* __restrict__ tile_rec, const uint32_t* __restrict__ tile_ns,
+                                                   const uint32_t* __restrict__ off, const unsigned long long* __restrict__ keys,
+                                                   const uint32_t* __restrict__ vals, long long cap, const uint32_t* __restrict__ hdr,
+                                                   const uint2* __restrict__ work, float4* __restrict__ seg_raw,
+                                                   uint32_t* __restrict__ seg_last, float4* __restrict__ seg_ct,
+                                                   const float2* __restrict__ xy, const float* __restrict__ rgb,
+                                                   const float4* __restrict__ conop, float* __restrict__ final_T,
+                                                   uint32_t* __restrict__ n_contrib, float* __restrict__ out) {
+  __shared__ CompLds L;
+  const int b = blockIdx.x;
+  if (b < ntile)
+    render_whole(L, k, nbx, b % k.gx, b / k.gx + k.ty0, off, keys, vals, cap, hdr, tile_rec, xy, rgb, conop, final_T, n_contrib, out);
+  else
+    render_seg(L, k, nbx, stage, (uint32_t)(b - ntile), tile_mode, tile_ns, off, keys, vals, cap, hdr, work, seg_raw, seg_last, seg_ct,
+               xy, rgb, conop, final_T, n_contrib, out);
+}
+
+// pass 2, again one workgroup per segment: with the transmittance in front of the segment known (product over the earlier
+// segments' records) a pixel either passes through the segment (record kept), has stopped earlier (record cleared), or
+// stops inside it - then the segment is walked again for those pixels from the true T, which reproduces the reference's
+// termination exactly.  seg_fix receives the final records (what the segment really contributed, relative to its own
+// start).  The last workgroup of a tile to finish sums the tile's records and leaves the checkpoints (C, T) in front of
+// every segment for the reverse sweep.
+__global__ void __launch_bounds__(NM_TPB) k_render_fix(RK k, int nbx, const uint32_t* __restrict__ off,
+                                                       const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                       long long cap, const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ tile_rec,
+                                                       const uint32_t* __restrict__ tile_ns, uint32_t* __restrict__ tile_cnt,
+                                                       const uint32_t* __restrict__ tile_mode,
+                                                       const uint2* __restrict__ work, const float4* __restrict__ seg_raw,
+                                                       float4* __restrict__ seg_fix, float4* __restrict__ seg_ct,
+                                                       uint32_t* __restrict__ seg_last,
+                                                       const float2* __restrict__ xy, const float* __restrict__ rgb,
+                                                       const float4* __restrict__ conop, float* __restrict__ final_T,
+                                                       uint32_t* __restrict__ n_contrib, float* __restrict__ out) {
+  __shared__ CompLds L;
+  __shared__ int s_flag;
+  const uint32_t w = blockIdx.x;
+  if (w >= hdr[8]) return;
+  const uint2 wk = work[w];
+  const uint32_t ns = tile_ns[wk.x], r0 = tile_rec[wk.x];
+  if (tile_mode[wk.x] != 1u || wk.y >= ns) return;        // finished by its first segment's workgroup / the tile's extra record
+  const int tile_x = wk.x % k.gx, tile_y = wk.x / k.gx;
+  const long long seg = hdr[9];
+  const int tid = threadIdx.x;
+  const int px = tile_x * NM_TILE + (tid & 15), py = tile_y * NM_TILE + (tid >> 4);
+  const bool inside = px < k.W && py < k.H;
+  const float fxp = (float)px, fyp = (float)py;
+  const int bin = (tile_y / NM_BT) * nbx + tile_x / NM_BT;
+  const uint32_t bit = 1u << ((tile_y % NM_BT) * NM_BT + tile_x % NM_BT);
+  const long long lo = off[bin * NM_NS], hi = min((long long)off[(bin + 1) * NM_NS], cap);
+  {
+    float Tp = 1.f;
+    bool stopped = !inside;
+    for (uint32_t m0 = 0; m0 < wk.y && !stopped; m0 += 8) {        // (eight independent loads in flight, not a chain of round trips)
+      float tw[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) tw[q] = m0 + q < wk.y ? seg_raw[(size_t)(r0 + m0 + q) * NM_TPB + tid].w : 1.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (stopped) continue;
+        if (tw[q] < 0.f || Tp * tw[q] < 0.0001f) stopped = true;     // some Gaussian of segment m brings T below 1e-4
+        else Tp *= tw[q];
+      }
+    }
+    const size_t ri = (size_t)w * NM_TPB + tid;
+    float4 ct = seg_raw[ri];
+    uint32_t ls = seg_last[ri];
+    const bool need = !stopped && (ct.w < 0.f || Tp * ct.w < 0.0001f);
+    if (__syncthreads_or(need)) {
+      const long long a = lo + seg * wk.y, b = min(hi, a + seg);
+      Pix r = {Tp, 0.f, 0.f, 0.f, 0u, !need};
+      composite_range(L, lo, a, b, bit, keys, vals, xy, rgb, conop, fxp, fyp, r);
+      if (need) {
+        const float inv = 1.f / Tp;
+        ct = make_float4(r.C0 * inv, r.C1 * inv, r.C2 * inv, r.T * inv);
+        ls = r.last;
+      }
+    }
+    if (stopped) { ct = make_float4(0.f, 0.f, 0.f, 1.f); ls = 0u; }
+    seg_fix[ri] = ct;
+    seg_last[ri] = ls;
+  }
+  // ---- the last segment of the tile to finish sums the records
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) s_flag = atomicAdd(&tile_cnt[wk.x], 1u) == ns - 1u;
+  __syncthreads();
+  if (!s_flag) return;
+  __threadfence();
+  Pix q = {1.f, 0.f, 0.f, 0.f, 0u, !inside};
+  for (uint32_t sg = 0; sg < ns; ++sg) {
+    const size_t ri = (size_t)(r0 + sg) * NM_TPB + tid;
+    const float4 ct = seg_fix[ri];
+    const uint32_t ls = seg_last[ri];
+    seg_ct[ri] = make_float4(q.C0, q.C1, q.C2, q.T);
+    q.C0 += q.T * ct.x; q.C1 += q.T * ct.y; q.C2 += q.T * ct.z;
+    q.T *= ct.w;
+    if (ls) q.last = ls;
+  }
+  seg_ct[(size_t)(r0 + ns) * NM_TPB + tid] = make_float4(q.C0, q.C1, q.C2, q.T);
+  if (inside) write_pixel(k, px, py, q, final_T, n_contrib, out);
 }
 
 // exact number of (Gaussian, tile) pairs of the view (what the reference's duplicateWithKeys would emit after the conic
@@ -749,96 +1019,93 @@ __device__ __forceinline__ float wave_sum_dpp(float x) {
 // slot order inside an accumulator row: [0..7] = values of wave_fold8 order, [8] = opacity
 //   v[0]=d/dndc.x v[1]=d/dndc.y v[2]=d/dconic.x v[3]=d/dconic.y v[4]=d/dconic.z v[5..7]=d/drgb
 
+struct BwdLdsR {
+  uint32_t hit[NM_RB_SCAN];
+  uint32_t id[NM_RB_BATCH];
+  uint32_t pos[NM_RB_BATCH];
+  float2 xy[NM_RB_BATCH];
+  float4 co[NM_RB_BATCH];
+  float rgb[NM_RB_BATCH * 3];
+  float acc[4][NM_RB_BATCH * NM_NG];   // one private table per wave: plain stores, no LDS atomics
+  int wcnt[4];
+  uint32_t last[4];
+};
+// per-pixel state of the reverse walk
+struct PixB {
+  float T;                  // transmittance behind the Gaussian about to be visited
+  float T_final;
+  uint32_t last;            // positions > last do not contribute for this pixel
+  float dp0, dp1, dp2;      // dL/dpixel
+  float ar0, ar1, ar2, last_alpha, lc0, lc1, lc2;    // colour composited behind (upstream renderCUDA backward recurrence)
+};
+// Reverse walk of one tile over list positions (floor, tile_top] of its bin (1-based, counted from lo): the bin's list is
+// examined NM_RB_SCAN candidates at a time, back to front (tile-mask bit test); the survivors are staged in LDS NM_RB_BATCH
+// at a time.  The four per-wave tables are what limits the number of resident tiles (LDS), and this loop lives on latency
+// hiding - 128 per batch = 25 KB per tile = 6 waves per SIMD
 template <bool WITH_OPACITY>
-__global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, int nbx, const uint32_t* __restrict__ off,
-                                                       const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                       const float2* __restrict__ xy, const float* __restrict__ rgb,
-                                                       const float4* __restrict__ conop, const float* __restrict__ final_T,
-                                                       const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                                                       float* __restrict__ acc /* (K, 9) */) {
-  // the bin's list is examined NM_RB_SCAN candidates at a time, back to front from the tile's last contributor (tile-mask bit
-  // test); the survivors are staged in LDS NM_RB_BATCH at a time.  The four per-wave tables are what limits the number of
-  // resident tiles (LDS), and this loop lives on latency hiding - 128 per batch = 25 KB per tile = 6 waves per SIMD
-  __shared__ uint32_t s_hit[NM_RB_SCAN];
-  __shared__ uint32_t s_id[NM_RB_BATCH];
-  __shared__ uint32_t s_pos[NM_RB_BATCH];
-  __shared__ float2 s_xy[NM_RB_BATCH];
-  __shared__ float4 s_co[NM_RB_BATCH];
-  __shared__ float s_rgb[NM_RB_BATCH * 3];
-  __shared__ float s_acc[4][NM_RB_BATCH * NM_NG];   // one private table per wave: plain stores, no LDS atomics
-  __shared__ int s_wcnt[4];
-  const int tile_x = blockIdx.x, tile_y = blockIdx.y + k.ty0;
+__device__ __forceinline__ void render_bwd_range(BwdLdsR& L, const RK& k, long long lo, uint32_t floor_pos, uint32_t bit,
+                                                 const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                 const float2* __restrict__ xy, const float* __restrict__ rgb,
+                                                 const float4* __restrict__ conop, float fxp, float fyp, PixB& P,
+                                                 float* __restrict__ acc /* (K, 9) */) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int px = tile_x * NM_TILE + (tid & 15), py = tile_y * NM_TILE + (tid >> 4);
-  const bool inside = px < k.W && py < k.H;
-  const float fxp = (float)px, fyp = (float)py;
-  const int bin = (tile_y / NM_BT) * nbx + tile_x / NM_BT;
-  const uint32_t bit = 1u << ((tile_y % NM_BT) * NM_BT + tile_x % NM_BT);
-  const long long lo = off[bin * NM_NS];
-  const size_t pix = (size_t)py * k.W + px, hw = (size_t)k.H * k.W;
-  const float T_final = inside ? final_T[pix] : 0.f;
-  float T = T_final;
-  const uint32_t last_contributor = inside ? n_contrib[pix] : 0u;      // 1-based position in the bin's list, 0 = none
-  float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f;
-  if (inside) { dp0 = dL_dpix[pix]; dp1 = dL_dpix[hw + pix]; dp2 = dL_dpix[2 * hw + pix]; }
-  const float bg_dot = k.bg[0] * dp0 + k.bg[1] * dp1 + k.bg[2] * dp2;
-  float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
+  const float bg_dot = k.bg[0] * P.dp0 + k.bg[1] * P.dp1 + k.bg[2] * P.dp2;
   const float ddelx_dx = 0.5f * k.W, ddely_dy = 0.5f * k.H;
-  float* my_acc = s_acc[wave];
+  float* my_acc = L.acc[wave];
   // lane l < 8 owns fold slot value index:
   const int slot = 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1);
   for (int i = lane; i < NM_RB_BATCH * NM_NG; i += 64) my_acc[i] = 0.f;
   // Gaussians behind every pixel's last contributor (the forward pass stopped compositing there) cannot
   // contribute: the wave skips them before doing any arithmetic, the tile skips whole batches of them
-  uint32_t wave_last = last_contributor;
+  uint32_t wave_last = P.last;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, o, 64));
-  __shared__ uint32_t s_last[4];
-  if (lane == 0) s_last[wave] = wave_last;
+  if (lane == 0) L.last[wave] = wave_last;
   __syncthreads();
-  const uint32_t tile_last = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
-  for (long long top = lo + (long long)tile_last; top > lo; top -= NM_RB_SCAN) {
+  const uint32_t tile_last = max(max(L.last[0], L.last[1]), max(L.last[2], L.last[3]));
+  const long long bottom = lo + (long long)floor_pos;       // absolute index of the first candidate of the range
+  for (long long top = lo + (long long)tile_last; top > bottom; top -= NM_RB_SCAN) {
     __syncthreads();
-    // ---- candidates top-1, top-2, ... (back to front): which of them touch this tile?  Thread t < 128 looks at four.
+    // ---- candidates top-1, top-2, ... (back to front): which of them touch this tile?  Thread t < 128 looks at sixteen.
     const long long c = top - 1 - 16 * tid;     // this thread's candidates: c, c-1, ..., c-15
     uint32_t m16 = 0;
     if (tid < NM_RB_SCAN / 16) {
 #pragma unroll
       for (int q = 0; q < 16; ++q)
-        if (c - q >= lo && (vals[c - q] & bit)) m16 |= 1u << q;
+        if (c - q >= bottom && (vals[c - q] & bit)) m16 |= 1u << q;
     }
     const int mine = __popc(m16);
     int incl = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
-    if (lane == 63) s_wcnt[wave] = incl;
+    if (lane == 63) L.wcnt[wave] = incl;
     __syncthreads();
     int before = 0, nh = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { const int n = s_wcnt[w]; before += w < wave ? n : 0; nh += n; }
+    for (int w = 0; w < 4; ++w) { const int n = L.wcnt[w]; before += w < wave ? n : 0; nh += n; }
     {
       int hslot = before + incl - mine;
-      for (uint32_t mm = m16; mm; mm &= mm - 1u) s_hit[hslot++] = (uint32_t)(c - (__ffs((int)mm) - 1) - lo) + 1u;   // 1-based, descending
+      for (uint32_t mm = m16; mm; mm &= mm - 1u) L.hit[hslot++] = (uint32_t)(c - (__ffs((int)mm) - 1) - lo) + 1u;   // 1-based, descending
     }
     for (int h0 = 0; h0 < nh; h0 += NM_RB_BATCH) {
     __syncthreads();
     const int nb = min(NM_RB_BATCH, nh - h0);
     if (tid < nb) {
-      const uint32_t pos = s_hit[h0 + tid];
+      const uint32_t pos = L.hit[h0 + tid];
       const uint32_t id = (uint32_t)keys[lo + pos - 1];
-      s_id[tid] = id;
-      s_pos[tid] = pos;
-      s_xy[tid] = xy[id];
-      s_co[tid] = conop[id];
-      s_rgb[3 * tid] = rgb[3 * id]; s_rgb[3 * tid + 1] = rgb[3 * id + 1]; s_rgb[3 * tid + 2] = rgb[3 * id + 2];
+      L.id[tid] = id;
+      L.pos[tid] = pos;
+      L.xy[tid] = xy[id];
+      L.co[tid] = conop[id];
+      L.rgb[3 * tid] = rgb[3 * id]; L.rgb[3 * tid + 1] = rgb[3 * id + 1]; L.rgb[3 * tid + 2] = rgb[3 * id + 2];
     }
     __syncthreads();
     for (int j = 0; j < nb; ++j) {
-      const uint32_t pos = s_pos[j];
+      const uint32_t pos = L.pos[j];
       if (pos > wave_last) continue;            // wave-uniform: behind every pixel's last contributor
-      bool act = pos <= last_contributor;
-      float2 p = s_xy[j];
-      float4 co = s_co[j];
+      bool act = pos <= P.last;
+      float2 p = L.xy[j];
+      float4 co = L.co[j];
       float dx = p.x - fxp, dy = p.y - fyp;
       float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
       float G = __expf(power);
@@ -852,17 +1119,17 @@ __global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, int nbx, const uint
         // one hardware reciprocal (1 ulp) for both quotients below: the IEEE divisions were a quarter of the
         // instructions of an evaluated (pixel, Gaussian) pair; alpha <= 0.99 keeps the denominator >= 0.01
         const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);
-        T = T * inv1ma;
-        float dch = alpha * T;
-        float c0 = s_rgb[3 * j], c1 = s_rgb[3 * j + 1], c2 = s_rgb[3 * j + 2];
-        ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = c0;
-        ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = c1;
-        ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = c2;
-        float dL_dalpha = (c0 - ar0) * dp0 + (c1 - ar1) * dp1 + (c2 - ar2) * dp2;
-        g[5] = dch * dp0; g[6] = dch * dp1; g[7] = dch * dp2;
-        dL_dalpha *= T;
-        last_alpha = alpha;
-        dL_dalpha += (-T_final * inv1ma) * bg_dot;
+        P.T = P.T * inv1ma;
+        float dch = alpha * P.T;
+        float c0 = L.rgb[3 * j], c1 = L.rgb[3 * j + 1], c2 = L.rgb[3 * j + 2];
+        P.ar0 = P.last_alpha * P.lc0 + (1.f - P.last_alpha) * P.ar0; P.lc0 = c0;
+        P.ar1 = P.last_alpha * P.lc1 + (1.f - P.last_alpha) * P.ar1; P.lc1 = c1;
+        P.ar2 = P.last_alpha * P.lc2 + (1.f - P.last_alpha) * P.ar2; P.lc2 = c2;
+        float dL_dalpha = (c0 - P.ar0) * P.dp0 + (c1 - P.ar1) * P.dp1 + (c2 - P.ar2) * P.dp2;
+        g[5] = dch * P.dp0; g[6] = dch * P.dp1; g[7] = dch * P.dp2;
+        dL_dalpha *= P.T;
+        P.last_alpha = alpha;
+        dL_dalpha += (-P.T_final * inv1ma) * bg_dot;
         float dL_dG = co.w * dL_dalpha;
         float gdx = G * dx, gdy = G * dy;
         float dG_ddelx = -gdx * co.x - gdy * co.y;
@@ -889,12 +1156,12 @@ __global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, int nbx, const uint
     __syncthreads();
     // one global atomic set per (tile, Gaussian): sum the four wave tables
     if (tid < nb) {
-      uint32_t id = s_id[tid];
+      uint32_t id = L.id[tid];
       float* dst = acc + (size_t)id * NM_NG;
 #pragma unroll
       for (int q = 0; q < (WITH_OPACITY ? NM_NG : 8); ++q) {
         int o = tid * NM_NG + q;
-        float v = (s_acc[0][o] + s_acc[1][o]) + (s_acc[2][o] + s_acc[3][o]);
+        float v = (L.acc[0][o] + L.acc[1][o]) + (L.acc[2][o] + L.acc[3][o]);
         if (v != 0.f) unsafeAtomicAdd(dst + q, v);
       }
     }
@@ -902,6 +1169,100 @@ __global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, int nbx, const uint
     for (int i = lane; i < nb * NM_NG; i += 64) my_acc[i] = 0.f;
     }
   }
+}
+
+template <bool WITH_OPACITY>
+__device__ __forceinline__ void bwd_whole(BwdLdsR& L, const RK& k, int nbx, int tile_x, int tile_y, const uint32_t* __restrict__ off,
+                                          const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                          const uint32_t* __restrict__ tile_rec,
+                                          const float2* __restrict__ xy, const float* __restrict__ rgb,
+                                          const float4* __restrict__ conop, const float* __restrict__ final_T,
+                                          const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
+                                          float* __restrict__ acc /* (K, 9) */) {
+  if (tile_rec[tile_y * k.gx + tile_x] != 0xFFFFFFFFu) return;      // bwd_seg
+  const int tid = threadIdx.x;
+  const int px = tile_x * NM_TILE + (tid & 15), py = tile_y * NM_TILE + (tid >> 4);
+  const bool inside = px < k.W && py < k.H;
+  const int bin = (tile_y / NM_BT) * nbx + tile_x / NM_BT;
+  const uint32_t bit = 1u << ((tile_y % NM_BT) * NM_BT + tile_x % NM_BT);
+  const long long lo = off[bin * NM_NS];
+  const size_t pix = (size_t)py * k.W + px, hw = (size_t)k.H * k.W;
+  PixB P = {};
+  if (inside) {
+    P.T_final = final_T[pix];
+    P.last = n_contrib[pix];                       // 1-based position in the bin's list, 0 = none
+    P.dp0 = dL_dpix[pix]; P.dp1 = dL_dpix[hw + pix]; P.dp2 = dL_dpix[2 * hw + pix];
+  }
+  P.T = P.T_final;
+  render_bwd_range<WITH_OPACITY>(L, k, lo, 0u, bit, keys, vals, xy, rgb, conop, (float)px, (float)py, P, acc);
+}
+
+// reverse walk of one segment of a candidate tile (k_split_plan), all segments of a tile in parallel.  The state a pixel
+// arrives with at the top of segment s comes from the forward pass's checkpoints: T behind the segment = T in front of
+// segment s+1, colour composited behind it (seen from there) = (C_final - C in front of s+1) / T in front of s+1.  Feeding
+// that colour as (last_alpha, last_colour) = (1, colour) makes the upstream recurrence
+// accum = last_alpha last_colour + (1 - last_alpha) accum start from it.
+template <bool WITH_OPACITY>
+__device__ __forceinline__ void bwd_seg(BwdLdsR& L, const RK& k, int nbx, uint32_t w, const uint32_t* __restrict__ off,
+                                        const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                        const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ tile_rec,
+                                        const uint32_t* __restrict__ tile_ns, const uint2* __restrict__ work,
+                                        const float4* __restrict__ seg_ct,
+                                        const float2* __restrict__ xy, const float* __restrict__ rgb,
+                                        const float4* __restrict__ conop, const float* __restrict__ final_T,
+                                        const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
+                                        float* __restrict__ acc /* (K, 9) */) {
+  if (w >= hdr[8]) return;
+  const uint2 wk = work[w];
+  const uint32_t seg = hdr[9], sg = wk.y, ns = tile_ns[wk.x], r0 = tile_rec[wk.x];
+  if (sg >= ns) return;            // the tile's extra record
+  const int tile_x = wk.x % k.gx, tile_y = wk.x / k.gx;
+  const int tid = threadIdx.x;
+  const int px = tile_x * NM_TILE + (tid & 15), py = tile_y * NM_TILE + (tid >> 4);
+  const bool inside = px < k.W && py < k.H;
+  const int bin = (tile_y / NM_BT) * nbx + tile_x / NM_BT;
+  const uint32_t bit = 1u << ((tile_y % NM_BT) * NM_BT + tile_x % NM_BT);
+  const long long lo = off[bin * NM_NS];
+  const size_t pix = (size_t)py * k.W + px, hw = (size_t)k.H * k.W;
+  const uint32_t floor_pos = seg * sg, ceil_pos = floor_pos + seg;      // the segment holds positions floor_pos+1 .. ceil_pos
+  PixB P = {};
+  uint32_t last = 0u;
+  if (inside) {
+    P.T_final = final_T[pix];
+    last = n_contrib[pix];
+    P.dp0 = dL_dpix[pix]; P.dp1 = dL_dpix[hw + pix]; P.dp2 = dL_dpix[2 * hw + pix];
+  }
+  P.T = P.T_final;
+  if (last > ceil_pos) {            // the pixel's last contributor lies in a later segment
+    const float4 nx = seg_ct[(size_t)(r0 + sg + 1) * NM_TPB + tid], fin = seg_ct[(size_t)(r0 + ns) * NM_TPB + tid];
+    const float inv = 1.f / nx.w;
+    P.T = nx.w;
+    P.last_alpha = 1.f; P.lc0 = (fin.x - nx.x) * inv; P.lc1 = (fin.y - nx.y) * inv; P.lc2 = (fin.z - nx.z) * inv;
+    P.last = ceil_pos;
+  } else {
+    P.last = last > floor_pos ? last : 0u;      // ends in this segment, or in an earlier one (nothing to do here)
+  }
+  render_bwd_range<WITH_OPACITY>(L, k, lo, floor_pos, bit, keys, vals, xy, rgb, conop, (float)px, (float)py, P, acc);
+}
+
+// one launch, 1-D grid: workgroups [0, ntile) = whole tiles, the others = segments of the candidate tiles, side by side
+template <bool WITH_OPACITY>
+__global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, int nbx, int ntile, const uint32_t* __restrict__ off,
+                                                       const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                       const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ tile_rec,
+                                                       const uint32_t* __restrict__ tile_ns, const uint2* __restrict__ work,
+                                                       const float4* __restrict__ seg_ct,
+                                                       const float2* __restrict__ xy, const float* __restrict__ rgb,
+                                                       const float4* __restrict__ conop, const float* __restrict__ final_T,
+                                                       const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
+                                                       float* __restrict__ acc /* (K, 9) */) {
+  __shared__ BwdLdsR L;
+  const int b = blockIdx.x;
+  if (b < ntile)
+    bwd_whole<WITH_OPACITY>(L, k, nbx, b % k.gx, b / k.gx + k.ty0, off, keys, vals, tile_rec, xy, rgb, conop, final_T, n_contrib, dL_dpix, acc);
+  else
+    bwd_seg<WITH_OPACITY>(L, k, nbx, (uint32_t)(b - ntile), off, keys, vals, hdr, tile_rec, tile_ns, work, seg_ct, xy, rgb, conop,
+                          final_T, n_contrib, dL_dpix, acc);
 }
 
 // adjoint of k_preprocess: per-Gaussian chain rule to means3D / cov3D / SH (upstream computeCov2DCUDA +
@@ -1052,6 +1413,15 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(RK k, int K, const float
 }
 
 // ---------------------------------------------------------------- host API
+static int g_split_busy = NM_SPLIT_BUSY, g_split_minseg = NM_SPLIT_MINSEG;
+static long long g_split_fwd = NM_SPLIT_FWD_MAX;
+extern "C" int nm_raster_set_split(int32_t busy_tiles, int32_t min_segment, int64_t forward_budget) {
+  NM_REQUIRE(busy_tiles >= 0 && min_segment >= 1 && forward_budget >= 0, "busy_tiles >= 0, min_segment >= 1, forward_budget >= 0");
+  g_split_busy = busy_tiles;
+  g_split_minseg = min_segment;
+  g_split_fwd = forward_budget;
+  return NM_OK;
+}
 // One view, forward: 6 launches, no host synchronisation.  status_host (optional, pinned host memory, 2 x int64): receives
 // {pairs binned, overflow flag} by an asynchronous copy at the end - overflow != 0 means cap_pairs was too small and the image
 // is incomplete (the caller re-runs with a capacity >= pairs).
@@ -1096,8 +1466,25 @@ extern "C" int nm_raster_forward(const nm_raster_cfg* cfg, int32_t K, int32_t m,
               (long long)cap_pairs, (const uint32_t*)t.hdr);
     NM_LAUNCH_CHECK();
   }
-  NM_LAUNCH(k_render, dim3(k.gx, k.ty1 - k.ty0), dim3(NM_TPB), 0, s, k, t.nbx, (const uint32_t*)t.off, (const unsigned long long*)t.keys,
-            (const uint32_t*)t.vals, (long long)cap_pairs, (const uint32_t*)t.hdr, t.xy, t.rgb, t.conop, t.final_T, t.n_contrib, out_color);
+  NM_LAUNCH(k_split_plan, dim3(1), dim3(1024), 0, s, k, t.nbx, (uint32_t)g_split_busy, (uint32_t)g_split_minseg,
+            (unsigned long long)g_split_fwd,
+            (const uint32_t*)t.off, (long long)cap_pairs, t.hdr, t.tile_rec,
+            t.tile_ns, t.tile_cnt, t.tile_mode, t.work);
+  NM_LAUNCH_CHECK();
+  const int ntile = k.gx * (k.ty1 - k.ty0);
+  // stage 0: whole tiles + first segments of the candidates (which decide how their tile goes on); stage 1: other segments
+  // of the tiles that are split.  A view without candidates has no work items and those workgroups leave at once.
+  for (int stage = 0; stage < 2; ++stage) {
+    NM_LAUNCH(k_render, dim3((stage == 0 ? ntile : 0) + NM_SPLIT_WORK), dim3(NM_TPB), 0, s, k, t.nbx, stage, stage == 0 ? ntile : 0,
+              t.tile_mode, (const uint32_t*)t.tile_rec, (const uint32_t*)t.tile_ns, (const uint32_t*)t.off,
+              (const unsigned long long*)t.keys, (const uint32_t*)t.vals, (long long)cap_pairs, (const uint32_t*)t.hdr,
+              (const uint2*)t.work, t.seg_raw, t.seg_last, t.seg_ct, t.xy, t.rgb, t.conop, t.final_T, t.n_contrib, out_color);
+    NM_LAUNCH_CHECK();
+  }
+  NM_LAUNCH(k_render_fix, dim3(NM_SPLIT_WORK), dim3(NM_TPB), 0, s, k, t.nbx, (const uint32_t*)t.off, (const unsigned long long*)t.keys,
+            (const uint32_t*)t.vals, (long long)cap_pairs, (const uint32_t*)t.hdr, (const uint32_t*)t.tile_rec,
+            (const uint32_t*)t.tile_ns, t.tile_cnt, (const uint32_t*)t.tile_mode, (const uint2*)t.work, (const float4*)t.seg_raw,
+            t.seg_fix, t.seg_ct, t.seg_last, t.xy, t.rgb, t.conop, t.final_T, t.n_contrib, out_color);
   NM_LAUNCH_CHECK();
   if (status_host) {
     // hdr[2], hdr[3] are 32-bit: widen on the host side of the copy (4-byte copies into the low halves; the caller zeroes the buffer)
@@ -1164,12 +1551,17 @@ extern "C" int nm_raster_backward(const nm_raster_cfg* cfg, int32_t K, int32_t m
   State t = carve_state((void*)state, k.W, k.H, K, cap_pairs);
   float* acc = (float*)workspace;
   NM_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)K * NM_NG * sizeof(float), s));
+  const int ntile = k.gx * (k.ty1 - k.ty0);
   if (dL_dopacity)
-    NM_LAUNCH(k_render_bwd<true>, dim3(k.gx, k.ty1 - k.ty0), dim3(NM_TPB), 0, s, k, t.nbx, (const uint32_t*)t.off,
-              (const unsigned long long*)t.keys, (const uint32_t*)t.vals, t.xy, t.rgb, t.conop, t.final_T, t.n_contrib, dL_dcolor, acc);
+    NM_LAUNCH(k_render_bwd<true>, dim3(ntile + NM_SPLIT_WORK), dim3(NM_TPB), 0, s, k, t.nbx, ntile, (const uint32_t*)t.off,
+              (const unsigned long long*)t.keys, (const uint32_t*)t.vals, (const uint32_t*)t.hdr, (const uint32_t*)t.tile_rec,
+              (const uint32_t*)t.tile_ns, (const uint2*)t.work, (const float4*)t.seg_ct, t.xy, t.rgb, t.conop, t.final_T,
+              t.n_contrib, dL_dcolor, acc);
   else
-    NM_LAUNCH(k_render_bwd<false>, dim3(k.gx, k.ty1 - k.ty0), dim3(NM_TPB), 0, s, k, t.nbx, (const uint32_t*)t.off,
-              (const unsigned long long*)t.keys, (const uint32_t*)t.vals, t.xy, t.rgb, t.conop, t.final_T, t.n_contrib, dL_dcolor, acc);
+    NM_LAUNCH(k_render_bwd<false>, dim3(ntile + NM_SPLIT_WORK), dim3(NM_TPB), 0, s, k, t.nbx, ntile, (const uint32_t*)t.off,
+              (const unsigned long long*)t.keys, (const uint32_t*)t.vals, (const uint32_t*)t.hdr, (const uint32_t*)t.tile_rec,
+              (const uint32_t*)t.tile_ns, (const uint2*)t.work, (const float4*)t.seg_ct, t.xy, t.rgb, t.conop, t.final_T,
+              t.n_contrib, dL_dcolor, acc);
   NM_LAUNCH_CHECK();
   NM_LAUNCH(k_preprocess_bwd, dim3(nm_div_up(K, 256)), dim3(256), 0, s, k, K, means3D, shs, cov3D, (const int*)t.rad, t.clamped, acc,
             dL_dmeans3D, dL_dmeans2D, dL_dcov3D, dL_dopacity, dL_dshs, dL_dcolors, shs ? 1 : 0);

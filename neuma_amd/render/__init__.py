@@ -195,6 +195,25 @@ def count_tile_pairs(rasterizer, means3D, opacities, shs=None, colors_precomp=No
     return int(out.value)
 
 
+def split_plan(rasterizer, means3D, opacities, shs=None, colors_precomp=None, cov3D_precomp=None) -> Tuple[int, int]:
+    """(work items, segment length) the split compositing chose for this view (nm_raster_set_split; 0 work items = every
+    tile composited by one workgroup).  Diagnostics: runs a forward pass into a scratch state and reads its header."""
+    lib = L.lib()
+    cam = rasterizer._cam
+    m3, sh, cp, op, cv = _raster_inputs(means3D, shs, colors_precomp, opacities, cov3D_precomp)
+    dev, K = m3.device, m3.size(0)
+    M = 0 if sh is None else sh.size(1)
+    cap = 8 * K + 4096
+    state_bytes = int(lib.nm_raster_state_bytes(C.byref(cam.cfg), K, cap))
+    state = torch.empty(state_bytes, dtype=torch.uint8, device=dev)
+    radii = torch.empty(K, dtype=torch.int32, device=dev)
+    color = torch.empty(3, cam.cfg.image_height, cam.cfg.image_width, dtype=torch.float32, device=dev)
+    L.check(lib.nm_raster_forward(C.byref(cam.cfg), K, M, L.ptr(m3), L.ptr(sh), L.ptr(cp), L.ptr(op), L.ptr(cv), L.ptr(radii),
+                                  L.ptr(state), state_bytes, cap, L.ptr(color), None, L.stream_ptr(dev)), "nm_raster_forward")
+    hdr = state[:64].view(torch.int32).cpu()
+    return int(hdr[8]), int(hdr[9])
+
+
 class GaussianRasterizer(nn.Module):
     def __init__(self, raster_settings: GaussianRasterizationSettings, tile_rows: Optional[Tuple[int, int]] = None):
         super().__init__()

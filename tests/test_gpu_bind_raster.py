@@ -78,27 +78,40 @@ def test_raster_colors_precomp_mask_path_and_scale_rot_inputs():
         rast(means3D=means.to(dev()), means2D=None, opacities=op.to(dev()), cov3D_precomp=cov.to(dev()))
 
 
-def test_raster_tile_stripes_reassemble_the_full_image_and_gradient():
+@pytest.mark.parametrize("split", [False, True])
+def test_raster_tile_stripes_reassemble_the_full_image_and_gradient(split):
+    """A stripe of tile rows renders exactly the pixels of the full image.  With the split compositing off (or the same plan on
+    both sides) bit for bit; with it on, a stripe and the full view cut their lists into different segments (the plan depends
+    on how many tiles are busy), which changes the order of the transmittance products: equal to 2e-6."""
+    from neuma_amd import _lib
+    lib = _lib.lib()
     s, means, cov, op, shs, _, _ = _scene(deg=3, K=900)
-    full = _gpu_raster(s)
-    m = means.to(dev()).requires_grad_(True)
-    args = dict(means2D=None, opacities=op.to(dev()), shs=shs.to(dev()), cov3D_precomp=cov.to(dev()))
-    img, _ = full(means3D=m, **args)
-    gw = torch.randn(3, s.image_height, s.image_width, generator=torch.Generator().manual_seed(1)).to(dev())
-    (gfull,) = torch.autograd.grad((img * gw).sum(), m)
-    rows = (s.image_height + 15) // 16
-    acc_img = torch.zeros_like(img)
-    acc_g = torch.zeros_like(gfull)
-    for r0, r1 in [(0, 2), (2, 3), (3, rows)]:
-        part, _ = _gpu_raster(s, tile_rows=(r0, r1))(means3D=m, **args)
-        y0, y1 = r0 * 16, min(s.image_height, r1 * 16)
-        assert torch.equal(part[:, y0:y1], img[:, y0:y1])          # same pixels, bit for bit
-        assert float(part[:, :y0].abs().sum()) == 0 and float(part[:, y1:].abs().sum()) == 0
-        acc_img += part
-        (gp,) = torch.autograd.grad((part * gw).sum(), m)
-        acc_g += gp
-    assert torch.equal(acc_img, img)
-    assert rel_max(acc_g, gfull) < 1e-5
+    _lib.check(lib.nm_raster_set_split(1 << 20 if split else 0, 32, 1 << 40), "nm_raster_set_split")
+    try:
+        full = _gpu_raster(s)
+        m = means.to(dev()).requires_grad_(True)
+        args = dict(means2D=None, opacities=op.to(dev()), shs=shs.to(dev()), cov3D_precomp=cov.to(dev()))
+        img, _ = full(means3D=m, **args)
+        gw = torch.randn(3, s.image_height, s.image_width, generator=torch.Generator().manual_seed(1)).to(dev())
+        (gfull,) = torch.autograd.grad((img * gw).sum(), m)
+        rows = (s.image_height + 15) // 16
+        acc_img = torch.zeros_like(img)
+        acc_g = torch.zeros_like(gfull)
+        for r0, r1 in [(0, 2), (2, 3), (3, rows)]:
+            part, _ = _gpu_raster(s, tile_rows=(r0, r1))(means3D=m, **args)
+            y0, y1 = r0 * 16, min(s.image_height, r1 * 16)
+            if split:
+                assert abs_max(part[:, y0:y1], img[:, y0:y1]) < 2e-6
+            else:
+                assert torch.equal(part[:, y0:y1], img[:, y0:y1])          # same pixels, bit for bit
+            assert float(part[:, :y0].abs().sum()) == 0 and float(part[:, y1:].abs().sum()) == 0
+            acc_img += part
+            (gp,) = torch.autograd.grad((part * gw).sum(), m)
+            acc_g += gp
+        assert abs_max(acc_img, img) < 2e-6 if split else torch.equal(acc_img, img)
+        assert rel_max(acc_g, gfull) < (2e-5 if split else 1e-5)
+    finally:
+        _lib.check(lib.nm_raster_set_split(256, 512, 1 << 21), "nm_raster_set_split")
 
 
 def test_raster_empty_and_all_culled():
@@ -210,3 +223,47 @@ def test_raster_heavy_depth_cell_and_capacity_growth():
         rast2(means3D=means.to(dev()), means2D=None, opacities=op.to(dev()), colors_precomp=col.to(dev()), cov3D_precomp=cov.to(dev()))
     img3, _ = rast2(means3D=means.to(dev()), means2D=None, opacities=op.to(dev()), colors_precomp=col.to(dev()), cov3D_precomp=cov.to(dev()))
     assert torch.equal(img3, img.detach())
+
+
+@pytest.mark.parametrize("opaque", [False, True])
+def test_raster_split_compositing_equals_whole_tile_compositing_and_the_oracle(opaque):
+    """nm_raster_set_split: the tiles' depth-sorted lists cut into segments on separate workgroups and combined (what a view
+    with few busy tiles gets by default) - same image, same last contributors, same gradients as one workgroup per tile, and
+    both equal the oracle.  opaque: high opacities, so most pixels stop (T < 1e-4) inside some segment and the combine
+    pass has to walk that segment again from the true transmittance."""
+    from neuma_amd import _lib
+    lib = _lib.lib()
+    s, means, cov, op, shs, _, _ = _scene(deg=0, K=1500, scale=(0.04, 0.12))
+    if opaque:
+        op = torch.full_like(op, 0.97)
+    gw = torch.randn(3, s.image_height, s.image_width, generator=torch.Generator().manual_seed(5))
+    res = {}
+    try:
+        # split16 / split48: forward and reverse in segments; ckpt32: sequential forward leaving checkpoints, reverse in segments
+        for mode, (busy, minseg, fwd) in {"whole": (0, 1024, 1 << 21), "split16": (1 << 20, 16, 1 << 40),
+                                          "split48": (1 << 20, 48, 1 << 40), "ckpt32": (1 << 20, 32, 0)}.items():
+            _lib.check(lib.nm_raster_set_split(busy, minseg, fwd), "nm_raster_set_split")
+            rast = _gpu_raster(s)
+            ins = [t.to(dev()).requires_grad_(True) for t in (means, shs, op, cov)]
+            img, _ = rast(means3D=ins[0], means2D=None, opacities=ins[2], shs=ins[1], cov3D_precomp=ins[3])
+            grads = torch.autograd.grad((img * gw.to(dev())).sum(), ins)
+            res[mode] = (img.detach().clone(), [g.clone() for g in grads])
+            from neuma_amd.render import split_plan
+            work, seg = split_plan(rast, ins[0], ins[2], shs=ins[1], cov3D_precomp=ins[3])
+            assert (work == 0) if mode == "whole" else (work > 200 and seg % 16 == 0 and seg >= minseg), (mode, work, seg)
+    finally:
+        _lib.check(lib.nm_raster_set_split(256, 512, 1 << 21), "nm_raster_set_split")
+    if opaque:
+        assert float((res["whole"][0].mean(0) < 0.999).float().mean()) > 0.2      # a good part of the image is covered ...
+    for mode in ("split16", "split48", "ckpt32"):
+        # images: a pixel differs only by the order of the products (prefix x segment instead of one running product)
+        assert abs_max(res[mode][0], res["whole"][0]) < 2e-6, mode
+        for nme, a, b in zip(["means3D", "shs", "opacity", "cov3D"], res[mode][1], res["whole"][1]):
+            assert rel_max(a, b) < 2e-5, (mode, nme)
+    oins = [t.double().requires_grad_(True) for t in (means, shs, op, cov)]
+    sd = orr.Settings(*[(f.double() if torch.is_tensor(f) else f) for f in s])
+    oimg, _, aux = orr.render(sd, oins[0], oins[3], oins[2], shs=oins[1], return_aux=True)
+    ograds = torch.autograd.grad((oimg * gw.double()).sum(), oins)
+    assert abs_max(res["split16"][0], oimg) < 1e-3
+    for nme, a, b, tol in zip(["means3D", "shs", "opacity", "cov3D"], res["split16"][1], ograds, [2e-3, 1e-3, 1e-3, 2e-3]):
+        assert rel_max(a, b) < tol, nme

@@ -119,10 +119,12 @@ def test_render_stripes_background_linearity_and_gradients(rt):
     for r0, r1 in [(0, rows // 3), (rows // 3, rows // 2), (rows // 2, rows)]:
         part = rt.render_view(m, dg, 0, tile_rows=(r0, r1))
         y0, y1 = r0 * 16, min(H, r1 * 16)
-        assert torch.equal(part[:, y0:y1], full[:, y0:y1])
+        # (bit for bit when the stripe and the full view are composited with the same plan; a few-tile view is split into
+        # list segments whose length depends on the stripe: transmittance products in another order, 2e-6)
+        assert abs_max(part[:, y0:y1], full[:, y0:y1]) < 2e-6
         acc += part.detach()
         gacc += torch.autograd.grad((part * gw).sum(), m)[0]
-    assert torch.equal(acc, full.detach()) and rel_max(gacc, gfull) < 1e-4
+    assert abs_max(acc, full.detach()) < 2e-6 and rel_max(gacc, gfull) < 1e-4
     bg0 = rt.background
     imgs = {}
     for name, val in (("black", 0.0), ("grey", 0.5), ("white", 1.0)):

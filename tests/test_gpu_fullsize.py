@@ -94,11 +94,13 @@ def test_render_1080p_stripes_background_linearity_and_gradient_consistency(rt):
     for r0, r1 in [(0, rows // 3), (rows // 3, rows // 2), (rows // 2, rows)]:
         part = rt.render_view(m, dg, 0, tile_rows=(r0, r1))
         y0, y1 = r0 * 16, min(H, r1 * 16)
-        assert torch.equal(part[:, y0:y1], full[:, y0:y1])
+        # (bit for bit when the stripe and the full view are composited with the same plan; a few-tile view is split into
+        # list segments whose length depends on the stripe: transmittance products in another order, 2e-6)
+        assert abs_max(part[:, y0:y1], full[:, y0:y1]) < 2e-6
         acc += part.detach()
         (gp,) = torch.autograd.grad((part * gw).sum(), m)
         gacc += gp
-    assert torch.equal(acc, full.detach())
+    assert abs_max(acc, full.detach()) < 2e-6
     assert rel_max(gacc, gfull) < 1e-4
     # out = C + T_final * bg is affine in the background colour
     bg0 = rt.background
