@@ -755,14 +755,31 @@ __global__ void __launch_bounds__(1024) k_split_plan(RK k, int nbx, uint32_t bus
     return hi > lo ? (uint32_t)(hi - lo) : 0u;
   };
   unsigned long long tot = 0ull; uint32_t busy = 0u;
-  if (!hdr[3])
-    for (int i = tid; i < ntile; i += 1024) { const uint32_t n = list_len(i); tot += n; busy += n ? 1u : 0u; }
+  if (!hdr[3]) {         // all tiles of a bin share its list: one thread per bin
+    const int nby = (k.gy + NM_BT - 1) / NM_BT;
+    for (int bin = tid; bin < nbx * nby; bin += 1024) {
+      const int bx = bin % nbx, by = bin / nbx;
+      const int nx = min(k.gx, (bx + 1) * NM_BT) - bx * NM_BT;
+      const int ny = min(k.ty1, (by + 1) * NM_BT) - max(k.ty0, by * NM_BT);
+      if (nx <= 0 || ny <= 0) continue;
+      const long long lo = off[bin * NM_NS], hi = min((long long)off[(bin + 1) * NM_NS], cap);
+      if (hi > lo) { tot += (unsigned long long)(hi - lo) * (unsigned)(nx * ny); busy += (uint32_t)(nx * ny); }
+    }
+  }
   if (busy) { atomicAdd(&s_total, tot); atomicAdd(&s_busy, busy); }
   __syncthreads();
   const bool split = s_busy > 0u && s_busy < busy_limit;
   uint32_t seg = (uint32_t)((s_total + NM_SPLIT_WGS - 1) / NM_SPLIT_WGS);
   seg = max(seg, min_seg);
   seg = (seg + 15u) & ~15u;
+  if (!split) {                                  // the usual case (a view that fills the chip): no candidates
+    for (int i = tid; i < ntile; i += 1024) {
+      const int t = (i / k.gx + k.ty0) * k.gx + i % k.gx;
+      tile_rec[t] = 0xFFFFFFFFu; tile_ns[t] = 0u; tile_cnt[t] = 0u; tile_mode[t] = 0u;
+    }
+    if (tid == 0) { hdr[8] = 0u; hdr[9] = seg; hdr[10] = 0u; }
+    return;
+  }
   for (int i0 = 0; i0 < ntile; i0 += 1024) {     // segments per tile, exclusive prefix in tile order
     const int i = i0 + tid;
     uint32_t ns = 0u;
