@@ -231,18 +231,22 @@ __device__ __forceinline__ void stage_raw_weights(const float* __restrict__ w0, 
     if (i < NM_W2) raw[NM_RAW2 + (i >> 6) * NM_RLD + (i & 63)] = a2[k];
   }
 }
+// Operand order in LDS: the A operands of four consecutive MFMAs sit side by side per lane - row (op / 4), lane, op % 4 -
+// so that a lane fetches them with ONE 16-byte LDS read (an LDS instruction between MFMAs is not free: ~6 cycles of the
+// wave's issue, tools/ubench_valu.hip).
+#define NM_WIDX(idx) (((((idx) >> 6) >> 2) * 64 + ((idx) & 63)) * 4 + (((idx) >> 6) & 3))
 __device__ __forceinline__ void stage_fwd_weights(const float* raw, float* P0, float* P1, float* P2) {
   const float *w0 = raw, *w1 = raw + NM_RAW1, *w2 = raw + NM_RAW2;
   const int tid = threadIdx.x;
   for (int idx = tid; idx < 16 * 64; idx += blockDim.x) {
     int l = idx & 63, op = idx >> 6, ks = op >> 2, rt = op & 3, k = 4 * ks + (l >> 4);
-    P0[idx] = k < 13 ? w0[(16 * rt + (l & 15)) * 13 + k] : 0.f;
+    P0[NM_WIDX(idx)] = k < 13 ? w0[(16 * rt + (l & 15)) * 13 + k] : 0.f;
     int reg = op & 3, rtp = op >> 2, row = l & 15;
-    P2[idx] = row < 9 ? w2[row * NM_RLD + 16 * rtp + 4 * (l >> 4) + reg] : 0.f;
+    P2[NM_WIDX(idx)] = row < 9 ? w2[row * NM_RLD + 16 * rtp + 4 * (l >> 4) + reg] : 0.f;
   }
   for (int idx = tid; idx < 64 * 64; idx += blockDim.x) {
     int l = idx & 63, op = idx >> 6, rt = op & 3, reg = (op >> 2) & 3, rtp = op >> 4;
-    P1[idx] = w1[(16 * rt + (l & 15)) * NM_RLD + 16 * rtp + 4 * (l >> 4) + reg];
+    P1[NM_WIDX(idx)] = w1[(16 * rt + (l & 15)) * NM_RLD + 16 * rtp + 4 * (l >> 4) + reg];
   }
 }
 __device__ __forceinline__ void stage_bwd_weights(const float* raw, float* Q0, float* Q1, float* Q2) {
@@ -250,15 +254,15 @@ __device__ __forceinline__ void stage_bwd_weights(const float* raw, float* Q0, f
   const int tid = threadIdx.x;
   for (int idx = tid; idx < 12 * 64; idx += blockDim.x) {
     int l = idx & 63, op = idx >> 6, ks = op >> 2, rt = op & 3, row = 4 * ks + (l >> 4);
-    Q2[idx] = row < 9 ? w2[row * NM_RLD + 16 * rt + (l & 15)] : 0.f;
+    Q2[NM_WIDX(idx)] = row < 9 ? w2[row * NM_RLD + 16 * rt + (l & 15)] : 0.f;
   }
   for (int idx = tid; idx < 16 * 64; idx += blockDim.x) {
     int l = idx & 63, op = idx >> 6, reg = op & 3, rtp = op >> 2, col = l & 15;
-    Q0[idx] = col < 13 ? w0[(16 * rtp + 4 * (l >> 4) + reg) * 13 + col] : 0.f;
+    Q0[NM_WIDX(idx)] = col < 13 ? w0[(16 * rtp + 4 * (l >> 4) + reg) * 13 + col] : 0.f;
   }
   for (int idx = tid; idx < 64 * 64; idx += blockDim.x) {
     int l = idx & 63, op = idx >> 6, rt = op & 3, reg = (op >> 2) & 3, rtp = op >> 4;
-    Q1[idx] = w1[(16 * rtp + 4 * (l >> 4) + reg) * NM_RLD + 16 * rt + (l & 15)];
+    Q1[NM_WIDX(idx)] = w1[(16 * rtp + 4 * (l >> 4) + reg) * NM_RLD + 16 * rt + (l & 15)];
   }
 }
 
@@ -310,8 +314,9 @@ __device__ __forceinline__ void nm_features(const M3& F, float z[13], M3& R, M3&
 // wait ...) exposed one LDS latency per 8 MFMAs (29 % of the wave's cycles were spent waiting, SQ_WAIT_INST_ANY in
 // profiles/r02a).  Here the reads of group g+1 are issued BEFORE the MFMAs of group g (sched_barrier keeps the compiler
 // from sinking them back), and the first group of a chain is fetched by the caller ahead of the phase in front of it.
-// LDS instructions issued between MFMAs cost nothing (the matrix pipe is busy 32 cycles per MFMA); VALU work does not
-// hide, so everything that can be an LDS access in the shadow of a chain is placed there (`mid`).
+// An LDS instruction between MFMAs costs its issue slot only (~6 cycles, nothing when it replaces a wait); VALU work
+// does not hide at all, so everything that can be an LDS access in the shadow of a chain is placed there
+// (`mid`), and the operands of four MFMAs come with one 16-byte read.
 #define NM_SB() __builtin_amdgcn_sched_barrier(0)
 template <int G>
 struct AGroup {
@@ -319,8 +324,12 @@ struct AGroup {
 };
 template <int G>
 __device__ __forceinline__ void a_fetch(AGroup<G>& o, const float* __restrict__ base, int lane, int grp) {
+  static_assert(G % 4 == 0, "groups of four operands (one 16-byte read each)");
 #pragma unroll
-  for (int i = 0; i < G; ++i) o.a[i] = base[(grp * G + i) * 64 + lane];
+  for (int q = 0; q < G / 4; ++q) {
+    const f4 v = *reinterpret_cast<const f4*>(base + ((grp * (G / 4) + q) * 64 + lane) * 4);
+    o.a[4 * q] = v[0]; o.a[4 * q + 1] = v[1]; o.a[4 * q + 2] = v[2]; o.a[4 * q + 3] = v[3];
+  }
 }
 struct NoMid {
   __device__ __forceinline__ void operator()() const {}

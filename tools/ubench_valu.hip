@@ -79,6 +79,39 @@ __global__ void __launch_bounds__(256) k(float* out, long long* cyc, int reps) {
                         "v_mfma_f32_16x16x4_f32 %2, %4, %5, %2\n v_mfma_f32_16x16x4_f32 %3, %4, %5, %3\n"
                         : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3) : "v"(c), "v"(d));)
       a0 += acc0[0] + acc1[1] + acc2[2] + acc3[3];
+    } else if (MODE == 14) {  // mfma only, 8 accumulators, distinct A/B registers per MFMA (32 MFMAs)
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      f4 q0 = {0, 0, 0, 0}, q1 = q0, q2 = q0, q3 = q0, q4 = q0, q5 = q0, q6 = q0, q7 = q0;
+      REP8(asm volatile("v_mfma_f32_16x16x4_f32 %0, %8, %9, %0\n v_mfma_f32_16x16x4_f32 %1, %10, %11, %1\n"
+                        "v_mfma_f32_16x16x4_f32 %2, %12, %13, %2\n v_mfma_f32_16x16x4_f32 %3, %14, %15, %3\n"
+                        : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7)
+                        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7));)
+      a0 += q0[0] + q1[1] + q2[2] + q3[3];
+    } else if (MODE == 15) {  // mfma with accumulators in AGPRs ("a" constraint), 4 in rotation
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      f4 acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+      REP8(asm volatile("v_mfma_f32_16x16x4_f32 %0, %4, %5, %0\n v_mfma_f32_16x16x4_f32 %1, %4, %5, %1\n"
+                        "v_mfma_f32_16x16x4_f32 %2, %4, %5, %2\n v_mfma_f32_16x16x4_f32 %3, %4, %5, %3\n"
+                        : "+a"(acc0), "+a"(acc1), "+a"(acc2), "+a"(acc3) : "v"(c), "v"(d));)
+      a0 += acc0[0] + acc1[1] + acc2[2] + acc3[3];
+    } else if (MODE == 16) {  // 32x32x2 f32 (16 MFMAs = the flops of 32 16x16x4), 2 accumulators in rotation
+      typedef float f16v __attribute__((ext_vector_type(16)));
+      f16v r0 = {0}, r1 = {0};
+      REP8(asm volatile("v_mfma_f32_32x32x2_f32 %0, %2, %3, %0\n v_mfma_f32_32x32x2_f32 %1, %2, %3, %1\n"
+                        : "+v"(r0), "+v"(r1) : "v"(c), "v"(d));)
+      a0 += r0[0] + r1[1];
+    } else if (MODE == 17) {  // mfma 16x16x4 interleaved with one ds_read_b32 each (LDS in the shadow)
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      __shared__ float lds[256];
+      lds[threadIdx.x] = a0;
+      f4 acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+      float l0, l1, l2, l3;
+      const float* lp = lds + (threadIdx.x & 63);
+      REP8(asm volatile("v_mfma_f32_16x16x4_f32 %0, %8, %9, %0\n ds_read_b32 %4, %10\n v_mfma_f32_16x16x4_f32 %1, %8, %9, %1\n ds_read_b32 %5, %10 offset:256\n"
+                        "v_mfma_f32_16x16x4_f32 %2, %8, %9, %2\n ds_read_b32 %6, %10 offset:512\n v_mfma_f32_16x16x4_f32 %3, %8, %9, %3\n ds_read_b32 %7, %10 offset:768\n s_waitcnt lgkmcnt(0)\n"
+                        : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3), "=v"(l0), "=v"(l1), "=v"(l2), "=v"(l3)
+                        : "v"(c), "v"(d), "v"((unsigned)(size_t)lp));)
+      a0 += acc0[0] + acc1[1] + acc2[2] + acc3[3] + l0 + l1 + l2 + l3;
     }
   }
   long long t1 = clock64();
@@ -126,5 +159,9 @@ int main() {
   run<10>("v_accvgpr_write x32 + v_accvgpr_read x32", 64, out, cyc);
   run<13>("v_mfma_f32_16x16x4_f32 x32, 4 accumulators", 32, out, cyc);
   run<12>("(mfma ; 2 independent v_fma) x32  [96 instr]", 96, out, cyc);
+  run<14>("v_mfma_f32_16x16x4_f32 x32, 4 acc, distinct A/B registers", 32, out, cyc);
+  run<15>("v_mfma_f32_16x16x4_f32 x32, 4 accumulators in AGPRs", 32, out, cyc);
+  run<16>("v_mfma_f32_32x32x2_f32 x16, 2 accumulators", 16, out, cyc);
+  run<17>("(mfma ; ds_read_b32) x32, wait per 4", 32, out, cyc);
   return 0;
 }
