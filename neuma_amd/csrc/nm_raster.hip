@@ -361,6 +361,9 @@ __global__ void __launch_bounds__(256) k_bin_count(RK k, int K, int nbx, const i
                                                    const uint2* __restrict__ zrange, int nrange, uint32_t* __restrict__ pad,
                                                    PairLog* __restrict__ log, uint32_t* __restrict__ hdr, long long cap) {
   __shared__ uint32_t s_lo[4], s_hi[4];
+  __shared__ int s_excl[4][64];
+  __shared__ TileCull s_tc[4][64];
+  __shared__ int4 s_geo[4][64], s_bin[4][64];
   const int lane = threadIdx.x & 63;
   uint32_t zlo = 0x7f800000u, zhi = 0u;
   for (int q = threadIdx.x; q < nrange; q += 256) { const uint2 z = zrange[q]; zlo = min(zlo, z.x); zhi = max(zhi, z.y); }
@@ -389,7 +392,8 @@ __global__ void __launch_bounds__(256) k_bin_count(RK k, int K, int nbx, const i
   const int bx0 = x0 / NM_BT, bx1 = live ? (x1 - 1) / NM_BT : -1, by0 = y0 / NM_BT, by1 = live ? (y1 - 1) / NM_BT : -1;
   // ---- log slots: one per bin of the rectangle (an upper bound - bins no tile of which passes the conic test leave a dead
   //      entry), exclusive prefix over the lanes, ONE atomic for the wave
-  const int mine = live ? (bx1 - bx0 + 1) * (by1 - by0 + 1) : 0;
+  const int nbw = bx1 - bx0 + 1;
+  const int mine = live ? nbw * (by1 - by0 + 1) : 0;
   int incl = mine;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
@@ -397,22 +401,40 @@ __global__ void __launch_bounds__(256) k_bin_count(RK k, int K, int nbx, const i
   uint32_t base = 0;
   if (lane == 0 && wave_total) base = atomicAdd(&hdr[2], (uint32_t)wave_total);
   base = (uint32_t)__shfl((int)base, 0, 64);
-  long long at = (long long)base + (incl - mine);
-  for (int by = by0; by <= by1; ++by)
-    for (int bx = bx0; bx <= bx1; ++bx) {
+  // ---- the wave's pairs are spread over its lanes, one pair per lane and round: a thread that walked the bins of ITS
+  //      Gaussian waited for one returning atomic per bin, one after the other (up to 25 round trips, and the wave waits
+  //      for its longest lane: 146 us).  Now 64 atomics are in flight per round, the rounds are balanced, and the log is
+  //      written in whole lines (it was 94 MB of HBM writes for 24 MB of entries).
+  const int wv = threadIdx.x >> 6;
+  s_excl[wv][lane] = incl - mine;
+  s_tc[wv][lane] = tc;
+  s_geo[wv][lane] = make_int4(x0, y0, x1, y1);
+  s_bin[wv][lane] = make_int4(bx0, by0, nbw, slab);
+  __builtin_amdgcn_wave_barrier();
+  for (int p0 = 0; p0 < wave_total; p0 += 64) {
+    const int pr = p0 + lane;
+    if (pr < wave_total) {
+      int lo_ = 0, hi_ = 64;                       // owner: the last lane whose exclusive prefix is <= pr
+#pragma unroll
+      for (int it = 0; it < 6; ++it) { const int mid = (lo_ + hi_) >> 1; if (s_excl[wv][mid] <= pr) lo_ = mid; else hi_ = mid; }
+      const int q = pr - s_excl[wv][lo_];
+      const int4 g = s_geo[wv][lo_], bn = s_bin[wv][lo_];
+      const TileCull t = s_tc[wv][lo_];
+      const int by = bn.y + q / bn.z, bx = bn.x + q % bn.z;
       uint32_t m = 0;
-      for (int ty = max(y0, by * NM_BT); ty < min(y1, by * NM_BT + NM_BT); ++ty)
-        for (int tx = max(x0, bx * NM_BT); tx < min(x1, bx * NM_BT + NM_BT); ++tx)
-          m |= tile_contributes(tc, tx, ty) ? (1u << ((ty - by * NM_BT) * NM_BT + (tx - bx * NM_BT))) : 0u;
+      for (int ty = max(g.y, by * NM_BT); ty < min(g.w, by * NM_BT + NM_BT); ++ty)
+        for (int tx = max(g.x, bx * NM_BT); tx < min(g.z, bx * NM_BT + NM_BT); ++tx)
+          m |= tile_contributes(t, tx, ty) ? (1u << ((ty - by * NM_BT) * NM_BT + (tx - bx * NM_BT))) : 0u;
       PairLog e;
-      e.cell = 0xffffffffu; e.rank = 0u; e.id = (uint32_t)i; e.mask = m;
+      e.cell = 0xffffffffu; e.rank = 0u; e.id = (uint32_t)(blockIdx.x * blockDim.x + (wv << 6) + lo_); e.mask = m;
       if (m) {
-        e.cell = (uint32_t)((by * nbx + bx) * NM_NS + slab);
+        e.cell = (uint32_t)((by * nbx + bx) * NM_NS + bn.w);
         e.rank = atomicAdd(&pad[(size_t)e.cell * NM_PAD], 1u);
       }
+      const long long at = (long long)base + pr;
       if (at < cap) log[at] = e;
-      ++at;
     }
+  }
 }
 
 // padded counters -> compact array; per-bin totals (one workgroup per bin, one thread per depth slab)
