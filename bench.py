@@ -351,7 +351,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {cfg['N']} particles / {cfg['G']}^3 grid / {cfg['K']} Gaussians / "
                                    f"{cfg['W']}x{cfg['H']}", "substeps_per_frame": cfg["S"], "views_per_frame": cfg["V"],
-                       "sh_degree": cfg["sh"], "material": cfg["mat"] + "_0300 + LoRA r16", "path": "per-op" if (args.per_op or shard_sim) else "fused-rollout",
+                       "sh_degree": cfg["sh"], "material": cfg["mat"] + "_0300 + LoRA r16", "path": "per-op" if args.per_op else ("fused-rollout (library-level sharded loop)" if shard_sim else "fused-rollout"),
                        "parallelism": (("particle-sharded sim" if shard_sim else "replicated sim") + " + render stripes") if world > 1 else "single GPU",
                        "start_state": rt.state_kind,
                        "touched_grid_nodes": int(rt.touched_nodes), "gaussian_tile_pairs_per_view": int(D)},

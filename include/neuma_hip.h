@@ -265,6 +265,40 @@ int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cfg, const n
                         const void* gridcache, const float* gstate_last, float* gstate_first, float* gw_e,
                         float* gw_p, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Particle-sharded roll-out (no reference counterpart - the reference is single-device): the same S-substep
+ * node for ONE rank's share of the particles.  The MPM part of every substep is cut at the two points where the grid
+ * blocks that several ranks touch have to be summed ("Particle-sharded substep" above); the loop over substeps and phases
+ * - launches and collectives alike - runs inside the library, on `stream`.  The collectives themselves are the caller's
+ * (one process per GPU: torch.distributed over RCCL; any transport in tests): nm_comm is a table of two functions that
+ * must enqueue, in stream order on `stream`,
+ *   all_gather_i32      recv[r * count + i] = rank r's send[i]   (count = 1 + cap int32 per rank: the ranks' block lists)
+ *   all_reduce_sum_f32  buf[i] = sum over ranks of buf[i]        (count = cap_shared * 256 floats: the shared blocks)
+ * and return 0 on success.  send / recv / buf point into `shard_ws`.  Per substep: one all-gather + one all-reduce in the
+ * forward pass, one all-reduce in the reverse sweep.  gridcache is mandatory (grid_cache_blocks >= the blocks a rank
+ * touches): the reverse sweep restores the already-summed grid from it - there is no recompute across ranks.
+ * shard_ws: device memory of nm_rollout_shard_workspace(world, cap, cap_shared, substeps) bytes, written by the forward
+ * pass (the shared-block list of every substep) and handed unchanged to the backward pass.  Capacity overflows do not
+ * stop the roll-out: they set bits in a status word (nm_rollout_shard_status: 1 = a rank listed more than `cap` blocks,
+ * 2 = more than `cap_shared` blocks are shared, 4 = a grid cache record overflowed) - any bit means the results are
+ * incomplete and the caller must enlarge the capacity and redo the roll-out.  A rank with n = 0 particles takes part. */
+typedef struct nm_comm {
+  int32_t world, rank;
+  int (*all_gather_i32)(void* user, const int32_t* send, int32_t* recv, int64_t count, void* stream);
+  int (*all_reduce_sum_f32)(void* user, float* buf, int64_t count, void* stream);
+  void* user;
+} nm_comm;
+size_t nm_rollout_shard_workspace(int32_t world, int32_t cap, int32_t cap_shared, int32_t substeps);
+int nm_rollout_forward_sharded(nm_mpm* h, int32_t n, const nm_rollout_cfg* cfg, const nm_statics* st,
+                               const nm_mlp* elasticity, const nm_mlp* plasticity, float* states, void* gridcache,
+                               void* workspace, size_t workspace_bytes, const nm_comm* comm, int32_t cap,
+                               int32_t cap_shared, void* shard_ws, size_t shard_ws_bytes, void* stream);
+int nm_rollout_backward_sharded(nm_mpm* h, int32_t n, const nm_rollout_cfg* cfg, const nm_statics* st,
+                                const nm_mlp* elasticity, const nm_mlp* plasticity, const float* states,
+                                const void* gridcache, const float* gstate_last, float* gstate_first, float* gw_e,
+                                float* gw_p, void* workspace, size_t workspace_bytes, const nm_comm* comm, int32_t cap,
+                                int32_t cap_shared, const void* shard_ws, size_t shard_ws_bytes, void* stream);
+int nm_rollout_shard_status(const void* shard_ws, int32_t* status_host, void* stream);
+
 /* ------------------------------------------------------------------ Particle-GS binding (modules/tune/utils.py) */
 
 /* torch.sparse.mm(bindings, X) of compute_bindings_xyz / compute_bindings_F, tune/utils.py:424-472,

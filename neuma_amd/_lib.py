@@ -46,6 +46,15 @@ class nm_rollout_cfg(C.Structure):
                 ("cache_verified", C.c_int32), ("svd_adjoint", C.c_int32)]
 
 
+COMM_ALL_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+COMM_ALL_REDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+
+class nm_comm(C.Structure):
+    _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("all_gather_i32", COMM_ALL_GATHER),
+                ("all_reduce_sum_f32", COMM_ALL_REDUCE), ("user", C.c_void_p)]
+
+
 # name -> (restype, argtypes); kept in one table so tests can check the exports against the header
 _P, _I32, _I64, _F, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 SIGNATURES = {
@@ -110,6 +119,13 @@ SIGNATURES = {
                                      C.POINTER(nm_mlp), _P, _P, _P, _SZ, _P]),
     "nm_rollout_backward": (C.c_int, [_P, _I32, C.POINTER(nm_rollout_cfg), C.POINTER(nm_statics), C.POINTER(nm_mlp),
                                       C.POINTER(nm_mlp), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "nm_rollout_shard_workspace": (_SZ, [_I32, _I32, _I32, _I32]),
+    "nm_rollout_forward_sharded": (C.c_int, [_P, _I32, C.POINTER(nm_rollout_cfg), C.POINTER(nm_statics), C.POINTER(nm_mlp),
+                                             C.POINTER(nm_mlp), _P, _P, _P, _SZ, C.POINTER(nm_comm), _I32, _I32, _P, _SZ, _P]),
+    "nm_rollout_backward_sharded": (C.c_int, [_P, _I32, C.POINTER(nm_rollout_cfg), C.POINTER(nm_statics), C.POINTER(nm_mlp),
+                                              C.POINTER(nm_mlp), _P, _P, _P, _P, _P, _P, _P, _SZ, C.POINTER(nm_comm), _I32, _I32,
+                                              _P, _SZ, _P]),
+    "nm_rollout_shard_status": (C.c_int, [_P, _P, _P]),
 }
 
 _lib = None

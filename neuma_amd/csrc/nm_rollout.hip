@@ -192,3 +192,196 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
   if (rc) return rc;
   return nm_material_wgrad_reduce(w.part_p, n, gw_p, gw_p + 64 * 13, gw_p + 64 * 13 + 64 * 64, 0, stream);
 }
+
+// ---------------------------------------------------------------- particle-sharded roll-out
+// The same S-substep node for ONE rank's share of the particles: the substep's MPM part is cut at the two points where the
+// grid blocks several ranks touch have to be summed (include/neuma_hip.h, "Particle-sharded substep"), and the loop -
+// launches and collectives alike - runs here, in the library, on the caller's stream.  The collectives are the caller's
+// (nm_comm: torch.distributed over RCCL in production, gloo in the tests); the library owns everything between them.
+struct ShardWs {
+  int32_t* status;   // capacity overflow bits of the roll-out (nm_mpm_shared_blocks / nm_mpm_forward_finish)
+  int32_t* mine;     // this rank's block list: [0] count, [1..cap] ids
+  int32_t* gathered; // world x (1 + cap)
+  int32_t* shared;   // per substep: 2 + 2 * cap_shared (kept for the reverse sweep)
+  float* buf;        // cap_shared x 64 float4: the all-reduced payload
+  void* sws;         // workspace of nm_mpm_shared_blocks
+  size_t sws_bytes, shared_stride, total;
+};
+static ShardWs carve_shard(void* base, int world, int cap, int cap_shared, int substeps) {
+  ShardWs w;
+  char* p = (char*)base;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { void* r = p + o; o += al256r(bytes); return r; };
+  w.status = (int32_t*)take(256);
+  w.mine = (int32_t*)take((size_t)(1 + cap) * sizeof(int32_t));
+  w.gathered = (int32_t*)take((size_t)world * (1 + cap) * sizeof(int32_t));
+  w.shared_stride = al256r((size_t)(2 + 2 * cap_shared) * sizeof(int32_t)) / sizeof(int32_t);
+  w.shared = (int32_t*)take((size_t)(substeps > 0 ? substeps : 1) * w.shared_stride * sizeof(int32_t));
+  w.buf = (float*)take((size_t)cap_shared * 64 * 4 * sizeof(float));
+  w.sws_bytes = nm_mpm_shared_workspace(world, cap);
+  w.sws = take(w.sws_bytes);
+  w.total = o;
+  return w;
+}
+extern "C" size_t nm_rollout_shard_workspace(int32_t world, int32_t cap, int32_t cap_shared, int32_t substeps) {
+  if (world < 1 || cap < 1 || cap_shared < 1 || substeps < 1) return 0;
+  return carve_shard(nullptr, world, cap, cap_shared, substeps).total;
+}
+static int shard_args_ok(const nm_comm* comm, int32_t cap, int32_t cap_shared, const nm_rollout_cfg* cfg, const void* gridcache,
+                         const void* shard_ws, size_t shard_ws_bytes, ShardWs& sw) {
+  NM_REQUIRE(comm && comm->all_gather_i32 && comm->all_reduce_sum_f32 && comm->world >= 1 && comm->rank >= 0 && comm->rank < comm->world,
+             "nm_comm incomplete");
+  NM_REQUIRE(cap >= 1 && cap_shared >= 1, "cap and cap_shared must be positive");
+  NM_REQUIRE(gridcache && cfg->grid_cache_blocks >= 1,
+             "the sharded roll-out needs the grid cache (the reverse sweep restores the summed grid from it; there is no recompute across ranks)");
+  sw = carve_shard(const_cast<void*>(shard_ws), comm->world, cap, cap_shared, cfg->substeps);
+  if (!shard_ws || shard_ws_bytes < sw.total) {
+    nm_set_error("sharded roll-out workspace too small: need %zu got %zu", sw.total, shard_ws_bytes);
+    return NM_ERR_WORKSPACE;
+  }
+  return NM_OK;
+}
+// {mv, m} (which = 0) or the node-velocity adjoint (which = 1) of the blocks in `shared`: summed over the ranks
+static int shard_sum_blocks(nm_mpm* h, const nm_comm* comm, int which, const int32_t* shared, int cap_shared, float* buf, void* stream) {
+  int rc = nm_mpm_blocks_pack(h, which, shared, cap_shared, buf, stream);
+  if (rc) return rc;
+  if (comm->all_reduce_sum_f32(comm->user, buf, (int64_t)cap_shared * 64 * 4, stream)) {
+    nm_set_error("nm_comm.all_reduce_sum_f32 failed");
+    return NM_ERR_INVALID;
+  }
+  return nm_mpm_blocks_unpack(h, which, shared, cap_shared, buf, stream);
+}
+
+extern "C" int nm_rollout_forward_sharded(nm_mpm* h, int32_t n, const nm_rollout_cfg* cfg, const nm_statics* st, const nm_mlp* we,
+                                          const nm_mlp* wp, float* states, void* gridcache, void* workspace, size_t workspace_bytes,
+                                          const nm_comm* comm, int32_t cap, int32_t cap_shared, void* shard_ws, size_t shard_ws_bytes,
+                                          void* stream) {
+  NM_REQUIRE(h && cfg && st && we && wp && states, "null pointer");
+  NM_REQUIRE(n >= 0 && cfg->substeps >= 1, "bad sizes");
+  ShardWs sw;
+  int rc = shard_args_ok(comm, cap, cap_shared, cfg, gridcache, shard_ws, shard_ws_bytes, sw);
+  if (rc) return rc;
+  RolloutWs w = carve_ws(workspace, n);
+  if (!workspace || workspace_bytes < w.total) {
+    nm_set_error("rollout workspace too small: need %zu got %zu", w.total, workspace_bytes);
+    return NM_ERR_WORKSPACE;
+  }
+  NM_HIP_CHECK(hipMemsetAsync(sw.status, 0, sizeof(int32_t), (hipStream_t)stream));
+  if (n > 0) {
+    rc = nm_material_prepare(we, w.perm_e, stream);
+    if (rc) return rc;
+    rc = nm_material_prepare(wp, w.perm_p, stream);
+    if (rc) return rc;
+  }
+  const int nrec = n > 0 ? n : 1;     // (a rank without particles still walks the exchange, with empty lists)
+  for (int t = 0; t < cfg->substeps; ++t) {
+    nm_particles cur = rec(states, nrec, t), nxt = rec(states, nrec, t + 1);
+    int32_t* shared = sw.shared + (size_t)t * sw.shared_stride;
+    if (n > 0) {
+      rc = nm_material_fwd_launch(n, NM_ELASTICITY, 0.f, cur.F, we, w.perm_e, cur.stress, nullptr, nullptr, stream);   // finetune.py:362
+      if (rc) return rc;
+    }
+    rc = nm_mpm_p2g(h, n, st, &cur, stream);                                  // clear + this rank's scatter (mpm.py:281-290)
+    if (rc) return rc;
+    rc = nm_mpm_active_list(h, sw.mine, cap, stream);
+    if (rc) return rc;
+    if (comm->all_gather_i32(comm->user, sw.mine, sw.gathered, (int64_t)(1 + cap), stream)) {
+      nm_set_error("nm_comm.all_gather_i32 failed");
+      return NM_ERR_INVALID;
+    }
+    rc = nm_mpm_shared_blocks(h, sw.gathered, comm->world, cap, shared, cap_shared, sw.status, sw.sws, sw.sws_bytes, stream);
+    if (rc) return rc;
+    rc = shard_sum_blocks(h, comm, 0, shared, cap_shared, sw.buf, stream);
+    if (rc) return rc;
+    nm_particles trial = nxt;
+    trial.F = w.ftrial;                                                        // g2p leaves the trial F here, plasticity maps it to nxt.F
+    rc = nm_mpm_forward_finish(h, n, st, &cur, &trial, grid_rec(gridcache, cfg, t), cfg->grid_cache_blocks, sw.status, stream);  // :291-297
+    if (rc) return rc;
+    if (n > 0) {
+      rc = nm_material_fwd_launch(n, NM_PLASTICITY, cfg->plasticity_alpha, w.ftrial, wp, w.perm_p, nxt.F, nullptr, nullptr, stream);  // finetune.py:364
+      if (rc) return rc;
+    }
+  }
+  return NM_OK;
+}
+
+extern "C" int nm_rollout_backward_sharded(nm_mpm* h, int32_t n, const nm_rollout_cfg* cfg, const nm_statics* st, const nm_mlp* we,
+                                           const nm_mlp* wp, const float* states, const void* gridcache, const float* gstate_last,
+                                           float* gstate_first, float* gw_e, float* gw_p, void* workspace, size_t workspace_bytes,
+                                           const nm_comm* comm, int32_t cap, int32_t cap_shared, const void* shard_ws,
+                                           size_t shard_ws_bytes, void* stream) {
+  NM_REQUIRE(h && cfg && st && we && wp && states && gstate_last && gstate_first && gw_e && gw_p, "null pointer");
+  NM_REQUIRE(n >= 0 && cfg->substeps >= 1, "bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  ShardWs sw;
+  int rc = shard_args_ok(comm, cap, cap_shared, cfg, gridcache, shard_ws, shard_ws_bytes, sw);
+  if (rc) return rc;
+  RolloutWs w = carve_ws(workspace, n);
+  if (!workspace || workspace_bytes < w.total) {
+    nm_set_error("rollout workspace too small: need %zu got %zu", w.total, workspace_bytes);
+    return NM_ERR_WORKSPACE;
+  }
+  const size_t N = (size_t)(n > 0 ? n : 1);
+  const int nrec = (int)N;
+  float* states_m = const_cast<float*>(states);
+  const float* gin = gstate_last;
+  if (n > 0) {
+    rc = nm_material_prepare(we, w.perm_e, stream);
+    if (rc) return rc;
+    rc = nm_material_prepare(wp, w.perm_p, stream);
+    if (rc) return rc;
+  }
+  const int polar = cfg->svd_adjoint == NM_SVD_ADJOINT_POLAR ? 1 : 0;
+  const float dt = nm_mpm_get_dt(h);
+  for (int t = cfg->substeps - 1; t >= 0; --t) {
+    nm_particles cur = rec(states_m, nrec, t), nxt = rec(states_m, nrec, t + 1);
+    const int32_t* shared = sw.shared + (size_t)t * sw.shared_stride;
+    float* gout = (t == 0) ? gstate_first : ((gin == w.ga) ? w.gb : w.ga);
+    const int wmode = (t == cfg->substeps - 1) ? 1 : 2;
+    if (n > 0 && t == cfg->substeps - 1) {
+      rc = nm_material_bwd_launch(n, NM_PLASTICITY, cfg->plasticity_alpha, cur.F, wp, w.perm_p, gin + 15 * N, w.gFtr, w.part_p, wmode,
+                                  nxt.C, st->enabled, dt, polar ? 2 : 0, nullptr, stream);
+      if (rc) return rc;
+    }
+    nm_particles gn, gc;
+    gn.x = const_cast<float*>(gin); gn.v = const_cast<float*>(gin) + 3 * N; gn.C = const_cast<float*>(gin) + 6 * N;
+    gn.F = w.gFtr; gn.stress = nullptr;
+    gc.x = gout; gc.v = gout + 3 * N; gc.C = gout + 6 * N; gc.F = gout + 15 * N; gc.stress = w.gS;
+    // restore the (summed) grid of substep t from its record, scatter this rank's g2p adjoint, sum the shared blocks of the
+    // node-velocity adjoint over the ranks, then the grid-update and p2g adjoints
+    rc = nm_mpm_backward_begin(h, n, st, &cur, &nxt, &gn, &gc, grid_rec(gridcache, cfg, t), cfg->grid_cache_blocks, stream);
+    if (rc) return rc;
+    rc = shard_sum_blocks(h, comm, 1, shared, cap_shared, sw.buf, stream);
+    if (rc) return rc;
+    rc = nm_mpm_backward_finish(h, n, st, &cur, &gc, stream);
+    if (rc) return rc;
+    if (n > 0) {
+      if (t == 0) {
+        rc = nm_material_bwd_launch(n, NM_ELASTICITY, 0.f, cur.F, we, w.perm_e, w.gS, gc.F, w.part_e, wmode, nullptr, nullptr, 0.f,
+                                    1 | (polar ? 2 : 0), nullptr, stream);
+      } else {
+        nm_particles prev = rec(states_m, nrec, t - 1);
+        rc = nm_material_bwd_pair_launch(n, cur.F, we, w.perm_e, w.gS, gc.F, w.part_e, wmode, cfg->plasticity_alpha, prev.F, wp,
+                                         w.perm_p, w.gFtr, w.part_p, 2, cur.C, st->enabled, dt, polar, nullptr, stream);
+      }
+      if (rc) return rc;
+    }
+    gin = gout;
+  }
+  if (n == 0) {
+    NM_HIP_CHECK(hipMemsetAsync(gw_e, 0, NM_WTOT_ * sizeof(float), s));
+    NM_HIP_CHECK(hipMemsetAsync(gw_p, 0, NM_WTOT_ * sizeof(float), s));
+    return NM_OK;
+  }
+  rc = nm_material_wgrad_reduce(w.part_e, n, gw_e, gw_e + 64 * 13, gw_e + 64 * 13 + 64 * 64, 0, stream);
+  if (rc) return rc;
+  return nm_material_wgrad_reduce(w.part_p, n, gw_p, gw_p + 64 * 13, gw_p + 64 * 13 + 64 * 64, 0, stream);
+}
+
+// status bits of the roll-out's exchanges (1: a rank's block list exceeded cap, 2: more shared blocks than cap_shared,
+// 4: a grid cache record overflowed) - asynchronous copy of one int32 to (pinned) host memory
+extern "C" int nm_rollout_shard_status(const void* shard_ws, int32_t* status_host, void* stream) {
+  NM_REQUIRE(shard_ws && status_host, "null pointer");
+  NM_HIP_CHECK(hipMemcpyAsync(status_host, shard_ws, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return NM_OK;
+}

@@ -90,8 +90,8 @@ class SceneRuntime(object):
         self.rank, self.world, self.group = rank, world, group
         # (NEUMA_SHARD_FORCE=1: keep the exchange machinery on with a single rank, to measure its overhead on one GPU)
         self.shard_sim = bool(shard_sim) and (world > 1 or os.environ.get("NEUMA_SHARD_FORCE") == "1")
-        if self.shard_sim:
-            self.fused = False          # the exchange sits between the phases of a substep: per-operator path
+        # (shard_sim with fused=True: nm_rollout_forward_sharded runs the substep loop, phases and collectives, inside the
+        # library; fused=False: the per-operator classes drive the phases from Python)
         # the render jobs of a frame (views, or view stripes on several GPUs) go round-robin over HIP streams so that one job's
         # binning (small sort / scan kernels) runs under another job's compositing kernel - same results, ~9 % shorter frame
         self.overlap_views = os.environ.get("NEUMA_OVERLAP_VIEWS", "1") != "0"

@@ -28,6 +28,47 @@ def _zeros(count: int, device) -> torch.Tensor:
     return _ZEROS[key]
 
 
+class _ShardLink(object):
+    """nm_comm of one sharded roll-out: the two collectives the library calls back for (include/neuma_hip.h, "Particle-sharded
+    roll-out"), issued through torch.distributed on views of the roll-out's shard workspace.  The library enqueues
+    everything else itself; the callbacks run on the host, in program order, while it does."""
+
+    def __init__(self, exchange, ws: torch.Tensor):
+        import torch.distributed as dist
+        self.ws, self.group, self.world = ws, exchange.group, exchange.world
+        self.error = None
+        base = ws.data_ptr()
+
+        def view(ptr, count, dtype):
+            off = int(ptr) - base
+            return ws[off:off + 4 * int(count)].view(dtype)
+
+        def all_gather(user, send, recv, count, stream):
+            try:
+                dist.all_gather_into_tensor(view(recv, count * self.world, torch.int32), view(send, count, torch.int32), group=self.group)
+                return 0
+            except Exception as e:      # an exception must not unwind through the C frames
+                self.error = e
+                return 1
+
+        def all_reduce(user, buf, count, stream):
+            try:
+                dist.all_reduce(view(buf, count, torch.float32), op=dist.ReduceOp.SUM, group=self.group)
+                return 0
+            except Exception as e:
+                self.error = e
+                return 1
+
+        self._cbs = (L.COMM_ALL_GATHER(all_gather), L.COMM_ALL_REDUCE(all_reduce))      # keep the thunks alive
+        self.comm = L.nm_comm(exchange.world, exchange.rank, self._cbs[0], self._cbs[1], None)
+
+    def check(self, rc: int, what: str):
+        if rc and self.error is not None:
+            e, self.error = self.error, None
+            raise L.NeumaHipError(f"{what}: collective failed: {type(e).__name__}: {e}") from e
+        L.check(rc, what)
+
+
 class _Rollout(autograd.Function):
 
     @staticmethod
@@ -44,6 +85,10 @@ class _Rollout(autograd.Function):
         wp = [t.detach().float().contiguous() for t in (p0, p1, p2)]
         ws_bytes = int(lib.nm_rollout_workspace(n, S))
         ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
+        ex = model.exchange
+        if ex is not None:
+            return _Rollout._forward_sharded(ctx, lib, model, ex, statics, S, float(alpha), int(svd_adjoint), n, states, we, wp, ws,
+                                             ws_bytes)
         # grid cache: only when a backward pass can follow (ground-truth / inference roll-outs skip it)
         cache_blocks = int(cache_blocks) if any(ctx.needs_input_grad) else 0
         gc_bytes = int(lib.nm_rollout_gridcache_bytes(S, cache_blocks)) if cache_blocks > 0 else 0
@@ -66,6 +111,42 @@ class _Rollout(autograd.Function):
             ev = torch.cuda.Event()
             ev.record()
             ctx.cache_status, ctx.cache_event = status, ev
+        ctx.save_for_backward(states, *we, *wp)
+        last = states[S]
+        return (last[:3 * n].view(n, 3), last[3 * n:6 * n].view(n, 3), last[6 * n:15 * n].view(n, 3, 3),
+                last[15 * n:24 * n].view(n, 3, 3))
+
+    @staticmethod
+    def _forward_sharded(ctx, lib, model, ex, statics, S, alpha, svd_adjoint, n, states, we, wp, ws, ws_bytes):
+        """This rank's share of the particles (model.shard(group)): the library runs the whole S-substep loop, phases and
+        collectives, and calls back for the latter (nm_rollout_forward_sharded)."""
+        dev = states.device
+        st = statics.c_struct()
+        if ex.cap is None or ex.cap_shared is None:
+            # capacities from the blocks the start state touches (one p2g of the inputs with zero stress, two host reads)
+            r0 = states[0]
+            r0[24 * n:].zero_()
+            base = r0.data_ptr()
+            cur = L.nm_particles(base, base + 12 * n, base + 24 * n, base + 60 * n, base + 96 * n)
+            L.check(lib.nm_mpm_p2g(model.handle(), n, C.byref(st), C.byref(cur), L.stream_ptr(dev)), "nm_mpm_p2g")
+            ex._ensure_sized()
+        cap, cap_shared = int(ex.cap), int(ex.cap_shared)
+        gcache = torch.empty(int(lib.nm_rollout_gridcache_bytes(S, cap)), dtype=torch.uint8, device=dev)
+        sws_bytes = int(lib.nm_rollout_shard_workspace(ex.world, cap, cap_shared, S))
+        sws = torch.empty(sws_bytes, dtype=torch.uint8, device=dev)
+        link = _ShardLink(ex, sws)
+        cfg = L.nm_rollout_cfg(S, alpha, cap, 0, svd_adjoint)
+        mle = L.nm_mlp(*[L.ptr(t) for t in we])
+        mlp = L.nm_mlp(*[L.ptr(t) for t in wp])
+        link.check(lib.nm_rollout_forward_sharded(model.handle(), n, C.byref(cfg), C.byref(st), C.byref(mle), C.byref(mlp), L.ptr(states),
+                                                  L.ptr(gcache), L.ptr(ws), ws_bytes, C.byref(link.comm), cap, cap_shared, L.ptr(sws),
+                                                  sws_bytes, L.stream_ptr(dev)), "nm_rollout_forward_sharded")
+        ex.watch(lib, sws, dev)          # status word -> pinned host memory; ex.check() raises on a capacity overflow
+        ctx.model, ctx.statics, ctx.S, ctx.alpha, ctx.n = model, statics, S, alpha, n
+        ctx.svd_adjoint = svd_adjoint
+        ctx.cache_blocks, ctx.gcache = cap, gcache
+        ctx.cache_status = ctx.cache_event = None
+        ctx.shard = (ex, sws, sws_bytes, cap, cap_shared)
         ctx.save_for_backward(states, *we, *wp)
         last = states[S]
         return (last[:3 * n].view(n, 3), last[3 * n:6 * n].view(n, 3), last[6 * n:15 * n].view(n, 3, 3),
@@ -95,9 +176,17 @@ class _Rollout(autograd.Function):
         st = ctx.statics.c_struct()
         mle = L.nm_mlp(L.ptr(e0), L.ptr(e1), L.ptr(e2))
         mlp = L.nm_mlp(L.ptr(p0), L.ptr(p1), L.ptr(p2))
-        L.check(lib.nm_rollout_backward(ctx.model.handle(), n, C.byref(cfg), C.byref(st), C.byref(mle), C.byref(mlp),
-                                        L.ptr(states), L.ptr(gcache) if gcache is not None else None, L.ptr(glast), L.ptr(gfirst),
-                                        L.ptr(gwe), L.ptr(gwp), L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "nm_rollout_backward")
+        if getattr(ctx, "shard", None) is not None:
+            ex, sws, sws_bytes, cap, cap_shared = ctx.shard
+            link = _ShardLink(ex, sws)
+            link.check(lib.nm_rollout_backward_sharded(ctx.model.handle(), n, C.byref(cfg), C.byref(st), C.byref(mle), C.byref(mlp),
+                                                       L.ptr(states), L.ptr(gcache), L.ptr(glast), L.ptr(gfirst), L.ptr(gwe), L.ptr(gwp),
+                                                       L.ptr(ws), ws_bytes, C.byref(link.comm), cap, cap_shared, L.ptr(sws), sws_bytes,
+                                                       L.stream_ptr(dev)), "nm_rollout_backward_sharded")
+        else:
+            L.check(lib.nm_rollout_backward(ctx.model.handle(), n, C.byref(cfg), C.byref(st), C.byref(mle), C.byref(mlp),
+                                            L.ptr(states), L.ptr(gcache) if gcache is not None else None, L.ptr(glast), L.ptr(gfirst),
+                                            L.ptr(gwe), L.ptr(gwp), L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "nm_rollout_backward")
         ctx.gcache = None
         torch.nan_to_num_(gfirst, 0.0, 0.0, 0.0)   # interface.py:65-74 at the boundary of the fused node
         a, b = _WSZ[0], _WSZ[0] + _WSZ[1]
@@ -167,7 +256,7 @@ class MPMFusedDiffSim(nn.Module):
         else:
             out = _Rollout.apply(self.model, statics, self.substeps, self.plasticity.alpha, self.grid_cache_blocks(),
                                  L.SVD_ADJOINT[self.svd_adjoint], x, v, C_, F, *e, *p)
-        if self._cache_blocks is None:      # first roll-out: size the cache from what the scene touches
+        if self._cache_blocks is None and self.model.exchange is None:      # first roll-out: size the cache from what the scene touches
             blocks, _ = self.model.grid_stats()
             self._cache_blocks = int(1.5 * blocks) + 64
         return out

@@ -119,6 +119,7 @@ class GridExchange(object):
         self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.generation = 0
         self._mine = self._gathered = self._ws = self._buf = self._scratch_shared = None
+        self._watched = []          # (pinned int32, event) of fused sharded roll-outs whose status word has not been examined
 
     # -- sizing (first substep only: two host reads + two tiny collectives)
     def _ensure_sized(self) -> None:
@@ -169,10 +170,23 @@ class GridExchange(object):
         L.check(lib.nm_mpm_blocks_unpack(h, which, L.ptr(shared), self.cap_shared, L.ptr(self._buf), s), "nm_mpm_blocks_unpack")
 
     # -- status
+    def watch(self, lib, shard_ws: torch.Tensor, device) -> None:
+        """A fused sharded roll-out (rollout._Rollout) keeps its own status word at the head of its workspace: copy it to
+        pinned host memory in stream order; check() looks at it."""
+        host = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+        L.check(lib.nm_rollout_shard_status(L.ptr(shard_ws), C.c_void_p(host.data_ptr()), L.stream_ptr(device)), "nm_rollout_shard_status")
+        ev = torch.cuda.Event()
+        ev.record()
+        self._watched.append((host, ev))
+
     def check(self) -> None:
         """Raise if any substep since the last check exceeded a capacity (one host read).  Called once per backward
         pass by MPMModel.backward and by the frame driver after the forward roll-out."""
         bits = int(self.status.item())
+        for host, ev in self._watched:
+            ev.synchronize()
+            bits |= int(host[0])
+        self._watched = []
         self.generation += 1
         if bits:
             self.status.zero_()

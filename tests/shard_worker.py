@@ -73,9 +73,11 @@ def gpu_substeps(rank, world, port, q, steps=3, cap_shared=None, cap=None):
         q.put({"rank": rank, "error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()})
 
 
-def gpu_frame(rank, world, port, q, name="tiny"):
+def gpu_frame(rank, world, port, q, name="tiny", fused=False):
     """One frame of the driver (materials + roll-out + bindings + render + loss, forward and backward): sharded
-    simulation on `world` ranks vs the single-process frame."""
+    simulation on `world` ranks vs the single-process frame.  fused: the sharded ranks run nm_rollout_forward_sharded /
+    nm_rollout_backward_sharded (substep loop, phases and collectives inside the library) instead of the per-operator
+    classes driven from Python."""
     try:
         dist = _init(rank, world, port)
         from neuma_amd import synth
@@ -84,7 +86,8 @@ def gpu_frame(rank, world, port, q, name="tiny"):
         scene = synth.make_scene(name)
         ref = SceneRuntime(scene, dev, fused=False)
         ref.make_ground_truth()
-        rt = SceneRuntime(scene, dev, rank=rank, world=world, shard_sim=True)
+        rt = SceneRuntime(scene, dev, rank=rank, world=world, shard_sim=True, fused=fused)
+        assert rt.fused == fused and rt.model.exchange is not None
         rt.gt = ref.gt
         for run in (ref, rt):
             # a material that is visibly wrong for the ground truth, so that the LoRA gradients are a signal and not the

@@ -62,8 +62,11 @@ def test_capacity_overflow_is_reported_on_every_rank():
         assert "error" in r and "cap_shared" in r["error"] and "NeumaHipError" in r["error"], r
 
 
-def test_sharded_frame_matches_the_single_process_frame():
-    res = _run(shard_worker.gpu_frame, 2)
+@pytest.mark.parametrize("world,fused", [(2, False), (2, True), (3, True)])
+def test_sharded_frame_matches_the_single_process_frame(world, fused):
+    """fused: the library-level sharded roll-out (nm_rollout_forward_sharded: the loop over substeps, phases and collectives
+    runs in C and calls back for the two collectives per substep); otherwise the phases are driven from Python."""
+    res = _run(shard_worker.gpu_frame, world, "tiny", fused)
     for r in res:
         assert abs(r["loss"] - r["ref_loss"]) <= 1e-3 * abs(r["ref_loss"]) + 1e-9, r
         assert r["x_err"] < 1e-5 and r["F_err"] < 1e-5, r
