@@ -107,21 +107,47 @@ extern "C" int nm_bind_frame(int32_t k, const int32_t* rowptr, const int32_t* co
   return NM_OK;
 }
 
-// loss over (3,H,W): rows [row0,row1) only; grad written for every pixel (zero outside the stripe)
+// loss over (3,H,W): rows [row0,row1) only; grad written for every pixel (zero outside the stripe).  One image row per
+// loop iteration of a workgroup (no per-element index arithmetic), 16-byte accesses when the row length allows it.
+template <bool VEC4>
 __global__ void __launch_bounds__(256) k_pixel_loss(int kind, float scale, int h, int w, int row0, int row1,
                                                     const float* __restrict__ img, const float* __restrict__ gt,
                                                     float* __restrict__ loss, float* __restrict__ grad) {
-  const int total = 3 * h * w;
   float acc = 0.f;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    int y = (i / w) % h;
-    float gval = 0.f;
-    if (y >= row0 && y < row1) {
-      float d = img[i] - gt[i];
-      if (kind == 0) { acc += fabsf(d); gval = d > 0.f ? scale : (d < 0.f ? -scale : 0.f); }
-      else { acc += d * d; gval = 2.f * d * scale; }
+  for (int r = blockIdx.x; r < 3 * h; r += gridDim.x) {
+    const int y = r % h;
+    const bool in = y >= row0 && y < row1;
+    const size_t base = (size_t)r * w;
+    if (VEC4) {
+      const float4* a4 = reinterpret_cast<const float4*>(img + base);
+      const float4* g4 = reinterpret_cast<const float4*>(gt + base);
+      float4* o4 = grad ? reinterpret_cast<float4*>(grad + base) : nullptr;
+      for (int i = threadIdx.x; i < w / 4; i += 256) {
+        float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in) {
+          const float4 a = a4[i], g = g4[i];
+          const float d[4] = {a.x - g.x, a.y - g.y, a.z - g.z, a.w - g.w};
+          float o[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (kind == 0) { acc += fabsf(d[q]); o[q] = d[q] > 0.f ? scale : (d[q] < 0.f ? -scale : 0.f); }
+            else { acc += d[q] * d[q]; o[q] = 2.f * d[q] * scale; }
+          }
+          gv = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        if (o4) o4[i] = gv;
+      }
+    } else {
+      for (int i = threadIdx.x; i < w; i += 256) {
+        float gval = 0.f;
+        if (in) {
+          const float d = img[base + i] - gt[base + i];
+          if (kind == 0) { acc += fabsf(d); gval = d > 0.f ? scale : (d < 0.f ? -scale : 0.f); }
+          else { acc += d * d; gval = 2.f * d * scale; }
+        }
+        if (grad) grad[base + i] = gval;
+      }
     }
-    if (grad) grad[i] = gval;
   }
   acc = nm_wave_sum(acc);
   __shared__ float part[4];
@@ -136,10 +162,15 @@ extern "C" int nm_pixel_loss(int32_t kind, float weight, int32_t h, int32_t w, i
   NM_REQUIRE(h > 0 && w > 0 && img && gt && loss_out, "bad arguments");
   if (row1 <= row0) { row0 = 0; row1 = h; }
   float scale = weight / (3.0f * (float)h * (float)w);
-  int grid = nm_div_up((int64_t)3 * h * w, 256);
+  int grid = 3 * h;
   if (grid > 2048) grid = 2048;
-  NM_LAUNCH(k_pixel_loss, dim3(grid), dim3(256), 0, (hipStream_t)stream, kind, scale, h, w, row0, row1, img, gt,
-                     loss_out, dL_dimg);
+  const bool vec4 = w % 4 == 0 && ((uintptr_t)img | (uintptr_t)gt | (uintptr_t)dL_dimg) % 16 == 0;
+  if (vec4)
+    NM_LAUNCH(k_pixel_loss<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, kind, scale, h, w, row0, row1, img, gt,
+                       loss_out, dL_dimg);
+  else
+    NM_LAUNCH(k_pixel_loss<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, kind, scale, h, w, row0, row1, img, gt,
+                       loss_out, dL_dimg);
   NM_LAUNCH_CHECK();
   return NM_OK;
 }
