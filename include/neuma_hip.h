@@ -374,7 +374,7 @@ int nm_raster_forward(const nm_raster_cfg* cfg, int32_t k, int32_t m, const floa
  * pass for the tiles that still have a barely covered pixel after their first segment, provided the view's candidate
  * lists hold no more than `forward_budget` entries together (every segment of such a tile is composited, also those
  * behind the point where its pixels stop).  Same image, same termination rule (forward.cu: stop when T would fall below
- * 1e-4), same gradients.  Defaults 256 (one tile per CU) / 512 / 2^21; busy_tiles = 0 switches the splitting off,
+ * 1e-4), same gradients.  Defaults 512 (two tiles per CU) / 512 / 2^21; busy_tiles = 0 switches the splitting off,
  * forward_budget = 0 keeps the forward walk sequential.  min_segment is rounded up to a multiple of 16. */
 int nm_raster_set_split(int32_t busy_tiles, int32_t min_segment, int64_t forward_budget);
 /* Exact number of (Gaussian, 16x16 tile) pairs of the view held in `state` - the `num_rendered` the reference extension

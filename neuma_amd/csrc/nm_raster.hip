@@ -58,7 +58,7 @@ static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 #define NM_CELL_LDS 2048   // pairs a cell's workgroup sorts in LDS (bigger cells: same network on global memory)
 #define NM_PAD 32          // words between two cell counters (one 128-byte line each)
 #define NM_SPLIT_WORK 8192    // (tile, segment) work items a view may have (its segment records: 36 B per pixel each)
-#define NM_SPLIT_BUSY 256     // a view with this many non-empty tiles (one per CU) fills the chip: no splitting (default of nm_raster_set_split)
+#define NM_SPLIT_BUSY 512     // a view with this many non-empty tiles (two per CU) fills the chip: no splitting (default of nm_raster_set_split)
 #define NM_SPLIT_MINSEG 512   // shortest segment (list entries; default): ~50-90 us of one workgroup's walk
 #define NM_SPLIT_WGS 4096     // segments aimed at
 #define NM_SPLIT_TAU 0.01f    // a tile is split when, after its first segment, some pixel still has T above this

@@ -111,7 +111,7 @@ def test_raster_tile_stripes_reassemble_the_full_image_and_gradient(split):
         assert abs_max(acc_img, img) < 2e-6 if split else torch.equal(acc_img, img)
         assert rel_max(acc_g, gfull) < (2e-5 if split else 1e-5)
     finally:
-        _lib.check(lib.nm_raster_set_split(256, 512, 1 << 21), "nm_raster_set_split")
+        _lib.check(lib.nm_raster_set_split(512, 512, 1 << 21), "nm_raster_set_split")
 
 
 def test_raster_empty_and_all_culled():
@@ -252,7 +252,7 @@ def test_raster_split_compositing_equals_whole_tile_compositing_and_the_oracle(o
             work, seg = split_plan(rast, ins[0], ins[2], shs=ins[1], cov3D_precomp=ins[3])
             assert (work == 0) if mode == "whole" else (work > 200 and seg % 16 == 0 and seg >= minseg), (mode, work, seg)
     finally:
-        _lib.check(lib.nm_raster_set_split(256, 512, 1 << 21), "nm_raster_set_split")
+        _lib.check(lib.nm_raster_set_split(512, 512, 1 << 21), "nm_raster_set_split")
     if opaque:
         assert float((res["whole"][0].mean(0) < 0.999).float().mean()) > 0.2      # a good part of the image is covered ...
     for mode in ("split16", "split48", "ckpt32"):

@@ -11,7 +11,7 @@ from neuma_amd.render import split_plan, deform_cov_by_F
 from neuma_amd.tune import compute_bindings_xyz, compute_bindings_F
 
 name = sys.argv[1] if len(sys.argv) > 1 else "bb"
-busy = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+busy = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 minseg = int(sys.argv[3]) if len(sys.argv) > 3 else 512
 dev = torch.device("cuda", 0)
 rt = SceneRuntime(synth.make_scene(name), dev)
