@@ -161,8 +161,8 @@ __device__ __forceinline__ void get_rect(const RK& k, float px, float py, int r,
 struct TileCull {   // per-Gaussian constants of the tile test (the two divisions and the log are hoisted out of the tile loop)
   float mx, my, ca, cb, cc, cb_over_cc, cb_over_ca, qmax;
 };
-// fp contraction is switched off in the two functions below: the count pass (k_preprocess) and the emit pass
-// (k_emit_keys) must take bit-identical decisions, and a multiply-add fused in one inlined copy but not in the other
+// fp contraction is switched off in the two functions below: the binning pass (k_bin_count) and the statistics pass
+// (k_count_pairs) must take bit-identical decisions, and a multiply-add fused in one inlined copy but not in the other
 // would let them disagree on a borderline tile.
 __device__ __forceinline__ TileCull make_tile_cull(float mx, float my, const float4& co) {
 #pragma clang fp contract(off)
@@ -198,8 +198,8 @@ __device__ __forceinline__ float tile_min_q(const TileCull& t, int tx, int ty) {
 }
 // A (Gaussian, tile) pair is kept iff some pixel of the tile can reach alpha >= 1/255 (the compositing kernels skip
 // anything below, so dropping the pair leaves every pixel bit-identical).  0.01 of slack in the exponent keeps the
-// test conservative against fp32 rounding of the per-pixel evaluation.  k_preprocess (count) and k_emit_keys (emit)
-// evaluate this same function on the same inputs, so the two passes always agree.
+// test conservative against fp32 rounding of the per-pixel evaluation.  k_bin_count (the pairs' tile masks) and
+// k_count_pairs (statistics) evaluate this same function on the same inputs, so they always agree.
 __device__ __forceinline__ bool tile_contributes(const TileCull& t, int tx, int ty) {
   return !(tile_min_q(t, tx, ty) > t.qmax);
 }
