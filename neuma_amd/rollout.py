@@ -40,8 +40,10 @@ class _ShardLink(object):
         base = ws.data_ptr()
 
         def view(ptr, count, dtype):
-            off = int(ptr) - base
-            return ws[off:off + 4 * int(count)].view(dtype)
+            off, nbytes = int(ptr) - base, 4 * int(count)
+            if off < 0 or off + nbytes > ws.numel():
+                raise ValueError(f"collective buffer [{off}, {off + nbytes}) lies outside the roll-out's shard workspace of {ws.numel()} bytes")
+            return ws[off:off + nbytes].view(dtype)
 
         def all_gather(user, send, recv, count, stream):
             try:

@@ -237,3 +237,45 @@ def cpu_exchange(rank, world, port, q):
     except Exception as e:
         import traceback
         q.put({"rank": rank, "error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()})
+
+
+def cpu_comm_link(rank, world, port, q):
+    """The nm_comm callback table of the library-level sharded roll-out (rollout._ShardLink), invoked the way the library
+    invokes it - through the C function pointers, with raw addresses inside the roll-out's workspace - on CPU tensors over
+    gloo: rank-major all-gather of int32 lists and in-place float sum."""
+    try:
+        import ctypes as C
+        import types
+        dist = _init(rank, world, port)
+        from neuma_amd import _lib as L
+        from neuma_amd.rollout import _ShardLink
+        ws = torch.zeros(4096, dtype=torch.uint8)
+        ex = types.SimpleNamespace(group=None, world=world, rank=rank)
+        link = _ShardLink(ex, ws)
+        assert link.comm.world == world and link.comm.rank == rank
+        base = ws.data_ptr()
+        count = 5
+        send_off, recv_off, buf_off = 256, 512, 2048
+        ws[send_off:send_off + 4 * count].view(torch.int32).copy_(torch.arange(count, dtype=torch.int32) + 100 * rank)
+        rc = link.comm.all_gather_i32(None, base + send_off, base + recv_off, count, None)
+        got = ws[recv_off:recv_off + 4 * count * world].view(torch.int32).view(world, count)
+        want = torch.stack([torch.arange(count, dtype=torch.int32) + 100 * r for r in range(world)])
+        ok_gather = rc == 0 and bool(torch.equal(got, want))
+        n = 7
+        ws[buf_off:buf_off + 4 * n].view(torch.float32).copy_(torch.arange(n, dtype=torch.float32) * (rank + 1))
+        rc = link.comm.all_reduce_sum_f32(None, base + buf_off, n, None)
+        tot = sum(r + 1 for r in range(world))
+        ok_reduce = rc == 0 and bool(torch.allclose(ws[buf_off:buf_off + 4 * n].view(torch.float32), torch.arange(n, dtype=torch.float32) * tot))
+        # a failing collective is reported by the return code (no exception may cross the C frames) and re-raised by check()
+        rc = link.comm.all_reduce_sum_f32(None, base + ws.numel() + 64, n, None)       # address outside the workspace
+        ok_err = rc != 0 and link.error is not None
+        try:
+            link.check(-1, "nm_rollout_forward_sharded")
+            ok_err = False
+        except L.NeumaHipError as e:
+            ok_err = ok_err and "collective failed" in str(e)
+        q.put({"rank": rank, "ok": [ok_gather, ok_reduce, ok_err]})
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put({"rank": rank, "error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()})

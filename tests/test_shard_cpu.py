@@ -53,6 +53,15 @@ def test_shared_block_rule_and_exchange_bookkeeping_over_gloo():
             assert r["n_shared"] >= 4
 
 
+def test_comm_callbacks_of_the_library_level_sharded_rollout_over_gloo():
+    """rollout._ShardLink: the two collectives nm_rollout_forward_sharded calls back for, driven through the C function pointers."""
+    for world in (2, 3):
+        res = _run(shard_worker.cpu_comm_link, world)
+        for r in res:
+            assert "error" not in r, r
+            assert all(r["ok"]), r
+
+
 def test_stripe_plan_covers_every_tile_row_once():
     from neuma_amd.harness import stripe_plan
     for V, rows, world in [(3, 68, 2), (3, 68, 8), (1, 16, 4), (3, 68, 3), (2, 5, 7)]:
