@@ -31,7 +31,7 @@ def once():
 
 
 for label, (b, s) in (("whole tiles", (0, 1024)), (f"split busy<{busy} minseg {minseg}", (busy, minseg))):
-    lib.nm_raster_set_split(b, s, 1 << 21)
+    lib.nm_raster_set_split(b, s, int(sys.argv[4]) if len(sys.argv) > 4 else (1 << 21))
     for _ in range(3):
         img = once()
     torch.cuda.synchronize()
