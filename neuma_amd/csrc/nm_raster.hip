@@ -92,6 +92,8 @@ struct State {
   float4* seg_fix;     // the same after pass 2: what the segment really contributes (pixels that stop inside / before it)
   float4* seg_ct;      // checkpoints: (C, T) of the pixel in front of the segment; the tile's extra item ns holds the final (C, T)
   uint32_t* seg_last;  // per work item and pixel: last contributor inside the segment (1-based list position), 0 = none
+  uint32_t* seg_pos;   // per work item: list position its segment starts behind (segment s of a tile = positions
+                       // (seg_pos[s], seg_pos[s + 1]]); s * seg by default, where the walk really stood for checkpoints
   int nbx, nby, ncell;
   size_t total;
 };
@@ -128,6 +130,7 @@ static State carve_state(void* base, int W, int H, int k, int64_t cap) {
   t.seg_fix = (float4*)(p + o); o += al256((size_t)NM_SPLIT_WORK * NM_TPB * sizeof(float4));
   t.seg_ct = (float4*)(p + o); o += al256((size_t)NM_SPLIT_WORK * NM_TPB * sizeof(float4));
   t.seg_last = (uint32_t*)(p + o); o += al256((size_t)NM_SPLIT_WORK * NM_TPB * sizeof(uint32_t));
+  t.seg_pos = (uint32_t*)(p + o); o += al256((size_t)NM_SPLIT_WORK * sizeof(uint32_t));
   t.total = o;
   return t;
 }
@@ -653,8 +656,20 @@ struct Pix {
 __device__ __forceinline__ void composite_range(CompLds& L, long long lo, long long a, long long b, uint32_t bit,
                                                 const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                 const float2* __restrict__ xy, const float* __restrict__ rgb,
-                                                const float4* __restrict__ conop, float fxp, float fyp, Pix& p) {
+                                                const float4* __restrict__ conop, float fxp, float fyp, Pix& p,
+                                                uint32_t seg = 0u, uint32_t ck_s = 0u, uint32_t ck_n = 0u,
+                                                float4* __restrict__ ck = nullptr, uint32_t* __restrict__ ck_pos = nullptr) {
+  // ck != NULL: checkpoints for the reverse sweep.  Whenever the walk has passed the nominal start s * seg of segment s
+  // (looked at after every batch of hits and at the end of every round - never inside the compositing loop), the pixels'
+  // (C, T) go to ck[s] and the position the walk stands at to ck_pos[s]: segment s starts exactly there.  s = ck_s .. ck_n-1.
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  auto checkpoint = [&](uint32_t reached) {
+    while (ck_s < ck_n && reached >= ck_s * seg) {
+      ck[(size_t)ck_s * NM_TPB + tid] = make_float4(p.C0, p.C1, p.C2, p.T);
+      if (tid == 0) ck_pos[ck_s] = reached;
+      ++ck_s;
+    }
+  };
   for (long long base = a & ~3ll; base < b; base += NM_SCAN) {     // rounds start 16-byte aligned; positions < a are masked out
     if (__syncthreads_count(p.done) == NM_TPB) break;
     // ---- NM_SCAN candidates: which of them touch this tile (bit of their tile mask)?
@@ -710,7 +725,9 @@ __device__ __forceinline__ void composite_range(CompLds& L, long long lo, long l
         p.T = test_T;
         p.last = L.hit[h0 + j];
       }
+      if (ck) checkpoint(L.hit[h0 + nb - 1]);
     }
+    if (ck) checkpoint((uint32_t)(min(base + NM_SCAN, b) - lo));
   }
 }
 __device__ __forceinline__ void write_pixel(const RK& k, int px, int py, const Pix& p, float* __restrict__ final_T,
@@ -764,7 +781,8 @@ __global__ void __launch_bounds__(1024) k_split_plan(RK k, int nbx, uint32_t bus
                                                      const uint32_t* __restrict__ off, long long cap,
                                                      uint32_t* __restrict__ hdr, uint32_t* __restrict__ tile_rec,
                                                      uint32_t* __restrict__ tile_ns, uint32_t* __restrict__ tile_cnt,
-                                                     uint32_t* __restrict__ tile_mode, uint2* __restrict__ work) {
+                                                     uint32_t* __restrict__ tile_mode, uint2* __restrict__ work,
+                                                     uint32_t* __restrict__ seg_pos) {
   __shared__ unsigned long long s_total;
   __shared__ uint32_t s_busy, s_base, s_scan[1024];
   const int tid = threadIdx.x, rows = k.ty1 - k.ty0, ntile = k.gx * rows;
@@ -823,7 +841,10 @@ __global__ void __launch_bounds__(1024) k_split_plan(RK k, int nbx, uint32_t bus
       tile_ns[t] = ok ? ns : 0u;
       tile_cnt[t] = 0u;
       tile_mode[t] = 0u;
-      if (ok) for (uint32_t q = 0; q <= ns; ++q) work[rec + q] = make_uint2((uint32_t)t, q);
+      if (ok) {
+        const uint32_t n = list_len(i);
+        for (uint32_t q = 0; q <= ns; ++q) { work[rec + q] = make_uint2((uint32_t)t, q); seg_pos[rec + q] = min(q * seg, n); }
+      }
     }
     __syncthreads();
     if (tid == 1023) s_base += s_scan[1023];
@@ -838,7 +859,7 @@ __device__ __forceinline__ void render_seg(CompLds& L, const RK& k, int nbx, int
                                            const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
                                            long long cap, const uint32_t* __restrict__ hdr, const uint2* __restrict__ work,
                                            float4* __restrict__ seg_raw, uint32_t* __restrict__ seg_last,
-                                           float4* __restrict__ seg_ct,
+                                           float4* __restrict__ seg_ct, uint32_t* __restrict__ seg_pos,
                                            const float2* __restrict__ xy, const float* __restrict__ rgb,
                                            const float4* __restrict__ conop, float* __restrict__ final_T,
                                            uint32_t* __restrict__ n_contrib, float* __restrict__ out) {
@@ -861,15 +882,12 @@ __device__ __forceinline__ void render_seg(CompLds& L, const RK& k, int nbx, int
   if (stage == 0) {
     const bool far = __syncthreads_or(!p.done && p.T > NM_SPLIT_TAU);
     if (!(far && hdr[10])) {
-      // nobody is far from stopping (or the view's lists are too much speculative work): this workgroup walks on, segment by
-      // segment, leaving a checkpoint (C, T) in front of each - the reverse sweep starts its parallel walks from them
+      // nobody is far from stopping (or the view's lists are too much speculative work): this workgroup walks on as a whole
+      // tile would, leaving a checkpoint (C, T) roughly every `seg` list entries - the reverse sweep starts its parallel
+      // walks from them
       seg_ct[(size_t)w * NM_TPB + tid] = make_float4(0.f, 0.f, 0.f, 1.f);
-      for (uint32_t sg = 1; sg < ns; ++sg) {
-        if (__syncthreads_and(p.done)) break;
-        seg_ct[(size_t)(w + sg) * NM_TPB + tid] = make_float4(p.C0, p.C1, p.C2, p.T);
-        const long long a2 = lo + seg * sg, b2 = min(hi, a2 + seg);
-        composite_range(L, lo, a2, b2, bit, keys, vals, xy, rgb, conop, fxp, fyp, p);
-      }
+      composite_range(L, lo, b, hi, bit, keys, vals, xy, rgb, conop, fxp, fyp, p, (uint32_t)seg, 1u, ns, seg_ct + (size_t)w * NM_TPB,
+                      seg_pos + w);
       seg_ct[(size_t)(w + ns) * NM_TPB + tid] = make_float4(p.C0, p.C1, p.C2, p.T);
       if (inside) write_pixel(k, px, py, p, final_T, n_contrib, out);
       return;
@@ -888,6 +906,7 @@ __global__ void __launch_bounds__(NM_TPB) k_render(RK k, int nbx, int stage, int
                                                    const uint32_t* __restrict__ vals, long long cap, const uint32_t* __restrict__ hdr,
                                                    const uint2* __restrict__ work, float4* __restrict__ seg_raw,
                                                    uint32_t* __restrict__ seg_last, float4* __restrict__ seg_ct,
+                                                   uint32_t* __restrict__ seg_pos,
                                                    const float2* __restrict__ xy, const float* __restrict__ rgb,
                                                    const float4* __restrict__ conop, float* __restrict__ final_T,
                                                    uint32_t* __restrict__ n_contrib, float* __restrict__ out) {
@@ -897,7 +916,7 @@ __global__ void __launch_bounds__(NM_TPB) k_render(RK k, int nbx, int stage, int
     render_whole(L, k, nbx, b % k.gx, b / k.gx + k.ty0, off, keys, vals, cap, hdr, tile_rec, xy, rgb, conop, final_T, n_contrib, out);
   else
     render_seg(L, k, nbx, stage, (uint32_t)(b - ntile), tile_mode, tile_ns, off, keys, vals, cap, hdr, work, seg_raw, seg_last, seg_ct,
-               xy, rgb, conop, final_T, n_contrib, out);
+               seg_pos, xy, rgb, conop, final_T, n_contrib, out);
 }
 
 // pass 2, again one workgroup per segment: with the transmittance in front of the segment known (product over the earlier
@@ -1246,7 +1265,7 @@ __device__ __forceinline__ void bwd_seg(BwdLdsR& L, const RK& k, int nbx, uint32
                                         const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
                                         const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ tile_rec,
                                         const uint32_t* __restrict__ tile_ns, const uint2* __restrict__ work,
-                                        const float4* __restrict__ seg_ct,
+                                        const float4* __restrict__ seg_ct, const uint32_t* __restrict__ seg_pos,
                                         const float2* __restrict__ xy, const float* __restrict__ rgb,
                                         const float4* __restrict__ conop, const float* __restrict__ final_T,
                                         const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
@@ -1263,7 +1282,8 @@ __device__ __forceinline__ void bwd_seg(BwdLdsR& L, const RK& k, int nbx, uint32
   const uint32_t bit = 1u << ((tile_y % NM_BT) * NM_BT + tile_x % NM_BT);
   const long long lo = off[bin * NM_NS];
   const size_t pix = (size_t)py * k.W + px, hw = (size_t)k.H * k.W;
-  const uint32_t floor_pos = seg * sg, ceil_pos = floor_pos + seg;      // the segment holds positions floor_pos+1 .. ceil_pos
+  const uint32_t floor_pos = seg_pos[r0 + sg], ceil_pos = seg_pos[r0 + sg + 1];      // the segment holds positions floor_pos+1 .. ceil_pos
+  if (ceil_pos <= floor_pos) return;                                                   // (an empty segment: the walk passed two nominal starts in one batch)
   PixB P = {};
   uint32_t last = 0u;
   if (inside) {
@@ -1290,7 +1310,7 @@ __global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, int nbx, int ntile,
                                                        const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                        const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ tile_rec,
                                                        const uint32_t* __restrict__ tile_ns, const uint2* __restrict__ work,
-                                                       const float4* __restrict__ seg_ct,
+                                                       const float4* __restrict__ seg_ct, const uint32_t* __restrict__ seg_pos,
                                                        const float2* __restrict__ xy, const float* __restrict__ rgb,
                                                        const float4* __restrict__ conop, const float* __restrict__ final_T,
                                                        const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
@@ -1300,7 +1320,7 @@ __global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, int nbx, int ntile,
   if (b < ntile)
     bwd_whole<WITH_OPACITY>(L, k, nbx, b % k.gx, b / k.gx + k.ty0, off, keys, vals, tile_rec, xy, rgb, conop, final_T, n_contrib, dL_dpix, acc);
   else
-    bwd_seg<WITH_OPACITY>(L, k, nbx, (uint32_t)(b - ntile), off, keys, vals, hdr, tile_rec, tile_ns, work, seg_ct, xy, rgb, conop,
+    bwd_seg<WITH_OPACITY>(L, k, nbx, (uint32_t)(b - ntile), off, keys, vals, hdr, tile_rec, tile_ns, work, seg_ct, seg_pos, xy, rgb, conop,
                           final_T, n_contrib, dL_dpix, acc);
 }
 
@@ -1508,7 +1528,7 @@ extern "C" int nm_raster_forward(const nm_raster_cfg* cfg, int32_t K, int32_t m,
   NM_LAUNCH(k_split_plan, dim3(1), dim3(1024), 0, s, k, t.nbx, (uint32_t)g_split_busy, (uint32_t)g_split_minseg,
             (unsigned long long)g_split_fwd,
             (const uint32_t*)t.off, (long long)cap_pairs, t.hdr, t.tile_rec,
-            t.tile_ns, t.tile_cnt, t.tile_mode, t.work);
+            t.tile_ns, t.tile_cnt, t.tile_mode, t.work, t.seg_pos);
   NM_LAUNCH_CHECK();
   const int ntile = k.gx * (k.ty1 - k.ty0);
   // stage 0: whole tiles + first segments of the candidates (which decide how their tile goes on); stage 1: other segments
@@ -1517,7 +1537,8 @@ extern "C" int nm_raster_forward(const nm_raster_cfg* cfg, int32_t K, int32_t m,
     NM_LAUNCH(k_render, dim3((stage == 0 ? ntile : 0) + NM_SPLIT_WORK), dim3(NM_TPB), 0, s, k, t.nbx, stage, stage == 0 ? ntile : 0,
               t.tile_mode, (const uint32_t*)t.tile_rec, (const uint32_t*)t.tile_ns, (const uint32_t*)t.off,
               (const unsigned long long*)t.keys, (const uint32_t*)t.vals, (long long)cap_pairs, (const uint32_t*)t.hdr,
-              (const uint2*)t.work, t.seg_raw, t.seg_last, t.seg_ct, t.xy, t.rgb, t.conop, t.final_T, t.n_contrib, out_color);
+              (const uint2*)t.work, t.seg_raw, t.seg_last, t.seg_ct, t.seg_pos, t.xy, t.rgb, t.conop, t.final_T, t.n_contrib,
+              out_color);
     NM_LAUNCH_CHECK();
   }
   NM_LAUNCH(k_render_fix, dim3(NM_SPLIT_WORK), dim3(NM_TPB), 0, s, k, t.nbx, (const uint32_t*)t.off, (const unsigned long long*)t.keys,
@@ -1594,13 +1615,13 @@ extern "C" int nm_raster_backward(const nm_raster_cfg* cfg, int32_t K, int32_t m
   if (dL_dopacity)
     NM_LAUNCH(k_render_bwd<true>, dim3(ntile + NM_SPLIT_WORK), dim3(NM_TPB), 0, s, k, t.nbx, ntile, (const uint32_t*)t.off,
               (const unsigned long long*)t.keys, (const uint32_t*)t.vals, (const uint32_t*)t.hdr, (const uint32_t*)t.tile_rec,
-              (const uint32_t*)t.tile_ns, (const uint2*)t.work, (const float4*)t.seg_ct, t.xy, t.rgb, t.conop, t.final_T,
-              t.n_contrib, dL_dcolor, acc);
+              (const uint32_t*)t.tile_ns, (const uint2*)t.work, (const float4*)t.seg_ct, (const uint32_t*)t.seg_pos, t.xy, t.rgb,
+              t.conop, t.final_T, t.n_contrib, dL_dcolor, acc);
   else
     NM_LAUNCH(k_render_bwd<false>, dim3(ntile + NM_SPLIT_WORK), dim3(NM_TPB), 0, s, k, t.nbx, ntile, (const uint32_t*)t.off,
               (const unsigned long long*)t.keys, (const uint32_t*)t.vals, (const uint32_t*)t.hdr, (const uint32_t*)t.tile_rec,
-              (const uint32_t*)t.tile_ns, (const uint2*)t.work, (const float4*)t.seg_ct, t.xy, t.rgb, t.conop, t.final_T,
-              t.n_contrib, dL_dcolor, acc);
+              (const uint32_t*)t.tile_ns, (const uint2*)t.work, (const float4*)t.seg_ct, (const uint32_t*)t.seg_pos, t.xy, t.rgb,
+              t.conop, t.final_T, t.n_contrib, dL_dcolor, acc);
   NM_LAUNCH_CHECK();
   NM_LAUNCH(k_preprocess_bwd, dim3(nm_div_up(K, 256)), dim3(256), 0, s, k, K, means3D, shs, cov3D, (const int*)t.rad, t.clamped, acc,
             dL_dmeans3D, dL_dmeans2D, dL_dcov3D, dL_dopacity, dL_dshs, dL_dcolors, shs ? 1 : 0);
