@@ -243,10 +243,15 @@ typedef struct nm_rollout_cfg {
   int32_t cache_verified;    /* backward only: the caller has read nm_rollout_cache_status and every record is valid, so the
                               * (early-exit) fallback launches of p2g / grid_op can be left out altogether */
   int32_t svd_adjoint;       /* backward only: NM_SVD_ADJOINT_REFERENCE (0, clamped like warp's adj_svd3) or NM_SVD_ADJOINT_POLAR */
+  void* svd_cache;           /* optional device buffer of nm_rollout_svdcache_bytes(n, substeps): the forward pass keeps U, sigma, V of
+                              * both nets' inputs of every substep (168 B/particle/substep) and the reverse sweep reads them back
+                              * instead of repeating the Jacobi SVD; NULL = recompute (same results to rounding: the trial F the
+                              * reverse sweep rebuilds from the checkpoints differs from the forward's in the last bit) */
 } nm_rollout_cfg;
 #define NM_SVD_ADJOINT_REFERENCE 0
 #define NM_SVD_ADJOINT_POLAR 1
 size_t nm_rollout_workspace(int32_t n, int32_t substeps);
+size_t nm_rollout_svdcache_bytes(int32_t n, int32_t substeps);
 /* bytes of the optional `gridcache` buffer: substeps records of nm_mpm_gridcache_bytes(grid_cache_blocks) */
 size_t nm_rollout_gridcache_bytes(int32_t substeps, int32_t grid_cache_blocks);
 /* Asynchronous read-back of the S record headers of a grid cache into host memory (pinned recommended): status[t] = number

@@ -305,13 +305,16 @@ int nm_mpm_backward_cached(nm_mpm* h, int32_t n, const nm_statics* st, const nm_
 // pro: grid housekeeping performed in the kernel's prologue (NULL = none)
 int nm_material_bwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* wperm,
                            const float* gout, float* gF, float* wpart, int wmode, const float* trial_C, const int* enabled,
-                           float dt, int flags /* bit 0: gF += ; bit 1: polar SVD adjoint */, const GridPrologue* pro, void* stream);
+                           float dt, int flags /* bit 0: gF += ; bit 1: polar SVD adjoint */, const GridPrologue* pro, void* stream,
+                           const float* svd_in = nullptr /* U | sigma | V of the input as the forward kernel stored them */);
 int nm_material_bwd_pair_launch(int32_t n, const float* F_e, const nm_mlp* we, const float* wperm_e, const float* gS, float* gF,
                                 float* wpart_e, int wmode_e, float alpha_p, const float* F_p, const nm_mlp* wp,
                                 const float* wperm_p, float* gFtrial, float* wpart_p, int wmode_p, const float* trial_C,
-                                const int* enabled, float dt, int polar, const GridPrologue* pro, void* stream);
+                                const int* enabled, float dt, int polar, const GridPrologue* pro, void* stream,
+                                const float* svd_in_e = nullptr, const float* svd_in_p = nullptr);
 int nm_material_fwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* wperm, float* out,
-                           const GridPrologue* pro, const G2pFuse* g2p, void* stream);
+                           const GridPrologue* pro, const G2pFuse* g2p, void* stream,
+                           float* svd_out = nullptr /* roll-out: keep U | sigma | V for the reverse sweep (21 n floats) */);
 // g2p fused into the next constitutive kernel (roll-out forward): fills the descriptor / runs the substep without its g2p
 int nm_mpm_g2p_fuse(nm_mpm* h, const nm_statics* st, const nm_particles* cur, nm_particles* next, G2pFuse* f);
 int nm_mpm_forward_prepared_nog2p(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, void* gridrec,

@@ -299,8 +299,29 @@ __global__ void __launch_bounds__(256) k_permute_weights(const float* __restrict
 }
 
 // invariants of meta.py:197-213 for one particle: z[13], R = U V^T (also returns U, V, sigma)
+// SVD cache of the fused roll-out (nm_rollout_cfg.svd_cache): the forward kernels leave U | sigma | V of every particle (21
+// floats, component-major so that a wave's accesses are contiguous), the reverse sweep reads them back instead of running
+// the Jacobi iteration again on the same matrix (5 k of the 7 k cycles a 64-particle round spends before its first tile).
+__device__ __forceinline__ void svd_store(float* __restrict__ dst, int n, int p, const M3& U, const float s[3], const M3& V) {
+#pragma unroll
+  for (int c = 0; c < 9; ++c) dst[(size_t)c * n + p] = U.m[c];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) dst[(size_t)(9 + c) * n + p] = s[c];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) dst[(size_t)(12 + c) * n + p] = V.m[c];
+}
+__device__ __forceinline__ void svd_load(const float* __restrict__ src, int n, int p, M3& U, float s[3], M3& V) {
+#pragma unroll
+  for (int c = 0; c < 9; ++c) U.m[c] = src[(size_t)c * n + p];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) s[c] = src[(size_t)(9 + c) * n + p];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) V.m[c] = src[(size_t)(12 + c) * n + p];
+}
+// HAVE_SVD: U, s, V are given (svd_load)
+template <bool HAVE_SVD = false>
 __device__ __forceinline__ void nm_features(const M3& F, float z[13], M3& R, M3& U, M3& V, float s[3]) {
-  nm_svd3(F, U, s, V);
+  if (!HAVE_SVD) nm_svd3(F, U, s, V);
   R = m3_mul_nt(U, V);
   M3 G = m3_mul_tn(F, F);
   z[0] = s[0] - 1.f; z[1] = s[1] - 1.f; z[2] = s[2] - 1.f;
@@ -446,7 +467,8 @@ template <int KIND>
 __global__ void __launch_bounds__(256) k_material_fwd(int n, int q, float alpha, const float* __restrict__ F,
                                                       const float* __restrict__ w0, const float* __restrict__ w1,
                                                       const float* __restrict__ w2, const float* __restrict__ wperm,
-                                                      float* __restrict__ out, GridPrologue pro, G2pFuse gf) {
+                                                      float* __restrict__ out, GridPrologue pro, G2pFuse gf,
+                                                      float* __restrict__ svd_out) {
   __shared__ __attribute__((aligned(16))) float sP[NM_PERM_FWD];
   float *sP0 = sP, *sP1 = sP + 16 * 64, *sP2 = sP + 16 * 64 + 64 * 64;
   // per-wave buffers (features 64x17, outputs 64x9); before the main loop the same memory holds the raw weights
@@ -486,6 +508,7 @@ __global__ void __launch_bounds__(256) k_material_fwd(int n, int q, float alpha,
     M3 R, U, V;
     float z[13], s[3];
     nm_features(Fp, z, R, U, V, s);
+    if (svd_out && valid) svd_store(svd_out, n, p, U, s, V);
 #pragma unroll
     for (int c = 0; c < 13; ++c) zb[lane * 17 + c] = z[c];
     zb[lane * 17 + 13] = 0.f; zb[lane * 17 + 14] = 0.f; zb[lane * 17 + 15] = 0.f;
@@ -544,7 +567,7 @@ __global__ void __launch_bounds__(256) k_material_fwd(int n, int q, float alpha,
 
 // internal (fused roll-out): wperm != NULL -> weights come pre-permuted from nm_material_prepare
 int nm_material_fwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* wperm, float* out,
-                           const GridPrologue* pro, const G2pFuse* g2p, void* stream) {
+                           const GridPrologue* pro, const G2pFuse* g2p, void* stream, float* svd_out) {
   int grid, q;
   nm_wave_quota(n, grid, q);
   hipStream_t s = (hipStream_t)stream;
@@ -556,9 +579,9 @@ int nm_material_fwd_launch(int32_t n, int32_t kind, float alpha, const float* F,
   gp.mat_grid = grid;
   const int launch = (pro && grid + NM_PRO_WGS <= NM_BWD_GRID) ? grid + NM_PRO_WGS : grid;
   if (kind == NM_ELASTICITY)
-    NM_LAUNCH(k_material_fwd<NM_ELASTICITY>, dim3(launch), dim3(256), 0, s, n, q, alpha, F, w0, w1, w2, wperm, out, gp, gf);
+    NM_LAUNCH(k_material_fwd<NM_ELASTICITY>, dim3(launch), dim3(256), 0, s, n, q, alpha, F, w0, w1, w2, wperm, out, gp, gf, svd_out);
   else
-    NM_LAUNCH(k_material_fwd<NM_PLASTICITY>, dim3(launch), dim3(256), 0, s, n, q, alpha, F, w0, w1, w2, wperm, out, gp, gf);
+    NM_LAUNCH(k_material_fwd<NM_PLASTICITY>, dim3(launch), dim3(256), 0, s, n, q, alpha, F, w0, w1, w2, wperm, out, gp, gf, svd_out);
   NM_LAUNCH_CHECK();
   return NM_OK;
 }
@@ -586,6 +609,7 @@ struct BwdFuse {
   float dt;
   int add_to_gF;          // gF += result instead of gF = result
   int polar;              // 0: the reference's SVD adjoint (denominators clamped like warp's adj_svd3); 1: exact polar derivative
+  const float* svd_in;    // != NULL: U | sigma | V of the input as the forward kernel left them (svd_store layout)
 };
 struct BwdLds {
   float P0[16 * 64], P1[64 * 64], P2[16 * 64];
@@ -665,7 +689,13 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
     }
     M3 R, U, V;
     float z[13], s[3];
-    nm_features(Fp, z, R, U, V, s);
+    if (fz.svd_in) {        // (workgroup-uniform)
+      if (valid) svd_load(fz.svd_in, n, p, U, s, V);
+      else { U = m3_ident(); V = m3_ident(); s[0] = s[1] = s[2] = 1.f; }
+      nm_features<true>(Fp, z, R, U, V, s);
+    } else {
+      nm_features(Fp, z, R, U, V, s);
+    }
 #pragma unroll
     for (int c = 0; c < 13; ++c) zb[lane * 17 + c] = z[c];
     zb[lane * 17 + 13] = 0.f; zb[lane * 17 + 14] = 0.f; zb[lane * 17 + 15] = 0.f;
@@ -1020,18 +1050,20 @@ static int bwd_attr_once() {
   return NM_OK;
 }
 static BwdArgs bwd_args(int32_t n, int q, float alpha, const float* F, const nm_mlp* w, const float* wperm, const float* gout,
-                        float* gF, float* wpart, int wmode, const float* trial_C, const int* enabled, float dt, int flags) {
+                        float* gF, float* wpart, int wmode, const float* trial_C, const int* enabled, float dt, int flags,
+                        const float* svd_in = nullptr) {
   BwdArgs a;
   a.n = n; a.q = q; a.alpha = alpha; a.F = F;
   a.w0 = w ? w->w0 : nullptr; a.w1 = w ? w->w1 : nullptr; a.w2 = w ? w->w2 : nullptr;
   a.wperm = wperm; a.gout = gout; a.gF = gF; a.wpart = wpart; a.want_w = wmode;
   a.fz.trial_C = trial_C; a.fz.enabled = enabled; a.fz.dt = dt; a.fz.add_to_gF = flags & 1; a.fz.polar = (flags >> 1) & 1;
+  a.fz.svd_in = svd_in;
   return a;
 }
 
 int nm_material_bwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* wperm,
                            const float* gout, float* gF, float* wpart, int wmode, const float* trial_C, const int* enabled,
-                           float dt, int add_to_gF, const GridPrologue* pro, void* stream) {
+                           float dt, int add_to_gF, const GridPrologue* pro, void* stream, const float* svd_in) {
   GridPrologue gp;
   if (pro) gp = *pro; else { memset(&gp, 0, sizeof(gp)); }
   hipStream_t s = (hipStream_t)stream;
@@ -1041,7 +1073,7 @@ int nm_material_bwd_launch(int32_t n, int32_t kind, float alpha, const float* F,
   const int launch = (pro && grid + NM_PRO_WGS <= NM_BWD_GRID) ? grid + NM_PRO_WGS : grid;
   int rc = bwd_attr_once();
   if (rc) return rc;
-  BwdArgs a = bwd_args(n, q, alpha, F, w, wperm, gout, gF, wpart, wmode, trial_C, enabled, dt, add_to_gF);
+  BwdArgs a = bwd_args(n, q, alpha, F, w, wperm, gout, gF, wpart, wmode, trial_C, enabled, dt, add_to_gF, svd_in);
   if (kind == NM_ELASTICITY)
     NM_LAUNCH(k_material_bwd<NM_ELASTICITY>, dim3(launch), dim3(256), sizeof(BwdLds), s, a, gp);
   else
@@ -1055,7 +1087,8 @@ int nm_material_bwd_launch(int32_t n, int32_t kind, float alpha, const float* F,
 int nm_material_bwd_pair_launch(int32_t n, const float* F_e, const nm_mlp* we, const float* wperm_e, const float* gS, float* gF,
                                 float* wpart_e, int wmode_e, float alpha_p, const float* F_p, const nm_mlp* wp,
                                 const float* wperm_p, float* gFtrial, float* wpart_p, int wmode_p, const float* trial_C,
-                                const int* enabled, float dt, int polar, const GridPrologue* pro, void* stream) {
+                                const int* enabled, float dt, int polar, const GridPrologue* pro, void* stream,
+                                const float* svd_in_e, const float* svd_in_p) {
   GridPrologue gp;
   if (pro) gp = *pro; else { memset(&gp, 0, sizeof(gp)); }
   hipStream_t s = (hipStream_t)stream;
@@ -1065,8 +1098,8 @@ int nm_material_bwd_pair_launch(int32_t n, const float* F_e, const nm_mlp* we, c
   const int launch = (pro && grid + NM_PRO_WGS <= NM_BWD_GRID) ? grid + NM_PRO_WGS : grid;
   int rc = bwd_attr_once();
   if (rc) return rc;
-  BwdArgs e = bwd_args(n, q, 0.f, F_e, we, wperm_e, gS, gF, wpart_e, wmode_e, nullptr, nullptr, 0.f, 1 | (polar ? 2 : 0));
-  BwdArgs p = bwd_args(n, q, alpha_p, F_p, wp, wperm_p, gF, gFtrial, wpart_p, wmode_p, trial_C, enabled, dt, polar ? 2 : 0);
+  BwdArgs e = bwd_args(n, q, 0.f, F_e, we, wperm_e, gS, gF, wpart_e, wmode_e, nullptr, nullptr, 0.f, 1 | (polar ? 2 : 0), svd_in_e);
+  BwdArgs p = bwd_args(n, q, alpha_p, F_p, wp, wperm_p, gF, gFtrial, wpart_p, wmode_p, trial_C, enabled, dt, polar ? 2 : 0, svd_in_p);
   NM_LAUNCH(k_material_bwd_pair, dim3(launch), dim3(256), sizeof(BwdLds), s, e, p, gp);
   NM_LAUNCH_CHECK();
   return NM_OK;

@@ -70,6 +70,16 @@ static inline void* grid_rec(const void* gridcache, const nm_rollout_cfg* cfg, i
   return (char*)const_cast<void*>(gridcache) + (size_t)t * nm_mpm_gridcache_bytes(cfg->grid_cache_blocks);
 }
 
+// SVD cache (cfg->svd_cache, optional): U | sigma | V of both nets' inputs of every substep, 2 x 21 x N floats per substep
+extern "C" size_t nm_rollout_svdcache_bytes(int32_t n, int32_t substeps) {
+  if (n < 1 || substeps < 1) return 0;
+  return (size_t)substeps * 2 * 21 * (size_t)n * sizeof(float);
+}
+static inline float* svd_rec(const nm_rollout_cfg* cfg, int n, int t, int net) {
+  if (!cfg->svd_cache) return nullptr;
+  return (float*)cfg->svd_cache + ((size_t)t * 2 + net) * 21 * (size_t)n;
+}
+
 extern "C" int nm_rollout_cache_status(const void* gridcache, const nm_rollout_cfg* cfg, int32_t* status_host, void* stream) {
   NM_REQUIRE(gridcache && cfg && status_host, "null pointer");
   NM_REQUIRE(cfg->substeps >= 1 && cfg->grid_cache_blocks >= 1, "no grid cache configured");
@@ -99,7 +109,7 @@ extern "C" int nm_rollout_forward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cf
     GridPrologue pro;
     rc = nm_mpm_prologue_forward(h, &pro);
     if (rc) return rc;
-    rc = nm_material_fwd_launch(n, NM_ELASTICITY, 0.f, cur.F, we, w.perm_e, cur.stress, &pro, nullptr, stream);  // finetune.py:362
+    rc = nm_material_fwd_launch(n, NM_ELASTICITY, 0.f, cur.F, we, w.perm_e, cur.stress, &pro, nullptr, stream, svd_rec(cfg, n, t, 0));  // finetune.py:362
     if (rc) return rc;
     // p2g + grid update here; the substep's g2p runs inside the plasticity kernel, which consumes its trial F from
     // registers (the reverse sweep recomputes the trial F from the checkpointed C', so it is never stored)
@@ -108,7 +118,8 @@ extern "C" int nm_rollout_forward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cf
     G2pFuse g2p;
     rc = nm_mpm_g2p_fuse(h, st, &cur, &nxt, &g2p);
     if (rc) return rc;
-    rc = nm_material_fwd_launch(n, NM_PLASTICITY, cfg->plasticity_alpha, nullptr, wp, w.perm_p, nxt.F, nullptr, &g2p, stream);  // finetune.py:364
+    rc = nm_material_fwd_launch(n, NM_PLASTICITY, cfg->plasticity_alpha, nullptr, wp, w.perm_p, nxt.F, nullptr, &g2p, stream,
+                                svd_rec(cfg, n, t, 1));  // finetune.py:364
     if (rc) return rc;
   }
   return NM_OK;
@@ -151,7 +162,7 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
       // plasticity backward on the trial F of the last substep (recomputed in-kernel from the checkpoints):
       // dL/dF_{t+1} -> dL/dFtrial.  For every earlier substep it rides in the pair launch at the end of this loop body.
       rc = nm_material_bwd_launch(n, NM_PLASTICITY, cfg->plasticity_alpha, cur.F, wp, w.perm_p, gin + 15 * N, w.gFtr, w.part_p, wmode,
-                                  nxt.C, st->enabled, dt, polar ? 2 : 0, nullptr, stream);
+                                  nxt.C, st->enabled, dt, polar ? 2 : 0, nullptr, stream, svd_rec(cfg, n, t, 1));
       if (rc) return rc;
     }
     // sim backward (stress of this step was checkpointed by the forward pass).  Verified sweep: from the second substep
@@ -169,7 +180,7 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
     if (t == 0) {
       // elasticity backward: dL/dstress -> dL/dF (added to the sim's dL/dF)
       rc = nm_material_bwd_launch(n, NM_ELASTICITY, 0.f, cur.F, we, w.perm_e, w.gS, gc.F, w.part_e, wmode, nullptr, nullptr, 0.f,
-                                  1 | (polar ? 2 : 0), nullptr, stream);
+                                  1 | (polar ? 2 : 0), nullptr, stream, svd_rec(cfg, n, t, 0));
       if (rc) return rc;
     } else {
       // elasticity backward of this substep and plasticity backward of the previous one (its input dL/dF_t is exactly
@@ -182,7 +193,8 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
         restored = true;
       }
       rc = nm_material_bwd_pair_launch(n, cur.F, we, w.perm_e, w.gS, gc.F, w.part_e, wmode, cfg->plasticity_alpha, prev.F, wp,
-                                       w.perm_p, w.gFtr, w.part_p, 2, cur.C, st->enabled, dt, polar, verified ? &pro : nullptr, stream);
+                                       w.perm_p, w.gFtr, w.part_p, 2, cur.C, st->enabled, dt, polar, verified ? &pro : nullptr, stream,
+                                       svd_rec(cfg, n, t, 0), svd_rec(cfg, n, t - 1, 1));
       if (rc) return rc;
     }
     gin = gout;

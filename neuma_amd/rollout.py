@@ -15,6 +15,7 @@ from .sim.order import ParticleOrder, hilbert_index_torch  # noqa: F401 (re-expo
 
 _WSZ = (64 * 13, 64 * 64, 9 * 64)
 _CACHE_STATUS = __import__('os').environ.get('NEUMA_CACHE_STATUS', '1') != '0'
+_SVD_CACHE = __import__('os').environ.get('NEUMA_SVD_CACHE', '1') != '0'
 
 
 _ZEROS = {}
@@ -95,7 +96,12 @@ class _Rollout(autograd.Function):
         cache_blocks = int(cache_blocks) if any(ctx.needs_input_grad) else 0
         gc_bytes = int(lib.nm_rollout_gridcache_bytes(S, cache_blocks)) if cache_blocks > 0 else 0
         gcache = torch.empty(gc_bytes, dtype=torch.uint8, device=dev) if gc_bytes > 0 else None
-        cfg = L.nm_rollout_cfg(S, float(alpha), cache_blocks if gcache is not None else 0, 0, int(svd_adjoint))
+        # SVD cache (U, sigma, V of both nets' inputs per substep, 168 B/particle/substep): also only when a backward pass can follow
+        svdc = (torch.empty(int(lib.nm_rollout_svdcache_bytes(n, S)), dtype=torch.uint8, device=dev)
+                if (_SVD_CACHE and n > 0 and any(ctx.needs_input_grad)) else None)
+        cfg = L.nm_rollout_cfg(S, float(alpha), cache_blocks if gcache is not None else 0, 0, int(svd_adjoint),
+                               L.ptr(svdc) if svdc is not None else None)
+        ctx.svdc = svdc
         st = statics.c_struct()
         mle = L.nm_mlp(*[L.ptr(t) for t in we])
         mlp = L.nm_mlp(*[L.ptr(t) for t in wp])
@@ -137,7 +143,8 @@ class _Rollout(autograd.Function):
         sws_bytes = int(lib.nm_rollout_shard_workspace(ex.world, cap, cap_shared, S))
         sws = torch.empty(sws_bytes, dtype=torch.uint8, device=dev)
         link = _ShardLink(ex, sws)
-        cfg = L.nm_rollout_cfg(S, alpha, cap, 0, svd_adjoint)
+        cfg = L.nm_rollout_cfg(S, alpha, cap, 0, svd_adjoint, None)
+        ctx.svdc = None
         mle = L.nm_mlp(*[L.ptr(t) for t in we])
         mlp = L.nm_mlp(*[L.ptr(t) for t in wp])
         link.check(lib.nm_rollout_forward_sharded(model.handle(), n, C.byref(cfg), C.byref(st), C.byref(mle), C.byref(mlp), L.ptr(states),
@@ -174,7 +181,8 @@ class _Rollout(autograd.Function):
         verified = 0
         if gcache is not None and ctx.cache_event is not None and ctx.cache_event.query():
             verified = int(bool((ctx.cache_status >= 0).all()))
-        cfg = L.nm_rollout_cfg(S, ctx.alpha, ctx.cache_blocks, verified, ctx.svd_adjoint)
+        svdc = getattr(ctx, "svdc", None)
+        cfg = L.nm_rollout_cfg(S, ctx.alpha, ctx.cache_blocks, verified, ctx.svd_adjoint, L.ptr(svdc) if svdc is not None else None)
         st = ctx.statics.c_struct()
         mle = L.nm_mlp(L.ptr(e0), L.ptr(e1), L.ptr(e2))
         mlp = L.nm_mlp(L.ptr(p0), L.ptr(p1), L.ptr(p2))
@@ -190,6 +198,7 @@ class _Rollout(autograd.Function):
                                             L.ptr(states), L.ptr(gcache) if gcache is not None else None, L.ptr(glast), L.ptr(gfirst),
                                             L.ptr(gwe), L.ptr(gwp), L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "nm_rollout_backward")
         ctx.gcache = None
+        ctx.svdc = None
         torch.nan_to_num_(gfirst, 0.0, 0.0, 0.0)   # interface.py:65-74 at the boundary of the fused node
         a, b = _WSZ[0], _WSZ[0] + _WSZ[1]
         return (None, None, None, None, None, None,
