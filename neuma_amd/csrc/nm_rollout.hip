@@ -268,7 +268,7 @@ extern "C" int nm_rollout_forward_sharded(nm_mpm* h, int32_t n, const nm_rollout
                                           const nm_mlp* wp, float* states, void* gridcache, void* workspace, size_t workspace_bytes,
                                           const nm_comm* comm, int32_t cap, int32_t cap_shared, void* shard_ws, size_t shard_ws_bytes,
                                           void* stream) {
-  NM_REQUIRE(h && cfg && st && we && wp && states, "null pointer");
+  NM_REQUIRE(h && cfg && st && we && wp && (states || n == 0), "null pointer");
   NM_REQUIRE(n >= 0 && cfg->substeps >= 1, "bad sizes");
   ShardWs sw;
   int rc = shard_args_ok(comm, cap, cap_shared, cfg, gridcache, shard_ws, shard_ws_bytes, sw);
@@ -322,7 +322,7 @@ extern "C" int nm_rollout_backward_sharded(nm_mpm* h, int32_t n, const nm_rollou
                                            float* gstate_first, float* gw_e, float* gw_p, void* workspace, size_t workspace_bytes,
                                            const nm_comm* comm, int32_t cap, int32_t cap_shared, const void* shard_ws,
                                            size_t shard_ws_bytes, void* stream) {
-  NM_REQUIRE(h && cfg && st && we && wp && states && gstate_last && gstate_first && gw_e && gw_p, "null pointer");
+  NM_REQUIRE(h && cfg && st && we && wp && gw_e && gw_p && ((states && gstate_last && gstate_first) || n == 0), "null pointer");
   NM_REQUIRE(n >= 0 && cfg->substeps >= 1, "bad sizes");
   hipStream_t s = (hipStream_t)stream;
   ShardWs sw;
