@@ -247,11 +247,16 @@ typedef struct nm_rollout_cfg {
                               * both nets' inputs of every substep (168 B/particle/substep) and the reverse sweep reads them back
                               * instead of repeating the Jacobi SVD; NULL = recompute (same results to rounding: the trial F the
                               * reverse sweep rebuilds from the checkpoints differs from the forward's in the last bit) */
+  void* act_cache;           /* optional device buffer of nm_rollout_actcache_bytes(n, substeps): the forward pass keeps the two hidden
+                              * layers' activations and GELU derivatives of both nets (2.2 KB/particle/substep) and the reverse
+                              * sweep loads them instead of recomputing the MLPs' forward pass (a third of its matrix work and all
+                              * of its GELUs); NULL = recompute.  Same arithmetic, same results. */
 } nm_rollout_cfg;
 #define NM_SVD_ADJOINT_REFERENCE 0
 #define NM_SVD_ADJOINT_POLAR 1
 size_t nm_rollout_workspace(int32_t n, int32_t substeps);
 size_t nm_rollout_svdcache_bytes(int32_t n, int32_t substeps);
+size_t nm_rollout_actcache_bytes(int32_t n, int32_t substeps);
 /* bytes of the optional `gridcache` buffer: substeps records of nm_mpm_gridcache_bytes(grid_cache_blocks) */
 size_t nm_rollout_gridcache_bytes(int32_t substeps, int32_t grid_cache_blocks);
 /* Asynchronous read-back of the S record headers of a grid cache into host memory (pinned recommended): status[t] = number

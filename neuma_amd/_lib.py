@@ -43,7 +43,7 @@ class nm_lora_layer(C.Structure):
 
 class nm_rollout_cfg(C.Structure):
     _fields_ = [("substeps", C.c_int32), ("plasticity_alpha", C.c_float), ("grid_cache_blocks", C.c_int32),
-                ("cache_verified", C.c_int32), ("svd_adjoint", C.c_int32), ("svd_cache", C.c_void_p)]
+                ("cache_verified", C.c_int32), ("svd_adjoint", C.c_int32), ("svd_cache", C.c_void_p), ("act_cache", C.c_void_p)]
 
 
 COMM_ALL_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
@@ -120,6 +120,7 @@ SIGNATURES = {
     "nm_rollout_backward": (C.c_int, [_P, _I32, C.POINTER(nm_rollout_cfg), C.POINTER(nm_statics), C.POINTER(nm_mlp),
                                       C.POINTER(nm_mlp), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "nm_rollout_svdcache_bytes": (_SZ, [_I32, _I32]),
+    "nm_rollout_actcache_bytes": (_SZ, [_I32, _I32]),
     "nm_rollout_shard_workspace": (_SZ, [_I32, _I32, _I32, _I32]),
     "nm_rollout_forward_sharded": (C.c_int, [_P, _I32, C.POINTER(nm_rollout_cfg), C.POINTER(nm_statics), C.POINTER(nm_mlp),
                                              C.POINTER(nm_mlp), _P, _P, _P, _SZ, C.POINTER(nm_comm), _I32, _I32, _P, _SZ, _P]),

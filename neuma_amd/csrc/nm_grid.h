@@ -306,15 +306,19 @@ int nm_mpm_backward_cached(nm_mpm* h, int32_t n, const nm_statics* st, const nm_
 int nm_material_bwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* wperm,
                            const float* gout, float* gF, float* wpart, int wmode, const float* trial_C, const int* enabled,
                            float dt, int flags /* bit 0: gF += ; bit 1: polar SVD adjoint */, const GridPrologue* pro, void* stream,
-                           const float* svd_in = nullptr /* U | sigma | V of the input as the forward kernel stored them */);
+                           const float* svd_in = nullptr /* U | sigma | V of the input as the forward kernel stored them */,
+                           const float* act = nullptr /* the forward kernel's activation cache */);
 int nm_material_bwd_pair_launch(int32_t n, const float* F_e, const nm_mlp* we, const float* wperm_e, const float* gS, float* gF,
                                 float* wpart_e, int wmode_e, float alpha_p, const float* F_p, const nm_mlp* wp,
                                 const float* wperm_p, float* gFtrial, float* wpart_p, int wmode_p, const float* trial_C,
                                 const int* enabled, float dt, int polar, const GridPrologue* pro, void* stream,
-                                const float* svd_in_e = nullptr, const float* svd_in_p = nullptr);
+                                const float* svd_in_e = nullptr, const float* svd_in_p = nullptr, const float* act_e = nullptr,
+                                const float* act_p = nullptr);
 int nm_material_fwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* wperm, float* out,
                            const GridPrologue* pro, const G2pFuse* g2p, void* stream,
-                           float* svd_out = nullptr /* roll-out: keep U | sigma | V for the reverse sweep (21 n floats) */);
+                           float* svd_out = nullptr /* roll-out: keep U | sigma | V for the reverse sweep (21 n floats) */,
+                           float* act_out = nullptr /* roll-out: keep the hidden activations (nm_material_act_floats(n)) */);
+size_t nm_material_act_floats(int32_t n);
 // g2p fused into the next constitutive kernel (roll-out forward): fills the descriptor / runs the substep without its g2p
 int nm_mpm_g2p_fuse(nm_mpm* h, const nm_statics* st, const nm_particles* cur, nm_particles* next, G2pFuse* f);
 int nm_mpm_forward_prepared_nog2p(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, void* gridrec,

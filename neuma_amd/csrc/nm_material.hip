@@ -388,7 +388,11 @@ struct MlpFwd {
 template <bool WITH_GRAD>
 __device__ __forceinline__ void mlp_forward_tile(const float* __restrict__ P0, const float* __restrict__ P1,
                                                  const float* __restrict__ P2, const float* zin /* 4 B operands of layer 0 */,
-                                                 int lane, AGroup<8>& first, MlpFwd& o, float* th1 = nullptr, float* th2 = nullptr) {
+                                                 int lane, AGroup<8>& first, MlpFwd& o, float* th1 = nullptr, float* th2 = nullptr,
+                                                 f4* __restrict__ act = nullptr) {
+  // act != NULL (activation cache of the fused roll-out, WITH_GRAD only): the tile's hidden activations and GELU derivatives
+  // are written out in the accumulator layout itself - NM_ACT_SLOTS x 64 lanes x 16 B, slot k: h1[k], g1[k-4], h2[k-8],
+  // g2[k-12], y - in the shadow of the following MFMA chains; the reverse sweep loads them back instead of recomputing.
   const f4 zero = {0.f, 0.f, 0.f, 0.f};
   const int j = lane & 15, g = lane >> 4;
   f4 a1[4] = {zero, zero, zero, zero};
@@ -419,6 +423,13 @@ __device__ __forceinline__ void mlp_forward_tile(const float* __restrict__ P0, c
         for (int r = 0; r < 4; ++r) th1[(16 * rt + 4 * g + r) * 17 + j] = hb[4 * rt + r];
       __builtin_amdgcn_wave_barrier();   // (other lanes read these words: keep the compiler from reordering around them)
     }
+    if (WITH_GRAD && act) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        act[rt * 64 + lane] = (f4){hb[4 * rt], hb[4 * rt + 1], hb[4 * rt + 2], hb[4 * rt + 3]};
+        act[(4 + rt) * 64 + lane] = o.g1[rt];
+      }
+    }
   });
   AGroup<8> w2g;
   a_fetch<8>(w2g, P2, lane, 0);
@@ -445,9 +456,18 @@ __device__ __forceinline__ void mlp_forward_tile(const float* __restrict__ P0, c
         for (int r = 0; r < 4; ++r) th2[(16 * rt + 4 * g + r) * 17 + j] = hb[4 * rt + r];
       __builtin_amdgcn_wave_barrier();
     }
+    if (WITH_GRAD && act) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        act[(8 + rt) * 64 + lane] = (f4){hb[4 * rt], hb[4 * rt + 1], hb[4 * rt + 2], hb[4 * rt + 3]};
+        act[(12 + rt) * 64 + lane] = o.g2[rt];
+      }
+    }
   });
   o.y = yy[0] + yy[1];
+  if (WITH_GRAD && act) act[16 * 64 + lane] = o.y;
 }
+#define NM_ACT_SLOTS 17      // f4 slots per lane and 16-particle tile in the activation cache
 
 // ---------------------------------------------------------------- forward
 // Work split of the constitutive kernels: one workgroup (4 waves, one per SIMD) per CU, each wave owns q consecutive
@@ -463,12 +483,12 @@ static inline void nm_wave_quota(int n, int& grid, int& q) {
   if (grid < 1) grid = 1;
 }
 
-template <int KIND>
+template <int KIND, bool ACT>
 __global__ void __launch_bounds__(256) k_material_fwd(int n, int q, float alpha, const float* __restrict__ F,
                                                       const float* __restrict__ w0, const float* __restrict__ w1,
                                                       const float* __restrict__ w2, const float* __restrict__ wperm,
                                                       float* __restrict__ out, GridPrologue pro, G2pFuse gf,
-                                                      float* __restrict__ svd_out) {
+                                                      float* __restrict__ svd_out, f4* __restrict__ act_out) {
   __shared__ __attribute__((aligned(16))) float sP[NM_PERM_FWD];
   float *sP0 = sP, *sP1 = sP + 16 * 64, *sP2 = sP + 16 * 64 + 64 * 64;
   // per-wave buffers (features 64x17, outputs 64x9); before the main loop the same memory holds the raw weights
@@ -528,7 +548,11 @@ __global__ void __launch_bounds__(256) k_material_fwd(int n, int q, float alpha,
         MlpFwd m;
         AGroup<8> first;
         a_fetch<8>(first, sP0, lane, 0);
-        mlp_forward_tile<false>(sP0, sP1, sP2, zin[ct], lane, first, m);
+        if (ACT)      // tiles are 16 consecutive particles starting at a multiple of 16 (nm_wave_quota): tile id = particle / 16
+          mlp_forward_tile<true>(sP0, sP1, sP2, zin[ct], lane, first, m, nullptr, nullptr,
+                                 act_out + (size_t)((c0 >> 4) + ct) * NM_ACT_SLOTS * 64);
+        else
+          mlp_forward_tile<false>(sP0, sP1, sP2, zin[ct], lane, first, m);
         yv[ct] = m.y;
       } else {
         yv[ct] = (f4){0.f, 0.f, 0.f, 0.f};
@@ -565,9 +589,12 @@ __global__ void __launch_bounds__(256) k_material_fwd(int n, int q, float alpha,
   NM_PH_STORE
 }
 
+// floats of one net's activation cache for n particles (one record per 16-particle tile)
+size_t nm_material_act_floats(int32_t n) { return (size_t)nm_div_up(n > 0 ? n : 1, 16) * NM_ACT_SLOTS * 64 * 4; }
+
 // internal (fused roll-out): wperm != NULL -> weights come pre-permuted from nm_material_prepare
 int nm_material_fwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* wperm, float* out,
-                           const GridPrologue* pro, const G2pFuse* g2p, void* stream, float* svd_out) {
+                           const GridPrologue* pro, const G2pFuse* g2p, void* stream, float* svd_out, float* act_out) {
   int grid, q;
   nm_wave_quota(n, grid, q);
   hipStream_t s = (hipStream_t)stream;
@@ -578,10 +605,15 @@ int nm_material_fwd_launch(int32_t n, int32_t kind, float alpha, const float* F,
   if (g2p) gf = *g2p; else { memset(&gf, 0, sizeof(gf)); }
   gp.mat_grid = grid;
   const int launch = (pro && grid + NM_PRO_WGS <= NM_BWD_GRID) ? grid + NM_PRO_WGS : grid;
-  if (kind == NM_ELASTICITY)
-    NM_LAUNCH(k_material_fwd<NM_ELASTICITY>, dim3(launch), dim3(256), 0, s, n, q, alpha, F, w0, w1, w2, wperm, out, gp, gf, svd_out);
+  f4* act4 = reinterpret_cast<f4*>(act_out);
+  if (kind == NM_ELASTICITY && act4)
+    NM_LAUNCH((k_material_fwd<NM_ELASTICITY, true>), dim3(launch), dim3(256), 0, s, n, q, alpha, F, w0, w1, w2, wperm, out, gp, gf, svd_out, act4);
+  else if (kind == NM_ELASTICITY)
+    NM_LAUNCH((k_material_fwd<NM_ELASTICITY, false>), dim3(launch), dim3(256), 0, s, n, q, alpha, F, w0, w1, w2, wperm, out, gp, gf, svd_out, act4);
+  else if (act4)
+    NM_LAUNCH((k_material_fwd<NM_PLASTICITY, true>), dim3(launch), dim3(256), 0, s, n, q, alpha, F, w0, w1, w2, wperm, out, gp, gf, svd_out, act4);
   else
-    NM_LAUNCH(k_material_fwd<NM_PLASTICITY>, dim3(launch), dim3(256), 0, s, n, q, alpha, F, w0, w1, w2, wperm, out, gp, gf, svd_out);
+    NM_LAUNCH((k_material_fwd<NM_PLASTICITY, false>), dim3(launch), dim3(256), 0, s, n, q, alpha, F, w0, w1, w2, wperm, out, gp, gf, svd_out, act4);
   NM_LAUNCH_CHECK();
   return NM_OK;
 }
@@ -630,9 +662,10 @@ struct BwdArgs {
   float *gF, *wpart;
   int want_w;
   BwdFuse fz;
+  const f4* act;      // activation cache written by the forward kernel (mlp_forward_tile), or NULL: recompute
 };
 
-template <int KIND>
+template <int KIND, bool ACT>
 __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_raw) {
   const int n = a.n, q = a.q, want_w = a.want_w;
   const float alpha = a.alpha;
@@ -678,6 +711,14 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
     const int p = c0 + lane;
     const bool valid = p < pend;
     const int ntile = (min(64, pend - c0) + 15) >> 4;
+    // activation cache: the records of the round's first tile are requested now (they arrive under the feature computation),
+    // those of tile ct + 1 at the top of tile ct - one tile of work (~7 k cycles) covers an HBM round trip
+    f4 nx[ACT ? NM_ACT_SLOTS : 1];
+    const f4* act_tile = ACT ? a.act + (size_t)(c0 >> 4) * NM_ACT_SLOTS * 64 + lane : nullptr;
+    if (ACT) {
+#pragma unroll
+      for (int k = 0; k < NM_ACT_SLOTS; ++k) nx[k] = act_tile[k * 64];
+    }
     M3 Fp = valid ? m3_load(F + 9 * p) : m3_ident();
     M3 go = valid ? m3_load(gout + 9 * p) : m3_zero();
     if (fz.trial_C && valid && fz.enabled[p] != 0) {   // roll-out: input is the trial F = (I + dt C') F of mpm.py:489
@@ -727,12 +768,33 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
       //   (f) zbar = W0^T pre1bar                                      [fetch (e)]
       //   (e) W0bar += pre1bar z^T          (TB, Z)
       MlpFwd m;
-      float zin[4];
+      if (ACT) {
+        f4 h1[4], h2[4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) zin[ks] = zb[(ct * 16 + j) * 17 + 4 * ks + g];
-      AGroup<8> first;
-      a_fetch<8>(first, L.P0, lane, 0);
-      mlp_forward_tile<true>(L.P0, L.P1, L.P2, zin, lane, first, m, want_w ? tc : nullptr, want_w ? tb : nullptr);
+        for (int rt = 0; rt < 4; ++rt) { h1[rt] = nx[rt]; m.g1[rt] = nx[4 + rt]; h2[rt] = nx[8 + rt]; m.g2[rt] = nx[12 + rt]; }
+        m.y = nx[16];
+        if (ct + 1 < ntile) {
+#pragma unroll
+          for (int k = 0; k < NM_ACT_SLOTS; ++k) nx[k] = act_tile[((size_t)(ct + 1) * NM_ACT_SLOTS + k) * 64];
+        }
+        if (want_w) {       // h1 -> TC, h2 -> TB, transposed, as the recompute path leaves them
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              tc[(16 * rt + 4 * g + r) * 17 + j] = h1[rt][r];
+              tb[(16 * rt + 4 * g + r) * 17 + j] = h2[rt][r];
+            }
+          __builtin_amdgcn_wave_barrier();
+        }
+      } else {
+        float zin[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) zin[ks] = zb[(ct * 16 + j) * 17 + 4 * ks + g];
+        AGroup<8> first;
+        a_fetch<8>(first, L.P0, lane, 0);
+        mlp_forward_tile<true>(L.P0, L.P1, L.P2, zin, lane, first, m, want_w ? tc : nullptr, want_w ? tb : nullptr);
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int row = 4 * g + r;
@@ -984,25 +1046,26 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
   }
 }
 
-template <int KIND>
+template <int KIND, bool ACT>
 __global__ void __launch_bounds__(256, 1) k_material_bwd(BwdArgs a, GridPrologue pro) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // roll-out: grid restore + clear of the MPM adjoint that follows (nm_grid.h) - on workgroups of its own when CUs are to spare
   if (NM_PROLOGUE_SPLIT(pro)) return;
-  material_bwd_body<KIND>(a, smem_raw);
+  material_bwd_body<KIND, ACT>(a, smem_raw);
 }
 
 // Roll-out reverse sweep: the elasticity adjoint of substep t and the plasticity adjoint of substep t-1 in ONE launch.  The
 // second only needs the first's dL/dF of the same particle (a wave owns the same particles in both), so the pair saves a
 // launch boundary - and k_material_bwd's boundaries are expensive: its waves own a SIMD's whole register file, so the
 // neighbouring kernels cannot overlap its ramp-up / drain (~5 us).  `pro` is the grid prologue of substep t-1.
+template <bool ACT>
 __global__ void __launch_bounds__(256, 1) k_material_bwd_pair(BwdArgs e, BwdArgs p, GridPrologue pro) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (NM_PROLOGUE_SPLIT(pro)) return;
-  material_bwd_body<NM_ELASTICITY>(e, smem_raw);
+  material_bwd_body<NM_ELASTICITY, ACT>(e, smem_raw);
   __threadfence_block();     // dL/dF written by this workgroup's lanes is read back by the same lanes below
   __syncthreads();
-  material_bwd_body<NM_PLASTICITY>(p, smem_raw);
+  material_bwd_body<NM_PLASTICITY, ACT>(p, smem_raw);
 }
 
 // sum the per-workgroup partials: a workgroup owns 64 consecutive weights, its four waves each sum a quarter of the
@@ -1039,11 +1102,17 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
 static int bwd_attr_once() {
   static bool attr_set = false;
   if (!attr_set) {
-    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd<NM_ELASTICITY>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd<NM_ELASTICITY, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)sizeof(BwdLds)));
-    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd<NM_PLASTICITY>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd<NM_PLASTICITY, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)sizeof(BwdLds)));
-    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd_pair, hipFuncAttributeMaxDynamicSharedMemorySize,
+    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd_pair<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)sizeof(BwdLds)));
+    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd<NM_ELASTICITY, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)sizeof(BwdLds)));
+    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd<NM_PLASTICITY, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)sizeof(BwdLds)));
+    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd_pair<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)sizeof(BwdLds)));
     attr_set = true;
   }
@@ -1051,19 +1120,20 @@ static int bwd_attr_once() {
 }
 static BwdArgs bwd_args(int32_t n, int q, float alpha, const float* F, const nm_mlp* w, const float* wperm, const float* gout,
                         float* gF, float* wpart, int wmode, const float* trial_C, const int* enabled, float dt, int flags,
-                        const float* svd_in = nullptr) {
+                        const float* svd_in = nullptr, const float* act = nullptr) {
   BwdArgs a;
   a.n = n; a.q = q; a.alpha = alpha; a.F = F;
   a.w0 = w ? w->w0 : nullptr; a.w1 = w ? w->w1 : nullptr; a.w2 = w ? w->w2 : nullptr;
   a.wperm = wperm; a.gout = gout; a.gF = gF; a.wpart = wpart; a.want_w = wmode;
   a.fz.trial_C = trial_C; a.fz.enabled = enabled; a.fz.dt = dt; a.fz.add_to_gF = flags & 1; a.fz.polar = (flags >> 1) & 1;
   a.fz.svd_in = svd_in;
+  a.act = reinterpret_cast<const f4*>(act);
   return a;
 }
 
 int nm_material_bwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* wperm,
                            const float* gout, float* gF, float* wpart, int wmode, const float* trial_C, const int* enabled,
-                           float dt, int add_to_gF, const GridPrologue* pro, void* stream, const float* svd_in) {
+                           float dt, int add_to_gF, const GridPrologue* pro, void* stream, const float* svd_in, const float* act) {
   GridPrologue gp;
   if (pro) gp = *pro; else { memset(&gp, 0, sizeof(gp)); }
   hipStream_t s = (hipStream_t)stream;
@@ -1073,11 +1143,15 @@ int nm_material_bwd_launch(int32_t n, int32_t kind, float alpha, const float* F,
   const int launch = (pro && grid + NM_PRO_WGS <= NM_BWD_GRID) ? grid + NM_PRO_WGS : grid;
   int rc = bwd_attr_once();
   if (rc) return rc;
-  BwdArgs a = bwd_args(n, q, alpha, F, w, wperm, gout, gF, wpart, wmode, trial_C, enabled, dt, add_to_gF, svd_in);
-  if (kind == NM_ELASTICITY)
-    NM_LAUNCH(k_material_bwd<NM_ELASTICITY>, dim3(launch), dim3(256), sizeof(BwdLds), s, a, gp);
+  BwdArgs a = bwd_args(n, q, alpha, F, w, wperm, gout, gF, wpart, wmode, trial_C, enabled, dt, add_to_gF, svd_in, act);
+  if (kind == NM_ELASTICITY && act)
+    NM_LAUNCH((k_material_bwd<NM_ELASTICITY, true>), dim3(launch), dim3(256), sizeof(BwdLds), s, a, gp);
+  else if (kind == NM_ELASTICITY)
+    NM_LAUNCH((k_material_bwd<NM_ELASTICITY, false>), dim3(launch), dim3(256), sizeof(BwdLds), s, a, gp);
+  else if (act)
+    NM_LAUNCH((k_material_bwd<NM_PLASTICITY, true>), dim3(launch), dim3(256), sizeof(BwdLds), s, a, gp);
   else
-    NM_LAUNCH(k_material_bwd<NM_PLASTICITY>, dim3(launch), dim3(256), sizeof(BwdLds), s, a, gp);
+    NM_LAUNCH((k_material_bwd<NM_PLASTICITY, false>), dim3(launch), dim3(256), sizeof(BwdLds), s, a, gp);
   NM_LAUNCH_CHECK();
   return NM_OK;
 }
@@ -1088,7 +1162,7 @@ int nm_material_bwd_pair_launch(int32_t n, const float* F_e, const nm_mlp* we, c
                                 float* wpart_e, int wmode_e, float alpha_p, const float* F_p, const nm_mlp* wp,
                                 const float* wperm_p, float* gFtrial, float* wpart_p, int wmode_p, const float* trial_C,
                                 const int* enabled, float dt, int polar, const GridPrologue* pro, void* stream,
-                                const float* svd_in_e, const float* svd_in_p) {
+                                const float* svd_in_e, const float* svd_in_p, const float* act_e, const float* act_p) {
   GridPrologue gp;
   if (pro) gp = *pro; else { memset(&gp, 0, sizeof(gp)); }
   hipStream_t s = (hipStream_t)stream;
@@ -1098,9 +1172,12 @@ int nm_material_bwd_pair_launch(int32_t n, const float* F_e, const nm_mlp* we, c
   const int launch = (pro && grid + NM_PRO_WGS <= NM_BWD_GRID) ? grid + NM_PRO_WGS : grid;
   int rc = bwd_attr_once();
   if (rc) return rc;
-  BwdArgs e = bwd_args(n, q, 0.f, F_e, we, wperm_e, gS, gF, wpart_e, wmode_e, nullptr, nullptr, 0.f, 1 | (polar ? 2 : 0), svd_in_e);
-  BwdArgs p = bwd_args(n, q, alpha_p, F_p, wp, wperm_p, gF, gFtrial, wpart_p, wmode_p, trial_C, enabled, dt, polar ? 2 : 0, svd_in_p);
-  NM_LAUNCH(k_material_bwd_pair, dim3(launch), dim3(256), sizeof(BwdLds), s, e, p, gp);
+  BwdArgs e = bwd_args(n, q, 0.f, F_e, we, wperm_e, gS, gF, wpart_e, wmode_e, nullptr, nullptr, 0.f, 1 | (polar ? 2 : 0), svd_in_e, act_e);
+  BwdArgs p = bwd_args(n, q, alpha_p, F_p, wp, wperm_p, gF, gFtrial, wpart_p, wmode_p, trial_C, enabled, dt, polar ? 2 : 0, svd_in_p, act_p);
+  if (act_e && act_p)
+    NM_LAUNCH(k_material_bwd_pair<true>, dim3(launch), dim3(256), sizeof(BwdLds), s, e, p, gp);
+  else
+    NM_LAUNCH(k_material_bwd_pair<false>, dim3(launch), dim3(256), sizeof(BwdLds), s, e, p, gp);
   NM_LAUNCH_CHECK();
   return NM_OK;
 }

@@ -75,6 +75,16 @@ extern "C" size_t nm_rollout_svdcache_bytes(int32_t n, int32_t substeps) {
   if (n < 1 || substeps < 1) return 0;
   return (size_t)substeps * 2 * 21 * (size_t)n * sizeof(float);
 }
+// activation cache (cfg->act_cache, optional): the MLPs' hidden activations and GELU derivatives of every substep, in the
+// kernels' own accumulator layout (17 x 16 B per lane and 16-particle tile = 1088 B per particle, substep and net)
+extern "C" size_t nm_rollout_actcache_bytes(int32_t n, int32_t substeps) {
+  if (n < 1 || substeps < 1) return 0;
+  return (size_t)substeps * 2 * nm_material_act_floats(n) * sizeof(float);
+}
+static inline float* act_rec(const nm_rollout_cfg* cfg, int n, int t, int net) {
+  if (!cfg->act_cache) return nullptr;
+  return (float*)cfg->act_cache + ((size_t)t * 2 + net) * nm_material_act_floats(n);
+}
 static inline float* svd_rec(const nm_rollout_cfg* cfg, int n, int t, int net) {
   if (!cfg->svd_cache) return nullptr;
   return (float*)cfg->svd_cache + ((size_t)t * 2 + net) * 21 * (size_t)n;
@@ -109,7 +119,8 @@ extern "C" int nm_rollout_forward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cf
     GridPrologue pro;
     rc = nm_mpm_prologue_forward(h, &pro);
     if (rc) return rc;
-    rc = nm_material_fwd_launch(n, NM_ELASTICITY, 0.f, cur.F, we, w.perm_e, cur.stress, &pro, nullptr, stream, svd_rec(cfg, n, t, 0));  // finetune.py:362
+    rc = nm_material_fwd_launch(n, NM_ELASTICITY, 0.f, cur.F, we, w.perm_e, cur.stress, &pro, nullptr, stream, svd_rec(cfg, n, t, 0),
+                                act_rec(cfg, n, t, 0));  // finetune.py:362
     if (rc) return rc;
     // p2g + grid update here; the substep's g2p runs inside the plasticity kernel, which consumes its trial F from
     // registers (the reverse sweep recomputes the trial F from the checkpointed C', so it is never stored)
@@ -119,7 +130,7 @@ extern "C" int nm_rollout_forward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cf
     rc = nm_mpm_g2p_fuse(h, st, &cur, &nxt, &g2p);
     if (rc) return rc;
     rc = nm_material_fwd_launch(n, NM_PLASTICITY, cfg->plasticity_alpha, nullptr, wp, w.perm_p, nxt.F, nullptr, &g2p, stream,
-                                svd_rec(cfg, n, t, 1));  // finetune.py:364
+                                svd_rec(cfg, n, t, 1), act_rec(cfg, n, t, 1));  // finetune.py:364
     if (rc) return rc;
   }
   return NM_OK;
@@ -162,7 +173,7 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
       // plasticity backward on the trial F of the last substep (recomputed in-kernel from the checkpoints):
       // dL/dF_{t+1} -> dL/dFtrial.  For every earlier substep it rides in the pair launch at the end of this loop body.
       rc = nm_material_bwd_launch(n, NM_PLASTICITY, cfg->plasticity_alpha, cur.F, wp, w.perm_p, gin + 15 * N, w.gFtr, w.part_p, wmode,
-                                  nxt.C, st->enabled, dt, polar ? 2 : 0, nullptr, stream, svd_rec(cfg, n, t, 1));
+                                  nxt.C, st->enabled, dt, polar ? 2 : 0, nullptr, stream, svd_rec(cfg, n, t, 1), act_rec(cfg, n, t, 1));
       if (rc) return rc;
     }
     // sim backward (stress of this step was checkpointed by the forward pass).  Verified sweep: from the second substep
@@ -180,7 +191,7 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
     if (t == 0) {
       // elasticity backward: dL/dstress -> dL/dF (added to the sim's dL/dF)
       rc = nm_material_bwd_launch(n, NM_ELASTICITY, 0.f, cur.F, we, w.perm_e, w.gS, gc.F, w.part_e, wmode, nullptr, nullptr, 0.f,
-                                  1 | (polar ? 2 : 0), nullptr, stream, svd_rec(cfg, n, t, 0));
+                                  1 | (polar ? 2 : 0), nullptr, stream, svd_rec(cfg, n, t, 0), act_rec(cfg, n, t, 0));
       if (rc) return rc;
     } else {
       // elasticity backward of this substep and plasticity backward of the previous one (its input dL/dF_t is exactly
@@ -194,7 +205,7 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
       }
       rc = nm_material_bwd_pair_launch(n, cur.F, we, w.perm_e, w.gS, gc.F, w.part_e, wmode, cfg->plasticity_alpha, prev.F, wp,
                                        w.perm_p, w.gFtr, w.part_p, 2, cur.C, st->enabled, dt, polar, verified ? &pro : nullptr, stream,
-                                       svd_rec(cfg, n, t, 0), svd_rec(cfg, n, t - 1, 1));
+                                       svd_rec(cfg, n, t, 0), svd_rec(cfg, n, t - 1, 1), act_rec(cfg, n, t, 0), act_rec(cfg, n, t - 1, 1));
       if (rc) return rc;
     }
     gin = gout;

@@ -16,6 +16,11 @@ from .sim.order import ParticleOrder, hilbert_index_torch  # noqa: F401 (re-expo
 _WSZ = (64 * 13, 64 * 64, 9 * 64)
 _CACHE_STATUS = __import__('os').environ.get('NEUMA_CACHE_STATUS', '1') != '0'
 _SVD_CACHE = __import__('os').environ.get('NEUMA_SVD_CACHE', '1') != '0'
+# activation cache of the fused roll-out (2.2 KB per particle and substep; nm_rollout_cfg.act_cache).  Measured at the metric
+# workload: the reverse sweep's pair kernel 124.5 -> 109 us, the forward kernels 28 -> 36 us (106 MB of stores each), frame
+# unchanged - so it is OFF by default: '1' = on, 'auto' = on up to NEUMA_ACT_CACHE_GB (default 8) per node
+_ACT_CACHE = __import__('os').environ.get('NEUMA_ACT_CACHE', '0')
+_ACT_CACHE_GB = float(__import__('os').environ.get('NEUMA_ACT_CACHE_GB', '8'))
 
 
 _ZEROS = {}
@@ -99,9 +104,14 @@ class _Rollout(autograd.Function):
         # SVD cache (U, sigma, V of both nets' inputs per substep, 168 B/particle/substep): also only when a backward pass can follow
         svdc = (torch.empty(int(lib.nm_rollout_svdcache_bytes(n, S)), dtype=torch.uint8, device=dev)
                 if (_SVD_CACHE and n > 0 and any(ctx.needs_input_grad)) else None)
+        actc = None
+        if _ACT_CACHE != '0' and n > 0 and any(ctx.needs_input_grad):
+            act_bytes = int(lib.nm_rollout_actcache_bytes(n, S))
+            if _ACT_CACHE == '1' or act_bytes <= _ACT_CACHE_GB * (1 << 30):
+                actc = torch.empty(act_bytes, dtype=torch.uint8, device=dev)
         cfg = L.nm_rollout_cfg(S, float(alpha), cache_blocks if gcache is not None else 0, 0, int(svd_adjoint),
-                               L.ptr(svdc) if svdc is not None else None)
-        ctx.svdc = svdc
+                               L.ptr(svdc) if svdc is not None else None, L.ptr(actc) if actc is not None else None)
+        ctx.svdc, ctx.actc = svdc, actc
         st = statics.c_struct()
         mle = L.nm_mlp(*[L.ptr(t) for t in we])
         mlp = L.nm_mlp(*[L.ptr(t) for t in wp])
@@ -143,8 +153,8 @@ class _Rollout(autograd.Function):
         sws_bytes = int(lib.nm_rollout_shard_workspace(ex.world, cap, cap_shared, S))
         sws = torch.empty(sws_bytes, dtype=torch.uint8, device=dev)
         link = _ShardLink(ex, sws)
-        cfg = L.nm_rollout_cfg(S, alpha, cap, 0, svd_adjoint, None)
-        ctx.svdc = None
+        cfg = L.nm_rollout_cfg(S, alpha, cap, 0, svd_adjoint, None, None)
+        ctx.svdc = ctx.actc = None
         mle = L.nm_mlp(*[L.ptr(t) for t in we])
         mlp = L.nm_mlp(*[L.ptr(t) for t in wp])
         link.check(lib.nm_rollout_forward_sharded(model.handle(), n, C.byref(cfg), C.byref(st), C.byref(mle), C.byref(mlp), L.ptr(states),
@@ -181,8 +191,9 @@ class _Rollout(autograd.Function):
         verified = 0
         if gcache is not None and ctx.cache_event is not None and ctx.cache_event.query():
             verified = int(bool((ctx.cache_status >= 0).all()))
-        svdc = getattr(ctx, "svdc", None)
-        cfg = L.nm_rollout_cfg(S, ctx.alpha, ctx.cache_blocks, verified, ctx.svd_adjoint, L.ptr(svdc) if svdc is not None else None)
+        svdc, actc = getattr(ctx, "svdc", None), getattr(ctx, "actc", None)
+        cfg = L.nm_rollout_cfg(S, ctx.alpha, ctx.cache_blocks, verified, ctx.svd_adjoint, L.ptr(svdc) if svdc is not None else None,
+                               L.ptr(actc) if actc is not None else None)
         st = ctx.statics.c_struct()
         mle = L.nm_mlp(L.ptr(e0), L.ptr(e1), L.ptr(e2))
         mlp = L.nm_mlp(L.ptr(p0), L.ptr(p1), L.ptr(p2))
@@ -198,7 +209,7 @@ class _Rollout(autograd.Function):
                                             L.ptr(states), L.ptr(gcache) if gcache is not None else None, L.ptr(glast), L.ptr(gfirst),
                                             L.ptr(gwe), L.ptr(gwp), L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "nm_rollout_backward")
         ctx.gcache = None
-        ctx.svdc = None
+        ctx.svdc = ctx.actc = None
         torch.nan_to_num_(gfirst, 0.0, 0.0, 0.0)   # interface.py:65-74 at the boundary of the fused node
         a, b = _WSZ[0], _WSZ[0] + _WSZ[1]
         return (None, None, None, None, None, None,
