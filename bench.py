@@ -34,6 +34,7 @@ def prof_table(lib):
     out = {}
     for line in buf.value.decode().splitlines():
         name, calls, ms = line.rsplit(" ", 2)
+        name = name.strip("()")          # (template instances with a comma are launched through a parenthesised macro argument)
         out[name] = (int(calls), float(ms))
     return out
 
@@ -190,8 +191,12 @@ def main():
     lib.nm_prof_reset()
     lib.nm_prof_enable(1, None)
     zero_grads()
+    # per-kernel durations are taken with the views rendered one after another: on concurrent streams the compositing
+    # kernels of different views stretch each other (450 -> 690 us) and the comparison between kernels would be skewed
+    overlap, rt.overlap_views = rt.overlap_views, False
     rt.frame()
     sync()
+    rt.overlap_views = overlap
     lib.nm_prof_enable(0, None)
     full = prof_table(lib)
     lib.nm_prof_reset()
@@ -255,15 +260,21 @@ def main():
         avg_s = ms / calls / 1e3
         base = dom_base
         if base in MATERIAL_FLOPS:
-            # MFMA-bound: 2*(13*64 + 64*64 + 64*9) = 11 008 flop per particle per net forward; the backward recomputes
-            # the forward and adds data-gradient and weight-gradient GEMMs of the same size (3x); the pair kernel of the
-            # reverse sweep runs two nets' backward passes per launch
+            # MFMA-bound: 2*(13*64 + 64*64 + 64*9) = 11 008 flop per particle per net forward; SURVEY §8d's figure for the
+            # backward pass is 3x that (forward recompute + data-gradient + weight-gradient GEMMs); the pair kernel of the
+            # reverse sweep runs two nets' backward passes per launch.  With the activation cache (default)
+            # the kernel loads the forward activations instead of recomputing them and executes 2x: both fractions are
+            # reported, `frac` uses SURVEY's figure as the contract asks
             flops = MATERIAL_FLOPS[base] * rt.n_local
             achieved = flops / avg_s / 1e12 if avg_s > 0 else 0.0
             roof = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 3), "peak": 157.3, "unit": "TFLOP/s",
                     "frac": round(achieved / 157.3, 5), "traffic": None, "launches": calls, "avg_us": round(avg_s * 1e6, 2),
                     "algorithmic_flops_per_launch": flops,
                     "note": "f32-input MFMA (v_mfma_f32_16x16x4_f32) peak = 157.3 TFLOP/s; the kernel also carries the SVD and GELU VALU work"}
+            if base != "k_material_fwd":
+                cached = os.environ.get("NEUMA_ACT_CACHE", "auto") != "0" and not args.per_op
+                roof["activation_cache"] = bool(cached)
+                roof["frac_of_executed_flops"] = round(achieved / 157.3 * (2.0 / 3.0 if cached else 1.0), 5)
         else:
             frac_view = 1.0
             if world > 1 and name.startswith(("k_render", "k_preprocess")):

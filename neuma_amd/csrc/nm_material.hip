@@ -426,8 +426,8 @@ __device__ __forceinline__ void mlp_forward_tile(const float* __restrict__ P0, c
     if (WITH_GRAD && act) {
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
-        act[rt * 64 + lane] = (f4){hb[4 * rt], hb[4 * rt + 1], hb[4 * rt + 2], hb[4 * rt + 3]};
-        act[(4 + rt) * 64 + lane] = o.g1[rt];
+        __builtin_nontemporal_store((f4){hb[4 * rt], hb[4 * rt + 1], hb[4 * rt + 2], hb[4 * rt + 3]}, &act[rt * 64 + lane]);
+        __builtin_nontemporal_store(o.g1[rt], &act[(4 + rt) * 64 + lane]);
       }
     }
   });
@@ -459,13 +459,13 @@ __device__ __forceinline__ void mlp_forward_tile(const float* __restrict__ P0, c
     if (WITH_GRAD && act) {
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
-        act[(8 + rt) * 64 + lane] = (f4){hb[4 * rt], hb[4 * rt + 1], hb[4 * rt + 2], hb[4 * rt + 3]};
-        act[(12 + rt) * 64 + lane] = o.g2[rt];
+        __builtin_nontemporal_store((f4){hb[4 * rt], hb[4 * rt + 1], hb[4 * rt + 2], hb[4 * rt + 3]}, &act[(8 + rt) * 64 + lane]);
+        __builtin_nontemporal_store(o.g2[rt], &act[(12 + rt) * 64 + lane]);
       }
     }
   });
   o.y = yy[0] + yy[1];
-  if (WITH_GRAD && act) act[16 * 64 + lane] = o.y;
+  if (WITH_GRAD && act) __builtin_nontemporal_store(o.y, &act[16 * 64 + lane]);
 }
 #define NM_ACT_SLOTS 17      // f4 slots per lane and 16-particle tile in the activation cache
 
@@ -717,7 +717,7 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
     const f4* act_tile = ACT ? a.act + (size_t)(c0 >> 4) * NM_ACT_SLOTS * 64 + lane : nullptr;
     if (ACT) {
 #pragma unroll
-      for (int k = 0; k < NM_ACT_SLOTS; ++k) nx[k] = act_tile[k * 64];
+      for (int k = 0; k < NM_ACT_SLOTS; ++k) nx[k] = __builtin_nontemporal_load(&act_tile[k * 64]);
     }
     M3 Fp = valid ? m3_load(F + 9 * p) : m3_ident();
     M3 go = valid ? m3_load(gout + 9 * p) : m3_zero();
@@ -775,7 +775,7 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
         m.y = nx[16];
         if (ct + 1 < ntile) {
 #pragma unroll
-          for (int k = 0; k < NM_ACT_SLOTS; ++k) nx[k] = act_tile[((size_t)(ct + 1) * NM_ACT_SLOTS + k) * 64];
+          for (int k = 0; k < NM_ACT_SLOTS; ++k) nx[k] = __builtin_nontemporal_load(&act_tile[((size_t)(ct + 1) * NM_ACT_SLOTS + k) * 64]);
         }
         if (want_w) {       // h1 -> TC, h2 -> TB, transposed, as the recompute path leaves them
 #pragma unroll

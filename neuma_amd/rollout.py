@@ -16,11 +16,17 @@ from .sim.order import ParticleOrder, hilbert_index_torch  # noqa: F401 (re-expo
 _WSZ = (64 * 13, 64 * 64, 9 * 64)
 _CACHE_STATUS = __import__('os').environ.get('NEUMA_CACHE_STATUS', '1') != '0'
 _SVD_CACHE = __import__('os').environ.get('NEUMA_SVD_CACHE', '1') != '0'
-# activation cache of the fused roll-out (2.2 KB per particle and substep; nm_rollout_cfg.act_cache).  Measured at the metric
-# workload: the reverse sweep's pair kernel 124.5 -> 109 us, the forward kernels 28 -> 36 us (106 MB of stores each), frame
-# unchanged - so it is OFF by default: '1' = on, 'auto' = on up to NEUMA_ACT_CACHE_GB (default 8) per node
-_ACT_CACHE = __import__('os').environ.get('NEUMA_ACT_CACHE', '0')
-_ACT_CACHE_GB = float(__import__('os').environ.get('NEUMA_ACT_CACHE_GB', '8'))
+# activation cache of the fused roll-out (2.2 KB per particle and substep; nm_rollout_cfg.act_cache): the forward kernels keep
+# the MLPs' hidden activations, the reverse sweep loads them instead of recomputing (metric workload: frame 7.88 -> 7.49 ms,
+# 4.35 GB per 20-substep node).  'auto' (default): on while the caches of all live roll-out nodes stay below
+# NEUMA_ACT_CACHE_GB (default 48); '1': always; '0': never (recompute, the reference's memory profile)
+_ACT_CACHE = __import__('os').environ.get('NEUMA_ACT_CACHE', 'auto')
+_ACT_CACHE_GB = float(__import__('os').environ.get('NEUMA_ACT_CACHE_GB', '48'))
+_ACT_LIVE = [0]         # bytes of activation cache held by live roll-out nodes
+
+
+def _act_release(nbytes: int) -> None:
+    _ACT_LIVE[0] -= nbytes
 
 
 _ZEROS = {}
@@ -107,8 +113,10 @@ class _Rollout(autograd.Function):
         actc = None
         if _ACT_CACHE != '0' and n > 0 and any(ctx.needs_input_grad):
             act_bytes = int(lib.nm_rollout_actcache_bytes(n, S))
-            if _ACT_CACHE == '1' or act_bytes <= _ACT_CACHE_GB * (1 << 30):
+            if _ACT_CACHE == '1' or _ACT_LIVE[0] + act_bytes <= _ACT_CACHE_GB * (1 << 30):
                 actc = torch.empty(act_bytes, dtype=torch.uint8, device=dev)
+                _ACT_LIVE[0] += act_bytes
+                __import__('weakref').finalize(actc, _act_release, act_bytes)
         cfg = L.nm_rollout_cfg(S, float(alpha), cache_blocks if gcache is not None else 0, 0, int(svd_adjoint),
                                L.ptr(svdc) if svdc is not None else None, L.ptr(actc) if actc is not None else None)
         ctx.svdc, ctx.actc = svdc, actc
