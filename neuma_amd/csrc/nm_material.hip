@@ -304,19 +304,19 @@ __global__ void __launch_bounds__(256) k_permute_weights(const float* __restrict
 // the Jacobi iteration again on the same matrix (5 k of the 7 k cycles a 64-particle round spends before its first tile).
 __device__ __forceinline__ void svd_store(float* __restrict__ dst, int n, int p, const M3& U, const float s[3], const M3& V) {
 #pragma unroll
-  for (int c = 0; c < 9; ++c) dst[(size_t)c * n + p] = U.m[c];
+  for (int c = 0; c < 9; ++c) __builtin_nontemporal_store(U.m[c], &dst[(size_t)c * n + p]);
 #pragma unroll
-  for (int c = 0; c < 3; ++c) dst[(size_t)(9 + c) * n + p] = s[c];
+  for (int c = 0; c < 3; ++c) __builtin_nontemporal_store(s[c], &dst[(size_t)(9 + c) * n + p]);
 #pragma unroll
-  for (int c = 0; c < 9; ++c) dst[(size_t)(12 + c) * n + p] = V.m[c];
+  for (int c = 0; c < 9; ++c) __builtin_nontemporal_store(V.m[c], &dst[(size_t)(12 + c) * n + p]);
 }
 __device__ __forceinline__ void svd_load(const float* __restrict__ src, int n, int p, M3& U, float s[3], M3& V) {
 #pragma unroll
-  for (int c = 0; c < 9; ++c) U.m[c] = src[(size_t)c * n + p];
+  for (int c = 0; c < 9; ++c) U.m[c] = __builtin_nontemporal_load(&src[(size_t)c * n + p]);
 #pragma unroll
-  for (int c = 0; c < 3; ++c) s[c] = src[(size_t)(9 + c) * n + p];
+  for (int c = 0; c < 3; ++c) s[c] = __builtin_nontemporal_load(&src[(size_t)(9 + c) * n + p]);
 #pragma unroll
-  for (int c = 0; c < 9; ++c) V.m[c] = src[(size_t)(12 + c) * n + p];
+  for (int c = 0; c < 9; ++c) V.m[c] = __builtin_nontemporal_load(&src[(size_t)(12 + c) * n + p]);
 }
 // HAVE_SVD: U, s, V are given (svd_load)
 template <bool HAVE_SVD = false>
