@@ -120,12 +120,14 @@ __global__ void __launch_bounds__(256) k_pixel_loss(int kind, float scale, int h
     const size_t base = (size_t)r * w;
     if (VEC4) {
       const float4* a4 = reinterpret_cast<const float4*>(img + base);
-      const float4* g4 = reinterpret_cast<const float4*>(gt + base);
+      typedef float f4v __attribute__((ext_vector_type(4)));
+      const f4v* g4 = reinterpret_cast<const f4v*>(gt + base);      // the ground truth is read once per frame: streamed past the caches
       float4* o4 = grad ? reinterpret_cast<float4*>(grad + base) : nullptr;
       for (int i = threadIdx.x; i < w / 4; i += 256) {
         float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (in) {
-          const float4 a = a4[i], g = g4[i];
+          const float4 a = a4[i];
+          const f4v g = __builtin_nontemporal_load(&g4[i]);
           const float d[4] = {a.x - g.x, a.y - g.y, a.z - g.z, a.w - g.w};
           float o[4];
 #pragma unroll

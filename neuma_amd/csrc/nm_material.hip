@@ -775,7 +775,7 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
         m.y = nx[16];
         if (ct + 1 < ntile) {
 #pragma unroll
-          for (int k = 0; k < NM_ACT_SLOTS; ++k) nx[k] = __builtin_nontemporal_load(&act_tile[((size_t)(ct + 1) * NM_ACT_SLOTS + k) * 64]);
+          for (int k = 0; k < 8; ++k) nx[k] = __builtin_nontemporal_load(&act_tile[((size_t)(ct + 1) * NM_ACT_SLOTS + k) * 64]);
         }
         if (want_w) {       // h1 -> TC, h2 -> TB, transposed, as the recompute path leaves them
 #pragma unroll
@@ -846,6 +846,10 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
         }
       }
       NM_PH(3)
+      if (ACT && ct + 1 < ntile) {      // second half of the next tile's record (two smaller bursts instead of one)
+#pragma unroll
+        for (int k = 8; k < NM_ACT_SLOTS; ++k) nx[k] = __builtin_nontemporal_load(&act_tile[((size_t)(ct + 1) * NM_ACT_SLOTS + k) * 64]);
+      }
       // ---- (d)
       f4 d1[4] = {zero, zero, zero, zero};
       float w1a[2][4], w1b[2][4];  // (c): A = pre2bar via TA, B = h1 via TC
