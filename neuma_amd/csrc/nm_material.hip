@@ -678,7 +678,8 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
   NM_PH_DECL
   if (wperm) {
     static_assert(offsetof(BwdLds, Z) == NM_PERM_ALL * sizeof(float), "P0..Q2 must be contiguous in operand order");
-    stage_permuted<NM_PERM_ALL>(wperm, L.P0);
+    if (ACT) stage_permuted<NM_PERM_ALL - NM_PERM_FWD>(wperm + NM_PERM_FWD, L.Q0);   // no forward recompute: transposed operands only
+    else stage_permuted<NM_PERM_ALL>(wperm, L.P0);
     __syncthreads();
   } else {
     float* raw = &L.Z[0][0];   // the per-wave buffers (>= 22 016 floats) are free until the main loop
