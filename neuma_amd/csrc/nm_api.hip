@@ -36,6 +36,7 @@ static hipEvent_t prof_event() {
 }
 static bool prof_match(const char* name) {
   if (g_only.empty()) return true;
+  if (*name == '(') ++name;      // (a template instance with a comma is a parenthesised macro argument)
   // template instantiations arrive as "k_material_fwd<NM_ELASTICITY>": match on the prefix
   return strncmp(name, g_only.c_str(), g_only.size()) == 0;
 }
