@@ -776,7 +776,7 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
         m.y = nx[16];
         if (ct + 1 < ntile) {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) nx[k] = __builtin_nontemporal_load(&act_tile[((size_t)(ct + 1) * NM_ACT_SLOTS + k) * 64]);
+          for (int k = 0; k < 6; ++k) nx[k] = __builtin_nontemporal_load(&act_tile[((size_t)(ct + 1) * NM_ACT_SLOTS + k) * 64]);
         }
         if (want_w) {       // h1 -> TC, h2 -> TB, transposed, as the recompute path leaves them
 #pragma unroll
@@ -847,9 +847,9 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
         }
       }
       NM_PH(3)
-      if (ACT && ct + 1 < ntile) {      // second half of the next tile's record (two smaller bursts instead of one)
+      if (ACT && ct + 1 < ntile) {      // second third of the next tile's record (three smaller bursts instead of one)
 #pragma unroll
-        for (int k = 8; k < NM_ACT_SLOTS; ++k) nx[k] = __builtin_nontemporal_load(&act_tile[((size_t)(ct + 1) * NM_ACT_SLOTS + k) * 64]);
+        for (int k = 6; k < 12; ++k) nx[k] = __builtin_nontemporal_load(&act_tile[((size_t)(ct + 1) * NM_ACT_SLOTS + k) * 64]);
       }
       // ---- (d)
       f4 d1[4] = {zero, zero, zero, zero};
@@ -872,6 +872,10 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) d1[rt] *= m.g1[rt];
       NM_PH(6)
+      if (ACT && ct + 1 < ntile) {
+#pragma unroll
+        for (int k = 12; k < NM_ACT_SLOTS; ++k) nx[k] = __builtin_nontemporal_load(&act_tile[((size_t)(ct + 1) * NM_ACT_SLOTS + k) * 64]);
+      }
       AGroup<8> q0g;
       a_fetch<8>(q0g, L.Q0, lane, 0);
       NM_SB();
