@@ -263,7 +263,7 @@ def main():
             # MFMA-bound: 2*(13*64 + 64*64 + 64*9) = 11 008 flop per particle per net forward; SURVEY §8d's figure for the
             # backward pass is 3x that (forward recompute + data-gradient + weight-gradient GEMMs); the pair kernel of the
             # reverse sweep runs two nets' backward passes per launch.  With the activation cache (default)
-            # the kernel loads the forward activations instead of recomputing them and executes 2x: both fractions are
+            # the kernel loads the second layer's activations instead of recomputing them and executes 2.15x: both fractions are
             # reported, `frac` uses SURVEY's figure as the contract asks
             flops = MATERIAL_FLOPS[base] * rt.n_local
             achieved = flops / avg_s / 1e12 if avg_s > 0 else 0.0
@@ -274,7 +274,8 @@ def main():
             if base != "k_material_fwd":
                 cached = os.environ.get("NEUMA_ACT_CACHE", "auto") != "0" and not args.per_op
                 roof["activation_cache"] = bool(cached)
-                roof["frac_of_executed_flops"] = round(achieved / 157.3 * (2.0 / 3.0 if cached else 1.0), 5)
+                # with the cache the kernel runs 204 of the 284 MFMAs per tile (second and third layer of the forward pass loaded, first recomputed)
+                roof["frac_of_executed_flops"] = round(achieved / 157.3 * (204.0 / 284.0 if cached else 1.0), 5)
         else:
             frac_view = 1.0
             if world > 1 and name.startswith(("k_render", "k_preprocess")):

@@ -248,7 +248,7 @@ typedef struct nm_rollout_cfg {
                               * instead of repeating the Jacobi SVD; NULL = recompute (same results to rounding: the trial F the
                               * reverse sweep rebuilds from the checkpoints differs from the forward's in the last bit) */
   void* act_cache;           /* optional device buffer of nm_rollout_actcache_bytes(n, substeps): the forward pass keeps the two hidden
-                              * layers' activations and GELU derivatives of both nets (2.2 KB/particle/substep) and the reverse
+                              * layer outputs the reverse sweep cannot cheaply rebuild (second hidden layer + GELU derivative + output of both nets: 1.2 KB/particle/substep) and the reverse
                               * sweep loads them instead of recomputing the MLPs' forward pass (a third of its matrix work and all
                               * of its GELUs); NULL = recompute.  Same arithmetic, same results. */
 } nm_rollout_cfg;

@@ -390,9 +390,11 @@ __device__ __forceinline__ void mlp_forward_tile(const float* __restrict__ P0, c
                                                  const float* __restrict__ P2, const float* zin /* 4 B operands of layer 0 */,
                                                  int lane, AGroup<8>& first, MlpFwd& o, float* th1 = nullptr, float* th2 = nullptr,
                                                  f4* __restrict__ act = nullptr) {
-  // act != NULL (activation cache of the fused roll-out, WITH_GRAD only): the tile's hidden activations and GELU derivatives
-  // are written out in the accumulator layout itself - NM_ACT_SLOTS x 64 lanes x 16 B, slot k: h1[k], g1[k-4], h2[k-8],
-  // g2[k-12], y - in the shadow of the following MFMA chains; the reverse sweep loads them back instead of recomputing.
+  // act != NULL (activation cache of the fused roll-out, WITH_GRAD only): the second hidden layer's activations and GELU
+  // derivatives and the output are written out in the accumulator layout itself - NM_ACT_SLOTS x 64 lanes x 16 B, slots
+  // h2[0..3], g2[4..7], y[8] - in the shadow of the last MFMA chain; the reverse sweep loads them back and recomputes only
+  // the first layer (16 of the forward pass's 96 MFMAs, half of its GELUs).  The whole record (17 slots) was measured too:
+  // the reverse sweep's tile loops then ask for 5.3 TB/s and the forward kernels write twice as much - slower overall.
   const f4 zero = {0.f, 0.f, 0.f, 0.f};
   const int j = lane & 15, g = lane >> 4;
   f4 a1[4] = {zero, zero, zero, zero};
@@ -423,13 +425,6 @@ __device__ __forceinline__ void mlp_forward_tile(const float* __restrict__ P0, c
         for (int r = 0; r < 4; ++r) th1[(16 * rt + 4 * g + r) * 17 + j] = hb[4 * rt + r];
       __builtin_amdgcn_wave_barrier();   // (other lanes read these words: keep the compiler from reordering around them)
     }
-    if (WITH_GRAD && act) {
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-        __builtin_nontemporal_store((f4){hb[4 * rt], hb[4 * rt + 1], hb[4 * rt + 2], hb[4 * rt + 3]}, &act[rt * 64 + lane]);
-        __builtin_nontemporal_store(o.g1[rt], &act[(4 + rt) * 64 + lane]);
-      }
-    }
   });
   AGroup<8> w2g;
   a_fetch<8>(w2g, P2, lane, 0);
@@ -459,15 +454,15 @@ __device__ __forceinline__ void mlp_forward_tile(const float* __restrict__ P0, c
     if (WITH_GRAD && act) {
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
-        __builtin_nontemporal_store((f4){hb[4 * rt], hb[4 * rt + 1], hb[4 * rt + 2], hb[4 * rt + 3]}, &act[(8 + rt) * 64 + lane]);
-        __builtin_nontemporal_store(o.g2[rt], &act[(12 + rt) * 64 + lane]);
+        __builtin_nontemporal_store((f4){hb[4 * rt], hb[4 * rt + 1], hb[4 * rt + 2], hb[4 * rt + 3]}, &act[rt * 64 + lane]);
+        __builtin_nontemporal_store(o.g2[rt], &act[(4 + rt) * 64 + lane]);
       }
     }
   });
   o.y = yy[0] + yy[1];
-  if (WITH_GRAD && act) __builtin_nontemporal_store(o.y, &act[16 * 64 + lane]);
+  if (WITH_GRAD && act) __builtin_nontemporal_store(o.y, &act[8 * 64 + lane]);
 }
-#define NM_ACT_SLOTS 17      // f4 slots per lane and 16-particle tile in the activation cache
+#define NM_ACT_SLOTS 9       // f4 slots per lane and 16-particle tile in the activation cache: h2[4], g2[4], y
 
 // ---------------------------------------------------------------- forward
 // Work split of the constitutive kernels: one workgroup (4 waves, one per SIMD) per CU, each wave owns q consecutive
@@ -678,8 +673,12 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
   NM_PH_DECL
   if (wperm) {
     static_assert(offsetof(BwdLds, Z) == NM_PERM_ALL * sizeof(float), "P0..Q2 must be contiguous in operand order");
-    if (ACT) stage_permuted<NM_PERM_ALL - NM_PERM_FWD>(wperm + NM_PERM_FWD, L.Q0);   // no forward recompute: transposed operands only
-    else stage_permuted<NM_PERM_ALL>(wperm, L.P0);
+    if (ACT) {      // only the first layer is recomputed: its operands + the transposed ones
+      stage_permuted<16 * 64>(wperm, L.P0);
+      stage_permuted<NM_PERM_ALL - NM_PERM_FWD>(wperm + NM_PERM_FWD, L.Q0);
+    } else {
+      stage_permuted<NM_PERM_ALL>(wperm, L.P0);
+    }
     __syncthreads();
   } else {
     float* raw = &L.Z[0][0];   // the per-wave buffers (>= 22 016 floats) are free until the main loop
@@ -712,32 +711,34 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
     const int p = c0 + lane;
     const bool valid = p < pend;
     const int ntile = (min(64, pend - c0) + 15) >> 4;
-    // activation cache: the records of the round's first tile are requested now (they arrive under the feature computation),
-    // those of tile ct + 1 at the top of tile ct - one tile of work (~7 k cycles) covers an HBM round trip
+    // The round's loads are issued in the order they are needed - F, dL/dout, trial C', the SVD factors, and only then the
+    // activation record of the round's first tile (vmcnt retires in order: with the 17 KB record in front, the feature
+    // computation waited for all of it: +6 k cycles per round).  Tile ct + 1's record is requested during tile ct.
     f4 nx[ACT ? NM_ACT_SLOTS : 1];
     const f4* act_tile = ACT ? a.act + (size_t)(c0 >> 4) * NM_ACT_SLOTS * 64 + lane : nullptr;
-    if (ACT) {
-#pragma unroll
-      for (int k = 0; k < NM_ACT_SLOTS; ++k) nx[k] = __builtin_nontemporal_load(&act_tile[k * 64]);
-    }
     M3 Fp = valid ? m3_load(F + 9 * p) : m3_ident();
     M3 go = valid ? m3_load(gout + 9 * p) : m3_zero();
-    if (fz.trial_C && valid && fz.enabled[p] != 0) {   // roll-out: input is the trial F = (I + dt C') F of mpm.py:489
-      M3 T = m3_load(fz.trial_C + 9 * p);
-#pragma unroll
-      for (int i = 0; i < 9; ++i) T.m[i] *= fz.dt;
-      T.m[0] += 1.f; T.m[4] += 1.f; T.m[8] += 1.f;
-      Fp = m3_mul(T, Fp);
-    }
+    const bool trial = fz.trial_C && valid && fz.enabled[p] != 0;
+    M3 T = trial ? m3_load(fz.trial_C + 9 * p) : m3_zero();
     M3 R, U, V;
     float z[13], s[3];
     if (fz.svd_in) {        // (workgroup-uniform)
       if (valid) svd_load(fz.svd_in, n, p, U, s, V);
       else { U = m3_ident(); V = m3_ident(); s[0] = s[1] = s[2] = 1.f; }
-      nm_features<true>(Fp, z, R, U, V, s);
-    } else {
-      nm_features(Fp, z, R, U, V, s);
     }
+    if (ACT) {
+#pragma unroll
+      for (int k = 0; k < NM_ACT_SLOTS; ++k) nx[k] = __builtin_nontemporal_load(&act_tile[k * 64]);
+    }
+    NM_SB();
+    if (trial) {   // roll-out: input is the trial F = (I + dt C') F of mpm.py:489
+#pragma unroll
+      for (int i = 0; i < 9; ++i) T.m[i] *= fz.dt;
+      T.m[0] += 1.f; T.m[4] += 1.f; T.m[8] += 1.f;
+      Fp = m3_mul(T, Fp);
+    }
+    if (fz.svd_in) nm_features<true>(Fp, z, R, U, V, s);
+    else nm_features(Fp, z, R, U, V, s);
 #pragma unroll
     for (int c = 0; c < 13; ++c) zb[lane * 17 + c] = z[c];
     zb[lane * 17 + 13] = 0.f; zb[lane * 17 + 14] = 0.f; zb[lane * 17 + 15] = 0.f;
@@ -770,24 +771,45 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
       //   (e) W0bar += pre1bar z^T          (TB, Z)
       MlpFwd m;
       if (ACT) {
-        f4 h1[4], h2[4];
+        // first layer recomputed (16 MFMAs + 16 GELU pairs), second layer's activations, derivatives and the output loaded
+        f4 h2[4];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) { h1[rt] = nx[rt]; m.g1[rt] = nx[4 + rt]; h2[rt] = nx[8 + rt]; m.g2[rt] = nx[12 + rt]; }
-        m.y = nx[16];
+        for (int rt = 0; rt < 4; ++rt) { h2[rt] = nx[rt]; m.g2[rt] = nx[4 + rt]; }
+        m.y = nx[8];
         if (ct + 1 < ntile) {
 #pragma unroll
-          for (int k = 0; k < 6; ++k) nx[k] = __builtin_nontemporal_load(&act_tile[((size_t)(ct + 1) * NM_ACT_SLOTS + k) * 64]);
+          for (int k = 0; k < 5; ++k) nx[k] = __builtin_nontemporal_load(&act_tile[((size_t)(ct + 1) * NM_ACT_SLOTS + k) * 64]);
         }
-        if (want_w) {       // h1 -> TC, h2 -> TB, transposed, as the recompute path leaves them
+        float zin[4];
 #pragma unroll
-          for (int rt = 0; rt < 4; ++rt)
+        for (int ks = 0; ks < 4; ++ks) zin[ks] = zb[(ct * 16 + j) * 17 + 4 * ks + g];
+        AGroup<8> first;
+        a_fetch<8>(first, L.P0, lane, 0);
+        const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        f4 a1[4] = {zero4, zero4, zero4, zero4};
+        a_chain<16, 8, 3, 2>(first, L.P0, lane, zin, a1, [&]() {
+          if (want_w) {       // h2 -> TB, transposed, as the recompute path leaves it (in the shadow of the layer-0 chain)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              tc[(16 * rt + 4 * g + r) * 17 + j] = h1[rt][r];
-              tb[(16 * rt + 4 * g + r) * 17 + j] = h2[rt][r];
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) tb[(16 * rt + 4 * g + r) * 17 + j] = h2[rt][r];
+            __builtin_amdgcn_wave_barrier();
+          }
+        });
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            f2 h, dh;
+            nm_gelu_both2((f2){a1[rt][2 * pr], a1[rt][2 * pr + 1]}, h, dh);
+            m.g1[rt][2 * pr] = dh[0];
+            m.g1[rt][2 * pr + 1] = dh[1];
+            if (want_w) {     // h1 -> TC
+              tc[(16 * rt + 4 * g + 2 * pr) * 17 + j] = h[0];
+              tc[(16 * rt + 4 * g + 2 * pr + 1) * 17 + j] = h[1];
             }
-          __builtin_amdgcn_wave_barrier();
-        }
+          }
+        __builtin_amdgcn_wave_barrier();
       } else {
         float zin[4];
 #pragma unroll
@@ -847,9 +869,9 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
         }
       }
       NM_PH(3)
-      if (ACT && ct + 1 < ntile) {      // second third of the next tile's record (three smaller bursts instead of one)
+      if (ACT && ct + 1 < ntile) {      // second half of the next tile's record
 #pragma unroll
-        for (int k = 6; k < 12; ++k) nx[k] = __builtin_nontemporal_load(&act_tile[((size_t)(ct + 1) * NM_ACT_SLOTS + k) * 64]);
+        for (int k = 5; k < NM_ACT_SLOTS; ++k) nx[k] = __builtin_nontemporal_load(&act_tile[((size_t)(ct + 1) * NM_ACT_SLOTS + k) * 64]);
       }
       // ---- (d)
       f4 d1[4] = {zero, zero, zero, zero};
@@ -872,10 +894,6 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) d1[rt] *= m.g1[rt];
       NM_PH(6)
-      if (ACT && ct + 1 < ntile) {
-#pragma unroll
-        for (int k = 12; k < NM_ACT_SLOTS; ++k) nx[k] = __builtin_nontemporal_load(&act_tile[((size_t)(ct + 1) * NM_ACT_SLOTS + k) * 64]);
-      }
       AGroup<8> q0g;
       a_fetch<8>(q0g, L.Q0, lane, 0);
       NM_SB();

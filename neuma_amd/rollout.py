@@ -16,17 +16,44 @@ from .sim.order import ParticleOrder, hilbert_index_torch  # noqa: F401 (re-expo
 _WSZ = (64 * 13, 64 * 64, 9 * 64)
 _CACHE_STATUS = __import__('os').environ.get('NEUMA_CACHE_STATUS', '1') != '0'
 _SVD_CACHE = __import__('os').environ.get('NEUMA_SVD_CACHE', '1') != '0'
-# activation cache of the fused roll-out (2.2 KB per particle and substep; nm_rollout_cfg.act_cache): the forward kernels keep
-# the MLPs' hidden activations, the reverse sweep loads them instead of recomputing (metric workload: frame 7.88 -> 7.49 ms,
-# 4.35 GB per 20-substep node).  'auto' (default): on while the caches of all live roll-out nodes stay below
+# activation cache of the fused roll-out (1.2 KB per particle and substep; nm_rollout_cfg.act_cache): the forward kernels keep
+# the second hidden layer of the MLPs, the reverse sweep loads it instead of recomputing (metric workload: 127.5 -> 132.3 frames/s,
+# 2.3 GB per 20-substep node).  'auto' (default): on while the caches of all live roll-out nodes stay below
 # NEUMA_ACT_CACHE_GB (default 48); '1': always; '0': never (recompute, the reference's memory profile)
 _ACT_CACHE = __import__('os').environ.get('NEUMA_ACT_CACHE', 'auto')
 _ACT_CACHE_GB = float(__import__('os').environ.get('NEUMA_ACT_CACHE_GB', '48'))
 _ACT_LIVE = [0]         # bytes of activation cache held by live roll-out nodes
+_POOL = {}              # (device, bytes) -> idle cache buffers.  The caches are GB-sized: handing them back to the caching
+                        # allocator every frame makes it release and re-acquire device memory now and then (tens of
+                        # milliseconds inside a training loop), so a node returns them here after its backward pass
 
 
-def _act_release(nbytes: int) -> None:
-    _ACT_LIVE[0] -= nbytes
+class _Lease(object):
+    """A cache buffer held by one roll-out node: back to the pool after the node's backward pass; if the node is dropped
+    without one (inference, an abandoned graph) the buffer just dies with it."""
+
+    def __init__(self, nbytes: int, device, counted: bool):
+        key = (str(device), int(nbytes))
+        free = _POOL.get(key)
+        self.key, self.counted = key, counted
+        self.t = free.pop() if free else torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        if counted:
+            _ACT_LIVE[0] += int(nbytes)
+
+    def release(self):
+        if self.t is not None:
+            free = _POOL.setdefault(self.key, [])
+            if len(free) < 4:
+                free.append(self.t)
+            self._forget()
+
+    def _forget(self):
+        if self.t is not None and self.counted:
+            _ACT_LIVE[0] -= self.key[1]
+        self.t = None
+
+    def __del__(self):
+        self._forget()
 
 
 _ZEROS = {}
@@ -108,17 +135,15 @@ class _Rollout(autograd.Function):
         gc_bytes = int(lib.nm_rollout_gridcache_bytes(S, cache_blocks)) if cache_blocks > 0 else 0
         gcache = torch.empty(gc_bytes, dtype=torch.uint8, device=dev) if gc_bytes > 0 else None
         # SVD cache (U, sigma, V of both nets' inputs per substep, 168 B/particle/substep): also only when a backward pass can follow
-        svdc = (torch.empty(int(lib.nm_rollout_svdcache_bytes(n, S)), dtype=torch.uint8, device=dev)
+        svdc = (_Lease(int(lib.nm_rollout_svdcache_bytes(n, S)), dev, False)
                 if (_SVD_CACHE and n > 0 and any(ctx.needs_input_grad)) else None)
         actc = None
         if _ACT_CACHE != '0' and n > 0 and any(ctx.needs_input_grad):
             act_bytes = int(lib.nm_rollout_actcache_bytes(n, S))
             if _ACT_CACHE == '1' or _ACT_LIVE[0] + act_bytes <= _ACT_CACHE_GB * (1 << 30):
-                actc = torch.empty(act_bytes, dtype=torch.uint8, device=dev)
-                _ACT_LIVE[0] += act_bytes
-                __import__('weakref').finalize(actc, _act_release, act_bytes)
+                actc = _Lease(act_bytes, dev, True)
         cfg = L.nm_rollout_cfg(S, float(alpha), cache_blocks if gcache is not None else 0, 0, int(svd_adjoint),
-                               L.ptr(svdc) if svdc is not None else None, L.ptr(actc) if actc is not None else None)
+                               L.ptr(svdc.t) if svdc is not None else None, L.ptr(actc.t) if actc is not None else None)
         ctx.svdc, ctx.actc = svdc, actc
         st = statics.c_struct()
         mle = L.nm_mlp(*[L.ptr(t) for t in we])
@@ -200,8 +225,8 @@ class _Rollout(autograd.Function):
         if gcache is not None and ctx.cache_event is not None and ctx.cache_event.query():
             verified = int(bool((ctx.cache_status >= 0).all()))
         svdc, actc = getattr(ctx, "svdc", None), getattr(ctx, "actc", None)
-        cfg = L.nm_rollout_cfg(S, ctx.alpha, ctx.cache_blocks, verified, ctx.svd_adjoint, L.ptr(svdc) if svdc is not None else None,
-                               L.ptr(actc) if actc is not None else None)
+        cfg = L.nm_rollout_cfg(S, ctx.alpha, ctx.cache_blocks, verified, ctx.svd_adjoint, L.ptr(svdc.t) if svdc is not None else None,
+                               L.ptr(actc.t) if actc is not None else None)
         st = ctx.statics.c_struct()
         mle = L.nm_mlp(L.ptr(e0), L.ptr(e1), L.ptr(e2))
         mlp = L.nm_mlp(L.ptr(p0), L.ptr(p1), L.ptr(p2))
@@ -217,6 +242,9 @@ class _Rollout(autograd.Function):
                                             L.ptr(states), L.ptr(gcache) if gcache is not None else None, L.ptr(glast), L.ptr(gfirst),
                                             L.ptr(gwe), L.ptr(gwp), L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "nm_rollout_backward")
         ctx.gcache = None
+        for lease in (svdc, actc):
+            if lease is not None:
+                lease.release()
         ctx.svdc = ctx.actc = None
         torch.nan_to_num_(gfirst, 0.0, 0.0, 0.0)   # interface.py:65-74 at the boundary of the fused node
         a, b = _WSZ[0], _WSZ[0] + _WSZ[1]

@@ -1,0 +1,31 @@
+"""-DNM_PHASES build: per-phase cycles of the LAST constitutive adjoint kernel of a fused roll-out's reverse sweep (the
+elasticity adjoint of substep 0), with the activation cache on or off (NEUMA_ACT_CACHE).
+    python tools/exp_phases_rollout.py"""
+import os, subprocess, sys, ctypes as C
+import numpy as np
+sys.path.insert(0, ".")
+src = "neuma_amd/csrc"
+out = "/tmp/libneuma_phases.so"
+subprocess.run(f"/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -DNM_PHASES -Iinclude -shared "
+               f"{src}/nm_api.hip {src}/nm_mpm.hip {src}/nm_shard.hip {src}/nm_material.hip {src}/nm_bind.hip {src}/nm_bindbuild.hip {src}/nm_raster.hip {src}/nm_rollout.hip -o {out}",
+               shell=True, check=True)
+os.environ["NEUMA_HIP_LIB"] = out
+import torch
+from neuma_amd import _lib, synth
+from neuma_amd.harness import SceneRuntime
+lib = _lib.lib()
+dev = torch.device("cuda", 0)
+rt = SceneRuntime(synth.make_scene("metric", override=dict(K=1000, S=3)), dev)
+for _ in range(3):
+    x = rt.x0.clone().requires_grad_(True)
+    o = rt.rollout(x, rt.v0, rt.C0, rt.F0)
+    (o[0].sum() + o[3].sum()).backward()
+torch.cuda.synchronize()
+fn = lib.nm_debug_phases; fn.argtypes = [C.c_void_p, C.c_int]
+buf = np.zeros(8 * 2048, dtype=np.int64)
+print("rc", fn(buf.ctypes.data, 8 * 2048), "act cache:", os.environ.get("NEUMA_ACT_CACHE", "auto"))
+b = buf.reshape(2048, 8)[:893]
+names = ["stage weights", "svd+feat+ybar", "fwd recompute / act", "(a) W2 grad", "(b) h2bar", "(c) W1 grad", "(d) h1bar", "(e,f)+epilogue"]
+for i, nm in enumerate(names):
+    print(f"{nm:20s} mean {b[:, i].mean():9.0f} median {np.median(b[:, i]):9.0f} max {b[:, i].max():9.0f}")
+print("total mean", b.sum(1).mean(), "max", b.sum(1).max())
