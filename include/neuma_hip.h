@@ -247,10 +247,11 @@ typedef struct nm_rollout_cfg {
                               * both nets' inputs of every substep (168 B/particle/substep) and the reverse sweep reads them back
                               * instead of repeating the Jacobi SVD; NULL = recompute (same results to rounding: the trial F the
                               * reverse sweep rebuilds from the checkpoints differs from the forward's in the last bit) */
-  void* act_cache;           /* optional device buffer of nm_rollout_actcache_bytes(n, substeps): the forward pass keeps the two hidden
-                              * layer outputs the reverse sweep cannot cheaply rebuild (second hidden layer + GELU derivative + output of both nets: 1.2 KB/particle/substep) and the reverse
-                              * sweep loads them instead of recomputing the MLPs' forward pass (a third of its matrix work and all
-                              * of its GELUs); NULL = recompute.  Same arithmetic, same results. */
+  void* act_cache;           /* optional device buffer of nm_rollout_actcache_bytes(n, substeps): the forward pass keeps what the
+                              * reverse sweep cannot cheaply rebuild - the second hidden layer's activations and GELU derivatives
+                              * and the output of both nets, 1.2 KB/particle/substep - and the reverse sweep loads it, recomputing
+                              * only the first layer (16 of the forward pass's 96 matrix instructions per tile); NULL = recompute
+                              * everything.  Same arithmetic, same results. */
 } nm_rollout_cfg;
 #define NM_SVD_ADJOINT_REFERENCE 0
 #define NM_SVD_ADJOINT_POLAR 1
