@@ -52,6 +52,7 @@ def algorithmic_bytes(kernel: str, rt, D: float) -> float:
     table = {
         "k_render_bwd": 40.0 * D + 20.0 * W * H + 36.0 * K,
         "k_render": 40.0 * D + 20.0 * W * H,
+        "k_render_fix": 40.0 * D + 20.0 * W * H,      # second pass of the split compositing: at most the same lists once more
         "k_preprocess": (4 * (3 + 6 + 1) + 12 * (cfg["sh"] + 1) ** 2) * K + 60.0 * K,
         "k_preprocess_bwd": (4 * (3 + 6) + 12 * (cfg["sh"] + 1) ** 2) * K + 36.0 * K + 12.0 * K,
         "k_material_fwd": 72.0 * N,
