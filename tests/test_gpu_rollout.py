@@ -305,3 +305,38 @@ def test_long_rollout_keeps_the_active_block_list_consistent():
             assert abs(float(m.double().sum()) - pm) < 1e-4 * pm
             hit_floor = hit_floor or float(x[:, 1].min()) < 2.5 / G
     assert hit_floor, "the scenario is meant to include wall contact"
+
+
+def test_svd_and_activation_caches_do_not_change_the_reverse_sweep():
+    """nm_rollout_cfg.svd_cache / act_cache: the reverse sweep loads what the forward kernels kept (SVD factors; second-layer
+    activations, derivatives, outputs) instead of recomputing it.  Same arithmetic: outputs unchanged, gradients equal to the
+    full recompute up to the scatter's atomics order and the last-bit difference between the forward pass's trial F and the one rebuilt from the checkpoints.
+    Two nodes alive at once (two leases of the pooled cache buffers)."""
+    import neuma_amd.rollout as R
+    S = 4
+    rt = _runtime("tiny", fused=True, S=S)
+    params = rt.parameters()
+    gen = torch.Generator().manual_seed(11)
+    F0 = (torch.eye(3) + 0.04 * torch.randn(rt.N, 3, 3, generator=gen)).to(dev())
+    gw = [torch.randn(rt.N, 3, generator=gen).to(dev()), torch.randn(rt.N, 3, 3, generator=gen).to(dev())]
+    saved = (R._SVD_CACHE, R._ACT_CACHE)
+    res = {}
+    try:
+        for mode, (svd, act) in {"recompute": (False, "0"), "svd": (True, "0"), "both": (True, "1")}.items():
+            R._SVD_CACHE, R._ACT_CACHE = svd, act
+            for p in params:
+                p.grad = None
+            ins = [t.clone().requires_grad_(True) for t in (rt.x0, rt.v0)]
+            out = rt.rollout(ins[0], ins[1], rt.C0, F0)
+            out2 = rt.rollout(ins[0], ins[1], rt.C0, F0)            # a second live node: its own buffers
+            ((out2[0] * gw[0]).sum() + (out2[3] * gw[1]).sum() + (out[0] * gw[0]).sum() + (out[3] * gw[1]).sum()).backward()
+            res[mode] = ([o.detach().clone() for o in out], [t.grad.clone() for t in ins + params])
+            if mode == "both":
+                assert R._ACT_LIVE[0] == 0 and sum(len(v) for v in R._POOL.values()) >= 2      # both leases back in the pool
+    finally:
+        R._SVD_CACHE, R._ACT_CACHE = saved
+    for mode in ("svd", "both"):
+        for a, b in zip(res[mode][0], res["recompute"][0]):
+            assert rel_max(a, b) < 1e-5, mode           # the forward pass itself does not change (fp32 atomics order: not bitwise)
+        for a, b in zip(res[mode][1], res["recompute"][1]):
+            assert torch.isfinite(a).all() and rel_max(a, b) < 2e-4, mode
