@@ -119,6 +119,13 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")))
 
+    # stdout carries exactly ONE line (the JSON result of rank 0); everything else the libraries print goes to stderr
+    # (at the file-descriptor level: gloo and the HIP runtime write from C)
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    sys.stdout = sys.stderr
+
     # the shared library is a build artefact: build it if this checkout does not have it (rank 0 builds, the others wait)
     libpath = ROOT / "neuma_amd" / "lib" / "libneuma_hip.so"
     if not libpath.exists() and not os.environ.get("NEUMA_HIP_LIB"):
@@ -391,7 +398,7 @@ def main():
         import ctypes
         sys.stdout.flush()
         ctypes.CDLL(None).fflush(None)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=result_out, flush=True)
 
 
 if __name__ == "__main__":
