@@ -359,6 +359,10 @@ typedef struct nm_raster_cfg {
   int32_t debug;
   int32_t tile_y0;
   int32_t tile_y1;
+  int32_t split_items;   /* capacity, in (tile, list segment) work items, of the split compositing's records inside the
+                          * state buffer (256 x 16 B kept for the backward pass + 256 x 36 B of forward scratch per item);
+                          * 0 = 8192.  A view that wants more composites its remaining tiles whole: slower, same result;
+                          * nm_raster_forward_ex reports what the view asked for */
 } nm_raster_cfg;
 
 /* One caller-allocated state buffer per rendered view replaces the geomBuffer / binningBuffer / imgBuffer tensors of the
@@ -378,6 +382,33 @@ int nm_raster_forward(const nm_raster_cfg* cfg, int32_t k, int32_t m, const floa
                       const float* shs, const float* colors_precomp, const float* opacities,
                       const float* cov3D, int32_t* radii, void* state, size_t state_bytes, int64_t cap_pairs,
                       float* out_color, int64_t* status_host, void* stream);
+/* The same with (a) the forward-only arrays in a buffer of their own and (b) a per-camera walk record.
+ * (a) nm_raster_state_bytes_ex splits what nm_raster_state_bytes adds up: *state_bytes = what the backward pass reads again
+ * (keep it until then), *scratch_bytes = what only the forward pass uses (pair log, cell counters, per-segment scratch: the
+ * larger half) - free it, or hand it to the next render on the same stream, as soon as the call has been enqueued.
+ * scratch == NULL: one-buffer layout as in nm_raster_forward (state_bytes >= the sum).  nm_raster_count_pairs needs that
+ * layout.
+ * (b) tile_walk: NULL, or device memory of one uint32 per 16x16 tile of the image (ceil(W/16) * ceil(H/16), row-major),
+ * zeroed by the caller when the camera is created and then handed to every render with that camera (the reference keeps
+ * no state between two calls of the rasterizer, gaussian_renderer/__init__.py:103-119; this is an addition underneath
+ * it).  The forward pass leaves in it how far along its depth-sorted list each tile had to walk, and plans the NEXT render
+ * with the same camera from it: tiles with a long walk are cut into segments that are composited in parallel (forward and
+ * reverse sweep), however many busy tiles the view has.  A stale or wrong record costs time, never accuracy: image,
+ * termination rule and gradients are those of nm_raster_forward.
+ * status_host: NULL or pinned memory of THREE zero-initialised int64: {pairs binned, overflow flag, work items the split
+ * compositing asked for (compare with cfg.split_items)}. */
+int nm_raster_state_bytes_ex(const nm_raster_cfg* cfg, int32_t k, int64_t cap_pairs, size_t* state_bytes,
+                             size_t* scratch_bytes);
+int nm_raster_forward_ex(const nm_raster_cfg* cfg, int32_t k, int32_t m, const float* means3D,
+                         const float* shs, const float* colors_precomp, const float* opacities,
+                         const float* cov3D, int32_t* radii, void* state, size_t state_bytes, void* scratch,
+                         size_t scratch_bytes, int64_t cap_pairs, float* out_color, int64_t* status_host,
+                         uint32_t* tile_walk, void* stream);
+/* Tuning of the hinted plan (process-wide).  forward_split_length: tiles whose planned walk is longer than this many list
+ * entries are composited in parallel segments in the forward pass as well; shorter ones are walked front to back (leaving
+ * checkpoints) and only their reverse sweep runs in segments.  min_segment: shortest segment (rounded up to a multiple of
+ * 16).  Defaults 0 (every planned tile: measured best for forward + backward together) and 256. */
+int nm_raster_set_hinted(int32_t forward_split_length, int32_t min_segment);
 /* Tuning of the split compositing (process-wide; read by the following nm_raster_forward calls).  A view with fewer than
  * `busy_tiles` non-empty tiles leaves most of the chip idle; its tiles whose depth-sorted list is longer than a segment
  * (>= `min_segment` entries, ~4096 segments per view at most) are walked segment by segment on separate workgroups:

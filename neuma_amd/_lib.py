@@ -33,7 +33,8 @@ class nm_raster_cfg(C.Structure):
     _fields_ = [("image_height", C.c_int32), ("image_width", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
                 ("bg", C.c_float * 3), ("scale_modifier", C.c_float), ("viewmatrix", C.c_float * 16),
                 ("projmatrix", C.c_float * 16), ("sh_degree", C.c_int32), ("campos", C.c_float * 3),
-                ("prefiltered", C.c_int32), ("debug", C.c_int32), ("tile_y0", C.c_int32), ("tile_y1", C.c_int32)]
+                ("prefiltered", C.c_int32), ("debug", C.c_int32), ("tile_y0", C.c_int32), ("tile_y1", C.c_int32),
+                ("split_items", C.c_int32)]
 
 
 class nm_lora_layer(C.Structure):
@@ -102,6 +103,10 @@ SIGNATURES = {
     "nm_bind_frame": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nm_raster_state_bytes": (_SZ, [C.POINTER(nm_raster_cfg), _I32, _I64]),
     "nm_raster_forward": (C.c_int, [C.POINTER(nm_raster_cfg), _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _SZ, _I64, _P, _P, _P]),
+    "nm_raster_state_bytes_ex": (C.c_int, [C.POINTER(nm_raster_cfg), _I32, _I64, C.POINTER(_SZ), C.POINTER(_SZ)]),
+    "nm_raster_forward_ex": (C.c_int, [C.POINTER(nm_raster_cfg), _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _SZ, _I64, _P, _P, _P,
+                                       _P]),
+    "nm_raster_set_hinted": (C.c_int, [_I32, _I32]),
     "nm_raster_set_split": (C.c_int, [_I32, _I32, _I64]),
     "nm_raster_count_pairs": (C.c_int, [C.POINTER(nm_raster_cfg), _I32, _P, _I64, _P, _P]),
     "nm_raster_bwd_workspace": (_SZ, [_I32]),

@@ -78,7 +78,11 @@ __device__ __forceinline__ float sel3(const float* a, int i) { return i == 0 ? a
 
 
 // mpm.py:432-498 for one particle: gather v and C' from the 27 stencil nodes, advance x (clamped), return the trial
-// deformation gradient (I + dt C') F in Fo.  Disabled particles pass their state through (mpm.py:443-444).  UNROLL: all 27
+// deformation gradient (I + dt C') F in Fo.  A disabled particle (mpm.py:443-444: the reference's g2p returns at once) leaves
+// its row of the next state as the buffer held it - zeros / identity in the fresh model.state() that MPMDiffSim hands over
+// (interface.py:101-105), the particle's own state when the step is in place (MPMForwardSim).  `fresh`: the next buffer is not
+// such a state object (the roll-out's checkpoints live in a raw workspace), so those values are written here: x = v = 0, C = 0,
+// Fo = I, exactly what a chain of MPMDiffSim calls produces.  UNROLL: all 27
 // gathers in flight (for callers that run one wave per SIMD); otherwise nine per trip, which keeps k_g2p at 4+ waves/SIMD.
 // FILL (passive extra sets, mpm.py:260-277): a stencil node in a block the scattering particles did not touch reads what the
 // reference's dense grid_op sweep leaves there - BC(g dt) of an empty node (mpm.py:384-385 / 413-414) - instead of the
@@ -87,14 +91,16 @@ template <bool UNROLL, bool FILL = false>
 __device__ __forceinline__ void g2p_particle(const MpmK& K, int p, const float* __restrict__ clip, const int* __restrict__ enabled,
                                              const float* x, const float* v, const float* C, const float* F,
                                              const float4* __restrict__ gv, float* xn, float* vn, float* Cn, M3& Fo,
-                                             const int* __restrict__ flags = nullptr, int epoch = 0) {
+                                             const int* __restrict__ flags = nullptr, int epoch = 0, bool fresh = false) {
   if (enabled[p] == 0) {
-    Fo = m3_load(F + 9 * p);
-    if (xn != x) {
+    if (fresh && xn != x) {
+      Fo = m3_ident();
 #pragma unroll
-      for (int a = 0; a < 3; ++a) { xn[3 * p + a] = x[3 * p + a]; vn[3 * p + a] = v[3 * p + a]; }
+      for (int a = 0; a < 3; ++a) { xn[3 * p + a] = 0.f; vn[3 * p + a] = 0.f; }
 #pragma unroll
-      for (int a = 0; a < 9; ++a) Cn[9 * p + a] = C[9 * p + a];
+      for (int a = 0; a < 9; ++a) Cn[9 * p + a] = 0.f;
+    } else {
+      Fo = m3_load(F + 9 * p);     // (not stored by the callers)
     }
     return;
   }

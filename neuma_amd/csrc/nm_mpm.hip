@@ -42,7 +42,9 @@ struct nm_mpm {
   int epoch;
   int* sh_cnt;    // sharded runs only (nm_shard.hip): per-block rank counter / first position, allocated on first use
   int* sh_pos;
+  int fresh_rows; // g2p writes a fresh state's values into the rows of disabled particles (roll-out checkpoints, nm_grid.h)
 };
+void nm_mpm_set_fresh_rows(nm_mpm* h, int on) { h->fresh_rows = on; }
 
 #ifdef NM_PHASES
 __device__ int g_nm_markslow[4];
@@ -654,12 +656,12 @@ __global__ void __launch_bounds__(256) k_grid_op_bwd(MpmK K, const float4* __res
 // mpm.py:432-498 (body: g2p_particle, nm_grid.h)
 __global__ void __launch_bounds__(256, 4) k_g2p(MpmK K, int n, const float* __restrict__ clip, const int* __restrict__ enabled,
                                              const float* x, const float* v, const float* C, const float* F,
-                                             const float4* __restrict__ gv, float* xn, float* vn, float* Cn, float* Fn) {
+                                             const float4* __restrict__ gv, float* xn, float* vn, float* Cn, float* Fn, int fresh) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   M3 Fo;
-  g2p_particle<false>(K, p, clip, enabled, x, v, C, F, gv, xn, vn, Cn, Fo);
-  if (enabled[p] != 0 || Fn != F) m3_store(Fn + 9 * p, Fo);
+  g2p_particle<false>(K, p, clip, enabled, x, v, C, F, gv, xn, vn, Cn, Fo, nullptr, 0, fresh != 0);
+  if (enabled[p] != 0 || (fresh && Fn != F)) m3_store(Fn + 9 * p, Fo);      // a disabled row is left alone (mpm.py:443-444)
 }
 
 // g2p onto a passive particle set (MPMModel.forward_extra, mpm.py:260-277): in place, untouched blocks read as BC(g dt)
@@ -1050,7 +1052,7 @@ static int mpm_forward_impl(nm_mpm* h, int32_t n, const nm_statics* st, const nm
   if (rc) return rc;
   if (!next) return NM_OK;   // g2p is performed by the caller's next kernel (nm_mpm_g2p_fuse)
   NM_LAUNCH(k_g2p, dim3(nm_div_up(n, 256)), dim3(256), 0, s, h->k, n, st->clip_bound, st->enabled, cur->x,
-                     cur->v, cur->C, cur->F, h->gv, next->x, next->v, next->C, next->F);
+                     cur->v, cur->C, cur->F, h->gv, next->x, next->v, next->C, next->F, h->fresh_rows);
   NM_LAUNCH_CHECK();
   return NM_OK;
 }
@@ -1214,7 +1216,7 @@ extern "C" int nm_mpm_forward_finish(nm_mpm* h, int32_t n, const nm_statics* st,
   rc = check_particles(st, next, false);
   if (rc) return rc;
   NM_LAUNCH(k_g2p, dim3(nm_div_up(n, 256)), dim3(256), 0, s, h->k, n, st->clip_bound, st->enabled, cur->x, cur->v, cur->C,
-                     cur->F, h->gv, next->x, next->v, next->C, next->F);
+                     cur->F, h->gv, next->x, next->v, next->C, next->F, h->fresh_rows);
   NM_LAUNCH_CHECK();
   return NM_OK;
 }

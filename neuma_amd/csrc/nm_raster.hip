@@ -24,11 +24,12 @@
 #define NM_TPB 256
 
 struct RK {
-  int W, H, gx, gy, ty0, ty1, deg, M;
+  int W, H, gx, gy, ty0, ty1, deg, M, K, items;
   float tanx, tany, fx, fy;
   float view[16], proj[16], cam[3], bg[3];
 };
 
+static int split_items_of(const nm_raster_cfg* c);
 static int make_rk(const nm_raster_cfg* c, int m, RK& k) {
   NM_REQUIRE(c, "null raster cfg");
   NM_REQUIRE(c->image_width > 0 && c->image_height > 0, "bad image size");
@@ -40,7 +41,7 @@ static int make_rk(const nm_raster_cfg* c, int m, RK& k) {
     NM_REQUIRE(c->tile_y0 >= 0 && c->tile_y1 <= k.gy, "tile stripe out of range");
     k.ty0 = c->tile_y0; k.ty1 = c->tile_y1;
   }
-  k.deg = c->sh_degree; k.M = m;
+  k.deg = c->sh_degree; k.M = m; k.K = 0; k.items = split_items_of(c);
   k.tanx = c->tanfovx; k.tany = c->tanfovy;
   k.fx = k.W / (2.0f * c->tanfovx); k.fy = k.H / (2.0f * c->tanfovy);
   memcpy(k.view, c->viewmatrix, sizeof(k.view));
@@ -60,18 +61,31 @@ static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 #define NM_SPLIT_WORK 8192    // (tile, segment) work items a view may have (its segment records: 36 B per pixel each)
 #define NM_SPLIT_BUSY 512     // a view with this many non-empty tiles (two per CU) fills the chip: no splitting (default of nm_raster_set_split)
 #define NM_SPLIT_MINSEG 512   // shortest segment (list entries; default): ~50-90 us of one workgroup's walk
-#define NM_SPLIT_WGS 4096     // segments aimed at
+#define NM_SPLIT_WGS 4096     // segments aimed at (unhinted plan)
+#define NM_HINT_WGS 12288     // segments a hinted plan may ask for (the caller sizes cfg.split_items from what it asked)
+#define NM_PLAN_PER 8         // tiles per thread of the hinted plan (images up to 8192 tiles; larger ones are planned unhinted)
+#define NM_HINT_FWD 0         // hinted plan: tiles planned longer than this are composited in parallel segments in the forward pass too
+#define NM_HINT_MINSEG 256    // hinted plan: shortest segment
 #define NM_SPLIT_TAU 0.01f    // a tile is split when, after its first segment, some pixel still has T above this
 #define NM_SPLIT_FWD_MAX (2u << 20)   // forward splitting composites every segment of a split tile, also those behind the
                                       // point where its pixels stop: only when all candidate lists together are about one
                                       // chip-load of work (256 CUs x 8 workgroups x 1024 entries)
 
-struct PairLog { uint32_t cell, rank, id, mask; };   // one (Gaussian, bin) pair as the count pass saw it
+struct PairLog { uint32_t cell, rank, id, mask; };
+// Compositing record of one Gaussian (k_preprocess): everything the per-tile loops need, in one 64-byte line that a wave
+// fetches with SCALAR loads - the operands are the same for all 64 lanes (one Gaussian against 64 pixels), so they belong in
+// SGPRs, not in LDS: as wave-uniform LDS broadcasts (36 B per wave and Gaussian, 24 waves per CU on one LDS pipe) they were
+// what bounded both compositing kernels.  a, b, c = the conic pre-multiplied so that the Gaussian's exponent comes out in base
+// 2: log2(G) = a dx^2 + b dx dy + c dy^2  (a = -0.5 log2(e) conic.x, b = -log2(e) conic.y, c = -0.5 log2(e) conic.z).
+struct __attribute__((aligned(64))) GRec { float x, y, a, b, c, lop, r, g, bl, op, pad[6]; };
+#define NM_G 2       // Gaussians per scalar-fetch group of the forward composite (two groups per trip: 64 % (2 NM_G) == 0)
+#define NM_LOG2E 1.4426950408889634f   // one (Gaussian, bin) pair as the count pass saw it
 
 struct State {
   uint32_t* hdr;       // [2] pairs binned (may exceed cap) [3] overflow flag [4..5] exact pair count (stats) [6] largest cell
                        // [8] (tile, segment) work items of the split compositing [9] segment length [10] forward splitting allowed
   float2* xy; float* depth; float4* conop; float* rgb; uint32_t* clamped; int* rad;
+  GRec* recs;
   uint32_t* pad;       // per cell, one counter per 128-byte line (NM_PAD words apart): count, then fill cursor.  Neighbouring
                        // cells are hit by the same burst of atomics; packed they would serialise on one L2 channel
   uint32_t* cnt;       // per cell: count (compact copy of pad)
@@ -94,50 +108,68 @@ struct State {
   uint32_t* seg_last;  // per work item and pixel: last contributor inside the segment (1-based list position), 0 = none
   uint32_t* seg_pos;   // per work item: list position its segment starts behind (segment s of a tile = positions
                        // (seg_pos[s], seg_pos[s + 1]]); s * seg by default, where the walk really stood for checkpoints
-  int nbx, nby, ncell;
-  size_t total;
+  int nbx, nby, ncell, items;
+  size_t total, scratch_total;
 };
-static State carve_state(void* base, int W, int H, int k, int64_t cap) {
+// persistent part (read again by the reverse sweep) from `base`; forward-only scratch from `scratch`, or - scratch == NULL -
+// behind the persistent part in the same buffer (the one-buffer layout of nm_raster_state_bytes / nm_raster_forward).
+// items = capacity in (tile, segment) work items of the split compositing (cfg.split_items, 0 = NM_SPLIT_WORK).
+static int split_items_of(const nm_raster_cfg* c) {
+  int it = c->split_items > 0 ? c->split_items : NM_SPLIT_WORK;
+  return it < 64 ? 64 : it;
+}
+static State carve_state(void* base, void* scratch, int W, int H, int k, int64_t cap, int items) {
   State t; char* p = (char*)base; size_t o = 0; size_t K = (size_t)(k > 0 ? k : 1), n = (size_t)W * H;
   const int gx = (W + NM_TILE - 1) / NM_TILE, gy = (H + NM_TILE - 1) / NM_TILE;
   t.nbx = (gx + NM_BT - 1) / NM_BT; t.nby = (gy + NM_BT - 1) / NM_BT; t.ncell = t.nbx * t.nby * NM_NS;
+  t.items = items;
+  const size_t cp = (size_t)(cap > 0 ? cap : 1), ntile = (size_t)gx * gy, it = (size_t)items;
   t.hdr = (uint32_t*)(p + o); o += 256;
-  t.xy = (float2*)(p + o); o += al256(K * sizeof(float2));
-  t.depth = (float*)(p + o); o += al256(K * sizeof(float));
-  t.conop = (float4*)(p + o); o += al256(K * sizeof(float4));
-  t.rgb = (float*)(p + o); o += al256(K * 3 * sizeof(float));
+  t.recs = (GRec*)(p + o); o += al256((K + 1) * sizeof(GRec));      // [K] = the null record
   t.clamped = (uint32_t*)(p + o); o += al256(K * sizeof(uint32_t));
   t.rad = (int*)(p + o); o += al256(K * sizeof(int));
-  t.pad = (uint32_t*)(p + o); o += al256((size_t)t.ncell * NM_PAD * sizeof(uint32_t));
-  t.cnt = (uint32_t*)(p + o); o += al256(((size_t)t.ncell + 1) * sizeof(uint32_t));
   t.off = (uint32_t*)(p + o); o += al256(((size_t)t.ncell + 1) * sizeof(uint32_t));
-  t.zrange = (uint2*)(p + o); o += al256((K / 256 + 1) * sizeof(uint2));
-  const size_t cp = (size_t)(cap > 0 ? cap : 1);
   t.keys = (unsigned long long*)(p + o); o += al256(cp * sizeof(unsigned long long));
   t.vals = (uint32_t*)(p + o); o += al256(cp * sizeof(uint32_t));
-  t.log = (PairLog*)(p + o); o += al256(cp * sizeof(PairLog));
-  t.bin_total = (uint32_t*)(p + o); o += al256(((size_t)t.nbx * t.nby + 1) * sizeof(uint32_t));
-  t.bin_off = (uint32_t*)(p + o); o += al256(((size_t)t.nbx * t.nby + 1) * sizeof(uint32_t));
   t.final_T = (float*)(p + o); o += al256(n * sizeof(float));
   t.n_contrib = (uint32_t*)(p + o); o += al256(n * sizeof(uint32_t));
-  const size_t ntile = (size_t)gx * gy;
   t.tile_rec = (uint32_t*)(p + o); o += al256(ntile * sizeof(uint32_t));
   t.tile_ns = (uint32_t*)(p + o); o += al256(ntile * sizeof(uint32_t));
-  t.tile_cnt = (uint32_t*)(p + o); o += al256(ntile * sizeof(uint32_t));
-  t.tile_mode = (uint32_t*)(p + o); o += al256(ntile * sizeof(uint32_t));
-  t.work = (uint2*)(p + o); o += al256((size_t)NM_SPLIT_WORK * sizeof(uint2));
-  t.seg_raw = (float4*)(p + o); o += al256((size_t)NM_SPLIT_WORK * NM_TPB * sizeof(float4));
-  t.seg_fix = (float4*)(p + o); o += al256((size_t)NM_SPLIT_WORK * NM_TPB * sizeof(float4));
-  t.seg_ct = (float4*)(p + o); o += al256((size_t)NM_SPLIT_WORK * NM_TPB * sizeof(float4));
-  t.seg_last = (uint32_t*)(p + o); o += al256((size_t)NM_SPLIT_WORK * NM_TPB * sizeof(uint32_t));
-  t.seg_pos = (uint32_t*)(p + o); o += al256((size_t)NM_SPLIT_WORK * sizeof(uint32_t));
+  t.work = (uint2*)(p + o); o += al256(it * sizeof(uint2));
+  t.seg_ct = (float4*)(p + o); o += al256(it * NM_TPB * sizeof(float4));
+  t.seg_pos = (uint32_t*)(p + o); o += al256((it + 1) * sizeof(uint32_t));
   t.total = o;
+  // ---- forward-only
+  char* q = scratch ? (char*)scratch : p + o; size_t so = 0;
+  t.xy = (float2*)(q + so); so += al256(K * sizeof(float2));
+  t.depth = (float*)(q + so); so += al256(K * sizeof(float));
+  t.conop = (float4*)(q + so); so += al256(K * sizeof(float4));
+  t.rgb = (float*)(q + so); so += al256(K * 3 * sizeof(float));
+  t.pad = (uint32_t*)(q + so); so += al256((size_t)t.ncell * NM_PAD * sizeof(uint32_t));
+  t.cnt = (uint32_t*)(q + so); so += al256(((size_t)t.ncell + 1) * sizeof(uint32_t));
+  t.zrange = (uint2*)(q + so); so += al256((K / 256 + 1) * sizeof(uint2));
+  t.log = (PairLog*)(q + so); so += al256(cp * sizeof(PairLog));
+  t.bin_total = (uint32_t*)(q + so); so += al256(((size_t)t.nbx * t.nby + 1) * sizeof(uint32_t));
+  t.bin_off = (uint32_t*)(q + so); so += al256(((size_t)t.nbx * t.nby + 1) * sizeof(uint32_t));
+  t.tile_cnt = (uint32_t*)(q + so); so += al256(ntile * sizeof(uint32_t));
+  t.tile_mode = (uint32_t*)(q + so); so += al256(ntile * sizeof(uint32_t));
+  t.seg_raw = (float4*)(q + so); so += al256(it * NM_TPB * sizeof(float4));
+  t.seg_fix = (float4*)(q + so); so += al256(it * NM_TPB * sizeof(float4));
+  t.seg_last = (uint32_t*)(q + so); so += al256(it * NM_TPB * sizeof(uint32_t));
+  t.scratch_total = so;
   return t;
 }
 
 extern "C" size_t nm_raster_state_bytes(const nm_raster_cfg* c, int32_t k, int64_t cap_pairs) {
   if (!c) return 0;
-  return carve_state(nullptr, c->image_width, c->image_height, k, cap_pairs).total;
+  const State t = carve_state(nullptr, nullptr, c->image_width, c->image_height, k, cap_pairs, split_items_of(c));
+  return t.total + t.scratch_total;
+}
+extern "C" int nm_raster_state_bytes_ex(const nm_raster_cfg* c, int32_t k, int64_t cap_pairs, size_t* state_bytes, size_t* scratch_bytes) {
+  NM_REQUIRE(c && state_bytes && scratch_bytes, "null pointer");
+  const State t = carve_state(nullptr, nullptr, c->image_width, c->image_height, k, cap_pairs, split_items_of(c));
+  *state_bytes = t.total; *scratch_bytes = t.scratch_total;
+  return NM_OK;
 }
 
 // ---------------------------------------------------------------- device helpers
@@ -251,7 +283,8 @@ __global__ void __launch_bounds__(256) k_preprocess(RK k, int K, const float* __
                                                     const float* __restrict__ colors, const float* __restrict__ opac,
                                                     const float* __restrict__ cov3D, int* __restrict__ radii, float2* __restrict__ xy,
                                                     float* __restrict__ depth, float4* __restrict__ conop, float* __restrict__ rgb,
-                                                    uint32_t* __restrict__ clamped, int* __restrict__ grad_, uint2* __restrict__ zrange) {
+                                                    uint32_t* __restrict__ clamped, int* __restrict__ grad_, uint2* __restrict__ zrange,
+                                                    GRec* __restrict__ recs) {
   __shared__ uint32_t s_lo[4], s_hi[4];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   // depth range of the visible Gaussians (positive floats order like their bit patterns), reduced per workgroup; the
@@ -332,6 +365,17 @@ __global__ void __launch_bounds__(256) k_preprocess(RK k, int K, const float* __
     depth[i] = pv.z;
     conop[i] = make_float4(cv.c * det_inv, -cv.b * det_inv, cv.a * det_inv, opac[i]);
     rgb[3 * i] = col[0]; rgb[3 * i + 1] = col[1]; rgb[3 * i + 2] = col[2];
+    if (i == 0) {      // the null record (alpha 0 everywhere): what the padding slots of a compositing trip point at
+      float4* np = (float4*)(recs + K);
+      np[0] = make_float4(0.f, 0.f, -1.f, 0.f); np[1] = make_float4(-1.f, -__builtin_inff(), 0.f, 0.f); np[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    {
+      float4* rp = (float4*)(recs + i);
+      const float op = opac[i];
+      rp[0] = make_float4(px, py, -0.5f * NM_LOG2E * (cv.c * det_inv), NM_LOG2E * (cv.b * det_inv));
+      rp[1] = make_float4(-0.5f * NM_LOG2E * (cv.a * det_inv), __log2f(op), col[0], col[1]);
+      rp[2] = make_float4(col[2], op, 0.f, 0.f);
+    }
     clamped[i] = cl;
     zlo = zhi = __float_as_uint(pv.z);
   }
@@ -638,13 +682,24 @@ __global__ void __launch_bounds__(256) k_cell_sort(int ncell, const uint32_t* __
   }
 }
 
+#ifdef NM_FIXDBG
+__device__ unsigned long long* g_fixdbg;
+extern "C" int nm_debug_fix_buffer(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_fixdbg), &p, sizeof(p)) == hipSuccess ? 0 : -2; }
+#define FIXDBG(slot) do { if (threadIdx.x == 0 && g_fixdbg) g_fixdbg[(size_t)blockIdx.x * 8 + (slot)] = clock64(); } while (0)
+#define FIXDBGV(slot, v) do { if (threadIdx.x == 0 && g_fixdbg) g_fixdbg[(size_t)blockIdx.x * 8 + (slot)] = (v); } while (0)
+#define FIXACC(slot, t0) do { if (threadIdx.x == 0 && g_fixdbg) { const long long t1_ = clock64(); g_fixdbg[(size_t)blockIdx.x * 8 + (slot)] += t1_ - (t0); (t0) = t1_; } } while (0)
+#define FIXCNT(slot, v) do { if (threadIdx.x == 0 && g_fixdbg) g_fixdbg[(size_t)blockIdx.x * 8 + (slot)] += (v); } while (0)
+#else
+#define FIXACC(slot, t0)
+#define FIXCNT(slot, v)
+#define FIXDBG(slot)
+#define FIXDBGV(slot, v)
+#endif
 #define NM_SCAN 4096   // candidates a tile examines per round (16 per thread: four 16-byte loads of their tile masks)
 struct CompLds {
   uint32_t hit[NM_SCAN];      // 1-based list positions of the candidates that touch this tile, in list order
-  float2 xy[NM_TPB];
-  float4 co[NM_TPB];
-  float rgb[NM_TPB * 3];
   int wcnt[4];
+  uint32_t wreach[4];
 };
 struct Pix {
   float T, C0, C1, C2;
@@ -653,25 +708,38 @@ struct Pix {
 };
 // front-to-back composite of one 16x16 tile (upstream renderCUDA forward) over entries [a, b) of the depth-sorted list of
 // the tile's bin (the bin's list starts at lo; positions are counted from there)
-__device__ __forceinline__ void composite_range(CompLds& L, long long lo, long long a, long long b, uint32_t bit,
+__device__ __forceinline__ uint32_t composite_range(CompLds& L, long long lo, long long a, long long b, uint32_t bit,
                                                 const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                const float2* __restrict__ xy, const float* __restrict__ rgb,
-                                                const float4* __restrict__ conop, float fxp, float fyp, Pix& p,
+                                                const GRec* __restrict__ recs, uint32_t null_off, float fxp, float fyp, Pix& p,
                                                 uint32_t seg = 0u, uint32_t ck_s = 0u, uint32_t ck_n = 0u,
                                                 float4* __restrict__ ck = nullptr, uint32_t* __restrict__ ck_pos = nullptr) {
-  // ck != NULL: checkpoints for the reverse sweep.  Whenever the walk has passed the nominal start s * seg of segment s
+  // ck != NULL: checkpoints for the reverse sweep.  Whenever the walk has passed the nominal start ck_pos[s] of segment s
   // (looked at after every batch of hits and at the end of every round - never inside the compositing loop), the pixels'
   // (C, T) go to ck[s] and the position the walk stands at to ck_pos[s]: segment s starts exactly there.  s = ck_s .. ck_n-1.
+  // Returns the list position (counted from lo) the walk had examined when it ended - every pixel stopped, or b reached.
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  auto checkpoint = [&](uint32_t reached) {
-    while (ck_s < ck_n && reached >= ck_s * seg) {
+  uint32_t reached = (uint32_t)(a - lo);
+  // every wave writes the checkpoints of its own pixels (and the same boundary position: a benign race) - the waves of a
+  // tile meet only between rounds
+  auto checkpoint = [&](uint32_t at) {
+    while (ck_s < ck_n && at >= ck_pos[ck_s]) {     // (the plan's boundary: q * seg, or the tile's own step in a hinted plan)
       ck[(size_t)ck_s * NM_TPB + tid] = make_float4(p.C0, p.C1, p.C2, p.T);
-      if (tid == 0) ck_pos[ck_s] = reached;
+      if (lane == 0) ck_pos[ck_s] = at;
       ++ck_s;
     }
   };
+  // A pixel that has stopped (or lies outside the image) is moved to x = +inf: every Gaussian's exponent is -inf there,
+  // its alpha 0, and the loop body needs no `done` mask at all.
+  const float kInf = __builtin_inff();
+  float fx = p.done ? kInf : fxp;
+  uint32_t wreach = reached;        // where this wave stands
+  if (lane == 0) L.wreach[wave] = wreach;
+#ifdef NM_FIXDBG
+  long long tph = clock64();
+#endif
   for (long long base = a & ~3ll; base < b; base += NM_SCAN) {     // rounds start 16-byte aligned; positions < a are masked out
-    if (__syncthreads_count(p.done) == NM_TPB) break;
+    if (__syncthreads_count(!(fx < kInf)) == NM_TPB) break;
+    FIXACC(5, tph);
     // ---- NM_SCAN candidates: which of them touch this tile (bit of their tile mask)?
     const long long c = base + 16 * tid;
     uint32_t m16 = 0;
@@ -699,36 +767,81 @@ __device__ __forceinline__ void composite_range(CompLds& L, long long lo, long l
     int slot = before + incl - mine;
     for (uint32_t mm = m16; mm; mm &= mm - 1u) L.hit[slot++] = (uint32_t)(c + (__ffs((int)mm) - 1) - lo) + 1u;
     __syncthreads();
-    // ---- composite the survivors, in list (= depth) order, NM_TPB at a time
-    for (int h0 = 0; h0 < nh; h0 += NM_TPB) {
-      if (h0 > 0 && __syncthreads_count(p.done) == NM_TPB) break;
+    FIXACC(2, tph);
+    FIXCNT(6, (unsigned long long)nh);
+    // ---- composite the survivors, in list (= depth) order, 256 at a time - every wave by itself, no barrier until the round
+    // is over.  No staging either: a wave keeps the batch's Gaussians (byte offsets of their records) in four registers
+    // (lane l: hits l, l + 64, ...), pulls hit j's out with v_readlane and fetches the record with scalar loads into one of
+    // two alternating register sets, NM_G Gaussians ahead of the arithmetic.  Slots past the batch's end point at the null
+    // record (opacity 0), so a trip never needs a bound check.
+    bool live = __ballot(fx < kInf) != 0ull;
+    for (int h0 = 0; h0 < nh && live; h0 += NM_TPB) {
       const int nb = min(NM_TPB, nh - h0);
-      if (tid < nb) {
-        const uint32_t id = (uint32_t)keys[lo + L.hit[h0 + tid] - 1];
-        L.xy[tid] = xy[id];
-        L.co[tid] = conop[id];
-        L.rgb[3 * tid] = rgb[3 * id]; L.rgb[3 * tid + 1] = rgb[3 * id + 1]; L.rgb[3 * tid + 2] = rgb[3 * id + 2];
+      uint32_t idr[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int t = 64 * q + lane;
+        idr[q] = t < nb ? (uint32_t)keys[lo + L.hit[h0 + t] - 1] * (uint32_t)sizeof(GRec) : null_off;
       }
-      __syncthreads();
-      for (int j = 0; !p.done && j < nb; ++j) {
-        float2 q = L.xy[j];
-        float4 cj = L.co[j];
-        float dx = q.x - fxp, dy = q.y - fyp;
-        float power = -0.5f * (cj.x * dx * dx + cj.z * dy * dy) - cj.y * dx * dy;
-        if (power > 0.f) continue;
-        float alpha = fminf(0.99f, cj.w * __expf(power));
-        if (alpha < 1.0f / 255.0f) continue;
-        float test_T = p.T * (1.f - alpha);
-        if (test_T < 0.0001f) { p.done = true; continue; }
-        float w = alpha * p.T;
-        p.C0 += L.rgb[3 * j] * w; p.C1 += L.rgb[3 * j + 1] * w; p.C2 += L.rgb[3 * j + 2] * w;
-        p.T = test_T;
-        p.last = L.hit[h0 + j];
+      FIXACC(3, tph);
+      int lastj = -1;
+      // one Gaussian against this lane's pixel (upstream renderCUDA forward; `valid` / `upd` are lane masks)
+      auto one = [&](const float4& g0, const float4& g1, float bl, int j) {
+        const float dx = g0.x - fx, dy = g0.y - fyp;
+        const float e2 = dx * (g0.z * dx + g0.w * dy) + (g1.x * dy) * dy;     // log2 of the Gaussian's falloff
+        const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(e2 + g1.y));    // opacity folded into the exponent
+        const bool valid = !(e2 > 0.f) && !(alpha < 1.0f / 255.0f);
+        if (__ballot(valid) == 0ull) return;
+        const float test_T = p.T * (1.f - alpha);
+        const bool upd = valid && !(test_T < 0.0001f);
+        const float w = upd ? alpha * p.T : 0.f;
+        p.C0 += g1.z * w; p.C1 += g1.w * w; p.C2 += bl * w;
+        p.T = upd ? test_T : p.T;
+        lastj = upd ? j : lastj;
+        fx = (valid && !upd) ? kInf : fx;            // T would fall below 1e-4: the pixel stops
+      };
+      struct Set { float4 a[NM_G], b[NM_G]; float c[NM_G]; };
+      auto fetch = [&](Set& g, uint32_t offs, int j0) {
+#pragma unroll
+        for (int u = 0; u < NM_G; ++u) {
+          const char* rp = (const char*)recs + (uint32_t)__builtin_amdgcn_readlane((int)offs, j0 + u);
+          g.a[u] = *(const float4*)rp; g.b[u] = *(const float4*)(rp + 16); g.c[u] = *(const float*)(rp + 32);
+        }
+      };
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int nq = min(64, nb - 64 * q);          // (wave-uniform)
+        if (nq <= 0 || !live) break;
+        Set A, B;
+        fetch(A, idr[q], 0);
+        for (int j0 = 0; j0 < nq; j0 += 2 * NM_G) {
+          fetch(B, idr[q], j0 + NM_G);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < NM_G; ++u) one(A.a[u], A.b[u], A.c[u], 64 * q + j0 + u);
+          fetch(A, idr[q], (j0 + 2 * NM_G) & 63);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < NM_G; ++u) one(B.a[u], B.b[u], B.c[u], 64 * q + j0 + NM_G + u);
+          if (__ballot(fx < kInf) == 0ull) { live = false; break; }
+        }
       }
-      if (ck) checkpoint(L.hit[h0 + nb - 1]);
+      if (lastj >= 0) p.last = L.hit[h0 + lastj];
+      wreach = L.hit[h0 + nb - 1];
+      FIXACC(4, tph);
+      if (ck) checkpoint(wreach);
     }
-    if (ck) checkpoint((uint32_t)(min(base + NM_SCAN, b) - lo));
+    if (live) {
+      wreach = (uint32_t)(min(base + NM_SCAN, b) - lo);
+      if (ck) checkpoint(wreach);
+    }
+    if (lane == 0) L.wreach[wave] = wreach;
   }
+  __syncthreads();
+  reached = max(max(L.wreach[0], L.wreach[1]), max(L.wreach[2], L.wreach[3]));       // the wave that went furthest
+  __syncthreads();       // (L.wreach is written again by the caller's next range)
+  p.done = !(fx < kInf);
+  return reached;
 }
 __device__ __forceinline__ void write_pixel(const RK& k, int px, int py, const Pix& p, float* __restrict__ final_T,
                                             uint32_t* __restrict__ n_contrib, float* __restrict__ out) {
@@ -743,9 +856,9 @@ __device__ __forceinline__ void write_pixel(const RK& k, int px, int py, const P
 __device__ __forceinline__ void render_whole(CompLds& L, const RK& k, int nbx, int tile_x, int tile_y, const uint32_t* __restrict__ off,
                                              const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
                                              long long cap, const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ tile_rec,
-                                             const float2* __restrict__ xy, const float* __restrict__ rgb,
-                                             const float4* __restrict__ conop, float* __restrict__ final_T,
-                                             uint32_t* __restrict__ n_contrib, float* __restrict__ out) {
+                                             const GRec* __restrict__ recs, float* __restrict__ final_T,
+                                             uint32_t* __restrict__ n_contrib, float* __restrict__ out,
+                                             uint32_t* __restrict__ hint) {
   if (tile_rec[tile_y * k.gx + tile_x] != 0xFFFFFFFFu) return;      // a candidate of the split compositing (render_seg)
   const int tid = threadIdx.x;
   const int px = tile_x * NM_TILE + (tid & 15), py = tile_y * NM_TILE + (tid >> 4);
@@ -756,8 +869,9 @@ __device__ __forceinline__ void render_whole(CompLds& L, const RK& k, int nbx, i
   // capacity overflow (hdr[3]): slots of the lists were never written - render the background only, the caller re-runs
   const long long hi = hdr[3] ? lo : min((long long)off[(bin + 1) * NM_NS], cap);
   Pix p = {1.f, 0.f, 0.f, 0.f, 0u, !inside};
-  composite_range(L, lo, lo, hi, bit, keys, vals, xy, rgb, conop, (float)px, (float)py, p);
+  const uint32_t reached = composite_range(L, lo, lo, hi, bit, keys, vals, recs, (uint32_t)k.K * (uint32_t)sizeof(GRec), (float)px, (float)py, p);
   if (inside) write_pixel(k, px, py, p, final_T, n_contrib, out);
+  if (hint && tid == 0) hint[tile_y * k.gx + tile_x] = reached;
 }
 
 // ---- split compositing.  A view whose Gaussians all fall into a few dozen tiles (the single-object scenes: 36-240 busy
@@ -782,11 +896,12 @@ __global__ void __launch_bounds__(1024) k_split_plan(RK k, int nbx, uint32_t bus
                                                      uint32_t* __restrict__ hdr, uint32_t* __restrict__ tile_rec,
                                                      uint32_t* __restrict__ tile_ns, uint32_t* __restrict__ tile_cnt,
                                                      uint32_t* __restrict__ tile_mode, uint2* __restrict__ work,
-                                                     uint32_t* __restrict__ seg_pos) {
+                                                     uint32_t* __restrict__ seg_pos, const uint32_t* __restrict__ hint,
+                                                     uint32_t fwd_len, uint32_t hint_seg) {
   __shared__ unsigned long long s_total;
-  __shared__ uint32_t s_busy, s_base, s_scan[1024];
+  __shared__ uint32_t s_busy, s_base, s_used, s_scan[1024];
   const int tid = threadIdx.x, rows = k.ty1 - k.ty0, ntile = k.gx * rows;
-  if (tid == 0) { s_total = 0ull; s_busy = 0u; s_base = 0u; }
+  if (tid == 0) { s_total = 0ull; s_busy = 0u; s_base = 0u; s_used = 0u; }
   __syncthreads();
   auto list_len = [&](int i) -> uint32_t {
     const int tx = i % k.gx, ty = i / k.gx + k.ty0;
@@ -794,6 +909,66 @@ __global__ void __launch_bounds__(1024) k_split_plan(RK k, int nbx, uint32_t bus
     const long long lo = off[bin * NM_NS], hi = min((long long)off[(bin + 1) * NM_NS], cap);
     return hi > lo ? (uint32_t)(hi - lo) : 0u;
   };
+  // ---- hinted plan.  hint[t] = list position the previous forward walk of tile t with this camera had reached when it ended
+  // (every pixel saturated, or the end of the list for a tile with a pixel that never saturates); 0 = nothing known.  The
+  // scene moves little between two renders of a camera, so the walk is planned to be about as long again: the tile is cut
+  // into equal segments of ~seg entries up to 1.25 x the hint.  The reverse sweep walks all segments in parallel, whatever
+  // the number of busy tiles.  The forward pass composites a tile's segments in parallel from T = 1 only where the walk is
+  // long (> fwd_len entries: the view's critical path) - k_render_fix then restores the exact termination - and walks the
+  // other tiles front to back as ever, leaving the (C, T) checkpoints in front of the segments on the way (no work is done
+  // twice there).  Behind the planned stretch (record too short) the walk simply goes on.  A wrong hint costs time, never
+  // accuracy.  Every thread owns NM_PLAN_PER consecutive tiles (all their loads in flight at once).
+  if (hint && !hdr[3] && ntile <= 1024 * NM_PLAN_PER) {
+    uint32_t ln[NM_PLAN_PER], ll[NM_PLAN_PER];
+    unsigned long long tot = 0ull; uint32_t any = 0u;
+#pragma unroll
+    for (int u = 0; u < NM_PLAN_PER; ++u) {
+      const int i = tid * NM_PLAN_PER + u;
+      uint32_t h = 0u; ln[u] = 0u;
+      if (i < ntile) { h = hint[(i / k.gx + k.ty0) * k.gx + i % k.gx]; ln[u] = list_len(i); }
+      ll[u] = h ? min(ln[u], h + h / 4u + 64u) : 0u;
+      tot += ll[u]; any += ll[u] ? 1u : 0u;
+    }
+    if (any) { atomicAdd(&s_total, tot); atomicAdd(&s_busy, any); }
+    __syncthreads();
+    if (s_busy > 0u) {
+      uint32_t seg = (uint32_t)((s_total + NM_HINT_WGS - 1) / NM_HINT_WGS);      // (independent of the capacity: see hdr[12])
+      seg = max(seg, hint_seg);
+      seg = (seg + 15u) & ~15u;
+      auto segments = [&](uint32_t l) -> uint32_t { return l > seg + seg / 2u ? (l + seg - 1) / seg : 0u; };
+      uint32_t mine = 0u;
+#pragma unroll
+      for (int u = 0; u < NM_PLAN_PER; ++u) { const uint32_t ns = segments(ll[u]); mine += ns ? ns + 1u : 0u; }
+      uint32_t incl = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, o, 64); if ((tid & 63) >= o) incl += y; }
+      if ((tid & 63) == 63) s_scan[tid >> 6] = incl;
+      __syncthreads();
+      uint32_t rec = incl - mine;
+      for (int w = 0; w < (tid >> 6); ++w) rec += s_scan[w];
+      if (tid == 1023) s_base = rec + mine;
+#pragma unroll
+      for (int u = 0; u < NM_PLAN_PER; ++u) {
+        const int i = tid * NM_PLAN_PER + u;
+        if (i >= ntile) break;
+        const uint32_t l = ll[u], ns = segments(l), items = ns ? ns + 1u : 0u;
+        const int t = (i / k.gx + k.ty0) * k.gx + i % k.gx;
+        const bool ok = ns > 0u && rec + items <= (uint32_t)k.items;
+        tile_rec[t] = ok ? rec : 0xFFFFFFFFu;
+        tile_ns[t] = ok ? ns : 0u;
+        tile_cnt[t] = ok ? (((l + ns - 1) / ns + 15u) & ~15u) : 0u;      // the tile's segment length (k_hint_fill)
+        tile_mode[t] = ok && l > fwd_len ? 1u : 0u;
+        if (ok) atomicMax(&s_used, rec + items);       // work items beyond the last assigned one do not exist (hdr[8])
+        rec += items;
+      }
+      __syncthreads();
+      if (tid == 0) { hdr[8] = s_used; hdr[9] = seg; hdr[10] = 1u; hdr[11] = 1u; hdr[12] = s_base; }
+      return;
+    }
+    __syncthreads();
+    if (tid == 0) { s_total = 0ull; s_busy = 0u; }
+    __syncthreads();
+  }
   unsigned long long tot = 0ull; uint32_t busy = 0u;
   if (!hdr[3]) {         // all tiles of a bin share its list: one thread per bin
     const int nby = (k.gy + NM_BT - 1) / NM_BT;
@@ -836,12 +1011,13 @@ __global__ void __launch_bounds__(1024) k_split_plan(RK k, int nbx, uint32_t bus
     const uint32_t rec = s_base + s_scan[tid] - items;
     if (i < ntile) {
       const int t = (i / k.gx + k.ty0) * k.gx + i % k.gx;
-      const bool ok = ns > 0u && rec + items <= NM_SPLIT_WORK;    // (holds by construction of seg; kept as a guard)
+      const bool ok = ns > 0u && rec + items <= (uint32_t)k.items;    // (holds by construction of seg; kept as a guard)
       tile_rec[t] = ok ? rec : 0xFFFFFFFFu;
       tile_ns[t] = ok ? ns : 0u;
       tile_cnt[t] = 0u;
       tile_mode[t] = 0u;
       if (ok) {
+        atomicMax(&s_used, rec + items);
         const uint32_t n = list_len(i);
         for (uint32_t q = 0; q <= ns; ++q) { work[rec + q] = make_uint2((uint32_t)t, q); seg_pos[rec + q] = min(q * seg, n); }
       }
@@ -850,7 +1026,25 @@ __global__ void __launch_bounds__(1024) k_split_plan(RK k, int nbx, uint32_t bus
     if (tid == 1023) s_base += s_scan[1023];
     __syncthreads();
   }
-  if (tid == 0) { hdr[8] = min(s_base, (uint32_t)NM_SPLIT_WORK); hdr[9] = seg; hdr[10] = s_total <= fwd_max ? 1u : 0u; }
+  if (tid == 0) { hdr[8] = s_used; hdr[9] = seg; hdr[10] = s_total <= fwd_max ? 1u : 0u; hdr[12] = s_base; }
+}
+
+// work items of a hinted plan: one wave per tile writes its (tile, segment) pairs and segment boundaries
+__global__ void __launch_bounds__(256) k_hint_fill(RK k, int nbx, const uint32_t* __restrict__ off, long long cap,
+                                                   const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ tile_rec,
+                                                   const uint32_t* __restrict__ tile_ns, const uint32_t* __restrict__ tile_cnt,
+                                                   uint2* __restrict__ work, uint32_t* __restrict__ seg_pos) {
+  if (!hdr[11]) return;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, ntile = k.gx * (k.ty1 - k.ty0);
+  if (i >= ntile) return;
+  const int tx = i % k.gx, ty = i / k.gx + k.ty0, t = ty * k.gx + tx;
+  const uint32_t ns = tile_ns[t];
+  if (!ns) return;
+  const uint32_t rec = tile_rec[t], step = tile_cnt[t];
+  const int bin = (ty / NM_BT) * nbx + tx / NM_BT;
+  const long long lo = off[bin * NM_NS], hi = min((long long)off[(bin + 1) * NM_NS], cap);
+  const uint32_t n = hi > lo ? (uint32_t)(hi - lo) : 0u;
+  for (uint32_t q = lane; q <= ns; q += 64) { work[rec + q] = make_uint2((uint32_t)t, q); seg_pos[rec + q] = min(q * step, n); }
 }
 
 // pass 1 (two launches: stage 0 = first segments, which decide; stage 1 = the other segments of the split tiles)
@@ -860,13 +1054,18 @@ __device__ __forceinline__ void render_seg(CompLds& L, const RK& k, int nbx, int
                                            long long cap, const uint32_t* __restrict__ hdr, const uint2* __restrict__ work,
                                            float4* __restrict__ seg_raw, uint32_t* __restrict__ seg_last,
                                            float4* __restrict__ seg_ct, uint32_t* __restrict__ seg_pos,
-                                           const float2* __restrict__ xy, const float* __restrict__ rgb,
-                                           const float4* __restrict__ conop, float* __restrict__ final_T,
-                                           uint32_t* __restrict__ n_contrib, float* __restrict__ out) {
+                                           const GRec* __restrict__ recs, float* __restrict__ final_T,
+                                           uint32_t* __restrict__ n_contrib, float* __restrict__ out,
+                                           uint32_t* __restrict__ hint) {
   if (w >= hdr[8]) return;
   const uint2 wk = work[w];
   const uint32_t ns = tile_ns[wk.x];
-  if (stage == 0 ? wk.y != 0u : (wk.y == 0u || wk.y >= ns || tile_mode[wk.x] != 1u)) return;
+  // hinted plan: everything in the first launch, nothing is decided on the way - the plan itself has chosen the tiles that
+  // are composited in parallel segments (tile_mode 1); the other tiles are walked front to back by their first work item
+  const bool hinted = hdr[11] != 0u;
+  const bool walk_on = hinted && tile_mode[wk.x] != 1u;
+  if (hinted ? (stage != 0 || wk.y >= ns || (walk_on && wk.y != 0u))
+             : (stage == 0 ? wk.y != 0u : (wk.y == 0u || wk.y >= ns || tile_mode[wk.x] != 1u))) return;
   const int tile_x = wk.x % k.gx, tile_y = wk.x / k.gx;
   const long long seg = hdr[9];
   const int tid = threadIdx.x;
@@ -876,26 +1075,32 @@ __device__ __forceinline__ void render_seg(CompLds& L, const RK& k, int nbx, int
   const int bin = (tile_y / NM_BT) * nbx + tile_x / NM_BT;
   const uint32_t bit = 1u << ((tile_y % NM_BT) * NM_BT + tile_x % NM_BT);
   const long long lo = off[bin * NM_NS], hi = min((long long)off[(bin + 1) * NM_NS], cap);
-  const long long a = lo + seg * wk.y, b = min(hi, a + seg);
+  const long long a = lo + seg_pos[w], b = min(hi, lo + (long long)seg_pos[w + 1]);     // (the plan's boundaries: q * seg by default)
   Pix p = {1.f, 0.f, 0.f, 0.f, 0u, !inside};
-  composite_range(L, lo, a, b, bit, keys, vals, xy, rgb, conop, fxp, fyp, p);
-  if (stage == 0) {
-    const bool far = __syncthreads_or(!p.done && p.T > NM_SPLIT_TAU);
+  composite_range(L, lo, a, b, bit, keys, vals, recs, (uint32_t)k.K * (uint32_t)sizeof(GRec), fxp, fyp, p);
+  if (stage == 0 && (!hinted || walk_on)) {
+    const bool far = walk_on ? false : __syncthreads_or(!p.done && p.T > NM_SPLIT_TAU);
     if (!(far && hdr[10])) {
       // nobody is far from stopping (or the view's lists are too much speculative work): this workgroup walks on as a whole
       // tile would, leaving a checkpoint (C, T) roughly every `seg` list entries - the reverse sweep starts its parallel
       // walks from them
       seg_ct[(size_t)w * NM_TPB + tid] = make_float4(0.f, 0.f, 0.f, 1.f);
-      composite_range(L, lo, b, hi, bit, keys, vals, xy, rgb, conop, fxp, fyp, p, (uint32_t)seg, 1u, ns, seg_ct + (size_t)w * NM_TPB,
-                      seg_pos + w);
+      const uint32_t reached = composite_range(L, lo, b, hi, bit, keys, vals, recs, (uint32_t)k.K * (uint32_t)sizeof(GRec), fxp, fyp, p, (uint32_t)seg, 1u, ns,
+                                               seg_ct + (size_t)w * NM_TPB, seg_pos + w);
       seg_ct[(size_t)(w + ns) * NM_TPB + tid] = make_float4(p.C0, p.C1, p.C2, p.T);
       if (inside) write_pixel(k, px, py, p, final_T, n_contrib, out);
+      if (tid == 0) {
+        if (hint) hint[wk.x] = reached;
+        // a hinted plan may end in front of where this walk did: the reverse sweep's last segment reaches that far
+        if (reached > seg_pos[w + ns]) seg_pos[w + ns] = reached;
+      }
       return;
     }
     if (tid == 0) tile_mode[wk.x] = 1u;
   }
-  // transmittance < 0: the segment stopped by itself (its own T would have fallen below 1e-4) - the pixel ends in it or earlier
-  seg_raw[(size_t)w * NM_TPB + tid] = make_float4(p.C0, p.C1, p.C2, (p.done && inside) ? -1.f : p.T);
+  // transmittance < 0 (-T: T >= 1e-4 whenever a pixel stops): the segment stopped by itself (its own T would have fallen below
+  // 1e-4) - the pixel ends in it or earlier.  For the tile's first segment the record is already the truth (it starts at T = 1)
+  seg_raw[(size_t)w * NM_TPB + tid] = make_float4(p.C0, p.C1, p.C2, (p.done && inside) ? -p.T : p.T);
   seg_last[(size_t)w * NM_TPB + tid] = p.last;
 }
 // one launch, 1-D grid: workgroups [0, ntile) = the tiles that are composited whole (stage 0 only), the others = the work
@@ -907,16 +1112,23 @@ __global__ void __launch_bounds__(NM_TPB) k_render(RK k, int nbx, int stage, int
                                                    const uint2* __restrict__ work, float4* __restrict__ seg_raw,
                                                    uint32_t* __restrict__ seg_last, float4* __restrict__ seg_ct,
                                                    uint32_t* __restrict__ seg_pos,
-                                                   const float2* __restrict__ xy, const float* __restrict__ rgb,
-                                                   const float4* __restrict__ conop, float* __restrict__ final_T,
-                                                   uint32_t* __restrict__ n_contrib, float* __restrict__ out) {
+                                                   const GRec* __restrict__ recs, float* __restrict__ final_T,
+                                                   uint32_t* __restrict__ n_contrib, float* __restrict__ out,
+                                                   uint32_t* __restrict__ hint) {
   __shared__ CompLds L;
   const int b = blockIdx.x;
+#ifdef NM_FIXDBG
+  if (stage == 0) FIXDBG(0);
+#endif
   if (b < ntile)
-    render_whole(L, k, nbx, b % k.gx, b / k.gx + k.ty0, off, keys, vals, cap, hdr, tile_rec, xy, rgb, conop, final_T, n_contrib, out);
+    render_whole(L, k, nbx, b % k.gx, b / k.gx + k.ty0, off, keys, vals, cap, hdr, tile_rec, recs, final_T, n_contrib, out,
+                 hint);
   else
     render_seg(L, k, nbx, stage, (uint32_t)(b - ntile), tile_mode, tile_ns, off, keys, vals, cap, hdr, work, seg_raw, seg_last, seg_ct,
-               seg_pos, xy, rgb, conop, final_T, n_contrib, out);
+               seg_pos, recs, final_T, n_contrib, out, hint);
+#ifdef NM_FIXDBG
+  if (stage == 0) FIXDBG(1);
+#endif
 }
 
 // pass 2, again one workgroup per segment: with the transmittance in front of the segment known (product over the earlier
@@ -932,19 +1144,17 @@ __global__ void __launch_bounds__(NM_TPB) k_render_fix(RK k, int nbx, const uint
                                                        const uint32_t* __restrict__ tile_mode,
                                                        const uint2* __restrict__ work, const float4* __restrict__ seg_raw,
                                                        float4* __restrict__ seg_fix, float4* __restrict__ seg_ct,
-                                                       uint32_t* __restrict__ seg_last,
-                                                       const float2* __restrict__ xy, const float* __restrict__ rgb,
-                                                       const float4* __restrict__ conop, float* __restrict__ final_T,
-                                                       uint32_t* __restrict__ n_contrib, float* __restrict__ out) {
+                                                       uint32_t* __restrict__ seg_last, uint32_t* __restrict__ seg_pos,
+                                                       const GRec* __restrict__ recs, float* __restrict__ final_T,
+                                                       uint32_t* __restrict__ n_contrib, float* __restrict__ out,
+                                                       uint32_t* __restrict__ hint) {
   __shared__ CompLds L;
-  __shared__ int s_flag;
   const uint32_t w = blockIdx.x;
   if (w >= hdr[8]) return;
   const uint2 wk = work[w];
   const uint32_t ns = tile_ns[wk.x], r0 = tile_rec[wk.x];
   if (tile_mode[wk.x] != 1u || wk.y >= ns) return;        // finished by its first segment's workgroup / the tile's extra record
   const int tile_x = wk.x % k.gx, tile_y = wk.x / k.gx;
-  const long long seg = hdr[9];
   const int tid = threadIdx.x;
   const int px = tile_x * NM_TILE + (tid & 15), py = tile_y * NM_TILE + (tid >> 4);
   const bool inside = px < k.W && py < k.H;
@@ -952,6 +1162,7 @@ __global__ void __launch_bounds__(NM_TPB) k_render_fix(RK k, int nbx, const uint
   const int bin = (tile_y / NM_BT) * nbx + tile_x / NM_BT;
   const uint32_t bit = 1u << ((tile_y % NM_BT) * NM_BT + tile_x % NM_BT);
   const long long lo = off[bin * NM_NS], hi = min((long long)off[(bin + 1) * NM_NS], cap);
+  FIXDBG(0);
   {
     float Tp = 1.f;
     bool stopped = !inside;
@@ -969,40 +1180,93 @@ __global__ void __launch_bounds__(NM_TPB) k_render_fix(RK k, int nbx, const uint
     const size_t ri = (size_t)w * NM_TPB + tid;
     float4 ct = seg_raw[ri];
     uint32_t ls = seg_last[ri];
-    const bool need = !stopped && (ct.w < 0.f || Tp * ct.w < 0.0001f);
+    // (segment 0 starts from the true T = 1: what pass 1 recorded stands, sign included)
+    const bool need = wk.y != 0u && !stopped && (ct.w < 0.f || Tp * ct.w < 0.0001f);
+    FIXDBG(1);
+#ifdef NM_FIXDBG
+    const int n_need = __syncthreads_count(need);
+    FIXDBGV(5, (unsigned long long)n_need | ((unsigned long long)wk.y << 16) | ((unsigned long long)ns << 32));
+#endif
     if (__syncthreads_or(need)) {
-      const long long a = lo + seg * wk.y, b = min(hi, a + seg);
+      const long long a = lo + seg_pos[w], b = min(hi, lo + (long long)seg_pos[w + 1]);
       Pix r = {Tp, 0.f, 0.f, 0.f, 0u, !need};
-      composite_range(L, lo, a, b, bit, keys, vals, xy, rgb, conop, fxp, fyp, r);
+      composite_range(L, lo, a, b, bit, keys, vals, recs, (uint32_t)k.K * (uint32_t)sizeof(GRec), fxp, fyp, r);
       if (need) {
         const float inv = 1.f / Tp;
-        ct = make_float4(r.C0 * inv, r.C1 * inv, r.C2 * inv, r.T * inv);
+        // sign of the record's transmittance = "the pixel has stopped in this segment" (read by the summing workgroup below)
+        ct = make_float4(r.C0 * inv, r.C1 * inv, r.C2 * inv, r.done ? -(r.T * inv) : r.T * inv);
         ls = r.last;
       }
     }
-    if (stopped) { ct = make_float4(0.f, 0.f, 0.f, 1.f); ls = 0u; }
+    if (stopped) { ct = make_float4(0.f, 0.f, 0.f, -1.f); ls = 0u; }
     seg_fix[ri] = ct;
     seg_last[ri] = ls;
   }
-  // ---- the last segment of the tile to finish sums the records
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) s_flag = atomicAdd(&tile_cnt[wk.x], 1u) == ns - 1u;
-  __syncthreads();
-  if (!s_flag) return;
-  __threadfence();
+  FIXDBG(2);
+}
+
+// pass 3, one workgroup per split tile: sums the tile's records, leaves the checkpoints (C, T) in front of every segment for
+// the reverse sweep, and walks on behind the planned stretch if a pixel is still alive there.  (A launch of its own: the
+// kernel boundary orders it behind pass 2.  An arrival counter in pass 2 needed two device-scope fences per workgroup -
+// on this chip each of them writes back and invalidates an XCD's L2, and a few thousand of them made every load of the
+// kernel miss: 620 us for the metric view against 60 with the extra launch.)
+__global__ void __launch_bounds__(NM_TPB) k_render_sum(RK k, int nbx, const uint32_t* __restrict__ off,
+                                                       const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                       long long cap, const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ tile_rec,
+                                                       const uint32_t* __restrict__ tile_ns, const uint32_t* __restrict__ tile_mode,
+                                                       const float4* __restrict__ seg_fix, float4* __restrict__ seg_ct,
+                                                       const uint32_t* __restrict__ seg_last, uint32_t* __restrict__ seg_pos,
+                                                       const GRec* __restrict__ recs, float* __restrict__ final_T,
+                                                       uint32_t* __restrict__ n_contrib, float* __restrict__ out,
+                                                       uint32_t* __restrict__ hint) {
+  __shared__ CompLds L;
+  __shared__ uint32_t s_last;
+  if (hdr[8] == 0u) return;
+  const int tile_x = blockIdx.x % k.gx, tile_y = blockIdx.x / k.gx + k.ty0, t = tile_y * k.gx + tile_x;
+  if (tile_mode[t] != 1u) return;
+  const uint32_t ns = tile_ns[t], r0 = tile_rec[t];
+  const int tid = threadIdx.x;
+  const int px = tile_x * NM_TILE + (tid & 15), py = tile_y * NM_TILE + (tid >> 4);
+  const bool inside = px < k.W && py < k.H;
+  const float fxp = (float)px, fyp = (float)py;
+  const int bin = (tile_y / NM_BT) * nbx + tile_x / NM_BT;
+  const uint32_t bit = 1u << ((tile_y % NM_BT) * NM_BT + tile_x % NM_BT);
+  const long long lo = off[bin * NM_NS], hi = min((long long)off[(bin + 1) * NM_NS], cap);
+  if (tid == 0) s_last = 0u;
   Pix q = {1.f, 0.f, 0.f, 0.f, 0u, !inside};
-  for (uint32_t sg = 0; sg < ns; ++sg) {
-    const size_t ri = (size_t)(r0 + sg) * NM_TPB + tid;
-    const float4 ct = seg_fix[ri];
-    const uint32_t ls = seg_last[ri];
-    seg_ct[ri] = make_float4(q.C0, q.C1, q.C2, q.T);
-    q.C0 += q.T * ct.x; q.C1 += q.T * ct.y; q.C2 += q.T * ct.z;
-    q.T *= ct.w;
-    if (ls) q.last = ls;
+  for (uint32_t s0 = 0; s0 < ns; s0 += 4) {          // (four records in flight)
+    float4 ct[4]; uint32_t ls[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t ri = (size_t)(r0 + min(s0 + u, ns - 1u)) * NM_TPB + tid;
+      ct[u] = seg_fix[ri]; ls[u] = seg_last[ri];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (s0 + u >= ns) break;
+      seg_ct[(size_t)(r0 + s0 + u) * NM_TPB + tid] = make_float4(q.C0, q.C1, q.C2, q.T);
+      q.C0 += q.T * ct[u].x; q.C1 += q.T * ct[u].y; q.C2 += q.T * ct[u].z;
+      q.T *= fabsf(ct[u].w);
+      q.done = q.done || __builtin_signbitf(ct[u].w);       // sign = the pixel has stopped in this segment or before
+      if (ls[u]) q.last = ls[u];
+    }
+  }
+  // list entries behind the planned stretch (hinted plans end at ~1.25 x the previous walk): walked here, from the true state
+  const long long planned = lo + (long long)seg_pos[r0 + ns];
+  uint32_t reached = (uint32_t)(planned - lo);
+  const bool all = __syncthreads_and(q.done);
+  if (!all && planned < hi) {
+    reached = composite_range(L, lo, planned, hi, bit, keys, vals, recs, (uint32_t)k.K * (uint32_t)sizeof(GRec), fxp, fyp, q);
+    if (tid == 0) seg_pos[r0 + ns] = reached;       // the reverse sweep's last segment ends where this walk did
+  } else if (all && hint) {
+    // where a sequential walk of this tile would have ended: just behind the last contributor
+    if (q.last) atomicMax(&s_last, q.last);
+    __syncthreads();
+    reached = min(reached, s_last + 1u);
   }
   seg_ct[(size_t)(r0 + ns) * NM_TPB + tid] = make_float4(q.C0, q.C1, q.C2, q.T);
   if (inside) write_pixel(k, px, py, q, final_T, n_contrib, out);
+  if (hint && tid == 0) hint[t] = reached;
 }
 
 // exact number of (Gaussian, tile) pairs of the view (what the reference's duplicateWithKeys would emit after the conic
@@ -1080,10 +1344,6 @@ __device__ __forceinline__ float wave_sum_dpp(float x) {
 struct BwdLdsR {
   uint32_t hit[NM_RB_SCAN];
   uint32_t id[NM_RB_BATCH];
-  uint32_t pos[NM_RB_BATCH];
-  float2 xy[NM_RB_BATCH];
-  float4 co[NM_RB_BATCH];
-  float rgb[NM_RB_BATCH * 3];
   float acc[4][NM_RB_BATCH * NM_NG];   // one private table per wave: plain stores, no LDS atomics
   int wcnt[4];
   uint32_t last[4];
@@ -1103,12 +1363,11 @@ struct PixB {
 template <bool WITH_OPACITY>
 __device__ __forceinline__ void render_bwd_range(BwdLdsR& L, const RK& k, long long lo, uint32_t floor_pos, uint32_t bit,
                                                  const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                 const float2* __restrict__ xy, const float* __restrict__ rgb,
-                                                 const float4* __restrict__ conop, float fxp, float fyp, PixB& P,
+                                                 const GRec* __restrict__ recs, float fxp, float fyp, PixB& P,
                                                  float* __restrict__ acc /* (K, 9) */) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float bg_dot = k.bg[0] * P.dp0 + k.bg[1] * P.dp1 + k.bg[2] * P.dp2;
-  const float ddelx_dx = 0.5f * k.W, ddely_dy = 0.5f * k.H;
+  const float kx = 0.5f * k.W / NM_LOG2E, ky = 0.5f * k.H / NM_LOG2E;
   float* my_acc = L.acc[wave];
   // lane l < 8 owns fold slot value index:
   const int slot = 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1);
@@ -1148,28 +1407,28 @@ __device__ __forceinline__ void render_bwd_range(BwdLdsR& L, const RK& k, long l
     for (int h0 = 0; h0 < nh; h0 += NM_RB_BATCH) {
     __syncthreads();
     const int nb = min(NM_RB_BATCH, nh - h0);
-    if (tid < nb) {
-      const uint32_t pos = L.hit[h0 + tid];
-      const uint32_t id = (uint32_t)keys[lo + pos - 1];
-      L.id[tid] = id;
-      L.pos[tid] = pos;
-      L.xy[tid] = xy[id];
-      L.co[tid] = conop[id];
-      L.rgb[3 * tid] = rgb[3 * id]; L.rgb[3 * tid + 1] = rgb[3 * id + 1]; L.rgb[3 * tid + 2] = rgb[3 * id + 2];
+    // no staging of Gaussian data: every wave keeps the batch's record offsets and list positions in two registers each
+    // (lane l: hits l and l + 64), pulls hit j's out with v_readlane and fetches the record with scalar loads (see GRec)
+    uint32_t offr[NM_RB_BATCH / 64], posr[NM_RB_BATCH / 64];
+#pragma unroll
+    for (int q = 0; q < NM_RB_BATCH / 64; ++q) {
+      const int t = 64 * q + lane;
+      offr[q] = k.K * (uint32_t)sizeof(GRec); posr[q] = 0xFFFFFFFFu;        // padding: the null record, behind everything
+      if (t < nb) {
+        const uint32_t pos = L.hit[h0 + t];
+        const uint32_t id = (uint32_t)keys[lo + pos - 1];
+        offr[q] = id * (uint32_t)sizeof(GRec); posr[q] = pos;
+        if (wave == 0) L.id[t] = id;
+      }
     }
-    __syncthreads();
-    for (int j = 0; j < nb; ++j) {
-      const uint32_t pos = L.pos[j];
-      if (pos > wave_last) continue;            // wave-uniform: behind every pixel's last contributor
-      bool act = pos <= P.last;
-      float2 p = L.xy[j];
-      float4 co = L.co[j];
-      float dx = p.x - fxp, dy = p.y - fyp;
-      float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-      float G = __expf(power);
-      float alpha = fminf(0.99f, co.w * G);
-      act = act && !(power > 0.f) && !(alpha < 1.0f / 255.0f);
-      if (__ballot(act) == 0ull) continue;  // whole wave skips this Gaussian
+    auto one = [&](const float4& g0, const float4& g1, const float2& g2, uint32_t pos, int j) {
+      if (pos > wave_last) return;              // wave-uniform: behind every pixel's last contributor
+      const float dx = g0.x - fxp, dy = g0.y - fyp;
+      const float e2 = dx * (g0.z * dx + g0.w * dy) + (g1.x * dy) * dy;      // log2 G
+      const float G = __builtin_amdgcn_exp2f(e2);
+      const float alpha = fminf(0.99f, g2.y * G);
+      const bool act = pos <= P.last && !(e2 > 0.f) && !(alpha < 1.0f / 255.0f);
+      if (__ballot(act) == 0ull) return;      // whole wave skips this Gaussian
       float g[8], gop = 0.f;
 #pragma unroll
       for (int q = 0; q < 8; ++q) g[q] = 0.f;
@@ -1178,8 +1437,8 @@ __device__ __forceinline__ void render_bwd_range(BwdLdsR& L, const RK& k, long l
         // instructions of an evaluated (pixel, Gaussian) pair; alpha <= 0.99 keeps the denominator >= 0.01
         const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);
         P.T = P.T * inv1ma;
-        float dch = alpha * P.T;
-        float c0 = L.rgb[3 * j], c1 = L.rgb[3 * j + 1], c2 = L.rgb[3 * j + 2];
+        const float dch = alpha * P.T;
+        const float c0 = g1.z, c1 = g1.w, c2 = g2.x;
         P.ar0 = P.last_alpha * P.lc0 + (1.f - P.last_alpha) * P.ar0; P.lc0 = c0;
         P.ar1 = P.last_alpha * P.lc1 + (1.f - P.last_alpha) * P.ar1; P.lc1 = c1;
         P.ar2 = P.last_alpha * P.lc2 + (1.f - P.last_alpha) * P.ar2; P.lc2 = c2;
@@ -1188,27 +1447,47 @@ __device__ __forceinline__ void render_bwd_range(BwdLdsR& L, const RK& k, long l
         dL_dalpha *= P.T;
         P.last_alpha = alpha;
         dL_dalpha += (-P.T_final * inv1ma) * bg_dot;
-        float dL_dG = co.w * dL_dalpha;
-        float gdx = G * dx, gdy = G * dy;
-        float dG_ddelx = -gdx * co.x - gdy * co.y;
-        float dG_ddely = -gdy * co.z - gdx * co.y;
-        g[0] = dL_dG * dG_ddelx * ddelx_dx;   // d/d(ndc x)
-        g[1] = dL_dG * dG_ddely * ddely_dy;
+        const float dL_dG = g2.y * dL_dalpha;
+        const float gdx = G * dx, gdy = G * dy;
+        // dG/d(delta) = -G (conic . delta) with conic = -(2a, b, 2c) / log2(e): the 1/log2(e) sits in kx, ky
+        g[0] = dL_dG * (2.f * g0.z * gdx + g0.w * gdy) * kx;   // d/d(ndc x)
+        g[1] = dL_dG * (2.f * g1.x * gdy + g0.w * gdx) * ky;
         g[2] = -0.5f * gdx * dx * dL_dG;       // d/d conic.x
         g[3] = -gdx * dy * dL_dG;              // d/d conic.y (full off-diagonal derivative)
         g[4] = -0.5f * gdy * dy * dL_dG;       // d/d conic.z
         gop = G * dL_dalpha;                   // d/d opacity
       }
-#if defined(NM_RB_VARIANT) && NM_RB_VARIANT == 1
-      float tot = g[0] + g[1] + g[2] + g[3] + g[4] + g[5] + g[6] + g[7];   // experiment: no cross-lane reduction
-      if (tot == 12345.f) my_acc[j * NM_NG + slot] += tot;
-#else
-      float tot = wave_fold8(g, lane);
+      const float tot = wave_fold8(g, lane);
       if (lane < 8) my_acc[j * NM_NG + slot] += tot;
-#endif
       if (WITH_OPACITY) {
-        float to = wave_sum_dpp(gop);
+        const float to = wave_sum_dpp(gop);
         if (lane == 0) my_acc[j * NM_NG + 8] += to;
+      }
+    };
+    struct Set { float4 a[NM_G], b[NM_G]; float2 c[NM_G]; uint32_t pos[NM_G]; };
+    auto fetch = [&](Set& g, uint32_t offs, uint32_t poss, int j0) {
+#pragma unroll
+      for (int u = 0; u < NM_G; ++u) {
+        const char* rp = (const char*)recs + (uint32_t)__builtin_amdgcn_readlane((int)offs, j0 + u);
+        g.a[u] = *(const float4*)rp; g.b[u] = *(const float4*)(rp + 16); g.c[u] = *(const float2*)(rp + 32);
+        g.pos[u] = (uint32_t)__builtin_amdgcn_readlane((int)poss, j0 + u);
+      }
+    };
+#pragma unroll
+    for (int q = 0; q < NM_RB_BATCH / 64; ++q) {
+      const int nq = min(64, nb - 64 * q);          // (wave-uniform)
+      if (nq <= 0) break;
+      Set A, B;
+      fetch(A, offr[q], posr[q], 0);
+      for (int j0 = 0; j0 < nq; j0 += 2 * NM_G) {
+        fetch(B, offr[q], posr[q], j0 + NM_G);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < NM_G; ++u) one(A.a[u], A.b[u], A.c[u], A.pos[u], 64 * q + j0 + u);
+        fetch(A, offr[q], posr[q], (j0 + 2 * NM_G) & 63);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < NM_G; ++u) one(B.a[u], B.b[u], B.c[u], B.pos[u], 64 * q + j0 + NM_G + u);
       }
     }
     __syncthreads();
@@ -1233,8 +1512,7 @@ template <bool WITH_OPACITY>
 __device__ __forceinline__ void bwd_whole(BwdLdsR& L, const RK& k, int nbx, int tile_x, int tile_y, const uint32_t* __restrict__ off,
                                           const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
                                           const uint32_t* __restrict__ tile_rec,
-                                          const float2* __restrict__ xy, const float* __restrict__ rgb,
-                                          const float4* __restrict__ conop, const float* __restrict__ final_T,
+                                          const GRec* __restrict__ recs, const float* __restrict__ final_T,
                                           const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
                                           float* __restrict__ acc /* (K, 9) */) {
   if (tile_rec[tile_y * k.gx + tile_x] != 0xFFFFFFFFu) return;      // bwd_seg
@@ -1252,7 +1530,7 @@ __device__ __forceinline__ void bwd_whole(BwdLdsR& L, const RK& k, int nbx, int 
     P.dp0 = dL_dpix[pix]; P.dp1 = dL_dpix[hw + pix]; P.dp2 = dL_dpix[2 * hw + pix];
   }
   P.T = P.T_final;
-  render_bwd_range<WITH_OPACITY>(L, k, lo, 0u, bit, keys, vals, xy, rgb, conop, (float)px, (float)py, P, acc);
+  render_bwd_range<WITH_OPACITY>(L, k, lo, 0u, bit, keys, vals, recs, (float)px, (float)py, P, acc);
 }
 
 // reverse walk of one segment of a candidate tile (k_split_plan), all segments of a tile in parallel.  The state a pixel
@@ -1266,8 +1544,7 @@ __device__ __forceinline__ void bwd_seg(BwdLdsR& L, const RK& k, int nbx, uint32
                                         const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ tile_rec,
                                         const uint32_t* __restrict__ tile_ns, const uint2* __restrict__ work,
                                         const float4* __restrict__ seg_ct, const uint32_t* __restrict__ seg_pos,
-                                        const float2* __restrict__ xy, const float* __restrict__ rgb,
-                                        const float4* __restrict__ conop, const float* __restrict__ final_T,
+                                        const GRec* __restrict__ recs, const float* __restrict__ final_T,
                                         const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
                                         float* __restrict__ acc /* (K, 9) */) {
   if (w >= hdr[8]) return;
@@ -1301,7 +1578,7 @@ __device__ __forceinline__ void bwd_seg(BwdLdsR& L, const RK& k, int nbx, uint32
   } else {
     P.last = last > floor_pos ? last : 0u;      // ends in this segment, or in an earlier one (nothing to do here)
   }
-  render_bwd_range<WITH_OPACITY>(L, k, lo, floor_pos, bit, keys, vals, xy, rgb, conop, (float)px, (float)py, P, acc);
+  render_bwd_range<WITH_OPACITY>(L, k, lo, floor_pos, bit, keys, vals, recs, (float)px, (float)py, P, acc);
 }
 
 // one launch, 1-D grid: workgroups [0, ntile) = whole tiles, the others = segments of the candidate tiles, side by side
@@ -1311,16 +1588,15 @@ __global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, int nbx, int ntile,
                                                        const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ tile_rec,
                                                        const uint32_t* __restrict__ tile_ns, const uint2* __restrict__ work,
                                                        const float4* __restrict__ seg_ct, const uint32_t* __restrict__ seg_pos,
-                                                       const float2* __restrict__ xy, const float* __restrict__ rgb,
-                                                       const float4* __restrict__ conop, const float* __restrict__ final_T,
+                                                       const GRec* __restrict__ recs, const float* __restrict__ final_T,
                                                        const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
                                                        float* __restrict__ acc /* (K, 9) */) {
   __shared__ BwdLdsR L;
   const int b = blockIdx.x;
   if (b < ntile)
-    bwd_whole<WITH_OPACITY>(L, k, nbx, b % k.gx, b / k.gx + k.ty0, off, keys, vals, tile_rec, xy, rgb, conop, final_T, n_contrib, dL_dpix, acc);
+    bwd_whole<WITH_OPACITY>(L, k, nbx, b % k.gx, b / k.gx + k.ty0, off, keys, vals, tile_rec, recs, final_T, n_contrib, dL_dpix, acc);
   else
-    bwd_seg<WITH_OPACITY>(L, k, nbx, (uint32_t)(b - ntile), off, keys, vals, hdr, tile_rec, tile_ns, work, seg_ct, seg_pos, xy, rgb, conop,
+    bwd_seg<WITH_OPACITY>(L, k, nbx, (uint32_t)(b - ntile), off, keys, vals, hdr, tile_rec, tile_ns, work, seg_ct, seg_pos, recs,
                           final_T, n_contrib, dL_dpix, acc);
 }
 
@@ -1474,6 +1750,13 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(RK k, int K, const float
 // ---------------------------------------------------------------- host API
 static int g_split_busy = NM_SPLIT_BUSY, g_split_minseg = NM_SPLIT_MINSEG;
 static long long g_split_fwd = NM_SPLIT_FWD_MAX;
+static int g_hint_fwd = NM_HINT_FWD, g_hint_seg = NM_HINT_MINSEG;
+extern "C" int nm_raster_set_hinted(int32_t forward_split_length, int32_t min_segment) {
+  NM_REQUIRE(forward_split_length >= 0 && min_segment >= 1, "forward_split_length >= 0, min_segment >= 1");
+  g_hint_fwd = forward_split_length;
+  g_hint_seg = (min_segment + 15) & ~15;
+  return NM_OK;
+}
 extern "C" int nm_raster_set_split(int32_t busy_tiles, int32_t min_segment, int64_t forward_budget) {
   NM_REQUIRE(busy_tiles >= 0 && min_segment >= 1 && forward_budget >= 0, "busy_tiles >= 0, min_segment >= 1, forward_budget >= 0");
   g_split_busy = busy_tiles;
@@ -1484,26 +1767,55 @@ extern "C" int nm_raster_set_split(int32_t busy_tiles, int32_t min_segment, int6
 // One view, forward: 6 launches, no host synchronisation.  status_host (optional, pinned host memory, 2 x int64): receives
 // {pairs binned, overflow flag} by an asynchronous copy at the end - overflow != 0 means cap_pairs was too small and the image
 // is incomplete (the caller re-runs with a capacity >= pairs).
+static int raster_forward_impl(const nm_raster_cfg* cfg, int32_t K, int32_t m, const float* means3D, const float* shs,
+                               const float* colors_precomp, const float* opacities, const float* cov3D, int32_t* radii,
+                               void* state, size_t state_bytes, void* scratch, size_t scratch_bytes, int64_t cap_pairs,
+                               float* out_color, int64_t* status_host, int status_words, uint32_t* tile_walk, void* stream);
 extern "C" int nm_raster_forward(const nm_raster_cfg* cfg, int32_t K, int32_t m, const float* means3D, const float* shs,
                                  const float* colors_precomp, const float* opacities, const float* cov3D, int32_t* radii,
                                  void* state, size_t state_bytes, int64_t cap_pairs, float* out_color, int64_t* status_host,
                                  void* stream) {
+  return raster_forward_impl(cfg, K, m, means3D, shs, colors_precomp, opacities, cov3D, radii, state, state_bytes, nullptr, 0,
+                             cap_pairs, out_color, status_host, 2, nullptr, stream);
+}
+// tile_walk (optional, device, one uint32 per 16x16 tile of the image, zero-initialised by the caller once per camera): in =
+// how far the previous forward walk of every tile with this camera went, out = the same for this render.  See k_split_plan.
+// scratch (optional): the forward-only arrays live there instead of behind the persistent part of `state`.
+extern "C" int nm_raster_forward_ex(const nm_raster_cfg* cfg, int32_t K, int32_t m, const float* means3D, const float* shs,
+                                    const float* colors_precomp, const float* opacities, const float* cov3D, int32_t* radii,
+                                    void* state, size_t state_bytes, void* scratch, size_t scratch_bytes, int64_t cap_pairs,
+                                    float* out_color, int64_t* status_host, uint32_t* tile_walk, void* stream) {
+  return raster_forward_impl(cfg, K, m, means3D, shs, colors_precomp, opacities, cov3D, radii, state, state_bytes, scratch,
+                             scratch_bytes, cap_pairs, out_color, status_host, 3, tile_walk, stream);
+}
+static int raster_forward_impl(const nm_raster_cfg* cfg, int32_t K, int32_t m, const float* means3D, const float* shs,
+                               const float* colors_precomp, const float* opacities, const float* cov3D, int32_t* radii,
+                               void* state, size_t state_bytes, void* scratch, size_t scratch_bytes, int64_t cap_pairs,
+                               float* out_color, int64_t* status_host, int status_words, uint32_t* tile_walk, void* stream) {
   RK k;
   int rc = make_rk(cfg, m, k);
   if (rc) return rc;
   NM_REQUIRE(K >= 0 && cap_pairs >= 0 && out_color && state, "bad arguments");
+  k.K = K;
   NM_REQUIRE(K == 0 || (shs != nullptr) != (colors_precomp != nullptr), "provide exactly one of shs / colors_precomp");
   NM_REQUIRE(!shs || m >= (cfg->sh_degree + 1) * (cfg->sh_degree + 1), "shs has too few coefficients for sh_degree");
   NM_REQUIRE(K == 0 || (means3D && opacities && cov3D && radii), "null pointer");
-  State t = carve_state(state, k.W, k.H, K, cap_pairs);
-  if (state_bytes < t.total) { nm_set_error("raster state buffer too small: need %zu got %zu", t.total, state_bytes); return NM_ERR_WORKSPACE; }
+  State t = carve_state(state, scratch, k.W, k.H, K, cap_pairs, k.items);
+  {
+    const size_t need = scratch ? t.total : t.total + t.scratch_total;
+    if (state_bytes < need) { nm_set_error("raster state buffer too small: need %zu got %zu", need, state_bytes); return NM_ERR_WORKSPACE; }
+    if (scratch && scratch_bytes < t.scratch_total) {
+      nm_set_error("raster scratch buffer too small: need %zu got %zu", t.scratch_total, scratch_bytes);
+      return NM_ERR_WORKSPACE;
+    }
+  }
   hipStream_t s = (hipStream_t)stream;
   const int nrange = nm_div_up(K, 256);
   NM_HIP_CHECK(hipMemsetAsync(t.hdr, 0, 256, s));
   NM_HIP_CHECK(hipMemsetAsync(t.pad, 0, (size_t)t.ncell * NM_PAD * sizeof(uint32_t), s));
   if (K > 0) {
     NM_LAUNCH(k_preprocess, dim3(nrange), dim3(256), 0, s, k, K, means3D, shs, colors_precomp, opacities, cov3D, radii,
-              t.xy, t.depth, t.conop, t.rgb, t.clamped, t.rad, t.zrange);
+              t.xy, t.depth, t.conop, t.rgb, t.clamped, t.rad, t.zrange, t.recs);
     NM_LAUNCH_CHECK();
     NM_LAUNCH(k_bin_count, dim3(nrange), dim3(256), 0, s, k, K, t.nbx, (const int*)t.rad, t.xy, t.depth, t.conop, t.zrange, nrange,
               t.pad, t.log, t.hdr, (long long)cap_pairs);
@@ -1528,29 +1840,42 @@ extern "C" int nm_raster_forward(const nm_raster_cfg* cfg, int32_t K, int32_t m,
   NM_LAUNCH(k_split_plan, dim3(1), dim3(1024), 0, s, k, t.nbx, (uint32_t)g_split_busy, (uint32_t)g_split_minseg,
             (unsigned long long)g_split_fwd,
             (const uint32_t*)t.off, (long long)cap_pairs, t.hdr, t.tile_rec,
-            t.tile_ns, t.tile_cnt, t.tile_mode, t.work, t.seg_pos);
+            t.tile_ns, t.tile_cnt, t.tile_mode, t.work, t.seg_pos, (const uint32_t*)tile_walk, (uint32_t)g_hint_fwd, (uint32_t)g_hint_seg);
   NM_LAUNCH_CHECK();
+  if (tile_walk) {
+    NM_LAUNCH(k_hint_fill, dim3(nm_div_up(k.gx * (k.ty1 - k.ty0), 4)), dim3(256), 0, s, k, t.nbx, (const uint32_t*)t.off,
+              (long long)cap_pairs, (const uint32_t*)t.hdr, (const uint32_t*)t.tile_rec, (const uint32_t*)t.tile_ns,
+              (const uint32_t*)t.tile_cnt, t.work, t.seg_pos);
+    NM_LAUNCH_CHECK();
+  }
   const int ntile = k.gx * (k.ty1 - k.ty0);
   // stage 0: whole tiles + first segments of the candidates (which decide how their tile goes on); stage 1: other segments
   // of the tiles that are split.  A view without candidates has no work items and those workgroups leave at once.
   for (int stage = 0; stage < 2; ++stage) {
-    NM_LAUNCH(k_render, dim3((stage == 0 ? ntile : 0) + NM_SPLIT_WORK), dim3(NM_TPB), 0, s, k, t.nbx, stage, stage == 0 ? ntile : 0,
+    NM_LAUNCH(k_render, dim3((stage == 0 ? ntile : 0) + t.items), dim3(NM_TPB), 0, s, k, t.nbx, stage, stage == 0 ? ntile : 0,
               t.tile_mode, (const uint32_t*)t.tile_rec, (const uint32_t*)t.tile_ns, (const uint32_t*)t.off,
               (const unsigned long long*)t.keys, (const uint32_t*)t.vals, (long long)cap_pairs, (const uint32_t*)t.hdr,
-              (const uint2*)t.work, t.seg_raw, t.seg_last, t.seg_ct, t.seg_pos, t.xy, t.rgb, t.conop, t.final_T, t.n_contrib,
-              out_color);
+              (const uint2*)t.work, t.seg_raw, t.seg_last, t.seg_ct, t.seg_pos, (const GRec*)t.recs, t.final_T, t.n_contrib,
+              out_color, tile_walk);
     NM_LAUNCH_CHECK();
   }
-  NM_LAUNCH(k_render_fix, dim3(NM_SPLIT_WORK), dim3(NM_TPB), 0, s, k, t.nbx, (const uint32_t*)t.off, (const unsigned long long*)t.keys,
+  NM_LAUNCH(k_render_fix, dim3(t.items), dim3(NM_TPB), 0, s, k, t.nbx, (const uint32_t*)t.off, (const unsigned long long*)t.keys,
             (const uint32_t*)t.vals, (long long)cap_pairs, (const uint32_t*)t.hdr, (const uint32_t*)t.tile_rec,
             (const uint32_t*)t.tile_ns, t.tile_cnt, (const uint32_t*)t.tile_mode, (const uint2*)t.work, (const float4*)t.seg_raw,
-            t.seg_fix, t.seg_ct, t.seg_last, t.xy, t.rgb, t.conop, t.final_T, t.n_contrib, out_color);
+            t.seg_fix, t.seg_ct, t.seg_last, t.seg_pos, (const GRec*)t.recs, t.final_T, t.n_contrib, out_color,
+            tile_walk);
+  NM_LAUNCH_CHECK();
+  NM_LAUNCH(k_render_sum, dim3(ntile), dim3(NM_TPB), 0, s, k, t.nbx, (const uint32_t*)t.off, (const unsigned long long*)t.keys,
+            (const uint32_t*)t.vals, (long long)cap_pairs, (const uint32_t*)t.hdr, (const uint32_t*)t.tile_rec,
+            (const uint32_t*)t.tile_ns, (const uint32_t*)t.tile_mode, (const float4*)t.seg_fix, t.seg_ct,
+            (const uint32_t*)t.seg_last, t.seg_pos, (const GRec*)t.recs, t.final_T, t.n_contrib, out_color, tile_walk);
   NM_LAUNCH_CHECK();
   if (status_host) {
     // hdr[2], hdr[3] are 32-bit: widen on the host side of the copy (4-byte copies into the low halves; the caller zeroes the buffer)
     NM_HIP_CHECK(hipMemcpyAsync(status_host, t.hdr + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     NM_HIP_CHECK(hipMemcpyAsync(status_host + 1, t.hdr + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     if (getenv("NM_RASTER_DEBUG")) NM_HIP_CHECK(hipMemcpyAsync((char*)(status_host + 1) + 4, t.hdr + 6, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (status_words >= 3) NM_HIP_CHECK(hipMemcpyAsync(status_host + 2, t.hdr + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   }
   return NM_OK;
 }
@@ -1563,7 +1888,7 @@ extern "C" int nm_raster_count_pairs(const nm_raster_cfg* cfg, int32_t K, void* 
   int rc = make_rk(cfg, 0, k);
   if (rc) return rc;
   NM_REQUIRE(K >= 0 && state && pairs_out, "bad arguments");
-  State t = carve_state(state, k.W, k.H, K, cap_pairs);
+  State t = carve_state(state, nullptr, k.W, k.H, K, cap_pairs, k.items);
   hipStream_t s = (hipStream_t)stream;
   unsigned long long* total = (unsigned long long*)(t.hdr + 4);
   NM_HIP_CHECK(hipMemsetAsync(total, 0, sizeof(unsigned long long), s));
@@ -1584,9 +1909,24 @@ extern "C" int nm_debug_raster_cells(const nm_raster_cfg* cfg, int32_t K, void* 
   RK k;
   int rc = make_rk(cfg, 0, k);
   if (rc) return rc;
-  State t = carve_state(state, k.W, k.H, K, cap_pairs);
+  State t = carve_state(state, nullptr, k.W, k.H, K, cap_pairs, k.items);
   *ncell_out = t.ncell;
   NM_HIP_CHECK(hipMemcpyAsync(counts_host, t.cnt, sizeof(uint32_t) * (size_t)(t.ncell < max_cells ? t.ncell : max_cells), hipMemcpyDeviceToHost,
+                              (hipStream_t)stream));
+  NM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  return NM_OK;
+}
+
+// debugging aid: copies the per-pixel last-contributor positions (W*H) and the cell offsets (ncell+1) of `state` to host memory
+extern "C" int nm_debug_raster_tiles(const nm_raster_cfg* cfg, int32_t K, void* state, int64_t cap_pairs, uint32_t* n_contrib_host,
+                                     uint32_t* off_host, int32_t max_cells, int32_t* ncell_out, void* stream) {
+  RK k;
+  int rc = make_rk(cfg, 0, k);
+  if (rc) return rc;
+  State t = carve_state(state, nullptr, k.W, k.H, K, cap_pairs, k.items);
+  *ncell_out = t.ncell;
+  NM_HIP_CHECK(hipMemcpyAsync(n_contrib_host, t.n_contrib, sizeof(uint32_t) * (size_t)k.W * k.H, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  NM_HIP_CHECK(hipMemcpyAsync(off_host, t.off, sizeof(uint32_t) * (size_t)((t.ncell < max_cells ? t.ncell : max_cells) + 1), hipMemcpyDeviceToHost,
                               (hipStream_t)stream));
   NM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
   return NM_OK;
@@ -1605,23 +1945,24 @@ extern "C" int nm_raster_backward(const nm_raster_cfg* cfg, int32_t K, int32_t m
   if (rc) return rc;
   NM_REQUIRE(K >= 0 && cap_pairs >= 0, "bad arguments");
   if (K == 0) return NM_OK;
+  k.K = K;
   NM_REQUIRE(means3D && cov3D && state && dL_dcolor && dL_dmeans3D && workspace, "null pointer");
   if (workspace_bytes < nm_raster_bwd_workspace(K)) { nm_set_error("raster backward workspace too small"); return NM_ERR_WORKSPACE; }
   hipStream_t s = (hipStream_t)stream;
-  State t = carve_state((void*)state, k.W, k.H, K, cap_pairs);
+  State t = carve_state((void*)state, nullptr, k.W, k.H, K, cap_pairs, k.items);
   float* acc = (float*)workspace;
   NM_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)K * NM_NG * sizeof(float), s));
   const int ntile = k.gx * (k.ty1 - k.ty0);
   if (dL_dopacity)
-    NM_LAUNCH(k_render_bwd<true>, dim3(ntile + NM_SPLIT_WORK), dim3(NM_TPB), 0, s, k, t.nbx, ntile, (const uint32_t*)t.off,
+    NM_LAUNCH(k_render_bwd<true>, dim3(ntile + t.items), dim3(NM_TPB), 0, s, k, t.nbx, ntile, (const uint32_t*)t.off,
               (const unsigned long long*)t.keys, (const uint32_t*)t.vals, (const uint32_t*)t.hdr, (const uint32_t*)t.tile_rec,
-              (const uint32_t*)t.tile_ns, (const uint2*)t.work, (const float4*)t.seg_ct, (const uint32_t*)t.seg_pos, t.xy, t.rgb,
-              t.conop, t.final_T, t.n_contrib, dL_dcolor, acc);
+              (const uint32_t*)t.tile_ns, (const uint2*)t.work, (const float4*)t.seg_ct, (const uint32_t*)t.seg_pos, (const GRec*)t.recs,
+              t.final_T, t.n_contrib, dL_dcolor, acc);
   else
-    NM_LAUNCH(k_render_bwd<false>, dim3(ntile + NM_SPLIT_WORK), dim3(NM_TPB), 0, s, k, t.nbx, ntile, (const uint32_t*)t.off,
+    NM_LAUNCH(k_render_bwd<false>, dim3(ntile + t.items), dim3(NM_TPB), 0, s, k, t.nbx, ntile, (const uint32_t*)t.off,
               (const unsigned long long*)t.keys, (const uint32_t*)t.vals, (const uint32_t*)t.hdr, (const uint32_t*)t.tile_rec,
-              (const uint32_t*)t.tile_ns, (const uint2*)t.work, (const float4*)t.seg_ct, (const uint32_t*)t.seg_pos, t.xy, t.rgb,
-              t.conop, t.final_T, t.n_contrib, dL_dcolor, acc);
+              (const uint32_t*)t.tile_ns, (const uint2*)t.work, (const float4*)t.seg_ct, (const uint32_t*)t.seg_pos, (const GRec*)t.recs,
+              t.final_T, t.n_contrib, dL_dcolor, acc);
   NM_LAUNCH_CHECK();
   NM_LAUNCH(k_preprocess_bwd, dim3(nm_div_up(K, 256)), dim3(256), 0, s, k, K, means3D, shs, cov3D, (const int*)t.rad, t.clamped, acc,
             dL_dmeans3D, dL_dmeans2D, dL_dcov3D, dL_dopacity, dL_dshs, dL_dcolors, shs ? 1 : 0);

@@ -42,7 +42,10 @@ def parse_args(argv=None):
 
 
 def save_image(img: torch.Tensor, path) -> None:
-    """torchvision.utils.save_image for one (3,H,W) image in [0,1]."""
+    """torchvision.utils.save_image for one (3,H,W) image in [0,1].  No image leaves the GPU unchecked: a render whose bin lists
+    overflowed (incomplete image) raises here (render.flush_pending)."""
+    from .render import flush_pending
+    flush_pending()
     from PIL import Image
     a = (img.detach().clamp(0, 1) * 255 + 0.5).to(torch.uint8).permute(1, 2, 0).cpu().numpy()
     Image.fromarray(a, "RGB").save(path)

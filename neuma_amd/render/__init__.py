@@ -8,6 +8,7 @@
 """
 import ctypes as C
 import math
+import os
 from typing import NamedTuple, Optional, Tuple
 
 import torch
@@ -53,6 +54,19 @@ class RasterCamera(object):
         self.tile_rows = tile_rows
         self.cfg = _c_cfg(settings, tile_rows)
         self.bins = BinCapacity()
+        self._walk = {}          # device -> per-tile walk record of the previous render (nm_raster_forward_ex)
+
+    def tile_walk(self, device) -> Optional[Tensor]:
+        """Per-tile walk record of this camera on `device` (int32 storage of the C ABI's uint32 array), created zeroed on
+        first use.  NEUMA_RASTER_HINT=0 switches the hinted split compositing off (every render planned from scratch)."""
+        if os.environ.get("NEUMA_RASTER_HINT", "1") == "0":
+            return None
+        key = torch.device(device)
+        w = self._walk.get(key)
+        if w is None:
+            gx, gy = (self.cfg.image_width + 15) // 16, (self.cfg.image_height + 15) // 16
+            w = self._walk[key] = torch.zeros(gx * gy, dtype=torch.int32, device=key)
+        return w
 
 
 def build_cov3D(scales: Tensor, rotations: Tensor, scale_modifier: float = 1.0) -> Tensor:
@@ -79,31 +93,76 @@ def _raster_inputs(means3D, shs, colors_precomp, opacities, cov3D):
 
 
 class BinCapacity(object):
-    """Capacity policy of the depth-sorted bin lists of one camera (nm_raster_forward's cap_pairs).  The first render with a
-    camera is checked synchronously (and repeated with a larger state buffer if it overflowed); afterwards the capacity is
-    twice the last observed number of pairs and the status of every render is read back asynchronously and examined at the
-    next call - an overflow that slipped through (the scene suddenly needs > 2x the pairs) raises instead of returning a
-    truncated image silently."""
+    """Capacity policy of one camera's rasterizer state: `cap` = (Gaussian, bin) pairs of the depth-sorted bin lists
+    (nm_raster_forward's cap_pairs), `items` = work items of the split compositing (nm_raster_cfg.split_items).  The first
+    render with a camera is checked synchronously (and repeated with a larger state buffer if it overflowed); afterwards the
+    pair capacity is twice the last observed number of pairs and the status of every render is read back asynchronously.
+    An overflow that slipped through (the scene suddenly needs > 2x the pairs) is never silent: the render's own backward
+    pass checks the status before it produces gradients, the next forward with any camera and `flush_pending()` (what
+    evaluate / the trainers call at the end of a frame) check it too, and all of them raise."""
 
     def __init__(self):
         self.cap = 0              # 0: not sized yet (first guess 8 K + 4096)
+        self.items = 0            # 0: the library's default (8192)
         self.verified = False     # a synchronously checked render has completed within `cap`
-        self.pending = None       # (pinned status tensor, event) of the last unchecked render
 
-    def check_pending(self):
-        if self.pending is None:
-            return
-        status, ev = self.pending
-        self.pending = None
-        ev.synchronize()
-        pairs, overflow = int(status[0]), int(status[1])
-        self.observe(pairs)
-        if overflow:
-            raise L.NeumaHipError(f"rasterizer bin lists overflowed in the previous render ({pairs} pairs > capacity): the image "
-                                  "was incomplete; the capacity has been raised, repeat the step")
-
-    def observe(self, pairs: int):
+    def observe(self, pairs: int, items_wanted: int = 0):
         self.cap = max(self.cap, 2 * pairs + 4096)
+        # work items: 1.5 x what the plan asked for, in steps of 1024 (too few only costs time: the other tiles go whole)
+        want = min(32768, max(1024, (3 * items_wanted // 2 + 1023) // 1024 * 1024))
+        if self.items == 0 or want > self.items or 2 * want < self.items:
+            self.items = want
+
+
+class _Pending(object):
+    """Status words of renders that have been enqueued but not looked at yet (pinned memory + an event each)."""
+
+    def __init__(self):
+        self.entries = []
+
+    def add(self, bins: BinCapacity, status: Tensor, ev) -> "list":
+        entry = [bins, status, ev, False]
+        self.entries.append(entry)
+        return entry
+
+    @staticmethod
+    def examine(entry, wait: bool) -> bool:
+        """True once the entry has been looked at; raises if that render overflowed its lists."""
+        bins, status, ev, seen = entry
+        if seen:
+            return True
+        if not wait and not ev.query():
+            return False
+        ev.synchronize()
+        entry[3] = True
+        pairs, overflow, items = int(status[0]), int(status[1]) & 0xFFFFFFFF, int(status[2])     # (high half: NM_RASTER_DEBUG)
+        bins.observe(pairs, items)
+        if overflow:
+            raise L.NeumaHipError(f"rasterizer bin lists overflowed ({pairs} pairs > capacity): that render's image is incomplete; "
+                                  "the capacity has been raised, repeat the step")
+        return True
+
+    def drain(self, wait: bool, bins: Optional[BinCapacity] = None):
+        """Look at every entry that has finished (wait: at all of them; bins: and wait for that camera's)."""
+        keep, err = [], None
+        for e in self.entries:
+            try:
+                if not self.examine(e, wait or e[0] is bins):
+                    keep.append(e)
+            except L.NeumaHipError as ex:
+                err = err or ex
+        self.entries = keep
+        if err is not None:
+            raise err
+
+
+_PENDING = _Pending()
+
+
+def flush_pending():
+    """Wait for every render enqueued so far and raise if one of them overflowed its bin lists (its image is incomplete).
+    Call it where an image leaves the GPU without a backward pass behind it: at the end of an evaluation frame / epoch."""
+    _PENDING.drain(wait=True)
 
 
 class _RasterizeGaussians(autograd.Function):
@@ -113,39 +172,48 @@ class _RasterizeGaussians(autograd.Function):
         lib = L.lib()
         dev = means3D.device
         stream = L.stream_ptr(dev)
-        cfg = cam.cfg
         K = means3D.size(0)
         m3, sh, cp, op, cv = _raster_inputs(means3D, shs, colors_precomp, opacities, cov3D)
         M = 0 if sh is None else sh.size(1)
-        H, W = cfg.image_height, cfg.image_width
+        H, W = cam.cfg.image_height, cam.cfg.image_width
         bins = cam.bins
-        bins.check_pending()
+        # renders that have finished meanwhile, and this camera's previous one: sizes observed, overflows raised
+        _PENDING.drain(wait=False, bins=bins)
         first = not bins.verified
         if bins.cap == 0:
             bins.cap = 8 * K + 4096
         radii = torch.empty(K, dtype=torch.int32, device=dev)            # k_preprocess writes every entry
-        full = cfg.tile_y1 <= cfg.tile_y0 or (cfg.tile_y0 == 0 and cfg.tile_y1 * 16 >= H)
+        full = cam.cfg.tile_y1 <= cam.cfg.tile_y0 or (cam.cfg.tile_y0 == 0 and cam.cfg.tile_y1 * 16 >= H)
         # a full-image render writes every pixel; a stripe leaves the rows outside it untouched (zero)
         color = (torch.empty if full else torch.zeros)(3, H, W, dtype=torch.float32, device=dev)
         while True:
             cap = int(bins.cap)
-            state_bytes = int(lib.nm_raster_state_bytes(C.byref(cfg), K, cap))
-            state = torch.empty(state_bytes, dtype=torch.uint8, device=dev)
-            status = torch.zeros(2, dtype=torch.int64, pin_memory=True)
-            L.check(lib.nm_raster_forward(C.byref(cfg), K, M, L.ptr(m3), L.ptr(sh), L.ptr(cp), L.ptr(op), L.ptr(cv), L.ptr(radii),
-                                          L.ptr(state), state_bytes, cap, L.ptr(color), C.c_void_p(status.data_ptr()), stream),
-                    "nm_raster_forward")
+            cfg = L.nm_raster_cfg.from_buffer_copy(cam.cfg)      # this render's own copy: the item capacity may change later
+            cfg.split_items = int(bins.items)
+            nstate, nscratch = C.c_size_t(0), C.c_size_t(0)
+            L.check(lib.nm_raster_state_bytes_ex(C.byref(cfg), K, cap, C.byref(nstate), C.byref(nscratch)), "nm_raster_state_bytes_ex")
+            # kept for the backward pass: records, lists, checkpoints.  The forward-only part (pair log, counters, per-segment
+            # scratch: the larger half) goes back to the caching allocator when this function returns - stream-ordered, so
+            # the next render on this stream reuses it
+            state = torch.empty(int(nstate.value), dtype=torch.uint8, device=dev)
+            scratch = torch.empty(int(nscratch.value), dtype=torch.uint8, device=dev)
+            status = torch.zeros(3, dtype=torch.int64, pin_memory=True)
+            L.check(lib.nm_raster_forward_ex(C.byref(cfg), K, M, L.ptr(m3), L.ptr(sh), L.ptr(cp), L.ptr(op), L.ptr(cv), L.ptr(radii),
+                                             L.ptr(state), int(nstate.value), L.ptr(scratch), int(nscratch.value), cap, L.ptr(color),
+                                             C.c_void_p(status.data_ptr()), L.ptr(cam.tile_walk(dev)), stream),
+                    "nm_raster_forward_ex")
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))
             if not first:
-                bins.pending = (status, ev)
+                ctx.pending = _PENDING.add(bins, status, ev)
                 break
             ev.synchronize()                      # first render with this camera: size the lists from what the view needs
-            bins.observe(int(status[0]))
-            if not int(status[1]):
+            bins.observe(int(status[0]), int(status[2]))
+            if not (int(status[1]) & 0xFFFFFFFF):
                 bins.verified = True
+                ctx.pending = None
                 break
-        ctx.cam, ctx.K, ctx.M, ctx.cap = cam, K, M, cap
+        ctx.cfg, ctx.K, ctx.M, ctx.cap = cfg, K, M, cap
         ctx.has_sh = sh is not None
         ctx.save_for_backward(m3, sh if sh is not None else cp, op, cv, state)
         ctx.mark_non_differentiable(radii)
@@ -156,7 +224,9 @@ class _RasterizeGaussians(autograd.Function):
         lib = L.lib()
         m3, shcol, op, cv, state = ctx.saved_tensors
         dev = m3.device
-        cfg = ctx.cam.cfg
+        cfg = ctx.cfg
+        if ctx.pending is not None:
+            _Pending.examine(ctx.pending, wait=True)     # no gradients of an incomplete image (the forward finished long ago)
         K, M = ctx.K, ctx.M
         g = grad_color.float().contiguous()
         need = ctx.needs_input_grad  # means3D, means2D, shs, colors, opac, cov3D, cam
@@ -195,9 +265,10 @@ def count_tile_pairs(rasterizer, means3D, opacities, shs=None, colors_precomp=No
     return int(out.value)
 
 
-def split_plan(rasterizer, means3D, opacities, shs=None, colors_precomp=None, cov3D_precomp=None) -> Tuple[int, int]:
+def split_plan(rasterizer, means3D, opacities, shs=None, colors_precomp=None, cov3D_precomp=None, hinted: bool = False) -> Tuple[int, int]:
     """(work items, segment length) the split compositing chose for this view (nm_raster_set_split; 0 work items = every
-    tile composited by one workgroup).  Diagnostics: runs a forward pass into a scratch state and reads its header."""
+    tile composited by one workgroup).  hinted: plan from a copy of the camera's walk record, as its next render will
+    (nm_raster_forward_ex).  Diagnostics: runs a forward pass into a scratch state and reads its header."""
     lib = L.lib()
     cam = rasterizer._cam
     m3, sh, cp, op, cv = _raster_inputs(means3D, shs, colors_precomp, opacities, cov3D_precomp)
@@ -208,8 +279,11 @@ def split_plan(rasterizer, means3D, opacities, shs=None, colors_precomp=None, co
     state = torch.empty(state_bytes, dtype=torch.uint8, device=dev)
     radii = torch.empty(K, dtype=torch.int32, device=dev)
     color = torch.empty(3, cam.cfg.image_height, cam.cfg.image_width, dtype=torch.float32, device=dev)
-    L.check(lib.nm_raster_forward(C.byref(cam.cfg), K, M, L.ptr(m3), L.ptr(sh), L.ptr(cp), L.ptr(op), L.ptr(cv), L.ptr(radii),
-                                  L.ptr(state), state_bytes, cap, L.ptr(color), None, L.stream_ptr(dev)), "nm_raster_forward")
+    walk = cam.tile_walk(dev) if hinted else None
+    walk = None if walk is None else walk.clone()
+    L.check(lib.nm_raster_forward_ex(C.byref(cam.cfg), K, M, L.ptr(m3), L.ptr(sh), L.ptr(cp), L.ptr(op), L.ptr(cv), L.ptr(radii),
+                                     L.ptr(state), state_bytes, None, 0, cap, L.ptr(color), None, L.ptr(walk), L.stream_ptr(dev)),
+            "nm_raster_forward_ex")
     hdr = state[:64].view(torch.int32).cpu()
     return int(hdr[8]), int(hdr[9])
 

@@ -223,6 +223,19 @@ def test_raster_heavy_depth_cell_and_capacity_growth():
         rast2(means3D=means.to(dev()), means2D=None, opacities=op.to(dev()), colors_precomp=col.to(dev()), cov3D_precomp=cov.to(dev()))
     img3, _ = rast2(means3D=means.to(dev()), means2D=None, opacities=op.to(dev()), colors_precomp=col.to(dev()), cov3D_precomp=cov.to(dev()))
     assert torch.equal(img3, img.detach())
+    # ... nor used: the overflowing render's own backward pass refuses to produce gradients, and flush_pending() (what an
+    # evaluation loop calls before an image leaves the GPU) raises too
+    from neuma_amd.render import flush_pending
+    for how in ("backward", "flush"):
+        flush_pending()                 # (the previous render's status has been looked at: nothing re-grows the capacity below)
+        rast2._cam.bins.cap = 64
+        mm = means.to(dev()).requires_grad_(True)
+        bad, _ = rast2(means3D=mm, means2D=None, opacities=op.to(dev()), colors_precomp=col.to(dev()), cov3D_precomp=cov.to(dev()))
+        with pytest.raises(NeumaHipError):
+            bad.sum().backward() if how == "backward" else flush_pending()
+        flush_pending()                 # (nothing left behind)
+    img4, _ = rast2(means3D=means.to(dev()), means2D=None, opacities=op.to(dev()), colors_precomp=col.to(dev()), cov3D_precomp=cov.to(dev()))
+    assert torch.equal(img4, img.detach())
 
 
 @pytest.mark.parametrize("opaque", [False, True])
@@ -266,4 +279,61 @@ def test_raster_split_compositing_equals_whole_tile_compositing_and_the_oracle(o
     ograds = torch.autograd.grad((oimg * gw.double()).sum(), oins)
     assert abs_max(res["split16"][0], oimg) < 1e-3
     for nme, a, b, tol in zip(["means3D", "shs", "opacity", "cov3D"], res["split16"][1], ograds, [2e-3, 1e-3, 1e-3, 2e-3]):
+        assert rel_max(a, b) < tol, nme
+
+
+@pytest.mark.parametrize("fwd_len", [0, 96, 1 << 20])
+@pytest.mark.parametrize("opaque", [False, True])
+def test_raster_hinted_split_from_the_previous_render_of_the_camera(opaque, fwd_len):
+    """nm_raster_forward_ex: the second render with a camera is planned from the walk record the first one left (tiles cut
+    into segments composited in parallel, forward and reverse) - same image and gradients as the unhinted render and as the
+    oracle; a record that is stale (the Gaussians moved), far too short or far too long changes nothing but the plan.
+    fwd_len (nm_raster_set_hinted): 0 = every planned tile composited in parallel segments in the forward pass too, 2^20 = the
+    forward pass walks front to back and leaves checkpoints (only the reverse sweep runs in segments), 96 = both kinds."""
+    from neuma_amd import _lib
+    from neuma_amd.render import split_plan
+    lib = _lib.lib()
+    s, means, cov, op, shs, _, _ = _scene(deg=0, K=1500, scale=(0.04, 0.12))
+    if opaque:
+        op = torch.full_like(op, 0.97)
+    gw = torch.randn(3, s.image_height, s.image_width, generator=torch.Generator().manual_seed(6)).to(dev())
+
+    def render(rast, m):
+        ins = [t.to(dev()).requires_grad_(True) for t in (m, shs, op, cov)]
+        img, _ = rast(means3D=ins[0], means2D=None, opacities=ins[2], shs=ins[1], cov3D_precomp=ins[3])
+        grads = torch.autograd.grad((img * gw).sum(), ins)
+        return img.detach().clone(), [g.clone() for g in grads], ins
+
+    moved = means + 0.01 * torch.randn(means.shape, generator=torch.Generator().manual_seed(7))
+    try:
+        _lib.check(lib.nm_raster_set_split(0, 32, 1 << 21), "nm_raster_set_split")      # unhinted renders: whole tiles
+        _lib.check(lib.nm_raster_set_hinted(fwd_len, 32), "nm_raster_set_hinted")
+        ref, ref_moved = render(_gpu_raster(s), means), render(_gpu_raster(s), moved)
+        rast = _gpu_raster(s)
+        first = render(rast, means)                                    # no record yet: whole tiles, leaves the record
+        walk = rast._cam.tile_walk(dev())
+        assert int((walk > 0).sum()) > 20 and torch.equal(first[0], ref[0])
+        work, seg = split_plan(rast, first[2][0], first[2][2], shs=first[2][1], cov3D_precomp=first[2][3], hinted=True)
+        assert work > 100 and seg == 32, (work, seg)
+        cases = {"hinted": render(rast, means), "again": render(rast, means)}
+        cases["stale"] = render(rast, moved)
+        walk.fill_(20)
+        cases["short"] = render(rast, means)
+        walk.fill_(1 << 20)
+        cases["long"] = render(rast, means)
+        cases["after_long"] = render(rast, means)
+    finally:
+        _lib.check(lib.nm_raster_set_split(512, 512, 1 << 21), "nm_raster_set_split")
+        _lib.check(lib.nm_raster_set_hinted(0, 256), "nm_raster_set_hinted")
+    for name, (img, grads, _) in cases.items():
+        want = ref_moved if name == "stale" else ref
+        assert abs_max(img, want[0]) < 2e-6, name
+        for nme, a, b in zip(["means3D", "shs", "opacity", "cov3D"], grads, want[1]):
+            assert rel_max(a, b) < 2e-5, (name, nme)
+    oins = [t.double().requires_grad_(True) for t in (means, shs, op, cov)]
+    sd = orr.Settings(*[(f.double() if torch.is_tensor(f) else f) for f in s])
+    oimg, _ = orr.render(sd, oins[0], oins[3], oins[2], shs=oins[1])
+    ograds = torch.autograd.grad((oimg * gw.cpu().double()).sum(), oins)
+    assert abs_max(cases["hinted"][0], oimg) < 1e-3
+    for nme, a, b, tol in zip(["means3D", "shs", "opacity", "cov3D"], cases["hinted"][1], ograds, [2e-3, 1e-3, 1e-3, 2e-3]):
         assert rel_max(a, b) < tol, nme

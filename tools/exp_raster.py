@@ -53,11 +53,12 @@ b.record(); torch.cuda.synchronize()
 print(f"wall per render fwd+bwd (incl. torch glue): {1e3 * a.elapsed_time(b) / reps:.1f} us")
 os.environ["NM_RASTER_DEBUG"] = "1"
 cam = rt.cameras[0]._nm_raster_cache[1]._cam
-cam.bins.check_pending()
+from neuma_amd import render as _r
+_r.flush_pending()
 once(); torch.cuda.synchronize()
-st = cam.bins.pending[0]
-print("pairs binned", int(st[0]), " largest cell", int(st[1]) >> 32)
-cam.bins.pending = None
+st = _r._PENDING.entries[-1][1]
+print("pairs binned", int(st[0]), " largest cell", int(st[1]) >> 32, " work items wanted", int(st[2]), " capacity", cam.bins.items)
+_r._PENDING.entries.clear()
 
 # ---- cell size distribution
 import numpy as np
@@ -68,6 +69,7 @@ cov = deform_cov_by_F(rt._cov, dg)
 m3c, sh, cp, op, cv = _raster_inputs(m3, rt._shs, None, rt._opacity, cov)
 K = m3c.size(0)
 cap = 16 * K
+cfg = cam.cfg
 lib.nm_raster_state_bytes.restype = C.c_size_t
 sb = int(lib.nm_raster_state_bytes(C.byref(cfg), K, cap))
 state = torch.empty(sb, dtype=torch.uint8, device=dev)
