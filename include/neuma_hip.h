@@ -142,6 +142,9 @@ int nm_mpm_forward_extra(nm_mpm* h, int32_t n, const nm_statics* st, const nm_pa
  * all-reduce has a fixed size and needs no host synchronisation. */
 int nm_mpm_p2g(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, void* stream);
 int nm_mpm_active_list(nm_mpm* h, int32_t* out, int32_t cap, void* stream);
+/* The same for the 27-neighbourhood (in blocks) of the rank's touched blocks: what the sharded roll-out announces once per
+ * frame (nm_rollout_forward_sharded).  Exported so that the caller can size `cap` / `cap_shared` from a probe. */
+int nm_mpm_dilated_list(nm_mpm* h, int32_t* out, int32_t cap, void* stream);
 size_t nm_mpm_shared_workspace(int32_t world, int32_t cap);
 int nm_mpm_shared_blocks(nm_mpm* h, const int32_t* gathered, int32_t world, int32_t cap, int32_t* shared,
                          int32_t cap_shared, int32_t* status, void* workspace, size_t workspace_bytes, void* stream);

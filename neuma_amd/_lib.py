@@ -79,6 +79,7 @@ SIGNATURES = {
                                        C.POINTER(nm_statics), C.POINTER(nm_particles), _P]),
     "nm_mpm_p2g": (C.c_int, [_P, _I32, C.POINTER(nm_statics), C.POINTER(nm_particles), _P]),
     "nm_mpm_active_list": (C.c_int, [_P, _P, _I32, _P]),
+    "nm_mpm_dilated_list": (C.c_int, [_P, _P, _I32, _P]),
     "nm_mpm_shared_workspace": (_SZ, [_I32, _I32]),
     "nm_mpm_shared_blocks": (C.c_int, [_P, _P, _I32, _I32, _P, _I32, _P, _P, _SZ, _P]),
     "nm_mpm_blocks_pack": (C.c_int, [_P, _I32, _P, _I32, _P, _P]),

@@ -56,7 +56,15 @@ struct nm_mpm_view {   // what nm_shard.hip needs to see of a grid handle (valid
   int epoch, nblocks;
 };
 nm_mpm_view nm_mpm_get_view(nm_mpm* h);
-int nm_mpm_shared_counters(nm_mpm* h, int** cnt, int** pos);   // [nblocks] each: 0 / INT_MAX between exchanges
+void nm_mpm_set_fresh_rows(nm_mpm* h, int on);   // g2p writes a fresh state's rows for disabled particles (roll-out checkpoints)
+int nm_mpm_shared_counters(nm_mpm* h, int** cnt, int** pos);
+int nm_mpm_xchg_arrays(nm_mpm* h, int** slot, int** dil, int* new_tag);   // frame-level exchange: slot[] (-1 between frames), dil[]
+int nm_mpm_grid_dims(const nm_mpm* h);                                    // blocks per axis
+int nm_mpm_dil_tag(const nm_mpm* h);
+int nm_shard_slots(nm_mpm* h, const int32_t* shared, int32_t cap_shared, int assign, void* stream);
+int nm_shard_pack_fwd(nm_mpm* h, const int32_t* shared, int32_t cap_shared, float* buf, unsigned char* mine, int32_t* status,
+                      void* stream);
+int nm_shard_pack_bwd(nm_mpm* h, const int32_t* shared, int32_t cap_shared, float* buf, const unsigned char* mine, void* stream);   // [nblocks] each: 0 / INT_MAX between exchanges
 int nm_material_prepare(const nm_mlp* w, float* wperm, void* stream);   // weights -> MFMA operand order, once per roll-out
 size_t nm_material_prepared_floats();
 int nm_material_wgrad_reduce(const float* wpart, int32_t n, float* gw0, float* gw1, float* gw2, int accumulate, void* stream);

@@ -308,6 +308,15 @@ int nm_mpm_forward_prepared(nm_mpm* h, int32_t n, const nm_statics* st, const nm
 int nm_mpm_backward_cached(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, const nm_particles* next,
                            const nm_particles* gnext, nm_particles* gcur, const void* gridrec, int32_t cap_blocks, bool verified,
                            bool prepared, const void* stamp_rec, void* stream);
+// sharded roll-out: the same launches with the exchange of the shared blocks in between (nm_shard.hip / nm_rollout.hip)
+int nm_mpm_backward_cached_begin(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, const nm_particles* next,
+                                 const nm_particles* gnext, nm_particles* gcur, const void* gridrec, int32_t cap_blocks,
+                                 bool verified, bool prepared, void* stream);
+int nm_mpm_backward_cached_finish(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, nm_particles* gcur,
+                                  const void* stamp_rec, int32_t cap_blocks, const float* xbuf, void* stream);
+int nm_mpm_forward_prepared_p2g(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, void* stream);
+int nm_mpm_forward_gridop_x(nm_mpm* h, void* gridrec, int32_t cap_blocks, int32_t* status, const float* xbuf, void* stream);
+int nm_mpm_clear_only(nm_mpm* h, void* stream);
 // pro: grid housekeeping performed in the kernel's prologue (NULL = none)
 int nm_material_bwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* wperm,
                            const float* gout, float* gF, float* wpart, int wmode, const float* trial_C, const int* enabled,

@@ -516,7 +516,8 @@ __global__ void __launch_bounds__(256) k_material_fwd(int n, int q, float alpha,
     const int ntile = (min(64, pend - c0) + 15) >> 4;
     M3 Fp = m3_ident();
     if (gf.gv) {     // roll-out: this kernel performs the substep's g2p and takes the trial F straight from it
-      if (valid) g2p_particle<true>(gf.K, p, gf.clip, gf.enabled, gf.x, gf.v, gf.C, gf.F, gf.gv, gf.xn, gf.vn, gf.Cn, Fp);
+      // (a disabled particle's row of the checkpoint gets a fresh state's values, nm_grid.h: Fp = I goes through the net)
+      if (valid) g2p_particle<true>(gf.K, p, gf.clip, gf.enabled, gf.x, gf.v, gf.C, gf.F, gf.gv, gf.xn, gf.vn, gf.Cn, Fp, nullptr, 0, true);
     } else if (valid) {
       Fp = m3_load(F + 9 * p);
     }
@@ -716,9 +717,10 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
     // computation waited for all of it: +6 k cycles per round).  Tile ct + 1's record is requested during tile ct.
     f4 nx[ACT ? NM_ACT_SLOTS : 1];
     const f4* act_tile = ACT ? a.act + (size_t)(c0 >> 4) * NM_ACT_SLOTS * 64 + lane : nullptr;
-    M3 Fp = valid ? m3_load(F + 9 * p) : m3_ident();
-    M3 go = valid ? m3_load(gout + 9 * p) : m3_zero();
     const bool trial = fz.trial_C && valid && fz.enabled[p] != 0;
+    // roll-out: the forward pass fed the plasticity net I for a disabled particle (the fresh state of its next row, nm_grid.h)
+    M3 Fp = (valid && (trial || !fz.trial_C)) ? m3_load(F + 9 * p) : m3_ident();
+    M3 go = valid ? m3_load(gout + 9 * p) : m3_zero();
     M3 T = trial ? m3_load(fz.trial_C + 9 * p) : m3_zero();
     M3 R, U, V;
     float z[13], s[3];

@@ -42,6 +42,9 @@ struct nm_mpm {
   int epoch;
   int* sh_cnt;    // sharded runs only (nm_shard.hip): per-block rank counter / first position, allocated on first use
   int* sh_pos;
+  int* sh_slot;   // per block: slot of the block in the frame's exchange buffer, -1 = none (nm_mpm_xchg_arrays)
+  int* sh_dil;    // per block: tag of the last frame whose negotiated neighbourhood holds the block
+  int dil_tag;
   int fresh_rows; // g2p writes a fresh state's values into the rows of disabled particles (roll-out checkpoints, nm_grid.h)
 };
 void nm_mpm_set_fresh_rows(nm_mpm* h, int on) { h->fresh_rows = on; }
@@ -585,7 +588,10 @@ static inline GridRec gridrec_at(void* base, int cap) {
 // mpm.py:373-429 on the active blocks only; optionally saves the pre-grid-op node values into a cache record
 __global__ void __launch_bounds__(256) k_grid_op(MpmK K, const float4* __restrict__ gm, float4* __restrict__ gv,
                                                  const int* __restrict__ list, const int* __restrict__ count, GridRec rec,
-                                                 int cap, const int* __restrict__ skip_hdr, int* __restrict__ status) {
+                                                 int cap, const int* __restrict__ skip_hdr, int* __restrict__ status,
+                                                 const int* __restrict__ slot, const float4* __restrict__ xbuf) {
+  // slot / xbuf (sharded roll-out): a block with slot[b] >= 0 takes its {mv, m} - summed over the ranks - from the exchange
+  // buffer instead of this rank's grid (the unpack step of the exchange, fused)
   if (skip_hdr && *skip_hdr >= 0) return;
   const int cnt = *count;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -599,7 +605,8 @@ __global__ void __launch_bounds__(256) k_grid_op(MpmK K, const float4* __restric
     int i, j, k;
     block_coords(b, K.nb, lane, i, j, k);
     int node = (b << 6) + lane;
-    float4 a = gm[node];
+    const int sl = slot ? slot[b] : -1;
+    float4 a = sl >= 0 ? xbuf[(sl << 6) + lane] : gm[node];
     float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < K.G && j < K.G && k < K.G) {
       float u[3], mk[3];
@@ -624,7 +631,8 @@ __global__ void __launch_bounds__(256) k_grid_restore(MpmK K, GridRec rec, float
 // epoch its restore will run under, which is what lets that restore share one pass with the clear (GridPrologue mode 2)
 __global__ void __launch_bounds__(256) k_grid_op_bwd(MpmK K, const float4* __restrict__ gm, float4* __restrict__ gg,
                                                      const int* __restrict__ list, const int* __restrict__ count,
-                                                     GridRec stamp, int stamp_epoch, int* __restrict__ flags) {
+                                                     GridRec stamp, int stamp_epoch, int* __restrict__ flags,
+                                                     const int* __restrict__ slot, const float4* __restrict__ xbuf) {
   const int cnt = *count;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (stamp.hdr) {
@@ -642,7 +650,8 @@ __global__ void __launch_bounds__(256) k_grid_op_bwd(MpmK K, const float4* __res
       if (a.w > 0.f) {
         float u[3], mk[3];
         grid_velocity(K, i, j, k, a, u, mk);
-        float4 gb = gg[node];
+        const int sl = slot ? slot[b] : -1;
+        float4 gb = sl >= 0 ? xbuf[(sl << 6) + lane] : gg[node];     // (summed over the ranks)
         float inv = 1.f / (a.w + K.eps);
         float ux = gb.x * mk[0], uy = gb.y * mk[1], uz = gb.z * mk[2];
         out.x = ux * inv; out.y = uy * inv; out.z = uz * inv;
@@ -953,6 +962,8 @@ extern "C" int nm_mpm_destroy(nm_mpm* h) {
   hipFree(h->list[0]); hipFree(h->list[1]); hipFree(h->list[2]); hipFree(h->count);
   if (h->sh_cnt) hipFree(h->sh_cnt);
   if (h->sh_pos) hipFree(h->sh_pos);
+  if (h->sh_slot) hipFree(h->sh_slot);
+  if (h->sh_dil) hipFree(h->sh_dil);
   delete h;
   return NM_OK;
 }
@@ -995,7 +1006,7 @@ static int mpm_build_grid(nm_mpm* h, int n, const nm_statics* st, const nm_parti
     NM_LAUNCH_CHECK();
   }
   NM_LAUNCH(k_grid_op, dim3(kSweepGrid), dim3(256), 0, s, h->k, h->gm, h->gv, h->list[now], h->count + now, srec, cap, skip,
-            (int*)nullptr);
+            (int*)nullptr, (const int*)nullptr, (const float4*)nullptr);
   NM_LAUNCH_CHECK();
   return NM_OK;
 }
@@ -1117,38 +1128,112 @@ extern "C" int nm_mpm_backward_ex(nm_mpm* h, int32_t n, const nm_statics* st, co
 // verified: the host has seen the record's header (valid) - no fall-back launches.  prepared: a GridPrologue
 // (nm_mpm_prologue_backward) restored the grid in the kernel launched just before.  stamp_rec: record of the substep the
 // sweep visits next; its blocks get flagged for that substep's prologue.
-int nm_mpm_backward_cached(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, const nm_particles* next,
-                           const nm_particles* gnext, nm_particles* gcur, const void* gridrec, int32_t cap_blocks, bool verified,
-                           bool prepared, const void* stamp_rec, void* stream) {
+int nm_mpm_backward_cached_begin(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, const nm_particles* next,
+                                 const nm_particles* gnext, nm_particles* gcur, const void* gridrec, int32_t cap_blocks,
+                                 bool verified, bool prepared, void* stream) {
   NM_REQUIRE(h, "null handle");
   NM_REQUIRE(!gridrec || cap_blocks > 0, "grid cache record without capacity");
   NM_REQUIRE(n >= 0, "negative particle count");
-  if (n == 0) return NM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) {      // (a rank without particles of a sharded roll-out: an empty grid, but the lists still rotate)
+    if (!prepared) return mpm_build_grid(h, 0, st, cur, s, nullptr, gridrec, cap_blocks, verified && gridrec != nullptr);
+    return NM_OK;
+  }
   int rc = check_particles(st, cur, true);
   if (rc) return rc;
   NM_REQUIRE(next && next->v && next->C, "next state (v, C) required");
   NM_REQUIRE(gnext && gnext->x && gnext->v && gnext->C && gnext->F, "null incoming gradients");
   NM_REQUIRE(gcur && gcur->x && gcur->v && gcur->C && gcur->F && gcur->stress, "null outgoing gradients");
-  hipStream_t s = (hipStream_t)stream;
   if (!prepared) {
     rc = mpm_build_grid(h, n, st, cur, s, nullptr, gridrec, cap_blocks, verified && gridrec != nullptr);  // recompute (mpm.py:312-315) or restore
     if (rc) return rc;
   }
-  const int now = h->cur;
-  const int nwg = nm_div_up(n, 256);
   NM_LAUNCH(k_g2p_bwd, dim3(nm_div_up(n, NM_SC_T)), dim3(NM_SC_T), 0, s, h->k, n, st->clip_bound, st->enabled, cur->x, cur->F, next->v,
                      next->C, gnext->x, gnext->v, gnext->C, gnext->F, h->gv, h->gg, gcur->x, gcur->F);
   NM_LAUNCH_CHECK();
+  return NM_OK;
+}
+// xbuf != NULL (sharded roll-out): the node-velocity adjoint of the blocks with an exchange slot comes, summed over the
+// ranks, from there
+int nm_mpm_backward_cached_finish(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, nm_particles* gcur,
+                                  const void* stamp_rec, int32_t cap_blocks, const float* xbuf, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int now = h->cur;
   GridRec stamp = {nullptr, nullptr, nullptr};
   if (stamp_rec) stamp = gridrec_at(const_cast<void*>(stamp_rec), cap_blocks);
   NM_LAUNCH(k_grid_op_bwd, dim3(kSweepGrid), dim3(256), 0, s, h->k, h->gm, h->gg, h->list[now], h->count + now, stamp,
-                     h->epoch + 1, h->flags);
+                     h->epoch + 1, h->flags, (const int*)(xbuf ? h->sh_slot : nullptr), (const float4*)xbuf);
   NM_LAUNCH_CHECK();
-  NM_LAUNCH(k_p2g_bwd, dim3(nwg), dim3(256), 0, s, h->k, n, st->vol, st->rho, st->enabled, cur->x, cur->v, cur->C,
+  if (n == 0) return NM_OK;
+  NM_LAUNCH(k_p2g_bwd, dim3(nm_div_up(n, 256)), dim3(256), 0, s, h->k, n, st->vol, st->rho, st->enabled, cur->x, cur->v, cur->C,
                      cur->stress, h->gg, gcur->x, gcur->v, gcur->C, gcur->stress);
   NM_LAUNCH_CHECK();
   return NM_OK;
 }
+int nm_mpm_backward_cached(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, const nm_particles* next,
+                           const nm_particles* gnext, nm_particles* gcur, const void* gridrec, int32_t cap_blocks, bool verified,
+                           bool prepared, const void* stamp_rec, void* stream) {
+  if (n == 0) return NM_OK;
+  int rc = nm_mpm_backward_cached_begin(h, n, st, cur, next, gnext, gcur, gridrec, cap_blocks, verified, prepared, stream);
+  if (rc) return rc;
+  return nm_mpm_backward_cached_finish(h, n, st, cur, gcur, stamp_rec, cap_blocks, nullptr, stream);
+}
+
+// sharded roll-out, forward: this rank's scatter alone (the grid was cleared by a GridPrologue), then - after the exchange -
+// the grid update, which takes the blocks with an exchange slot from xbuf and writes the substep's cache record
+int nm_mpm_forward_prepared_p2g(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, void* stream) {
+  if (n == 0) return NM_OK;
+  int rc = check_particles(st, cur, true);
+  if (rc) return rc;
+  const int now = h->cur;
+  NM_LAUNCH(k_p2g, dim3(nm_div_up(n, NM_SC_T)), dim3(NM_SC_T), 0, (hipStream_t)stream, h->k, n, st->vol, st->rho, st->enabled, cur->x,
+                     cur->v, cur->C, cur->stress, h->gm, h->flags, h->list[now], h->count + now, h->epoch, (const int*)nullptr);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}
+int nm_mpm_forward_gridop_x(nm_mpm* h, void* gridrec, int32_t cap_blocks, int32_t* status, const float* xbuf, void* stream) {
+  NM_REQUIRE(!gridrec || cap_blocks > 0, "grid cache record without capacity");
+  const int now = h->cur;
+  GridRec none = {nullptr, nullptr, nullptr};
+  NM_LAUNCH(k_grid_op, dim3(kSweepGrid), dim3(256), 0, (hipStream_t)stream, h->k, h->gm, h->gv, h->list[now], h->count + now,
+                     gridrec ? gridrec_at(gridrec, cap_blocks) : none, cap_blocks, (const int*)nullptr, (int*)status,
+                     (const int*)(xbuf ? h->sh_slot : nullptr), (const float4*)xbuf);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}
+// clear + rotate for a rank without particles (no constitutive kernel carries the prologue there)
+int nm_mpm_clear_only(nm_mpm* h, void* stream) {
+  int prev, now, next;
+  mpm_rotate(h, prev, now, next);
+  NM_LAUNCH(k_clear, dim3(NM_CLEAR_WGS), dim3(256), 0, (hipStream_t)stream, h->gm, h->gv, h->gg, h->list[prev], h->count + prev,
+                     h->list[now], h->count + now, h->count + next, h->flags, h->epoch);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}
+
+__global__ void k_fill_int(int* __restrict__ a, int n, int v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = v;
+}
+// per-block arrays of the frame-level exchange: slot[b] (-1 between frames) and dil[b] (tag of the last negotiation whose
+// neighbourhood holds b); *tag = a fresh tag for a new negotiation
+int nm_mpm_xchg_arrays(nm_mpm* h, int** slot, int** dil, int* new_tag) {
+  if (!h->sh_slot) {
+    NM_HIP_CHECK(hipMalloc(&h->sh_slot, h->nblocks * sizeof(int)));
+    NM_HIP_CHECK(hipMalloc(&h->sh_dil, h->nblocks * sizeof(int)));
+    NM_LAUNCH(k_fill_int, dim3(nm_div_up(h->nblocks, 256)), dim3(256), 0, (hipStream_t)0, h->sh_slot, h->nblocks, -1);
+    NM_LAUNCH(k_fill_int, dim3(nm_div_up(h->nblocks, 256)), dim3(256), 0, (hipStream_t)0, h->sh_dil, h->nblocks, 0);
+    NM_LAUNCH_CHECK();
+    NM_HIP_CHECK(hipDeviceSynchronize());
+    h->dil_tag = 0;
+  }
+  if (slot) *slot = h->sh_slot;
+  if (dil) *dil = h->sh_dil;
+  if (new_tag) *new_tag = ++h->dil_tag;
+  return NM_OK;
+}
+int nm_mpm_grid_dims(const nm_mpm* h) { return h->k.nb; }
+int nm_mpm_dil_tag(const nm_mpm* h) { return h->dil_tag; }
 
 // ---------------------------------------------------------------- particle-sharded substep: the same launches, cut at the
 // two points where the caller sums the blocks that several ranks touch (nm_shard.hip has the exchange kernels)
@@ -1208,7 +1293,8 @@ extern "C" int nm_mpm_forward_finish(nm_mpm* h, int32_t n, const nm_statics* st,
   const int now = h->cur;
   GridRec none = {nullptr, nullptr, nullptr};
   NM_LAUNCH(k_grid_op, dim3(kSweepGrid), dim3(256), 0, s, h->k, h->gm, h->gv, h->list[now], h->count + now,
-                     gridrec ? gridrec_at(gridrec, cap_blocks) : none, cap_blocks, (const int*)nullptr, (int*)status);
+                     gridrec ? gridrec_at(gridrec, cap_blocks) : none, cap_blocks, (const int*)nullptr, (int*)status,
+                     (const int*)nullptr, (const float4*)nullptr);
   NM_LAUNCH_CHECK();
   if (n == 0) return NM_OK;
   int rc = check_particles(st, cur, true);
@@ -1251,7 +1337,7 @@ extern "C" int nm_mpm_backward_finish(nm_mpm* h, int32_t n, const nm_statics* st
   const int now = h->cur;
   GridRec nostamp = {nullptr, nullptr, nullptr};
   NM_LAUNCH(k_grid_op_bwd, dim3(kSweepGrid), dim3(256), 0, s, h->k, h->gm, h->gg, h->list[now], h->count + now, nostamp, 0,
-                     h->flags);
+                     h->flags, (const int*)nullptr, (const float4*)nullptr);
   NM_LAUNCH_CHECK();
   if (n == 0) return NM_OK;
   int rc = check_particles(st, cur, true);

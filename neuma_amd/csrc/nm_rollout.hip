@@ -222,13 +222,14 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
 // launches and collectives alike - runs here, in the library, on the caller's stream.  The collectives are the caller's
 // (nm_comm: torch.distributed over RCCL in production, gloo in the tests); the library owns everything between them.
 struct ShardWs {
-  int32_t* status;   // capacity overflow bits of the roll-out (nm_mpm_shared_blocks / nm_mpm_forward_finish)
-  int32_t* mine;     // this rank's block list: [0] count, [1..cap] ids
+  int32_t* status;   // capacity / neighbourhood bits of the roll-out (see nm_rollout_shard_status)
+  int32_t* mine;     // this rank's neighbourhood list: [0] count, [1..cap] block ids
   int32_t* gathered; // world x (1 + cap)
-  int32_t* shared;   // per substep: 2 + 2 * cap_shared (kept for the reverse sweep)
+  int32_t* shared;   // the frame's exchange list: 2 + 2 * cap_shared (kept for the reverse sweep)
+  unsigned char* held;   // per substep and slot: the rank held the block in that substep (kept for the reverse sweep)
   float* buf;        // cap_shared x 64 float4: the all-reduced payload
   void* sws;         // workspace of nm_mpm_shared_blocks
-  size_t sws_bytes, shared_stride, total;
+  size_t sws_bytes, held_stride, total;
 };
 static ShardWs carve_shard(void* base, int world, int cap, int cap_shared, int substeps) {
   ShardWs w;
@@ -238,8 +239,9 @@ static ShardWs carve_shard(void* base, int world, int cap, int cap_shared, int s
   w.status = (int32_t*)take(256);
   w.mine = (int32_t*)take((size_t)(1 + cap) * sizeof(int32_t));
   w.gathered = (int32_t*)take((size_t)world * (1 + cap) * sizeof(int32_t));
-  w.shared_stride = al256r((size_t)(2 + 2 * cap_shared) * sizeof(int32_t)) / sizeof(int32_t);
-  w.shared = (int32_t*)take((size_t)(substeps > 0 ? substeps : 1) * w.shared_stride * sizeof(int32_t));
+  w.shared = (int32_t*)take((size_t)(2 + 2 * cap_shared) * sizeof(int32_t));
+  w.held_stride = al256r((size_t)cap_shared);
+  w.held = (unsigned char*)take((size_t)(substeps > 0 ? substeps : 1) * w.held_stride);
   w.buf = (float*)take((size_t)cap_shared * 64 * 4 * sizeof(float));
   w.sws_bytes = nm_mpm_shared_workspace(world, cap);
   w.sws = take(w.sws_bytes);
@@ -264,17 +266,18 @@ static int shard_args_ok(const nm_comm* comm, int32_t cap, int32_t cap_shared, c
   }
   return NM_OK;
 }
-// {mv, m} (which = 0) or the node-velocity adjoint (which = 1) of the blocks in `shared`: summed over the ranks
-static int shard_sum_blocks(nm_mpm* h, const nm_comm* comm, int which, const int32_t* shared, int cap_shared, float* buf, void* stream) {
-  int rc = nm_mpm_blocks_pack(h, which, shared, cap_shared, buf, stream);
-  if (rc) return rc;
+static int shard_all_reduce(const nm_comm* comm, float* buf, int cap_shared, void* stream) {
   if (comm->all_reduce_sum_f32(comm->user, buf, (int64_t)cap_shared * 64 * 4, stream)) {
     nm_set_error("nm_comm.all_reduce_sum_f32 failed");
     return NM_ERR_INVALID;
   }
-  return nm_mpm_blocks_unpack(h, which, shared, cap_shared, buf, stream);
+  return NM_OK;
 }
 
+// Forward sweep of one rank.  Substep 0 negotiates the frame's exchange list (neighbourhoods all-gathered ONCE, nm_shard.hip);
+// every substep is then the unsharded fused substep - grid clear in the elasticity kernel's prologue, g2p inside the
+// plasticity kernel - with one pack launch and one all-reduce between the scatter and the grid update, which reads the
+// summed blocks straight from the exchange buffer.
 extern "C" int nm_rollout_forward_sharded(nm_mpm* h, int32_t n, const nm_rollout_cfg* cfg, const nm_statics* st, const nm_mlp* we,
                                           const nm_mlp* wp, float* states, void* gridcache, void* workspace, size_t workspace_bytes,
                                           const nm_comm* comm, int32_t cap, int32_t cap_shared, void* shard_ws, size_t shard_ws_bytes,
@@ -296,36 +299,53 @@ extern "C" int nm_rollout_forward_sharded(nm_mpm* h, int32_t n, const nm_rollout
     rc = nm_material_prepare(wp, w.perm_p, stream);
     if (rc) return rc;
   }
+  nm_mpm_set_fresh_rows(h, 1);
   const int nrec = n > 0 ? n : 1;     // (a rank without particles still walks the exchange, with empty lists)
-  for (int t = 0; t < cfg->substeps; ++t) {
+  for (int t = 0; t < cfg->substeps && !rc; ++t) {
     nm_particles cur = rec(states, nrec, t), nxt = rec(states, nrec, t + 1);
-    int32_t* shared = sw.shared + (size_t)t * sw.shared_stride;
     if (n > 0) {
-      rc = nm_material_fwd_launch(n, NM_ELASTICITY, 0.f, cur.F, we, w.perm_e, cur.stress, nullptr, nullptr, stream);   // finetune.py:362
-      if (rc) return rc;
+      GridPrologue pro;
+      rc = nm_mpm_prologue_forward(h, &pro);
+      if (rc) break;
+      rc = nm_material_fwd_launch(n, NM_ELASTICITY, 0.f, cur.F, we, w.perm_e, cur.stress, &pro, nullptr, stream, svd_rec(cfg, n, t, 0),
+                                  act_rec(cfg, n, t, 0));  // finetune.py:362
+      if (rc) break;
+      rc = nm_mpm_forward_prepared_p2g(h, n, st, &cur, stream);        // this rank's scatter (mpm.py:281-290)
+      if (rc) break;
+    } else {
+      rc = nm_mpm_clear_only(h, stream);
+      if (rc) break;
     }
-    rc = nm_mpm_p2g(h, n, st, &cur, stream);                                  // clear + this rank's scatter (mpm.py:281-290)
-    if (rc) return rc;
-    rc = nm_mpm_active_list(h, sw.mine, cap, stream);
-    if (rc) return rc;
-    if (comm->all_gather_i32(comm->user, sw.mine, sw.gathered, (int64_t)(1 + cap), stream)) {
-      nm_set_error("nm_comm.all_gather_i32 failed");
-      return NM_ERR_INVALID;
+    if (t == 0) {
+      rc = nm_mpm_dilated_list(h, sw.mine, cap, stream);
+      if (rc) break;
+      if (comm->all_gather_i32(comm->user, sw.mine, sw.gathered, (int64_t)(1 + cap), stream)) {
+        nm_set_error("nm_comm.all_gather_i32 failed");
+        rc = NM_ERR_INVALID;
+        break;
+      }
+      rc = nm_mpm_shared_blocks(h, sw.gathered, comm->world, cap, sw.shared, cap_shared, sw.status, sw.sws, sw.sws_bytes, stream);
+      if (rc) break;
+      rc = nm_shard_slots(h, sw.shared, cap_shared, 1, stream);
+      if (rc) break;
     }
-    rc = nm_mpm_shared_blocks(h, sw.gathered, comm->world, cap, shared, cap_shared, sw.status, sw.sws, sw.sws_bytes, stream);
-    if (rc) return rc;
-    rc = shard_sum_blocks(h, comm, 0, shared, cap_shared, sw.buf, stream);
-    if (rc) return rc;
-    nm_particles trial = nxt;
-    trial.F = w.ftrial;                                                        // g2p leaves the trial F here, plasticity maps it to nxt.F
-    rc = nm_mpm_forward_finish(h, n, st, &cur, &trial, grid_rec(gridcache, cfg, t), cfg->grid_cache_blocks, sw.status, stream);  // :291-297
-    if (rc) return rc;
+    rc = nm_shard_pack_fwd(h, sw.shared, cap_shared, sw.buf, sw.held + (size_t)t * sw.held_stride, sw.status, stream);
+    if (rc) break;
+    rc = shard_all_reduce(comm, sw.buf, cap_shared, stream);
+    if (rc) break;
+    rc = nm_mpm_forward_gridop_x(h, grid_rec(gridcache, cfg, t), cfg->grid_cache_blocks, sw.status, sw.buf, stream);   // :291-297
+    if (rc) break;
     if (n > 0) {
-      rc = nm_material_fwd_launch(n, NM_PLASTICITY, cfg->plasticity_alpha, w.ftrial, wp, w.perm_p, nxt.F, nullptr, nullptr, stream);  // finetune.py:364
-      if (rc) return rc;
+      G2pFuse g2p;
+      rc = nm_mpm_g2p_fuse(h, st, &cur, &nxt, &g2p);
+      if (rc) break;
+      rc = nm_material_fwd_launch(n, NM_PLASTICITY, cfg->plasticity_alpha, nullptr, wp, w.perm_p, nxt.F, nullptr, &g2p, stream,
+                                  svd_rec(cfg, n, t, 1), act_rec(cfg, n, t, 1));  // finetune.py:364
     }
   }
-  return NM_OK;
+  nm_mpm_set_fresh_rows(h, 0);
+  const int rc2 = nm_shard_slots(h, sw.shared, cap_shared, 0, stream);      // the handle's slot map is clean between roll-outs
+  return rc ? rc : rc2;
 }
 
 extern "C" int nm_rollout_backward_sharded(nm_mpm* h, int32_t n, const nm_rollout_cfg* cfg, const nm_statics* st, const nm_mlp* we,
@@ -356,41 +376,57 @@ extern "C" int nm_rollout_backward_sharded(nm_mpm* h, int32_t n, const nm_rollou
   }
   const int polar = cfg->svd_adjoint == NM_SVD_ADJOINT_POLAR ? 1 : 0;
   const float dt = nm_mpm_get_dt(h);
-  for (int t = cfg->substeps - 1; t >= 0; --t) {
+  rc = nm_shard_slots(h, sw.shared, cap_shared, 1, stream);      // the frame's slot map again
+  if (rc) return rc;
+  // The records of a sharded roll-out are never recomputed (an overflow is an error, status bit 4), so the sweep always runs
+  // the way the unsharded one does once its records are verified: each substep's grid is restored in the prologue of the
+  // constitutive launch in front of it.
+  bool restored = false;
+  for (int t = cfg->substeps - 1; t >= 0 && !rc; --t) {
     nm_particles cur = rec(states_m, nrec, t), nxt = rec(states_m, nrec, t + 1);
-    const int32_t* shared = sw.shared + (size_t)t * sw.shared_stride;
     float* gout = (t == 0) ? gstate_first : ((gin == w.ga) ? w.gb : w.ga);
     const int wmode = (t == cfg->substeps - 1) ? 1 : 2;
     if (n > 0 && t == cfg->substeps - 1) {
       rc = nm_material_bwd_launch(n, NM_PLASTICITY, cfg->plasticity_alpha, cur.F, wp, w.perm_p, gin + 15 * N, w.gFtr, w.part_p, wmode,
-                                  nxt.C, st->enabled, dt, polar ? 2 : 0, nullptr, stream);
-      if (rc) return rc;
+                                  nxt.C, st->enabled, dt, polar ? 2 : 0, nullptr, stream, svd_rec(cfg, n, t, 1), act_rec(cfg, n, t, 1));
+      if (rc) break;
     }
     nm_particles gn, gc;
     gn.x = const_cast<float*>(gin); gn.v = const_cast<float*>(gin) + 3 * N; gn.C = const_cast<float*>(gin) + 6 * N;
     gn.F = w.gFtr; gn.stress = nullptr;
     gc.x = gout; gc.v = gout + 3 * N; gc.C = gout + 6 * N; gc.F = gout + 15 * N; gc.stress = w.gS;
-    // restore the (summed) grid of substep t from its record, scatter this rank's g2p adjoint, sum the shared blocks of the
-    // node-velocity adjoint over the ranks, then the grid-update and p2g adjoints
-    rc = nm_mpm_backward_begin(h, n, st, &cur, &nxt, &gn, &gc, grid_rec(gridcache, cfg, t), cfg->grid_cache_blocks, stream);
-    if (rc) return rc;
-    rc = shard_sum_blocks(h, comm, 1, shared, cap_shared, sw.buf, stream);
-    if (rc) return rc;
-    rc = nm_mpm_backward_finish(h, n, st, &cur, &gc, stream);
-    if (rc) return rc;
+    // restore the (summed) grid of substep t from its record, scatter this rank's g2p adjoint, sum the exchange blocks of the
+    // node-velocity adjoint over the ranks, then the grid-update adjoint (reading them from the buffer) and the p2g adjoint
+    rc = nm_mpm_backward_cached_begin(h, n, st, &cur, &nxt, &gn, &gc, grid_rec(gridcache, cfg, t), cfg->grid_cache_blocks, true,
+                                      restored, stream);
+    if (rc) break;
+    restored = false;
+    rc = nm_shard_pack_bwd(h, sw.shared, cap_shared, sw.buf, sw.held + (size_t)t * sw.held_stride, stream);
+    if (rc) break;
+    rc = shard_all_reduce(comm, sw.buf, cap_shared, stream);
+    if (rc) break;
+    rc = nm_mpm_backward_cached_finish(h, n, st, &cur, &gc, (n > 0 && t > 0) ? grid_rec(gridcache, cfg, t - 1) : nullptr,
+                                       cfg->grid_cache_blocks, sw.buf, stream);
+    if (rc) break;
     if (n > 0) {
       if (t == 0) {
         rc = nm_material_bwd_launch(n, NM_ELASTICITY, 0.f, cur.F, we, w.perm_e, w.gS, gc.F, w.part_e, wmode, nullptr, nullptr, 0.f,
-                                    1 | (polar ? 2 : 0), nullptr, stream);
+                                    1 | (polar ? 2 : 0), nullptr, stream, svd_rec(cfg, n, t, 0), act_rec(cfg, n, t, 0));
       } else {
         nm_particles prev = rec(states_m, nrec, t - 1);
+        GridPrologue pro;
+        rc = nm_mpm_prologue_backward(h, grid_rec(gridcache, cfg, t - 1), cfg->grid_cache_blocks, &pro);
+        if (rc) break;
+        restored = true;
         rc = nm_material_bwd_pair_launch(n, cur.F, we, w.perm_e, w.gS, gc.F, w.part_e, wmode, cfg->plasticity_alpha, prev.F, wp,
-                                         w.perm_p, w.gFtr, w.part_p, 2, cur.C, st->enabled, dt, polar, nullptr, stream);
+                                         w.perm_p, w.gFtr, w.part_p, 2, cur.C, st->enabled, dt, polar, &pro, stream,
+                                         svd_rec(cfg, n, t, 0), svd_rec(cfg, n, t - 1, 1), act_rec(cfg, n, t, 0), act_rec(cfg, n, t - 1, 1));
       }
-      if (rc) return rc;
     }
     gin = gout;
   }
+  const int rc2 = nm_shard_slots(h, sw.shared, cap_shared, 0, stream);
+  if (rc || rc2) return rc ? rc : rc2;
   if (n == 0) {
     NM_HIP_CHECK(hipMemsetAsync(gw_e, 0, NM_WTOT_ * sizeof(float), s));
     NM_HIP_CHECK(hipMemsetAsync(gw_p, 0, NM_WTOT_ * sizeof(float), s));
@@ -401,8 +437,8 @@ extern "C" int nm_rollout_backward_sharded(nm_mpm* h, int32_t n, const nm_rollou
   return nm_material_wgrad_reduce(w.part_p, n, gw_p, gw_p + 64 * 13, gw_p + 64 * 13 + 64 * 64, 0, stream);
 }
 
-// status bits of the roll-out's exchanges (1: a rank's block list exceeded cap, 2: more shared blocks than cap_shared,
-// 4: a grid cache record overflowed) - asynchronous copy of one int32 to (pinned) host memory
+// status bits of the roll-out's exchanges (1: a rank's neighbourhood list exceeded cap, 2: more exchange blocks than cap_shared,
+// 4: a grid cache record overflowed, 8: a particle left the neighbourhood its rank announced at the first substep) - asynchronous copy of one int32 to (pinned) host memory
 extern "C" int nm_rollout_shard_status(const void* shard_ws, int32_t* status_host, void* stream) {
   NM_REQUIRE(shard_ws && status_host, "null pointer");
   NM_HIP_CHECK(hipMemcpyAsync(status_host, shard_ws, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));

@@ -16,6 +16,8 @@
 #include <limits.h>
 #include <rocprim/rocprim.hpp>
 
+static const int kXchgGrid = 512;
+
 struct SharedWs {
   unsigned char* sel;  // [world * (1 + cap)]
   int* picked;         // [world * (1 + cap)] compacted selection
@@ -223,7 +225,6 @@ __global__ void __launch_bounds__(256) k_blocks_unpack(float4* __restrict__ dst,
     if (shared[2 + cap_shared + i]) dst[(shared[2 + i] << 6) + lane] = buf[(i << 6) + lane];
 }
 
-static const int kXchgGrid = 512;
 
 extern "C" int nm_mpm_blocks_pack(nm_mpm* h, int32_t which, const int32_t* shared, int32_t cap_shared, float* buf, void* stream) {
   NM_REQUIRE(h && shared && buf, "null handle / buffer");
@@ -244,6 +245,104 @@ extern "C" int nm_mpm_blocks_unpack(nm_mpm* h, int32_t which, const int32_t* sha
   nm_mpm_view v = nm_mpm_get_view(h);
   NM_LAUNCH(k_blocks_unpack, dim3(min(kXchgGrid, nm_div_up(cap_shared, 4))), dim3(256), 0, (hipStream_t)stream,
                      which ? v.gg : v.gm, shared, cap_shared, (const float4*)buf);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}
+
+
+// ---------------------------------------------------------------- frame-level negotiation (sharded roll-out in the library)
+// The per-substep exchange above negotiates the shared-block list every substep (all-gather + selection + all-reduce).  A
+// body moves a fraction of a block during the S substeps of a frame, so the roll-out negotiates ONCE per frame instead, with
+// a superset: every rank lists the 27-neighbourhood (in blocks) of what it touches at the first substep - everything one of
+// its particles can reach while it moves less than a block (4 grid cells) - and a block is exchanged if it lies in the
+// neighbourhoods of two ranks.  Two ranks can only both touch a block that lies in both neighbourhoods, so the superset is
+// complete as long as no rank leaves its own neighbourhood; every substep checks exactly that (status bit 8), which makes a
+// wrong result impossible: the caller sees the bit and re-runs the frame.  A substep then costs one pack launch and one
+// all-reduce per direction; the unpack is part of k_grid_op / k_grid_op_bwd (slot[] lookup).
+__global__ void __launch_bounds__(256) k_dilate_export(const int* __restrict__ list, const int* __restrict__ count, int nb,
+                                                       int* __restrict__ dil, int tag, int* __restrict__ out, int cap) {
+  const int cnt = *count;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt * 27; i += gridDim.x * blockDim.x) {
+    const int b = list[i / 27], o = i % 27;
+    const int bk = b % nb, bj = (b / nb) % nb, bi = b / (nb * nb);
+    const int ni = bi + o / 9 - 1, nj = bj + (o / 3) % 3 - 1, nk = bk + o % 3 - 1;
+    if ((unsigned)ni >= (unsigned)nb || (unsigned)nj >= (unsigned)nb || (unsigned)nk >= (unsigned)nb) continue;
+    const int q = (ni * nb + nj) * nb + nk;
+    if (dil[q] != tag && atomicExch(&dil[q], tag) != tag) {
+      const int pos = atomicAdd(&out[0], 1);       // unclamped count: the consumers flag > cap as an overflow
+      if (pos < cap) out[1 + pos] = q;
+    }
+  }
+}
+__global__ void k_xslots(const int* __restrict__ shared, int cap_shared, int* __restrict__ slot, int assign) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < min(shared[0], cap_shared)) slot[shared[2 + i]] = assign ? i : -1;
+}
+// one wave per slot: this rank's {mv, m} of the block if it holds the block in this substep, zeros otherwise; the answer is
+// remembered per slot for the reverse sweep (mine).  The same launch checks that the rank stayed inside its neighbourhood.
+__global__ void __launch_bounds__(256) k_xpack_fwd(const float4* __restrict__ gm, const int* __restrict__ shared, int cap_shared,
+                                                   const int* __restrict__ flags, int epoch, float4* __restrict__ buf,
+                                                   unsigned char* __restrict__ mine, const int* __restrict__ list,
+                                                   const int* __restrict__ count, const int* __restrict__ dil, int tag,
+                                                   int* __restrict__ status) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int cnt = min(shared[0], cap_shared);
+  for (int i = blockIdx.x * 4 + wave; i < cap_shared; i += gridDim.x * 4) {
+    bool m = false;
+    int b = 0;
+    if (i < cnt) { b = shared[2 + i]; m = flags[b] == epoch; }
+    buf[(i << 6) + lane] = m ? gm[(b << 6) + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane == 0) mine[i] = m ? 1 : 0;
+  }
+  const int nl = *count;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nl; i += gridDim.x * blockDim.x)
+    if (dil[list[i]] != tag) atomicOr(status, 8);
+}
+__global__ void __launch_bounds__(256) k_xpack_bwd(const float4* __restrict__ gg, const int* __restrict__ shared, int cap_shared,
+                                                   const unsigned char* __restrict__ mine, float4* __restrict__ buf) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int i = blockIdx.x * 4 + wave; i < cap_shared; i += gridDim.x * 4)
+    buf[(i << 6) + lane] = mine[i] ? gg[(shared[2 + i] << 6) + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// {count, ids} of the 27-neighbourhood of the blocks the rank's current grid holds (out[0] must be zero on entry; the count
+// is not clamped).  Starts a new negotiation: the neighbourhood is what the following nm_shard_pack_fwd calls check against.
+extern "C" int nm_mpm_dilated_list(nm_mpm* h, int32_t* out, int32_t cap, void* stream) {
+  NM_REQUIRE(h && out, "null handle / output");
+  NM_REQUIRE(cap > 0, "list capacity must be positive");
+  nm_mpm_view v = nm_mpm_get_view(h);
+  int *dil = nullptr, tag = 0;
+  int rc = nm_mpm_xchg_arrays(h, nullptr, &dil, &tag);
+  if (rc) return rc;
+  NM_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(int32_t), (hipStream_t)stream));
+  NM_LAUNCH(k_dilate_export, dim3(64), dim3(256), 0, (hipStream_t)stream, v.list, v.count, nm_mpm_grid_dims(h), dil, tag, out, cap);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}
+int nm_shard_slots(nm_mpm* h, const int32_t* shared, int32_t cap_shared, int assign, void* stream) {
+  int* slot = nullptr;
+  int rc = nm_mpm_xchg_arrays(h, &slot, nullptr, nullptr);
+  if (rc) return rc;
+  NM_LAUNCH(k_xslots, dim3(nm_div_up(cap_shared, 256)), dim3(256), 0, (hipStream_t)stream, shared, cap_shared, slot, assign);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}
+int nm_shard_pack_fwd(nm_mpm* h, const int32_t* shared, int32_t cap_shared, float* buf, unsigned char* mine, int32_t* status,
+                      void* stream) {
+  nm_mpm_view v = nm_mpm_get_view(h);
+  int* dil = nullptr;
+  int rc = nm_mpm_xchg_arrays(h, nullptr, &dil, nullptr);
+  if (rc) return rc;
+  NM_LAUNCH(k_xpack_fwd, dim3(min(kXchgGrid, nm_div_up(cap_shared, 4))), dim3(256), 0, (hipStream_t)stream, (const float4*)v.gm,
+                     shared, cap_shared, (const int*)v.flags, v.epoch, (float4*)buf, mine, (const int*)v.list, (const int*)v.count,
+                     (const int*)dil, nm_mpm_dil_tag(h), status);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}
+int nm_shard_pack_bwd(nm_mpm* h, const int32_t* shared, int32_t cap_shared, float* buf, const unsigned char* mine, void* stream) {
+  nm_mpm_view v = nm_mpm_get_view(h);
+  NM_LAUNCH(k_xpack_bwd, dim3(min(kXchgGrid, nm_div_up(cap_shared, 4))), dim3(256), 0, (hipStream_t)stream, (const float4*)v.gg,
+                     shared, cap_shared, mine, (float4*)buf);
   NM_LAUNCH_CHECK();
   return NM_OK;
 }

@@ -127,12 +127,9 @@ class _Rollout(autograd.Function):
         ws_bytes = int(lib.nm_rollout_workspace(n, S))
         ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
         ex = model.exchange
-        if ex is not None:
-            return _Rollout._forward_sharded(ctx, lib, model, ex, statics, S, float(alpha), int(svd_adjoint), n, states, we, wp, ws,
-                                             ws_bytes)
         # grid cache: only when a backward pass can follow (ground-truth / inference roll-outs skip it)
         cache_blocks = int(cache_blocks) if any(ctx.needs_input_grad) else 0
-        gc_bytes = int(lib.nm_rollout_gridcache_bytes(S, cache_blocks)) if cache_blocks > 0 else 0
+        gc_bytes = int(lib.nm_rollout_gridcache_bytes(S, cache_blocks)) if (cache_blocks > 0 and ex is None) else 0
         gcache = torch.empty(gc_bytes, dtype=torch.uint8, device=dev) if gc_bytes > 0 else None
         # SVD cache (U, sigma, V of both nets' inputs per substep, 168 B/particle/substep): also only when a backward pass can follow
         svdc = (_Lease(int(lib.nm_rollout_svdcache_bytes(n, S)), dev, False)
@@ -145,6 +142,9 @@ class _Rollout(autograd.Function):
         cfg = L.nm_rollout_cfg(S, float(alpha), cache_blocks if gcache is not None else 0, 0, int(svd_adjoint),
                                L.ptr(svdc.t) if svdc is not None else None, L.ptr(actc.t) if actc is not None else None)
         ctx.svdc, ctx.actc = svdc, actc
+        if ex is not None:
+            return _Rollout._forward_sharded(ctx, lib, model, ex, statics, S, float(alpha), int(svd_adjoint), n, states, we, wp, ws,
+                                             ws_bytes, svdc, actc)
         st = statics.c_struct()
         mle = L.nm_mlp(*[L.ptr(t) for t in we])
         mlp = L.nm_mlp(*[L.ptr(t) for t in wp])
@@ -168,9 +168,10 @@ class _Rollout(autograd.Function):
                 last[15 * n:24 * n].view(n, 3, 3))
 
     @staticmethod
-    def _forward_sharded(ctx, lib, model, ex, statics, S, alpha, svd_adjoint, n, states, we, wp, ws, ws_bytes):
+    def _forward_sharded(ctx, lib, model, ex, statics, S, alpha, svd_adjoint, n, states, we, wp, ws, ws_bytes, svdc, actc):
         """This rank's share of the particles (model.shard(group)): the library runs the whole S-substep loop, phases and
-        collectives, and calls back for the latter (nm_rollout_forward_sharded)."""
+        collectives, and calls back for the latter (nm_rollout_forward_sharded): one all-gather per roll-out (the frame's
+        exchange list is negotiated at the first substep) and one all-reduce per substep and direction."""
         dev = states.device
         st = statics.c_struct()
         if ex.cap is None or ex.cap_shared is None:
@@ -181,13 +182,21 @@ class _Rollout(autograd.Function):
             cur = L.nm_particles(base, base + 12 * n, base + 24 * n, base + 60 * n, base + 96 * n)
             L.check(lib.nm_mpm_p2g(model.handle(), n, C.byref(st), C.byref(cur), L.stream_ptr(dev)), "nm_mpm_p2g")
             ex._ensure_sized()
-        cap, cap_shared = int(ex.cap), int(ex.cap_shared)
-        gcache = torch.empty(int(lib.nm_rollout_gridcache_bytes(S, cap)), dtype=torch.uint8, device=dev)
+        if ex.cap_dil is None or ex.cap_frame is None:
+            if ex._gathered is not None:          # (sized by an earlier substep: the probe needs a current grid)
+                r0 = states[0]
+                r0[24 * n:].zero_()
+                base = r0.data_ptr()
+                cur = L.nm_particles(base, base + 12 * n, base + 24 * n, base + 60 * n, base + 96 * n)
+                L.check(lib.nm_mpm_p2g(model.handle(), n, C.byref(st), C.byref(cur), L.stream_ptr(dev)), "nm_mpm_p2g")
+            ex.size_frame_lists()
+        cap_rec, cap, cap_shared = int(ex.cap), int(ex.cap_dil), int(ex.cap_frame)
+        gcache = torch.empty(int(lib.nm_rollout_gridcache_bytes(S, cap_rec)), dtype=torch.uint8, device=dev)
         sws_bytes = int(lib.nm_rollout_shard_workspace(ex.world, cap, cap_shared, S))
         sws = torch.empty(sws_bytes, dtype=torch.uint8, device=dev)
         link = _ShardLink(ex, sws)
-        cfg = L.nm_rollout_cfg(S, alpha, cap, 0, svd_adjoint, None, None)
-        ctx.svdc = ctx.actc = None
+        cfg = L.nm_rollout_cfg(S, alpha, cap_rec, 0, svd_adjoint, L.ptr(svdc.t) if svdc is not None else None,
+                               L.ptr(actc.t) if actc is not None else None)
         mle = L.nm_mlp(*[L.ptr(t) for t in we])
         mlp = L.nm_mlp(*[L.ptr(t) for t in wp])
         link.check(lib.nm_rollout_forward_sharded(model.handle(), n, C.byref(cfg), C.byref(st), C.byref(mle), C.byref(mlp), L.ptr(states),
@@ -196,7 +205,7 @@ class _Rollout(autograd.Function):
         ex.watch(lib, sws, dev)          # status word -> pinned host memory; ex.check() raises on a capacity overflow
         ctx.model, ctx.statics, ctx.S, ctx.alpha, ctx.n = model, statics, S, alpha, n
         ctx.svd_adjoint = svd_adjoint
-        ctx.cache_blocks, ctx.gcache = cap, gcache
+        ctx.cache_blocks, ctx.gcache = cap_rec, gcache
         ctx.cache_status = ctx.cache_event = None
         ctx.shard = (ex, sws, sws_bytes, cap, cap_shared)
         ctx.save_for_backward(states, *we, *wp)

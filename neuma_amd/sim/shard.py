@@ -34,7 +34,28 @@ def size_with_slack(count: int) -> int:
 
 STATUS_TEXT = {1: "a rank touched more grid blocks than the list capacity `cap`",
                2: "more blocks are shared between ranks than `cap_shared`",
-               4: "a substep touched more blocks than its grid cache record holds"}
+               4: "a substep touched more blocks than its grid cache record holds",
+               8: "a particle left the block neighbourhood its rank announced at the frame's first substep (it moved more than "
+                  "a block - 4 grid cells - within one roll-out): use fewer substeps per roll-out node"}
+
+
+def dilate_blocks_host(ids, nb: int):
+    """Host statement of nm_mpm_dilated_list (csrc/nm_shard.hip): the 27-neighbourhood, in 4x4x4-node blocks, of the blocks
+    `ids` (block id = (bi * nb + bj) * nb + bk), clipped to the nb^3 blocks of the grid; returned as a sorted array (the
+    device list is unordered).  This is what a rank announces once per frame in the fused sharded roll-out: every block one of
+    its particles can reach while it moves less than one block.  The frame's exchange list is then
+    shared_blocks_host(all-gathered neighbourhoods): two ranks can both touch only blocks that lie in both neighbourhoods."""
+    import numpy as np
+    ids = np.asarray(ids, dtype=np.int64).reshape(-1)
+    bi, bj, bk = ids // (nb * nb), (ids // nb) % nb, ids % nb
+    out = set()
+    for di in (-1, 0, 1):
+        for dj in (-1, 0, 1):
+            for dk in (-1, 0, 1):
+                i, j, k = bi + di, bj + dj, bk + dk
+                ok = (i >= 0) & (i < nb) & (j >= 0) & (j < nb) & (k >= 0) & (k < nb)
+                out.update(((i[ok] * nb + j[ok]) * nb + k[ok]).tolist())
+    return np.asarray(sorted(out), dtype=np.int32)
 
 
 def explain_status(bits: int) -> str:
@@ -115,6 +136,8 @@ class GridExchange(object):
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.cap = int(cap) if cap else None                    # blocks per rank list / grid cache record
         self.cap_shared = int(cap_shared) if cap_shared else None
+        self.cap_dil = None          # fused roll-out: blocks in a rank's announced neighbourhood ...
+        self.cap_frame = None        # ... and in the frame's exchange list (size_frame_lists)
         self.device = model.device
         self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.generation = 0
@@ -145,6 +168,33 @@ class GridExchange(object):
         if self._buf is None:
             self._buf = torch.empty(self.cap_shared * 64 * 4, dtype=torch.float32, device=self.device)
             self._scratch_shared = self.new_shared()
+
+    def size_frame_lists(self) -> None:
+        """Capacities of the fused roll-out's frame-level negotiation, from the grid the handle holds now (one probe: the
+        ranks' neighbourhoods all-gathered, the exchange list selected, two host reads)."""
+        import torch.distributed as dist
+        if self.cap_dil is not None and self.cap_frame is not None:
+            return
+        lib, h, s = L.lib(), self.model.handle(), self.model._stream()
+        nb3 = ((int(self.model.constant.num_grids) + 2 + 3) // 4) ** 3
+        probe_cap = min(nb3, 27 * int(self.cap))
+        mine = torch.empty(1 + probe_cap, dtype=torch.int32, device=self.device)
+        L.check(lib.nm_mpm_dilated_list(h, L.ptr(mine), probe_cap, s), "nm_mpm_dilated_list")
+        count = mine[:1].clone()
+        dist.all_reduce(count, op=dist.ReduceOp.MAX, group=self.group)
+        self.cap_dil = size_with_slack(int(count.item()))
+        if self.cap_dil < probe_cap:
+            mine = mine[:1 + self.cap_dil].contiguous()
+        else:
+            self.cap_dil = probe_cap
+        gathered = torch.empty(self.world, 1 + self.cap_dil, dtype=torch.int32, device=self.device)
+        dist.all_gather_into_tensor(gathered.view(-1), mine, group=self.group)
+        upper = max(1, (self.world * self.cap_dil) // 2)
+        probe = torch.zeros(2 + 2 * upper, dtype=torch.int32, device=self.device)
+        ws = torch.empty(int(lib.nm_mpm_shared_workspace(self.world, self.cap_dil)), dtype=torch.uint8, device=self.device)
+        L.check(lib.nm_mpm_shared_blocks(h, L.ptr(gathered), self.world, self.cap_dil, L.ptr(probe), upper, None, L.ptr(ws),
+                                         ws.numel(), s), "nm_mpm_shared_blocks")
+        self.cap_frame = size_with_slack(int(probe[0].item()))
 
     def new_shared(self) -> torch.Tensor:
         return torch.empty(2 + 2 * self.cap_shared, dtype=torch.int32, device=self.device)

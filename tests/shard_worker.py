@@ -279,3 +279,72 @@ def cpu_comm_link(rank, world, port, q):
     except Exception as e:
         import traceback
         q.put({"rank": rank, "error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()})
+
+
+def gpu_nccl_one_rank(rank, world, port, q, name="tiny"):
+    """world = 1 on the RCCL backend ("nccl"): the collectives of both multi-GPU modes issued for real - the frame's K x 3
+    gradient all-reduce (_AllReduceSum) and the fused sharded roll-out's callbacks on views of its device workspace
+    (_ShardLink: one all-gather per roll-out, one all-reduce per substep and direction) - against the plain frame."""
+    try:
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ["NEUMA_SHARD_FORCE"] = "1"
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        from neuma_amd import synth
+        from neuma_amd.harness import SceneRuntime, _AllReduceSum
+        scene = synth.make_scene(name)
+        ref = SceneRuntime(scene, dev, fused=True)
+        ref.make_ground_truth()
+        rt = SceneRuntime(scene, dev, rank=0, world=1, shard_sim=True, fused=True)
+        assert rt.shard_sim and rt.model.exchange is not None and rt.fused
+        rt.gt = ref.gt
+        for run in (ref, rt):
+            with torch.no_grad():
+                for p in run.parameters():
+                    if p.shape[0] in (64, 9):
+                        p.mul_(-4.0)
+            run.v0.requires_grad_(True)
+        r0, r1 = ref.frame(), rt.frame()
+        rt.model.exchange.check()
+        res = {"rank": rank, "backend": dist.get_backend(), "loss": float(r1.loss), "ref_loss": float(r0.loss),
+               "x_err": _err(r1.x, r0.x), "F_err": _err(r1.F, r0.F), "v0_err": _err(rt.v0.grad, ref.v0.grad),
+               "grad_err": [_err(a.grad, b.grad) for a, b in zip(rt.parameters(), ref.parameters())],
+               "cap_frame": int(rt.model.exchange.cap_frame), "cap_dil": int(rt.model.exchange.cap_dil)}
+        # the stripe mode's collective: identity forward, all-reduce(sum) of the gradient backward
+        g = torch.randn(1000, 3, device=dev)
+        y = torch.randn(1000, 3, device=dev, requires_grad=True)
+        (_AllReduceSum.apply(y, None) * g).sum().backward()
+        res["allreduce_ok"] = bool(torch.equal(y.grad, g))
+        q.put(res)
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put({"rank": rank, "error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()})
+
+
+def gpu_neighbourhood_miss(rank, world, port, q, cells=9.0):
+    """A body that crosses more than a block (4 cells) within one roll-out leaves the neighbourhood its rank announced at the
+    first substep: every rank must see status bit 8 (exchange.check() raises), never a silently wrong sum."""
+    try:
+        dist = _init(rank, world, port)
+        from neuma_amd import synth
+        from neuma_amd.harness import SceneRuntime
+        dev = torch.device("cuda", 0)
+        rt = SceneRuntime(synth.make_scene("tiny"), dev, rank=rank, world=world, shard_sim=True, fused=True)
+        rw = rt.rows
+        speed = float(cells) / (rt.S * float(rt.scene.cfg["dt"]) * float(rt.scene.cfg["G"]))     # grid cells crossed per roll-out
+        v = torch.zeros_like(rt.v0[rw]); v[:, 0] = speed
+        with torch.no_grad():
+            rt.rollout(rt.x0[rw], v, rt.C0[rw], rt.F0[rw])
+        moved = float(speed) * rt.S * float(rt.scene.cfg["dt"]) * float(rt.scene.cfg["G"])
+        try:
+            rt.model.exchange.check()
+            q.put({"rank": rank, "raised": False, "cells": moved})
+        except Exception as e:
+            q.put({"rank": rank, "raised": True, "text": str(e), "cells": moved})
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put({"rank": rank, "error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()})

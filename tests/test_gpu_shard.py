@@ -109,3 +109,58 @@ def test_device_shared_block_rule_equals_the_host_statement(world, cap):
             out = shared.cpu().numpy()
             assert int(out[0]) == len(ids) and int(out[1]) == bits and int(status.item()) == bits
             assert np.array_equal(out[2:2 + len(ids)], ids)
+
+
+def test_one_rank_on_the_rccl_backend_runs_both_multi_gpu_collective_paths():
+    """backend "nccl" (= RCCL), world = 1: the fused sharded roll-out with its callbacks on device-workspace views and the
+    stripe mode's gradient all-reduce, against the unsharded frame."""
+    (r,) = _run(shard_worker.gpu_nccl_one_rank, 1)
+    assert r["backend"] == "nccl" and r["allreduce_ok"]
+    assert abs(r["loss"] - r["ref_loss"]) <= 1e-4 * abs(r["ref_loss"]) + 1e-9, r
+    assert r["x_err"] < 1e-5 and r["F_err"] < 1e-5 and r["v0_err"] < 5e-3, r
+    assert max(r["grad_err"]) < 5e-3, r
+    assert r["cap_frame"] >= 64 and r["cap_dil"] > 64
+
+
+def test_a_particle_leaving_its_announced_neighbourhood_is_reported_on_every_rank():
+    res = _run(shard_worker.gpu_neighbourhood_miss, 2, 40.0)      # (20 cells = 5 blocks by the second substep)
+    for r in res:
+        assert r["cells"] > 30 and r["raised"] and "neighbourhood" in r["text"], r
+    res = _run(shard_worker.gpu_neighbourhood_miss, 2, 1.5)        # a normal speed: nothing to report
+    for r in res:
+        assert r["cells"] < 2 and not r["raised"], r
+
+
+def test_device_neighbourhood_list_equals_the_host_statement():
+    """nm_mpm_dilated_list against sim.shard.dilate_blocks_host, incl. blocks at the grid's faces (clipped neighbourhoods)."""
+    import ctypes as C
+    import numpy as np
+    from gpu_util import mpm_case, build_model, build_statics
+    from neuma_amd import _lib as L
+    from neuma_amd.sim.shard import dilate_blocks_host
+    d = torch.device("cuda", 0)
+    const, vol, rho, clip, en, x, v, Cm, F, S = mpm_case(N=3000, G=32, seed=5, near_wall=True, disabled=False)
+    model = build_model(const, d)
+    st = build_statics(model, vol, rho, clip, en, d)
+    lib, h, s = L.lib(), model.handle(), L.stream_ptr(d)
+    cur = L.nm_particles(*[L.ptr(t.float().to(d).contiguous()) for t in (x, v, Cm, F, S)])
+    keep = [t.float().to(d).contiguous() for t in (x, v, Cm, F, S)]
+    cur = L.nm_particles(*[L.ptr(t) for t in keep])
+    L.check(lib.nm_mpm_p2g(h, x.shape[0], C.byref(st.c_struct()), C.byref(cur), s), "nm_mpm_p2g")
+    nb = (32 + 2 + 3) // 4
+    act = torch.zeros(1 + nb ** 3, dtype=torch.int32, device=d)
+    L.check(lib.nm_mpm_active_list(h, L.ptr(act), nb ** 3, s), "nm_mpm_active_list")
+    ids = act[1:1 + int(act[0])].cpu().numpy()
+    want = dilate_blocks_host(ids, nb)
+    assert len(ids) > 20 and len(want) > len(ids) and want.min() == 0            # (the low wall: a clipped neighbourhood)
+    for cap in (nb ** 3, 16):
+        out = torch.zeros(1 + cap, dtype=torch.int32, device=d)
+        for _ in range(2):                                                        # twice: a new tag per negotiation
+            out.fill_(-1)
+            L.check(lib.nm_mpm_dilated_list(h, L.ptr(out), cap, s), "nm_mpm_dilated_list")
+            got = out.cpu().numpy()
+            assert int(got[0]) == len(want)                                       # the count is never clamped
+            if cap >= len(want):
+                assert np.array_equal(np.sort(got[1:1 + len(want)]), want)
+            else:
+                assert set(got[1:1 + cap].tolist()) <= set(want.tolist())

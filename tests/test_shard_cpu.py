@@ -73,3 +73,44 @@ def test_stripe_plan_covers_every_tile_row_once():
                     assert (v, y) not in seen
                     seen[(v, y)] = r
         assert len(seen) == V * rows
+
+
+def test_frame_level_exchange_list_is_complete_while_particles_stay_within_a_block():
+    """The rule of the fused sharded roll-out, on the host: ranks announce the 27-neighbourhood (in blocks) of what they touch at
+    the frame's first substep (dilate_blocks_host); the exchange list = blocks in two neighbourhoods (shared_blocks_host).
+    Whatever the particles do afterwards - as long as none moves a whole block - every block that two ranks touch in a later
+    substep is on that list, and a rank that leaves its neighbourhood is detectable locally."""
+    import numpy as np
+    from neuma_amd.sim.shard import dilate_blocks_host, shared_blocks_host
+    rng = np.random.default_rng(3)
+    G, nb, world = 32, (32 + 2 + 3) // 4, 3
+    block_of = lambda p: ((p[:, 0] // 4) * nb + p[:, 1] // 4) * nb + p[:, 2] // 4
+
+    def touched(cells):                    # blocks under the 3x3x3 stencils of the particles' base cells
+        out = set()
+        for d in np.ndindex(3, 3, 3):
+            out.update(block_of(np.clip(cells + np.array(d), 0, G + 1)).tolist())
+        return out
+    centre = rng.integers(6, G - 8, size=(400, 3))
+    owner = np.argsort(np.argsort(centre[:, 0] * 1000 + centre[:, 1])) * world // len(centre)      # slabs along x: real overlaps
+    first = [touched(centre[owner == r]) for r in range(world)]
+    hoods = [dilate_blocks_host(sorted(f), nb) for f in first]
+    cap = max(len(h) for h in hoods)
+    g = np.full((world, 1 + cap), -1, np.int32)
+    for r, h in enumerate(hoods):
+        g[r, 0] = len(h); g[r, 1:1 + len(h)] = h
+    ids, _, bits = shared_blocks_host(g, cap, nb ** 3, world * cap)
+    assert bits == 0 and len(ids) > 10
+    frame_list = set(ids.tolist())
+    for step in range(8):                                        # every particle drifts, at most 3 cells in total per axis
+        drift = rng.integers(-3, 4, size=centre.shape)
+        now = [touched(centre[owner == r] + drift[owner == r]) for r in range(world)]
+        for r in range(world):
+            assert now[r] <= set(hoods[r].tolist())              # nobody left the announced neighbourhood ...
+        for a in range(world):
+            for b in range(a + 1, world):
+                assert (now[a] & now[b]) <= frame_list           # ... so every doubly touched block is exchanged
+    far = touched(centre[owner == 0] + np.array([9, 0, 0]))      # a jump of more than two blocks
+    assert not far <= set(hoods[0].tolist())                     # is seen by the rank itself (status bit 8)
+    # clipped at the faces of the grid
+    assert dilate_blocks_host([0], nb).tolist() == sorted({(i * nb + j) * nb + k for i in (0, 1) for j in (0, 1) for k in (0, 1)})

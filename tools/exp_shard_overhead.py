@@ -18,8 +18,9 @@ os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER
 os.environ["NEUMA_SHARD_FORCE"] = "1"
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 scene = synth.make_scene(name, override=dict(N=npart, K=1000) if npart else None)
+fused = (sys.argv[3] if len(sys.argv) > 3 else "fused") == "fused"      # fused: the library-level loops (what bench.py runs)
 for shard in (False, True, False, True):
-    rt = SceneRuntime(scene, dev, fused=False, shard_sim=shard)
+    rt = SceneRuntime(scene, dev, fused=fused, shard_sim=shard)
     rw = rt.rows
 
     def fwd():
@@ -43,5 +44,5 @@ for shard in (False, True, False, True):
             fn()
         torch.cuda.synchronize()
         out.append(1e6 * (time.perf_counter() - t0) / reps / rt.S)
-    print(f"{name} N={rt.N} shard={shard}: {out[0]:.1f} us/substep fwd, {out[1]:.1f} us/substep fwd+bwd", flush=True)
+    print(f"{name} N={rt.N} fused={fused} shard={shard}: {out[0]:.1f} us/substep fwd, {out[1]:.1f} us/substep fwd+bwd", flush=True)
 dist.destroy_process_group()
