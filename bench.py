@@ -104,8 +104,9 @@ def main():
     ap.add_argument("--per-op", action="store_true", help="use the per-operator drop-in path instead of the fused roll-out")
     ap.add_argument("--shard-sim", choices=("auto", "on", "off"), default="auto",
                     help="N > 1: particle-sharded simulation (neuma_amd/sim/shard.py) instead of a replicated one; "
-                         "auto = on from 100k particles per rank (the 1M-particle stress workload), where a substep "
-                         "outlasts its two block all-reduces")
+                         "auto = whichever sim.shard.shard_cost_model estimates faster for this workload and world size "
+                         "(measured per-substep latency at N / world particles + exchange machinery + assumed xGMI "
+                         "all-reduce latency, DESIGN.md section 6)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -161,8 +162,9 @@ def main():
     lib = _lib.lib()
 
     scene = synth.make_scene(args.workload)
-    shard_sim = world > 1 and (args.shard_sim == "on" or
-                               (args.shard_sim == "auto" and scene.x0.shape[0] // world >= 100_000))
+    from neuma_amd.sim.shard import shard_cost_model
+    cost = shard_cost_model(int(scene.x0.shape[0]), world, int(scene.cfg["S"]))
+    shard_sim = world > 1 and (args.shard_sim == "on" or (args.shard_sim == "auto" and cost["shard"]))
     if world == 1 and args.shard_sim == "on" and os.environ.get("NEUMA_SHARD_FORCE") == "1":
         # overhead measurement on one GPU: a one-rank RCCL group, every collective of the sharded substep is issued
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")

@@ -31,12 +31,36 @@ from .tune import Bindings, compute_bindings_xyz, compute_bindings_F, diff_raste
 PIXEL_LOSSES = {"l1": l1_loss, "l2": l2_loss}
 
 
-def stripe_plan(num_views: int, tile_rows: int, world: int, rank: int) -> List[Tuple[int, int, int]]:
-    """Split the V*tile_rows work units of a frame into `world` contiguous chunks; return this rank's
-    (view, row0, row1) stripes.  Pure host logic (covered by the gloo CPU tests)."""
+def stripe_plan(num_views: int, tile_rows: int, world: int, rank: int, weights=None, snap: float = 0.15) -> List[Tuple[int, int, int]]:
+    """Split the V * tile_rows work units of a frame (a unit = one 16-pixel tile row of one view) into `world` contiguous
+    chunks; return this rank's (view, row0, row1) stripes.  Pure host logic (covered by the gloo CPU tests).
+
+    weights: None (every unit costs the same) or V x tile_rows non-negative costs - the compositing work each tile row had in
+    the previous frame (sum of its tiles' list walks, from the cameras' walk records).  Cuts are placed where the running
+    cost passes r / world of the total, then moved to a view boundary if one lies within `snap` of a rank's share: a rank
+    that renders a whole view pays that view's preprocessing and binning once, a cut through a view makes two ranks pay
+    it.  Same inputs -> same plan on every rank."""
     total = num_views * tile_rows
-    lo = (total * rank) // world
-    hi = (total * (rank + 1)) // world
+    if weights is None:
+        cuts = [(total * r) // world for r in range(world + 1)]
+    else:
+        w = np.asarray(weights, dtype=np.float64).reshape(-1)
+        if w.shape[0] != total:
+            raise ValueError(f"weights must hold {num_views} x {tile_rows} entries")
+        w = np.maximum(w, 0.0) + 1e-3 * max(float(w.sum()), 1.0) / total          # (empty rows still cost a launch's worth)
+        acc = np.concatenate([[0.0], np.cumsum(w)])
+        share = acc[-1] / world
+        cuts = [0]
+        for r in range(1, world):
+            c = int(np.searchsorted(acc, r * share, side="left"))
+            c = min(max(c, cuts[-1]), total)
+            # snap to the nearest view boundary if that moves no more than snap * share of work across the cut
+            for b in (round(c / tile_rows) * tile_rows,):
+                if 0 < b < total and b >= cuts[-1] and abs(acc[b] - acc[c]) <= snap * share:
+                    c = int(b)
+            cuts.append(c)
+        cuts.append(total)
+    lo, hi = cuts[rank], cuts[rank + 1]
     out = []
     for v in range(num_views):
         a, b = max(lo, v * tile_rows), min(hi, (v + 1) * tile_rows)
@@ -292,7 +316,7 @@ class SceneRuntime(object):
         if self.world == 1:
             jobs = [(vi, None) for vi in range(self.V)]                         # :378-389
         else:
-            jobs = [(vi, (r0, r1)) for (vi, r0, r1) in stripe_plan(self.V, self.tile_rows, self.world, self.rank)]
+            jobs = [(vi, (r0, r1)) for (vi, r0, r1) in stripe_plan(self.V, self.tile_rows, self.world, self.rank, self._stripe_weights())]
 
         # the covariance push-forward is the same for every view of the frame: once, not per view
         from .render import deform_cov_by_F
@@ -335,7 +359,51 @@ class SceneRuntime(object):
                 reduce_param_grads(self.parameters(), self.group)             # each rank saw only its particles
         if self.shard_sim:
             self.model.exchange.check()      # raises if a substep's block exchange was incomplete (capacity exceeded)
+        if self.world > 1:
+            self._collect_stripe_work(jobs)
         return FrameResult(loss.detach(), x.detach(), F.detach())
+
+    # ---- stripes balanced by the compositing work of the previous frame
+    def _stripe_weights(self):
+        """V x tile_rows work estimates all ranks agree on (None until a frame has been measured).  A new plan is adopted only
+        when the one in use would leave some rank with > 10 % more than its share: stripes that move every frame would make
+        the rasterizer re-size its lists for every new cut."""
+        pend = getattr(self, "_stripe_pending", None)
+        if pend is not None and pend[1].query():
+            self._stripe_pending = None
+            w = pend[0].numpy().copy()
+            cur = getattr(self, "_stripe_w", None)
+            if cur is None:
+                self._stripe_w = w
+            else:
+                parts = [sum(float(w[v, a:b].sum()) for (v, a, b) in stripe_plan(self.V, self.tile_rows, self.world, r, cur))
+                         for r in range(self.world)]
+                if max(parts) > 1.10 * (sum(parts) / self.world):
+                    self._stripe_w = w
+        return getattr(self, "_stripe_w", None)
+
+    def _collect_stripe_work(self, jobs):
+        """Per (view, tile row): the list entries its tiles walked in this frame's renders (the cameras' walk records; every rank
+        knows its own stripes), summed over the ranks by one small all-reduce and copied to the host asynchronously."""
+        import torch.distributed as dist
+        if getattr(self, "_stripe_pending", None) is not None or os.environ.get("NEUMA_STRIPE_BALANCE", "1") == "0":
+            return
+        W = torch.zeros(self.V, self.tile_rows, dtype=torch.float32, device=self.device)
+        gx = (int(self.scene.cfg["W"]) + 15) // 16
+        for vi, rows in jobs:
+            stores = getattr(self.camera_at(vi), "_nm_walk_stores", None)
+            walk = stores[1].get(self.device) if stores else None
+            if walk is None:
+                return              # (hinting switched off: keep the uniform plan)
+            r0, r1 = rows if rows is not None else (0, self.tile_rows)
+            t = walk.view(-1, gx)[r0:r1].float()
+            W[vi, r0:r1] = t.sum(1) + 32.0 * (t > 0).float().sum(1)
+        dist.all_reduce(W, op=dist.ReduceOp.SUM, group=self.group)
+        host = torch.empty(self.V, self.tile_rows, dtype=torch.float32, pin_memory=True)
+        host.copy_(W, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._stripe_pending = (host, ev)
 
 
 class DiskRuntime(SceneRuntime):

@@ -49,12 +49,14 @@ def _c_cfg(s: GaussianRasterizationSettings, tile_rows: Optional[Tuple[int, int]
 class RasterCamera(object):
     """Pre-marshalled camera: build once per (view, frame) and reuse, so the hot loop performs no host reads."""
 
-    def __init__(self, settings: GaussianRasterizationSettings, tile_rows: Optional[Tuple[int, int]] = None):
+    def __init__(self, settings: GaussianRasterizationSettings, tile_rows: Optional[Tuple[int, int]] = None, walk_store=None):
         self.settings = settings
         self.tile_rows = tile_rows
         self.cfg = _c_cfg(settings, tile_rows)
         self.bins = BinCapacity()
-        self._walk = {}          # device -> per-tile walk record of the previous render (nm_raster_forward_ex)
+        # device -> per-tile walk record of the previous render (nm_raster_forward_ex).  walk_store: a dict shared by all the
+        # RasterCameras of one viewpoint (its tile-row stripes on several GPUs render into the same full-image record)
+        self._walk = walk_store if walk_store is not None else {}
 
     def tile_walk(self, device) -> Optional[Tensor]:
         """Per-tile walk record of this camera on `device` (int32 storage of the C ABI's uint32 array), created zeroed on
@@ -289,10 +291,11 @@ def split_plan(rasterizer, means3D, opacities, shs=None, colors_precomp=None, co
 
 
 class GaussianRasterizer(nn.Module):
-    def __init__(self, raster_settings: GaussianRasterizationSettings, tile_rows: Optional[Tuple[int, int]] = None):
+    def __init__(self, raster_settings: GaussianRasterizationSettings, tile_rows: Optional[Tuple[int, int]] = None, walk_store=None):
         super().__init__()
         self.raster_settings = raster_settings
-        self._cam = RasterCamera(raster_settings, tile_rows) if not isinstance(raster_settings, RasterCamera) else raster_settings
+        self._cam = (RasterCamera(raster_settings, tile_rows, walk_store) if not isinstance(raster_settings, RasterCamera)
+                     else raster_settings)
 
     def markVisible(self, positions: Tensor) -> Tensor:
         s = self._cam.settings
@@ -317,15 +320,22 @@ def get_rasterizer(viewpoint_camera, active_sh_degree: int, debug, bg_color: Ten
                    tile_rows: Optional[Tuple[int, int]] = None) -> GaussianRasterizer:
     """gaussian_renderer/__init__.py:92-119 (viewpoint_camera: anything with FoVx, FoVy, image_height, image_width,
     world_view_transform, full_proj_transform, camera_center — Camera / PhysCamera / MiniCam of cameras.py)."""
-    cached = getattr(viewpoint_camera, "_nm_raster_cache", None)
+    cache = getattr(viewpoint_camera, "_nm_raster_cache", None)
     # the marshalled camera is reused only while nothing it was built from has changed: tensors are identified by storage
     # AND version counter, so an in-place update of a transform / the background (viewer-style camera reuse) rebuilds it
     tensors = (viewpoint_camera.world_view_transform, viewpoint_camera.full_proj_transform, viewpoint_camera.camera_center, bg_color)
     key = (int(active_sh_degree), float(scaling_modifier), tile_rows, bool(debug), float(viewpoint_camera.FoVx),
            float(viewpoint_camera.FoVy), int(viewpoint_camera.image_height), int(viewpoint_camera.image_width)) + \
         tuple((t.data_ptr(), t._version) for t in tensors)
-    if cached is not None and cached[0] == key:
-        return cached[1]
+    # (key, rasterizer) of the last use first; up to 8 stripe / setting variants of a viewpoint stay marshalled (a stripe plan
+    # that is re-balanced now and then must not pay the first-render synchronisation again when it returns to an old cut)
+    entries = cache if isinstance(cache, list) else ([cache] if cache else [])
+    for i, (k, r) in enumerate(entries):
+        if k == key:
+            if i:
+                entries.insert(0, entries.pop(i))
+                viewpoint_camera._nm_raster_cache = entries
+            return r
     raster_settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height),
         image_width=int(viewpoint_camera.image_width),
@@ -340,9 +350,14 @@ def get_rasterizer(viewpoint_camera, active_sh_degree: int, debug, bg_color: Ten
         prefiltered=False,
         debug=debug,
     )
-    rast = GaussianRasterizer(raster_settings=raster_settings, tile_rows=tile_rows)
+    walk_key = key[:2] + key[4:]              # everything but the stripe and the debug flag: one walk record per viewpoint
+    stores = getattr(viewpoint_camera, "_nm_walk_stores", None)
+    if stores is None or stores[0] != walk_key:
+        stores = (walk_key, {})
+    rast = GaussianRasterizer(raster_settings=raster_settings, tile_rows=tile_rows, walk_store=stores[1])
     try:
-        viewpoint_camera._nm_raster_cache = (key, rast)
+        viewpoint_camera._nm_walk_stores = stores
+        viewpoint_camera._nm_raster_cache = [(key, rast)] + entries[:7]
     except Exception:
         pass
     return rast

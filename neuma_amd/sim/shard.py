@@ -58,6 +58,45 @@ def dilate_blocks_host(ids, nb: int):
     return np.asarray(sorted(out), dtype=np.int32)
 
 
+# ---------------------------------------------------------------- replicate or shard the simulation? (bench.py --shard-sim auto)
+# Measured on 1x MI355X, fused roll-out, forward + backward, microseconds per substep at N particles (tools/exp_shard_overhead.py
+# <workload> <N>; profiles/r03_shard_overhead.txt).  Between the points: linear in N.  The small sizes are latency floors - a
+# substep is ~12 dependent launches - which is why dividing 100k particles by 8 buys 2.1x, not 8x.
+SUBSTEP_US = ((12_500, 120.0), (25_000, 182.0), (50_000, 174.0), (100_000, 256.0), (1_000_000, 2600.0))
+MACHINERY_US = 17.0      # measured with a one-rank RCCL group: 2 pack launches + 2 all-reduce calls per substep, fwd + bwd
+# NOT measured (no multi-GPU box so far): latency of one all-reduce of <= 1 MiB over xGMI at `world` ranks.  Assumption: a ring /
+# tree step costs ~6 us and RCCL's launch ~10 us.  NEUMA_XGMI_ALLREDUCE_US overrides the per-collective figure.
+def allreduce_us(world: int) -> float:
+    import math
+    import os
+    env = os.environ.get("NEUMA_XGMI_ALLREDUCE_US")
+    if env:
+        return float(env)
+    return 0.0 if world <= 1 else 10.0 + 6.0 * math.ceil(math.log2(world)) * 2
+
+
+def substep_us(n: int) -> float:
+    pts = SUBSTEP_US
+    if n <= pts[0][0]:
+        return pts[0][1]
+    for (n0, t0), (n1, t1) in zip(pts, pts[1:]):
+        if n <= n1:
+            return t0 + (t1 - t0) * (n - n0) / (n1 - n0)
+    return pts[-1][1] * n / pts[-1][0]
+
+
+def shard_cost_model(num_particles: int, world: int, substeps: int) -> dict:
+    """Estimated simulation time of one frame (S substeps, forward + backward) on `world` GPUs with the simulation replicated
+    (every rank steps all particles) and particle-sharded (every rank steps N / world of them and pays, per substep and
+    direction, one all-reduce of the exchange blocks, plus per frame the all-gather of x and F, the all-gather of the block
+    neighbourhoods and the reduction of the LoRA gradients).  `shard` = the sharded estimate is the smaller one."""
+    rep = substeps * substep_us(num_particles)
+    ar = allreduce_us(world)
+    per_frame = 4.0 * ar if world > 1 else 0.0                     # x, F, neighbourhoods, parameter gradients
+    sh = substeps * (substep_us(-(-num_particles // world)) + MACHINERY_US + 2.0 * ar) + per_frame
+    return {"replicated_us": rep, "sharded_us": sh, "allreduce_us_assumed": ar, "shard": world > 1 and sh < rep}
+
+
 def explain_status(bits: int) -> str:
     return "; ".join(text for bit, text in STATUS_TEXT.items() if bits & bit)
 

@@ -114,3 +114,36 @@ def test_frame_level_exchange_list_is_complete_while_particles_stay_within_a_blo
     assert not far <= set(hoods[0].tolist())                     # is seen by the rank itself (status bit 8)
     # clipped at the faces of the grid
     assert dilate_blocks_host([0], nb).tolist() == sorted({(i * nb + j) * nb + k for i in (0, 1) for j in (0, 1) for k in (0, 1)})
+
+
+def test_shard_cost_model_and_weighted_stripe_plan():
+    """bench.py --shard-sim auto and the frame driver's stripe plan: pure host logic."""
+    import numpy as np
+    from neuma_amd.sim.shard import shard_cost_model, substep_us
+    from neuma_amd.harness import stripe_plan
+    assert substep_us(100_000) == 256.0 and substep_us(75_000) == (174.0 + 256.0) / 2 and substep_us(2_000_000) == 5200.0
+    one = shard_cost_model(100_000, 1, 20)
+    assert not one["shard"] and one["replicated_us"] == 20 * 256.0
+    m8, s8 = shard_cost_model(100_000, 8, 20), shard_cost_model(1_000_000, 8, 1)
+    assert m8["shard"] and m8["sharded_us"] < 0.95 * m8["replicated_us"]         # metric workload: 12.5k per rank + 2 assumed 46-us all-reduces
+    assert s8["shard"] and s8["sharded_us"] < 0.25 * s8["replicated_us"]         # 1M particles: close to 1/8
+    assert not shard_cost_model(8_000, 2, 1)["shard"]                            # bb: nothing to gain below the latency floor
+    # stripes: every (view, tile row) exactly once for 1-8 ranks, work balanced, whole views where that is nearly balanced
+    rng = np.random.default_rng(1)
+    V, T = 3, 68
+    w = np.zeros((V, T)); w[:, 18:52] = 5 + 10 * rng.random((V, 34))
+    for world in range(1, 9):
+        plans = [stripe_plan(V, T, world, r, w) for r in range(world)]
+        seen = np.zeros((V, T), int)
+        for p in plans:
+            for (v, a, b) in p:
+                seen[v, a:b] += 1
+        assert (seen == 1).all()
+        parts = np.array([sum(w[v, a:b].sum() for (v, a, b) in p) for p in plans])
+        assert parts.max() <= 1.25 * parts.mean() + 1e-9, (world, parts)
+        assert plans == [stripe_plan(V, T, world, r, w.copy()) for r in range(world)]      # deterministic
+    assert [stripe_plan(V, T, 3, r, w) for r in range(3)] == [[(0, 0, 68)], [(1, 0, 68)], [(2, 0, 68)]]
+    assert stripe_plan(V, T, 2, 0, None) == [(0, 0, 68), (1, 0, 34)]                       # unweighted: as before
+    uneven = np.zeros((2, 10)); uneven[0, :2] = 100.0; uneven[1] = 1.0                      # all the work in two rows
+    a, b = stripe_plan(2, 10, 2, 0, uneven), stripe_plan(2, 10, 2, 1, uneven)
+    assert a == [(0, 0, 1)] and b[0] == (0, 1, 10)

@@ -52,7 +52,7 @@ for _ in range(reps):
 b.record(); torch.cuda.synchronize()
 print(f"wall per render fwd+bwd (incl. torch glue): {1e3 * a.elapsed_time(b) / reps:.1f} us")
 os.environ["NM_RASTER_DEBUG"] = "1"
-cam = rt.cameras[0]._nm_raster_cache[1]._cam
+cam = rt.cameras[0]._nm_raster_cache[0][1]._cam
 from neuma_amd import render as _r
 _r.flush_pending()
 once(); torch.cuda.synchronize()
@@ -63,7 +63,7 @@ _r._PENDING.entries.clear()
 # ---- cell size distribution
 import numpy as np
 from neuma_amd.render import _raster_inputs, deform_cov_by_F
-rast = rt.cameras[0]._nm_raster_cache[1]
+rast = rt.cameras[0]._nm_raster_cache[0][1]
 cfg = rast._cam.cfg
 cov = deform_cov_by_F(rt._cov, dg)
 m3c, sh, cp, op, cv = _raster_inputs(m3, rt._shs, None, rt._opacity, cov)

@@ -35,7 +35,7 @@ for label, (b, s) in (("whole tiles", (0, 1024)), (f"split busy<{busy} minseg {m
     for _ in range(3):
         img = once()
     torch.cuda.synchronize()
-    rast = rt.cameras[0]._nm_raster_cache[1]
+    rast = rt.cameras[0]._nm_raster_cache[0][1]
     print(f"== {label}: plan (work items, segment) = {split_plan(rast, m3, rt._opacity, shs=rt._shs, cov3D_precomp=deform_cov_by_F(rt._cov, dg))}"
           f"  final_T<1e-3 on {float((img.mean(0) < 2).float().mean()):.2f}")
     lib.nm_prof_reset(); lib.nm_prof_enable(1, None)

@@ -21,7 +21,7 @@ with torch.no_grad():
     m3 = compute_bindings_xyz(x, rt.x0, rt.gaussians.get_xyz, rt.bindings)
     dg = compute_bindings_F(F, rt.bindings)
     rt.render_view(m3, dg, view)
-rast = rt.cameras[view]._nm_raster_cache[1]
+rast = rt.cameras[view]._nm_raster_cache[0][1]
 cfg = rast._cam.cfg
 cov = deform_cov_by_F(rt._cov, dg)
 m3c, sh, cp, op, cv = _raster_inputs(m3, rt._shs, None, rt._opacity, cov)
@@ -62,7 +62,7 @@ pl = img.reshape(gy, 16, gx, 16).transpose(0, 2, 1, 3).reshape(gy, gx, 256)
 med = np.median(pl, axis=2)
 print("median pixel's last / tile's last over busy tiles: mean %.2f" % float((med[busy] / last[busy]).mean()))
 # ---- walk record of the camera (nm_raster_forward_ex): how far the forward walk really went
-walk = rt.cameras[view]._nm_raster_cache[1]._cam.tile_walk(dev)
+walk = rt.cameras[view]._nm_raster_cache[0][1]._cam.tile_walk(dev)
 if walk is not None:
     w = walk.cpu().numpy().astype(np.int64).reshape(gy, gx)
     nz = w > 0
