@@ -53,6 +53,8 @@ def stripe_plan(num_views: int, tile_rows: int, world: int, rank: int, weights=N
         cuts = [0]
         for r in range(1, world):
             c = int(np.searchsorted(acc, r * share, side="left"))
+            if c > 0 and r * share - acc[c - 1] < acc[min(c, total)] - r * share:
+                c -= 1                                           # the cut whose running cost is nearest the target
             c = min(max(c, cuts[-1]), total)
             # snap to the nearest view boundary if that moves no more than snap * share of work across the cut
             for b in (round(c / tile_rows) * tile_rows,):
