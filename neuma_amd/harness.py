@@ -390,6 +390,8 @@ class SceneRuntime(object):
         import torch.distributed as dist
         if getattr(self, "_stripe_pending", None) is not None or os.environ.get("NEUMA_STRIPE_BALANCE", "1") == "0":
             return
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) < 2:
+            return              # (a runtime that only pretends to be one of several ranks: tests)
         W = torch.zeros(self.V, self.tile_rows, dtype=torch.float32, device=self.device)
         gx = (int(self.scene.cfg["W"]) + 15) // 16
         for vi, rows in jobs:

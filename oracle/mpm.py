@@ -131,8 +131,11 @@ def grid_op(const: MPMConstant, grid_mv: Tensor, grid_m: Tensor) -> Tensor:
 
 def g2p(const: MPMConstant, clip_bound: Tensor, enabled: Tensor,
         x: Tensor, F: Tensor, grid_v: Tensor,
-        v_old: Optional[Tensor] = None, C_old: Optional[Tensor] = None):
-    """mpm.py:432-498. Returns x', v', C', F'."""
+        v_old: Optional[Tensor] = None, C_old: Optional[Tensor] = None, fresh: bool = False):
+    """mpm.py:432-498. Returns x', v', C', F'.  A disabled particle's row (mpm.py:443-444: the kernel returns at once) keeps
+    what the next-state buffer held: fresh=False - the step is in place (MPMForwardSim, interface.py:126-135), the row keeps the
+    particle's state; fresh=True - the buffer is a new model.state() (MPMDiffSim, interface.py:101-105; mpm.py:84-93): zeros,
+    F = identity."""
     G = const.num_grids
     dt_ = x.dtype
     base, f, w = _stencil(const, x)
@@ -154,7 +157,12 @@ def g2p(const: MPMConstant, clip_bound: Tensor, enabled: Tensor,
     # :491-497 wp.clamp — like torch.clamp, passes the gradient iff lo <= x <= hi
     new_x = torch.clamp(new_x, min=(0.0 + bnd).expand_as(new_x), max=(1.0 - bnd).expand_as(new_x))
     en = (enabled != 0)
-    if not bool(en.all()):
+    if not bool(en.all()) and fresh:
+        new_x = torch.where(en[:, None], new_x, torch.zeros_like(new_x))
+        new_v = torch.where(en[:, None], new_v, torch.zeros_like(new_v))
+        new_C = torch.where(en[:, None, None], new_C, torch.zeros_like(new_C))
+        new_F = torch.where(en[:, None, None], new_F, I.expand_as(new_F))
+    elif not bool(en.all()):
         v_old = torch.zeros_like(new_v) if v_old is None else v_old
         C_old = torch.zeros_like(new_C) if C_old is None else C_old
         new_x = torch.where(en[:, None], new_x, x.detach())
@@ -164,11 +172,11 @@ def g2p(const: MPMConstant, clip_bound: Tensor, enabled: Tensor,
     return new_x, new_v, new_C, new_F
 
 
-def step(const: MPMConstant, vol, rho, clip_bound, enabled, x, v, C, F, stress, return_grid=False):
-    """MPMModel.forward mpm.py:279-297."""
+def step(const: MPMConstant, vol, rho, clip_bound, enabled, x, v, C, F, stress, return_grid=False, fresh: bool = False):
+    """MPMModel.forward mpm.py:279-297 (fresh: see g2p)."""
     grid_mv, grid_m = p2g(const, vol, rho, enabled, x, v, C, stress)
     grid_v = grid_op(const, grid_mv, grid_m)
-    out = g2p(const, clip_bound, enabled, x, F, grid_v, v, C)
+    out = g2p(const, clip_bound, enabled, x, F, grid_v, v, C, fresh=fresh)
     if return_grid:
         return out, (grid_mv, grid_m, grid_v)
     return out

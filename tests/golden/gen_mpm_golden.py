@@ -95,8 +95,10 @@ def build_model(G, dt, bc, gravity=(0.0, -9.8, 0.0), bound=1, eps=6e-7):
     return rsim.MPMModelBuilder().parse_cfg(cfg).finalize("cpu", requires_grad=False)
 
 
-def run_step(case, bc, ftype, **over):
-    """One reference substep: MPMModel.forward (mpm.py:279-297) on fresh states. Returns dict of numpy arrays."""
+def run_step(case, bc, ftype, _sentinel=True, **over):
+    """One reference substep: MPMModel.forward (mpm.py:279-297) on fresh states. Returns dict of numpy arrays.
+    _sentinel=False: the next state is left exactly as model.state() created it (what MPMDiffSim hands to the kernels,
+    interface.py:101-105) - the rows of disabled particles then show what the reference's out-of-place sims return for them."""
     wps.set_float(ftype)
     wps.oob_atomics = 0
     c = dict(case)
@@ -112,7 +114,8 @@ def run_step(case, bc, ftype, **over):
         getattr(cur.particle, name).assign(c[name])
     # next state pre-filled with a sentinel: disabled particles must be left untouched by g2p (mpm.py:443-444)
     for name, val in [("x", -7.0), ("v", -7.0), ("C", -7.0), ("F", -7.0)]:
-        getattr(nxt.particle, name).data[...] = val
+        if _sentinel:
+            getattr(nxt.particle, name).data[...] = val
     model.forward(statics, cur, nxt, None)
     assert wps.oob_atomics == 0, "fixture touches out-of-range nodes (reference UB)"
     p = nxt.particle
@@ -132,6 +135,9 @@ def gen_steps():
                 out[f"f64_{k}"] = v
             for k, v in r32.items():
                 out[f"f32_{k}"] = v
+            rf = run_step(case, bc, np.float32, _sentinel=False)        # next state = a fresh model.state(): disabled rows
+            for k in ["x", "v", "C", "F"]:
+                out[f"fresh_{k}"] = rf[k]
             nz = int((r64["m"] > 0).sum())
             print(f"step {tag}: touched nodes {nz}/{G**3}, max|f32-f64| x {abs(r32['x'] - r64['x']).max():.2e} "
                   f"v {abs(r32['v'] - r64['v']).max():.2e} C {abs(r32['C'] - r64['C']).max():.2e} F {abs(r32['F'] - r64['F']).max():.2e}")

@@ -340,3 +340,40 @@ def test_svd_and_activation_caches_do_not_change_the_reverse_sweep():
             assert rel_max(a, b) < 1e-5, mode           # the forward pass itself does not change (fp32 atomics order: not bitwise)
         for a, b in zip(res[mode][1], res["recompute"][1]):
             assert torch.isfinite(a).all() and rel_max(a, b) < 2e-4, mode
+
+
+def test_disabled_particles_get_the_reference_rows_in_the_fused_and_the_per_operator_path():
+    """A disabled particle's row of the next state is what the reference's out-of-place sims return for it: the fresh
+    model.state() untouched by g2p (zeros, F = I; mpm.py:84-93, 443-444, interface.py:101-123), which the plasticity net then
+    maps like any other row (finetune.py:364).  The fused node writes exactly that into its checkpoints; all rows compared."""
+    S = 3
+    rt = _runtime("tiny", fused=True, S=S)
+    lo, hi = rt.N // 3, rt.N // 3 + rt.N // 8
+    rt.statics.enabled[lo:hi] = 0
+    params = rt.parameters()
+    g = torch.Generator().manual_seed(8)
+    F0 = (torch.eye(3) + 0.05 * torch.randn(rt.N, 3, 3, generator=g)).to(dev())
+    gws = [torch.randn(rt.N, 3, generator=g), torch.randn(rt.N, 3, generator=g), torch.randn(rt.N, 3, 3, generator=g),
+           torch.randn(rt.N, 3, 3, generator=g)]
+    res = {}
+    for fused in (True, False):
+        rt.fused = fused
+        for p in params:
+            p.grad = None
+        ins = [t.clone().requires_grad_(True) for t in (rt.x0, rt.v0, rt.C0, F0)]
+        outs = rt.rollout(*ins)
+        torch.autograd.backward(outs, [w.to(dev()) for w in gws], inputs=ins + params)
+        res[fused] = ([o.detach().clone() for o in outs], [t.grad.clone() for t in ins + params])
+    with torch.no_grad():
+        FI = rt.plasticity(torch.eye(3, device=dev()).repeat(hi - lo, 1, 1))
+    for fused in (True, False):
+        x, v, C, F = res[fused][0]
+        assert float(x[lo:hi].abs().max()) == 0 and float(v[lo:hi].abs().max()) == 0 and float(C[lo:hi].abs().max()) == 0, fused
+        assert abs_max(F[lo:hi], FI) < 1e-6, fused
+        for gi in res[fused][1][:4]:
+            assert float(gi[lo:hi].abs().max()) == 0, fused          # nothing flows back into a disabled particle's inputs
+    for nme, a, b, tol in zip("xvCF", res[True][0], res[False][0], [5e-6, 5e-5, 1e-3, 1e-5]):
+        assert abs_max(a, b) < tol * max(1.0, float(b.abs().max())), nme
+    for a, b in zip(res[True][1], res[False][1]):
+        assert rel_max(a, b) < 2e-3
+    rt.statics.enabled.fill_(1)

@@ -39,6 +39,11 @@ def test_step_matches_reference_fp64(golden_dir, tag):
         ref = z["f64_" + name]
         assert np.abs(got.numpy()[e] - ref[e]).max() <= 1e-11 * max(1.0, np.abs(ref[e]).max()), name
         assert (ref[~e] == -7.0).all(), "reference leaves disabled particles' next state untouched"
+    # ... which, for the fresh model.state() an out-of-place sim hands over, means zeros / identity (fixture rows fresh_*)
+    fx, fv, fC, fF = om.step(const, vol, rho, clip, en, x, v, C, F, S, fresh=True)
+    for name, got in zip(["x", "v", "C", "F"], [fx, fv, fC, fF]):
+        assert np.array_equal(got.numpy()[~e], z["fresh_" + name][~e].astype(np.float64)), name
+        assert np.array_equal(z["fresh_" + name][e], z["f32_" + name][e]), name
     # the fixture really exercises the special cases
     base = np.trunc(z["in_x"] * int(z["in_G"]) - 0.5)
     assert (base == 0).any() and ((z["in_x"] * int(z["in_G"]) - 0.5) < 0).any(), "int() truncation case present"
