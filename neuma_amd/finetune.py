@@ -98,6 +98,11 @@ def finetune(cfg: Cfg, log=print):
     exp_root = Path(cfg.root) / cfg.name
     if exp_root.exists() and not (cfg.get("resume") or cfg.get("overwrite")):
         raise FileExistsError(f"{exp_root} exists (set resume: true or overwrite: true)")
+    if exp_root.exists() and cfg.get("overwrite") and not cfg.get("resume"):
+        # nclaw/utils.py:42-47 mkdir(overwrite=True) removes the old experiment: a stale finetune/init.pt would make stage A
+        # skip with the old velocity, stale NNNN_lora.pt files would win the keep-newest-3 rotation
+        import shutil
+        shutil.rmtree(exp_root, ignore_errors=True)
     exp_root.mkdir(parents=True, exist_ok=True)
     save_config(cfg, exp_root / "config.yaml")
     tune_root = exp_root / "finetune"

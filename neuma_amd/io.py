@@ -138,6 +138,47 @@ def read_obj_mesh(path):
     return np.asarray(verts, dtype=np.float64), np.asarray(tris, dtype=np.int64).reshape(-1, 3)
 
 
+def points_in_mesh(points: np.ndarray, verts: np.ndarray, tris: np.ndarray) -> np.ndarray:
+    """Inside test of a closed triangle mesh by ray parity along +z (counterpart of trimesh's `mesh.contains`, which the
+    reference's samplers rely on, tune/utils.py:49-200).  points (n,3) -> bool (n,)."""
+    p = np.asarray(points, dtype=np.float64)
+    a, b, c = (np.asarray(verts, dtype=np.float64)[np.asarray(tris)[:, k]] for k in range(3))
+    inside = np.zeros(len(p), dtype=bool)
+    # (the ray is moved off the point by a tiny irrational offset: a grid point exactly above a triangle edge would otherwise
+    # count both triangles)
+    span = float(np.abs(np.asarray(verts)).max()) or 1.0
+    p = p + np.array([1.2345678e-7, 2.7182818e-7, 0.0]) * span
+    d = (b[:, 1] - c[:, 1]) * (a[:, 0] - c[:, 0]) + (c[:, 0] - b[:, 0]) * (a[:, 1] - c[:, 1])       # 2 x signed area in xy
+    ok = np.abs(d) > 1e-300
+    a, b, c, d = a[ok], b[ok], c[ok], d[ok]
+    for i0 in range(0, len(p), 2048):
+        q = p[i0:i0 + 2048]
+        px, py = q[:, 0:1], q[:, 1:2]
+        l0 = ((b[:, 1] - c[:, 1])[None] * (px - c[:, 0][None]) + (c[:, 0] - b[:, 0])[None] * (py - c[:, 1][None])) / d[None]
+        l1 = ((c[:, 1] - a[:, 1])[None] * (px - c[:, 0][None]) + (a[:, 0] - c[:, 0])[None] * (py - c[:, 1][None])) / d[None]
+        l2 = 1.0 - l0 - l1
+        hit = (l0 >= 0) & (l1 >= 0) & (l2 >= 0)
+        z = l0 * a[:, 2][None] + l1 * b[:, 2][None] + l2 * c[:, 2][None]
+        inside[i0:i0 + 2048] = ((hit & (z > q[:, 2:3])).sum(1) % 2) == 1
+    return inside
+
+
+def sample_mesh_points(verts: np.ndarray, tris: np.ndarray, mode: str = "volumetric", resolution: int = 30, seed: int = 0) -> np.ndarray:
+    """Particles inside a closed mesh (tune/utils.py:49-200 without trimesh / the prebuilt VolumeSampling binary):
+    'volumetric' = the points of a regular grid with `resolution` cells along the longest side of the bounding box that lie
+    inside; 'uniform' = resolution^3 uniformly random points of the bounding box, those inside kept."""
+    lo, hi = verts.min(0), verts.max(0)
+    if mode == "volumetric":
+        h = float((hi - lo).max()) / int(resolution)
+        axes = [np.arange(lo[k] + 0.5 * h, hi[k], h) for k in range(3)]
+        pts = np.stack(np.meshgrid(*axes, indexing="ij"), -1).reshape(-1, 3)
+    elif mode == "uniform":
+        pts = lo + (hi - lo) * np.random.default_rng(seed).random((int(resolution) ** 3, 3))
+    else:
+        raise ValueError(f"mesh_sample_mode '{mode}' is not available here (volumetric / uniform)")
+    return pts[points_in_mesh(pts, verts, tris)]
+
+
 def mesh_volume(verts: np.ndarray, tris: np.ndarray) -> float:
     """Signed volume of a closed triangle mesh (sum of tetrahedra against the origin), what trimesh's `mesh.volume` returns."""
     a, b, c = verts[tris[:, 0]], verts[tris[:, 1]], verts[tris[:, 2]]
@@ -324,7 +365,7 @@ def read_neuma_synthetic_cameras(path, transformsfile: str, white_background: bo
                 W, H = int(round(2 * K[0][2])), int(round(2 * K[1][2]))
             infos.append(CameraInfo(idx, R, T, focal2fov(K[1][1], H), focal2fov(K[0][0], W), img_path, W, H, view, step, image))
             idx += 1
-    return {"cam_infos": infos, "views": views, "steps": steps}
+    return {"cam_infos": infos, "views": views, "steps": steps_used}      # (dataset_readers.py:230: [init_frame] when one is given)
 
 
 def rodrigues(rvec) -> np.ndarray:
@@ -397,7 +438,7 @@ def read_realcapture_cameras(path, white_background: bool, extension: str = ".jp
                     else _load_image(img_path, white_background)
             infos.append(CameraInfo(idx, R, T, FovY, FovX, img_path, width, height, view, step, image))
             idx += 1
-    return {"cam_infos": infos, "views": views, "steps": steps}
+    return {"cam_infos": infos, "views": views, "steps": steps_used}      # (dataset_readers.py:329)
 
 
 class DiskCamera(object):

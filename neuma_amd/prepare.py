@@ -6,8 +6,9 @@ it writes, into experiments/assets/<sim_data_name>/:
                     centres of the Gaussians no particle fell into
     bindings.pt     sparse (K x N) binding weights + per-Gaussian particle counts
 The O(K N) Mahalanobis loop of binding_utils.py runs as the grid-hashed HIP search of neuma_amd.binding.
-Sampling particles out of a mesh (uniform / volumetric / surface, tune/utils.py:49-200; `VolumeSampling` is a prebuilt ELF)
-is asset preprocessing outside the hot path: pass `particles_path`, or place particles.ply in the asset folder."""
+Particles out of a mesh (particle_data.mesh_path, tune/utils.py:49-200): 'volumetric' / 'uniform' are sampled here with a
+ray-parity inside test (io.sample_mesh_points; the reference calls trimesh and a prebuilt `VolumeSampling` ELF); a
+particles.ply already lying in the asset folder is used as it is."""
 from pathlib import Path
 from typing import Optional
 
@@ -39,10 +40,16 @@ def prepare_simulation_data(save_dir: Path, kernels_path: Path, particles_path: 
     if particles_path is not None:
         print(f"Extracting particles from pcd file [{particles_path}] ...")
         particles = nio.load_particles_ply(particles_path)
+    elif mesh_path is not None and (save_dir / "particles.ply").is_file():
+        # particles sampled elsewhere (e.g. with the reference's tools) and placed in the asset folder: used as they are
+        print(f"Using the particles found in [{save_dir / 'particles.ply'}] ...")
+        particles = nio.load_particles_ply(save_dir / "particles.ply")
+        particles_downsample_factor = 1
     elif mesh_path is not None:
-        raise NotImplementedError(
-            f"sampling particles from a mesh ({mesh_sample_mode}, resolution {mesh_sample_resolution}) is asset preprocessing "
-            "outside this engine: sample the mesh with the reference's tools and pass particle_data.particles_path")
+        print(f"Sampling particles inside mesh [{mesh_path}] ({mesh_sample_mode}, resolution {mesh_sample_resolution}) ...")
+        reader = nio.read_obj_mesh if Path(mesh_path).suffix.lower() == ".obj" else nio.read_ply_mesh
+        particles = nio.sample_mesh_points(*reader(mesh_path), mode=mesh_sample_mode, resolution=int(mesh_sample_resolution))
+        particles_downsample_factor = 1
     else:
         raise ValueError("Either 'particles_path' or 'mesh_path' must be provided.")
     particles = torch.as_tensor(particles, dtype=torch.float32, device=device)

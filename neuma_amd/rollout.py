@@ -131,13 +131,20 @@ class _Rollout(autograd.Function):
         cache_blocks = int(cache_blocks) if any(ctx.needs_input_grad) else 0
         gc_bytes = int(lib.nm_rollout_gridcache_bytes(S, cache_blocks)) if (cache_blocks > 0 and ex is None) else 0
         gcache = torch.empty(gc_bytes, dtype=torch.uint8, device=dev) if gc_bytes > 0 else None
-        # SVD cache (U, sigma, V of both nets' inputs per substep, 168 B/particle/substep): also only when a backward pass can follow
-        svdc = (_Lease(int(lib.nm_rollout_svdcache_bytes(n, S)), dev, False)
-                if (_SVD_CACHE and n > 0 and any(ctx.needs_input_grad)) else None)
+        # SVD cache (U, sigma, V of both nets' inputs per substep, 168 B/particle/substep) and activation cache (1.2 KB): only
+        # when a backward pass can follow, and only while the caches of all live roll-out nodes together stay below
+        # NEUMA_ACT_CACHE_GB - a BPTT loop over hundreds of frames falls back to the recompute (the reference's memory
+        # profile) instead of running out of memory
+        budget = _ACT_CACHE_GB * (1 << 30)
+        svdc = None
+        if _SVD_CACHE and n > 0 and any(ctx.needs_input_grad):
+            svd_bytes = int(lib.nm_rollout_svdcache_bytes(n, S))
+            if _ACT_LIVE[0] + svd_bytes <= budget:
+                svdc = _Lease(svd_bytes, dev, True)
         actc = None
         if _ACT_CACHE != '0' and n > 0 and any(ctx.needs_input_grad):
             act_bytes = int(lib.nm_rollout_actcache_bytes(n, S))
-            if _ACT_CACHE == '1' or _ACT_LIVE[0] + act_bytes <= _ACT_CACHE_GB * (1 << 30):
+            if _ACT_CACHE == '1' or _ACT_LIVE[0] + act_bytes <= budget:
                 actc = _Lease(act_bytes, dev, True)
         cfg = L.nm_rollout_cfg(S, float(alpha), cache_blocks if gcache is not None else 0, 0, int(svd_adjoint),
                                L.ptr(svdc.t) if svdc is not None else None, L.ptr(actc.t) if actc is not None else None)

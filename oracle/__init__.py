@@ -18,12 +18,16 @@ Parity pinning status
   shipped checkpoints (tests/golden/gen_material_golden.py, tests/golden/material_*.npz).
 * SH basis, camera matrices, l1/l2 loss: PINNED — reference modules are pure torch/numpy and were
   imported to generate tests/golden/camera_sh_golden.npz.
-* MPM kernels (mpm.py:321-498), batch_svd sign rule (svd.py:61-96), deform_cov_by_F: the
-  reference can only run them through warp-lang 0.6.1, which is not installed and not
-  installable here, and the reference holds no tests or golden vectors => "parity unpinned" for
-  the generated adjoints, wp.svd3's internal ordering and the atomics order.  The restatement is
-  checked by construction invariants instead (mass / momentum conservation, affine-field
-  reproduction, finite differences).
+* MPM kernels (mpm.py:321-498), the statics / state initialisers, the in-place roll-out with span enabling and
+  forward_extra: PINNED - the reference's own `@wp.kernel` bodies are EXECUTED (unmodified modules imported from
+  /root/reference under a scalar numpy stand-in for the ~20 `wp.*` names, tests/golden/warp_scalar.py) in fp64 and fp32;
+  tests/golden/gen_mpm_golden.py writes one-substep vectors (both boundary conditions, wall / floor contact, clamp, a
+  disabled span - incl. the rows a fresh model.state() holds for disabled particles), central-difference gradient KATs
+  and a 12-step roll-out (mpm_step_*, mpm_grad_*, mpm_rollout, mpm_init .npz); tests/test_oracle_pinned.py holds this
+  package to them (1e-11 in fp64).
+* batch_svd det / sign rule (svd.py:61-96) and deform_cov_by_F (simulation_utils.py:25-48): PINNED the same way
+  (svd_rule.npz, cov_deform.npz).  NOT pinnable: what lives inside warp-lang itself - wp.svd3's Jacobi order and its adjoint
+  (adj_svd3); the convention adopted for those is stated in DESIGN.md section 2.
 * rasterizer: the reference calls the un-vendored `diff_gaussian_rasterization` CUDA extension
   (graphdeco-inria/gaussian-splatting @ b17ded92b56ba02b6b7eaba2e66a2b0510f27764, README.md:56-61).
   No source, tests or vectors for it exist under /root/reference => "parity unpinned"; the oracle

@@ -82,23 +82,40 @@ def test_constitutive_nets_frame_indifference_and_plastic_flow(rt):
 
 
 def test_fused_rollout_matches_per_operator_path(rt):
+    """States and ALL gradients (inputs and LoRA factors) of the fused node against the per-operator classes, at full size.
+    The comparison runs from a deformed state under random output weights: from the rest state with a plain sum as the loss
+    dL/dF, dL/dC are residues of node sums that cancel, and two runs of the SAME path differ by up to 15 % there (atomics
+    order; tools/exp_gradcheck_full.py) - with a well-conditioned loss both paths agree to 5e-5, and that is what is asked."""
     S = min(rt.S, 3)
     old = rt.S
     rt.S = rt.sim_fused.substeps = S
+    g = torch.Generator().manual_seed(4)
+    F0 = (torch.eye(3) + 0.05 * torch.randn(rt.N, 3, 3, generator=g)).to(dev())
+    wts = [torch.randn(sh, generator=g).to(dev()) for sh in ((rt.N, 3), (rt.N, 3), (rt.N, 3, 3), (rt.N, 3, 3))]
     try:
         res = {}
         for fused in (True, False):
             rt.fused = fused
             for p in rt.parameters():
                 p.grad = None
-            ins = [t.clone().requires_grad_(True) for t in (rt.x0, rt.v0)]
-            out = rt.rollout(ins[0], ins[1], rt.C0, rt.F0)
-            (out[0].sum() + (out[3] ** 2).sum()).backward()
+            ins = [t.clone().requires_grad_(True) for t in (rt.x0, rt.v0, rt.C0, F0)]
+            out = rt.rollout(*ins)
+            sum((o * w).sum() for o, w in zip(out, wts)).backward()
             res[fused] = ([o.detach().clone() for o in out], [t.grad.clone() for t in ins + rt.parameters()])
         for x, y, tol in zip(res[True][0], res[False][0], [1e-6, 1e-5, 1e-3, 1e-5]):
             assert abs_max(x, y) < tol * max(1.0, float(y.abs().max()))
         for a, b in zip(res[True][1], res[False][1]):
-            assert torch.isfinite(a).all() and rel_max(a, b) < 2e-2
+            assert torch.isfinite(a).all() and float(b.abs().max()) > 0 and rel_max(a, b) < 3e-4
+        # rest state, plain sum: the parameter gradients (sums over all particles) are well conditioned there too
+        for fused in (True, False):
+            rt.fused = fused
+            for p in rt.parameters():
+                p.grad = None
+            out = rt.rollout(rt.x0, rt.v0, rt.C0, rt.F0)
+            (out[0].sum() + (out[3] ** 2).sum()).backward()
+            res[fused] = [p.grad.clone() for p in rt.parameters()]
+        for a, b in zip(res[True], res[False]):
+            assert rel_max(a, b) < 3e-4
     finally:
         rt.S = rt.sim_fused.substeps = old
         rt.fused = True

@@ -112,18 +112,28 @@ def test_render_1080p_stripes_background_linearity_and_gradient_consistency(rt):
 
 
 def test_fused_rollout_matches_per_operator_path_at_100k(rt):
+    """States and gradients at the metric size (deformed start, random output weights: see test_gpu_configs.py for why)."""
     S = 3
     rt.sim_fused.substeps = S
     old = rt.S
     rt.S = S
+    g = torch.Generator().manual_seed(6)
+    F0 = (torch.eye(3) + 0.05 * torch.randn(rt.N, 3, 3, generator=g)).to(dev())
+    wts = [torch.randn(sh, generator=g).to(dev()) for sh in ((rt.N, 3), (rt.N, 3), (rt.N, 3, 3), (rt.N, 3, 3))]
     try:
-        with torch.no_grad():
-            rt.fused = True
-            a = [t.clone() for t in rt.rollout(rt.x0, rt.v0, rt.C0, rt.F0)]
-            rt.fused = False
-            b = rt.rollout(rt.x0, rt.v0, rt.C0, rt.F0)
-        for x, y, tol in zip(a, b, [1e-6, 1e-5, 1e-3, 1e-5]):
+        res = {}
+        for fused in (True, False):
+            rt.fused = fused
+            for p in rt.parameters():
+                p.grad = None
+            ins = [t.clone().requires_grad_(True) for t in (rt.x0, rt.v0, rt.C0, F0)]
+            out = rt.rollout(*ins)
+            sum((o * w).sum() for o, w in zip(out, wts)).backward()
+            res[fused] = ([o.detach().clone() for o in out], [t.grad.clone() for t in ins + rt.parameters()])
+        for x, y, tol in zip(res[True][0], res[False][0], [1e-6, 1e-5, 1e-3, 1e-5]):
             assert abs_max(x, y) < tol * max(1.0, float(y.abs().max()))
+        for a, b in zip(res[True][1], res[False][1]):
+            assert torch.isfinite(a).all() and rel_max(a, b) < 3e-4
     finally:
         rt.S = old
         rt.sim_fused.substeps = old

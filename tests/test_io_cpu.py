@@ -185,3 +185,31 @@ def test_init_and_lora_checkpoint_formats(tmp_path):
     torch.save({"init_x": torch.rand(5, 3), "init_v": torch.rand(5, 3)}, tmp_path / "init.pt")     # neuma_dataset.py:115-118
     x, v = nio.load_init_state(tmp_path / "init.pt")
     assert x.shape == (5, 3) and v.shape == (5, 3)
+
+
+def test_mesh_sampling_and_init_frame_steps(tmp_path):
+    """io.sample_mesh_points (prepare.py's particle_data.mesh_path) on a closed box, and the camera readers' `steps` entry with
+    an init_frame (dataset_readers.py:230, 329: only that frame)."""
+    import json
+    import numpy as np
+    from neuma_amd import io as nio
+    v = np.array([[0, 0, 0], [2, 0, 0], [2, 1, 0], [0, 1, 0], [0, 0, 1], [2, 0, 1], [2, 1, 1], [0, 1, 1]], float)
+    t = np.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4], [2, 3, 7], [2, 7, 6], [1, 2, 6], [1, 6, 5], [3, 0, 4], [3, 4, 7]])
+    p = np.array([[1.0, 0.5, 0.5], [2.5, 0.5, 0.5], [0.2, 0.9, 0.1], [1.0, 0.5, -0.1], [1.0, 0.5, 1.1]])
+    assert nio.points_in_mesh(p, v, t).tolist() == [True, False, True, False, False]
+    grid = nio.sample_mesh_points(v, t, "volumetric", 10)
+    assert len(grid) == 10 * 5 * 5 and grid.min() > 0 and (grid.max(0) < [2, 1, 1]).all()
+    rnd = nio.sample_mesh_points(v, t, "uniform", 8)
+    assert len(rnd) == 8 ** 3                                        # the box fills its own bounding box
+    # NeuMA-Synthetic layout: frames 0, 3, 7 of one view; init_frame = 3 -> steps == [3] (what dataset.steps / evaluate rely on)
+    root = tmp_path / "scene"
+    (root / "data_dynamic").mkdir(parents=True)
+    entries = []
+    for step in (0, 3, 7):
+        name = f"./data_dynamic/r_0_{step:03d}.png"
+        (root / name).write_bytes(b"")
+        entries.append({"file_path": name, "c2w": np.eye(4)[:3].tolist(), "intrinsic": [[100.0, 0, 32.0], [0, 100.0, 24.0], [0, 0, 1]]})
+    (root / "data_dynamic.json").write_text(json.dumps(entries))
+    out = nio.read_neuma_synthetic_cameras(str(root), "data_dynamic.json", True, init_frame=3)
+    assert out["steps"] == [3] and [c.step for c in out["cam_infos"]] == [3]
+    assert nio.read_neuma_synthetic_cameras(str(root), "data_dynamic.json", True)["steps"] == [0, 3, 7]
