@@ -43,16 +43,27 @@ def prof_table(lib):
 MATERIAL_FLOPS = {"k_material_fwd": 11008.0, "k_material_bwd": 3 * 11008.0, "k_material_bwd_pair": 6 * 11008.0}
 
 
-def algorithmic_bytes(kernel: str, rt, D: float) -> float:
-    """Compulsory HBM bytes of ONE launch of `kernel` (formulas stated in DESIGN.md §Kernels)."""
+def algorithmic_bytes(kernel: str, rt, D) -> float:
+    """Compulsory HBM bytes of ONE launch of `kernel` (formulas stated in DESIGN.md §Kernels).
+    D: (Gaussian, tile) pairs of a view, or the dict of render.view_stats: the compositing kernels are then charged only the
+    part of the lists they have to read - the entries up to where the tiles' pixels saturate (`walked`, from the forward
+    pass's own walk record): 12 B per examined list entry (key + tile mask) and 36 B of Gaussian record per pair among them
+    (pro rata: pairs x walked / list_entries), + the per-pixel state."""
     cfg = rt.scene.cfg
     N, K, W, H = rt.n_local, rt.K, cfg["W"], cfg["H"]   # simulation kernels see this rank's particles
     T = rt.touched_nodes
     base = kernel.split("<")[0]
+    if isinstance(D, dict):
+        st = D
+        D = float(st["pairs"])
+        walked = float(st["walked"]) if st.get("walked") else float(st["list_entries"])
+        comp = 12.0 * walked + 36.0 * D * min(1.0, walked / max(float(st["list_entries"]), 1.0))
+    else:
+        comp = 40.0 * D
     table = {
-        "k_render_bwd": 40.0 * D + 20.0 * W * H + 36.0 * K,
-        "k_render": 40.0 * D + 20.0 * W * H,
-        "k_render_fix": 40.0 * D + 20.0 * W * H,      # second pass of the split compositing: at most the same lists once more
+        "k_render_bwd": comp + 20.0 * W * H + 36.0 * K,
+        "k_render": comp + 20.0 * W * H,
+        "k_render_fix": comp + 20.0 * W * H,      # second pass of the split compositing: at most the same stretch once more
         "k_preprocess": (4 * (3 + 6 + 1) + 12 * (cfg["sh"] + 1) ** 2) * K + 60.0 * K,
         "k_preprocess_bwd": (4 * (3 + 6) + 12 * (cfg["sh"] + 1) ** 2) * K + 36.0 * K + 12.0 * K,
         "k_material_fwd": 72.0 * N,
@@ -242,19 +253,21 @@ def main():
         elapsed = float(t)
     fps = args.steps / elapsed
 
-    # (Gaussian, tile) pairs of one full view, for the byte accounting
-    D = 0.0
+    # (Gaussian, tile) pairs, list entries and walked list entries of one full view, for the byte accounting
+    D, vstats = 0.0, None
     try:
         from neuma_amd.tune import compute_bindings_xyz, compute_bindings_F
         with torch.no_grad():
             m3 = compute_bindings_xyz(last.x, rt.start[0], rt.g_start, rt.bindings)
             dg = compute_bindings_F(last.F, rt.bindings)
-            from neuma_amd.render import deform_cov_by_F, get_rasterizer, count_tile_pairs
+            from neuma_amd.render import deform_cov_by_F, get_rasterizer, view_stats
             cov = deform_cov_by_F(rt._cov, dg)
             rast = get_rasterizer(rt.cameras[0], rt.gaussians.active_sh_degree, False, rt.background)
-            D = float(count_tile_pairs(rast, m3.contiguous(), rt._opacity, shs=rt._shs, cov3D_precomp=cov))
+            vstats = view_stats(rast, m3.contiguous(), rt._opacity, shs=rt._shs, cov3D_precomp=cov)
+            D = float(vstats["pairs"])
     except Exception as e:  # accounting only
-        print(f"[bench] pair count unavailable: {e}", file=sys.stderr)
+        print(f"[bench] view statistics unavailable: {e}", file=sys.stderr)
+    Dacc = vstats if (vstats is not None and world == 1) else D
 
     pmc, pmc_mfma = {}, {}
     try:        # HBM bytes per launch and matrix-pipe counters from the committed PMC passes (profiles/pmc_traffic.json, tools/make_profile_md.py)
@@ -285,12 +298,12 @@ def main():
                 cached = os.environ.get("NEUMA_ACT_CACHE", "auto") != "0" and not args.per_op
                 roof["activation_cache"] = bool(cached)
                 # with the cache the kernel runs 204 of the 284 MFMAs per tile (second and third layer of the forward pass loaded, first recomputed)
-                roof["frac_of_executed_flops"] = round(achieved / 157.3 * (204.0 / 284.0 if cached else 1.0), 5)
+                roof["frac_of_executed_flops"] = round(achieved / 157.3 * (204.0 / 284.0 if cached else 1.0), 5)      # (replaced below by the counted flops when a PMC pass of this workload is on file)
         else:
             frac_view = 1.0
             if world > 1 and name.startswith(("k_render", "k_preprocess")):
                 frac_view = 1.0 / world            # a rank composites 1/world of the tile rows per launch on average
-            ab = algorithmic_bytes(name, rt, D) * frac_view
+            ab = algorithmic_bytes(name, rt, Dacc) * frac_view
             achieved = ab / avg_s / 1e9 if avg_s > 0 else 0.0
             roof = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(achieved / 8000.0, 5), "traffic": None, "launches": calls, "avg_us": round(avg_s * 1e6, 2),
@@ -350,14 +363,20 @@ def main():
         except Exception as e:
             print(f"[bench] cpu baseline unavailable: {e}", file=sys.stderr)
 
+    # PMC-derived fields are NOT measurements of this run: they are copied from the committed rocprofv3 counter passes of the
+    # same workload and build (profiles/pmc_traffic.json, made by tools/make_profile_md.py) and marked "static": true
     if roof is not None and roof["kernel"].split("<")[0] in pmc and args.workload == "metric" and world == 1:
         roof["traffic"] = pmc[roof["kernel"].split("<")[0]]["hbm_bytes_per_launch"]
-        roof["traffic_source"] = "profiles/pmc_traffic.json: rocprofv3 PMC passes of this workload (2 x FETCH_SIZE + WRITE_SIZE per launch)"
+        roof["traffic_static"] = {"static": True, "source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of "
+                                                            "this workload (2 x FETCH_SIZE + WRITE_SIZE per launch)"}
     if roof is not None and roof["kernel"].split("<")[0] in pmc_mfma and args.workload == "metric" and world == 1:
         m = pmc_mfma[roof["kernel"].split("<")[0]]
-        roof["mfma_busy_pct_of_simd_cycles"] = m["mfma_busy_pct_of_simd_cycles"]      # SQ_VALU_MFMA_BUSY_CYCLES / (duration x 2.4 GHz x 1024 SIMDs)
-        roof["mfma_flops_counted"] = m["mfma_flops"]                                  # SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 per launch
-        roof["counter_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 ... pass of this workload)"
+        roof["counters_static"] = {"static": True, "mfma_busy_pct_of_simd_cycles": m["mfma_busy_pct_of_simd_cycles"],
+                                   "mfma_flops_counted": m["mfma_flops"],
+                                   "source": "profiles/pmc_traffic.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 ... "
+                                             "pass of this workload; MOPS x 512 = flops per launch)"}
+        if roof.get("avg_us"):      # the flops the kernel executes (counted) over THIS run's measured duration
+            roof["frac_of_executed_flops"] = round(m["mfma_flops"] / (roof["avg_us"] * 1e-6) / 1e12 / 157.3, 5)
     devices = [f"rank {rank}: cuda:{local} {torch.cuda.get_device_name(dev)}"]
     if world > 1:
         gathered = [None] * world
@@ -384,7 +403,13 @@ def main():
             "cpu_baseline": cpu,
             "kernel_breakdown_ms_per_frame": {k: round(v[1], 3) for k, v in sorted(full.items(), key=lambda kv: -kv[1][1])[:12]},
             "kernel_time_fraction_of_frame": round(total_ms / (1e3 * elapsed / args.steps), 3),
-            "kernel_rooflines": kernel_rooflines(full, rt, D),
+            "kernel_time_note": "sum of the HIP-event durations of every launch of ONE profiled frame (its views rendered one after "
+                                "the other so that the events do not overlap) over the timed frame time; the timed frames run their V "
+                                "views on V streams side by side, so the sum exceeds the frame (> 1)",
+            "timed_region_s": round(elapsed, 4),
+            "view_stats": vstats,
+            "shard_cost_model": cost if world > 1 else None,
+            "kernel_rooflines": kernel_rooflines(full, rt, Dacc),
             "frame_ms_gpu": {"median": round(per_frame[len(per_frame) // 2], 3), "p10": round(per_frame[len(per_frame) // 10], 3),
                              "p90": round(per_frame[(9 * len(per_frame)) // 10], 3)},
             "rates": rates,

@@ -84,6 +84,7 @@ struct __attribute__((aligned(64))) GRec { float x, y, a, b, c, lop, r, g, bl, o
 struct State {
   uint32_t* hdr;       // [2] pairs binned (may exceed cap) [3] overflow flag [4..5] exact pair count (stats) [6] largest cell
                        // [8] (tile, segment) work items of the split compositing [9] segment length [10] forward splitting allowed
+                       // [11] hinted plan [12] work items the plan asked for [14..15] sum over the tiles of their lists' lengths
   float2* xy; float* depth; float4* conop; float* rgb; uint32_t* clamped; int* rad;
   GRec* recs;
   uint32_t* pad;       // per cell, one counter per 128-byte line (NM_PAD words apart): count, then fill cursor.  Neighbouring
@@ -898,10 +899,10 @@ __global__ void __launch_bounds__(1024) k_split_plan(RK k, int nbx, uint32_t bus
                                                      uint32_t* __restrict__ tile_mode, uint2* __restrict__ work,
                                                      uint32_t* __restrict__ seg_pos, const uint32_t* __restrict__ hint,
                                                      uint32_t fwd_len, uint32_t hint_seg) {
-  __shared__ unsigned long long s_total;
+  __shared__ unsigned long long s_total, s_lists;
   __shared__ uint32_t s_busy, s_base, s_used, s_scan[1024];
   const int tid = threadIdx.x, rows = k.ty1 - k.ty0, ntile = k.gx * rows;
-  if (tid == 0) { s_total = 0ull; s_busy = 0u; s_base = 0u; s_used = 0u; }
+  if (tid == 0) { s_total = 0ull; s_lists = 0ull; s_busy = 0u; s_base = 0u; s_used = 0u; }
   __syncthreads();
   auto list_len = [&](int i) -> uint32_t {
     const int tx = i % k.gx, ty = i / k.gx + k.ty0;
@@ -920,16 +921,43 @@ __global__ void __launch_bounds__(1024) k_split_plan(RK k, int nbx, uint32_t bus
   // accuracy.  Every thread owns NM_PLAN_PER consecutive tiles (all their loads in flight at once).
   if (hint && !hdr[3] && ntile <= 1024 * NM_PLAN_PER) {
     uint32_t ln[NM_PLAN_PER], ll[NM_PLAN_PER];
+    int tt[NM_PLAN_PER];                 // tile index ty * gx + tx of the thread's tiles (-1: past the end)
     unsigned long long tot = 0ull; uint32_t any = 0u;
+    {
+      // thread t owns tiles t, t + 1024, ...: this kernel is ONE workgroup on one CU, and with eight consecutive tiles per
+      // thread every load and store instruction of a wave touched 64 different cache lines (32 us; 9 us this way)
 #pragma unroll
-    for (int u = 0; u < NM_PLAN_PER; ++u) {
-      const int i = tid * NM_PLAN_PER + u;
-      uint32_t h = 0u; ln[u] = 0u;
-      if (i < ntile) { h = hint[(i / k.gx + k.ty0) * k.gx + i % k.gx]; ln[u] = list_len(i); }
-      ll[u] = h ? min(ln[u], h + h / 4u + 64u) : 0u;
-      tot += ll[u]; any += ll[u] ? 1u : 0u;
+      for (int u = 0; u < NM_PLAN_PER; ++u) {
+        const int i = u * 1024 + tid;
+        uint32_t h = 0u; ln[u] = 0u; tt[u] = -1;
+        if (i < ntile) {
+          const int ty = i / k.gx, tx = i - ty * k.gx, tyy = ty + k.ty0;
+          tt[u] = tyy * k.gx + tx;
+          h = hint[tt[u]];
+          const int bin = (tyy / NM_BT) * nbx + tx / NM_BT;
+          const long long lo = off[bin * NM_NS], hi = min((long long)off[(bin + 1) * NM_NS], cap);
+          ln[u] = hi > lo ? (uint32_t)(hi - lo) : 0u;
+        }
+        ll[u] = h ? min(ln[u], h + h / 4u + 64u) : 0u;
+        tot += ll[u]; any += ll[u] ? 1u : 0u;
+      }
     }
-    if (any) { atomicAdd(&s_total, tot); atomicAdd(&s_busy, any); }
+    {
+      unsigned long long lt = 0ull;       // (statistics: list entries a tile-by-tile walk of the whole lists would examine)
+#pragma unroll
+      for (int u = 0; u < NM_PLAN_PER; ++u) lt += ln[u];
+      // one LDS atomic per wave, not per thread (1024 64-bit LDS atomics in a row were most of this kernel's time)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        lt += (unsigned long long)__shfl_xor((long long)lt, o, 64);
+        tot += (unsigned long long)__shfl_xor((long long)tot, o, 64);
+        any += (uint32_t)__shfl_xor((int)any, o, 64);
+      }
+      if ((tid & 63) == 0) {
+        if (lt) atomicAdd(&s_lists, lt);
+        if (any) { atomicAdd(&s_total, tot); atomicAdd(&s_busy, any); }
+      }
+    }
     __syncthreads();
     if (s_busy > 0u) {
       uint32_t seg = (uint32_t)((s_total + NM_HINT_WGS - 1) / NM_HINT_WGS);      // (independent of the capacity: see hdr[12])
@@ -949,10 +977,9 @@ __global__ void __launch_bounds__(1024) k_split_plan(RK k, int nbx, uint32_t bus
       if (tid == 1023) s_base = rec + mine;
 #pragma unroll
       for (int u = 0; u < NM_PLAN_PER; ++u) {
-        const int i = tid * NM_PLAN_PER + u;
-        if (i >= ntile) break;
+        if (tt[u] < 0) continue;
         const uint32_t l = ll[u], ns = segments(l), items = ns ? ns + 1u : 0u;
-        const int t = (i / k.gx + k.ty0) * k.gx + i % k.gx;
+        const int t = tt[u];
         const bool ok = ns > 0u && rec + items <= (uint32_t)k.items;
         tile_rec[t] = ok ? rec : 0xFFFFFFFFu;
         tile_ns[t] = ok ? ns : 0u;
@@ -963,10 +990,11 @@ __global__ void __launch_bounds__(1024) k_split_plan(RK k, int nbx, uint32_t bus
       }
       __syncthreads();
       if (tid == 0) { hdr[8] = s_used; hdr[9] = seg; hdr[10] = 1u; hdr[11] = 1u; hdr[12] = s_base; }
+      if (tid == 0) { const unsigned long long lt = s_lists; hdr[14] = (uint32_t)lt; hdr[15] = (uint32_t)(lt >> 32); }
       return;
     }
     __syncthreads();
-    if (tid == 0) { s_total = 0ull; s_busy = 0u; }
+    if (tid == 0) { s_total = 0ull; s_lists = 0ull; s_busy = 0u; }
     __syncthreads();
   }
   unsigned long long tot = 0ull; uint32_t busy = 0u;
@@ -992,7 +1020,7 @@ __global__ void __launch_bounds__(1024) k_split_plan(RK k, int nbx, uint32_t bus
       const int t = (i / k.gx + k.ty0) * k.gx + i % k.gx;
       tile_rec[t] = 0xFFFFFFFFu; tile_ns[t] = 0u; tile_cnt[t] = 0u; tile_mode[t] = 0u;
     }
-    if (tid == 0) { hdr[8] = 0u; hdr[9] = seg; hdr[10] = 0u; }
+    if (tid == 0) { hdr[8] = 0u; hdr[9] = seg; hdr[10] = 0u; hdr[14] = (uint32_t)s_total; hdr[15] = (uint32_t)(s_total >> 32); }
     return;
   }
   for (int i0 = 0; i0 < ntile; i0 += 1024) {     // segments per tile, exclusive prefix in tile order
@@ -1026,7 +1054,7 @@ __global__ void __launch_bounds__(1024) k_split_plan(RK k, int nbx, uint32_t bus
     if (tid == 1023) s_base += s_scan[1023];
     __syncthreads();
   }
-  if (tid == 0) { hdr[8] = s_used; hdr[9] = seg; hdr[10] = s_total <= fwd_max ? 1u : 0u; hdr[12] = s_base; }
+  if (tid == 0) { hdr[8] = s_used; hdr[9] = seg; hdr[10] = s_total <= fwd_max ? 1u : 0u; hdr[12] = s_base; hdr[14] = (uint32_t)s_total; hdr[15] = (uint32_t)(s_total >> 32); }
 }
 
 // work items of a hinted plan: one wave per tile writes its (tile, segment) pairs and segment boundaries

@@ -267,6 +267,31 @@ def count_tile_pairs(rasterizer, means3D, opacities, shs=None, colors_precomp=No
     return int(out.value)
 
 
+def view_stats(rasterizer, means3D, opacities, shs=None, colors_precomp=None, cov3D_precomp=None) -> dict:
+    """Statistics of one view for the byte accounting (bench.py): pairs = exact (Gaussian, tile) pairs (count_tile_pairs),
+    list_entries = sum over the tiles of the length of their bin's depth-sorted list (what a tile-by-tile walk of the whole
+    lists would examine), walked = the same up to where the tiles' pixels saturate (the camera's walk record of its last
+    render; 0 if it has none)."""
+    lib = L.lib()
+    cam = rasterizer._cam
+    m3, sh, cp, op, cv = _raster_inputs(means3D, shs, colors_precomp, opacities, cov3D_precomp)
+    dev, K = m3.device, m3.size(0)
+    M = 0 if sh is None else sh.size(1)
+    cap = 8 * K + 4096
+    state_bytes = int(lib.nm_raster_state_bytes(C.byref(cam.cfg), K, cap))
+    state = torch.empty(state_bytes, dtype=torch.uint8, device=dev)
+    radii = torch.empty(K, dtype=torch.int32, device=dev)
+    color = torch.empty(3, cam.cfg.image_height, cam.cfg.image_width, dtype=torch.float32, device=dev)
+    L.check(lib.nm_raster_forward(C.byref(cam.cfg), K, M, L.ptr(m3), L.ptr(sh), L.ptr(cp), L.ptr(op), L.ptr(cv), L.ptr(radii),
+                                  L.ptr(state), state_bytes, cap, L.ptr(color), None, L.stream_ptr(dev)), "nm_raster_forward")
+    out = C.c_int64(0)
+    L.check(lib.nm_raster_count_pairs(C.byref(cam.cfg), K, L.ptr(state), cap, C.byref(out), L.stream_ptr(dev)), "nm_raster_count_pairs")
+    hdr = state[:64].view(torch.int32).cpu().numpy().astype("int64") & 0xFFFFFFFF
+    walk = cam._walk.get(torch.device(dev))
+    return {"pairs": int(out.value), "list_entries": int(hdr[14] + (hdr[15] << 32)),
+            "walked": int(walk.long().sum()) if walk is not None else 0}
+
+
 def split_plan(rasterizer, means3D, opacities, shs=None, colors_precomp=None, cov3D_precomp=None, hinted: bool = False) -> Tuple[int, int]:
     """(work items, segment length) the split compositing chose for this view (nm_raster_set_split; 0 work items = every
     tile composited by one workgroup).  hinted: plan from a copy of the camera's walk record, as its next render will
