@@ -73,9 +73,14 @@ __device__ __forceinline__ void mark_block(int b, int* __restrict__ flags, int* 
 }
 
 // ---------------------------------------------------------------- workgroup scatter (p2g, g2p adjoint)
+#ifndef NM_SC_T
 #define NM_SC_T 256      // threads = particles per workgroup
-#define NM_WT_CAP 2048   // tile nodes a workgroup can own (NM_NPT per thread)
+#endif
+#ifndef NM_WT_CAP
+#define NM_WT_CAP (8 * NM_SC_T)   // tile nodes a workgroup can own (NM_NPT per thread)
+#endif
 #define NM_NPT (NM_WT_CAP / NM_SC_T)
+#define NM_SC_NW (NM_SC_T / 64)   // waves per workgroup
 #define NM_WT_MAXPASS 12 // boxes a wave tries (wave_scatter) before its leftovers go to direct global atomics
 
 #ifdef NM_PHASES
@@ -120,7 +125,7 @@ __device__ __forceinline__ int wave_excl_scan_i(int v, int lane, int& total) {
 struct ScatterLds {
   float4 C[NM_SC_T * 9];     // one i-slab (9 stencil nodes) of every particle's contributions, in cell-sorted order
   float4 tile[NM_WT_CAP];    // node sums of the workgroup's bounding box
-  int cnt[NM_WT_CAP + 4];    // particles per stencil origin -> exclusive offsets (+ total as sentinel)
+  int cnt[NM_WT_CAP + 8];    // particles per stencil origin -> exclusive offsets (+ total as sentinel)
   short run_cell[NM_SC_T];   // compacted list of non-empty origin cells (<= one per particle)
   short ainv[3][NM_SC_T];    // axis compression: compressed coordinate -> grid coordinate
   int red[32];               // block reductions / broadcasts
@@ -297,8 +302,9 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
   __syncthreads();
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    lo[a] = min(min(L.red[a], L.red[6 + a]), min(L.red[12 + a], L.red[18 + a]));
-    hi[a] = max(max(L.red[3 + a], L.red[9 + a]), max(L.red[15 + a], L.red[21 + a]));
+    lo[a] = L.red[a]; hi[a] = L.red[3 + a];
+#pragma unroll
+    for (int w2 = 1; w2 < NM_SC_NW; ++w2) { lo[a] = min(lo[a], L.red[6 * w2 + a]); hi[a] = max(hi[a], L.red[6 * w2 + 3 + a]); }
   }
   __syncthreads();
   if (lo[0] == 0x7fffffff) return;  // nothing enabled in this workgroup
@@ -331,7 +337,9 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
     if (lane == 0) L.red[wave] = wtot;
     __syncthreads();
     for (int w2 = 0; w2 < wave; ++w2) off += L.red[w2];
-    const int total = L.red[0] + L.red[1] + L.red[2] + L.red[3];
+    int total = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < NM_SC_NW; ++w2) total += L.red[w2];
     for (int e = 0; e < E; ++e) { int idx = tid * E + e; if (idx < tot) { amap[idx] = (short)off; off += occ[idx]; } }
     __syncthreads();
     const int st1 = amap[Gp], st2 = amap[2 * Gp];
@@ -399,10 +407,12 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
       int wtot, wnz;
       int off = wave_excl_scan_i(sum, lane, wtot);
       int roff = wave_excl_scan_i(nz, lane, wnz);
-      if (lane == 0) { L.red[wave] = wtot; L.red[4 + wave] = wnz; }
+      if (lane == 0) { L.red[wave] = wtot; L.red[NM_SC_NW + wave] = wnz; }
       __syncthreads();
-      for (int w2 = 0; w2 < wave; ++w2) { off += L.red[w2]; roff += L.red[4 + w2]; }
-      nruns = L.red[4] + L.red[5] + L.red[6] + L.red[7];
+      for (int w2 = 0; w2 < wave; ++w2) { off += L.red[w2]; roff += L.red[NM_SC_NW + w2]; }
+      nruns = 0;
+#pragma unroll
+      for (int w2 = 0; w2 < NM_SC_NW; ++w2) nruns += L.red[NM_SC_NW + w2];
 #pragma unroll
       for (int q = 0; q < NM_NPT; ++q) {
         int c = tid * NM_NPT + q;
