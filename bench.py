@@ -200,8 +200,10 @@ def main():
     group = dist.group.WORLD if world > 1 else None
     rt.group = group
 
+    params = rt.parameters()
+
     def zero_grads():
-        for p in rt.parameters():
+        for p in params:
             p.grad = None
 
     # ---- pick the dominant kernel from a fully profiled frame (outside the timed region)

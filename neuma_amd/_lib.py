@@ -174,9 +174,13 @@ def stream_ptr(device=None) -> int:
     device), so an operator called on tensors of cuda:N while another device is current would otherwise fault."""
     import torch
     if device is not None:
-        dev = torch.device(device)
-        if dev.type == "cuda" and dev.index is not None and dev.index != torch.cuda.current_device():
-            torch.cuda.set_device(dev)
+        dev = device if isinstance(device, torch.device) else torch.device(device)
+        if dev.type == "cuda" and dev.index is not None:
+            if dev.index != torch.cuda.current_device():
+                torch.cuda.set_device(dev)
+            raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)      # (the handle without building a Stream object:
+            if raw is not None:                                             #  this function runs ~10 times per frame)
+                return raw(dev.index)
     return torch.cuda.current_stream(device).cuda_stream
 
 

