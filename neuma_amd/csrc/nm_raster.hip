@@ -295,6 +295,10 @@ __global__ void __launch_bounds__(256) k_preprocess(RK k, int K, const float* __
     radii[i] = 0;
     grad_[i] = 0;
   }
+  if (i == 0) {      // the null record (alpha 0 everywhere): what the padding slots of a compositing trip point at - written
+    float4* np = (float4*)(recs + K);      // whether or not Gaussian 0 itself is visible
+    np[0] = make_float4(0.f, 0.f, -1.f, 0.f); np[1] = make_float4(-1.f, -__builtin_inff(), 0.f, 0.f); np[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   bool live = i < K;
   float mx = 0.f, my = 0.f, mz = 0.f, px = 0.f, py = 0.f;
   float3 pv = make_float3(0.f, 0.f, 0.f);
@@ -366,10 +370,6 @@ __global__ void __launch_bounds__(256) k_preprocess(RK k, int K, const float* __
     depth[i] = pv.z;
     conop[i] = make_float4(cv.c * det_inv, -cv.b * det_inv, cv.a * det_inv, opac[i]);
     rgb[3 * i] = col[0]; rgb[3 * i + 1] = col[1]; rgb[3 * i + 2] = col[2];
-    if (i == 0) {      // the null record (alpha 0 everywhere): what the padding slots of a compositing trip point at
-      float4* np = (float4*)(recs + K);
-      np[0] = make_float4(0.f, 0.f, -1.f, 0.f); np[1] = make_float4(-1.f, -__builtin_inff(), 0.f, 0.f); np[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
     {
       float4* rp = (float4*)(recs + i);
       const float op = opac[i];

@@ -411,6 +411,14 @@ class SceneRuntime(object):
             if not hasattr(self, "_view_streams"):
                 self._view_streams = [torch.cuda.Stream(device=self.device) for _ in range(int(self.num_view_streams or self.V))]
             streams = [self._view_streams[k % len(self._view_streams)] for k in range(len(jobs))]
+        if os.environ.get("NEUMA_HINT_FWD_LEN") is None and getattr(self, "_hint_mode", None) != bool(streams):
+            # several render jobs share the chip (streams): the forward pass walks its tiles front to back and only the reverse
+            # sweep runs in segments - the T = 1 starts of parallel forward segments are extra work that then displaces another
+            # view's (metric frame: 140.3 -> 142.2 frames/s); a view that has the chip to itself needs the segments for its
+            # latency (sf 603 -> 1035 frames/s).  Process-wide knob of the library, set when the situation changes.
+            from . import _lib as L
+            L.check(L.lib().nm_raster_set_hinted((1 << 20) if streams else 0, 256), "nm_raster_set_hinted")
+            self._hint_mode = bool(streams)
         if getattr(self, "fused_tail", True) and os.environ.get("NEUMA_FUSED_TAIL", "1") != "0":
             # one autograd node for binding + covariance push-forward + every render job + loss (_FrameTail)
             self._tail_constants(de_x_prev, g_prev)

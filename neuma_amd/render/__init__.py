@@ -172,10 +172,23 @@ class RenderRecord(object):
     __slots__ = ("cfg", "K", "M", "cap", "has_sh", "m3", "shcol", "op", "cv", "state", "pending")
 
 
+_HINT_ENV_DONE = [False]
+
+
+def _apply_hint_env(lib):
+    """NEUMA_HINT_FWD_LEN / NEUMA_HINT_MINSEG: process-wide tuning of the hinted plan (nm_raster_set_hinted), read once."""
+    if not _HINT_ENV_DONE[0]:
+        _HINT_ENV_DONE[0] = True
+        fl, ms = os.environ.get("NEUMA_HINT_FWD_LEN"), os.environ.get("NEUMA_HINT_MINSEG")
+        if fl is not None or ms is not None:
+            L.check(lib.nm_raster_set_hinted(int(fl) if fl is not None else 0, int(ms) if ms is not None else 256), "nm_raster_set_hinted")
+
+
 def raster_forward_raw(cam: RasterCamera, m3: Tensor, sh: Optional[Tensor], cp: Optional[Tensor], op: Tensor, cv: Tensor):
     """GaussianRasterizer.forward on detached contiguous fp32 inputs, outside autograd: (color, radii, RenderRecord).  Shared by
     the autograd.Function below and by the frame driver's fused node (harness._FrameTail)."""
     lib = L.lib()
+    _apply_hint_env(lib)
     dev = m3.device
     stream = L.stream_ptr(dev)
     K = m3.size(0)

@@ -337,3 +337,23 @@ def test_raster_hinted_split_from_the_previous_render_of_the_camera(opaque, fwd_
     assert abs_max(cases["hinted"][0], oimg) < 1e-3
     for nme, a, b, tol in zip(["means3D", "shs", "opacity", "cov3D"], cases["hinted"][1], ograds, [2e-3, 1e-3, 1e-3, 2e-3]):
         assert rel_max(a, b) < tol, nme
+
+
+def test_raster_when_the_first_gaussian_is_culled():
+    """The padding slots of the compositing loops point at a null record behind the last Gaussian; it must exist whatever
+    happens to Gaussian 0 (a view in which that one is behind the camera crashed the reverse sweep once)."""
+    s, means, cov, op, shs, _, _ = _scene(deg=0, K=900)
+    means = means.clone()
+    means[0] = s.campos + 0.01                      # at the camera: culled by the near plane
+    rast = _gpu_raster(s)
+    ins = [t.to(dev()).requires_grad_(True) for t in (means, shs, op, cov)]
+    for _ in range(2):                              # unhinted, then planned from the walk record
+        img, radii = rast(means3D=ins[0], means2D=None, opacities=ins[2], shs=ins[1], cov3D_precomp=ins[3])
+        assert int(radii[0]) == 0
+        grads = torch.autograd.grad(img.sum(), ins)
+    oins = [t.double().requires_grad_(True) for t in (means, shs, op, cov)]
+    sd = orr.Settings(*[(f.double() if torch.is_tensor(f) else f) for f in s])
+    oimg, _ = orr.render(sd, oins[0], oins[3], oins[2], shs=oins[1])
+    assert abs_max(img, oimg) < 1e-3
+    (og,) = torch.autograd.grad(oimg.sum(), oins[0])
+    assert rel_max(grads[0], og) < 2e-3 and torch.isfinite(grads[0]).all()

@@ -16,6 +16,8 @@ view = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 dev = torch.device("cuda", 0)
 rt = SceneRuntime(synth.make_scene(name), dev)
 lib = _lib.lib()
+if len(sys.argv) > 3:
+    rt.set_start_state(sys.argv[3])
 with torch.no_grad():
     x, v, C_, F = rt.rollout(*rt.start)
     m3 = compute_bindings_xyz(x, rt.x0, rt.gaussians.get_xyz, rt.bindings)
@@ -49,6 +51,8 @@ last = img.reshape(gy, 16, gx, 16).max(axis=(1, 3))               # per tile: po
 binlen = (off[256 * np.arange(1, nbx * nby + 1)].astype(np.int64) - off[256 * np.arange(nbx * nby)].astype(np.int64)).reshape(nby, nbx)
 tl = np.repeat(np.repeat(binlen, 4, 0), 4, 1)[:gy, :gx]
 busy = last > 0
+print("last contributor beyond the end of the tile's list:", int((last > tl).sum()), "tiles; max last", int(last.max()), "max list", int(tl.max()),
+      "pairs binned vs capacity", int(off[ncell.value]), cap)
 print(f"tiles {gx * gy}, busy (something composited) {int(busy.sum())}, with a non-empty list {int((tl > 0).sum())}")
 q = [50, 90, 99, 100]
 print("walk length (list positions up to the last contributor) of busy tiles: mean %.0f  p50/p90/p99/max %s" % (last[busy].mean(), np.percentile(last[busy], q).tolist()))
