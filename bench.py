@@ -246,6 +246,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     gc.enable()
+    rt.flush()              # anything a frame reported late (exchange status, rasterizer overflow) surfaces here, loudly
     per_frame = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     lib.nm_prof_enable(0, None)
     dom = prof_table(lib)

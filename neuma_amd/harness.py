@@ -431,10 +431,20 @@ class SceneRuntime(object):
                 from .sim.shard import reduce_param_grads
                 reduce_param_grads(self.parameters(), self.group)             # each rank saw only its particles
         if self.shard_sim:
-            self.model.exchange.check()      # raises if a substep's block exchange was incomplete (capacity exceeded)
+            # raises if a substep's block exchange was incomplete (capacity exceeded, a particle outside its rank's announced
+            # neighbourhood).  Fused roll-outs report through pinned status words: examined without stalling the frame loop
+            # (one frame late at worst; flush() / the per-operator path wait)
+            self.model.exchange.check(wait=not self.fused)
         if self.world > 1:
             self._collect_stripe_work(jobs)
         return FrameResult(loss.detach(), x.detach(), F.detach())
+
+    def flush(self):
+        """Wait for everything enqueued so far and raise what is still unreported (sharded exchanges, rasterizer overflows)."""
+        from .render import flush_pending
+        if self.shard_sim:
+            self.model.exchange.check()
+        flush_pending()
 
     def _tail_constants(self, de_x_prev, g_prev):
         """Frame-invariant operands of _FrameTail as contiguous fp32 (rebuilt when the start state changes)."""

@@ -268,9 +268,24 @@ class GridExchange(object):
         ev.record()
         self._watched.append((host, ev))
 
-    def check(self) -> None:
+    def check(self, wait: bool = True) -> None:
         """Raise if any substep since the last check exceeded a capacity (one host read).  Called once per backward
-        pass by MPMModel.backward and by the frame driver after the forward roll-out."""
+        pass by MPMModel.backward and by the frame driver after the forward roll-out.
+        wait=False (frame driver, fused roll-outs only): look only at the status words of roll-outs that have FINISHED - no
+        host synchronisation in the frame loop, an incomplete exchange is reported one frame later (and at the latest by the
+        next check() with wait=True, which every consumer of final results calls)."""
+        if not wait:
+            bits, keep = 0, []
+            for host, ev in self._watched:
+                if ev.query():
+                    bits |= int(host[0])
+                else:
+                    keep.append((host, ev))
+            self._watched = keep
+            if bits:
+                raise L.NeumaHipError(f"sharded substep incomplete ({explain_status(bits)}): cap={self.cap}, cap_shared={self.cap_shared}, "
+                                      f"cap_dil={self.cap_dil}, cap_frame={self.cap_frame}; re-create the exchange with larger capacities")
+            return
         bits = int(self.status.item())
         for host, ev in self._watched:
             ev.synchronize()
