@@ -357,3 +357,49 @@ def test_raster_when_the_first_gaussian_is_culled():
     assert abs_max(img, oimg) < 1e-3
     (og,) = torch.autograd.grad(oimg.sum(), oins[0])
     assert rel_max(grads[0], og) < 2e-3 and torch.isfinite(grads[0]).all()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_raster_random_scenes_unhinted_hinted_and_stripes_agree(seed):
+    """Self-consistency sweep over random scenes (count, size, opacity, image shape incl. partial edge tiles, SH degree,
+    culled leading Gaussians): the first (unhinted) render, the renders planned from the walk record with parallel forward
+    segments / front-to-back forward, and the two halves of a stripe split all give the same image and gradients."""
+    from neuma_amd import _lib
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(100 + seed)
+    K = int(torch.randint(300, 4000, (1,), generator=g))
+    W = int(torch.randint(40, 200, (1,), generator=g)); H = int(torch.randint(40, 160, (1,), generator=g))
+    deg = int(torch.randint(0, 4, (1,), generator=g))
+    lo = float(0.01 + 0.05 * torch.rand(1, generator=g)); hi = lo + float(0.02 + 0.15 * torch.rand(1, generator=g))
+    s, means, cov, op, shs, _, _ = _scene(K=K, W=W, H=H, deg=deg, seed=seed, spread=float(0.2 + 0.5 * torch.rand(1, generator=g)), scale=(lo, hi))
+    if seed % 2:
+        op = torch.clamp(op * 3.0, max=0.995)
+    if seed % 3 == 0:
+        means = means.clone(); means[:5] = s.campos + 0.01          # culled, incl. Gaussian 0
+    gw = torch.randn(3, H, W, generator=g).to(dev())
+
+    def render(rast, rows=None):
+        ins = [t.to(dev()).requires_grad_(True) for t in (means, shs, op, cov)]
+        img, _ = rast(means3D=ins[0], means2D=None, opacities=ins[2], shs=ins[1], cov3D_precomp=ins[3])
+        grads = torch.autograd.grad((img * gw).sum(), ins)
+        return img.detach().clone(), [x.clone() for x in grads]
+
+    try:
+        _lib.check(lib.nm_raster_set_split(0, 32, 1 << 21), "nm_raster_set_split")
+        ref = render(_gpu_raster(s))
+        for fwd_len in (0, 1 << 20, 64):
+            _lib.check(lib.nm_raster_set_hinted(fwd_len, 16 if seed % 2 else 48), "nm_raster_set_hinted")
+            rast = _gpu_raster(s)
+            outs = [render(rast) for _ in range(3)]
+            for img, grads in outs:
+                assert abs_max(img, ref[0]) < 3e-6, (fwd_len,)
+                for a, b in zip(grads, ref[1]):
+                    assert torch.isfinite(a).all() and rel_max(a, b) < 5e-5, (fwd_len,)
+        gy = (H + 15) // 16
+        if gy >= 2:
+            cut = max(1, gy // 2)
+            parts = [render(_gpu_raster(s, tile_rows=r)) for r in ((0, cut), (cut, gy))]
+            assert abs_max(parts[0][0] + parts[1][0], ref[0]) < 3e-6
+    finally:
+        _lib.check(lib.nm_raster_set_split(512, 512, 1 << 21), "nm_raster_set_split")
+        _lib.check(lib.nm_raster_set_hinted(0, 256), "nm_raster_set_hinted")
