@@ -153,6 +153,10 @@ def lib():
         if not LIB_PATH.exists():
             raise NeumaHipError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                 f"(or `make -C neuma_amd/csrc`). neuma_amd has no CPU fallback.")
+        # torch first: it ships its own libamdhip64, and the library must bind to the HIP runtime the process's tensors live in
+        # (loaded before torch it binds to /opt/rocm's copy - two runtimes in one process, and launches fail with
+        # "no ROCm-capable device is detected")
+        import torch  # noqa: F401
         handle = C.CDLL(str(LIB_PATH))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError here == header/library mismatch
