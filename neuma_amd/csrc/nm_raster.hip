@@ -1382,7 +1382,7 @@ struct PixB {
   float T_final;
   uint32_t last;            // positions > last do not contribute for this pixel
   float dp0, dp1, dp2;      // dL/dpixel
-  float ar0, ar1, ar2, last_alpha, lc0, lc1, lc2;    // colour composited behind (upstream renderCUDA backward recurrence)
+  float ar0, ar1, ar2;      // colour composited behind the Gaussian about to be visited (upstream renderCUDA backward: accum_rec)
 };
 // Reverse walk of one tile over list positions (floor, tile_top] of its bin (1-based, counted from lo): the bin's list is
 // examined NM_RB_SCAN candidates at a time, back to front (tile-mask bit test); the survivors are staged in LDS NM_RB_BATCH
@@ -1405,6 +1405,7 @@ __device__ __forceinline__ void render_bwd_range(BwdLdsR& L, const RK& k, long l
   uint32_t wave_last = P.last;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, o, 64));
+  wave_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_last);     // (uniform: lets `pos > wave_last` be a scalar branch)
   if (lane == 0) L.last[wave] = wave_last;
   __syncthreads();
   const uint32_t tile_last = max(max(L.last[0], L.last[1]), max(L.last[2], L.last[3]));
@@ -1457,34 +1458,36 @@ __device__ __forceinline__ void render_bwd_range(BwdLdsR& L, const RK& k, long l
       const float alpha = fminf(0.99f, g2.y * G);
       const bool act = pos <= P.last && !(e2 > 0.f) && !(alpha < 1.0f / 255.0f);
       if (__ballot(act) == 0ull) return;      // whole wave skips this Gaussian
-      float g[8], gop = 0.f;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) g[q] = 0.f;
-      if (act) {
-        // one hardware reciprocal (1 ulp) for both quotients below: the IEEE divisions were a quarter of the
-        // instructions of an evaluated (pixel, Gaussian) pair; alpha <= 0.99 keeps the denominator >= 0.01
-        const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);
-        P.T = P.T * inv1ma;
-        const float dch = alpha * P.T;
-        const float c0 = g1.z, c1 = g1.w, c2 = g2.x;
-        P.ar0 = P.last_alpha * P.lc0 + (1.f - P.last_alpha) * P.ar0; P.lc0 = c0;
-        P.ar1 = P.last_alpha * P.lc1 + (1.f - P.last_alpha) * P.ar1; P.lc1 = c1;
-        P.ar2 = P.last_alpha * P.lc2 + (1.f - P.last_alpha) * P.ar2; P.lc2 = c2;
-        float dL_dalpha = (c0 - P.ar0) * P.dp0 + (c1 - P.ar1) * P.dp1 + (c2 - P.ar2) * P.dp2;
-        g[5] = dch * P.dp0; g[6] = dch * P.dp1; g[7] = dch * P.dp2;
-        dL_dalpha *= P.T;
-        P.last_alpha = alpha;
-        dL_dalpha += (-P.T_final * inv1ma) * bg_dot;
-        const float dL_dG = g2.y * dL_dalpha;
-        const float gdx = G * dx, gdy = G * dy;
-        // dG/d(delta) = -G (conic . delta) with conic = -(2a, b, 2c) / log2(e): the 1/log2(e) sits in kx, ky
-        g[0] = dL_dG * (2.f * g0.z * gdx + g0.w * gdy) * kx;   // d/d(ndc x)
-        g[1] = dL_dG * (2.f * g1.x * gdy + g0.w * gdx) * ky;
-        g[2] = -0.5f * gdx * dx * dL_dG;       // d/d conic.x
-        g[3] = -gdx * dy * dL_dG;              // d/d conic.y (full off-diagonal derivative)
-        g[4] = -0.5f * gdy * dy * dL_dG;       // d/d conic.z
-        gop = G * dL_dalpha;                   // d/d opacity
-      }
+      // Mask-free recurrence: an inactive lane takes part with alpha = 0 - its T (x 1 / (1 - 0)) and its colour behind
+      // (ar <- alpha c + (1 - alpha) ar) stay as they are and every gradient term carries a factor alpha or dL/dalpha, which
+      // is zeroed for it.  Upstream keeps (last_alpha, last_colour) and applies them one Gaussian late; updating `ar` right
+      // after its use is the same recurrence without the two extra state variables and their per-lane selects.
+      const float al = act ? alpha : 0.f;
+      // one hardware reciprocal (1 ulp) for both quotients below: the IEEE divisions were a quarter of the
+      // instructions of an evaluated (pixel, Gaussian) pair; alpha <= 0.99 keeps the denominator >= 0.01
+      const float inv1ma = __builtin_amdgcn_rcpf(1.f - al);
+      P.T = P.T * inv1ma;
+      const float dch = al * P.T;
+      const float c0 = g1.z, c1 = g1.w, c2 = g2.x;
+      float dL_dalpha = (c0 - P.ar0) * P.dp0 + (c1 - P.ar1) * P.dp1 + (c2 - P.ar2) * P.dp2;
+      P.ar0 = al * c0 + (1.f - al) * P.ar0;
+      P.ar1 = al * c1 + (1.f - al) * P.ar1;
+      P.ar2 = al * c2 + (1.f - al) * P.ar2;
+      float g[8];
+      g[5] = dch * P.dp0; g[6] = dch * P.dp1; g[7] = dch * P.dp2;
+      dL_dalpha *= P.T;
+      dL_dalpha += (-P.T_final * inv1ma) * bg_dot;
+      dL_dalpha = act ? dL_dalpha : 0.f;
+      const float dL_dG = g2.y * dL_dalpha;
+      const float Gm = act ? G : 0.f;        // (an inactive lane's G may be inf - e2 > 0 - and 0 x inf would poison the wave's sums)
+      const float gdx = Gm * dx, gdy = Gm * dy;
+      // dG/d(delta) = -G (conic . delta) with conic = -(2a, b, 2c) / log2(e): the 1/log2(e) sits in kx, ky
+      g[0] = dL_dG * (2.f * g0.z * gdx + g0.w * gdy) * kx;   // d/d(ndc x)
+      g[1] = dL_dG * (2.f * g1.x * gdy + g0.w * gdx) * ky;
+      g[2] = -0.5f * gdx * dx * dL_dG;       // d/d conic.x
+      g[3] = -gdx * dy * dL_dG;              // d/d conic.y (full off-diagonal derivative)
+      g[4] = -0.5f * gdy * dy * dL_dG;       // d/d conic.z
+      const float gop = Gm * dL_dalpha;      // d/d opacity
       const float tot = wave_fold8(g, lane);
       if (lane < 8) my_acc[j * NM_NG + slot] += tot;
       if (WITH_OPACITY) {
@@ -1564,8 +1567,7 @@ __device__ __forceinline__ void bwd_whole(BwdLdsR& L, const RK& k, int nbx, int 
 // reverse walk of one segment of a candidate tile (k_split_plan), all segments of a tile in parallel.  The state a pixel
 // arrives with at the top of segment s comes from the forward pass's checkpoints: T behind the segment = T in front of
 // segment s+1, colour composited behind it (seen from there) = (C_final - C in front of s+1) / T in front of s+1.  Feeding
-// that colour as (last_alpha, last_colour) = (1, colour) makes the upstream recurrence
-// accum = last_alpha last_colour + (1 - last_alpha) accum start from it.
+// that colour as the recurrence's `colour behind` makes it start from it.
 template <bool WITH_OPACITY>
 __device__ __forceinline__ void bwd_seg(BwdLdsR& L, const RK& k, int nbx, uint32_t w, const uint32_t* __restrict__ off,
                                         const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
@@ -1601,7 +1603,7 @@ __device__ __forceinline__ void bwd_seg(BwdLdsR& L, const RK& k, int nbx, uint32
     const float4 nx = seg_ct[(size_t)(r0 + sg + 1) * NM_TPB + tid], fin = seg_ct[(size_t)(r0 + ns) * NM_TPB + tid];
     const float inv = 1.f / nx.w;
     P.T = nx.w;
-    P.last_alpha = 1.f; P.lc0 = (fin.x - nx.x) * inv; P.lc1 = (fin.y - nx.y) * inv; P.lc2 = (fin.z - nx.z) * inv;
+    P.ar0 = (fin.x - nx.x) * inv; P.ar1 = (fin.y - nx.y) * inv; P.ar2 = (fin.z - nx.z) * inv;
     P.last = ceil_pos;
   } else {
     P.last = last > floor_pos ? last : 0u;      // ends in this segment, or in an earlier one (nothing to do here)
