@@ -812,20 +812,27 @@ __device__ __forceinline__ uint32_t composite_range(CompLds& L, long long lo, lo
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int nq = min(64, nb - 64 * q);          // (wave-uniform)
-        if (nq <= 0 || !live) break;
-        Set A, B;
-        fetch(A, idr[q], 0);
-        for (int j0 = 0; j0 < nq; j0 += 2 * NM_G) {
-          fetch(B, idr[q], j0 + NM_G);
-          __builtin_amdgcn_sched_barrier(0);
+        if (nq <= 0) break;
+        if (live) {
+          Set A, B;
+          fetch(A, idr[q], 0);
+          for (int j0 = 0; j0 < nq; j0 += 2 * NM_G) {
+            fetch(B, idr[q], j0 + NM_G);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int u = 0; u < NM_G; ++u) one(A.a[u], A.b[u], A.c[u], 64 * q + j0 + u);
-          fetch(A, idr[q], (j0 + 2 * NM_G) & 63);
-          __builtin_amdgcn_sched_barrier(0);
+            for (int u = 0; u < NM_G; ++u) one(A.a[u], A.b[u], A.c[u], 64 * q + j0 + u);
+            fetch(A, idr[q], (j0 + 2 * NM_G) & 63);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int u = 0; u < NM_G; ++u) one(B.a[u], B.b[u], B.c[u], 64 * q + j0 + NM_G + u);
-          if (__ballot(fx < kInf) == 0ull) { live = false; break; }
+            for (int u = 0; u < NM_G; ++u) one(B.a[u], B.b[u], B.c[u], 64 * q + j0 + NM_G + u);
+            if (__ballot(fx < kInf) == 0ull) { live = false; break; }
+          }
         }
+        // checkpoints can be taken every 64 hits (the reverse sweep's segments are what lies between two of them).  Every wave
+        // that entered the batch visits ALL of its group ends and its end, in order, whether or not its pixels have stopped on
+        // the way (their state is final then): the waves must agree on the position a boundary is moved to, and a boundary
+        // inside the batch that every wave dies in still has to be taken
+        if (ck && 64 * q + nq < nb) checkpoint(L.hit[h0 + 64 * q + nq - 1]);
       }
       if (lastj >= 0) p.last = L.hit[h0 + lastj];
       wreach = L.hit[h0 + nb - 1];
