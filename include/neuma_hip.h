@@ -271,6 +271,10 @@ int nm_rollout_cache_status(const void* gridcache, const nm_rollout_cfg* cfg, in
 int nm_rollout_forward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cfg, const nm_statics* st,
                        const nm_mlp* elasticity, const nm_mlp* plasticity, float* states, void* gridcache,
                        void* workspace, size_t workspace_bytes, void* stream);
+/* Forward sweep layout (process-wide, default on): plasticity of substep t and elasticity of substep t+1 - the two calls
+ * experiments/finetune.py:364 and :362 make back to back across the loop edge - run as ONE launch per substep boundary, F_{t+1}
+ * passing from one net to the other in registers; off = one launch per net.  Results are bit-identical either way. */
+int nm_rollout_set_forward_pair(int32_t on);
 /* gstate_last: dL/d(x,v,C,F of record S) (24*N floats: x|v|C|F); gstate_first: dL/d(x,v,C,F of record 0) (written);
  * gw_e / gw_p: 5504 floats each = dL/d(w0 | w1 | w2) of the elasticity / plasticity nets, summed over
  * particles and substeps (overwritten). */

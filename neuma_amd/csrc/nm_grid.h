@@ -191,7 +191,11 @@ struct GridRec {
 __device__ __forceinline__ void grid_clear_carry(float4* __restrict__ gm, float4* __restrict__ gv, float4* __restrict__ gg,
                                                  const int* __restrict__ list_prev, const int* __restrict__ count_prev,
                                                  int* __restrict__ list_now, int* __restrict__ count_now,
-                                                 int* __restrict__ count_next, int* __restrict__ flags, int epoch, int wg, int nwg) {
+                                                 int* __restrict__ count_next, int* __restrict__ flags, int epoch, int wg, int nwg,
+                                                 bool keep_gv = false) {
+  // keep_gv (forward pair kernel of the roll-out): the launch that carries this clear is still gathering the previous
+  // substep's velocities - gv is left alone; the coming grid update overwrites the blocks that stay and zeroes those that
+  // drop out (k_grid_op, `dropped`)
   const int cnt = *count_prev;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int nw = nwg * 4, w = wg * 4 + wave;
@@ -204,7 +208,7 @@ __device__ __forceinline__ void grid_clear_carry(float4* __restrict__ gm, float4
       const int node = (list_prev[li] << 6) + lane;
       const bool has = gm[node].w > 0.f;
       gm[node] = z;
-      gv[node] = z;
+      if (!keep_gv) gv[node] = z;
       gg[node] = z;
       if (__ballot(has) != 0ull) keep |= 1ull << it;
     }
@@ -262,6 +266,7 @@ __device__ __forceinline__ void grid_restore(const MpmK& K, const GridRec& rec, 
 //           are being overwritten by whichever workgroup restores it; a block that left the list is zeroed entirely.
 struct GridPrologue {
   int mode;   // 0 = none
+  int keep_gv;    // mode 1 only: leave the velocity array alone (see grid_clear_carry)
   int mat_grid;   // set by the constitutive launcher: workgroups that carry particles (the rest only run the prologue)
   MpmK K;
   float4 *gm, *gv, *gg;
@@ -277,7 +282,7 @@ __device__ __forceinline__ void grid_prologue(const GridPrologue& g, int wg, int
   const int nwg = min(nwg_all, NM_CLEAR_WGS);
   if (g.mode == 1) {
     if (wg < nwg) grid_clear_carry(g.gm, g.gv, g.gg, g.list_prev, g.count_prev, g.list_now, g.count_now, g.count_next, g.flags,
-                                   g.epoch, wg, nwg);
+                                   g.epoch, wg, nwg, g.keep_gv != 0);
     return;
   }
   // mode 2: the first nwg workgroups sweep the previous list, the next nwg restore the record (a launch with fewer
@@ -301,7 +306,7 @@ __device__ __forceinline__ void grid_prologue(const GridPrologue& g, int wg, int
 }
 
 // ---- internal cross-file entry points of the fused roll-out (nm_rollout.hip)
-int nm_mpm_prologue_forward(nm_mpm* h, GridPrologue* g);
+int nm_mpm_prologue_forward(nm_mpm* h, GridPrologue* g, bool keep_gv = false);
 int nm_mpm_prologue_backward(nm_mpm* h, const void* gridrec, int cap, GridPrologue* g);
 int nm_mpm_forward_prepared(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, nm_particles* next, void* gridrec,
                             int32_t cap_blocks, void* stream);
@@ -333,6 +338,9 @@ int nm_material_fwd_launch(int32_t n, int32_t kind, float alpha, const float* F,
                            const GridPrologue* pro, const G2pFuse* g2p, void* stream,
                            float* svd_out = nullptr /* roll-out: keep U | sigma | V for the reverse sweep (21 n floats) */,
                            float* act_out = nullptr /* roll-out: keep the hidden activations (nm_material_act_floats(n)) */);
+int nm_material_fwd_pair_launch(int32_t n, float alpha_p, const float* wperm_p, const float* wperm_e, float* F_next,
+                                float* stress_next, const GridPrologue* pro, const G2pFuse* g2p, void* stream, float* svd_p,
+                                float* svd_e, float* act_p, float* act_e);
 size_t nm_material_act_floats(int32_t n);
 // g2p fused into the next constitutive kernel (roll-out forward): fills the descriptor / runs the substep without its g2p
 int nm_mpm_g2p_fuse(nm_mpm* h, const nm_statics* st, const nm_particles* cur, nm_particles* next, G2pFuse* f);

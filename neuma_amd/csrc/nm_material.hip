@@ -478,6 +478,73 @@ static inline void nm_wave_quota(int n, int& grid, int& q) {
   if (grid < 1) grid = 1;
 }
 
+// One round (up to 64 particles, one per lane) of a constitutive net on the wave's LDS slices: invariants of Fp -> MLP on the
+// round's 16-particle tiles -> the net's output matrix (meta.py:219-221 / 486-488).  p = the lane's particle, c0 = the round's
+// first particle (a multiple of 16: tile id = particle / 16), ntile wave-uniform.
+template <int KIND, bool ACT>
+__device__ __forceinline__ M3 material_fwd_round(const M3& Fp, bool valid, int n, int p, int c0, int ntile, int lane, float alpha,
+                                                 const float* sP0, const float* sP1, const float* sP2, float* zb, float* yb,
+                                                 float* __restrict__ svd_out, f4* __restrict__ act_out) {
+  const int j = lane & 15, g = lane >> 4;
+  M3 R, U, V;
+  float z[13], s[3];
+  nm_features(Fp, z, R, U, V, s);
+  if (svd_out && valid) svd_store(svd_out, n, p, U, s, V);
+#pragma unroll
+  for (int c = 0; c < 13; ++c) zb[lane * 17 + c] = z[c];
+  zb[lane * 17 + 13] = 0.f; zb[lane * 17 + 14] = 0.f; zb[lane * 17 + 15] = 0.f;
+  __builtin_amdgcn_wave_barrier();
+  // layer-0 B operands of all four column tiles first, results kept in registers: the tile loop itself then has
+  // no LDS traffic besides the (hoisted) weights, so the scheduler may overlap one tile's GELU with another's MFMAs
+  float zin[4][4];
+  f4 yv[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) zin[ct][ks] = zb[(ct * 16 + j) * 17 + 4 * ks + g];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    if (ct < ntile) {     // wave-uniform
+      MlpFwd m;
+      AGroup<8> first;
+      a_fetch<8>(first, sP0, lane, 0);
+      if (ACT)
+        mlp_forward_tile<true>(sP0, sP1, sP2, zin[ct], lane, first, m, nullptr, nullptr,
+                               act_out + (size_t)((c0 >> 4) + ct) * NM_ACT_SLOTS * 64);
+      else
+        mlp_forward_tile<false>(sP0, sP1, sP2, zin[ct], lane, first, m);
+      yv[ct] = m.y;
+    } else {
+      yv[ct] = (f4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int row = 4 * g + r;
+      if (row < 9) yb[(ct * 16 + j) * 9 + row] = yv[ct][r];
+    }
+  __builtin_amdgcn_wave_barrier();
+  M3 X;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) X.m[i] = yb[lane * 9 + i];
+  M3 Xs;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Xs.m[3 * r + c] = 0.5f * (X.m[3 * r + c] + X.m[3 * c + r]);
+  M3 RX = m3_mul(R, Xs), o;
+  if (KIND == NM_ELASTICITY) {
+    o = m3_mul_nt(RX, Fp);  // R X F^T  (meta.py:219-221)
+  } else {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o.m[i] = alpha * RX.m[i] + Fp.m[i];  // meta.py:486-488
+  }
+  __builtin_amdgcn_wave_barrier();
+  return o;
+}
+
 template <int KIND, bool ACT>
 __global__ void __launch_bounds__(256) k_material_fwd(int n, int q, float alpha, const float* __restrict__ F,
                                                       const float* __restrict__ w0, const float* __restrict__ w1,
@@ -504,7 +571,6 @@ __global__ void __launch_bounds__(256) k_material_fwd(int n, int q, float alpha,
   __syncthreads();
   NM_PH(0)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int j = lane & 15, g = lane >> 4;
   float* zb = sZ[wave];
   float* yb = sY[wave];
   // wave w owns particles [w*q, (w+1)*q), q a multiple of 16 (nm_wave_quota): every wave runs the same number of SVD
@@ -521,68 +587,50 @@ __global__ void __launch_bounds__(256) k_material_fwd(int n, int q, float alpha,
     } else if (valid) {
       Fp = m3_load(F + 9 * p);
     }
-    M3 R, U, V;
-    float z[13], s[3];
-    nm_features(Fp, z, R, U, V, s);
-    if (svd_out && valid) svd_store(svd_out, n, p, U, s, V);
-#pragma unroll
-    for (int c = 0; c < 13; ++c) zb[lane * 17 + c] = z[c];
-    zb[lane * 17 + 13] = 0.f; zb[lane * 17 + 14] = 0.f; zb[lane * 17 + 15] = 0.f;
-    __builtin_amdgcn_wave_barrier();
     NM_PH(1)
-    // layer-0 B operands of all four column tiles first, results kept in registers: the tile loop itself then has
-    // no LDS traffic besides the (hoisted) weights, so the scheduler may overlap one tile's GELU with another's MFMAs
-    float zin[4][4];
-    f4 yv[4];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) zin[ct][ks] = zb[(ct * 16 + j) * 17 + 4 * ks + g];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      if (ct < ntile) {     // wave-uniform
-        MlpFwd m;
-        AGroup<8> first;
-        a_fetch<8>(first, sP0, lane, 0);
-        if (ACT)      // tiles are 16 consecutive particles starting at a multiple of 16 (nm_wave_quota): tile id = particle / 16
-          mlp_forward_tile<true>(sP0, sP1, sP2, zin[ct], lane, first, m, nullptr, nullptr,
-                                 act_out + (size_t)((c0 >> 4) + ct) * NM_ACT_SLOTS * 64);
-        else
-          mlp_forward_tile<false>(sP0, sP1, sP2, zin[ct], lane, first, m);
-        yv[ct] = m.y;
-      } else {
-        yv[ct] = (f4){0.f, 0.f, 0.f, 0.f};
-      }
-    }
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int row = 4 * g + r;
-        if (row < 9) yb[(ct * 16 + j) * 9 + row] = yv[ct][r];
-      }
-    __builtin_amdgcn_wave_barrier();
-    NM_PH(2)
-    M3 X;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) X.m[i] = yb[lane * 9 + i];
-    M3 Xs;
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) Xs.m[3 * r + c] = 0.5f * (X.m[3 * r + c] + X.m[3 * c + r]);
-    M3 RX = m3_mul(R, Xs), o;
-    if (KIND == NM_ELASTICITY) {
-      o = m3_mul_nt(RX, Fp);  // R X F^T  (meta.py:219-221)
-    } else {
-#pragma unroll
-      for (int i = 0; i < 9; ++i) o.m[i] = alpha * RX.m[i] + Fp.m[i];  // meta.py:486-488
-    }
+    const M3 o = material_fwd_round<KIND, ACT>(Fp, valid, n, p, c0, ntile, lane, alpha, sP0, sP1, sP2, zb, yb, svd_out, act_out);
     if (valid) m3_store(out + 9 * p, o);
-    __builtin_amdgcn_wave_barrier();
-    NM_PH(3)
+    NM_PH(2)
   }
   NM_PH_STORE
+}
+
+// Roll-out forward, substeps t and t+1 in one launch (finetune.py:362-364 seen from the particle): g2p of substep t ->
+// trial F -> plasticity net -> F_{t+1} (checkpointed) -> elasticity net -> stress_{t+1}.  F_{t+1} stays in registers between
+// the nets, both nets' operands are staged once, and the launch carries the grid housekeeping of substep t+1 (GridPrologue
+// mode 1 with keep_gv: the velocities are still being gathered here; the grid update of substep t+1 zeroes what drops out).
+template <bool ACT>
+__global__ void __launch_bounds__(256) k_material_fwd_pair(int n, int q, float alpha, const float* __restrict__ wperm_p,
+                                                           const float* __restrict__ wperm_e, float* __restrict__ F_next,
+                                                           float* __restrict__ stress_next, GridPrologue pro, G2pFuse gf,
+                                                           float* __restrict__ svd_p, float* __restrict__ svd_e,
+                                                           f4* __restrict__ act_p, f4* __restrict__ act_e) {
+  __shared__ __attribute__((aligned(16))) float sPp[NM_PERM_FWD];
+  __shared__ __attribute__((aligned(16))) float sPe[NM_PERM_FWD];
+  __shared__ __attribute__((aligned(16))) float sBuf[4 * 64 * 17 + 4 * 64 * 9];
+  float (*sZ)[64 * 17] = reinterpret_cast<float (*)[64 * 17]>(sBuf);
+  float (*sY)[64 * 9] = reinterpret_cast<float (*)[64 * 9]>(sBuf + 4 * 64 * 17);
+  if (NM_PROLOGUE_SPLIT(pro)) return;
+  stage_permuted<NM_PERM_FWD>(wperm_p, sPp);
+  stage_permuted<NM_PERM_FWD>(wperm_e, sPe);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* zb = sZ[wave];
+  float* yb = sY[wave];
+  const int pbeg = min(n, (blockIdx.x * 4 + wave) * q), pend = min(n, pbeg + q);
+  for (int c0 = pbeg; c0 < pend; c0 += 64) {
+    const int p = c0 + lane;
+    const bool valid = p < pend;
+    const int ntile = (min(64, pend - c0) + 15) >> 4;
+    M3 Ftr = m3_ident();
+    if (valid) g2p_particle<true>(gf.K, p, gf.clip, gf.enabled, gf.x, gf.v, gf.C, gf.F, gf.gv, gf.xn, gf.vn, gf.Cn, Ftr, nullptr, 0, true);
+    const M3 Fn = material_fwd_round<NM_PLASTICITY, ACT>(Ftr, valid, n, p, c0, ntile, lane, alpha, sPp, sPp + 16 * 64,
+                                                         sPp + 16 * 64 + 64 * 64, zb, yb, svd_p, act_p);
+    if (valid) m3_store(F_next + 9 * p, Fn);
+    const M3 S = material_fwd_round<NM_ELASTICITY, ACT>(Fn, valid, n, p, c0, ntile, lane, 0.f, sPe, sPe + 16 * 64,
+                                                        sPe + 16 * 64 + 64 * 64, zb, yb, svd_e, act_e);
+    if (valid) m3_store(stress_next + 9 * p, S);
+  }
 }
 
 // floats of one net's activation cache for n particles (one record per 16-particle tile)
@@ -610,6 +658,26 @@ int nm_material_fwd_launch(int32_t n, int32_t kind, float alpha, const float* F,
     NM_LAUNCH((k_material_fwd<NM_PLASTICITY, true>), dim3(launch), dim3(256), 0, s, n, q, alpha, F, w0, w1, w2, wperm, out, gp, gf, svd_out, act4);
   else
     NM_LAUNCH((k_material_fwd<NM_PLASTICITY, false>), dim3(launch), dim3(256), 0, s, n, q, alpha, F, w0, w1, w2, wperm, out, gp, gf, svd_out, act4);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}
+int nm_material_fwd_pair_launch(int32_t n, float alpha_p, const float* wperm_p, const float* wperm_e, float* F_next,
+                                float* stress_next, const GridPrologue* pro, const G2pFuse* g2p, void* stream, float* svd_p,
+                                float* svd_e, float* act_p, float* act_e) {
+  int grid, q;
+  nm_wave_quota(n, grid, q);
+  hipStream_t s = (hipStream_t)stream;
+  GridPrologue gp;
+  if (pro) gp = *pro; else { memset(&gp, 0, sizeof(gp)); }
+  gp.mat_grid = grid;
+  const int launch = (pro && grid + NM_PRO_WGS <= NM_BWD_GRID) ? grid + NM_PRO_WGS : grid;
+  f4 *ap = reinterpret_cast<f4*>(act_p), *ae = reinterpret_cast<f4*>(act_e);
+  if (ap && ae)
+    NM_LAUNCH((k_material_fwd_pair<true>), dim3(launch), dim3(256), 0, s, n, q, alpha_p, wperm_p, wperm_e, F_next, stress_next, gp, *g2p,
+              svd_p, svd_e, ap, ae);
+  else
+    NM_LAUNCH((k_material_fwd_pair<false>), dim3(launch), dim3(256), 0, s, n, q, alpha_p, wperm_p, wperm_e, F_next, stress_next, gp, *g2p,
+              svd_p, svd_e, ap, ae);
   NM_LAUNCH_CHECK();
   return NM_OK;
 }

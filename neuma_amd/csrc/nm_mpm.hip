@@ -45,6 +45,7 @@ struct nm_mpm {
   int* sh_slot;   // per block: slot of the block in the frame's exchange buffer, -1 = none (nm_mpm_xchg_arrays)
   int* sh_dil;    // per block: tag of the last frame whose negotiated neighbourhood holds the block
   int dil_tag;
+  int gv_stale;   // the last clear left the velocity array alone (GridPrologue keep_gv): the next grid update zeroes what dropped out
   int fresh_rows; // g2p writes a fresh state's values into the rows of disabled particles (roll-out checkpoints, nm_grid.h)
 };
 void nm_mpm_set_fresh_rows(nm_mpm* h, int on) { h->fresh_rows = on; }
@@ -595,16 +596,31 @@ static inline GridRec gridrec_at(void* base, int cap) {
   return r;
 }
 
+// blocks of the previous substep's list whose velocities the clear left in place (GridPrologue keep_gv); list == NULL: none
+struct DroppedBlocks {
+  const int* list;
+  const int* count;
+  const int* flags;
+  int epoch;
+};
 // mpm.py:373-429 on the active blocks only; optionally saves the pre-grid-op node values into a cache record
 __global__ void __launch_bounds__(256) k_grid_op(MpmK K, const float4* __restrict__ gm, float4* __restrict__ gv,
                                                  const int* __restrict__ list, const int* __restrict__ count, GridRec rec,
                                                  int cap, const int* __restrict__ skip_hdr, int* __restrict__ status,
-                                                 const int* __restrict__ slot, const float4* __restrict__ xbuf) {
+                                                 const int* __restrict__ slot, const float4* __restrict__ xbuf,
+                                                 DroppedBlocks dropped) {
   // slot / xbuf (sharded roll-out): a block with slot[b] >= 0 takes its {mv, m} - summed over the ranks - from the exchange
   // buffer instead of this rank's grid (the unpack step of the exchange, fused)
   if (skip_hdr && *skip_hdr >= 0) return;
   const int cnt = *count;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (dropped.list) {   // a block of the previous list that is not in this substep's (no stamp of this epoch) reads as empty again
+    const int pc = *dropped.count;
+    for (int li = blockIdx.x * 4 + wave; li < pc; li += gridDim.x * 4) {
+      const int b = dropped.list[li];
+      if (dropped.flags[b] != dropped.epoch) gv[(b << 6) + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
   const bool save = rec.hdr != nullptr && cnt <= cap;
   if (rec.hdr && blockIdx.x == 0 && threadIdx.x == 0) {
     rec.hdr[0] = save ? cnt : -1;
@@ -959,6 +975,7 @@ extern "C" int nm_mpm_create(const nm_mpm_cfg* cfg, nm_mpm** out) {
   NM_HIP_CHECK(hipDeviceSynchronize());
   h->cur = 0;
   h->epoch = 0;
+  h->gv_stale = 0;
   h->sh_cnt = h->sh_pos = nullptr;
   *out = h;
   return NM_OK;
@@ -1015,17 +1032,25 @@ static int mpm_build_grid(nm_mpm* h, int n, const nm_statics* st, const nm_parti
                        cur->v, cur->C, cur->stress, h->gm, h->flags, h->list[now], h->count + now, h->epoch, skip);
     NM_LAUNCH_CHECK();
   }
+  DroppedBlocks dropped = {nullptr, nullptr, nullptr, 0};
+  if (h->gv_stale) {
+    const int before = (now + 2) % 3;
+    dropped.list = h->list[before]; dropped.count = h->count + before; dropped.flags = h->flags; dropped.epoch = h->epoch;
+    h->gv_stale = 0;
+  }
   NM_LAUNCH(k_grid_op, dim3(kSweepGrid), dim3(256), 0, s, h->k, h->gm, h->gv, h->list[now], h->count + now, srec, cap, skip,
-            (int*)nullptr, (const int*)nullptr, (const float4*)nullptr);
+            (int*)nullptr, (const int*)nullptr, (const float4*)nullptr, dropped);
   NM_LAUNCH_CHECK();
   return NM_OK;
 }
 
 // ---- roll-out only: the clear / restore of a substep rides in the prologue of the constitutive kernel in front of it
-int nm_mpm_prologue_forward(nm_mpm* h, GridPrologue* g) {
+int nm_mpm_prologue_forward(nm_mpm* h, GridPrologue* g, bool keep_gv) {
   int prev, now, next;
   mpm_rotate(h, prev, now, next);
   g->mode = 1;
+  g->keep_gv = keep_gv ? 1 : 0;
+  h->gv_stale = keep_gv ? 1 : 0;
   g->K = h->k;
   g->gm = h->gm; g->gv = h->gv; g->gg = h->gg;
   g->list_prev = h->list[prev]; g->count_prev = h->count + prev;
@@ -1207,7 +1232,7 @@ int nm_mpm_forward_gridop_x(nm_mpm* h, void* gridrec, int32_t cap_blocks, int32_
   GridRec none = {nullptr, nullptr, nullptr};
   NM_LAUNCH(k_grid_op, dim3(kSweepGrid), dim3(256), 0, (hipStream_t)stream, h->k, h->gm, h->gv, h->list[now], h->count + now,
                      gridrec ? gridrec_at(gridrec, cap_blocks) : none, cap_blocks, (const int*)nullptr, (int*)status,
-                     (const int*)(xbuf ? h->sh_slot : nullptr), (const float4*)xbuf);
+                     (const int*)(xbuf ? h->sh_slot : nullptr), (const float4*)xbuf, DroppedBlocks{nullptr, nullptr, nullptr, 0});
   NM_LAUNCH_CHECK();
   return NM_OK;
 }
@@ -1304,7 +1329,7 @@ extern "C" int nm_mpm_forward_finish(nm_mpm* h, int32_t n, const nm_statics* st,
   GridRec none = {nullptr, nullptr, nullptr};
   NM_LAUNCH(k_grid_op, dim3(kSweepGrid), dim3(256), 0, s, h->k, h->gm, h->gv, h->list[now], h->count + now,
                      gridrec ? gridrec_at(gridrec, cap_blocks) : none, cap_blocks, (const int*)nullptr, (int*)status,
-                     (const int*)nullptr, (const float4*)nullptr);
+                     (const int*)nullptr, (const float4*)nullptr, DroppedBlocks{nullptr, nullptr, nullptr, 0});
   NM_LAUNCH_CHECK();
   if (n == 0) return NM_OK;
   int rc = check_particles(st, cur, true);

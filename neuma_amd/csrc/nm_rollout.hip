@@ -98,6 +98,13 @@ extern "C" int nm_rollout_cache_status(const void* gridcache, const nm_rollout_c
   return NM_OK;
 }
 
+// forward sweep: plasticity(t) and elasticity(t+1) in one launch (default) or one launch per net (A/B measurements, tests)
+static int g_forward_pair = 1;
+extern "C" int nm_rollout_set_forward_pair(int32_t on) {
+  g_forward_pair = on ? 1 : 0;
+  return NM_OK;
+}
+
 extern "C" int nm_rollout_forward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cfg, const nm_statics* st, const nm_mlp* we,
                                   const nm_mlp* wp, float* states, void* gridcache, void* workspace, size_t workspace_bytes,
                                   void* stream) {
@@ -115,13 +122,15 @@ extern "C" int nm_rollout_forward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cf
   if (rc) return rc;
   for (int t = 0; t < cfg->substeps; ++t) {
     nm_particles cur = rec(states, n, t), nxt = rec(states, n, t + 1);
-    // the elasticity kernel also clears the grid for the substep that follows it (GridPrologue mode 1, nm_grid.h)
-    GridPrologue pro;
-    rc = nm_mpm_prologue_forward(h, &pro);
-    if (rc) return rc;
-    rc = nm_material_fwd_launch(n, NM_ELASTICITY, 0.f, cur.F, we, w.perm_e, cur.stress, &pro, nullptr, stream, svd_rec(cfg, n, t, 0),
-                                act_rec(cfg, n, t, 0));  // finetune.py:362
-    if (rc) return rc;
+    if (t == 0 || !g_forward_pair) {
+      // the elasticity kernel also clears the grid for the substep that follows it (GridPrologue mode 1, nm_grid.h)
+      GridPrologue pro;
+      rc = nm_mpm_prologue_forward(h, &pro);
+      if (rc) return rc;
+      rc = nm_material_fwd_launch(n, NM_ELASTICITY, 0.f, cur.F, we, w.perm_e, cur.stress, &pro, nullptr, stream, svd_rec(cfg, n, t, 0),
+                                  act_rec(cfg, n, t, 0));  // finetune.py:362
+      if (rc) return rc;
+    }
     // p2g + grid update here; the substep's g2p runs inside the plasticity kernel, which consumes its trial F from
     // registers (the reverse sweep recomputes the trial F from the checkpointed C', so it is never stored)
     rc = nm_mpm_forward_prepared_nog2p(h, n, st, &cur, grid_rec(gridcache, cfg, t), cfg->grid_cache_blocks, stream);  // finetune.py:363
@@ -129,8 +138,19 @@ extern "C" int nm_rollout_forward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cf
     G2pFuse g2p;
     rc = nm_mpm_g2p_fuse(h, st, &cur, &nxt, &g2p);
     if (rc) return rc;
-    rc = nm_material_fwd_launch(n, NM_PLASTICITY, cfg->plasticity_alpha, nullptr, wp, w.perm_p, nxt.F, nullptr, &g2p, stream,
-                                svd_rec(cfg, n, t, 1), act_rec(cfg, n, t, 1));  // finetune.py:364
+    if (g_forward_pair && t + 1 < cfg->substeps) {
+      // plasticity of this substep and elasticity of the next in one launch (F_{t+1} goes from one net to the other in
+      // registers), which also carries the grid clear of substep t+1 - with the velocities left in place, because this very
+      // launch gathers them (finetune.py:364 -> :362 of the next iteration)
+      GridPrologue pro;
+      rc = nm_mpm_prologue_forward(h, &pro, true);
+      if (rc) return rc;
+      rc = nm_material_fwd_pair_launch(n, cfg->plasticity_alpha, w.perm_p, w.perm_e, nxt.F, nxt.stress, &pro, &g2p, stream,
+                                       svd_rec(cfg, n, t, 1), svd_rec(cfg, n, t + 1, 0), act_rec(cfg, n, t, 1), act_rec(cfg, n, t + 1, 0));
+    } else {
+      rc = nm_material_fwd_launch(n, NM_PLASTICITY, cfg->plasticity_alpha, nullptr, wp, w.perm_p, nxt.F, nullptr, &g2p, stream,
+                                  svd_rec(cfg, n, t, 1), act_rec(cfg, n, t, 1));  // finetune.py:364
+    }
     if (rc) return rc;
   }
   return NM_OK;

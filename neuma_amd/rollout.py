@@ -16,11 +16,15 @@ from .sim.order import ParticleOrder, hilbert_index_torch  # noqa: F401 (re-expo
 _WSZ = (64 * 13, 64 * 64, 9 * 64)
 _CACHE_STATUS = __import__('os').environ.get('NEUMA_CACHE_STATUS', '1') != '0'
 _SVD_CACHE = __import__('os').environ.get('NEUMA_SVD_CACHE', '1') != '0'
+_CACHE_WAIT = __import__('os').environ.get('NEUMA_CACHE_WAIT', '1') != '0'
 # activation cache of the fused roll-out (1.2 KB per particle and substep; nm_rollout_cfg.act_cache): the forward kernels keep
 # the second hidden layer of the MLPs, the reverse sweep loads it instead of recomputing (metric workload: 127.5 -> 132.3 frames/s,
 # 2.3 GB per 20-substep node).  'auto' (default): on while the caches of all live roll-out nodes stay below
 # NEUMA_ACT_CACHE_GB (default 48); '1': always; '0': never (recompute, the reference's memory profile)
 _ACT_CACHE = __import__('os').environ.get('NEUMA_ACT_CACHE', 'auto')
+# NEUMA_FWD_PAIR=0: one launch per net in the forward sweep instead of plasticity(t) + elasticity(t+1) in one (A/B runs)
+_FWD_PAIR = __import__('os').environ.get('NEUMA_FWD_PAIR')
+_FWD_PAIR_SET = [False]
 _ACT_CACHE_GB = float(__import__('os').environ.get('NEUMA_ACT_CACHE_GB', '48'))
 _ACT_LIVE = [0]         # bytes of activation cache held by live roll-out nodes
 _POOL = {}              # (device, bytes) -> idle cache buffers.  The caches are GB-sized: handing them back to the caching
@@ -155,6 +159,9 @@ class _Rollout(autograd.Function):
         st = statics.c_struct()
         mle = L.nm_mlp(*[L.ptr(t) for t in we])
         mlp = L.nm_mlp(*[L.ptr(t) for t in wp])
+        if _FWD_PAIR is not None and not _FWD_PAIR_SET[0]:
+            lib.nm_rollout_set_forward_pair(0 if _FWD_PAIR == '0' else 1)
+            _FWD_PAIR_SET[0] = True
         L.check(lib.nm_rollout_forward(model.handle(), n, C.byref(cfg), C.byref(st), C.byref(mle), C.byref(mlp), L.ptr(states),
                                        L.ptr(gcache) if gcache is not None else None, L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
                 "nm_rollout_forward")
@@ -238,7 +245,13 @@ class _Rollout(autograd.Function):
         ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
         gcache = ctx.gcache
         verified = 0
-        if gcache is not None and ctx.cache_event is not None and ctx.cache_event.query():
+        if gcache is not None and ctx.cache_event is not None:
+            # the record headers travel back right behind the forward sweep.  A host that gets here before the device has
+            # finished that sweep waits for it (the device still has whatever was enqueued in between - the frame's render -
+            # or idles for the few launches it takes to get the reverse sweep going): the unverified sweep it would otherwise
+            # run costs four extra launches per substep (+20 us each at 100k particles, 0.4 ms per 20-substep node)
+            if _CACHE_WAIT and not ctx.cache_event.query():
+                ctx.cache_event.synchronize()
             verified = int(bool((ctx.cache_status >= 0).all()))
         svdc, actc = getattr(ctx, "svdc", None), getattr(ctx, "actc", None)
         cfg = L.nm_rollout_cfg(S, ctx.alpha, ctx.cache_blocks, verified, ctx.svd_adjoint, L.ptr(svdc.t) if svdc is not None else None,

@@ -342,6 +342,38 @@ def test_svd_and_activation_caches_do_not_change_the_reverse_sweep():
             assert torch.isfinite(a).all() and rel_max(a, b) < 2e-4, mode
 
 
+def test_forward_pair_launch_equals_one_launch_per_net():
+    """nm_rollout_set_forward_pair: plasticity(t) + elasticity(t+1) in one launch (F_{t+1} handed over in registers, the grid
+    clear of substep t+1 riding along with the velocities left in place) against one launch per net (finetune.py:362-364).
+    Same arithmetic per particle; only the scatter's atomics order differs between two runs.  The scene drops and gains grid
+    blocks on the way (falling ball), and the checkpoints the reverse sweep reads (F, stress, SVD / activation caches of both
+    nets) are written by the other kernel in each mode, so the gradients cover them."""
+    from neuma_amd import _lib
+    S = 24
+    rt = _runtime("tiny", fused=True, S=S)
+    params = rt.parameters()
+    gen = torch.Generator().manual_seed(5)
+    F0 = (torch.eye(3) + 0.04 * torch.randn(rt.N, 3, 3, generator=gen)).to(dev())
+    gw = [torch.randn(rt.N, 3, generator=gen).to(dev()), torch.randn(rt.N, 3, 3, generator=gen).to(dev())]
+    res = {}
+    try:
+        for on in (1, 0):
+            assert _lib.lib().nm_rollout_set_forward_pair(on) == 0
+            for p in params:
+                p.grad = None
+            ins = [t.clone().requires_grad_(True) for t in (rt.x0, rt.v0)]
+            out = rt.rollout(ins[0], ins[1], rt.C0, F0)
+            ((out[0] * gw[0]).sum() + (out[3] * gw[1]).sum()).backward()
+            mv, m, vg = rt.model.grid_export()
+            res[on] = ([o.detach().clone() for o in out] + [m, vg], [t.grad.clone() for t in ins + params])
+    finally:
+        _lib.lib().nm_rollout_set_forward_pair(1)
+    for a, b in zip(res[1][0], res[0][0]):
+        assert torch.isfinite(a).all() and rel_max(a, b) < 2e-5
+    for a, b in zip(res[1][1], res[0][1]):
+        assert torch.isfinite(a).all() and rel_max(a, b) < 2e-4
+
+
 def test_disabled_particles_get_the_reference_rows_in_the_fused_and_the_per_operator_path():
     """A disabled particle's row of the next state is what the reference's out-of-place sims return for it: the fresh
     model.state() untouched by g2p (zeros, F = I; mpm.py:84-93, 443-444, interface.py:101-123), which the plasticity net then

@@ -24,10 +24,11 @@ def short(n):
     return n[:48]
 
 
-# roll-outs = stretches between the (rare) long idle gaps of the synchronised loop; take the last complete one
+# a roll-out starts with the LoRA merges of its two nets (the host synchronises between roll-outs, but a fast host leaves
+# gaps too short to tell apart from the ones inside); take the last complete one
 groups, cur = [], [rows[0]]
 for a, b in zip(rows, rows[1:]):
-    if b[0] - a[1] > 200_000:      # > 0.2 ms idle: the host's synchronize between two roll-outs
+    if "k_lora_merge_layers" in b[2] and "bwd" not in b[2] and any("k_material" in r[2] for r in cur):
         groups.append(cur); cur = []
     cur.append(b)
 groups.append(cur)
@@ -65,5 +66,5 @@ def show(title, first_pred, count_pred):
         print(f"| {short(n)} | {1e-3 * (s - g[a][0]):.1f} | {1e-3 * (e - s):.1f} | {1e-3 * (g[i + 1][0] - e):.2f} |")
 
 
-show("one forward substep", lambda n: n.startswith("k_material_fwd<0") or n.startswith("k_material_fwd<NM_ELASTICITY"), None)
+show("one forward substep", lambda n: n.startswith("k_material_fwd_pair"), None)
 show("one reverse substep", lambda n: n.startswith("k_material_bwd_pair"), None)
