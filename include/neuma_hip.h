@@ -214,10 +214,10 @@ int nm_lora_merge(int32_t out_f, int32_t in_f, int32_t r, float scaling, const f
 int nm_lora_merge_bwd(int32_t out_f, int32_t in_f, int32_t r, float scaling, const float* gW, const float* B,
                       const float* A, float* gB, float* gA, void* stream);
 
-/* The same for up to NM_LORA_MAX_LAYERS layers in ONE launch each way (a constitutive net has three; per-layer launches
+/* The same for up to NM_LORA_MAX_LAYERS layers in ONE launch each way (a constitutive net has three, a frame merges both nets' six; per-layer launches
  * of these tiny matrices are pure launch latency).  merge: o0 = W + scaling * B A.  merge_bwd: W holds dL/dW_eff,
  * o0 = dL/dB, o1 = dL/dA. */
-#define NM_LORA_MAX_LAYERS 4
+#define NM_LORA_MAX_LAYERS 8
 typedef struct nm_lora_layer {
   int32_t out_f, in_f, r;
   float scaling;

@@ -1006,6 +1006,17 @@ static void mpm_rotate(nm_mpm* h, int& prev, int& now, int& next) {
   h->cur = now;
 }
 
+// the previous substep's list, if the clear left its velocities in place (consumed by the grid update launched next)
+static DroppedBlocks take_dropped(nm_mpm* h, int now) {
+  DroppedBlocks d = {nullptr, nullptr, nullptr, 0};
+  if (h->gv_stale) {
+    const int before = (now + 2) % 3;
+    d.list = h->list[before]; d.count = h->count + before; d.flags = h->flags; d.epoch = h->epoch;
+    h->gv_stale = 0;
+  }
+  return d;
+}
+
 static int mpm_build_grid(nm_mpm* h, int n, const nm_statics* st, const nm_particles* cur, hipStream_t s, void* save = nullptr,
                           const void* restore = nullptr, int cap = 0, bool restore_verified = false, bool precleared = false) {
   int prev, now, next;
@@ -1032,12 +1043,7 @@ static int mpm_build_grid(nm_mpm* h, int n, const nm_statics* st, const nm_parti
                        cur->v, cur->C, cur->stress, h->gm, h->flags, h->list[now], h->count + now, h->epoch, skip);
     NM_LAUNCH_CHECK();
   }
-  DroppedBlocks dropped = {nullptr, nullptr, nullptr, 0};
-  if (h->gv_stale) {
-    const int before = (now + 2) % 3;
-    dropped.list = h->list[before]; dropped.count = h->count + before; dropped.flags = h->flags; dropped.epoch = h->epoch;
-    h->gv_stale = 0;
-  }
+  const DroppedBlocks dropped = take_dropped(h, now);
   NM_LAUNCH(k_grid_op, dim3(kSweepGrid), dim3(256), 0, s, h->k, h->gm, h->gv, h->list[now], h->count + now, srec, cap, skip,
             (int*)nullptr, (const int*)nullptr, (const float4*)nullptr, dropped);
   NM_LAUNCH_CHECK();
@@ -1230,9 +1236,10 @@ int nm_mpm_forward_gridop_x(nm_mpm* h, void* gridrec, int32_t cap_blocks, int32_
   NM_REQUIRE(!gridrec || cap_blocks > 0, "grid cache record without capacity");
   const int now = h->cur;
   GridRec none = {nullptr, nullptr, nullptr};
+  const DroppedBlocks dropped = take_dropped(h, now);
   NM_LAUNCH(k_grid_op, dim3(kSweepGrid), dim3(256), 0, (hipStream_t)stream, h->k, h->gm, h->gv, h->list[now], h->count + now,
                      gridrec ? gridrec_at(gridrec, cap_blocks) : none, cap_blocks, (const int*)nullptr, (int*)status,
-                     (const int*)(xbuf ? h->sh_slot : nullptr), (const float4*)xbuf, DroppedBlocks{nullptr, nullptr, nullptr, 0});
+                     (const int*)(xbuf ? h->sh_slot : nullptr), (const float4*)xbuf, dropped);
   NM_LAUNCH_CHECK();
   return NM_OK;
 }

@@ -324,12 +324,14 @@ extern "C" int nm_rollout_forward_sharded(nm_mpm* h, int32_t n, const nm_rollout
   for (int t = 0; t < cfg->substeps && !rc; ++t) {
     nm_particles cur = rec(states, nrec, t), nxt = rec(states, nrec, t + 1);
     if (n > 0) {
-      GridPrologue pro;
-      rc = nm_mpm_prologue_forward(h, &pro);
-      if (rc) break;
-      rc = nm_material_fwd_launch(n, NM_ELASTICITY, 0.f, cur.F, we, w.perm_e, cur.stress, &pro, nullptr, stream, svd_rec(cfg, n, t, 0),
-                                  act_rec(cfg, n, t, 0));  // finetune.py:362
-      if (rc) break;
+      if (t == 0 || !g_forward_pair) {
+        GridPrologue pro;
+        rc = nm_mpm_prologue_forward(h, &pro);
+        if (rc) break;
+        rc = nm_material_fwd_launch(n, NM_ELASTICITY, 0.f, cur.F, we, w.perm_e, cur.stress, &pro, nullptr, stream, svd_rec(cfg, n, t, 0),
+                                    act_rec(cfg, n, t, 0));  // finetune.py:362
+        if (rc) break;
+      }
       rc = nm_mpm_forward_prepared_p2g(h, n, st, &cur, stream);        // this rank's scatter (mpm.py:281-290)
       if (rc) break;
     } else {
@@ -359,8 +361,16 @@ extern "C" int nm_rollout_forward_sharded(nm_mpm* h, int32_t n, const nm_rollout
       G2pFuse g2p;
       rc = nm_mpm_g2p_fuse(h, st, &cur, &nxt, &g2p);
       if (rc) break;
-      rc = nm_material_fwd_launch(n, NM_PLASTICITY, cfg->plasticity_alpha, nullptr, wp, w.perm_p, nxt.F, nullptr, &g2p, stream,
-                                  svd_rec(cfg, n, t, 1), act_rec(cfg, n, t, 1));  // finetune.py:364
+      if (g_forward_pair && t + 1 < cfg->substeps) {     // plasticity(t) + elasticity(t+1) + the clear of substep t+1 (see nm_rollout_forward)
+        GridPrologue pro;
+        rc = nm_mpm_prologue_forward(h, &pro, true);
+        if (rc) break;
+        rc = nm_material_fwd_pair_launch(n, cfg->plasticity_alpha, w.perm_p, w.perm_e, nxt.F, nxt.stress, &pro, &g2p, stream,
+                                         svd_rec(cfg, n, t, 1), svd_rec(cfg, n, t + 1, 0), act_rec(cfg, n, t, 1), act_rec(cfg, n, t + 1, 0));
+      } else {
+        rc = nm_material_fwd_launch(n, NM_PLASTICITY, cfg->plasticity_alpha, nullptr, wp, w.perm_p, nxt.F, nullptr, &g2p, stream,
+                                    svd_rec(cfg, n, t, 1), act_rec(cfg, n, t, 1));  // finetune.py:364
+      }
     }
   }
   nm_mpm_set_fresh_rows(h, 0);

@@ -105,80 +105,235 @@ class _FrameTail(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rt, de_x, F, weight, jobs, streams):
-        import ctypes as C
-        from . import _lib as L
-        from .render import get_rasterizer, raster_forward_raw
-        lib, dev = L.lib(), de_x.device
-        b = rt.bindings
-        K = b.K
         p_cur = de_x.detach().float().contiguous()
         Fc = F.detach().float().reshape(-1, 9).contiguous()
-        means3D = torch.empty(K, 3, dtype=torch.float32, device=dev)
-        cov = torch.empty(K, 6, dtype=torch.float32, device=dev)
-        L.check(lib.nm_bind_frame(K, L.ptr(b.rowptr), L.ptr(b.col), L.ptr(b.val), L.ptr(p_cur), L.ptr(rt._de_x_prev), L.ptr(rt._g_prev),
-                                  L.ptr(Fc), L.ptr(rt._cov6), L.ptr(means3D), L.ptr(cov), None, L.stream_ptr(dev)), "nm_bind_frame")
-        loss = torch.zeros((), dtype=torch.float32, device=dev)
-        kind = 0 if rt.pixel_loss is l1_loss else 1
-        mask = getattr(rt, "force_mask_data", False)
-        sh = None if mask else rt._shs
-        cp = rt._ones_rgb(K) if mask else None
-        main = torch.cuda.current_stream(dev)
-        recs, grads, parts = [], [], []
-        for i, (vi, rows) in enumerate(jobs):
-            st = streams[i] if streams else None
-            if st is not None:
-                st.wait_stream(main)
-            with torch.cuda.stream(st if st is not None else main):
-                rast = get_rasterizer(rt.camera_at(vi), rt.gaussians.active_sh_degree, False, rt.background, tile_rows=rows)
-                img, _, rec = raster_forward_raw(rast._cam, means3D, sh, cp, rt._opacity, cov)
-                h, w = int(img.shape[-2]), int(img.shape[-1])
-                r0, r1 = (0, 0) if rows is None else (rows[0] * 16, min(h, rows[1] * 16))
-                part = loss if st is None else torch.zeros((), dtype=torch.float32, device=dev)
-                gimg = torch.empty_like(img)
-                L.check(lib.nm_pixel_loss(kind, float(weight), h, w, r0, r1, L.ptr(img), L.ptr(rt.gt[vi]), L.ptr(part), L.ptr(gimg),
-                                          L.stream_ptr(dev)), "nm_pixel_loss")
-                recs.append(rec); grads.append(gimg); parts.append(part)
-        if streams:
-            for st in set(streams):
-                main.wait_stream(st)
-            for t in [means3D, cov] + grads + parts:
-                t.record_stream(main)
-            loss = torch.stack(parts).sum() if len(parts) > 1 else parts[0]
+        loss, recs, grads, keep = _tail_forward(rt, p_cur, Fc, weight, jobs, streams)
         ctx.rt, ctx.recs, ctx.grads, ctx.streams = rt, recs, grads, streams
-        ctx.keep = (means3D, cov)          # (referenced by the records' raw pointers)
+        ctx.keep = keep                    # (referenced by the records' raw pointers)
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        import torch.distributed as dist
-        from . import _lib as L
-        from .render import raster_backward_raw
-        rt, recs, grads, streams = ctx.rt, ctx.recs, ctx.grads, ctx.streams
-        lib, dev = L.lib(), grads[0].device
-        main = torch.cuda.current_stream(dev)
-        total = None
-        outs = []
-        for i, (rec, gimg) in enumerate(zip(recs, grads)):
-            st = streams[i] if streams else None
-            if st is not None:
-                st.wait_stream(main)
-            with torch.cuda.stream(st if st is not None else main):
-                outs.append(raster_backward_raw(rec, gimg)[0])
-        if streams:
-            for st in set(streams):
-                main.wait_stream(st)
-            for t in outs:
-                t.record_stream(main)
-        for d in outs:
-            total = d if total is None else total.add_(d)
-        if rt.world > 1 and dist.is_available() and dist.is_initialized() and dist.get_world_size(rt.group) > 1:
-            dist.all_reduce(total, op=dist.ReduceOp.SUM, group=rt.group)        # the frame's one K x 3 all-reduce
-        b = rt.bindings
-        dx = torch.empty(b.N, 3, dtype=torch.float32, device=dev)
-        L.check(lib.nm_spmm_csr(b.N, 3, L.ptr(b.t_rowptr), L.ptr(b.t_col), L.ptr(b.t_val), L.ptr(total), L.ptr(dx), L.stream_ptr(dev)),
-                "nm_spmm_csr")
+        rt = ctx.rt
+        dx = torch.empty(rt.bindings.N, 3, dtype=torch.float32, device=ctx.grads[0].device)
+        _tail_backward(rt, ctx.recs, ctx.grads, ctx.streams, dx)
         ctx.recs = ctx.grads = ctx.keep = None
         return None, dx * g, None, None, None, None
+
+
+def _tail_forward(rt, p_cur, Fc, weight, jobs, streams):
+    """Binding + covariance push-forward (one launch), then per render job rasterizer forward + pixel loss (value and dL/dimage
+    in one pass).  p_cur (N, 3), Fc (N, 9): contiguous fp32, outside autograd.  Returns (loss, records, dL/dimage per job,
+    tensors the records point into)."""
+    from . import _lib as L
+    from .render import get_rasterizer, raster_forward_raw
+    lib, dev = L.lib(), p_cur.device
+    b = rt.bindings
+    K = b.K
+    means3D = torch.empty(K, 3, dtype=torch.float32, device=dev)
+    cov = torch.empty(K, 6, dtype=torch.float32, device=dev)
+    L.check(lib.nm_bind_frame(K, L.ptr(b.rowptr), L.ptr(b.col), L.ptr(b.val), L.ptr(p_cur), L.ptr(rt._de_x_prev), L.ptr(rt._g_prev),
+                              L.ptr(Fc), L.ptr(rt._cov6), L.ptr(means3D), L.ptr(cov), None, L.stream_ptr(dev)), "nm_bind_frame")
+    loss = torch.zeros((), dtype=torch.float32, device=dev)
+    kind = 0 if rt.pixel_loss is l1_loss else 1
+    mask = getattr(rt, "force_mask_data", False)
+    sh = None if mask else rt._shs
+    cp = rt._ones_rgb(K) if mask else None
+    main = torch.cuda.current_stream(dev) if streams else None
+    recs, grads, parts = [], [], []
+
+    def job(vi, rows, part):
+        rast = get_rasterizer(rt.camera_at(vi), rt.gaussians.active_sh_degree, False, rt.background, tile_rows=rows)
+        img, _, rec = raster_forward_raw(rast._cam, means3D, sh, cp, rt._opacity, cov)
+        h, w = int(img.shape[-2]), int(img.shape[-1])
+        r0, r1 = (0, 0) if rows is None else (rows[0] * 16, min(h, rows[1] * 16))
+        gimg = torch.empty_like(img)
+        L.check(lib.nm_pixel_loss(kind, float(weight), h, w, r0, r1, L.ptr(img), L.ptr(rt.gt[vi]), L.ptr(part), L.ptr(gimg),
+                                  L.stream_ptr(dev)), "nm_pixel_loss")
+        recs.append(rec); grads.append(gimg); parts.append(part)
+
+    for i, (vi, rows) in enumerate(jobs):
+        if streams:
+            st = streams[i]
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                job(vi, rows, torch.zeros((), dtype=torch.float32, device=dev))
+        else:
+            job(vi, rows, loss)
+    if streams:
+        for st in set(streams):
+            main.wait_stream(st)
+        for t in [means3D, cov] + grads + parts:
+            t.record_stream(main)
+        loss = torch.stack(parts).sum() if len(parts) > 1 else parts[0]
+    return loss, recs, grads, (means3D, cov)
+
+
+def _tail_backward(rt, recs, grads, streams, dx_out):
+    """Rasterizer adjoints of every job, dL/dmeans3D summed over the jobs (and the ranks), then B^T into dx_out (N, 3)."""
+    import torch.distributed as dist
+    from . import _lib as L
+    from .render import raster_backward_raw
+    lib, dev = L.lib(), grads[0].device
+    total = None
+    outs = []
+    if streams:
+        main = torch.cuda.current_stream(dev)
+        for st, rec, gimg in zip(streams, recs, grads):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                outs.append(raster_backward_raw(rec, gimg)[0])
+        for st in set(streams):
+            main.wait_stream(st)
+        for t in outs:
+            t.record_stream(main)
+    else:
+        for rec, gimg in zip(recs, grads):
+            outs.append(raster_backward_raw(rec, gimg)[0])
+    for d in outs:
+        total = d if total is None else total.add_(d)
+    if rt.world > 1 and dist.is_available() and dist.is_initialized() and dist.get_world_size(rt.group) > 1:
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=rt.group)        # the frame's one K x 3 all-reduce
+    b = rt.bindings
+    L.check(lib.nm_spmm_csr(b.N, 3, L.ptr(b.t_rowptr), L.ptr(b.t_col), L.ptr(b.t_val), L.ptr(total), L.ptr(dx_out), L.stream_ptr(dev)),
+            "nm_spmm_csr")
+
+
+class _Frame(torch.autograd.Function):
+    """The whole frame of a one-GPU runtime as ONE autograd node over the LoRA factors: effective weights of both nets (one
+    launch), the S-substep roll-out (nm_rollout_forward), binding + covariance push-forward, every render job + loss
+    (finetune.py:331-389); the reverse sweep runs the same chain backwards down to dL/dB, dL/dA of the six layers
+    (finetune.py:413-414).  Same library calls, same kernels and results as the composition LoRA merge -> _Rollout ->
+    _FrameTail that it replaces; what goes away is the host time between them (four autograd nodes each way, the packing /
+    unpacking of their inputs and outputs) - the frame time of the small configurations (bb, jd, sf) was host time."""
+
+    @staticmethod
+    def forward(ctx, rt, weight, jobs, streams, *ba):
+        import ctypes as C
+        from . import _lib as L
+        from . import rollout as R
+        lib, dev = L.lib(), rt.device
+        sim = rt.sim_fused
+        n, S = rt.n_local, int(sim.substeps)
+        stream = L.stream_ptr(dev)
+        layers = rt._lora_layers
+        # effective weights e0 | e1 | e2 | p0 | p1 | p2
+        nw = sum(R._WSZ)
+        eff = torch.empty(2 * nw, dtype=torch.float32, device=dev)
+        jobs6 = (L.nm_lora_layer * 6)()
+        off, base = 0, eff.data_ptr()
+        for i, l in enumerate(layers):
+            W = l.weight
+            jobs6[i] = L.nm_lora_layer(W.shape[0], W.shape[1], l.r, float(l.scaling), L.ptr(W), L.ptr(ba[2 * i]), L.ptr(ba[2 * i + 1]),
+                                       base + 4 * off, None)
+            off += W.numel()
+        L.check(lib.nm_lora_merge_layers(6, jobs6, stream), "nm_lora_merge_layers")
+        # roll-out: record 0 = the (packed) start state
+        states = torch.empty(S + 1, 33 * n, dtype=torch.float32, device=dev)
+        states[0, :24 * n].copy_(rt._start_packed())
+        ws_bytes = int(lib.nm_rollout_workspace(n, S))
+        ws = rt._scratch("ws", ws_bytes)
+        cache_blocks = int(sim.grid_cache_blocks())
+        gc_bytes = int(lib.nm_rollout_gridcache_bytes(S, cache_blocks)) if cache_blocks > 0 else 0
+        gcache = torch.empty(gc_bytes, dtype=torch.uint8, device=dev) if gc_bytes > 0 else None
+        budget = R._ACT_CACHE_GB * (1 << 30)
+        svdc = actc = None
+        if R._SVD_CACHE:
+            svd_bytes = int(lib.nm_rollout_svdcache_bytes(n, S))
+            if R._ACT_LIVE[0] + svd_bytes <= budget:
+                svdc = R._Lease(svd_bytes, dev, True)
+        if R._ACT_CACHE != '0':
+            act_bytes = int(lib.nm_rollout_actcache_bytes(n, S))
+            if R._ACT_CACHE == '1' or R._ACT_LIVE[0] + act_bytes <= budget:
+                actc = R._Lease(act_bytes, dev, True)
+        adj = L.SVD_ADJOINT[sim.svd_adjoint]
+        cfg = L.nm_rollout_cfg(S, float(sim.plasticity.alpha), cache_blocks if gcache is not None else 0, 0, adj,
+                               L.ptr(svdc.t) if svdc is not None else None, L.ptr(actc.t) if actc is not None else None)
+        st = rt.statics.c_struct()
+        mle = L.nm_mlp(base, base + 4 * R._WSZ[0], base + 4 * (R._WSZ[0] + R._WSZ[1]))
+        pb = base + 4 * nw
+        mlp = L.nm_mlp(pb, pb + 4 * R._WSZ[0], pb + 4 * (R._WSZ[0] + R._WSZ[1]))
+        L.check(lib.nm_rollout_forward(rt.model.handle(), n, C.byref(cfg), C.byref(st), C.byref(mle), C.byref(mlp), L.ptr(states),
+                                       L.ptr(gcache), L.ptr(ws), ws_bytes, stream), "nm_rollout_forward")
+        status = ev = None
+        if gcache is not None and R._CACHE_STATUS:
+            status = torch.empty(S, dtype=torch.int32, pin_memory=True)
+            L.check(lib.nm_rollout_cache_status(L.ptr(gcache), C.byref(cfg), C.c_void_p(status.data_ptr()), stream), "nm_rollout_cache_status")
+            ev = torch.cuda.Event()
+            ev.record()
+        if sim._cache_blocks is None:      # first roll-out: size the grid cache from what the scene touches (one host sync)
+            blocks, _ = rt.model.grid_stats()
+            sim._cache_blocks = int(1.5 * blocks) + 64
+        last = states[S]
+        x, Fl = last[:3 * n].view(n, 3), last[15 * n:24 * n].view(n, 9)
+        p_cur = x if rt._unit_frame() else ((x - rt.center) / rt.size).contiguous()      # finetune.py:373
+        loss, recs, grads, keep = _tail_forward(rt, p_cur, Fl, weight, jobs, streams)
+        ctx.rt, ctx.recs, ctx.grads, ctx.streams, ctx.keep = rt, recs, grads, streams, keep
+        ctx.roll = (states, eff, gcache, svdc, actc, status, ev, cache_blocks if gcache is not None else 0, adj)
+        ctx.mark_non_differentiable(x, Fl)
+        return loss, x, Fl
+
+    @staticmethod
+    def backward(ctx, g, _gx, _gF):
+        import ctypes as C
+        from . import _lib as L
+        from . import rollout as R
+        rt = ctx.rt
+        lib, dev = L.lib(), rt.device
+        sim = rt.sim_fused
+        n, S = rt.n_local, int(sim.substeps)
+        states, eff, gcache, svdc, actc, status, ev, cache_blocks, adj = ctx.roll
+        # dL/d(x, v, C, F of the last record): B^T of the summed rasterizer adjoints lands in the head of a buffer whose
+        # tail (v, C, F: nothing downstream of the roll-out reads them) stays zero
+        glast = rt._scratch("glast", 4 * 24 * n, zero=True).view(torch.float32)
+        dx = glast[:3 * n].view(n, 3)
+        _tail_backward(rt, ctx.recs, ctx.grads, ctx.streams, dx)
+        if rt._unit_frame():
+            dx.mul_(g)
+        else:
+            dx.mul_(g / rt.size)
+        stream = L.stream_ptr(dev)
+        verified = 0
+        if gcache is not None and ev is not None:
+            if R._CACHE_WAIT and not ev.query():
+                ev.synchronize()
+            verified = int(bool((status >= 0).all()))
+        nw = sum(R._WSZ)
+        gfirst = rt._scratch("gfirst", 4 * 24 * n)
+        gw = torch.empty(2 * nw, dtype=torch.float32, device=dev)
+        ws_bytes = int(lib.nm_rollout_workspace(n, S))
+        ws = rt._scratch("ws", ws_bytes)
+        cfg = L.nm_rollout_cfg(S, float(sim.plasticity.alpha), cache_blocks, verified, adj,
+                               L.ptr(svdc.t) if svdc is not None else None, L.ptr(actc.t) if actc is not None else None)
+        st = rt.statics.c_struct()
+        base = eff.data_ptr()
+        mle = L.nm_mlp(base, base + 4 * R._WSZ[0], base + 4 * (R._WSZ[0] + R._WSZ[1]))
+        pb = base + 4 * nw
+        mlp = L.nm_mlp(pb, pb + 4 * R._WSZ[0], pb + 4 * (R._WSZ[0] + R._WSZ[1]))
+        gbase = gw.data_ptr()
+        L.check(lib.nm_rollout_backward(rt.model.handle(), n, C.byref(cfg), C.byref(st), C.byref(mle), C.byref(mlp), L.ptr(states),
+                                        L.ptr(gcache), L.ptr(glast), L.ptr(gfirst), gbase, gbase + 4 * nw, L.ptr(ws), ws_bytes, stream),
+                "nm_rollout_backward")
+        for lease in (svdc, actc):
+            if lease is not None:
+                lease.release()
+        # dL/dW_eff -> dL/dB, dL/dA of the six layers: ONE launch
+        layers = rt._lora_layers
+        sizes = [(l.lora_B.numel(), l.lora_A.numel()) for l in layers]
+        gba = torch.empty(sum(a + b for a, b in sizes), dtype=torch.float32, device=dev)
+        jobs6 = (L.nm_lora_layer * 6)()
+        outs, off, goff, ob = [], 0, 0, gba.data_ptr()
+        for i, l in enumerate(layers):
+            W = l.weight
+            nb, na = sizes[i]
+            jobs6[i] = L.nm_lora_layer(W.shape[0], W.shape[1], l.r, float(l.scaling), gbase + 4 * off, L.ptr(l.lora_B), L.ptr(l.lora_A),
+                                       ob + 4 * goff, ob + 4 * (goff + nb))
+            outs += [gba[goff:goff + nb].view_as(l.lora_B), gba[goff + nb:goff + nb + na].view_as(l.lora_A)]
+            off += W.numel()
+            goff += nb + na
+        L.check(lib.nm_lora_merge_layers_bwd(6, jobs6, stream), "nm_lora_merge_layers_bwd")
+        ctx.recs = ctx.grads = ctx.keep = ctx.roll = None
+        return (None, None, None, None) + tuple(outs)
 
 
 def make_material_cfg(alpha=1e-3):
@@ -333,6 +488,52 @@ class SceneRuntime(object):
     def parameters(self):
         return [p for net in (self.elasticity, self.plasticity) for p in net.parameters() if p.requires_grad]
 
+    # ---- the one-node frame (_Frame)
+    def _lean_ok(self) -> bool:
+        """The frame can run as ONE autograd node: one GPU, library roll-out, particles in scatter order, and the only trainable
+        tensors are the LoRA factors of the six layers (finetune.py:295-313, the configuration NeuMA trains in).  Decided once
+        per set of layer modules (adding LoRA replaces them); `_lean = None` forgets the decision after a manual (un)freeze."""
+        fcs = [fc for net in (self.elasticity, self.plasticity) for fc in (net.layers[0].fc, net.layers[1].fc, net.final_layer.fc)]
+        key = tuple(id(fc) for fc in fcs)
+        ok = getattr(self, "_lean", None)
+        if ok is None or ok[0] != key:
+            from .material.loralib import LinearLoRA
+            good = (self.world == 1 and not self.shard_sim and self.model.exchange is None
+                    and all(isinstance(fc, LinearLoRA) and fc.r > 0 and not fc.merged and fc.weight.is_cuda and not fc.weight.requires_grad
+                            and fc.lora_A.requires_grad and fc.lora_B.requires_grad and fc.bias is None
+                            and fc.weight.dtype == torch.float32 and fc.weight.is_contiguous() for fc in fcs)
+                    and len(self.parameters()) == 12 and not self.sim_fused.order.active(self.start[0]))
+            ok = self._lean = (key, good)
+            self._lora_layers = fcs
+        # (a start state that wants gradients - the initial-velocity stage - goes through the roll-out node, which returns them)
+        return (ok[1] and self.fused and getattr(self, "fused_tail", True) and torch.is_grad_enabled()
+                and not any(t.requires_grad for t in self.start) and os.environ.get("NEUMA_FUSED_TAIL", "1") != "0" and os.environ.get("NEUMA_LEAN_FRAME", "1") != "0")
+
+    def _start_packed(self):
+        """x | v | C | F of the start state as one contiguous record (rebuilt when the start state changes)."""
+        st = self.start
+        key = tuple(t.data_ptr() for t in st) + tuple(t._version for t in st)
+        if getattr(self, "_packed_key", None) != key:
+            self._packed = torch.cat([t.detach().float().reshape(-1) for t in st])
+            self._packed_key = key
+        return self._packed
+
+    def _unit_frame(self) -> bool:
+        """de_x = (x - center) / size is the identity (synthetic scenes)."""
+        key = (self.center.data_ptr(), self.center._version, self.size.data_ptr(), self.size._version)
+        if getattr(self, "_unit_key", None) != key:
+            self._unit = bool((self.center == 0).all()) and bool((self.size == 1).all())
+            self._unit_key = key
+        return self._unit
+
+    def _scratch(self, name: str, nbytes: int, zero: bool = False):
+        """Per-runtime device buffers that live across frames (stream-ordered reuse): the roll-out workspace, dL/dstate records."""
+        pool = self.__dict__.setdefault("_scratch_pool", {})
+        t = pool.get(name)
+        if t is None or t.numel() != max(int(nbytes), 4):
+            t = pool[name] = (torch.zeros if zero else torch.empty)(max(int(nbytes), 4), dtype=torch.uint8, device=self.device)
+        return t
+
     def rollout(self, x, v, C, F, step0: int = 0):
         """S substeps (finetune.py:360-364)."""
         if self.fused:
@@ -386,13 +587,22 @@ class SceneRuntime(object):
 
     # ---- one frame, forward + backward
     def frame(self, weight: float = 1.0, backward: bool = True) -> FrameResult:
-        rows = self.rows
-        x, v, C, F = (t[rows] for t in self.start)
         if getattr(self, "_de_prev_key", None) != self.start[0].data_ptr():      # (constant between start-state changes)
             self._de_prev = ((self.start[0] - self.center) / self.size).detach()
             self._de_prev_key = self.start[0].data_ptr()
         de_x_prev = self._de_prev
         g_prev = self.g_start
+        if backward and self._lean_ok():
+            # one GPU, LoRA training: the whole frame is one autograd node over the LoRA factors (_Frame)
+            jobs = self._lean_jobs
+            streams = self._frame_streams(jobs)
+            self._tail_constants(de_x_prev, g_prev)
+            ba = [t for l in self._lora_layers for t in (l.lora_B, l.lora_A)]
+            loss, x, F = _Frame.apply(self, float(weight), jobs, streams, *ba)
+            loss.backward()
+            return FrameResult(loss.detach(), x, F.view(-1, 3, 3))
+        rows = self.rows
+        x, v, C, F = (t[rows] for t in self.start)
         x, v, C, F = self.rollout(x, v, C, F)
         if self.shard_sim:
             self.model.exchange.defer_check()                                 # checked once, at the end of the frame
@@ -406,19 +616,7 @@ class SceneRuntime(object):
             jobs = [(vi, (r0, r1)) for (vi, r0, r1) in stripe_plan(self.V, self.tile_rows, self.world, self.rank, self._stripe_weights())]
         # the jobs go round-robin over HIP streams: one job's binning (counts, scans, cell sorts: small latency-bound kernels)
         # executes under another job's compositing kernel - same results, ~9 % shorter frame
-        streams = None
-        if getattr(self, "overlap_views", False) and len(jobs) > 1:
-            if not hasattr(self, "_view_streams"):
-                self._view_streams = [torch.cuda.Stream(device=self.device) for _ in range(int(self.num_view_streams or self.V))]
-            streams = [self._view_streams[k % len(self._view_streams)] for k in range(len(jobs))]
-        if os.environ.get("NEUMA_HINT_FWD_LEN") is None and getattr(self, "_hint_mode", None) != bool(streams):
-            # several render jobs share the chip (streams): the forward pass walks its tiles front to back and only the reverse
-            # sweep runs in segments - the T = 1 starts of parallel forward segments are extra work that then displaces another
-            # view's (metric frame: 140.3 -> 142.2 frames/s); a view that has the chip to itself needs the segments for its
-            # latency (sf 603 -> 1035 frames/s).  Process-wide knob of the library, set when the situation changes.
-            from . import _lib as L
-            L.check(L.lib().nm_raster_set_hinted((1 << 20) if streams else 0, 256), "nm_raster_set_hinted")
-            self._hint_mode = bool(streams)
+        streams = self._frame_streams(jobs)
         if getattr(self, "fused_tail", True) and os.environ.get("NEUMA_FUSED_TAIL", "1") != "0":
             # one autograd node for binding + covariance push-forward + every render job + loss (_FrameTail)
             self._tail_constants(de_x_prev, g_prev)
@@ -438,6 +636,30 @@ class SceneRuntime(object):
         if self.world > 1:
             self._collect_stripe_work(jobs)
         return FrameResult(loss.detach(), x.detach(), F.detach())
+
+    @property
+    def _lean_jobs(self):
+        jobs = getattr(self, "_jobs1", None)
+        if jobs is None or len(jobs) != self.V:
+            jobs = self._jobs1 = [(vi, None) for vi in range(self.V)]
+        return jobs
+
+    def _frame_streams(self, jobs):
+        """HIP streams of the frame's render jobs (None: all on the caller's stream) and the compositing mode that goes with it."""
+        streams = None
+        if getattr(self, "overlap_views", False) and len(jobs) > 1:
+            if not hasattr(self, "_view_streams"):
+                self._view_streams = [torch.cuda.Stream(device=self.device) for _ in range(int(self.num_view_streams or self.V))]
+            streams = [self._view_streams[k % len(self._view_streams)] for k in range(len(jobs))]
+        if getattr(self, "_hint_mode", None) != bool(streams) and os.environ.get("NEUMA_HINT_FWD_LEN") is None:
+            # several render jobs share the chip (streams): the forward pass walks its tiles front to back and only the reverse
+            # sweep runs in segments - the T = 1 starts of parallel forward segments are extra work that then displaces another
+            # view's (metric frame: 140.3 -> 142.2 frames/s); a view that has the chip to itself needs the segments for its
+            # latency (sf 603 -> 1035 frames/s).  Process-wide knob of the library, set when the situation changes.
+            from . import _lib as L
+            L.check(L.lib().nm_raster_set_hinted((1 << 20) if streams else 0, 256), "nm_raster_set_hinted")
+            self._hint_mode = bool(streams)
+        return streams
 
     def flush(self):
         """Wait for everything enqueued so far and raise what is still unreported (sharded exchanges, rasterizer overflows)."""

@@ -139,6 +139,38 @@ def test_frame_forward_backward_finite_and_consistent():
     assert abs(total - float(r1.loss)) < 1e-5 * max(1.0, abs(float(r1.loss)))
 
 
+@pytest.mark.parametrize("scene,over", [("tiny", None), ("tiny", dict(S=4, V=2))])
+def test_one_node_frame_equals_the_composition_of_nodes(scene, over, monkeypatch):
+    """SceneRuntime.frame() on one GPU runs the whole frame as ONE autograd node over the LoRA factors (harness._Frame: merge of
+    both nets, nm_rollout_*, binding, renders, loss and their adjoints); NEUMA_LEAN_FRAME=0 keeps the composition LoRA merge ->
+    roll-out node -> frame-tail node.  Same library calls: loss, state and the twelve LoRA gradients agree (atomics order only);
+    a non-trivial de-normalisation (center / size, nclaw/utils.py:110-118) goes through both as well."""
+    from neuma_amd import synth
+    from neuma_amd.harness import SceneRuntime, _Frame
+    for unit in (True, False):
+        rt = SceneRuntime(synth.make_scene(scene, override=over), dev(), fused=True)
+        if not unit:
+            rt.center = torch.tensor([0.1, -0.2, 0.05], device=dev())
+            rt.size = torch.tensor([1.5, 0.8, 1.1], device=dev())
+        rt.set_start_state("deformed")      # (at F = I the gradients are run-to-run noise of a cancelling sum in either path)
+        rt.make_ground_truth()
+        res = {}
+        for lean in ("1", "0"):
+            monkeypatch.setenv("NEUMA_LEAN_FRAME", lean)
+            assert rt._lean_ok() == (lean == "1")
+            for _ in range(2):          # (second frame: cached capacities, pooled buffers, hinted plans)
+                for p in rt.parameters():
+                    p.grad = None
+                r = rt.frame()
+            res[lean] = (r, [p.grad.clone() for p in rt.parameters()])
+        (r1, g1), (r0, g0) = res["1"], res["0"]
+        assert torch.isfinite(r1.loss) and abs(float(r1.loss) - float(r0.loss)) < 1e-6 * max(1.0, abs(float(r0.loss)))
+        assert rel_max(r1.x, r0.x) < 1e-6 and rel_max(r1.F, r0.F) < 1e-5 and r1.F.shape == r0.F.shape
+        assert len(g1) == 12 and any(float(g.abs().max()) > 0 for g in g1)
+        for a, b in zip(g1, g0):
+            assert a.shape == b.shape and torch.isfinite(a).all() and rel_max(a, b) < 2e-5
+
+
 def test_frame_image_matches_oracle_render():
     """End-to-end image parity on the tiny scene: HIP sim+binding+raster vs oracle raster on the HIP state."""
     rt = _runtime("tiny", fused=True)
