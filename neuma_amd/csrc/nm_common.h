@@ -66,6 +66,7 @@ int nm_shard_pack_fwd(nm_mpm* h, const int32_t* shared, int32_t cap_shared, floa
                       void* stream);
 int nm_shard_pack_bwd(nm_mpm* h, const int32_t* shared, int32_t cap_shared, float* buf, const unsigned char* mine, void* stream);   // [nblocks] each: 0 / INT_MAX between exchanges
 int nm_material_prepare(const nm_mlp* w, float* wperm, void* stream);   // weights -> MFMA operand order, once per roll-out
+int nm_material_prepare2(const nm_mlp* wa, float* wperm_a, const nm_mlp* wb, float* wperm_b, void* stream);   // two nets, one launch
 size_t nm_material_prepared_floats();
 int nm_material_wgrad_reduce(const float* wpart, int32_t n, float* gw0, float* gw1, float* gw2, int accumulate, void* stream);
 

@@ -287,8 +287,11 @@ __device__ __forceinline__ void stage_permuted(const float* __restrict__ wperm, 
 }
 // one workgroup: raw (out,in) weights -> operand order in global memory (once per roll-out and net)
 __global__ void __launch_bounds__(256) k_permute_weights(const float* __restrict__ w0, const float* __restrict__ w1,
-                                                         const float* __restrict__ w2, float* __restrict__ wperm) {
+                                                         const float* __restrict__ w2, float* __restrict__ wperm,
+                                                         const float* __restrict__ w0b, const float* __restrict__ w1b,
+                                                         const float* __restrict__ w2b, float* __restrict__ wpermb) {
   __shared__ float raw[NM_RAWTOT];
+  if (blockIdx.x == 1) { w0 = w0b; w1 = w1b; w2 = w2b; wperm = wpermb; }     // (second net of a roll-out: same launch)
   __shared__ float perm[NM_PERM_ALL];
   stage_raw_weights(w0, w1, w2, raw);
   __syncthreads();
@@ -682,7 +685,15 @@ int nm_material_fwd_pair_launch(int32_t n, float alpha_p, const float* wperm_p, 
   return NM_OK;
 }
 int nm_material_prepare(const nm_mlp* w, float* wperm, void* stream) {
-  NM_LAUNCH(k_permute_weights, dim3(1), dim3(256), 0, (hipStream_t)stream, w->w0, w->w1, w->w2, wperm);
+  NM_LAUNCH(k_permute_weights, dim3(1), dim3(256), 0, (hipStream_t)stream, w->w0, w->w1, w->w2, wperm, (const float*)nullptr,
+            (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}
+// both nets of a roll-out in one launch
+int nm_material_prepare2(const nm_mlp* wa, float* wperm_a, const nm_mlp* wb, float* wperm_b, void* stream) {
+  NM_LAUNCH(k_permute_weights, dim3(2), dim3(256), 0, (hipStream_t)stream, wa->w0, wa->w1, wa->w2, wperm_a, wb->w0, wb->w1, wb->w2,
+            wperm_b);
   NM_LAUNCH_CHECK();
   return NM_OK;
 }
@@ -1392,8 +1403,20 @@ __global__ void __launch_bounds__(256) k_lora_merge_layers(LoraJobs jobs) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= L.out_f * L.in_f) return;
   const int o = e / L.in_f, i = e - o * L.in_f;
+  // (the loads of a chunk are independent and issued together: a rolled loop pays one L2 round trip per term - 64 of them
+  //  in the adjoint below - and these kernels were 9 / 20 us for a few kflop)
+  const float* __restrict__ Bp = L.B + o * L.r;
+  const float* __restrict__ Ap = L.A + i;
   float acc = 0.f;
-  for (int k = 0; k < L.r; ++k) acc = fmaf(L.B[o * L.r + k], L.A[k * L.in_f + i], acc);
+  int k = 0;
+  for (; k + 8 <= L.r; k += 8) {
+    float b[8], a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { b[u] = Bp[k + u]; a[u] = Ap[(k + u) * L.in_f]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = fmaf(b[u], a[u], acc);
+  }
+  for (; k < L.r; ++k) acc = fmaf(Bp[k], Ap[k * L.in_f], acc);
   L.o0[e] = fmaf(L.scaling, acc, L.W[e]);
 }
 __global__ void __launch_bounds__(256) k_lora_merge_layers_bwd(LoraJobs jobs) {
@@ -1401,16 +1424,36 @@ __global__ void __launch_bounds__(256) k_lora_merge_layers_bwd(LoraJobs jobs) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < L.out_f * L.r) {          // gB[o][k] = s * sum_i gW[o][i] A[k][i]
     const int o = e / L.r, k = e - o * L.r;
+    const float* __restrict__ Wp = L.W + o * L.in_f;
+    const float* __restrict__ Ap = L.A + k * L.in_f;
     float acc = 0.f;
-    for (int i = 0; i < L.in_f; ++i) acc = fmaf(L.W[o * L.in_f + i], L.A[k * L.in_f + i], acc);
+    int i = 0;
+    for (; i + 8 <= L.in_f; i += 8) {
+      float w[8], a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { w[u] = Wp[i + u]; a[u] = Ap[i + u]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = fmaf(w[u], a[u], acc);
+    }
+    for (; i < L.in_f; ++i) acc = fmaf(Wp[i], Ap[i], acc);
     L.o0[e] = L.scaling * acc;
     return;
   }
   e -= L.out_f * L.r;
   if (e < L.r * L.in_f) {           // gA[k][i] = s * sum_o B[o][k] gW[o][i]
     const int k = e / L.in_f, i = e - k * L.in_f;
+    const float* __restrict__ Bp = L.B + k;
+    const float* __restrict__ Wp = L.W + i;
     float acc = 0.f;
-    for (int o = 0; o < L.out_f; ++o) acc = fmaf(L.B[o * L.r + k], L.W[o * L.in_f + i], acc);
+    int o = 0;
+    for (; o + 8 <= L.out_f; o += 8) {
+      float b[8], w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { b[u] = Bp[(o + u) * L.r]; w[u] = Wp[(o + u) * L.in_f]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = fmaf(b[u], w[u], acc);
+    }
+    for (; o < L.out_f; ++o) acc = fmaf(Bp[o * L.r], Wp[o * L.in_f], acc);
     L.o1[e] = L.scaling * acc;
   }
 }

@@ -626,6 +626,22 @@ __device__ __forceinline__ void rank_sort_to_global(const unsigned long long* s_
   }
 }
 
+// elements per thread = ceil(n / NT), 1..8: the rank sort's cost is n x that, and a 330-pair cell is not a 512-pair one
+template <int NT>
+__device__ __forceinline__ void rank_sort_dispatch(const unsigned long long* s_key, const uint32_t* s_val, int n, int t,
+                                                   unsigned long long* __restrict__ gkey, uint32_t* __restrict__ gval) {
+  switch ((n + NT - 1) / NT) {
+    case 1: rank_sort_to_global<NT, 1>(s_key, s_val, n, t, gkey, gval); break;
+    case 2: rank_sort_to_global<NT, 2>(s_key, s_val, n, t, gkey, gval); break;
+    case 3: rank_sort_to_global<NT, 3>(s_key, s_val, n, t, gkey, gval); break;
+    case 4: rank_sort_to_global<NT, 4>(s_key, s_val, n, t, gkey, gval); break;
+    case 5: rank_sort_to_global<NT, 5>(s_key, s_val, n, t, gkey, gval); break;
+    case 6: rank_sort_to_global<NT, 6>(s_key, s_val, n, t, gkey, gval); break;
+    case 7: rank_sort_to_global<NT, 7>(s_key, s_val, n, t, gkey, gval); break;
+    default: rank_sort_to_global<NT, 8>(s_key, s_val, n, t, gkey, gval); break;
+  }
+}
+
 // A workgroup takes four consecutive cells.  All four small: each wave sorts its own in a private LDS slice.  Otherwise the
 // four are sorted one after the other by the whole workgroup (rank sort in LDS up to NM_CELL_LDS pairs; beyond that a bitonic
 // network directly on global memory).
@@ -657,9 +673,7 @@ __global__ void __launch_bounds__(256) k_cell_sort(int ncell, const uint32_t* __
         for (int i = lane; i < m; i += 64) { wk[i] = keys[l + i]; wv[i] = vals[l + i]; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (m <= 128) rank_sort_to_global<64, 2>(wk, wv, m, lane, keys + l, vals + l);
-        else if (m <= 256) rank_sort_to_global<64, 4>(wk, wv, m, lane, keys + l, vals + l);
-        else rank_sort_to_global<64, 8>(wk, wv, m, lane, keys + l, vals + l);
+        rank_sort_dispatch<64>(wk, wv, m, lane, keys + l, vals + l);      // (wave-uniform m)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
@@ -673,7 +687,7 @@ __global__ void __launch_bounds__(256) k_cell_sort(int ncell, const uint32_t* __
         if (m <= NM_CELL_LDS) {
           for (int i = tid; i < m; i += 256) { s_key[i] = keys[lo[q] + i]; s_val[i] = vals[lo[q] + i]; }
           __syncthreads();
-          rank_sort_to_global<256, 8>(s_key, s_val, m, tid, keys + lo[q], vals + lo[q]);
+          rank_sort_dispatch<256>(s_key, s_val, m, tid, keys + lo[q], vals + lo[q]);
         } else {   // thousands of Gaussians of one bin in one depth slab: a sorting network on global memory
           bitonic_sort_kv<256>((volatile unsigned long long*)(keys + lo[q]), (volatile uint32_t*)(vals + lo[q]), m, tid, bsync);
         }
@@ -1630,6 +1644,10 @@ __global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, int nbx, int ntile,
                                                        float* __restrict__ acc /* (K, 9) */) {
   __shared__ BwdLdsR L;
   const int b = blockIdx.x;
+  // A render whose bin lists overflowed composited the background only and left lists / checkpoints unwritten: it contributes
+  // no gradient (the accumulators stay zero).  The host learns of the overflow from the status words and raises; this guard
+  // is what lets it do so without stalling the reverse sweep on the forward pass's completion.
+  if (hdr[3]) return;
   if (b < ntile)
     bwd_whole<WITH_OPACITY>(L, k, nbx, b % k.gx, b / k.gx + k.ty0, off, keys, vals, tile_rec, recs, final_T, n_contrib, dL_dpix, acc);
   else

@@ -116,9 +116,7 @@ extern "C" int nm_rollout_forward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cf
     nm_set_error("rollout workspace too small: need %zu got %zu", w.total, workspace_bytes);
     return NM_ERR_WORKSPACE;
   }
-  int rc = nm_material_prepare(we, w.perm_e, stream);
-  if (rc) return rc;
-  rc = nm_material_prepare(wp, w.perm_p, stream);
+  int rc = nm_material_prepare2(we, w.perm_e, wp, w.perm_p, stream);
   if (rc) return rc;
   for (int t = 0; t < cfg->substeps; ++t) {
     nm_particles cur = rec(states, n, t), nxt = rec(states, n, t + 1);
@@ -177,9 +175,7 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
   const size_t N = (size_t)n;
   float* states_m = const_cast<float*>(states);
   const float* gin = gstate_last;
-  int rc = nm_material_prepare(we, w.perm_e, stream);
-  if (rc) return rc;
-  rc = nm_material_prepare(wp, w.perm_p, stream);
+  int rc = nm_material_prepare2(we, w.perm_e, wp, w.perm_p, stream);
   if (rc) return rc;
   const bool verified = cfg->cache_verified != 0 && gridcache != nullptr && cfg->grid_cache_blocks > 0;
   const int polar = cfg->svd_adjoint == NM_SVD_ADJOINT_POLAR ? 1 : 0;
@@ -314,9 +310,7 @@ extern "C" int nm_rollout_forward_sharded(nm_mpm* h, int32_t n, const nm_rollout
   }
   NM_HIP_CHECK(hipMemsetAsync(sw.status, 0, sizeof(int32_t), (hipStream_t)stream));
   if (n > 0) {
-    rc = nm_material_prepare(we, w.perm_e, stream);
-    if (rc) return rc;
-    rc = nm_material_prepare(wp, w.perm_p, stream);
+    rc = nm_material_prepare2(we, w.perm_e, wp, w.perm_p, stream);
     if (rc) return rc;
   }
   nm_mpm_set_fresh_rows(h, 1);
@@ -399,9 +393,7 @@ extern "C" int nm_rollout_backward_sharded(nm_mpm* h, int32_t n, const nm_rollou
   float* states_m = const_cast<float*>(states);
   const float* gin = gstate_last;
   if (n > 0) {
-    rc = nm_material_prepare(we, w.perm_e, stream);
-    if (rc) return rc;
-    rc = nm_material_prepare(wp, w.perm_p, stream);
+    rc = nm_material_prepare2(we, w.perm_e, wp, w.perm_p, stream);
     if (rc) return rc;
   }
   const int polar = cfg->svd_adjoint == NM_SVD_ADJOINT_POLAR ? 1 : 0;

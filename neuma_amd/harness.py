@@ -199,141 +199,187 @@ def _tail_backward(rt, recs, grads, streams, dx_out):
             "nm_spmm_csr")
 
 
+class _FrameState(object):
+    """What the forward half of a one-node frame keeps for its reverse sweep."""
+    __slots__ = ("recs", "grads", "streams", "keep", "states", "eff", "gcache", "svdc", "actc", "status", "ev", "cache_blocks",
+                 "adj", "weight")
+
+
+def _frame_static(rt):
+    """ctypes arguments of a one-node frame that do not change from frame to frame (statics, the LoRA layers' job templates),
+    rebuilt when one of the tensors behind them is replaced."""
+    from . import _lib as L
+    from . import rollout as R
+    layers = rt._lora_layers
+    st_t = (rt.statics.vol, rt.statics.rho, rt.statics.clip_bound, rt.statics.enabled)
+    key = tuple(t.data_ptr() for t in st_t) + tuple(t.data_ptr() for l in layers for t in (l.weight, l.lora_B, l.lora_A))
+    c = rt.__dict__.get("_frame_static_cache")
+    if c is None or c[0] != key:
+        fwd, bwd = (L.nm_lora_layer * 6)(), (L.nm_lora_layer * 6)()
+        woff, goff, sizes = [], [], []
+        wo = go = 0
+        for i, l in enumerate(layers):
+            W = l.weight
+            fwd[i] = L.nm_lora_layer(W.shape[0], W.shape[1], l.r, float(l.scaling), L.ptr(W), L.ptr(l.lora_B), L.ptr(l.lora_A), None, None)
+            bwd[i] = L.nm_lora_layer(W.shape[0], W.shape[1], l.r, float(l.scaling), None, L.ptr(l.lora_B), L.ptr(l.lora_A), None, None)
+            woff.append(wo); goff.append(go)
+            sizes += [l.lora_B.numel(), l.lora_A.numel()]
+            wo += W.numel()
+            go += l.lora_B.numel() + l.lora_A.numel()
+        shapes = [tuple(t.shape) for l in layers for t in (l.lora_B, l.lora_A)]
+        c = rt._frame_static_cache = (key, rt.statics.c_struct(), fwd, bwd, woff, goff, sizes, shapes, go, sum(R._WSZ))
+    return c
+
+
+def _frame_forward(rt, weight, jobs, streams):
+    """Forward half of the whole frame of a one-GPU runtime, outside autograd: effective weights of both nets (one launch), the
+    S-substep roll-out (nm_rollout_forward), binding + covariance push-forward, every render job + loss (finetune.py:331-389).
+    Returns (loss, x, F (N, 9), _FrameState)."""
+    import ctypes as C
+    from . import _lib as L
+    from . import rollout as R
+    lib, dev = L.lib(), rt.device
+    sim = rt.sim_fused
+    n, S = rt.n_local, int(sim.substeps)
+    stream = L.stream_ptr(dev)
+    _, st, jf, _jb, woff, _goff, _sizes, _shapes, _gtot, nw = _frame_static(rt)
+    # effective weights e0 | e1 | e2 | p0 | p1 | p2
+    eff = torch.empty(2 * nw, dtype=torch.float32, device=dev)
+    base = eff.data_ptr()
+    for i in range(6):
+        jf[i].o0 = base + 4 * woff[i]
+    L.check(lib.nm_lora_merge_layers(6, jf, stream), "nm_lora_merge_layers")
+    # roll-out: record 0 = the (packed) start state
+    states = torch.empty(S + 1, 33 * n, dtype=torch.float32, device=dev)
+    states[0, :24 * n].copy_(rt._start_packed())
+    sz = rt.__dict__.get("_roll_sizes")
+    cache_blocks = int(sim.grid_cache_blocks())
+    if sz is None or sz[0] != (n, S, cache_blocks):
+        sz = rt._roll_sizes = ((n, S, cache_blocks), int(lib.nm_rollout_workspace(n, S)),
+                               int(lib.nm_rollout_gridcache_bytes(S, cache_blocks)) if cache_blocks > 0 else 0,
+                               int(lib.nm_rollout_svdcache_bytes(n, S)), int(lib.nm_rollout_actcache_bytes(n, S)))
+    _, ws_bytes, gc_bytes, svd_bytes, act_bytes = sz
+    ws = rt._scratch("ws", ws_bytes)
+    gcache = torch.empty(gc_bytes, dtype=torch.uint8, device=dev) if gc_bytes > 0 else None
+    budget = R._ACT_CACHE_GB * (1 << 30)
+    svdc = actc = None
+    if R._SVD_CACHE and R._ACT_LIVE[0] + svd_bytes <= budget:
+        svdc = R._Lease(svd_bytes, dev, True)
+    if R._ACT_CACHE != '0' and (R._ACT_CACHE == '1' or R._ACT_LIVE[0] + act_bytes <= budget):
+        actc = R._Lease(act_bytes, dev, True)
+    adj = L.SVD_ADJOINT[sim.svd_adjoint]
+    cfg = L.nm_rollout_cfg(S, float(sim.plasticity.alpha), cache_blocks if gcache is not None else 0, 0, adj,
+                           svdc.t.data_ptr() if svdc is not None else None, actc.t.data_ptr() if actc is not None else None)
+    w0, w1 = R._WSZ[0], R._WSZ[0] + R._WSZ[1]
+    mle = L.nm_mlp(base, base + 4 * w0, base + 4 * w1)
+    pb = base + 4 * nw
+    mlp = L.nm_mlp(pb, pb + 4 * w0, pb + 4 * w1)
+    gptr = gcache.data_ptr() if gcache is not None else None
+    L.check(lib.nm_rollout_forward(rt.model.handle(), n, C.byref(cfg), C.byref(st), C.byref(mle), C.byref(mlp), states.data_ptr(),
+                                   gptr, ws.data_ptr(), ws_bytes, stream), "nm_rollout_forward")
+    fs = _FrameState()
+    fs.status = fs.ev = None
+    if gcache is not None and R._CACHE_STATUS:
+        pool = rt.__dict__.setdefault("_status_pool", [])      # (pinned words + event: handed back by the backward pass)
+        if pool and pool[-1][0].numel() == S:
+            fs.status, fs.ev = pool.pop()
+        else:
+            fs.status, fs.ev = torch.empty(S, dtype=torch.int32, pin_memory=True), torch.cuda.Event()
+        L.check(lib.nm_rollout_cache_status(gptr, C.byref(cfg), C.c_void_p(fs.status.data_ptr()), stream), "nm_rollout_cache_status")
+        fs.ev.record()
+    if sim._cache_blocks is None:      # first roll-out: size the grid cache from what the scene touches (one host sync)
+        blocks, _ = rt.model.grid_stats()
+        sim._cache_blocks = int(1.5 * blocks) + 64
+    last = states[S]
+    x, Fl = last[:3 * n].view(n, 3), last[15 * n:24 * n].view(n, 9)
+    p_cur = x if rt._unit_frame() else ((x - rt.center) / rt.size).contiguous()      # finetune.py:373
+    loss, fs.recs, fs.grads, fs.keep = _tail_forward(rt, p_cur, Fl, weight, jobs, streams)
+    fs.streams, fs.states, fs.eff, fs.gcache, fs.svdc, fs.actc = streams, states, eff, gcache, svdc, actc
+    fs.cache_blocks, fs.adj = (cache_blocks if gcache is not None else 0), adj
+    return loss, x, Fl, fs
+
+
+def _frame_backward(rt, fs, g=None):
+    """Reverse sweep of _frame_forward down to dL/dB, dL/dA of the six LoRA layers (finetune.py:413-414), for dL/dloss = g (None:
+    1).  Returns the twelve gradients, views of one buffer, in the order B, A per layer (elasticity's three, plasticity's three)."""
+    import ctypes as C
+    from . import _lib as L
+    from . import rollout as R
+    lib, dev = L.lib(), rt.device
+    sim = rt.sim_fused
+    n, S = rt.n_local, int(sim.substeps)
+    _, st, _jf, jb, woff, goff, sizes, shapes, gtot, nw = _frame_static(rt)
+    # dL/d(x, v, C, F of the last record): B^T of the summed rasterizer adjoints lands in the head of a buffer whose
+    # tail (v, C, F: nothing downstream of the roll-out reads them) stays zero
+    glast = rt._scratch("glast", 4 * 24 * n, zero=True)
+    dx = glast[:12 * n].view(torch.float32).view(n, 3)
+    _tail_backward(rt, fs.recs, fs.grads, fs.streams, dx)
+    if not rt._unit_frame():
+        dx.div_(rt.size)
+    if g is not None:
+        dx.mul_(g)
+    stream = L.stream_ptr(dev)
+    verified = 0
+    gcache = fs.gcache
+    if gcache is not None and fs.ev is not None:
+        # the record headers travel back right behind the forward sweep: they are here long before the renders are through
+        if R._CACHE_WAIT and not fs.ev.query():
+            fs.ev.synchronize()
+        if fs.ev.query():
+            verified = int(min(fs.status.tolist()) >= 0)
+            rt._status_pool.append((fs.status, fs.ev))
+    gfirst = rt._scratch("gfirst", 4 * 24 * n)
+    gw = torch.empty(2 * nw, dtype=torch.float32, device=dev)
+    ws_bytes = rt._roll_sizes[1]
+    ws = rt._scratch("ws", ws_bytes)
+    svdc, actc = fs.svdc, fs.actc
+    cfg = L.nm_rollout_cfg(S, float(sim.plasticity.alpha), fs.cache_blocks, verified, fs.adj,
+                           svdc.t.data_ptr() if svdc is not None else None, actc.t.data_ptr() if actc is not None else None)
+    base = fs.eff.data_ptr()
+    w0, w1 = R._WSZ[0], R._WSZ[0] + R._WSZ[1]
+    mle = L.nm_mlp(base, base + 4 * w0, base + 4 * w1)
+    pb = base + 4 * nw
+    mlp = L.nm_mlp(pb, pb + 4 * w0, pb + 4 * w1)
+    gbase = gw.data_ptr()
+    L.check(lib.nm_rollout_backward(rt.model.handle(), n, C.byref(cfg), C.byref(st), C.byref(mle), C.byref(mlp), fs.states.data_ptr(),
+                                    gcache.data_ptr() if gcache is not None else None, glast.data_ptr(), gfirst.data_ptr(), gbase,
+                                    gbase + 4 * nw, ws.data_ptr(), ws_bytes, stream), "nm_rollout_backward")
+    for lease in (svdc, actc):
+        if lease is not None:
+            lease.release()
+    # dL/dW_eff -> dL/dB, dL/dA of the six layers: ONE launch
+    gba = torch.empty(gtot, dtype=torch.float32, device=dev)
+    ob = gba.data_ptr()
+    for i in range(6):
+        j = jb[i]
+        j.W = gbase + 4 * woff[i]
+        j.o0 = ob + 4 * goff[i]
+        j.o1 = ob + 4 * (goff[i] + sizes[2 * i])
+    L.check(lib.nm_lora_merge_layers_bwd(6, jb, stream), "nm_lora_merge_layers_bwd")
+    fs.recs = fs.grads = fs.keep = fs.states = fs.eff = fs.gcache = fs.svdc = fs.actc = None
+    return [v.view(sh) for v, sh in zip(gba.split(sizes), shapes)]
+
+
 class _Frame(torch.autograd.Function):
-    """The whole frame of a one-GPU runtime as ONE autograd node over the LoRA factors: effective weights of both nets (one
-    launch), the S-substep roll-out (nm_rollout_forward), binding + covariance push-forward, every render job + loss
-    (finetune.py:331-389); the reverse sweep runs the same chain backwards down to dL/dB, dL/dA of the six layers
-    (finetune.py:413-414).  Same library calls, same kernels and results as the composition LoRA merge -> _Rollout ->
-    _FrameTail that it replaces; what goes away is the host time between them (four autograd nodes each way, the packing /
-    unpacking of their inputs and outputs) - the frame time of the small configurations (bb, jd, sf) was host time."""
+    """The whole frame of a one-GPU runtime as ONE autograd node over the LoRA factors (_frame_forward / _frame_backward): the
+    same library calls, kernels and results as the composition LoRA merge -> _Rollout -> _FrameTail that it replaces; what goes
+    away is the host time between them (four autograd nodes each way, the packing / unpacking of their inputs and outputs) -
+    the frame time of the small configurations (bb, jd, sf) was host time.  SceneRuntime.frame(backward=True) calls the two
+    halves directly and adds the gradients to the parameters' .grad itself (no graph, no engine thread); this node is the same
+    thing for callers that want the loss inside a larger graph."""
 
     @staticmethod
     def forward(ctx, rt, weight, jobs, streams, *ba):
-        import ctypes as C
-        from . import _lib as L
-        from . import rollout as R
-        lib, dev = L.lib(), rt.device
-        sim = rt.sim_fused
-        n, S = rt.n_local, int(sim.substeps)
-        stream = L.stream_ptr(dev)
-        layers = rt._lora_layers
-        # effective weights e0 | e1 | e2 | p0 | p1 | p2
-        nw = sum(R._WSZ)
-        eff = torch.empty(2 * nw, dtype=torch.float32, device=dev)
-        jobs6 = (L.nm_lora_layer * 6)()
-        off, base = 0, eff.data_ptr()
-        for i, l in enumerate(layers):
-            W = l.weight
-            jobs6[i] = L.nm_lora_layer(W.shape[0], W.shape[1], l.r, float(l.scaling), L.ptr(W), L.ptr(ba[2 * i]), L.ptr(ba[2 * i + 1]),
-                                       base + 4 * off, None)
-            off += W.numel()
-        L.check(lib.nm_lora_merge_layers(6, jobs6, stream), "nm_lora_merge_layers")
-        # roll-out: record 0 = the (packed) start state
-        states = torch.empty(S + 1, 33 * n, dtype=torch.float32, device=dev)
-        states[0, :24 * n].copy_(rt._start_packed())
-        ws_bytes = int(lib.nm_rollout_workspace(n, S))
-        ws = rt._scratch("ws", ws_bytes)
-        cache_blocks = int(sim.grid_cache_blocks())
-        gc_bytes = int(lib.nm_rollout_gridcache_bytes(S, cache_blocks)) if cache_blocks > 0 else 0
-        gcache = torch.empty(gc_bytes, dtype=torch.uint8, device=dev) if gc_bytes > 0 else None
-        budget = R._ACT_CACHE_GB * (1 << 30)
-        svdc = actc = None
-        if R._SVD_CACHE:
-            svd_bytes = int(lib.nm_rollout_svdcache_bytes(n, S))
-            if R._ACT_LIVE[0] + svd_bytes <= budget:
-                svdc = R._Lease(svd_bytes, dev, True)
-        if R._ACT_CACHE != '0':
-            act_bytes = int(lib.nm_rollout_actcache_bytes(n, S))
-            if R._ACT_CACHE == '1' or R._ACT_LIVE[0] + act_bytes <= budget:
-                actc = R._Lease(act_bytes, dev, True)
-        adj = L.SVD_ADJOINT[sim.svd_adjoint]
-        cfg = L.nm_rollout_cfg(S, float(sim.plasticity.alpha), cache_blocks if gcache is not None else 0, 0, adj,
-                               L.ptr(svdc.t) if svdc is not None else None, L.ptr(actc.t) if actc is not None else None)
-        st = rt.statics.c_struct()
-        mle = L.nm_mlp(base, base + 4 * R._WSZ[0], base + 4 * (R._WSZ[0] + R._WSZ[1]))
-        pb = base + 4 * nw
-        mlp = L.nm_mlp(pb, pb + 4 * R._WSZ[0], pb + 4 * (R._WSZ[0] + R._WSZ[1]))
-        L.check(lib.nm_rollout_forward(rt.model.handle(), n, C.byref(cfg), C.byref(st), C.byref(mle), C.byref(mlp), L.ptr(states),
-                                       L.ptr(gcache), L.ptr(ws), ws_bytes, stream), "nm_rollout_forward")
-        status = ev = None
-        if gcache is not None and R._CACHE_STATUS:
-            status = torch.empty(S, dtype=torch.int32, pin_memory=True)
-            L.check(lib.nm_rollout_cache_status(L.ptr(gcache), C.byref(cfg), C.c_void_p(status.data_ptr()), stream), "nm_rollout_cache_status")
-            ev = torch.cuda.Event()
-            ev.record()
-        if sim._cache_blocks is None:      # first roll-out: size the grid cache from what the scene touches (one host sync)
-            blocks, _ = rt.model.grid_stats()
-            sim._cache_blocks = int(1.5 * blocks) + 64
-        last = states[S]
-        x, Fl = last[:3 * n].view(n, 3), last[15 * n:24 * n].view(n, 9)
-        p_cur = x if rt._unit_frame() else ((x - rt.center) / rt.size).contiguous()      # finetune.py:373
-        loss, recs, grads, keep = _tail_forward(rt, p_cur, Fl, weight, jobs, streams)
-        ctx.rt, ctx.recs, ctx.grads, ctx.streams, ctx.keep = rt, recs, grads, streams, keep
-        ctx.roll = (states, eff, gcache, svdc, actc, status, ev, cache_blocks if gcache is not None else 0, adj)
+        loss, x, Fl, fs = _frame_forward(rt, weight, jobs, streams)
+        ctx.rt, ctx.fs = rt, fs
         ctx.mark_non_differentiable(x, Fl)
         return loss, x, Fl
 
     @staticmethod
     def backward(ctx, g, _gx, _gF):
-        import ctypes as C
-        from . import _lib as L
-        from . import rollout as R
-        rt = ctx.rt
-        lib, dev = L.lib(), rt.device
-        sim = rt.sim_fused
-        n, S = rt.n_local, int(sim.substeps)
-        states, eff, gcache, svdc, actc, status, ev, cache_blocks, adj = ctx.roll
-        # dL/d(x, v, C, F of the last record): B^T of the summed rasterizer adjoints lands in the head of a buffer whose
-        # tail (v, C, F: nothing downstream of the roll-out reads them) stays zero
-        glast = rt._scratch("glast", 4 * 24 * n, zero=True).view(torch.float32)
-        dx = glast[:3 * n].view(n, 3)
-        _tail_backward(rt, ctx.recs, ctx.grads, ctx.streams, dx)
-        if rt._unit_frame():
-            dx.mul_(g)
-        else:
-            dx.mul_(g / rt.size)
-        stream = L.stream_ptr(dev)
-        verified = 0
-        if gcache is not None and ev is not None:
-            if R._CACHE_WAIT and not ev.query():
-                ev.synchronize()
-            verified = int(bool((status >= 0).all()))
-        nw = sum(R._WSZ)
-        gfirst = rt._scratch("gfirst", 4 * 24 * n)
-        gw = torch.empty(2 * nw, dtype=torch.float32, device=dev)
-        ws_bytes = int(lib.nm_rollout_workspace(n, S))
-        ws = rt._scratch("ws", ws_bytes)
-        cfg = L.nm_rollout_cfg(S, float(sim.plasticity.alpha), cache_blocks, verified, adj,
-                               L.ptr(svdc.t) if svdc is not None else None, L.ptr(actc.t) if actc is not None else None)
-        st = rt.statics.c_struct()
-        base = eff.data_ptr()
-        mle = L.nm_mlp(base, base + 4 * R._WSZ[0], base + 4 * (R._WSZ[0] + R._WSZ[1]))
-        pb = base + 4 * nw
-        mlp = L.nm_mlp(pb, pb + 4 * R._WSZ[0], pb + 4 * (R._WSZ[0] + R._WSZ[1]))
-        gbase = gw.data_ptr()
-        L.check(lib.nm_rollout_backward(rt.model.handle(), n, C.byref(cfg), C.byref(st), C.byref(mle), C.byref(mlp), L.ptr(states),
-                                        L.ptr(gcache), L.ptr(glast), L.ptr(gfirst), gbase, gbase + 4 * nw, L.ptr(ws), ws_bytes, stream),
-                "nm_rollout_backward")
-        for lease in (svdc, actc):
-            if lease is not None:
-                lease.release()
-        # dL/dW_eff -> dL/dB, dL/dA of the six layers: ONE launch
-        layers = rt._lora_layers
-        sizes = [(l.lora_B.numel(), l.lora_A.numel()) for l in layers]
-        gba = torch.empty(sum(a + b for a, b in sizes), dtype=torch.float32, device=dev)
-        jobs6 = (L.nm_lora_layer * 6)()
-        outs, off, goff, ob = [], 0, 0, gba.data_ptr()
-        for i, l in enumerate(layers):
-            W = l.weight
-            nb, na = sizes[i]
-            jobs6[i] = L.nm_lora_layer(W.shape[0], W.shape[1], l.r, float(l.scaling), gbase + 4 * off, L.ptr(l.lora_B), L.ptr(l.lora_A),
-                                       ob + 4 * goff, ob + 4 * (goff + nb))
-            outs += [gba[goff:goff + nb].view_as(l.lora_B), gba[goff + nb:goff + nb + na].view_as(l.lora_A)]
-            off += W.numel()
-            goff += nb + na
-        L.check(lib.nm_lora_merge_layers_bwd(6, jobs6, stream), "nm_lora_merge_layers_bwd")
-        ctx.recs = ctx.grads = ctx.keep = ctx.roll = None
-        return (None, None, None, None) + tuple(outs)
+        grads = _frame_backward(ctx.rt, ctx.fs, g)
+        ctx.fs = None
+        return (None, None, None, None) + tuple(grads)
 
 
 def make_material_cfg(alpha=1e-3):
@@ -598,9 +644,19 @@ class SceneRuntime(object):
             streams = self._frame_streams(jobs)
             self._tail_constants(de_x_prev, g_prev)
             ba = [t for l in self._lora_layers for t in (l.lora_B, l.lora_A)]
-            loss, x, F = _Frame.apply(self, float(weight), jobs, streams, *ba)
-            loss.backward()
-            return FrameResult(loss.detach(), x, F.view(-1, 3, 3))
+            if os.environ.get("NEUMA_LEAN_GRAPH") == "1":       # (the same through the autograd engine: tests)
+                loss, x, F = _Frame.apply(self, float(weight), jobs, streams, *ba)
+                loss.backward()
+                return FrameResult(loss.detach(), x, F.view(-1, 3, 3))
+            # forward, reverse sweep, and what loss.backward() would do with the result: accumulate into .grad
+            with torch.no_grad():
+                loss, x, F, fs = _frame_forward(self, float(weight), jobs, streams)
+                for p, gr in zip(ba, _frame_backward(self, fs)):
+                    if p.grad is None:
+                        p.grad = gr
+                    else:
+                        p.grad.add_(gr)
+            return FrameResult(loss, x, F.view(-1, 3, 3))
         rows = self.rows
         x, v, C, F = (t[rows] for t in self.start)
         x, v, C, F = self.rollout(x, v, C, F)

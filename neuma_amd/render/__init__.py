@@ -99,9 +99,10 @@ class BinCapacity(object):
     (nm_raster_forward's cap_pairs), `items` = work items of the split compositing (nm_raster_cfg.split_items).  The first
     render with a camera is checked synchronously (and repeated with a larger state buffer if it overflowed); afterwards the
     pair capacity is twice the last observed number of pairs and the status of every render is read back asynchronously.
-    An overflow that slipped through (the scene suddenly needs > 2x the pairs) is never silent: the render's own backward
-    pass checks the status before it produces gradients, the next forward with any camera and `flush_pending()` (what
-    evaluate / the trainers call at the end of a frame) check it too, and all of them raise."""
+    An overflow that slipped through (the scene suddenly needs > 2x the pairs) is never silent and never turns into garbage
+    gradients: such a render composites the background only, its backward pass contributes exactly zero (device-side guard in
+    k_render_bwd) and raises if the status has already arrived; the next forward with this camera, any later drain and
+    `flush_pending()` (what evaluate / the trainers call at the end of a frame) raise."""
 
     def __init__(self):
         self.cap = 0              # 0: not sized yet (first guess 8 K + 4096)
@@ -138,6 +139,8 @@ class _Pending(object):
         ev.synchronize()
         entry[3] = True
         pairs, overflow, items = int(status[0]), int(status[1]) & 0xFFFFFFFF, int(status[2])     # (high half: NM_RASTER_DEBUG)
+        _STATUS_POOL.append((status, ev))          # pinned words + event go round (allocating them was ~20 us per render)
+        entry[1] = entry[2] = None
         bins.observe(pairs, items)
         if overflow:
             raise L.NeumaHipError(f"rasterizer bin lists overflowed ({pairs} pairs > capacity): that render's image is incomplete; "
@@ -159,6 +162,10 @@ class _Pending(object):
 
 
 _PENDING = _Pending()
+_STATUS_POOL = []       # (pinned int64[3], event) pairs whose render has been looked at
+# NEUMA_RASTER_BACKWARD_WAIT=1: the backward pass waits for its forward pass's status before it produces gradients (an
+# overflow then raises before any gradient exists, at the price of a host stall per render)
+_BACKWARD_WAITS = os.environ.get("NEUMA_RASTER_BACKWARD_WAIT", "0") == "1"
 
 
 def flush_pending():
@@ -207,21 +214,30 @@ def raster_forward_raw(cam: RasterCamera, m3: Tensor, sh: Optional[Tensor], cp: 
     rec = RenderRecord()
     while True:
         cap = int(bins.cap)
-        cfg = L.nm_raster_cfg.from_buffer_copy(cam.cfg)      # this render's own copy: the item capacity may change later
-        cfg.split_items = int(bins.items)
-        nstate, nscratch = C.c_size_t(0), C.c_size_t(0)
-        L.check(lib.nm_raster_state_bytes_ex(C.byref(cfg), K, cap, C.byref(nstate), C.byref(nscratch)), "nm_raster_state_bytes_ex")
+        # this render's own copy of the settings (the item capacity may change later) and the buffer sizes that go with it:
+        # kept per (K, cap, items) - a steady frame loop asks for the same ones every frame
+        sized = cam.__dict__.get("_sized")
+        if sized is None or sized[0] != (K, cap, int(bins.items)):
+            cfg = L.nm_raster_cfg.from_buffer_copy(cam.cfg)
+            cfg.split_items = int(bins.items)
+            nstate, nscratch = C.c_size_t(0), C.c_size_t(0)
+            L.check(lib.nm_raster_state_bytes_ex(C.byref(cfg), K, cap, C.byref(nstate), C.byref(nscratch)), "nm_raster_state_bytes_ex")
+            sized = cam._sized = ((K, cap, int(bins.items)), cfg, int(nstate.value), int(nscratch.value))
+        _, cfg, nstate, nscratch = sized
         # kept for the backward pass: records, lists, checkpoints.  The forward-only part (pair log, counters, per-segment
         # scratch: the larger half) goes back to the caching allocator when this function returns - stream-ordered, so
         # the next render on this stream reuses it
-        state = torch.empty(int(nstate.value), dtype=torch.uint8, device=dev)
-        scratch = torch.empty(int(nscratch.value), dtype=torch.uint8, device=dev)
-        status = torch.zeros(3, dtype=torch.int64, pin_memory=True)
+        state = torch.empty(nstate, dtype=torch.uint8, device=dev)
+        scratch = torch.empty(nscratch, dtype=torch.uint8, device=dev)
+        if _STATUS_POOL:
+            status, ev = _STATUS_POOL.pop()
+            status.zero_()
+        else:
+            status, ev = torch.zeros(3, dtype=torch.int64, pin_memory=True), torch.cuda.Event()
         L.check(lib.nm_raster_forward_ex(C.byref(cfg), K, M, L.ptr(m3), L.ptr(sh), L.ptr(cp), L.ptr(op), L.ptr(cv), L.ptr(radii),
-                                         L.ptr(state), int(nstate.value), L.ptr(scratch), int(nscratch.value), cap, L.ptr(color),
+                                         L.ptr(state), nstate, L.ptr(scratch), nscratch, cap, L.ptr(color),
                                          C.c_void_p(status.data_ptr()), L.ptr(cam.tile_walk(dev)), stream),
                 "nm_raster_forward_ex")
-        ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
         if not first:
             rec.pending = _PENDING.add(bins, status, ev)
@@ -243,7 +259,11 @@ def raster_backward_raw(rec: RenderRecord, grad_color: Tensor, need_means2D=Fals
     lib = L.lib()
     dev = rec.m3.device
     if rec.pending is not None:
-        _Pending.examine(rec.pending, wait=True)     # no gradients of an incomplete image (the forward finished long ago)
+        # no gradients of an incomplete image: raises if the forward pass is known to have overflowed its lists.  If it has not
+        # finished yet (a frame loop whose host runs ahead of the device) nothing waits here: k_render_bwd reads the overflow
+        # flag on the device and contributes zero gradient in that case, and the status stays registered - the next render with
+        # this camera, any later drain, and flush_pending() raise
+        _Pending.examine(rec.pending, wait=_BACKWARD_WAITS)
     K, M = rec.K, rec.M
     g = grad_color.float().contiguous()
     dmeans3D = torch.empty(K, 3, dtype=torch.float32, device=dev)

@@ -223,16 +223,37 @@ def test_raster_heavy_depth_cell_and_capacity_growth():
         rast2(means3D=means.to(dev()), means2D=None, opacities=op.to(dev()), colors_precomp=col.to(dev()), cov3D_precomp=cov.to(dev()))
     img3, _ = rast2(means3D=means.to(dev()), means2D=None, opacities=op.to(dev()), colors_precomp=col.to(dev()), cov3D_precomp=cov.to(dev()))
     assert torch.equal(img3, img.detach())
-    # ... nor used: the overflowing render's own backward pass refuses to produce gradients, and flush_pending() (what an
+    # ... nor used: the overflowing render's own backward pass produces no gradient from it, and flush_pending() (what an
     # evaluation loop calls before an image leaves the GPU) raises too
+    # "backward": the reverse sweep does not wait for the forward pass's status (a frame loop's host runs ahead of the device):
+    # it raises if the overflow is already known, otherwise the device-side guard makes the render contribute exactly zero
+    # gradient and the status stays registered for the next look.  "backward_wait" (NEUMA_RASTER_BACKWARD_WAIT=1): it waits and
+    # raises before any gradient exists.
+    import neuma_amd.render as NR
     from neuma_amd.render import flush_pending
-    for how in ("backward", "flush"):
+    for how in ("backward", "backward_wait", "flush"):
         flush_pending()                 # (the previous render's status has been looked at: nothing re-grows the capacity below)
         rast2._cam.bins.cap = 64
         mm = means.to(dev()).requires_grad_(True)
         bad, _ = rast2(means3D=mm, means2D=None, opacities=op.to(dev()), colors_precomp=col.to(dev()), cov3D_precomp=cov.to(dev()))
-        with pytest.raises(NeumaHipError):
-            bad.sum().backward() if how == "backward" else flush_pending()
+        if how == "backward":
+            try:
+                bad.sum().backward()
+                assert float(mm.grad.abs().max()) == 0.0
+                with pytest.raises(NeumaHipError):
+                    flush_pending()
+            except NeumaHipError:
+                pass
+        elif how == "backward_wait":
+            NR._BACKWARD_WAITS = True
+            try:
+                with pytest.raises(NeumaHipError):
+                    bad.sum().backward()
+            finally:
+                NR._BACKWARD_WAITS = False
+        else:
+            with pytest.raises(NeumaHipError):
+                flush_pending()
         flush_pending()                 # (nothing left behind)
     img4, _ = rast2(means3D=means.to(dev()), means2D=None, opacities=op.to(dev()), colors_precomp=col.to(dev()), cov3D_precomp=cov.to(dev()))
     assert torch.equal(img4, img.detach())

@@ -155,20 +155,29 @@ def test_one_node_frame_equals_the_composition_of_nodes(scene, over, monkeypatch
         rt.set_start_state("deformed")      # (at F = I the gradients are run-to-run noise of a cancelling sum in either path)
         rt.make_ground_truth()
         res = {}
-        for lean in ("1", "0"):
+        # "direct": the two halves called back to back, gradients added to .grad by the runtime (what frame() does);
+        # "graph": the same as an autograd node (harness._Frame) through loss.backward(); "nodes": the composition
+        for mode, (lean, graph) in {"direct": ("1", "0"), "graph": ("1", "1"), "nodes": ("0", "0")}.items():
             monkeypatch.setenv("NEUMA_LEAN_FRAME", lean)
+            monkeypatch.setenv("NEUMA_LEAN_GRAPH", graph)
             assert rt._lean_ok() == (lean == "1")
             for _ in range(2):          # (second frame: cached capacities, pooled buffers, hinted plans)
                 for p in rt.parameters():
                     p.grad = None
                 r = rt.frame()
-            res[lean] = (r, [p.grad.clone() for p in rt.parameters()])
-        (r1, g1), (r0, g0) = res["1"], res["0"]
-        assert torch.isfinite(r1.loss) and abs(float(r1.loss) - float(r0.loss)) < 1e-6 * max(1.0, abs(float(r0.loss)))
-        assert rel_max(r1.x, r0.x) < 1e-6 and rel_max(r1.F, r0.F) < 1e-5 and r1.F.shape == r0.F.shape
-        assert len(g1) == 12 and any(float(g.abs().max()) > 0 for g in g1)
-        for a, b in zip(g1, g0):
-            assert a.shape == b.shape and torch.isfinite(a).all() and rel_max(a, b) < 2e-5
+            grads = [p.grad.clone() for p in rt.parameters()]
+            r = rt.frame()              # a third frame without clearing: the gradients accumulate like loss.backward() does
+            for p, g in zip(rt.parameters(), grads):
+                assert rel_max(p.grad, 2 * g) < 2e-5
+            res[mode] = (r, grads)
+        (r0, g0) = res["nodes"]
+        for mode in ("direct", "graph"):
+            r1, g1 = res[mode]
+            assert torch.isfinite(r1.loss) and abs(float(r1.loss) - float(r0.loss)) < 1e-6 * max(1.0, abs(float(r0.loss)))
+            assert rel_max(r1.x, r0.x) < 1e-6 and rel_max(r1.F, r0.F) < 1e-5 and r1.F.shape == r0.F.shape
+            assert len(g1) == 12 and any(float(g.abs().max()) > 0 for g in g1)
+            for a, b in zip(g1, g0):
+                assert a.shape == b.shape and torch.isfinite(a).all() and rel_max(a, b) < 2e-5, mode
 
 
 def test_frame_image_matches_oracle_render():
