@@ -40,7 +40,7 @@ def prof_table(lib):
 
 
 # algorithmic flop per particle and launch of the constitutive kernels (see the roofline block in main)
-MATERIAL_FLOPS = {"k_material_fwd": 11008.0, "k_material_bwd": 3 * 11008.0, "k_material_bwd_pair": 6 * 11008.0}
+MATERIAL_FLOPS = {"k_material_fwd": 11008.0, "k_material_fwd_pair": 2 * 11008.0, "k_material_bwd": 3 * 11008.0, "k_material_bwd_pair": 6 * 11008.0}
 
 
 def algorithmic_bytes(kernel: str, rt, D) -> float:
@@ -67,6 +67,7 @@ def algorithmic_bytes(kernel: str, rt, D) -> float:
         "k_preprocess": (4 * (3 + 6 + 1) + 12 * (cfg["sh"] + 1) ** 2) * K + 60.0 * K,
         "k_preprocess_bwd": (4 * (3 + 6) + 12 * (cfg["sh"] + 1) ** 2) * K + 36.0 * K + 12.0 * K,
         "k_material_fwd": 72.0 * N,
+        "k_material_fwd_pair": (96.0 + 2 * 36.0) * N + 16.0 * T,     # g2p inputs + stencil nodes, F_{t+1} and stress_{t+1} out
         "k_material_bwd": 108.0 * N,
         "k_material_bwd_pair": 216.0 * N,
         "k_p2g": 124.0 * N + 16.0 * T,
@@ -297,7 +298,7 @@ def main():
                     "frac": round(achieved / 157.3, 5), "traffic": None, "launches": calls, "avg_us": round(avg_s * 1e6, 2),
                     "algorithmic_flops_per_launch": flops,
                     "note": "f32-input MFMA (v_mfma_f32_16x16x4_f32) peak = 157.3 TFLOP/s; the kernel also carries the SVD and GELU VALU work"}
-            if base != "k_material_fwd":
+            if not base.startswith("k_material_fwd"):
                 cached = os.environ.get("NEUMA_ACT_CACHE", "auto") != "0" and not args.per_op
                 roof["activation_cache"] = bool(cached)
                 # with the cache the kernel runs 204 of the 284 MFMAs per tile (second and third layer of the forward pass loaded, first recomputed)
