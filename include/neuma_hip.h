@@ -45,7 +45,8 @@ const char* nm_last_error(void);
 
 /* HIP-event timing of the library's own kernel launches, on the stream they are launched on.
  * nm_prof_enable(1, NULL) times every kernel; nm_prof_enable(1, "k_render_bwd") only that one (two event
- * records per launch); nm_prof_enable(0, NULL) stops.  nm_prof_report synchronises the recorded events and
+ * records per launch); nm_prof_enable(n > 1, name) times every n-th matching launch only (a pair of event records costs
+ * ~11 us of bubble around the launch: sampling keeps a timed region honest); nm_prof_enable(0, NULL) stops.  nm_prof_report synchronises the recorded events and
  * writes "name calls total_ms\n" lines (NUL-terminated, truncated to cap); nm_prof_reset drops the samples. */
 int nm_prof_enable(int32_t on, const char* only_kernel);
 int nm_prof_report(char* out, size_t cap);

@@ -40,9 +40,12 @@ static bool prof_match(const char* name) {
   // template instantiations arrive as "k_material_fwd<NM_ELASTICITY>": match on the prefix
   return strncmp(name, g_only.c_str(), g_only.size()) == 0;
 }
+static int g_stride = 1;        // time every g_stride-th matching launch (nm_prof_enable(on > 1))
+static long g_seen = 0;
 void nm_prof_begin(const char* name, hipStream_t s) {
   g_cur_active = false;
   if (!prof_match(name) || g_samples.size() > 2000000) return;
+  if (g_stride > 1 && (g_seen++ % g_stride) != 0) return;
   g_cur = prof_event();
   if (!g_cur) return;
   (void)hipEventRecord(g_cur, s);
@@ -59,6 +62,8 @@ void nm_prof_end(const char* name, hipStream_t s) {
 extern "C" int nm_prof_enable(int32_t on, const char* only_kernel) {
   g_only = only_kernel ? only_kernel : "";
   g_nm_prof_on = on ? 1 : 0;
+  g_stride = on > 1 ? on : 1;
+  g_seen = 0;
   return NM_OK;
 }
 extern "C" int nm_prof_reset(void) {
