@@ -1374,6 +1374,31 @@ __device__ __forceinline__ float wave_fold8(const float* v, int lane) {
   d += dpp_mov<0x128>(d);                 // row_ror:8 == lane ^ 8 within the row of 16
   return add_xor32(add_xor16(d));
 }
+// The same sums with register-pair swaps for the two widest steps: v_permlane32_swap / v_permlane16_swap exchange halves
+// (rows) BETWEEN two registers, which is exactly the keep / send exchange of a folding step - no selects, no DPP hazards.
+// 8 -> 4 values over lane bit 5, 4 -> 2 over bit 4, 2 -> 1 over bit 3 (one select pair), then three single-value steps
+// inside the groups of eight: 18 instructions instead of 28 + the s_nops of seven DPP adds in a row.
+// On return the lanes with (lane & 7) == 0 hold the wave total of value  lane >> 3.
+__device__ __forceinline__ float wave_fold8_swap(const float* v, int lane) {
+  float a[4], c[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 4]), false, false);
+    a[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);      // lanes 0-31: value i, lanes 32-63: value i + 4
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[i]), __float_as_uint(a[i + 2]), false, false);
+    c[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);      // even rows: a[i], odd rows: a[i + 2]
+  }
+  const bool b3 = lane & 8;
+  const float keep = b3 ? c[1] : c[0], send = b3 ? c[0] : c[1];
+  float d = keep + dpp_mov<0x128>(send);    // row_ror:8: the partner with bit 3 flipped
+  d += dpp_mov<0xB1>(d);                    // lane ^ 1
+  d += dpp_mov<0x4E>(d);                    // lane ^ 2
+  d += dpp_mov<0x141>(d);                   // row_half_mirror: lane l reads lane 7 - l of its group of eight (the other quad)
+  return d;
+}
 __device__ __forceinline__ float wave_sum_dpp(float x) {
   x += dpp_mov<0xB1>(x);
   x += dpp_mov<0x4E>(x);
@@ -1418,8 +1443,8 @@ __device__ __forceinline__ void render_bwd_range(BwdLdsR& L, const RK& k, long l
   const float bg_dot = k.bg[0] * P.dp0 + k.bg[1] * P.dp1 + k.bg[2] * P.dp2;
   const float kx = 0.5f * k.W / NM_LOG2E, ky = 0.5f * k.H / NM_LOG2E;
   float* my_acc = L.acc[wave];
-  // lane l < 8 owns fold slot value index:
-  const int slot = 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1);
+  // fold slot (value index) of the lanes that end up holding a total:
+  const int slot = lane >> 3;           // (wave_fold8_swap: lanes 0, 8, ..., 56 hold values 0..7)
   for (int i = lane; i < NM_RB_BATCH * NM_NG; i += 64) my_acc[i] = 0.f;
   // Gaussians behind every pixel's last contributor (the forward pass stopped compositing there) cannot
   // contribute: the wave skips them before doing any arithmetic, the tile skips whole batches of them
@@ -1509,11 +1534,12 @@ __device__ __forceinline__ void render_bwd_range(BwdLdsR& L, const RK& k, long l
       g[3] = -gdx * dy * dL_dG;              // d/d conic.y (full off-diagonal derivative)
       g[4] = -0.5f * gdy * dy * dL_dG;       // d/d conic.z
       const float gop = Gm * dL_dalpha;      // d/d opacity
-      const float tot = wave_fold8(g, lane);
-      if (lane < 8) my_acc[j * NM_NG + slot] += tot;
+      // (each Gaussian of a batch is visited once per wave and the table starts from zero: a plain store, no read-modify-write)
+      const float tot = wave_fold8_swap(g, lane);
+      if ((lane & 7) == 0) my_acc[j * NM_NG + slot] = tot;
       if (WITH_OPACITY) {
         const float to = wave_sum_dpp(gop);
-        if (lane == 0) my_acc[j * NM_NG + 8] += to;
+        if (lane == 0) my_acc[j * NM_NG + 8] = to;
       }
     };
     struct Set { float4 a[NM_G], b[NM_G]; float2 c[NM_G]; uint32_t pos[NM_G]; };
