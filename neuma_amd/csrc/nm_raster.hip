@@ -1658,6 +1658,240 @@ __device__ __forceinline__ void bwd_seg(BwdLdsR& L, const RK& k, int nbx, uint32
   render_bwd_range<WITH_OPACITY>(L, k, lo, floor_pos, bit, keys, vals, recs, (float)px, (float)py, P, acc);
 }
 
+// ---------------------------------------------------------------- reverse compositing, two pixels per lane
+// The same walk with 128 threads per tile: lane (x, h) owns the pixels (x, 2h) and (x, 2h + 1) of the tile, a wave a 16 x 8
+// block.  The kernel is instruction-issue bound (§5): with two pixels per lane the per-Gaussian overhead of a wave (record
+// fetch, skip tests, the fold of the eight partial gradients over the lanes) is paid once for 128 pixels instead of twice,
+// and the arithmetic in between runs on float2 operands (v_pk_fma_f32 / v_pk_mul_f32: two results for 6.2 cycles against
+// 5.3 for one).  Per pixel the expressions are those of render_bwd_range, element by element.
+typedef float f2r __attribute__((ext_vector_type(2)));
+struct BwdLdsR2 {
+  uint32_t hit[NM_RB_SCAN];
+  uint32_t id[NM_RB_BATCH];
+  float acc[2][NM_RB_BATCH * NM_NG];
+  int wcnt[2];
+  uint32_t last[2];
+};
+struct PixB2 {
+  f2r T, T_final;
+  uint32_t last[2];
+  f2r dp0, dp1, dp2, ar0, ar1, ar2;
+};
+template <bool WITH_OPACITY>
+__device__ __forceinline__ void render_bwd_range2(BwdLdsR2& L, const RK& k, long long lo, uint32_t floor_pos, uint32_t bit,
+                                                  const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                  const GRec* __restrict__ recs, float fxp, float fy0, PixB2& P,
+                                                  float* __restrict__ acc /* (K, 9) */) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const f2r bg_dot = k.bg[0] * P.dp0 + k.bg[1] * P.dp1 + k.bg[2] * P.dp2;
+  const float kx = 0.5f * k.W / NM_LOG2E, ky = 0.5f * k.H / NM_LOG2E;
+  const f2r fy = {fy0, fy0 + 1.f};
+  float* my_acc = L.acc[wave];
+  const int slot = lane >> 3;           // (wave_fold8_swap: lanes 0, 8, ..., 56 hold values 0..7)
+  for (int i = lane; i < NM_RB_BATCH * NM_NG; i += 64) my_acc[i] = 0.f;
+  uint32_t wave_last = max(P.last[0], P.last[1]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, o, 64));
+  wave_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_last);
+  if (lane == 0) L.last[wave] = wave_last;
+  __syncthreads();
+  const uint32_t tile_last = max(L.last[0], L.last[1]);
+  const long long bottom = lo + (long long)floor_pos;
+  for (long long top = lo + (long long)tile_last; top > bottom; top -= NM_RB_SCAN) {
+    __syncthreads();
+    const long long c = top - 1 - 16 * tid;     // this thread's candidates: c, c-1, ..., c-15 (128 threads x 16 = NM_RB_SCAN)
+    uint32_t m16 = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      if (c - q >= bottom && (vals[c - q] & bit)) m16 |= 1u << q;
+    const int mine = __popc(m16);
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
+    if (lane == 63) L.wcnt[wave] = incl;
+    __syncthreads();
+    const int n0 = L.wcnt[0], nh = n0 + L.wcnt[1];
+    {
+      int hslot = (wave ? n0 : 0) + incl - mine;
+      for (uint32_t mm = m16; mm; mm &= mm - 1u) L.hit[hslot++] = (uint32_t)(c - (__ffs((int)mm) - 1) - lo) + 1u;   // 1-based, descending
+    }
+    for (int h0 = 0; h0 < nh; h0 += NM_RB_BATCH) {
+      __syncthreads();
+      const int nb = min(NM_RB_BATCH, nh - h0);
+      uint32_t offr[NM_RB_BATCH / 64], posr[NM_RB_BATCH / 64];
+#pragma unroll
+      for (int q = 0; q < NM_RB_BATCH / 64; ++q) {
+        const int t = 64 * q + lane;
+        offr[q] = k.K * (uint32_t)sizeof(GRec); posr[q] = 0xFFFFFFFFu;        // padding: the null record, behind everything
+        if (t < nb) {
+          const uint32_t pos = L.hit[h0 + t];
+          const uint32_t id = (uint32_t)keys[lo + pos - 1];
+          offr[q] = id * (uint32_t)sizeof(GRec); posr[q] = pos;
+          if (wave == 0) L.id[t] = id;
+        }
+      }
+      auto one = [&](const float4& g0, const float4& g1, const float2& g2, uint32_t pos, int j) {
+        if (pos > wave_last) return;              // wave-uniform: behind every pixel's last contributor
+        const float dxs = g0.x - fxp;
+        const f2r dx = {dxs, dxs};
+        const f2r dy = g0.y - fy;
+        const f2r e2 = dx * (g0.z * dx + g0.w * dy) + (g1.x * dy) * dy;      // log2 G, element by element as in the forward pass
+        f2r G;
+        G[0] = __builtin_amdgcn_exp2f(e2[0]); G[1] = __builtin_amdgcn_exp2f(e2[1]);
+        f2r alpha = g2.y * G;
+        alpha[0] = fminf(0.99f, alpha[0]); alpha[1] = fminf(0.99f, alpha[1]);
+        const bool act0 = pos <= P.last[0] && !(e2[0] > 0.f) && !(alpha[0] < 1.0f / 255.0f);
+        const bool act1 = pos <= P.last[1] && !(e2[1] > 0.f) && !(alpha[1] < 1.0f / 255.0f);
+        if (__ballot(act0 || act1) == 0ull) return;      // whole wave skips this Gaussian
+        // mask-free recurrence (see render_bwd_range): an inactive pixel takes part with alpha = 0
+        f2r al;
+        al[0] = act0 ? alpha[0] : 0.f; al[1] = act1 ? alpha[1] : 0.f;
+        const f2r oma = 1.f - al;
+        f2r inv1ma;
+        inv1ma[0] = __builtin_amdgcn_rcpf(oma[0]); inv1ma[1] = __builtin_amdgcn_rcpf(oma[1]);
+        P.T = P.T * inv1ma;
+        const f2r dch = al * P.T;
+        const float c0 = g1.z, c1 = g1.w, c2 = g2.x;
+        f2r dL_dalpha = (c0 - P.ar0) * P.dp0 + (c1 - P.ar1) * P.dp1 + (c2 - P.ar2) * P.dp2;
+        P.ar0 = al * c0 + oma * P.ar0;
+        P.ar1 = al * c1 + oma * P.ar1;
+        P.ar2 = al * c2 + oma * P.ar2;
+        const f2r q5 = dch * P.dp0, q6 = dch * P.dp1, q7 = dch * P.dp2;
+        dL_dalpha *= P.T;
+        dL_dalpha += (-P.T_final * inv1ma) * bg_dot;
+        dL_dalpha[0] = act0 ? dL_dalpha[0] : 0.f; dL_dalpha[1] = act1 ? dL_dalpha[1] : 0.f;
+        const f2r dL_dG = g2.y * dL_dalpha;
+        f2r Gm;        // (an inactive pixel's G may be inf - e2 > 0 - and 0 x inf would poison the sums)
+        Gm[0] = act0 ? G[0] : 0.f; Gm[1] = act1 ? G[1] : 0.f;
+        const f2r gdx = Gm * dx, gdy = Gm * dy;
+        const f2r q0 = dL_dG * (2.f * g0.z * gdx + g0.w * gdy) * kx;   // d/d(ndc x)
+        const f2r q1 = dL_dG * (2.f * g1.x * gdy + g0.w * gdx) * ky;
+        const f2r q2 = -0.5f * gdx * dx * dL_dG;       // d/d conic.x
+        const f2r q3 = -gdx * dy * dL_dG;              // d/d conic.y
+        const f2r q4 = -0.5f * gdy * dy * dL_dG;       // d/d conic.z
+        float g[8];
+        g[0] = q0[0] + q0[1]; g[1] = q1[0] + q1[1]; g[2] = q2[0] + q2[1]; g[3] = q3[0] + q3[1];
+        g[4] = q4[0] + q4[1]; g[5] = q5[0] + q5[1]; g[6] = q6[0] + q6[1]; g[7] = q7[0] + q7[1];
+        const float tot = wave_fold8_swap(g, lane);
+        if ((lane & 7) == 0) my_acc[j * NM_NG + slot] = tot;
+        if (WITH_OPACITY) {
+          const f2r gop = Gm * dL_dalpha;      // d/d opacity
+          const float to = wave_sum_dpp(gop[0] + gop[1]);
+          if (lane == 0) my_acc[j * NM_NG + 8] = to;
+        }
+      };
+      struct Set { float4 a[NM_G], b[NM_G]; float2 c[NM_G]; uint32_t pos[NM_G]; };
+      auto fetch = [&](Set& g, uint32_t offs, uint32_t poss, int j0) {
+#pragma unroll
+        for (int u = 0; u < NM_G; ++u) {
+          const char* rp = (const char*)recs + (uint32_t)__builtin_amdgcn_readlane((int)offs, j0 + u);
+          g.a[u] = *(const float4*)rp; g.b[u] = *(const float4*)(rp + 16); g.c[u] = *(const float2*)(rp + 32);
+          g.pos[u] = (uint32_t)__builtin_amdgcn_readlane((int)poss, j0 + u);
+        }
+      };
+#pragma unroll
+      for (int q = 0; q < NM_RB_BATCH / 64; ++q) {
+        const int nq = min(64, nb - 64 * q);          // (wave-uniform)
+        if (nq <= 0) break;
+        Set A, B;
+        fetch(A, offr[q], posr[q], 0);
+        for (int j0 = 0; j0 < nq; j0 += 2 * NM_G) {
+          fetch(B, offr[q], posr[q], j0 + NM_G);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < NM_G; ++u) one(A.a[u], A.b[u], A.c[u], A.pos[u], 64 * q + j0 + u);
+          fetch(A, offr[q], posr[q], (j0 + 2 * NM_G) & 63);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < NM_G; ++u) one(B.a[u], B.b[u], B.c[u], B.pos[u], 64 * q + j0 + NM_G + u);
+        }
+      }
+      __syncthreads();
+      // one global atomic set per (tile, Gaussian): sum the two wave tables
+      if (tid < nb) {
+        uint32_t id = L.id[tid];
+        float* dst = acc + (size_t)id * NM_NG;
+#pragma unroll
+        for (int q = 0; q < (WITH_OPACITY ? NM_NG : 8); ++q) {
+          int o = tid * NM_NG + q;
+          float v = L.acc[0][o] + L.acc[1][o];
+          if (v != 0.f) unsafeAtomicAdd(dst + q, v);
+        }
+      }
+      __syncthreads();
+      for (int i = lane; i < nb * NM_NG; i += 64) my_acc[i] = 0.f;
+    }
+  }
+}
+
+// the state the two pixels of a lane arrive with: whole tile (segment == nullptr) or the segment [floor_pos, ceil_pos) of a
+// split tile, from the forward pass's checkpoints (see bwd_seg)
+template <bool WITH_OPACITY>
+__global__ void __launch_bounds__(128) k_render_bwd2(RK k, int nbx, int ntile, const uint32_t* __restrict__ off,
+                                                     const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                     const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ tile_rec,
+                                                     const uint32_t* __restrict__ tile_ns, const uint2* __restrict__ work,
+                                                     const float4* __restrict__ seg_ct, const uint32_t* __restrict__ seg_pos,
+                                                     const GRec* __restrict__ recs, const float* __restrict__ final_T,
+                                                     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
+                                                     float* __restrict__ acc /* (K, 9) */) {
+  __shared__ BwdLdsR2 L;
+  if (hdr[3]) return;          // (overflowed render: no gradient, see k_render_bwd)
+  const int b = blockIdx.x;
+  int tile;
+  bool seg = false;
+  uint32_t sg = 0, ns = 0, r0 = 0;
+  if (b < ntile) {
+    tile = (b / k.gx + k.ty0) * k.gx + b % k.gx;
+    if (tile_rec[tile] != 0xFFFFFFFFu) return;      // a split tile: its segments do the work
+  } else {
+    const uint32_t w = (uint32_t)(b - ntile);
+    if (w >= hdr[8]) return;
+    const uint2 wk = work[w];
+    tile = (int)wk.x; sg = wk.y; ns = tile_ns[wk.x]; r0 = tile_rec[wk.x];
+    if (sg >= ns) return;            // the tile's extra record
+    seg = true;
+  }
+  const int tile_x = tile % k.gx, tile_y = tile / k.gx;
+  const int tid = threadIdx.x;
+  const int px = tile_x * NM_TILE + (tid & 15), py = tile_y * NM_TILE + 2 * (tid >> 4);
+  const int bin = (tile_y / NM_BT) * nbx + tile_x / NM_BT;
+  const uint32_t bit = 1u << ((tile_y % NM_BT) * NM_BT + tile_x % NM_BT);
+  const long long lo = off[bin * NM_NS];
+  const size_t hw = (size_t)k.H * k.W;
+  uint32_t floor_pos = 0u, ceil_pos = 0xFFFFFFFFu;
+  if (seg) {
+    floor_pos = seg_pos[r0 + sg]; ceil_pos = seg_pos[r0 + sg + 1];      // the segment holds positions floor_pos+1 .. ceil_pos
+    if (ceil_pos <= floor_pos) return;
+  }
+  PixB2 P = {};
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const bool inside = px < k.W && py + e < k.H;
+    uint32_t last = 0u;
+    if (inside) {
+      const size_t pix = (size_t)(py + e) * k.W + px;
+      P.T_final[e] = final_T[pix];
+      last = n_contrib[pix];                       // 1-based position in the bin's list, 0 = none
+      P.dp0[e] = dL_dpix[pix]; P.dp1[e] = dL_dpix[hw + pix]; P.dp2[e] = dL_dpix[2 * hw + pix];
+    }
+    P.T[e] = P.T_final[e];
+    if (!seg) {
+      P.last[e] = last;
+    } else if (last > ceil_pos) {            // the pixel's last contributor lies in a later segment
+      const int pin = (2 * (tid >> 4) + e) * NM_TILE + (tid & 15);      // the pixel's index in its tile (the forward pass's thread)
+      const float4 nx = seg_ct[(size_t)(r0 + sg + 1) * NM_TPB + pin], fin = seg_ct[(size_t)(r0 + ns) * NM_TPB + pin];
+      const float inv = 1.f / nx.w;
+      P.T[e] = nx.w;
+      P.ar0[e] = (fin.x - nx.x) * inv; P.ar1[e] = (fin.y - nx.y) * inv; P.ar2[e] = (fin.z - nx.z) * inv;
+      P.last[e] = ceil_pos;
+    } else {
+      P.last[e] = last > floor_pos ? last : 0u;      // ends in this segment, or in an earlier one (nothing to do here)
+    }
+  }
+  render_bwd_range2<WITH_OPACITY>(L, k, lo, floor_pos, bit, keys, vals, recs, (float)px, (float)py, P, acc);
+}
+
 // one launch, 1-D grid: workgroups [0, ntile) = whole tiles, the others = segments of the candidate tiles, side by side
 template <bool WITH_OPACITY>
 __global__ void __launch_bounds__(NM_TPB) k_render_bwd(RK k, int nbx, int ntile, const uint32_t* __restrict__ off,
@@ -2034,7 +2268,22 @@ extern "C" int nm_raster_backward(const nm_raster_cfg* cfg, int32_t K, int32_t m
   float* acc = (float*)workspace;
   NM_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)K * NM_NG * sizeof(float), s));
   const int ntile = k.gx * (k.ty1 - k.ty0);
-  if (dL_dopacity)
+  // NM_BWD_PX2=1: two pixels per lane (k_render_bwd2).  Measured: 4 % less reverse-compositing time when three
+  // views share the chip, 15 % MORE for a view that has it to itself (half the waves per tile: the long tiles' latency
+  // counts there) - off by default, read per call so that the tests can exercise both.
+  const char* px2_env = getenv("NM_BWD_PX2");
+  const bool px2 = px2_env && atoi(px2_env) != 0;
+  if (px2 && dL_dopacity)
+    NM_LAUNCH(k_render_bwd2<true>, dim3(ntile + t.items), dim3(128), 0, s, k, t.nbx, ntile, (const uint32_t*)t.off,
+              (const unsigned long long*)t.keys, (const uint32_t*)t.vals, (const uint32_t*)t.hdr, (const uint32_t*)t.tile_rec,
+              (const uint32_t*)t.tile_ns, (const uint2*)t.work, (const float4*)t.seg_ct, (const uint32_t*)t.seg_pos, (const GRec*)t.recs,
+              t.final_T, t.n_contrib, dL_dcolor, acc);
+  else if (px2)
+    NM_LAUNCH(k_render_bwd2<false>, dim3(ntile + t.items), dim3(128), 0, s, k, t.nbx, ntile, (const uint32_t*)t.off,
+              (const unsigned long long*)t.keys, (const uint32_t*)t.vals, (const uint32_t*)t.hdr, (const uint32_t*)t.tile_rec,
+              (const uint32_t*)t.tile_ns, (const uint2*)t.work, (const float4*)t.seg_ct, (const uint32_t*)t.seg_pos, (const GRec*)t.recs,
+              t.final_T, t.n_contrib, dL_dcolor, acc);
+  else if (dL_dopacity)
     NM_LAUNCH(k_render_bwd<true>, dim3(ntile + t.items), dim3(NM_TPB), 0, s, k, t.nbx, ntile, (const uint32_t*)t.off,
               (const unsigned long long*)t.keys, (const uint32_t*)t.vals, (const uint32_t*)t.hdr, (const uint32_t*)t.tile_rec,
               (const uint32_t*)t.tile_ns, (const uint2*)t.work, (const float4*)t.seg_ct, (const uint32_t*)t.seg_pos, (const GRec*)t.recs,

@@ -37,8 +37,10 @@ def _gpu_raster(s, tile_rows=None):
     return GaussianRasterizer(gs, tile_rows=tile_rows)
 
 
-@pytest.mark.parametrize("deg", [0, 3])
-def test_raster_forward_backward_vs_oracle(deg):
+@pytest.mark.parametrize("deg,px2", [(0, "0"), (3, "0"), (3, "1")])
+def test_raster_forward_backward_vs_oracle(deg, px2, monkeypatch):
+    # px2: the reverse compositing kernel with two pixels per lane (k_render_bwd2, NM_BWD_PX2=1; opt-in)
+    monkeypatch.setenv("NM_BWD_PX2", px2)
     s, means, cov, op, shs, _, _ = _scene(deg=deg)
     rast = _gpu_raster(s)
     ins = [t.to(dev()).requires_grad_(True) for t in (means, shs, op, cov)]
@@ -259,14 +261,15 @@ def test_raster_heavy_depth_cell_and_capacity_growth():
     assert torch.equal(img4, img.detach())
 
 
-@pytest.mark.parametrize("opaque", [False, True])
-def test_raster_split_compositing_equals_whole_tile_compositing_and_the_oracle(opaque):
+@pytest.mark.parametrize("opaque,px2", [(False, "0"), (True, "0"), (True, "1")])
+def test_raster_split_compositing_equals_whole_tile_compositing_and_the_oracle(opaque, px2, monkeypatch):
     """nm_raster_set_split: the tiles' depth-sorted lists cut into segments on separate workgroups and combined (what a view
     with few busy tiles gets by default) - same image, same last contributors, same gradients as one workgroup per tile, and
     both equal the oracle.  opaque: high opacities, so most pixels stop (T < 1e-4) inside some segment and the combine
     pass has to walk that segment again from the true transmittance."""
     from neuma_amd import _lib
     lib = _lib.lib()
+    monkeypatch.setenv("NM_BWD_PX2", px2)      # (the segments' checkpoints feed both reverse kernels)
     s, means, cov, op, shs, _, _ = _scene(deg=0, K=1500, scale=(0.04, 0.12))
     if opaque:
         op = torch.full_like(op, 0.97)

@@ -10,7 +10,9 @@ from neuma_amd.harness import SceneRuntime
 name = sys.argv[1] if len(sys.argv) > 1 else "metric"
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 dev = torch.device("cuda", 0)
-rt = SceneRuntime(synth.make_scene(name), dev)
+import os
+_S = os.environ.get("EXP_SUBSTEPS")
+rt = SceneRuntime(synth.make_scene(name, override=dict(S=int(_S)) if _S else None), dev)
 rt.make_ground_truth()
 marks = []
 
