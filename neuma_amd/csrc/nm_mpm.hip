@@ -519,10 +519,16 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
         }
       }
     }
-    // the atomics go last: nothing waits for them, they drain while other workgroups compute
+    // the atomics go last: nothing waits for them, they drain while other workgroups compute.  One FLOAT per lane, not one
+    // node: four lanes cover a node's {mv, m}, a wave instruction sixteen consecutive nodes of the tile's z runs - the memory
+    // side adds 64 consecutive floats 4x faster than 64 floats 16 bytes apart (tools/ubench_flush.hip: 314 against 77 G/s),
+    // and this flush is what the scatter kernels' duration hangs on (§5)
+    // (measured on one box, two builds back to back: k_p2g 24.4 -> 21.8 us; the three-channel adjoint scatter k_g2p_bwd leaves a
+    //  quarter of the lanes idle in this mapping and got 1 us slower, so it keeps one node per lane)
+    if (NCH != 4) {
     for (int nidx = tid; nidx < g.vol; nidx += NM_SC_T) {
       const float4 t = L.tile[nidx];
-      if (!NM_DBG_BIT(K, 1) && (t.x != 0.f || t.y != 0.f || t.z != 0.f || t.w != 0.f)) {
+      if (t.x != 0.f || t.y != 0.f || t.z != 0.f || t.w != 0.f) {
         int a_ = nidx / nyz, r = nidx - a_ * nyz;
         int b_ = r / g.n[2], c_ = r - b_ * g.n[2];
         const int x_ = cmp ? (int)L.ainv[0][a_] : g.o[0] + a_, y_ = cmp ? (int)L.ainv[1][b_] : g.o[1] + b_,
@@ -533,6 +539,20 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
         unsafeAtomicAdd(dst + 2, t.z);
         if (NCH == 4) unsafeAtomicAdd(dst + 3, t.w);
       }
+    }
+    } else {
+    const float* tilef = (const float*)L.tile;
+    for (int idx = tid; idx < 4 * g.vol; idx += NM_SC_T) {
+      const int nidx = idx >> 2, comp = idx & 3;
+      const float v = tilef[idx];
+      if (!NM_DBG_BIT(K, 1) && v != 0.f) {
+        int a_ = nidx / nyz, r = nidx - a_ * nyz;
+        int b_ = r / g.n[2], c_ = r - b_ * g.n[2];
+        const int x_ = cmp ? (int)L.ainv[0][a_] : g.o[0] + a_, y_ = cmp ? (int)L.ainv[1][b_] : g.o[1] + b_,
+                  z_ = cmp ? (int)L.ainv[2][c_] : g.o[2] + c_;
+        unsafeAtomicAdd((float*)&grid[node_addr(x_, y_, z_, K.nb)] + comp, v);
+      }
+    }
     }
     SC_PH(6)
   }

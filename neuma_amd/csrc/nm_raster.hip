@@ -1412,6 +1412,10 @@ __device__ __forceinline__ float wave_sum_dpp(float x) {
 #endif
 #define NM_RB_SCAN 2048
 #define NM_NG 9  // per-Gaussian reduced quantities: ndc-mean(2) conic(3) colour(3) | opacity(1)
+#define NM_NGS 16 // row stride of the per-Gaussian accumulator in global memory: a row's eight values in one aligned 32-byte
+                  // piece of one line - the flush adds eight rows x eight consecutive floats per wave instruction, which is
+                  // what the memory side's float atomics are fast at (tools/ubench_flush.hip: 166 G/s; 116 at stride 9; 20 with
+                  // one row per lane and one instruction per column, which is what this kernel used to do)
 // slot order inside an accumulator row: [0..7] = values of wave_fold8 order, [8] = opacity
 //   v[0]=d/dndc.x v[1]=d/dndc.y v[2]=d/dconic.x v[3]=d/dconic.y v[4]=d/dconic.z v[5..7]=d/drgb
 
@@ -1569,16 +1573,16 @@ __device__ __forceinline__ void render_bwd_range(BwdLdsR& L, const RK& k, long l
       }
     }
     __syncthreads();
-    // one global atomic set per (tile, Gaussian): sum the four wave tables
-    if (tid < nb) {
-      uint32_t id = L.id[tid];
-      float* dst = acc + (size_t)id * NM_NG;
-#pragma unroll
-      for (int q = 0; q < (WITH_OPACITY ? NM_NG : 8); ++q) {
-        int o = tid * NM_NG + q;
-        float v = (L.acc[0][o] + L.acc[1][o]) + (L.acc[2][o] + L.acc[3][o]);
-        if (v != 0.f) unsafeAtomicAdd(dst + q, v);
-      }
+    // one global atomic set per (tile, Gaussian): sum the four wave tables; a wave instruction covers eight Gaussians' rows
+    for (int r = tid >> 3; r < nb; r += NM_TPB / 8) {
+      const int o = r * NM_NG + (tid & 7);
+      const float v = (L.acc[0][o] + L.acc[1][o]) + (L.acc[2][o] + L.acc[3][o]);
+      if (v != 0.f) unsafeAtomicAdd(acc + (size_t)L.id[r] * NM_NGS + (tid & 7), v);
+    }
+    if (WITH_OPACITY && tid < nb) {
+      const int o = tid * NM_NG + 8;
+      const float v = (L.acc[0][o] + L.acc[1][o]) + (L.acc[2][o] + L.acc[3][o]);
+      if (v != 0.f) unsafeAtomicAdd(acc + (size_t)L.id[tid] * NM_NGS + 8, v);
     }
     __syncthreads();
     for (int i = lane; i < nb * NM_NG; i += 64) my_acc[i] = 0.f;
@@ -1808,15 +1812,15 @@ __device__ __forceinline__ void render_bwd_range2(BwdLdsR2& L, const RK& k, long
       }
       __syncthreads();
       // one global atomic set per (tile, Gaussian): sum the two wave tables
-      if (tid < nb) {
-        uint32_t id = L.id[tid];
-        float* dst = acc + (size_t)id * NM_NG;
-#pragma unroll
-        for (int q = 0; q < (WITH_OPACITY ? NM_NG : 8); ++q) {
-          int o = tid * NM_NG + q;
-          float v = L.acc[0][o] + L.acc[1][o];
-          if (v != 0.f) unsafeAtomicAdd(dst + q, v);
-        }
+      for (int r = tid >> 3; r < nb; r += 16) {
+        const int o = r * NM_NG + (tid & 7);
+        const float v = L.acc[0][o] + L.acc[1][o];
+        if (v != 0.f) unsafeAtomicAdd(acc + (size_t)L.id[r] * NM_NGS + (tid & 7), v);
+      }
+      if (WITH_OPACITY && tid < nb) {
+        const int o = tid * NM_NG + 8;
+        const float v = L.acc[0][o] + L.acc[1][o];
+        if (v != 0.f) unsafeAtomicAdd(acc + (size_t)L.id[tid] * NM_NGS + 8, v);
       }
       __syncthreads();
       for (int i = lane; i < nb * NM_NG; i += 64) my_acc[i] = 0.f;
@@ -1928,7 +1932,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(RK k, int K, const float
   float gm[3] = {0.f, 0.f, 0.f};
   float gc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const bool vis = tiles_or_radii[i] > 0;
-  const float* a = acc + (size_t)i * NM_NG;
+  const float* a = acc + (size_t)i * NM_NGS;
   if (vis) {
     float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
     // ---- colour -> SH / view direction
@@ -2247,7 +2251,7 @@ extern "C" int nm_debug_raster_tiles(const nm_raster_cfg* cfg, int32_t K, void* 
   return NM_OK;
 }
 
-extern "C" size_t nm_raster_bwd_workspace(int32_t K) { return al256((size_t)(K > 0 ? K : 1) * NM_NG * sizeof(float)); }
+extern "C" size_t nm_raster_bwd_workspace(int32_t K) { return al256((size_t)(K > 0 ? K : 1) * NM_NGS * sizeof(float)); }
 
 extern "C" int nm_raster_backward(const nm_raster_cfg* cfg, int32_t K, int32_t m, const float* means3D, const float* shs,
                                   const float* colors_precomp, const float* opacities, const float* cov3D, const void* state,
@@ -2266,7 +2270,7 @@ extern "C" int nm_raster_backward(const nm_raster_cfg* cfg, int32_t K, int32_t m
   hipStream_t s = (hipStream_t)stream;
   State t = carve_state((void*)state, nullptr, k.W, k.H, K, cap_pairs, k.items);
   float* acc = (float*)workspace;
-  NM_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)K * NM_NG * sizeof(float), s));
+  NM_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)K * NM_NGS * sizeof(float), s));
   const int ntile = k.gx * (k.ty1 - k.ty0);
   // NM_BWD_PX2=1: two pixels per lane (k_render_bwd2).  Measured: 4 % less reverse-compositing time when three
   // views share the chip, 15 % MORE for a view that has it to itself (half the waves per tile: the long tiles' latency
