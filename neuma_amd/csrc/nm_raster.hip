@@ -285,7 +285,8 @@ __global__ void __launch_bounds__(256) k_preprocess(RK k, int K, const float* __
                                                     const float* __restrict__ cov3D, int* __restrict__ radii, float2* __restrict__ xy,
                                                     float* __restrict__ depth, float4* __restrict__ conop, float* __restrict__ rgb,
                                                     uint32_t* __restrict__ clamped, int* __restrict__ grad_, uint2* __restrict__ zrange,
-                                                    GRec* __restrict__ recs) {
+                                                    GRec* __restrict__ recs, uint32_t* __restrict__ hdr) {
+  if (blockIdx.x == 0 && threadIdx.x < 64) hdr[threadIdx.x] = 0u;      // the view's header words (counters, flags): no memset launch for them
   __shared__ uint32_t s_lo[4], s_hi[4];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   // depth range of the visible Gaussians (positive floats order like their bit patterns), reduced per workgroup; the
@@ -913,6 +914,12 @@ __device__ __forceinline__ void render_whole(CompLds& L, const RK& k, int nbx, i
 //                     reference's termination rule (stop when T would fall below 1e-4, forward.cu) is kept exactly;
 //                     the tile's last workgroup to finish sums the records.
 // The reverse sweep walks the segments of a split tile in parallel too (k_render_bwd_seg).
+// The render's status words for the host, as three 64-bit values behind one another (one 24-byte copy instead of three
+// 4-byte ones - each was a blit kernel of its own): pairs binned | overflow flag (high half: the largest cell, debugging) |
+// work items the plan asked for.  Written by the last thread that knows them all.
+__device__ __forceinline__ void plan_status(uint32_t* __restrict__ hdr) {
+  hdr[16] = hdr[2]; hdr[17] = 0u; hdr[18] = hdr[3]; hdr[19] = hdr[6]; hdr[20] = hdr[12]; hdr[21] = 0u;
+}
 __global__ void __launch_bounds__(1024) k_split_plan(RK k, int nbx, uint32_t busy_limit, uint32_t min_seg, unsigned long long fwd_max,
                                                      const uint32_t* __restrict__ off, long long cap,
                                                      uint32_t* __restrict__ hdr, uint32_t* __restrict__ tile_rec,
@@ -1011,12 +1018,23 @@ __global__ void __launch_bounds__(1024) k_split_plan(RK k, int nbx, uint32_t bus
       }
       __syncthreads();
       if (tid == 0) { hdr[8] = s_used; hdr[9] = seg; hdr[10] = 1u; hdr[11] = 1u; hdr[12] = s_base; }
-      if (tid == 0) { const unsigned long long lt = s_lists; hdr[14] = (uint32_t)lt; hdr[15] = (uint32_t)(lt >> 32); }
+      if (tid == 0) { const unsigned long long lt = s_lists; hdr[14] = (uint32_t)lt; hdr[15] = (uint32_t)(lt >> 32); plan_status(hdr); }
       return;
     }
-    __syncthreads();
-    if (tid == 0) { s_total = 0ull; s_lists = 0ull; s_busy = 0u; }
-    __syncthreads();
+    // nothing known yet (the first render with this camera, or nothing in view): every tile is walked whole and leaves its
+    // record - the next render is planned.  (A hinted call therefore never needs the second compositing stage: the host
+    // does not launch it.)
+#pragma unroll
+    for (int u = 0; u < NM_PLAN_PER; ++u) {
+      if (tt[u] < 0) continue;
+      tile_rec[tt[u]] = 0xFFFFFFFFu; tile_ns[tt[u]] = 0u; tile_cnt[tt[u]] = 0u; tile_mode[tt[u]] = 0u;
+    }
+    if (tid == 0) {
+      const unsigned long long lt = s_lists;
+      hdr[8] = 0u; hdr[9] = (hint_seg + 15u) & ~15u; hdr[10] = 1u; hdr[11] = 1u; hdr[12] = 0u; hdr[14] = (uint32_t)lt; hdr[15] = (uint32_t)(lt >> 32);
+      plan_status(hdr);
+    }
+    return;
   }
   unsigned long long tot = 0ull; uint32_t busy = 0u;
   if (!hdr[3]) {         // all tiles of a bin share its list: one thread per bin
@@ -1041,7 +1059,7 @@ __global__ void __launch_bounds__(1024) k_split_plan(RK k, int nbx, uint32_t bus
       const int t = (i / k.gx + k.ty0) * k.gx + i % k.gx;
       tile_rec[t] = 0xFFFFFFFFu; tile_ns[t] = 0u; tile_cnt[t] = 0u; tile_mode[t] = 0u;
     }
-    if (tid == 0) { hdr[8] = 0u; hdr[9] = seg; hdr[10] = 0u; hdr[14] = (uint32_t)s_total; hdr[15] = (uint32_t)(s_total >> 32); }
+    if (tid == 0) { hdr[8] = 0u; hdr[9] = seg; hdr[10] = 0u; hdr[14] = (uint32_t)s_total; hdr[15] = (uint32_t)(s_total >> 32); plan_status(hdr); }
     return;
   }
   for (int i0 = 0; i0 < ntile; i0 += 1024) {     // segments per tile, exclusive prefix in tile order
@@ -1075,7 +1093,10 @@ __global__ void __launch_bounds__(1024) k_split_plan(RK k, int nbx, uint32_t bus
     if (tid == 1023) s_base += s_scan[1023];
     __syncthreads();
   }
-  if (tid == 0) { hdr[8] = s_used; hdr[9] = seg; hdr[10] = s_total <= fwd_max ? 1u : 0u; hdr[12] = s_base; hdr[14] = (uint32_t)s_total; hdr[15] = (uint32_t)(s_total >> 32); }
+  if (tid == 0) {
+    hdr[8] = s_used; hdr[9] = seg; hdr[10] = s_total <= fwd_max ? 1u : 0u; hdr[12] = s_base; hdr[14] = (uint32_t)s_total; hdr[15] = (uint32_t)(s_total >> 32);
+    plan_status(hdr);
+  }
 }
 
 // work items of a hinted plan: one wave per tile writes its (tile, segment) pairs and segment boundaries
@@ -2130,11 +2151,11 @@ static int raster_forward_impl(const nm_raster_cfg* cfg, int32_t K, int32_t m, c
   }
   hipStream_t s = (hipStream_t)stream;
   const int nrange = nm_div_up(K, 256);
-  NM_HIP_CHECK(hipMemsetAsync(t.hdr, 0, 256, s));
+  if (K == 0) NM_HIP_CHECK(hipMemsetAsync(t.hdr, 0, 256, s));      // (otherwise k_preprocess zeroes the header)
   NM_HIP_CHECK(hipMemsetAsync(t.pad, 0, (size_t)t.ncell * NM_PAD * sizeof(uint32_t), s));
   if (K > 0) {
     NM_LAUNCH(k_preprocess, dim3(nrange), dim3(256), 0, s, k, K, means3D, shs, colors_precomp, opacities, cov3D, radii,
-              t.xy, t.depth, t.conop, t.rgb, t.clamped, t.rad, t.zrange, t.recs);
+              t.xy, t.depth, t.conop, t.rgb, t.clamped, t.rad, t.zrange, t.recs, t.hdr);
     NM_LAUNCH_CHECK();
     NM_LAUNCH(k_bin_count, dim3(nrange), dim3(256), 0, s, k, K, t.nbx, (const int*)t.rad, t.xy, t.depth, t.conop, t.zrange, nrange,
               t.pad, t.log, t.hdr, (long long)cap_pairs);
@@ -2170,7 +2191,8 @@ static int raster_forward_impl(const nm_raster_cfg* cfg, int32_t K, int32_t m, c
   const int ntile = k.gx * (k.ty1 - k.ty0);
   // stage 0: whole tiles + first segments of the candidates (which decide how their tile goes on); stage 1: other segments
   // of the tiles that are split.  A view without candidates has no work items and those workgroups leave at once.
-  for (int stage = 0; stage < 2; ++stage) {
+  const int stages = (tile_walk && ntile <= 1024 * NM_PLAN_PER) ? 1 : 2;      // (a hinted plan does everything in the first launch)
+  for (int stage = 0; stage < stages; ++stage) {
     NM_LAUNCH(k_render, dim3((stage == 0 ? ntile : 0) + t.items), dim3(NM_TPB), 0, s, k, t.nbx, stage, stage == 0 ? ntile : 0,
               t.tile_mode, (const uint32_t*)t.tile_rec, (const uint32_t*)t.tile_ns, (const uint32_t*)t.off,
               (const unsigned long long*)t.keys, (const uint32_t*)t.vals, (long long)cap_pairs, (const uint32_t*)t.hdr,
@@ -2189,13 +2211,8 @@ static int raster_forward_impl(const nm_raster_cfg* cfg, int32_t K, int32_t m, c
             (const uint32_t*)t.tile_ns, (const uint32_t*)t.tile_mode, (const float4*)t.seg_fix, t.seg_ct,
             (const uint32_t*)t.seg_last, t.seg_pos, (const GRec*)t.recs, t.final_T, t.n_contrib, out_color, tile_walk);
   NM_LAUNCH_CHECK();
-  if (status_host) {
-    // hdr[2], hdr[3] are 32-bit: widen on the host side of the copy (4-byte copies into the low halves; the caller zeroes the buffer)
-    NM_HIP_CHECK(hipMemcpyAsync(status_host, t.hdr + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    NM_HIP_CHECK(hipMemcpyAsync(status_host + 1, t.hdr + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    if (getenv("NM_RASTER_DEBUG")) NM_HIP_CHECK(hipMemcpyAsync((char*)(status_host + 1) + 4, t.hdr + 6, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    if (status_words >= 3) NM_HIP_CHECK(hipMemcpyAsync(status_host + 2, t.hdr + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-  }
+  if (status_host)      // pairs | overflow | items wanted (plan_status), one copy
+    NM_HIP_CHECK(hipMemcpyAsync(status_host, t.hdr + 16, sizeof(int64_t) * (size_t)(status_words < 3 ? status_words : 3), hipMemcpyDeviceToHost, s));
   return NM_OK;
 }
 
