@@ -256,6 +256,9 @@ typedef struct nm_rollout_cfg {
                               * and the output of both nets, 1.2 KB/particle/substep - and the reverse sweep loads it, recomputing
                               * only the first layer (16 of the forward pass's 96 matrix instructions per tile); NULL = recompute
                               * everything.  Same arithmetic, same results. */
+  int32_t weights_prepared;  /* nm_rollout_backward only: the workspace is the one the forward call of this node used and
+                              * nothing has touched it since, so both nets' weights still sit there in operand order and the
+                              * reverse sweep skips that launch.  0 (and every caller that does not know) = prepare them. */
 } nm_rollout_cfg;
 #define NM_SVD_ADJOINT_REFERENCE 0
 #define NM_SVD_ADJOINT_POLAR 1

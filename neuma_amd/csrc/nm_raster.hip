@@ -507,52 +507,36 @@ __global__ void __launch_bounds__(NM_NS) k_bin_compact(int nbin, const uint32_t*
   }
 }
 
-// exclusive scan of the bin totals by one workgroup (510 bins at 1080p)
-__global__ void __launch_bounds__(1024) k_bin_scan(int nbin, const uint32_t* __restrict__ bin_total, uint32_t* __restrict__ bin_off,
-                                                   uint32_t* __restrict__ hdr, long long cap) {
-  __shared__ uint32_t s_w[16];
-  __shared__ uint32_t s_run;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) s_run = 0u;
-  __syncthreads();
-  for (int base = 0; base < nbin; base += 1024) {
-    const int c = base + tid;
-    const uint32_t n = c < nbin ? bin_total[c] : 0u;
-    uint32_t x = n;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, o, 64); if (lane >= o) x += y; }
-    if (lane == 63) s_w[wave] = x;
-    __syncthreads();
-    uint32_t before = s_run;
-    for (int w = 0; w < wave; ++w) before += s_w[w];
-    if (c < nbin) bin_off[c] = before + x - n;
-    __syncthreads();
-    if (tid == 1023) s_run = before + x;
-    __syncthreads();
-  }
-  if (tid == 0) {
-    bin_off[nbin] = s_run;
-    // hdr[2] = pairs logged by the count pass (may exceed the capacity: the log and the lists then miss pairs)
-    hdr[3] = ((long long)hdr[2] > cap) ? 1u : 0u;
-  }
-}
-
-// cell offsets: bin offset + exclusive scan over the bin's depth slabs (one workgroup per bin)
-__global__ void __launch_bounds__(NM_NS) k_cell_offsets(int nbin, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ bin_off,
-                                                        uint32_t* __restrict__ off) {
-  __shared__ uint32_t s_w[NM_NS / 64];
+// cell offsets: bin offset + exclusive scan over the bin's depth slabs (one workgroup per bin).  The bin's own offset is the
+// sum of the totals of the bins in front of it, which every workgroup adds up for itself (<= a few hundred words out of
+// L2): cheaper than a scan kernel of its own between two 5-us launches.  The last bin's workgroup knows the grand total:
+// it closes the offset array and sets the overflow flag (hdr[2] = pairs logged by the count pass, may exceed the capacity:
+// the log and the lists then miss pairs).
+__global__ void __launch_bounds__(NM_NS) k_cell_offsets(int nbin, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ bin_total,
+                                                        uint32_t* __restrict__ off, uint32_t* __restrict__ hdr, long long cap) {
+  __shared__ uint32_t s_w[NM_NS / 64], s_p[NM_NS / 64];
   const int bin = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t pre = 0u;
+  for (int b = threadIdx.x; b < bin; b += NM_NS) pre += bin_total[b];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) pre += (uint32_t)__shfl_xor((int)pre, o, 64);
   const int c = bin * NM_NS + threadIdx.x;
   const uint32_t n = cnt[c];
   uint32_t x = n;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, o, 64); if (lane >= o) x += y; }
   if (lane == 63) s_w[wave] = x;
+  if (lane == 0) s_p[wave] = pre;
   __syncthreads();
-  uint32_t before = bin_off[bin];
+  uint32_t before = 0u;
+#pragma unroll
+  for (int w = 0; w < NM_NS / 64; ++w) before += s_p[w];
   for (int w = 0; w < wave; ++w) before += s_w[w];
   off[c] = before + x - n;
-  if (bin == nbin - 1 && threadIdx.x == NM_NS - 1) off[c + 1] = bin_off[nbin];
+  if (bin == nbin - 1 && threadIdx.x == NM_NS - 1) {
+    off[c + 1] = before + x;
+    hdr[3] = ((long long)hdr[2] > cap) ? 1u : 0u;
+  }
 }
 
 // Fill pass: replay of the pair log - no atomics, no geometry: slot = cell offset + rank
@@ -2164,9 +2148,8 @@ static int raster_forward_impl(const nm_raster_cfg* cfg, int32_t K, int32_t m, c
   const int nbin = t.nbx * t.nby;
   NM_LAUNCH(k_bin_compact, dim3(nbin), dim3(NM_NS), 0, s, nbin, (const uint32_t*)t.pad, t.cnt, t.bin_total, t.hdr);
   NM_LAUNCH_CHECK();
-  NM_LAUNCH(k_bin_scan, dim3(1), dim3(1024), 0, s, nbin, (const uint32_t*)t.bin_total, t.bin_off, t.hdr, (long long)cap_pairs);
-  NM_LAUNCH_CHECK();
-  NM_LAUNCH(k_cell_offsets, dim3(nbin), dim3(NM_NS), 0, s, nbin, (const uint32_t*)t.cnt, (const uint32_t*)t.bin_off, t.off);
+  NM_LAUNCH(k_cell_offsets, dim3(nbin), dim3(NM_NS), 0, s, nbin, (const uint32_t*)t.cnt, (const uint32_t*)t.bin_total, t.off, t.hdr,
+            (long long)cap_pairs);
   NM_LAUNCH_CHECK();
   if (K > 0) {
     NM_LAUNCH(k_bin_fill, dim3(min(2048, nm_div_up((int)min((int64_t)cap_pairs, (int64_t)K * 64), 256) + 1)), dim3(256), 0, s,

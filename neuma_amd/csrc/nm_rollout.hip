@@ -175,7 +175,8 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
   const size_t N = (size_t)n;
   float* states_m = const_cast<float*>(states);
   const float* gin = gstate_last;
-  int rc = nm_material_prepare2(we, w.perm_e, wp, w.perm_p, stream);
+  int rc = NM_OK;
+  if (!cfg->weights_prepared) rc = nm_material_prepare2(we, w.perm_e, wp, w.perm_p, stream);
   if (rc) return rc;
   const bool verified = cfg->cache_verified != 0 && gridcache != nullptr && cfg->grid_cache_blocks > 0;
   const int polar = cfg->svd_adjoint == NM_SVD_ADJOINT_POLAR ? 1 : 0;

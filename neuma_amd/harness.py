@@ -202,7 +202,7 @@ def _tail_backward(rt, recs, grads, streams, dx_out):
 class _FrameState(object):
     """What the forward half of a one-node frame keeps for its reverse sweep."""
     __slots__ = ("recs", "grads", "streams", "keep", "states", "eff", "gcache", "svdc", "actc", "status", "ev", "cache_blocks",
-                 "adj", "weight")
+                 "adj", "weight", "ws_token", "ws_ptr")
 
 
 def _frame_static(rt):
@@ -278,6 +278,8 @@ def _frame_forward(rt, weight, jobs, streams):
     L.check(lib.nm_rollout_forward(rt.model.handle(), n, C.byref(cfg), C.byref(st), C.byref(mle), C.byref(mlp), states.data_ptr(),
                                    gptr, ws.data_ptr(), ws_bytes, stream), "nm_rollout_forward")
     fs = _FrameState()
+    fs.ws_token = rt._ws_token = rt.__dict__.get("_ws_token", 0) + 1      # (whose operand-order weights the workspace holds)
+    fs.ws_ptr = ws.data_ptr()
     fs.status = fs.ev = None
     if gcache is not None and R._CACHE_STATUS:
         pool = rt.__dict__.setdefault("_status_pool", [])      # (pinned words + event: handed back by the backward pass)
@@ -334,7 +336,8 @@ def _frame_backward(rt, fs, g=None):
     ws = rt._scratch("ws", ws_bytes)
     svdc, actc = fs.svdc, fs.actc
     cfg = L.nm_rollout_cfg(S, float(sim.plasticity.alpha), fs.cache_blocks, verified, fs.adj,
-                           svdc.t.data_ptr() if svdc is not None else None, actc.t.data_ptr() if actc is not None else None)
+                           svdc.t.data_ptr() if svdc is not None else None, actc.t.data_ptr() if actc is not None else None,
+                           1 if rt.__dict__.get("_ws_token") == fs.ws_token and ws.data_ptr() == fs.ws_ptr else 0)
     base = fs.eff.data_ptr()
     w0, w1 = R._WSZ[0], R._WSZ[0] + R._WSZ[1]
     mle = L.nm_mlp(base, base + 4 * w0, base + 4 * w1)
