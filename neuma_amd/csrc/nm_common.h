@@ -69,6 +69,7 @@ int nm_material_prepare(const nm_mlp* w, float* wperm, void* stream);   // weigh
 int nm_material_prepare2(const nm_mlp* wa, float* wperm_a, const nm_mlp* wb, float* wperm_b, void* stream);   // two nets, one launch
 size_t nm_material_prepared_floats();
 int nm_material_wgrad_reduce(const float* wpart, int32_t n, float* gw0, float* gw1, float* gw2, int accumulate, void* stream);
+int nm_material_wgrad_reduce2(const float* wpart_a, const float* wpart_b, int32_t n, float* gw_a, float* gw_b, void* stream);
 
 static inline int nm_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

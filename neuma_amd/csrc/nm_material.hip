@@ -1179,8 +1179,12 @@ __global__ void __launch_bounds__(256, 1) k_material_bwd_pair(BwdArgs e, BwdArgs
 // sum the per-workgroup partials: a workgroup owns 64 consecutive weights, its four waves each sum a quarter of the
 // partials (coalesced 256 B rows) and combine through LDS — deterministic, ~86 workgroups instead of 22 serial ones
 __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ wpart, int nparts, float* __restrict__ g0,
-                                                      float* __restrict__ g1, float* __restrict__ g2, int accumulate) {
+                                                      float* __restrict__ g1, float* __restrict__ g2, int accumulate,
+                                                      const float* __restrict__ wpart_b, float* __restrict__ gb) {
   __shared__ float part[4][64];
+  if (blockIdx.y == 1) {      // the second net of a roll-out in the same launch: its gradients are w0 | w1 | w2 back to back
+    wpart = wpart_b; g0 = gb; g1 = gb + NM_W0; g2 = gb + NM_W0 + NM_W1;
+  }
   const int li = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + li;
   float acc = 0.f;
@@ -1294,7 +1298,16 @@ int nm_material_wgrad_reduce(const float* wpart, int32_t n, float* gw0, float* g
   int grid, q;
   nm_wave_quota(n, grid, q);
   NM_LAUNCH(k_wgrad_reduce, dim3(nm_div_up(NM_WTOT, 64)), dim3(256), 0, (hipStream_t)stream, wpart, grid, gw0, gw1, gw2,
-                     accumulate);
+                     accumulate, (const float*)nullptr, (float*)nullptr);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}
+// both nets of a roll-out (gw_a, gw_b: w0 | w1 | w2 back to back, overwritten) in one launch
+int nm_material_wgrad_reduce2(const float* wpart_a, const float* wpart_b, int32_t n, float* gw_a, float* gw_b, void* stream) {
+  int grid, q;
+  nm_wave_quota(n, grid, q);
+  NM_LAUNCH(k_wgrad_reduce, dim3(nm_div_up(NM_WTOT, 64), 2), dim3(256), 0, (hipStream_t)stream, wpart_a, grid, gw_a, gw_a + NM_W0,
+            gw_a + NM_W0 + NM_W1, 0, wpart_b, gw_b);
   NM_LAUNCH_CHECK();
   return NM_OK;
 }

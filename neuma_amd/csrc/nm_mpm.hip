@@ -45,6 +45,8 @@ struct nm_mpm {
   int* sh_slot;   // per block: slot of the block in the frame's exchange buffer, -1 = none (nm_mpm_xchg_arrays)
   int* sh_dil;    // per block: tag of the last frame whose negotiated neighbourhood holds the block
   int dil_tag;
+  const void* resident_rec;   // the grid cache record whose substep the grid holds right now (forward pass just built it) ...
+  int resident_epoch;         // ... as long as the epoch has not moved: the reverse sweep's first substep then restores nothing
   int gv_stale;   // the last clear left the velocity array alone (GridPrologue keep_gv): the next grid update zeroes what dropped out
   int fresh_rows; // g2p writes a fresh state's values into the rows of disabled particles (roll-out checkpoints, nm_grid.h)
 };
@@ -996,6 +998,7 @@ extern "C" int nm_mpm_create(const nm_mpm_cfg* cfg, nm_mpm** out) {
   h->cur = 0;
   h->epoch = 0;
   h->gv_stale = 0;
+  h->resident_rec = nullptr; h->resident_epoch = -1;
   h->sh_cnt = h->sh_pos = nullptr;
   *out = h;
   return NM_OK;
@@ -1122,6 +1125,7 @@ static int mpm_forward_impl(nm_mpm* h, int32_t n, const nm_statics* st, const nm
   hipStream_t s = (hipStream_t)stream;
   rc = mpm_build_grid(h, n, st, cur, s, gridrec, nullptr, cap_blocks, false, precleared);
   if (rc) return rc;
+  h->resident_rec = gridrec; h->resident_epoch = h->epoch;
   if (!next) return NM_OK;   // g2p is performed by the caller's next kernel (nm_mpm_g2p_fuse)
   NM_LAUNCH(k_g2p, dim3(nm_div_up(n, 256)), dim3(256), 0, s, h->k, n, st->clip_bound, st->enabled, cur->x,
                      cur->v, cur->C, cur->F, h->gv, next->x, next->v, next->C, next->F, h->fresh_rows);
@@ -1205,10 +1209,16 @@ int nm_mpm_backward_cached_begin(nm_mpm* h, int32_t n, const nm_statics* st, con
   NM_REQUIRE(next && next->v && next->C, "next state (v, C) required");
   NM_REQUIRE(gnext && gnext->x && gnext->v && gnext->C && gnext->F, "null incoming gradients");
   NM_REQUIRE(gcur && gcur->x && gcur->v && gcur->C && gcur->F && gcur->stress, "null outgoing gradients");
-  if (!prepared) {
+  // The reverse sweep usually starts right behind the forward one: the grid still holds the last substep - {mv, m}, velocities,
+  // active list, a clean adjoint array (nothing but a reverse substep writes it, and each one cleans up behind the previous) -
+  // exactly what clear + restore would rebuild from the (valid) record.  Two launches less per roll-out; for the one-substep
+  // configurations that is all of them.
+  const bool resident = !prepared && verified && gridrec != nullptr && gridrec == h->resident_rec && h->epoch == h->resident_epoch;
+  if (!prepared && !resident) {
     rc = mpm_build_grid(h, n, st, cur, s, nullptr, gridrec, cap_blocks, verified && gridrec != nullptr);  // recompute (mpm.py:312-315) or restore
     if (rc) return rc;
   }
+  h->resident_rec = nullptr;      // (the adjoint scatter below dirties the grid's adjoint array: resident no more)
   NM_LAUNCH(k_g2p_bwd, dim3(nm_div_up(n, NM_SC_T)), dim3(NM_SC_T), 0, s, h->k, n, st->clip_bound, st->enabled, cur->x, cur->F, next->v,
                      next->C, gnext->x, gnext->v, gnext->C, gnext->F, h->gv, h->gg, gcur->x, gcur->F);
   NM_LAUNCH_CHECK();

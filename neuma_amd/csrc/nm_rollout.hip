@@ -228,9 +228,7 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
     gin = gout;
   }
   // one deterministic reduction per net for the whole roll-out
-  rc = nm_material_wgrad_reduce(w.part_e, n, gw_e, gw_e + 64 * 13, gw_e + 64 * 13 + 64 * 64, 0, stream);
-  if (rc) return rc;
-  return nm_material_wgrad_reduce(w.part_p, n, gw_p, gw_p + 64 * 13, gw_p + 64 * 13 + 64 * 64, 0, stream);
+  return nm_material_wgrad_reduce2(w.part_e, w.part_p, n, gw_e, gw_p, stream);
 }
 
 // ---------------------------------------------------------------- particle-sharded roll-out
@@ -455,9 +453,7 @@ extern "C" int nm_rollout_backward_sharded(nm_mpm* h, int32_t n, const nm_rollou
     NM_HIP_CHECK(hipMemsetAsync(gw_p, 0, NM_WTOT_ * sizeof(float), s));
     return NM_OK;
   }
-  rc = nm_material_wgrad_reduce(w.part_e, n, gw_e, gw_e + 64 * 13, gw_e + 64 * 13 + 64 * 64, 0, stream);
-  if (rc) return rc;
-  return nm_material_wgrad_reduce(w.part_p, n, gw_p, gw_p + 64 * 13, gw_p + 64 * 13 + 64 * 64, 0, stream);
+  return nm_material_wgrad_reduce2(w.part_e, w.part_p, n, gw_e, gw_p, stream);
 }
 
 // status bits of the roll-out's exchanges (1: a rank's neighbourhood list exceeded cap, 2: more exchange blocks than cap_shared,
