@@ -62,7 +62,7 @@ def dilate_blocks_host(ids, nb: int):
 # Measured on 1x MI355X, fused roll-out, forward + backward, microseconds per substep at N particles (tools/exp_shard_overhead.py
 # <workload> <N>; profiles/r03_shard_overhead.txt).  Between the points: linear in N.  The small sizes are latency floors - a
 # substep is ~12 dependent launches - which is why dividing 100k particles by 8 buys 2.1x, not 8x.
-SUBSTEP_US = ((12_500, 106.0), (25_000, 168.0), (50_000, 159.0), (100_000, 236.0), (1_000_000, 2400.0))
+SUBSTEP_US = ((12_500, 108.0), (25_000, 167.0), (50_000, 159.0), (100_000, 232.0), (1_000_000, 2400.0))
 MACHINERY_US = 23.0      # measured with a one-rank RCCL group: 2 pack launches + 2 all-reduce calls per substep, fwd + bwd
 #                          (profiles/r03c_shard_overhead.txt; the 12.5 us of the mid-round table compared against an unsharded
 #                          reverse sweep that ran unverified)
