@@ -63,6 +63,7 @@ def dilate_blocks_host(ids, nb: int):
 # <workload> <N>; profiles/r03_shard_overhead.txt).  Between the points: linear in N.  The small sizes are latency floors - a
 # substep is ~12 dependent launches - which is why dividing 100k particles by 8 buys 2.1x, not 8x.
 SUBSTEP_US = ((12_500, 108.0), (25_000, 167.0), (50_000, 159.0), (100_000, 232.0), (1_000_000, 2400.0))
+SHARD_MARGIN = 0.10
 MACHINERY_US = 23.0      # measured with a one-rank RCCL group: 2 pack launches + 2 all-reduce calls per substep, fwd + bwd
 #                          (profiles/r03c_shard_overhead.txt; the 12.5 us of the mid-round table compared against an unsharded
 #                          reverse sweep that ran unverified)
@@ -91,12 +92,14 @@ def shard_cost_model(num_particles: int, world: int, substeps: int) -> dict:
     """Estimated simulation time of one frame (S substeps, forward + backward) on `world` GPUs with the simulation replicated
     (every rank steps all particles) and particle-sharded (every rank steps N / world of them and pays, per substep and
     direction, one all-reduce of the exchange blocks, plus per frame the all-gather of x and F, the all-gather of the block
-    neighbourhoods and the reduction of the LoRA gradients).  `shard` = the sharded estimate is the smaller one."""
+    neighbourhoods and the reduction of the LoRA gradients).  `shard` = the sharded estimate is smaller by at least
+    SHARD_MARGIN (10 %): the all-reduce latency in it is an assumption until a multi-GPU box has been measured, and a
+    predicted gain inside that uncertainty is not worth the extra collectives on the critical path."""
     rep = substeps * substep_us(num_particles)
     ar = allreduce_us(world)
     per_frame = 4.0 * ar if world > 1 else 0.0                     # x, F, neighbourhoods, parameter gradients
     sh = substeps * (substep_us(-(-num_particles // world)) + MACHINERY_US + 2.0 * ar) + per_frame
-    return {"replicated_us": rep, "sharded_us": sh, "allreduce_us_assumed": ar, "shard": world > 1 and sh < rep}
+    return {"replicated_us": rep, "sharded_us": sh, "allreduce_us_assumed": ar, "shard": world > 1 and sh < (1.0 - SHARD_MARGIN) * rep}
 
 
 def explain_status(bits: int) -> str:
