@@ -627,7 +627,7 @@ __device__ __forceinline__ void rank_sort_dispatch(const unsigned long long* s_k
   }
 }
 
-// A workgroup takes four consecutive cells.  All four small: each wave sorts its own in a private LDS slice.  Otherwise the
+// A workgroup takes four cells.  All four small: each wave sorts its own in a private LDS slice.  Otherwise the
 // four are sorted one after the other by the whole workgroup (rank sort in LDS up to NM_CELL_LDS pairs; beyond that a bitonic
 // network directly on global memory).
 __global__ void __launch_bounds__(256) k_cell_sort(int ncell, const uint32_t* __restrict__ off, unsigned long long* __restrict__ keys,
@@ -636,14 +636,21 @@ __global__ void __launch_bounds__(256) k_cell_sort(int ncell, const uint32_t* __
   __shared__ unsigned long long s_key[NM_CELL_LDS];
   __shared__ uint32_t s_val[NM_CELL_LDS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int c0 = blockIdx.x * 4; c0 < ncell; c0 += gridDim.x * 4) {
+  // A group = four consecutive cells (neighbouring depth slabs of a bin are about equally big: the four waves finish together),
+  // unless the view has cells the workgroup must sort as a whole (hdr[6] = the largest cell): four of those in one
+  // workgroup are sorted one after the other (jd: four 536-pair neighbours were the kernel's critical path, 51 us), so the
+  // group then takes its cells a quarter of the cell array apart
+  const int ngroup = (ncell + 3) / 4;
+  const bool spread = hdr[6] > NM_CELL_WAVE;
+  for (int g0 = blockIdx.x; g0 < ngroup; g0 += gridDim.x) {
     long long lo[4];
     int n[4], biggest = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int c = min(c0 + q, ncell - 1);
+      const int cq = spread ? g0 + q * ngroup : 4 * g0 + q;
+      const int c = min(cq, ncell - 1);
       lo[q] = off[c];
-      n[q] = (c0 + q < ncell) ? (int)max(0ll, min((long long)off[c + 1], cap) - lo[q]) : 0;
+      n[q] = (cq < ncell) ? (int)max(0ll, min((long long)off[c + 1], cap) - lo[q]) : 0;
       biggest = max(biggest, n[q]);
     }
     if (biggest < 2) continue;
