@@ -447,9 +447,18 @@ __global__ void __launch_bounds__(256) k_bin_count(RK k, int K, int nbx, const i
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
   const int wave_total = __shfl(incl, 63, 64);
-  uint32_t base = 0;
-  if (lane == 0 && wave_total) base = atomicAdd(&hdr[2], (uint32_t)wave_total);
-  base = (uint32_t)__shfl((int)base, 0, 64);
+  // ONE reservation per workgroup: every returning atomic on this one word queues behind all the others (~12 ns each;
+  // one per wave was 3 k of them per view)
+  __shared__ uint32_t s_wtot[4], s_wgbase;
+  if (lane == 0) s_wtot[threadIdx.x >> 6] = (uint32_t)wave_total;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t tot = s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
+    s_wgbase = tot ? atomicAdd(&hdr[2], tot) : 0u;
+  }
+  __syncthreads();
+  uint32_t base = s_wgbase;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += s_wtot[w];
   // ---- the wave's pairs are spread over its lanes, one pair per lane and round: a thread that walked the bins of ITS
   //      Gaussian waited for one returning atomic per bin, one after the other (up to 25 round trips, and the wave waits
   //      for its longest lane: 146 us).  Now 64 atomics are in flight per round, the rounds are balanced, and the log is
