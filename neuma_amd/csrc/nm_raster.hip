@@ -95,7 +95,7 @@ struct State {
   unsigned long long* keys;    // (depth bits << 32 | Gaussian id), cell-major; cap entries
   uint32_t* vals;              // tile mask of the pair: bit (ty % 4) * 4 + (tx % 4) set iff the Gaussian can reach that tile of the bin
   PairLog* log;                // the count pass's pair log (cap entries; dead after the fill pass)
-  uint32_t *bin_total, *bin_off;
+  uint32_t* bin_total;
   float* final_T; uint32_t* n_contrib;
   // split compositing (k_split_plan): tiles of a view that leaves most of the chip idle are composited in list segments
   uint32_t* tile_rec;  // per tile: index of its first segment record, 0xFFFFFFFF = composited whole by k_render
@@ -151,7 +151,6 @@ static State carve_state(void* base, void* scratch, int W, int H, int k, int64_t
   t.zrange = (uint2*)(q + so); so += al256((K / 256 + 1) * sizeof(uint2));
   t.log = (PairLog*)(q + so); so += al256(cp * sizeof(PairLog));
   t.bin_total = (uint32_t*)(q + so); so += al256(((size_t)t.nbx * t.nby + 1) * sizeof(uint32_t));
-  t.bin_off = (uint32_t*)(q + so); so += al256(((size_t)t.nbx * t.nby + 1) * sizeof(uint32_t));
   t.tile_cnt = (uint32_t*)(q + so); so += al256(ntile * sizeof(uint32_t));
   t.tile_mode = (uint32_t*)(q + so); so += al256(ntile * sizeof(uint32_t));
   t.seg_raw = (float4*)(q + so); so += al256(it * NM_TPB * sizeof(float4));
