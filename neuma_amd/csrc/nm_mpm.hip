@@ -543,17 +543,23 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
       }
     }
     } else {
+    // (the node's address - two integer divisions and the block / in-block split - once per node into LDS, not once per
+    //  float: the largest boxes, 2048 nodes, are the workgroups the launch waits for)
+    int* naddr = L.cnt;               // free since the slab loop (the block marking above was its last user)
+    __syncthreads();
+    for (int nidx = tid; nidx < g.vol; nidx += NM_SC_T) {
+      int a_ = nidx / nyz, r = nidx - a_ * nyz;
+      int b_ = r / g.n[2], c_ = r - b_ * g.n[2];
+      const int x_ = cmp ? (int)L.ainv[0][a_] : g.o[0] + a_, y_ = cmp ? (int)L.ainv[1][b_] : g.o[1] + b_,
+                z_ = cmp ? (int)L.ainv[2][c_] : g.o[2] + c_;
+      naddr[nidx] = 4 * node_addr(x_, y_, z_, K.nb);
+    }
+    __syncthreads();
     const float* tilef = (const float*)L.tile;
+    float* gridf = (float*)grid;
     for (int idx = tid; idx < 4 * g.vol; idx += NM_SC_T) {
-      const int nidx = idx >> 2, comp = idx & 3;
       const float v = tilef[idx];
-      if (!NM_DBG_BIT(K, 1) && v != 0.f) {
-        int a_ = nidx / nyz, r = nidx - a_ * nyz;
-        int b_ = r / g.n[2], c_ = r - b_ * g.n[2];
-        const int x_ = cmp ? (int)L.ainv[0][a_] : g.o[0] + a_, y_ = cmp ? (int)L.ainv[1][b_] : g.o[1] + b_,
-                  z_ = cmp ? (int)L.ainv[2][c_] : g.o[2] + c_;
-        unsafeAtomicAdd((float*)&grid[node_addr(x_, y_, z_, K.nb)] + comp, v);
-      }
+      if (!NM_DBG_BIT(K, 1) && v != 0.f) unsafeAtomicAdd(gridf + naddr[idx >> 2] + (idx & 3), v);
     }
     }
     SC_PH(6)
