@@ -437,9 +437,20 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
       const int a_ = mycell / nyz, r_ = mycell - a_ * nyz;
       const int b_ = r_ / g.n[2], c_ = r_ - b_ * g.n[2];
       const int o0 = (int)L.ainv[0][a_], o1 = (int)L.ainv[1][b_], o2 = (int)L.ainv[2][c_];
-      for (int i = o0 >> 2; i <= (o0 + 2) >> 2; ++i)
-        for (int j = o1 >> 2; j <= (o1 + 2) >> 2; ++j)
-          for (int k = o2 >> 2; k <= (o2 + 2) >> 2; ++k) mark_block((i * K.nb + j) * K.nb + k, flags, list, count, epoch);
+      // the (up to) eight blocks of the cell's stencil: all their stamps are read first, in one round trip - nearly all are
+      // current (k_clear carried them over), and one dependent global read per block was 8 k cycles of the two or three
+      // workgroups per launch that take this path, which were the ones the launch waited for
+      int bid[8], fl[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int i = (o0 >> 2) + (q >> 2), j = (o1 >> 2) + ((q >> 1) & 1), k = (o2 >> 2) + (q & 1);
+        const bool ok = i <= (o0 + 2) >> 2 && j <= (o1 + 2) >> 2 && k <= (o2 + 2) >> 2;
+        bid[q] = ok ? (i * K.nb + j) * K.nb + k : -1;
+        fl[q] = ok ? flags[bid[q]] : epoch;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (fl[q] != epoch) mark_block(bid[q], flags, list, count, epoch);
     }
 #pragma unroll 1
     for (int i = 0; i < 3; ++i) {
