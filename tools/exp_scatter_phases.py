@@ -15,8 +15,15 @@ lib = _lib.lib()
 dev = torch.device("cuda", 0)
 rt = SceneRuntime(synth.make_scene(sys.argv[1] if len(sys.argv) > 1 else "metric", override=dict(K=1000)), dev)
 ms = (C.c_int * 4)()
+if len(sys.argv) > 2 and sys.argv[2] == "bwd":      # the last wg_scatter launch is then k_g2p_bwd of substep 0
+    for it in range(2):
+        for p_ in rt.parameters():
+            p_.grad = None
+        o = rt.rollout(rt.x0, rt.v0, rt.C0, rt.F0)
+        (o[0].sum() + o[3].sum()).backward()
+        torch.cuda.synchronize()
 with torch.no_grad():
-    for it in range(3):
+    for it in range(0 if (len(sys.argv) > 2 and sys.argv[2] == "bwd") else 3):
         rt.rollout(rt.x0, rt.v0, rt.C0, rt.F0)      # last launch using wg_scatter = k_p2g of substep 20
         torch.cuda.synchronize()
         lib.nm_debug_markslow(ms)
