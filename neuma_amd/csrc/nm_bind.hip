@@ -165,9 +165,10 @@ extern "C" int nm_pixel_loss(int32_t kind, float weight, int32_t h, int32_t w, i
   if (row1 <= row0) { row0 = 0; row1 = h; }
   float scale = weight / (3.0f * (float)h * (float)w);
   // every workgroup ends with one atomic on the SAME word (the loss): ~12 ns each, one after the other - 2048 workgroups
-  // of one row each spent 25 us of a 30-us kernel queueing there.  512 workgroups take a few rows each.
-  int grid = 3 * h;
-  if (grid > 512) grid = 512;
+  // of one row each spent 25 us of a 30-us kernel queueing there.  About six rows per workgroup, 128..512 workgroups
+  // (tools/exp_pixel_loss.py: 256^2 5.7 us, 800^2 ~10, 1080p 19; 12 / 29 / 34 us with 2048)
+  int grid = (3 * h + 5) / 6;
+  grid = grid < 128 ? (3 * h < 128 ? 3 * h : 128) : (grid > 512 ? 512 : grid);
   const bool vec4 = w % 4 == 0 && ((uintptr_t)img | (uintptr_t)gt | (uintptr_t)dL_dimg) % 16 == 0;
   if (vec4)
     NM_LAUNCH(k_pixel_loss<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, kind, scale, h, w, row0, row1, img, gt,
