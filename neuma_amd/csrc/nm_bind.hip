@@ -13,6 +13,25 @@ __global__ void __launch_bounds__(256) k_spmm_csr(int rows, int D, const int* __
   const int c = threadIdx.x & 15;
   if (r >= rows) return;
   const int b = rowptr[r], e = rowptr[r + 1];
+  if (D <= 4) {
+    // few columns (the frame's B^T dL/dmeans3D has three): the sixteen lanes share the row's ENTRIES instead of its columns -
+    // with a lane per column 13 of 16 lanes idled and every lane walked the whole row through a chain of dependent loads
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int q = b + c; q < e; q += 16) {
+      const float w = val[q];
+      const float* src = in + (size_t)col[q] * D;
+      a0 += w * src[0];
+      if (D > 1) a1 += w * src[1];
+      if (D > 2) a2 += w * src[2];
+      if (D > 3) a3 += w * src[3];
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      a0 += __shfl_xor(a0, o, 16); a1 += __shfl_xor(a1, o, 16); a2 += __shfl_xor(a2, o, 16); a3 += __shfl_xor(a3, o, 16);
+    }
+    if (c < D) out[(size_t)r * D + c] = c == 0 ? a0 : (c == 1 ? a1 : (c == 2 ? a2 : a3));
+    return;
+  }
   for (int cc = c; cc < D; cc += 16) {
     float acc = 0.f;
     for (int q = b; q < e; ++q) acc += val[q] * in[(size_t)col[q] * D + cc];
@@ -71,14 +90,37 @@ __global__ void __launch_bounds__(256) k_bind_frame(int k, const int* __restrict
   if (i >= k) return;
   float d[3] = {0.f, 0.f, 0.f};
   M3 Fk = m3_zero();
-  for (int q = rowptr[i]; q < rowptr[i + 1]; ++q) {
-    int c = col[q];
-    float w = val[q];
+  // four bound particles per trip, all their loads issued before the first use (a rolled loop pays the column-index round
+  // trip and then the gather round trip for every particle, one after the other); summation order unchanged
+  const int q1 = rowptr[i + 1];
+  for (int q = rowptr[i]; q < q1; q += 4) {
+    int c[4];
+    float w[4], dp[4][3], Fv[4][9];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) d[a] += w * (pc[3 * c + a] - pp[3 * c + a]);
-    if (F) {
+    for (int u = 0; u < 4; ++u) {
+      const bool ok = q + u < q1;
+      c[u] = col[ok ? q + u : q];
+      w[u] = ok ? val[q + u] : 0.f;
+    }
 #pragma unroll
-      for (int a = 0; a < 9; ++a) Fk.m[a] += w * F[9 * (size_t)c + a];
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) dp[u][a] = pc[3 * c[u] + a] - pp[3 * c[u] + a];
+      if (F) {
+#pragma unroll
+        for (int a = 0; a < 9; ++a) Fv[u][a] = F[9 * (size_t)c[u] + a];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (q + u < q1) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) d[a] += w[u] * dp[u][a];
+        if (F) {
+#pragma unroll
+          for (int a = 0; a < 9; ++a) Fk.m[a] += w[u] * Fv[u][a];
+        }
+      }
     }
   }
 #pragma unroll
