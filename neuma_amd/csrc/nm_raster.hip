@@ -2199,6 +2199,11 @@ static int raster_forward_impl(const nm_raster_cfg* cfg, int32_t K, int32_t m, c
               out_color, tile_walk);
     NM_LAUNCH_CHECK();
   }
+  // A hinted plan splits the forward pass of a tile only if its planned walk is longer than g_hint_fwd entries; no list is
+  // longer than the capacity, so with the threshold at or above it (the frame driver's setting when several views share the
+  // chip: every tile walks front to back) the second and third pass have nothing to do and are not launched.
+  const bool no_split_fwd = stages == 1 && (long long)g_hint_fwd >= (long long)cap_pairs;
+  if (!no_split_fwd) {
   NM_LAUNCH(k_render_fix, dim3(t.items), dim3(NM_TPB), 0, s, k, t.nbx, (const uint32_t*)t.off, (const unsigned long long*)t.keys,
             (const uint32_t*)t.vals, (long long)cap_pairs, (const uint32_t*)t.hdr, (const uint32_t*)t.tile_rec,
             (const uint32_t*)t.tile_ns, t.tile_cnt, (const uint32_t*)t.tile_mode, (const uint2*)t.work, (const float4*)t.seg_raw,
@@ -2210,6 +2215,7 @@ static int raster_forward_impl(const nm_raster_cfg* cfg, int32_t K, int32_t m, c
             (const uint32_t*)t.tile_ns, (const uint32_t*)t.tile_mode, (const float4*)t.seg_fix, t.seg_ct,
             (const uint32_t*)t.seg_last, t.seg_pos, (const GRec*)t.recs, t.final_T, t.n_contrib, out_color, tile_walk);
   NM_LAUNCH_CHECK();
+  }
   if (status_host)      // pairs | overflow | items wanted (plan_status), one copy
     NM_HIP_CHECK(hipMemcpyAsync(status_host, t.hdr + 16, sizeof(int64_t) * (size_t)(status_words < 3 ? status_words : 3), hipMemcpyDeviceToHost, s));
   return NM_OK;

@@ -716,7 +716,7 @@ class SceneRuntime(object):
             # view's (metric frame: 140.3 -> 142.2 frames/s); a view that has the chip to itself needs the segments for its
             # latency (sf 603 -> 1035 frames/s).  Process-wide knob of the library, set when the situation changes.
             from . import _lib as L
-            L.check(L.lib().nm_raster_set_hinted((1 << 20) if streams else 0, 256), "nm_raster_set_hinted")
+            L.check(L.lib().nm_raster_set_hinted(0x7FFFFFFF if streams else 0, 256), "nm_raster_set_hinted")      # (>= any capacity: the library then skips its second and third compositing pass)
             self._hint_mode = bool(streams)
         return streams
 
