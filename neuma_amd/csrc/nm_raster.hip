@@ -278,6 +278,25 @@ __device__ __forceinline__ Cov2D compute_cov2d(const RK& k, float mx, float my, 
   return o;
 }
 
+// One Gaussian's SH coefficients into registers: 16-byte loads when the row allows it (degree 1 and 3: 12 / 48 floats per
+// row; rows of 576 bytes) instead of 48 scalar loads 576 bytes apart between lanes
+__device__ __forceinline__ void load_sh_row(const float* __restrict__ shs, size_t i, int M, float* sh) {
+  const int nf = 3 * M;
+  const float* row = shs + i * (size_t)nf;
+  if ((nf & 3) == 0 && (reinterpret_cast<uintptr_t>(shs) & 15) == 0) {
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+      if (4 * q < nf) {
+        const float4 v = reinterpret_cast<const float4*>(row)[q];
+        sh[4 * q] = v.x; sh[4 * q + 1] = v.y; sh[4 * q + 2] = v.z; sh[4 * q + 3] = v.w;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 48; ++q) if (q < nf) sh[q] = row[q];
+  }
+}
+
 // ---------------------------------------------------------------- forward kernels
 __global__ void __launch_bounds__(256) k_preprocess(RK k, int K, const float* __restrict__ means, const float* __restrict__ shs,
                                                     const float* __restrict__ colors, const float* __restrict__ opac,
@@ -341,7 +360,8 @@ __global__ void __launch_bounds__(256) k_preprocess(RK k, int K, const float* __
       float dx = mx - k.cam[0], dy = my - k.cam[1], dz = mz - k.cam[2];
       float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
       float x = dx * inv, y = dy * inv, z = dz * inv;
-      const float* sh = shs + (size_t)i * k.M * 3;
+      float sh[48];
+      load_sh_row(shs, (size_t)i, k.M, sh);
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
         float res = SH_C0 * sh[ch];
@@ -1963,7 +1983,8 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(RK k, int K, const float
       float len2 = dx * dx + dy * dy + dz * dz;
       float inv = 1.f / sqrtf(len2);
       float x = dx * inv, y = dy * inv, z = dz * inv;
-      const float* sh = shs + (size_t)i * k.M * 3;
+      float sh[48];
+      load_sh_row(shs, (size_t)i, k.M, sh);
       float* gsh = dsh ? dsh + (size_t)i * k.M * 3 : nullptr;
       float ddir[3] = {0.f, 0.f, 0.f};
 #pragma unroll
