@@ -539,7 +539,8 @@ class SceneRuntime(object):
 
     # ---- the one-node frame (_Frame)
     def _lean_ok(self) -> bool:
-        """The frame can run as ONE autograd node: one GPU, library roll-out, particles in scatter order, and the only trainable
+        """The frame can run as ONE autograd node: simulation not sharded (one GPU, or several with the simulation replicated and
+        the render in stripes), library roll-out, particles in scatter order, and the only trainable
         tensors are the LoRA factors of the six layers (finetune.py:295-313, the configuration NeuMA trains in).  Decided once
         per set of layer modules (adding LoRA replaces them); `_lean = None` forgets the decision after a manual (un)freeze."""
         fcs = [fc for net in (self.elasticity, self.plasticity) for fc in (net.layers[0].fc, net.layers[1].fc, net.final_layer.fc)]
@@ -547,7 +548,7 @@ class SceneRuntime(object):
         ok = getattr(self, "_lean", None)
         if ok is None or ok[0] != key:
             from .material.loralib import LinearLoRA
-            good = (self.world == 1 and not self.shard_sim and self.model.exchange is None
+            good = (not self.shard_sim and self.model.exchange is None
                     and all(isinstance(fc, LinearLoRA) and fc.r > 0 and not fc.merged and fc.weight.is_cuda and not fc.weight.requires_grad
                             and fc.lora_A.requires_grad and fc.lora_B.requires_grad and fc.bias is None
                             and fc.weight.dtype == torch.float32 and fc.weight.is_contiguous() for fc in fcs)
@@ -642,8 +643,13 @@ class SceneRuntime(object):
         de_x_prev = self._de_prev
         g_prev = self.g_start
         if backward and self._lean_ok():
-            # one GPU, LoRA training: the whole frame is one autograd node over the LoRA factors (_Frame)
-            jobs = self._lean_jobs
+            # LoRA training, simulation on this GPU: the whole frame is two plain calls (_frame_forward / _frame_backward).
+            # Several ranks with the simulation replicated: every rank rolls out all particles, renders its stripes, and the
+            # reverse sweep's one K x 3 all-reduce (inside _tail_backward) gives every rank the full gradient
+            if self.world == 1:
+                jobs = self._lean_jobs
+            else:
+                jobs = [(vi, (r0, r1)) for (vi, r0, r1) in stripe_plan(self.V, self.tile_rows, self.world, self.rank, self._stripe_weights())]
             streams = self._frame_streams(jobs)
             self._tail_constants(de_x_prev, g_prev)
             ba = [t for l in self._lora_layers for t in (l.lora_B, l.lora_A)]
@@ -659,6 +665,8 @@ class SceneRuntime(object):
                         p.grad = gr
                     else:
                         p.grad.add_(gr)
+            if self.world > 1:
+                self._collect_stripe_work(jobs)
             return FrameResult(loss, x, F.view(-1, 3, 3))
         rows = self.rows
         x, v, C, F = (t[rows] for t in self.start)

@@ -281,6 +281,43 @@ def cpu_comm_link(rank, world, port, q):
         q.put({"rank": rank, "error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()})
 
 
+def gpu_stripes_frame(rank, world, port, q, name="tiny"):
+    """The replicated-simulation multi-GPU frame (what `--shard-sim auto` picks for the metric workload): every rank rolls out
+    all particles, renders its stripes of the views' tile rows, the ranks sum dL/dmeans3D with ONE all-reduce per frame and
+    finish the reverse sweep identically.  Against the single-process frame: the ranks' losses add up to its loss, and every
+    rank ends with ITS full LoRA gradients (no parameter reduction in this mode)."""
+    try:
+        dist = _init(rank, world, port)
+        from neuma_amd import synth
+        from neuma_amd.harness import SceneRuntime
+        dev = torch.device("cuda", 0)
+        scene = synth.make_scene(name)
+        ref = SceneRuntime(scene, dev, fused=True)
+        ref.set_start_state("deformed")
+        ref.make_ground_truth()
+        rt = SceneRuntime(scene, dev, rank=rank, world=world, shard_sim=False, fused=True, group=dist.group.WORLD)
+        rt.set_start_state("deformed")
+        rt.gt = ref.gt
+        out = {}
+        for tag, run in (("ref", ref), ("rt", rt)):
+            for _ in range(2):          # (second frame: stripe weights from the first, hinted plans, pooled buffers)
+                for p in run.parameters():
+                    p.grad = None
+                r = run.frame()
+            out[tag] = (r, [p.grad.clone() for p in run.parameters()])
+        tot = out["rt"][0].loss.clone()
+        dist.all_reduce(tot)
+        res = {"rank": rank, "loss": float(tot), "ref_loss": float(out["ref"][0].loss),
+               "x_err": _err(out["rt"][0].x, out["ref"][0].x),
+               "grad_err": [_err(a, b) for a, b in zip(out["rt"][1], out["ref"][1])],
+               "grad_mag": [float(b.abs().max()) for b in out["ref"][1]], "lean": bool(rt._lean_ok())}
+        q.put(res)
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put({"rank": rank, "error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()})
+
+
 def gpu_nccl_one_rank(rank, world, port, q, name="tiny"):
     """world = 1 on the RCCL backend ("nccl"): the collectives of both multi-GPU modes issued for real - the frame's K x 3
     gradient all-reduce (_AllReduceSum) and the fused sharded roll-out's callbacks on views of its device workspace

@@ -75,6 +75,18 @@ def test_sharded_frame_matches_the_single_process_frame(world, fused):
         assert max(r["grad_err"]) < 2e-3 and min(r["grad_mag"]) > 1e-9, r
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_striped_frame_with_replicated_simulation_matches_the_single_process_frame(world):
+    """Render stripes + one gradient all-reduce per frame, the simulation replicated on every rank (what --shard-sim auto picks
+    for the metric workload): summed loss, state and every rank's LoRA gradients against the one-GPU frame."""
+    res = _run(shard_worker.gpu_stripes_frame, world, "tiny")
+    for r in res:
+        assert abs(r["loss"] - r["ref_loss"]) <= 1e-5 * abs(r["ref_loss"]) + 1e-12, r
+        assert r["x_err"] < 1e-6, r
+        assert max(r["grad_err"]) < 1e-4 and min(r["grad_mag"]) > 0, r
+        assert r["lean"], r          # (the ranks ran the two-call frame: harness._frame_forward / _frame_backward)
+
+
 @pytest.mark.parametrize("world,cap", [(2, 300), (3, 12000)])
 def test_device_shared_block_rule_equals_the_host_statement(world, cap):
     """nm_mpm_shared_blocks (one-workgroup path for short lists, mark / flag / select / finish path for long ones) against
