@@ -323,3 +323,41 @@ def test_fused_rollout_svd_adjoint_default_matches_per_operator_reference_mode()
             for a, b_ in zip(res[("reference", True)], res[("polar", True)]):
                 assert rel_max(a, b_) < 5e-3
     rt.sim_fused.svd_adjoint = "reference"
+
+
+def test_kernel_timing_hooks_count_and_sample_launches():
+    """nm_prof_enable(1, name): HIP events around every launch of that kernel; nm_prof_enable(n, name): around every n-th one
+    (what bench.py uses inside its timed region for a kernel launched many times per frame); nm_prof_enable(0): none."""
+    import ctypes as C
+    from neuma_amd import _lib as L
+    lib = L.lib()
+    n = 4096
+    F = (torch.eye(3, device=dev()).repeat(n, 1, 1) + 0.05 * torch.randn(n, 3, 3, device=dev())).contiguous()
+    U, s, Vh = torch.empty_like(F), torch.empty(n, 3, device=dev()), torch.empty_like(F)
+
+    def run(times):
+        for _ in range(times):
+            L.check(lib.nm_svd3_fwd(n, L.ptr(F), L.ptr(U), L.ptr(s), L.ptr(Vh), L.stream_ptr(dev())), "nm_svd3_fwd")
+
+    def report():
+        buf = C.create_string_buffer(1 << 14)
+        lib.nm_prof_report(buf, len(buf))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, calls, ms = line.rsplit(" ", 2)
+            out[name.strip("()")] = (int(calls), float(ms))
+        return out
+
+    try:
+        for stride, launches, expect in ((1, 6, 6), (3, 7, 3), (8, 8, 1)):
+            lib.nm_prof_reset()
+            lib.nm_prof_enable(stride, b"k_svd_fwd")
+            run(launches)
+            lib.nm_prof_enable(0, None)
+            run(2)                                  # not timed
+            torch.cuda.synchronize()
+            rep = report()
+            assert list(rep) == ["k_svd_fwd"] and rep["k_svd_fwd"][0] == expect and rep["k_svd_fwd"][1] > 0.0, (stride, rep)
+    finally:
+        lib.nm_prof_enable(0, None)
+        lib.nm_prof_reset()
