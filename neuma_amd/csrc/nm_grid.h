@@ -10,6 +10,8 @@ struct MpmK {
   int bound, bc;
   int dbg;
   int maxpass;  // NM_DBG experiment switches (0 in production)
+  int ppw;      // scatter kernels: particles per workgroup (set per launch, scatter_k)
+  int smode;    // scatter kernels: 1 = fp64 LDS atomics into the workgroup tile (default), 0 = counting sort + barrier-separated pushes (NEUMA_SCATTER=sort)
 };
 
 __device__ __forceinline__ void block_coords(int b, int nb, int lane, int& i, int& j, int& k) {

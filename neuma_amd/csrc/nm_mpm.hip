@@ -19,6 +19,7 @@
 #include "nm_common.h"
 #include "nm_grid.h"
 #include <stdlib.h>
+#include <string.h>
 
 
 // experiment switches (tools/exp_*.py) exist only in -DNM_PHASES builds; in the shipped library they fold to constants
@@ -269,6 +270,264 @@ __device__ __forceinline__ void wave_scatter(const MpmK& K, bool en, const int* 
   }
 }
 
+// ---- fp64-atomic scatter (round 4; K.smode == 1, the default).
+// ds_add_f64 retires 6.5 lanes/clk/CU on gfx950 where ds_add_f32 retires 0.33 (tools/ubench_lds_int.hip: the f32 form is the
+// slow one, not LDS atomics as such; ds_add_u64 8.3, ds_add_u32 9.2), so every particle adds its 27 x NCH contributions
+// straight into the workgroup's tile - kept as NCH planes of doubles, node-contiguous.  With the thread -> particle
+// permutation of the callers (scatter_particle: the 16 lanes an LDS cycle serves hold 16 different cells) the pattern runs at
+// 2.6-3.6 lanes/clk/CU, against 1.3-1.4 in particle order and 0.9 with the four channels of a node side by side.  No sort, no
+// per-offset barriers (6 workgroup barriers instead of ~45), and a node sum is rounded once (double -> float at the flush)
+// instead of once per addend.
+// A chunk of the particle list that the space-filling curve leaves and re-enters (bounding box > tile) is cut at the jumps -
+// consecutive particles more than two cells apart - into up to four GROUPS, each with a box of its own inside the same tile
+// memory; what still does not fit (an arbitrary order) goes particle by particle to global atomics: any order is correct.
+#define NM_F64_PS (NM_WT_CAP + 8)      // plane stride in doubles (+8: the four channels of a node sit in different banks at the flush)
+#define NM_F64_MAXG 4
+template <int NCH, class ContribF>
+__device__ __forceinline__ void wg_scatter_f64(const MpmK& K, bool en, int lp, const int* base, float4* __restrict__ grid, int* flags,
+                                               int* list, int* count, int epoch, ScatterLds& L, ContribF contrib) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  SC_DECL
+  double* acc = reinterpret_cast<double*>(L.C);                 // C | tile are contiguous: 68 KiB >= 4 planes x 2056 x 8 B
+  static_assert(sizeof(L.C) + sizeof(L.tile) >= (size_t)NM_F64_PS * 4 * sizeof(double) && offsetof(ScatterLds, tile) == sizeof(L.C),
+                "the fp64 tile overlays the sort path's contribution buffer and tile");
+  // ---- bounding box of the stencil origins
+  int lo[3], hi[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    lo[a] = wave_min_i(en ? base[a] : 0x7fffffff);
+    hi[a] = wave_max_i(en ? base[a] : -0x7fffffff);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { L.red[wave * 6 + a] = lo[a]; L.red[wave * 6 + 3 + a] = hi[a]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    lo[a] = L.red[a]; hi[a] = L.red[3 + a];
+#pragma unroll
+    for (int w2 = 1; w2 < NM_SC_NW; ++w2) { lo[a] = min(lo[a], L.red[6 * w2 + a]); hi[a] = max(hi[a], L.red[6 * w2 + 3 + a]); }
+  }
+  __syncthreads();
+  if (lo[0] == 0x7fffffff) return;  // nothing enabled in this workgroup
+  if (NM_DBG_BIT(K, 4)) return;
+  // geometry of this thread's group: origin, extents, first tile slot
+  int go[3] = {lo[0], lo[1], lo[2]}, gn[3] = {hi[0] - lo[0] + 3, hi[1] - lo[1] + 3, hi[2] - lo[2] + 3}, goff = 0;
+  int total = gn[0] * gn[1] * gn[2], ngroups = 1;
+  bool direct = false;      // last resort: this workgroup's particles go to global memory one by one
+  int* gtab = L.cnt + 3 * NM_SC_T;     // group boxes while they are being reduced: per group min[3], max[3] (8 ints)
+  if (total > NM_WT_CAP) {
+    // ---- cut the chunk at its jumps
+    int* pk = L.cnt;                 // stencil origins by position in the chunk, three arrays of NM_SC_T (-1: disabled)
+    int* jl = L.red + 24;            // [0] number of jumps, [1..3] their positions
+#pragma unroll
+    for (int a = 0; a < 3; ++a) pk[a * NM_SC_T + lp] = en ? base[a] : -1;
+    if (tid == 0) jl[0] = 0;
+    if (tid < NM_F64_MAXG * 8) gtab[tid] = (tid & 7) < 3 ? 0x7fffffff : ((tid & 7) < 6 ? -1 : 0);     // min | max | -
+    __syncthreads();
+    if (en && lp > 0) {
+      const int q = pk[lp - 1];
+      if (q >= 0) {
+        const int d0 = abs(q - base[0]), d1 = abs(pk[NM_SC_T + lp - 1] - base[1]), d2 = abs(pk[2 * NM_SC_T + lp - 1] - base[2]);
+        if (max(d0, max(d1, d2)) > 2) {
+          const int pos = atomicAdd(&jl[0], 1);
+          if (pos < NM_F64_MAXG - 1) jl[1 + pos] = lp;
+        }
+      }
+    }
+    __syncthreads();
+    const int nj = jl[0];
+    direct = nj > NM_F64_MAXG - 1;
+    int grp = 0;
+    if (!direct) {
+      for (int q = 0; q < nj; ++q) grp += jl[1 + q] <= lp ? 1 : 0;
+      if (en) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { atomicMin(&gtab[grp * 8 + a], base[a]); atomicMax(&gtab[grp * 8 + 3 + a], base[a]); }
+      }
+    }
+    __syncthreads();
+    if (!direct) {
+      ngroups = nj + 1;
+      int off = 0;
+      for (int q = 0; q < ngroups; ++q) {
+        int n_[3], v_ = 1;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { n_[a] = gtab[q * 8 + 3 + a] < 0 ? 0 : gtab[q * 8 + 3 + a] - gtab[q * 8 + a] + 3; v_ *= n_[a]; }
+        if (q == grp) {
+#pragma unroll
+          for (int a = 0; a < 3; ++a) { go[a] = gtab[q * 8 + a]; gn[a] = n_[a]; }
+          goff = off;
+        }
+        off += v_;
+      }
+      total = off;
+      direct = total > NM_WT_CAP;
+    }
+    __syncthreads();       // everybody has read the min / max words; the table is rewritten below in (origin, extent, offset) form
+    if (!direct && tid < ngroups) {
+      int n_[3], o_[3], off = 0;
+      for (int q = 0; q <= tid; ++q) {
+        int v_ = 1;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { o_[a] = gtab[q * 8 + a]; n_[a] = gtab[q * 8 + 3 + a] < 0 ? 0 : gtab[q * 8 + 3 + a] - o_[a] + 3; v_ *= n_[a]; }
+        if (q < tid) off += v_;
+      }
+      // (written after the loop's reads of THIS thread; other threads read only rows <= their own id, row tid is ours)
+      int* row = L.red;    // red[0..31]: 4 groups x (o[3], n[3], off, end)
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { row[tid * 8 + a] = o_[a]; row[tid * 8 + 3 + a] = n_[a]; }
+      row[tid * 8 + 6] = off;
+      row[tid * 8 + 7] = off + n_[0] * n_[1] * n_[2];
+    }
+    // (L.red is published by the barrier that follows the tile clear)
+  }
+  SC_PH(0)
+  if (direct) {
+    if (en) {
+#pragma unroll 1
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const float4 c = contrib(i, j, k);
+            float* dst = (float*)&grid[node_addr(base[0] + i, base[1] + j, base[2] + k, K.nb)];
+            unsafeAtomicAdd(dst, c.x);
+            unsafeAtomicAdd(dst + 1, c.y);
+            unsafeAtomicAdd(dst + 2, c.z);
+            if (NCH == 4) unsafeAtomicAdd(dst + 3, c.w);
+          }
+      if (flags) {
+        for (int i = base[0] >> 2; i <= (base[0] + 2) >> 2; ++i)
+          for (int j = base[1] >> 2; j <= (base[1] + 2) >> 2; ++j)
+            for (int k = base[2] >> 2; k <= (base[2] + 2) >> 2; ++k)
+              mark_block((i * K.nb + j) * K.nb + k, flags, list, count, epoch);
+      }
+    }
+    SC_STORE(99)
+    return;
+  }
+  const bool multi = ngroups > 1;
+  // Block stamps of the bounding box are read NOW, while the memory system is quiet: at the end of the kernel the same
+  // read queues behind every workgroup's atomic flush (10-25k cycles under load).
+  int pre_flag = epoch;
+  const int b0 = go[0] >> 2, b1 = go[1] >> 2, b2 = go[2] >> 2;
+  const int m1 = ((go[1] + gn[1] - 1) >> 2) - b1 + 1, m2 = ((go[2] + gn[2] - 1) >> 2) - b2 + 1;
+  const int nblk = (((go[0] + gn[0] - 1) >> 2) - b0 + 1) * m1 * m2;
+  if (flags && !multi && tid < nblk) {
+    const int i = tid / (m1 * m2), r = tid - i * (m1 * m2);
+    pre_flag = flags[((b0 + i) * K.nb + (b1 + r / m2)) * K.nb + (b2 + r % m2)];
+  }
+  SC_PH(1)
+  {
+    const double2 z2 = make_double2(0.0, 0.0);
+    double2* a2 = reinterpret_cast<double2*>(acc);
+    const int half = (total + 1) >> 1;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      for (int i = tid; i < half; i += NM_SC_T) a2[c * (NM_F64_PS / 2) + i] = z2;
+  }
+  if (flags && multi && en && !NM_DBG_BIT(K, 2)) {      // several boxes: every particle stamps the blocks of its own stencil
+    int bid[8], fl[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = (base[0] >> 2) + (q >> 2), j = (base[1] >> 2) + ((q >> 1) & 1), k = (base[2] >> 2) + (q & 1);
+      const bool ok = i <= (base[0] + 2) >> 2 && j <= (base[1] + 2) >> 2 && k <= (base[2] + 2) >> 2;
+      bid[q] = ok ? (i * K.nb + j) * K.nb + k : -1;
+      fl[q] = ok ? flags[bid[q]] : epoch;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (fl[q] != epoch) mark_block(bid[q], flags, list, count, epoch);
+  }
+  __syncthreads();
+  SC_PH(2)
+  const int ny = gn[1], nz = gn[2];
+  if (en) {
+    double* a0 = acc + goff + ((base[0] - go[0]) * ny + (base[1] - go[1])) * nz + (base[2] - go[2]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        double* row = a0 + (i * ny + j) * nz;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float4 c = contrib(i, j, k);
+          unsafeAtomicAdd(row + k, (double)c.x);
+          unsafeAtomicAdd(row + NM_F64_PS + k, (double)c.y);
+          unsafeAtomicAdd(row + 2 * NM_F64_PS + k, (double)c.z);
+          if (NCH == 4) unsafeAtomicAdd(row + 3 * NM_F64_PS + k, (double)c.w);
+        }
+      }
+  }
+  __syncthreads();
+  SC_PH(3)
+  // node addresses (two integer divisions and the block / in-block split, once per node) and - one box - which blocks of the
+  // bounding box received something (an untouched block stamped here would hold no mass, drop out at the next clear and take
+  // the atomic path of mark_block again every substep)
+  const bool mark = flags != nullptr && !multi && !NM_DBG_BIT(K, 2);
+  int* naddr = L.cnt;
+  int* touched = reinterpret_cast<int*>(&L.ainv[0][0]);
+  static_assert(sizeof(L.ainv) >= 320 * sizeof(int), "block table of a 2048-node box (<= ~232 blocks)");
+  if (mark) {
+    for (int t = tid; t < nblk; t += NM_SC_T) touched[t] = 0;
+    __syncthreads();
+  }
+  for (int nidx = tid; nidx < total; nidx += NM_SC_T) {
+    int o_[3] = {go[0], go[1], go[2]}, n1 = gn[1], n2 = gn[2], loc = nidx;
+    if (multi) {
+      int q = 0;
+      while (q + 1 < ngroups && nidx >= L.red[q * 8 + 7]) ++q;
+      o_[0] = L.red[q * 8]; o_[1] = L.red[q * 8 + 1]; o_[2] = L.red[q * 8 + 2];
+      n1 = L.red[q * 8 + 4]; n2 = L.red[q * 8 + 5];
+      loc = nidx - L.red[q * 8 + 6];
+    }
+    const int a_ = loc / (n1 * n2), r = loc - a_ * (n1 * n2);
+    const int b_ = r / n2, c_ = r - b_ * n2;
+    const int x_ = o_[0] + a_, y_ = o_[1] + b_, z_ = o_[2] + c_;
+    naddr[nidx] = 4 * node_addr(x_, y_, z_, K.nb);
+    if (mark) {
+      bool nzv = acc[nidx] != 0.0 || acc[NM_F64_PS + nidx] != 0.0 || acc[2 * NM_F64_PS + nidx] != 0.0;
+      if (NCH == 4) nzv = nzv || acc[3 * NM_F64_PS + nidx] != 0.0;
+      if (nzv) touched[(((x_ >> 2) - b0) * m1 + ((y_ >> 2) - b1)) * m2 + ((z_ >> 2) - b2)] = 1;
+    }
+  }
+  __syncthreads();
+  if (mark) {
+    for (int t = tid; t < nblk; t += NM_SC_T) {
+      if (touched[t] == 0 || (t == tid && pre_flag == epoch)) continue;     // already stamped when we looked
+      const int i = t / (m1 * m2), r = t - i * (m1 * m2);
+      const int j = r / m2, k = r - j * m2;
+      mark_block(((b0 + i) * K.nb + (b1 + j)) * K.nb + (b2 + k), flags, list, count, epoch);
+    }
+  }
+  SC_PH(4)
+  // the flush: one global atomic set per touched node, the sums rounded to fp32 here.  Four channels: one FLOAT per lane
+  // (four lanes cover a node, a wave instruction sixteen consecutive nodes of a z run: 314 against 77 G/s, tools/ubench_flush.hip);
+  // three channels: one node per lane (the float-per-lane mapping leaves a quarter of the lanes idle there and measured slower)
+  float* gridf = (float*)grid;
+  if (NCH == 4) {
+    for (int idx = tid; idx < 4 * total; idx += NM_SC_T) {
+      const float v = (float)acc[(idx & 3) * NM_F64_PS + (idx >> 2)];
+      if (!NM_DBG_BIT(K, 1) && v != 0.f) unsafeAtomicAdd(gridf + naddr[idx >> 2] + (idx & 3), v);
+    }
+  } else {
+    for (int nidx = tid; nidx < total; nidx += NM_SC_T) {
+      const float vx = (float)acc[nidx], vy = (float)acc[NM_F64_PS + nidx], vz = (float)acc[2 * NM_F64_PS + nidx];
+      if (vx != 0.f || vy != 0.f || vz != 0.f) {
+        float* dst = gridf + naddr[nidx];
+        unsafeAtomicAdd(dst, vx);
+        unsafeAtomicAdd(dst + 1, vy);
+        unsafeAtomicAdd(dst + 2, vz);
+      }
+    }
+  }
+  SC_PH(6)
+  SC_STORE(ngroups + 1)
+}
+
 // Scatter of the workgroup's 256 particles (one per thread) into `grid` WITHOUT floating-point atomics in LDS
 // (ds_add_f32 retires ~0.33 lanes/clk/CU on gfx950) and without serial per-wave chains:
 //   1. the particles are counting-sorted by stencil origin inside LDS (256 integer LDS atomics + a block scan), so
@@ -286,8 +545,12 @@ __device__ __forceinline__ void wave_scatter(const MpmK& K, bool en, const int* 
 // private boxes); after NM_WT_MAXPASS boxes the leftovers use per-particle global atomics, so any order is correct.
 //   contrib(i, j, k) -> float4 contribution of THIS thread's particle to stencil node (i,j,k)
 template <int NCH, class ContribF>
-__device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* base, float4* __restrict__ grid, int* flags,
+__device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, int lp, const int* base, float4* __restrict__ grid, int* flags,
                                            int* list, int* count, int epoch, ScatterLds& L, ContribF contrib) {
+  if (K.smode == 1) {     // (uniform over the launch)
+    wg_scatter_f64<NCH>(K, en, lp, base, grid, flags, list, count, epoch, L, contrib);
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   SC_DECL
   int sc_pass = 0;
@@ -578,6 +841,15 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, const int* ba
   SC_STORE(sc_pass)
 }
 
+// Which particle of its workgroup a thread of the scatter kernels takes.  fp64-atomic mode: thread t takes particle
+// 16 (t % 16) + t / 16, so that the sixteen lanes one LDS cycle serves hold particles sixteen apart in the (cell-ordered)
+// list - sixteen different cells, no same-address serialisation inside the atomic instruction (2x on the atomic phase,
+// tools/ubench_lds_int.hip).  The sort path re-orders the particles in LDS anyway and keeps thread = particle.
+__device__ __forceinline__ int scatter_particle(const MpmK& K, int t) {
+  static_assert(NM_SC_T == 256, "the permutation is written for 256-particle workgroups");
+  return (K.smode == 1 && !NM_DBG_BIT(K, 64)) ? (((t & 15) << 4) | (t >> 4)) : t;
+}
+
 // ---------------------------------------------------------------- kernels
 __global__ void __launch_bounds__(256) k_clear(float4* __restrict__ gm, float4* __restrict__ gv, float4* __restrict__ gg,
                                                const int* __restrict__ list_prev, const int* __restrict__ count_prev,
@@ -594,8 +866,9 @@ __global__ void __launch_bounds__(NM_SC_T) k_p2g(MpmK K, int n, const float* __r
                                                  int* count, int epoch, const int* __restrict__ skip_hdr) {
   __shared__ ScatterLds L;
   if (skip_hdr && *skip_hdr >= 0) return;   // the grid of this substep was restored from a cache record
-  const int p = blockIdx.x * NM_SC_T + threadIdx.x;
-  const bool en = p < n && enabled[p] != 0;
+  const int lp = scatter_particle(K, threadIdx.x);
+  const int p = blockIdx.x * K.ppw + lp;
+  const bool en = lp < K.ppw && p < n && enabled[p] != 0;
   Stencil st;
   float pm = 0.f, mom[3] = {0.f, 0.f, 0.f};
   M3 A = m3_zero();
@@ -621,7 +894,7 @@ __global__ void __launch_bounds__(NM_SC_T) k_p2g(MpmK K, int n, const float* __r
                        w * (mom[1] + A.m[3] * d0 + A.m[4] * d1 + A.m[5] * d2),
                        w * (mom[2] + A.m[6] * d0 + A.m[7] * d1 + A.m[8] * d2), w * pm);
   };
-  wg_scatter<4>(K, en, st.b, gm, flags, list, count, epoch, L, contrib);
+  wg_scatter<4>(K, en, lp, st.b, gm, flags, list, count, epoch, L, contrib);
 }
 
 static inline size_t gridrec_list_bytes(int cap) { return ((size_t)cap * sizeof(int) + 255) & ~(size_t)255; }
@@ -808,7 +1081,8 @@ __global__ void __launch_bounds__(NM_SC_T) k_g2p_bwd(MpmK K, int n, const float*
                                                      float* __restrict__ gx, float* __restrict__ gF) {
   __shared__ ScatterLds L;
   const float kap = 4.0f * K.inv_dx * K.inv_dx;
-  const int p = blockIdx.x * NM_SC_T + threadIdx.x;
+  const int lp = scatter_particle(K, threadIdx.x);
+  const int p = lp < K.ppw ? blockIdx.x * K.ppw + lp : n;      // (a thread beyond the workgroup's share owns no particle)
   G2pBwdP q;
   const bool active = g2p_bwd_particle(K, n, p, clip, enabled, x, F, vnext, Cnext, gxn, gvn, gCn, gFn, q);
   // (1) per-particle outputs: gF and gx (direct + through weights/dpos, gathering the forward grid velocity)
@@ -861,7 +1135,7 @@ __global__ void __launch_bounds__(NM_SC_T) k_g2p_bwd(MpmK K, int n, const float*
     float c2_ = q.Ct.m[6] * d0 + q.Ct.m[7] * d1 + q.Ct.m[8] * d2;
     return make_float4(w * q.vt[0] + kw * c0_, w * q.vt[1] + kw * c1_, w * q.vt[2] + kw * c2_, 0.f);
   };
-  wg_scatter<3>(K, active, q.st.b, gg, nullptr, nullptr, nullptr, 0, L, contrib);
+  wg_scatter<3>(K, active, lp, q.st.b, gg, nullptr, nullptr, nullptr, 0, L, contrib);
 }
 
 // adjoint of p2g: gathers {mvbar, mbar}; writes gv, gC, gS and adds to gx.  These are the substep's returned gradients:
@@ -997,6 +1271,11 @@ extern "C" int nm_mpm_create(const nm_mpm_cfg* cfg, nm_mpm** out) {
   K.dbg = 0;
   K.maxpass = NM_WT_MAXPASS;
 #endif
+  {
+    const char* sm = getenv("NEUMA_SCATTER");
+    K.smode = (sm && (!strcmp(sm, "sort") || !strcmp(sm, "0"))) ? 0 : 1;
+  }
+  K.ppw = NM_SC_T;
   h->nblocks = K.nb * K.nb * K.nb;
   size_t nodes = (size_t)h->nblocks * 64;
   h->gm = h->gv = h->gg = nullptr;
@@ -1035,6 +1314,22 @@ extern "C" int nm_mpm_destroy(nm_mpm* h) {
   return NM_OK;
 }
 
+// Particles per workgroup of the scatter kernels.  fp64-atomic mode: the LDS atomic unit of a CU is what bounds them, so the
+// chunks are sized for a whole number of workgroups per CU (256 CUs) - 100 000 particles: 512 workgroups of 196 instead of 391
+// of 256, i.e. two on every CU instead of two on 135 CUs and one on the rest.  The sort path keeps 256.
+static int scatter_ppw(const nm_mpm* h, int n) {
+  if (h->k.smode != 1) return NM_SC_T;
+  const int per_cu = nm_div_up(n, 256 * NM_SC_T);
+  int ppw = nm_div_up(n, 256 * (per_cu > 0 ? per_cu : 1));
+  ppw = ((ppw + 3) / 4) * 4;
+  return ppw < 128 ? 128 : (ppw > NM_SC_T ? NM_SC_T : ppw);
+}
+static int scatter_grid(const nm_mpm* h, int n) { return nm_div_up(n, scatter_ppw(h, n)); }
+static MpmK scatter_k(const nm_mpm* h, int n) {
+  MpmK K = h->k;
+  K.ppw = scatter_ppw(h, n);
+  return K;
+}
 static const int kSweepGrid = 512;  // workgroups for the active-block sweeps (grid-stride over the list)
 
 // clear + p2g + grid_op (shared by forward, backward-recompute and forward_extra).
@@ -1079,7 +1374,7 @@ static int mpm_build_grid(nm_mpm* h, int n, const nm_statics* st, const nm_parti
     if (restore_verified) return NM_OK;   // the host has seen this record's header: it is valid, nothing to fall back to
   }
   if (n > 0) {
-    NM_LAUNCH(k_p2g, dim3(nm_div_up(n, NM_SC_T)), dim3(NM_SC_T), 0, s, h->k, n, st->vol, st->rho, st->enabled, cur->x,
+    NM_LAUNCH(k_p2g, dim3(scatter_grid(h, n)), dim3(NM_SC_T), 0, s, scatter_k(h, n), n, st->vol, st->rho, st->enabled, cur->x,
                        cur->v, cur->C, cur->stress, h->gm, h->flags, h->list[now], h->count + now, h->epoch, skip);
     NM_LAUNCH_CHECK();
   }
@@ -1236,7 +1531,7 @@ int nm_mpm_backward_cached_begin(nm_mpm* h, int32_t n, const nm_statics* st, con
     if (rc) return rc;
   }
   h->resident_rec = nullptr;      // (the adjoint scatter below dirties the grid's adjoint array: resident no more)
-  NM_LAUNCH(k_g2p_bwd, dim3(nm_div_up(n, NM_SC_T)), dim3(NM_SC_T), 0, s, h->k, n, st->clip_bound, st->enabled, cur->x, cur->F, next->v,
+  NM_LAUNCH(k_g2p_bwd, dim3(scatter_grid(h, n)), dim3(NM_SC_T), 0, s, scatter_k(h, n), n, st->clip_bound, st->enabled, cur->x, cur->F, next->v,
                      next->C, gnext->x, gnext->v, gnext->C, gnext->F, h->gv, h->gg, gcur->x, gcur->F);
   NM_LAUNCH_CHECK();
   return NM_OK;
@@ -1274,7 +1569,7 @@ int nm_mpm_forward_prepared_p2g(nm_mpm* h, int32_t n, const nm_statics* st, cons
   int rc = check_particles(st, cur, true);
   if (rc) return rc;
   const int now = h->cur;
-  NM_LAUNCH(k_p2g, dim3(nm_div_up(n, NM_SC_T)), dim3(NM_SC_T), 0, (hipStream_t)stream, h->k, n, st->vol, st->rho, st->enabled, cur->x,
+  NM_LAUNCH(k_p2g, dim3(scatter_grid(h, n)), dim3(NM_SC_T), 0, (hipStream_t)stream, scatter_k(h, n), n, st->vol, st->rho, st->enabled, cur->x,
                      cur->v, cur->C, cur->stress, h->gm, h->flags, h->list[now], h->count + now, h->epoch, (const int*)nullptr);
   NM_LAUNCH_CHECK();
   return NM_OK;
@@ -1365,7 +1660,7 @@ extern "C" int nm_mpm_p2g(nm_mpm* h, int32_t n, const nm_statics* st, const nm_p
                      h->count + now, h->count + next, h->flags, h->epoch);
   NM_LAUNCH_CHECK();
   if (n > 0) {   // a rank without particles still takes part in the exchange with an empty list
-    NM_LAUNCH(k_p2g, dim3(nm_div_up(n, NM_SC_T)), dim3(NM_SC_T), 0, s, h->k, n, st->vol, st->rho, st->enabled, cur->x,
+    NM_LAUNCH(k_p2g, dim3(scatter_grid(h, n)), dim3(NM_SC_T), 0, s, scatter_k(h, n), n, st->vol, st->rho, st->enabled, cur->x,
                        cur->v, cur->C, cur->stress, h->gm, h->flags, h->list[now], h->count + now, h->epoch, (const int*)nullptr);
     NM_LAUNCH_CHECK();
   }
@@ -1412,7 +1707,7 @@ extern "C" int nm_mpm_backward_begin(nm_mpm* h, int32_t n, const nm_statics* st,
   NM_REQUIRE(next && next->v && next->C, "next state (v, C) required");
   NM_REQUIRE(gnext && gnext->x && gnext->v && gnext->C && gnext->F, "null incoming gradients");
   NM_REQUIRE(gcur && gcur->x && gcur->v && gcur->C && gcur->F && gcur->stress, "null outgoing gradients");
-  NM_LAUNCH(k_g2p_bwd, dim3(nm_div_up(n, NM_SC_T)), dim3(NM_SC_T), 0, s, h->k, n, st->clip_bound, st->enabled, cur->x, cur->F,
+  NM_LAUNCH(k_g2p_bwd, dim3(scatter_grid(h, n)), dim3(NM_SC_T), 0, s, scatter_k(h, n), n, st->clip_bound, st->enabled, cur->x, cur->F,
                      next->v, next->C, gnext->x, gnext->v, gnext->C, gnext->F, h->gv, h->gg, gcur->x, gcur->F);
   NM_LAUNCH_CHECK();
   return NM_OK;

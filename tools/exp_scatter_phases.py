@@ -4,7 +4,10 @@ import numpy as np
 sys.path.insert(0, ".")
 src = "neuma_amd/csrc"
 out = "/tmp/libneuma_phases.so"
-subprocess.run(f"/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -DNM_PHASES -Iinclude -shared "
+if os.path.exists("tools/libneuma_phases.so"):      # prebuilt on the build host (make -C tools phases), shipped with the snapshot
+    out = os.path.abspath("tools/libneuma_phases.so")
+else:
+  subprocess.run(f"/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -DNM_PHASES -Iinclude -shared "
                f"{src}/nm_api.hip {src}/nm_mpm.hip {src}/nm_shard.hip {src}/nm_material.hip {src}/nm_bind.hip {src}/nm_bindbuild.hip {src}/nm_raster.hip {src}/nm_rollout.hip -o {out}",
                shell=True, check=True)
 os.environ["NEUMA_HIP_LIB"] = out
@@ -13,7 +16,7 @@ from neuma_amd import _lib, synth
 from neuma_amd.harness import SceneRuntime
 lib = _lib.lib()
 dev = torch.device("cuda", 0)
-rt = SceneRuntime(synth.make_scene(sys.argv[1] if len(sys.argv) > 1 else "metric", override=dict(K=1000)), dev)
+rt = SceneRuntime(synth.make_scene(sys.argv[1] if len(sys.argv) > 1 else "metric", override=dict(K=1000, **({"N": int(os.environ["NM_EXP_N"])} if os.environ.get("NM_EXP_N") else {}))), dev)
 ms = (C.c_int * 4)()
 if len(sys.argv) > 2 and sys.argv[2] == "bwd":      # the last wg_scatter launch is then k_g2p_bwd of substep 0
     for it in range(2):
@@ -34,7 +37,7 @@ buf = np.zeros(8 * 4096, dtype=np.int64)
 print("rc", fn(buf.ctypes.data, 8 * 4096))
 nwg = (rt.N + 255) // 256
 b = buf.reshape(4096, 8)[:nwg]
-names = ["bbox", "box select", "sort/scan", "contrib write", "cell sums", "9 pushes", "flush+mark", "passes"]
+names = ["bbox", "box select", "sort/scan | zero", "contrib write | atomics", "cell sums | addr+mark", "9 pushes", "flush(+mark)", "passes"]
 for i, nm in enumerate(names):
     print(f"{nm:14s} mean {b[:, i].mean():9.1f} median {np.median(b[:, i]):9.1f} max {b[:, i].max():9.0f}")
 print("total cycles mean", b[:, :7].sum(1).mean(), "max", b[:, :7].sum(1).max())

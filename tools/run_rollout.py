@@ -1,5 +1,5 @@
 """A few fused roll-outs (S substeps, forward + backward) of a workload and nothing else: the program rocprofv3 traces for the
-per-substep timeline (tools/timeline.py).  python tools/run_rollout.py [workload] [reps]"""
+per-substep timeline (tools/timeline.py).  python tools/run_rollout.py [workload] [reps] [particles]"""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -10,7 +10,8 @@ from neuma_amd.harness import SceneRuntime
 name = sys.argv[1] if len(sys.argv) > 1 else "metric"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 dev = torch.device("cuda", 0)
-rt = SceneRuntime(synth.make_scene(name), dev)
+npart = int(sys.argv[3]) if len(sys.argv) > 3 else None
+rt = SceneRuntime(synth.make_scene(name, override=dict(N=npart, K=1000) if npart else None), dev)
 g = torch.Generator().manual_seed(0)
 wx = torch.randn(rt.N, 3, generator=g).to(dev)
 wF = torch.randn(rt.N, 3, 3, generator=g).to(dev)
