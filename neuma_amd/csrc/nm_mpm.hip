@@ -868,24 +868,34 @@ __global__ void __launch_bounds__(NM_SC_T) k_p2g(MpmK K, int n, const float* __r
   if (skip_hdr && *skip_hdr >= 0) return;   // the grid of this substep was restored from a cache record
   const int lp = scatter_particle(K, threadIdx.x);
   const int p = blockIdx.x * K.ppw + lp;
-  const bool en = lp < K.ppw && p < n && enabled[p] != 0;
+  // every load of the particle is issued before the first one is waited for - `enabled` included: a branch on it in front of
+  // the others made two HBM round trips out of one (the kernel is a chain of latencies, not of bytes)
+  const bool mine = lp < K.ppw && p < n;
   Stencil st;
   float pm = 0.f, mom[3] = {0.f, 0.f, 0.f};
   M3 A = m3_zero();
-  if (en) {
-    make_stencil(K, x + 3 * p, st);
-    float vl = vol[p];
-    pm = vl * rho[p];
-    float ks = -K.dt * vl * 4.0f * K.inv_dx * K.inv_dx;  // mpm.py:357
-    M3 Sp = m3_load(S + 9 * p), Cp = m3_load(C + 9 * p);
+  bool en = false;
+  if (mine) {
+    const int e = enabled[p];
+    const float vl = vol[p], rh = rho[p];
+    const float xp[3] = {x[3 * p], x[3 * p + 1], x[3 * p + 2]};
+    const float vp[3] = {v[3 * p], v[3 * p + 1], v[3 * p + 2]};
+    const M3 Sp = m3_load(S + 9 * p), Cp = m3_load(C + 9 * p);
+    en = e != 0;
+    make_stencil(K, xp, st);
+    pm = vl * rh;
+    const float ks = -K.dt * vl * 4.0f * K.inv_dx * K.inv_dx;  // mpm.py:357
 #pragma unroll
     for (int i = 0; i < 9; ++i) A.m[i] = ks * Sp.m[i] + pm * Cp.m[i];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) mom[a] = pm * v[3 * p + a];
-  } else {
+    for (int a = 0; a < 3; ++a) mom[a] = pm * vp[a];
+  }
+  if (!en) {
     st.b[0] = st.b[1] = st.b[2] = 0;
+    pm = 0.f;
+    A = m3_zero();
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { st.f[a] = 0.f; st.w[a][0] = st.w[a][1] = st.w[a][2] = 0.f; }
+    for (int a = 0; a < 3; ++a) { mom[a] = 0.f; st.f[a] = 0.f; st.w[a][0] = st.w[a][1] = st.w[a][2] = 0.f; }
   }
   auto contrib = [&](int i, int j, int k) -> float4 {
     float d0 = ((float)i - st.f[0]) * K.dx, d1 = ((float)j - st.f[1]) * K.dx, d2 = ((float)k - st.f[2]) * K.dx;
@@ -1034,33 +1044,42 @@ __device__ __forceinline__ bool g2p_bwd_particle(const MpmK& K, int n, int p, co
                                                  const float* __restrict__ Cnext, const float* __restrict__ gxn,
                                                  const float* __restrict__ gvn, const float* __restrict__ gCn,
                                                  const float* __restrict__ gFn, G2pBwdP& q) {
-  const bool active = p < n && enabled[p] != 0;
+  // (all loads issued before the first is waited for, `enabled` included - see k_p2g)
+  bool active = false;
 #pragma unroll
   for (int a = 0; a < 3; ++a) { q.vt[a] = 0.f; q.xbar[a] = 0.f; }
   q.Ct = m3_zero();
   q.Fbar = m3_zero();
-  if (active) {
-    float xp[3] = {x[3 * p], x[3 * p + 1], x[3 * p + 2]};
-    make_stencil(K, xp, q.st);
-    float bnd = clip[p] * K.dx;
-    float lo = 0.0f + bnd, hi = 1.0f - bnd;
+  if (p < n) {
+    const int e = enabled[p];
+    const float xp[3] = {x[3 * p], x[3 * p + 1], x[3 * p + 2]};
+    const float vn[3] = {vnext[3 * p], vnext[3 * p + 1], vnext[3 * p + 2]};
+    const float gxv[3] = {gxn[3 * p], gxn[3 * p + 1], gxn[3 * p + 2]};
+    const float gvv[3] = {gvn[3 * p], gvn[3 * p + 1], gvn[3 * p + 2]};
+    const float bnd = clip[p] * K.dx;
+    const M3 Fp = m3_load(F + 9 * p), gFp = m3_load(gFn + 9 * p), Cn = m3_load(Cnext + 9 * p), gCp = m3_load(gCn + 9 * p);
+    active = e != 0;
+    if (active) {
+      make_stencil(K, xp, q.st);
+      const float lo = 0.0f + bnd, hi = 1.0f - bnd;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      float t = xp[a] + K.dt * vnext[3 * p + a];
-      float xe = (t >= lo && t <= hi) ? gxn[3 * p + a] : 0.f;  // clamp passes the gradient only inside
-      q.xbar[a] = xe;
-      q.vt[a] = gvn[3 * p + a] + K.dt * xe;
+      for (int a = 0; a < 3; ++a) {
+        float t = xp[a] + K.dt * vn[a];
+        float xe = (t >= lo && t <= hi) ? gxv[a] : 0.f;  // clamp passes the gradient only inside
+        q.xbar[a] = xe;
+        q.vt[a] = gvv[a] + K.dt * xe;
+      }
+      M3 T = Cn;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) T.m[i] *= K.dt;
+      T.m[0] += 1.f; T.m[4] += 1.f; T.m[8] += 1.f;
+      q.Fbar = m3_mul_tn(T, gFp);           // (I + dt C')^T Fbar'
+      M3 FF = m3_mul_nt(gFp, Fp);           // Fbar' F^T
+#pragma unroll
+      for (int i = 0; i < 9; ++i) q.Ct.m[i] = gCp.m[i] + K.dt * FF.m[i];
     }
-    M3 Fp = m3_load(F + 9 * p), gFp = m3_load(gFn + 9 * p), Cn = m3_load(Cnext + 9 * p), gCp = m3_load(gCn + 9 * p);
-    M3 T = Cn;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) T.m[i] *= K.dt;
-    T.m[0] += 1.f; T.m[4] += 1.f; T.m[8] += 1.f;
-    q.Fbar = m3_mul_tn(T, gFp);           // (I + dt C')^T Fbar'
-    M3 FF = m3_mul_nt(gFp, Fp);           // Fbar' F^T
-#pragma unroll
-    for (int i = 0; i < 9; ++i) q.Ct.m[i] = gCp.m[i] + K.dt * FF.m[i];
-  } else {
+  }
+  if (!active) {
     q.st.b[0] = q.st.b[1] = q.st.b[2] = 0;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
