@@ -94,7 +94,13 @@ __device__ __forceinline__ void g2p_particle(const MpmK& K, int p, const float* 
                                              const float* x, const float* v, const float* C, const float* F,
                                              const float4* __restrict__ gv, float* xn, float* vn, float* Cn, M3& Fo,
                                              const int* __restrict__ flags = nullptr, int epoch = 0, bool fresh = false) {
-  if (enabled[p] == 0) {
+  // (every load that does not depend on the stencil is issued before `enabled` is looked at: a wave of the constitutive kernels
+  //  is alone on its SIMD, and enabled -> x -> gathers -> F were four round trips in a row)
+  const int e_ = enabled[p];
+  float xp[3] = {x[3 * p], x[3 * p + 1], x[3 * p + 2]};
+  const float clip_p = clip[p];
+  const M3 Fp = m3_load(F + 9 * p);
+  if (e_ == 0) {
     if (fresh && xn != x) {
       Fo = m3_ident();
 #pragma unroll
@@ -102,11 +108,10 @@ __device__ __forceinline__ void g2p_particle(const MpmK& K, int p, const float* 
 #pragma unroll
       for (int a = 0; a < 9; ++a) Cn[9 * p + a] = 0.f;
     } else {
-      Fo = m3_load(F + 9 * p);     // (not stored by the callers)
+      Fo = Fp;     // (not stored by the callers)
     }
     return;
   }
-  float xp[3] = {x[3 * p], x[3 * p + 1], x[3 * p + 2]};
   Stencil st;
   make_stencil(K, xp, st);
   float nv[3] = {0.f, 0.f, 0.f};
@@ -147,13 +152,12 @@ __device__ __forceinline__ void g2p_particle(const MpmK& K, int p, const float* 
 #pragma unroll 1
     for (int i = 0; i < 3; ++i) slab(i);
   }
-  M3 Fp = m3_load(F + 9 * p);
   M3 T = nC;
 #pragma unroll
   for (int i = 0; i < 9; ++i) T.m[i] *= K.dt;
   T.m[0] += 1.f; T.m[4] += 1.f; T.m[8] += 1.f;
   Fo = m3_mul(T, Fp);  // mpm.py:489
-  float bnd = clip[p] * K.dx;
+  float bnd = clip_p * K.dx;
   float lo = 0.0f + bnd, hi = 1.0f - bnd;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {

@@ -796,11 +796,14 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
     // computation waited for all of it: +6 k cycles per round).  Tile ct + 1's record is requested during tile ct.
     f4 nx[ACT ? NM_ACT_SLOTS : 1];
     const f4* act_tile = ACT ? a.act + (size_t)(c0 >> 4) * NM_ACT_SLOTS * 64 + lane : nullptr;
-    const bool trial = fz.trial_C && valid && fz.enabled[p] != 0;
-    // roll-out: the forward pass fed the plasticity net I for a disabled particle (the fresh state of its next row, nm_grid.h)
-    M3 Fp = (valid && (trial || !fz.trial_C)) ? m3_load(F + 9 * p) : m3_ident();
+    // (F, dL/dout and C' are requested before `enabled` is looked at: behind a branch on it they were a second round trip)
+    const int en_p = (fz.trial_C && valid) ? fz.enabled[p] : 0;
+    M3 Fp = valid ? m3_load(F + 9 * p) : m3_ident();
     M3 go = valid ? m3_load(gout + 9 * p) : m3_zero();
-    M3 T = trial ? m3_load(fz.trial_C + 9 * p) : m3_zero();
+    M3 T = (fz.trial_C && valid) ? m3_load(fz.trial_C + 9 * p) : m3_zero();
+    const bool trial = en_p != 0;
+    // roll-out: the forward pass fed the plasticity net I for a disabled particle (the fresh state of its next row, nm_grid.h)
+    if (fz.trial_C && !trial) { Fp = m3_ident(); T = m3_zero(); }
     M3 R, U, V;
     float z[13], s[3];
     if (fz.svd_in) {        // (workgroup-uniform)

@@ -1011,7 +1011,7 @@ __global__ void __launch_bounds__(256) k_grid_op_bwd(MpmK K, const float4* __res
 }
 
 // mpm.py:432-498 (body: g2p_particle, nm_grid.h)
-__global__ void __launch_bounds__(256, 4) k_g2p(MpmK K, int n, const float* __restrict__ clip, const int* __restrict__ enabled,
+__global__ void __launch_bounds__(256, 3) k_g2p(MpmK K, int n, const float* __restrict__ clip, const int* __restrict__ enabled,
                                              const float* x, const float* v, const float* C, const float* F,
                                              const float4* __restrict__ gv, float* xn, float* vn, float* Cn, float* Fn, int fresh) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1022,7 +1022,7 @@ __global__ void __launch_bounds__(256, 4) k_g2p(MpmK K, int n, const float* __re
 }
 
 // g2p onto a passive particle set (MPMModel.forward_extra, mpm.py:260-277): in place, untouched blocks read as BC(g dt)
-__global__ void __launch_bounds__(256, 4) k_g2p_extra(MpmK K, int n, const float* __restrict__ clip, const int* __restrict__ enabled,
+__global__ void __launch_bounds__(256, 3) k_g2p_extra(MpmK K, int n, const float* __restrict__ clip, const int* __restrict__ enabled,
                                                    float* x, float* v, float* C, float* F, const float4* __restrict__ gv,
                                                    const int* __restrict__ flags, int epoch) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1168,23 +1168,27 @@ __global__ void __launch_bounds__(256, 2) k_p2g_bwd(MpmK K, int n, const float* 
                                                  float* __restrict__ gS) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
-  if (enabled[p] == 0) {
+  // (all of the particle's loads are issued before `enabled` is looked at: one HBM round trip instead of two)
+  const int e_ = enabled[p];
+  float xp[3] = {x[3 * p], x[3 * p + 1], x[3 * p + 2]};
+  const float vp[3] = {v[3 * p], v[3 * p + 1], v[3 * p + 2]};
+  float vl = vol[p];
+  const float rh = rho[p];
+  M3 Sp = m3_load(S + 9 * p), Cp = m3_load(C + 9 * p), A;
+  if (e_ == 0) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) { gvp[3 * p + a] = 0.f; gx[3 * p + a] = nm_finite_or_zero(gx[3 * p + a]); }
     m3_store(gC + 9 * p, m3_zero());
     m3_store(gS + 9 * p, m3_zero());
     return;
   }
-  float xp[3] = {x[3 * p], x[3 * p + 1], x[3 * p + 2]};
   Stencil st;
   make_stencil(K, xp, st);
-  float vl = vol[p];
-  float pm = vl * rho[p];
+  float pm = vl * rh;
   float ks = -K.dt * vl * 4.0f * K.inv_dx * K.inv_dx;
-  M3 Sp = m3_load(S + 9 * p), Cp = m3_load(C + 9 * p), A;
 #pragma unroll
   for (int i = 0; i < 9; ++i) A.m[i] = ks * Sp.m[i] + pm * Cp.m[i];
-  float mom[3] = {pm * v[3 * p], pm * v[3 * p + 1], pm * v[3 * p + 2]};
+  float mom[3] = {pm * vp[0], pm * vp[1], pm * vp[2]};
   float vb[3] = {0.f, 0.f, 0.f}, xb[3] = {0.f, 0.f, 0.f};
   M3 Ab = m3_zero();
 #pragma unroll 1

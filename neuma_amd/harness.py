@@ -60,6 +60,10 @@ def stripe_plan(num_views: int, tile_rows: int, world: int, rank: int, weights=N
             for b in (round(c / tile_rows) * tile_rows,):
                 if 0 < b < total and b >= cuts[-1] and abs(acc[b] - acc[c]) <= snap * share:
                     c = int(b)
+            # every rank keeps at least one unit (one tile row that holds more than a rank's share of the work makes
+            # consecutive cuts coincide otherwise) - as long as there are at least `world` units at all
+            if total >= world:
+                c = min(max(c, cuts[-1] + 1), total - (world - r))
             cuts.append(c)
         cuts.append(total)
     lo, hi = cuts[rank], cuts[rank + 1]
@@ -115,7 +119,7 @@ class _FrameTail(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         rt = ctx.rt
-        dx = torch.empty(rt.bindings.N, 3, dtype=torch.float32, device=ctx.grads[0].device)
+        dx = torch.empty(rt.bindings.N, 3, dtype=torch.float32, device=rt.device)
         _tail_backward(rt, ctx.recs, ctx.grads, ctx.streams, dx)
         ctx.recs = ctx.grads = ctx.keep = None
         return None, dx * g, None, None, None, None
@@ -174,7 +178,7 @@ def _tail_backward(rt, recs, grads, streams, dx_out):
     import torch.distributed as dist
     from . import _lib as L
     from .render import raster_backward_raw
-    lib, dev = L.lib(), grads[0].device
+    lib, dev = L.lib(), rt.device
     total = None
     outs = []
     if streams:
@@ -192,6 +196,8 @@ def _tail_backward(rt, recs, grads, streams, dx_out):
             outs.append(raster_backward_raw(rec, gimg)[0])
     for d in outs:
         total = d if total is None else total.add_(d)
+    if total is None:       # a rank without render jobs (more ranks than tile rows): zeros, and it still joins the all-reduce
+        total = torch.zeros(rt.bindings.K, 3, dtype=torch.float32, device=dev)
     if rt.world > 1 and dist.is_available() and dist.is_initialized() and dist.get_world_size(rt.group) > 1:
         dist.all_reduce(total, op=dist.ReduceOp.SUM, group=rt.group)        # the frame's one K x 3 all-reduce
     b = rt.bindings
@@ -637,6 +643,7 @@ class SceneRuntime(object):
 
     # ---- one frame, forward + backward
     def frame(self, weight: float = 1.0, backward: bool = True) -> FrameResult:
+        self._frame_no = getattr(self, "_frame_no", 0) + 1      # (the same on every rank: the stripe plans are keyed to it)
         if getattr(self, "_de_prev_key", None) != self.start[0].data_ptr():      # (constant between start-state changes)
             self._de_prev = ((self.start[0] - self.center) / self.size).detach()
             self._de_prev_key = self.start[0].data_ptr()
@@ -791,13 +798,21 @@ class SceneRuntime(object):
     def _stripe_weights(self):
         """V x tile_rows work estimates all ranks agree on (None until a frame has been measured).  A new plan is adopted only
         when the one in use would leave some rank with > 10 % more than its share: stripes that move every frame would make
-        the rasterizer re-size its lists for every new cut."""
+        the rasterizer re-size its lists for every new cut.
+        WHEN a measurement is adopted is a function of the frame counter alone - the table collected in frame n is looked at
+        in frame n + STRIPE_ADOPT_AFTER, after waiting for its copy (long finished by then) - never of how far this rank's
+        host happens to run ahead of its GPU: ranks that switched plans in different frames would render overlapping or
+        missing tile rows and pair a V x tile_rows all-reduce with another rank's K x 3 one."""
         pend = getattr(self, "_stripe_pending", None)
-        if pend is not None and pend[1].query():
+        if pend is not None and self._frame_no >= pend[2]:
+            pend[1].synchronize()
             self._stripe_pending = None
-            w = pend[0].numpy().copy()
+            flat = pend[0].numpy().copy()
+            w, invalid = flat[:-1].reshape(self.V, self.tile_rows), float(flat[-1])
             cur = getattr(self, "_stripe_w", None)
-            if cur is None:
+            if invalid > 0.0:          # some rank had no walk record for one of its stripes: keep the plan in use, everywhere
+                pass
+            elif cur is None:
                 self._stripe_w = w
             else:
                 parts = [sum(float(w[v, a:b].sum()) for (v, a, b) in stripe_plan(self.V, self.tile_rows, self.world, r, cur))
@@ -806,30 +821,35 @@ class SceneRuntime(object):
                     self._stripe_w = w
         return getattr(self, "_stripe_w", None)
 
+    STRIPE_ADOPT_AFTER = 2
+
     def _collect_stripe_work(self, jobs):
         """Per (view, tile row): the list entries its tiles walked in this frame's renders (the cameras' walk records; every rank
-        knows its own stripes), summed over the ranks by one small all-reduce and copied to the host asynchronously."""
+        knows its own stripes), summed over the ranks by one small all-reduce and copied to the host asynchronously.  Whether a
+        frame collects depends only on state every rank shares (no measurement in flight, i.e. the frame counter)."""
         import torch.distributed as dist
         if getattr(self, "_stripe_pending", None) is not None or os.environ.get("NEUMA_STRIPE_BALANCE", "1") == "0":
             return
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) < 2:
             return              # (a runtime that only pretends to be one of several ranks: tests)
-        W = torch.zeros(self.V, self.tile_rows, dtype=torch.float32, device=self.device)
+        W = torch.zeros(self.V * self.tile_rows + 1, dtype=torch.float32, device=self.device)
+        Wv = W[:-1].view(self.V, self.tile_rows)
         gx = (int(self.scene.cfg["W"]) + 15) // 16
         for vi, rows in jobs:
             stores = getattr(self.camera_at(vi), "_nm_walk_stores", None)
             walk = stores[1].get(self.device) if stores else None
             if walk is None:
-                return              # (hinting switched off: keep the uniform plan)
+                W[-1] = 1.0         # (hinting switched off / no record yet: this rank still joins the collective, the
+                continue            #  measurement is discarded on every rank)
             r0, r1 = rows if rows is not None else (0, self.tile_rows)
             t = walk.view(-1, gx)[r0:r1].float()
-            W[vi, r0:r1] = t.sum(1) + 32.0 * (t > 0).float().sum(1)
+            Wv[vi, r0:r1] = t.sum(1) + 32.0 * (t > 0).float().sum(1)
         dist.all_reduce(W, op=dist.ReduceOp.SUM, group=self.group)
-        host = torch.empty(self.V, self.tile_rows, dtype=torch.float32, pin_memory=True)
+        host = torch.empty(self.V * self.tile_rows + 1, dtype=torch.float32, pin_memory=True)
         host.copy_(W, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self._stripe_pending = (host, ev)
+        self._stripe_pending = (host, ev, self._frame_no + self.STRIPE_ADOPT_AFTER)
 
 
 class DiskRuntime(SceneRuntime):

@@ -158,3 +158,63 @@ def test_shard_cost_model_and_weighted_stripe_plan():
     uneven = np.zeros((2, 10)); uneven[0, :2] = 100.0; uneven[1] = 1.0                      # all the work in two rows
     a, b = stripe_plan(2, 10, 2, 0, uneven), stripe_plan(2, 10, 2, 1, uneven)
     assert a == [(0, 0, 1)] and b[0] == (0, 1, 10)
+
+
+def test_weighted_stripe_plan_never_leaves_a_rank_without_rows():
+    import numpy as np
+    """One tile row that holds more than a rank's share of the work used to make consecutive cuts coincide (ADVICE r3): every
+    rank keeps at least one unit while there are as many units as ranks, and the rows are still covered exactly once."""
+    from neuma_amd.harness import stripe_plan
+    for world in (2, 3, 4, 8):
+        for V, T in ((1, 8), (3, 8), (1, 16), (3, 68)):
+            w = np.full((V, T), 1e-3)
+            w[0, 3] = 1000.0                       # one row dominates
+            w[V - 1, T - 1] = 500.0
+            plans = [stripe_plan(V, T, world, r, w) for r in range(world)]
+            seen = np.zeros((V, T), dtype=int)
+            for pl in plans:
+                if V * T >= world:
+                    assert pl, (world, V, T, plans)
+                for (v, a, b) in pl:
+                    assert b > a
+                    seen[v, a:b] += 1
+            assert (seen == 1).all()
+    # more ranks than units: the extra ranks are empty, nothing is rendered twice
+    plans = [stripe_plan(1, 2, 4, r, np.array([[5.0, 1.0]])) for r in range(4)]
+    assert sorted(sum(plans, [])) == [(0, 0, 1), (0, 1, 2)]
+
+
+def test_stripe_measurements_are_adopted_by_frame_count_not_by_local_event_state():
+    """a rank whose copy of the work table happened to be finished used to switch plans a frame earlier than
+    a rank whose host ran further ahead.  Adoption now happens in frame n + STRIPE_ADOPT_AFTER on every rank, after WAITING for
+    the copy; a measurement flagged invalid by any rank is dropped everywhere."""
+    import types
+    import torch
+    from neuma_amd.harness import SceneRuntime
+
+    class Ev(object):
+        def __init__(self):
+            self.waited = 0
+
+        def query(self):
+            return True          # "finished" - must not matter
+
+        def synchronize(self):
+            self.waited += 1
+
+    V, T, world = 2, 4, 2
+    rt = types.SimpleNamespace(V=V, tile_rows=T, world=world, _frame_no=10)
+    flat = torch.arange(V * T + 1, dtype=torch.float32)
+    flat[-1] = 0.0
+    ev = Ev()
+    rt._stripe_pending = (flat, ev, 12)
+    assert SceneRuntime._stripe_weights(rt) is None and ev.waited == 0 and rt._stripe_pending is not None      # frame 10: too early
+    rt._frame_no = 11
+    assert SceneRuntime._stripe_weights(rt) is None and ev.waited == 0
+    rt._frame_no = 12
+    w = SceneRuntime._stripe_weights(rt)
+    assert ev.waited == 1 and rt._stripe_pending is None and w.shape == (V, T) and float(w[1, 3]) == 7.0
+    # an invalid measurement leaves the plan in use untouched
+    bad = torch.ones(V * T + 1)
+    rt._stripe_pending = (bad, Ev(), 12)
+    assert SceneRuntime._stripe_weights(rt) is w
