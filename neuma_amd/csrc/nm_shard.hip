@@ -256,8 +256,9 @@ extern "C" int nm_mpm_blocks_unpack(nm_mpm* h, int32_t which, const int32_t* sha
 // a superset: every rank lists the 27-neighbourhood (in blocks) of what it touches at the first substep - everything one of
 // its particles can reach while it moves less than a block (4 grid cells) - and a block is exchanged if it lies in the
 // neighbourhoods of two ranks.  Two ranks can only both touch a block that lies in both neighbourhoods, so the superset is
-// complete as long as no rank leaves its own neighbourhood; every substep checks exactly that (status bit 8), which makes a
-// wrong result impossible: the caller sees the bit and re-runs the frame.  A substep then costs one pack launch and one
+// complete as long as no rank leaves its own neighbourhood; every substep checks exactly that (status bit 8), so a wrong sum
+// never goes unnoticed: the frame driver waits for the roll-out's status word before it hands the frame's gradients to its
+// caller (GridExchange.check(wait="watched")) and raises - nothing re-runs the frame by itself.  A substep then costs one pack launch and one
 // all-reduce per direction; the unpack is part of k_grid_op / k_grid_op_bwd (slot[] lookup).
 __global__ void __launch_bounds__(256) k_dilate_export(const int* __restrict__ list, const int* __restrict__ count, int nb,
                                                        int* __restrict__ dil, int tag, int* __restrict__ out, int cap) {

@@ -704,9 +704,10 @@ class SceneRuntime(object):
                 reduce_param_grads(self.parameters(), self.group)             # each rank saw only its particles
         if self.shard_sim:
             # raises if a substep's block exchange was incomplete (capacity exceeded, a particle outside its rank's announced
-            # neighbourhood).  Fused roll-outs report through pinned status words: examined without stalling the frame loop
-            # (one frame late at worst; flush() / the per-operator path wait)
-            self.model.exchange.check(wait=not self.fused)
+            # neighbourhood) - BEFORE the caller can step an optimizer with this frame's gradients.  Fused roll-outs report
+            # through pinned status words copied out right behind the forward sweep: the host waits for that sweep here while the
+            # device still has the renders and the reverse sweep queued, so the frame loop does not drain
+            self.model.exchange.check(wait="watched" if self.fused else True)
         if self.world > 1:
             self._collect_stripe_work(jobs)
         return FrameResult(loss.detach(), x.detach(), F.detach())

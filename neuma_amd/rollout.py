@@ -188,21 +188,25 @@ class _Rollout(autograd.Function):
         exchange list is negotiated at the first substep) and one all-reduce per substep and direction."""
         dev = states.device
         st = statics.c_struct()
-        if ex.cap is None or ex.cap_shared is None:
-            # capacities from the blocks the start state touches (one p2g of the inputs with zero stress, two host reads)
+        def probe_start_state():
+            # one p2g of the inputs with zero stress: the handle then holds the blocks the start state touches
             r0 = states[0]
             r0[24 * n:].zero_()
             base = r0.data_ptr()
             cur = L.nm_particles(base, base + 12 * n, base + 24 * n, base + 60 * n, base + 96 * n)
             L.check(lib.nm_mpm_p2g(model.handle(), n, C.byref(st), C.byref(cur), L.stream_ptr(dev)), "nm_mpm_p2g")
+
+        probed = False
+        if ex.cap is None or ex.cap_shared is None:
+            probe_start_state()          # capacities from the blocks the start state touches (two host reads)
+            probed = True
             ex._ensure_sized()
         if ex.cap_dil is None or ex.cap_frame is None:
-            if ex._gathered is not None:          # (sized by an earlier substep: the probe needs a current grid)
-                r0 = states[0]
-                r0[24 * n:].zero_()
-                base = r0.data_ptr()
-                cur = L.nm_particles(base, base + 12 * n, base + 24 * n, base + 60 * n, base + 96 * n)
-                L.check(lib.nm_mpm_p2g(model.handle(), n, C.byref(st), C.byref(cur), L.stream_ptr(dev)), "nm_mpm_p2g")
+            # The frame-level capacities are sized from the grid the handle holds NOW: it must be the start state's, whatever
+            # the handle did before (model.shard(cap=..., cap_shared=...) with a fused roll-out as the first operation used to
+            # size them from an empty grid: 64 each, and every later frame overflowed - ADVICE r3)
+            if not probed:
+                probe_start_state()
             ex.size_frame_lists()
         cap_rec, cap, cap_shared = int(ex.cap), int(ex.cap_dil), int(ex.cap_frame)
         gcache = torch.empty(int(lib.nm_rollout_gridcache_bytes(S, cap_rec)), dtype=torch.uint8, device=dev)

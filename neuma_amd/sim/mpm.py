@@ -206,11 +206,13 @@ class MPMModel(Model):
         self._cache_blocks = None
         self.exchange = None        # set by shard(): this model steps one rank's share of the particles
 
-    def shard(self, group=None, cap=None, cap_shared=None):
+    def shard(self, group=None, cap=None, cap_shared=None, cap_dil=None, cap_frame=None):
         """Make this model one rank of a particle-sharded simulation (sim/shard.py): every forward / backward sums the
-        grid blocks it shares with other ranks over `group`.  Capacities default to 1.5x what the first substep needs."""
+        grid blocks it shares with other ranks over `group`.  Capacities default to 1.5x what the first substep needs
+        (cap, cap_shared: per-substep lists and grid cache records; cap_dil, cap_frame: the fused roll-out's frame-level
+        neighbourhood and exchange lists)."""
         from .shard import GridExchange
-        self.exchange = GridExchange(self, group, cap, cap_shared)
+        self.exchange = GridExchange(self, group, cap, cap_shared, cap_dil, cap_frame)
         return self.exchange
 
     def new_tape(self):

@@ -172,7 +172,8 @@ class ShardTape(object):
 class GridExchange(object):
     """Per-model state of the sharded substep: capacities, exchange buffers, the status word."""
 
-    def __init__(self, model, group=None, cap: Optional[int] = None, cap_shared: Optional[int] = None) -> None:
+    def __init__(self, model, group=None, cap: Optional[int] = None, cap_shared: Optional[int] = None,
+                 cap_dil: Optional[int] = None, cap_frame: Optional[int] = None) -> None:
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()):
             raise L.NeumaHipError("model.shard() needs an initialised torch.distributed process group")
@@ -180,8 +181,8 @@ class GridExchange(object):
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.cap = int(cap) if cap else None                    # blocks per rank list / grid cache record
         self.cap_shared = int(cap_shared) if cap_shared else None
-        self.cap_dil = None          # fused roll-out: blocks in a rank's announced neighbourhood ...
-        self.cap_frame = None        # ... and in the frame's exchange list (size_frame_lists)
+        self.cap_dil = int(cap_dil) if cap_dil else None        # fused roll-out: blocks in a rank's announced neighbourhood ...
+        self.cap_frame = int(cap_frame) if cap_frame else None  # ... and in the frame's exchange list (size_frame_lists)
         self.device = model.device
         self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.generation = 0
@@ -273,23 +274,45 @@ class GridExchange(object):
         ev.record()
         self._watched.append((host, ev))
 
-    def check(self, wait: bool = True) -> None:
+    def _raise(self, bits: int) -> None:
+        """An incomplete exchange: say which capacity it was, and forget the frame-level capacities so that the next fused
+        roll-out probes them again (they are sized from a start state; cap / cap_shared are the constructor's)."""
+        if bits & (1 | 2 | 8):
+            self.cap_dil = self.cap_frame = None
+        hint = []
+        if bits & 1:
+            hint.append(f"cap={self.cap} (per-rank block list; fused roll-outs: cap_dil, re-probed at the next roll-out)")
+        if bits & 2:
+            hint.append(f"cap_shared={self.cap_shared} (exchange list; fused roll-outs: cap_frame, re-probed at the next roll-out)")
+        if bits & 4:
+            hint.append(f"cap={self.cap} (blocks per grid cache record): model.shard(group, cap=...)")
+        if bits & 8:
+            hint.append("fewer substeps per roll-out node (the neighbourhood is negotiated once per node)")
+        raise L.NeumaHipError(f"sharded substep incomplete ({explain_status(bits)}); adjust: " + "; ".join(hint) +
+                              ".  The gradients of that roll-out are wrong: discard them (do not step the optimizer) and re-run it")
+
+    def check(self, wait=True) -> None:
         """Raise if any substep since the last check exceeded a capacity (one host read).  Called once per backward
         pass by MPMModel.backward and by the frame driver after the forward roll-out.
-        wait=False (frame driver, fused roll-outs only): look only at the status words of roll-outs that have FINISHED - no
-        host synchronisation in the frame loop, an incomplete exchange is reported one frame later (and at the latest by the
-        next check() with wait=True, which every consumer of final results calls)."""
-        if not wait:
+        wait=False: look only at the status words of fused roll-outs that have FINISHED - no host synchronisation.
+        wait="watched" (frame driver, fused roll-outs): wait for the status words of the fused roll-outs enqueued so far - each
+        is copied out right behind its FORWARD sweep, so the host waits for that sweep while the device still has the frame's
+        renders and reverse sweeps queued - and raise before the caller can use the frame's gradients; the per-operator status
+        word on the device is not read (no stream synchronisation).
+        wait=True: everything, including the device-side word of the per-operator substeps (synchronises the stream)."""
+        if wait is False or wait == "watched":
             bits, keep = 0, []
             for host, ev in self._watched:
+                if wait == "watched":
+                    ev.synchronize()
                 if ev.query():
                     bits |= int(host[0])
                 else:
                     keep.append((host, ev))
             self._watched = keep
             if bits:
-                raise L.NeumaHipError(f"sharded substep incomplete ({explain_status(bits)}): cap={self.cap}, cap_shared={self.cap_shared}, "
-                                      f"cap_dil={self.cap_dil}, cap_frame={self.cap_frame}; re-create the exchange with larger capacities")
+                self.generation += 1
+                self._raise(bits)
             return
         bits = int(self.status.item())
         for host, ev in self._watched:
@@ -299,8 +322,7 @@ class GridExchange(object):
         self.generation += 1
         if bits:
             self.status.zero_()
-            raise L.NeumaHipError(f"sharded substep incomplete ({explain_status(bits)}): cap={self.cap}, "
-                                  f"cap_shared={self.cap_shared}; re-create the exchange with larger capacities")
+            self._raise(bits)
 
     def defer_check(self) -> None:
         """The caller promises to call check() itself before it uses any result of the substeps recorded so far (the

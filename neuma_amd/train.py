@@ -101,6 +101,14 @@ def fetch_scheduler(config):
     raise ValueError(f"Scheduler {t} not supported.")
 
 
+def _flush(rt) -> None:
+    """Before an optimizer step: wait for the runtime's deferred status words (a render whose lists overflowed composited the
+    background only; a sharded substep whose exchange was incomplete summed too little) and raise instead of stepping on them."""
+    flush = getattr(rt, "flush", None)
+    if flush is not None:
+        flush()
+
+
 def rollout_decay_rate(cfg, epoch: int) -> float:
     """finetune.py:353-358"""
     lam = _get(cfg, "lambda_max_decay", 0)
@@ -244,6 +252,7 @@ def finetune_constitutive(rt, gt_frames: List[List[torch.Tensor]], cfg: Optional
         if not c["accumulate_grads_like_reference"]:
             e_opt.zero_grad(set_to_none=True); p_opt.zero_grad(set_to_none=True)
         loss_rgb.backward()
+        _flush(rt)      # deferred reports (rasterizer capacity, sharded exchanges) raise HERE, before the gradients are used
         e_gn = clip_grad_norm_(E.parameters(), max_norm=c["elasticity_grad_max_norm"], error_if_nonfinite=True)
         e_opt.step()
         p_gn = clip_grad_norm_(P.parameters(), max_norm=c["plasticity_grad_max_norm"], error_if_nonfinite=True)
@@ -312,6 +321,7 @@ def optimize_init_velocity(rt, gt_frames: List[List[torch.Tensor]], cfg: Optiona
         else:
             loss_reg = torch.zeros_like(loss_rgb)
         (loss_rgb + loss_reg).backward()
+        _flush(rt)      # (as in stage B: no optimizer step on a frame whose render overflowed)
         opt.step()
         losses.append(float(loss_rgb))
         if log is not None:

@@ -73,7 +73,7 @@ def gpu_substeps(rank, world, port, q, steps=3, cap_shared=None, cap=None):
         q.put({"rank": rank, "error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()})
 
 
-def gpu_frame(rank, world, port, q, name="tiny", fused=False):
+def gpu_frame(rank, world, port, q, name="tiny", fused=False, preset_caps=False):
     """One frame of the driver (materials + roll-out + bindings + render + loss, forward and backward): sharded
     simulation on `world` ranks vs the single-process frame.  fused: the sharded ranks run nm_rollout_forward_sharded /
     nm_rollout_backward_sharded (substep loop, phases and collectives inside the library) instead of the per-operator
@@ -88,6 +88,8 @@ def gpu_frame(rank, world, port, q, name="tiny", fused=False):
         ref.make_ground_truth()
         rt = SceneRuntime(scene, dev, rank=rank, world=world, shard_sim=True, fused=fused)
         assert rt.fused == fused and rt.model.exchange is not None
+        if preset_caps:      # the caller fixes cap / cap_shared and the FIRST operation is a fused roll-out: the frame-level
+            rt.model.shard(rt.group, cap=4096, cap_shared=4096)      # capacities must still be probed from the start state
         rt.gt = ref.gt
         for run in (ref, rt):
             # a material that is visibly wrong for the ground truth, so that the LoRA gradients are a signal and not the

@@ -62,11 +62,13 @@ def test_capacity_overflow_is_reported_on_every_rank():
         assert "error" in r and "cap_shared" in r["error"] and "NeumaHipError" in r["error"], r
 
 
-@pytest.mark.parametrize("world,fused", [(2, False), (2, True), (3, True)])
-def test_sharded_frame_matches_the_single_process_frame(world, fused):
+@pytest.mark.parametrize("world,fused,preset", [(2, False, False), (2, True, False), (3, True, False), (2, True, True)])
+def test_sharded_frame_matches_the_single_process_frame(world, fused, preset):
     """fused: the library-level sharded roll-out (nm_rollout_forward_sharded: the loop over substeps, phases and collectives
-    runs in C and calls back for the two collectives per substep); otherwise the phases are driven from Python."""
-    res = _run(shard_worker.gpu_frame, world, "tiny", fused)
+    runs in C and calls back for the two collectives per substep); otherwise the phases are driven from Python.
+    preset: model.shard(group, cap=..., cap_shared=...) given by the caller and a fused roll-out as the very first operation -
+    the frame-level capacities used to be sized from an empty grid then."""
+    res = _run(shard_worker.gpu_frame, world, "tiny", fused, preset)
     for r in res:
         assert abs(r["loss"] - r["ref_loss"]) <= 1e-3 * abs(r["ref_loss"]) + 1e-9, r
         assert r["x_err"] < 1e-5 and r["F_err"] < 1e-5, r
