@@ -58,3 +58,24 @@ def build_statics(model, vol, rho, clip, en, device):
     st = model.statics(vol.shape[0])
     st.vol.copy_(vol.float()); st.rho.copy_(rho.float()); st.clip_bound.copy_(clip.float()); st.enabled.copy_(en)
     return st
+
+
+def parity(case: str, name: str, measured: float, bound: float, noise=None) -> None:
+    """Record one measured parity error next to the bound it is held to (and, where a fixture carries the reference's own fp32
+    run, the distance of that run from its fp64 run): printed (`pytest -s`, or the captured log) and appended to
+    gpurun_out/parity_measured.jsonl, from which tools/parity_table.py makes DESIGN.md's table.  Then the assertion."""
+    import json
+    import os
+    from pathlib import Path
+    rec = {"case": case, "tensor": name, "measured": float(measured), "bound": float(bound)}
+    if noise is not None:
+        rec["reference_fp32_vs_fp64"] = float(noise)
+    print("PARITY " + json.dumps(rec))
+    out = Path(os.environ.get("NEUMA_PARITY_LOG", Path(__file__).resolve().parent.parent / "gpurun_out" / "parity_measured.jsonl"))
+    try:
+        out.parent.mkdir(parents=True, exist_ok=True)
+        with open(out, "a") as fh:
+            fh.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+    assert measured <= bound, rec

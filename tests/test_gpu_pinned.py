@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import mpm as om
-from gpu_util import dev, build_model, build_statics
+from gpu_util import dev, build_model, build_statics, parity
 
 pytestmark = pytest.mark.gpu
 
@@ -33,7 +33,14 @@ def test_substep_vs_reference_run(golden_dir, tag, reorder):
     outs = MPMDiffSim(model, reorder=reorder)(st, *ins)
     e = z["in_enabled"] != 0
     assert (~e).sum() > 0
-    for ref_key, tol in [("f64", dict(x=5e-7, v=2e-5, C=5e-5, F=5e-6)), ("f32", dict(x=5e-7, v=2e-5, C=1e-4, F=5e-6))]:
+    # Bounds (round 4: <= 3x what was measured on MI355X, DESIGN.md §2 has the table).  Against the reference's fp64 run the
+    # error IS the reference's own fp32-vs-fp64 distance on the same fixture (the GPU sees fp32-rounded inputs, like the
+    # reference's fp32 run does): SURVEY §8d's figure (x 2e-7, v 2e-6 rel, C 5e-6 rel, F 5e-7) or three times that distance,
+    # whichever is larger - on these fixtures the distance is v 7.5e-7..3.2e-6, C 2.1e-6..1.4e-5, F 2.7e-7..3.4e-7.  Against
+    # the reference's fp32 run only the summation order differs: measured x 6e-8, v 1.6e-7, C 3e-7, F 2.4e-7.
+    floor = {"f64": dict(x=2e-7, v=2e-6, C=5e-6, F=5e-7), "f32": dict(x=2e-7, v=5e-7, C=1e-6, F=7.5e-7)}
+    for ref_key in ("f64", "f32"):
+        tol = {}
         for name, got in zip(["x", "v", "C", "F"], outs):
             # every row: the rows of disabled particles are what the reference's MPMDiffSim returns for them - its fresh
             # model.state() untouched by g2p (mpm.py:84-93, 443-444; fixture rows `fresh_*`: zeros, F = identity), bit for bit
@@ -41,12 +48,16 @@ def test_substep_vs_reference_run(golden_dir, tag, reorder):
             ref[~e] = z[f"fresh_{name}"][~e]
             scale = max(1.0, np.abs(ref).max()) if name in ("v", "C") else 1.0
             g = got.detach().cpu().double().numpy()
-            assert np.abs(g - ref).max() <= tol[name] * scale, (ref_key, name)
+            noise = np.abs(z[f"f32_{name}"].astype(np.float64)[e] - z[f"f64_{name}"].astype(np.float64)[e]).max() / scale
+            tol[name] = max(floor[ref_key][name], 3.0 * noise) if ref_key == "f64" else floor[ref_key][name]
+            parity(f"substep {tag} vs reference {ref_key} run (reorder={reorder})", name, np.abs(g - ref).max() / scale, tol[name], noise)
             assert np.array_equal(g[~e], z[f"fresh_{name}"][~e].astype(np.float64)), (ref_key, name)
     if reorder is False:
         mv, m, gv = (a.cpu().double().numpy() for a in model.grid_export())
-        assert np.abs(m - z["f64_m"]).max() <= 2e-6 * z["f64_m"].max()
-        assert np.abs(mv - z["f64_mv"]).max() <= 5e-6 * np.abs(z["f64_mv"]).max()
+        gn = lambda k: np.abs(z["f32_" + k].astype(np.float64) - z["f64_" + k]).max() / np.abs(z["f64_" + k]).max()  # noqa: E731
+        parity(f"substep {tag} grid vs reference f64 run", "m (rel)", np.abs(m - z["f64_m"]).max() / z["f64_m"].max(), max(2e-7, 3 * gn("m")), gn("m"))
+        parity(f"substep {tag} grid vs reference f64 run", "mv (rel)", np.abs(mv - z["f64_mv"]).max() / np.abs(z["f64_mv"]).max(),
+               max(5e-7, 3 * gn("mv")), gn("mv"))
         w = z["f64_m"][..., None]
         assert np.abs(gv * m[..., None] - z["f64_gv"] * w).max() <= 2e-5 * np.abs(z["f64_gv"] * w).max()
         # untouched nodes: the reference's dense sweep leaves v = BC(g dt) there; the block-sparse grid must export the same
@@ -107,7 +118,9 @@ def test_inplace_forward_rollout_spans_and_extra_vs_reference_run(golden_dir):
     st_e.enabled.fill_(1); st_e.clip_bound.fill_(0.1)
     state_e = model.state(ne)
     state_e.particle.x.copy_(torch.from_numpy(z["xe0"]).float())
-    tol = {1: dict(x=5e-7, v=2e-5, C=2e-4, F=5e-6), 5: dict(x=2e-6, v=5e-5, C=1e-3, F=1e-5), 12: dict(x=5e-6, v=1e-4, C=2e-3, F=2e-5)}
+    # measured (MI355X, round 4) x | v | C | F: step 1 5.3e-8 | 2.4e-7 | 4.9e-6 | 6.0e-8, step 5 1.2e-7 | 3.1e-7 | 1.1e-6 | 3.1e-7,
+    # step 12 1.9e-7 | 4.1e-7 | 7.1e-7 | 5.6e-7 - at or below the reference's own fp32-vs-fp64 distance on this roll-out
+    tol = {1: dict(x=2e-7, v=1e-6, C=1.5e-5, F=2e-7), 5: dict(x=4e-7, v=1.5e-6, C=6e-6, F=1.1e-6), 12: dict(x=6e-7, v=2e-6, C=3e-6, F=2e-6)}
     for step in range(1, 13):
         F = state.particle.F
         state.from_torch(stress=_stress(F.double(), float(z["mu"]), float(z["lam"])).float())
@@ -122,7 +135,8 @@ def test_inplace_forward_rollout_spans_and_extra_vs_reference_run(golden_dir):
                 ref = z[f"f64_{name}_{step}"]
                 scale = max(1.0, np.abs(ref).max()) if name in ("v", "C") else 1.0
                 err = np.abs(got.cpu().double().numpy() - ref).max()
-                assert err <= tol[step][name] * scale, (step, name, err)
+                noise = np.abs(z[f"f32_{name}_{step}"].astype(np.float64) - ref).max() / scale if f"f32_{name}_{step}" in z else None
+                parity(f"in-place roll-out, step {step}, vs reference f64 run", name, err / scale, tol[step][name], noise)
 
 
 def test_svd_vs_reference_sign_rule(golden_dir):

@@ -45,7 +45,9 @@ def test_sharded_substeps_match_the_unsharded_model(world, cap):
         assert r["shared_blocks"] > 0, "the ranks' particle ranges must overlap in some grid blocks for this test to mean anything"
         assert r["status"] == 0
         # states: fp32 summation order differs (permuting particles moves x by 1e-7, C by 2e-5 over 50 steps)
-        assert r["out_abs"][0] < 5e-6 and r["out_abs"][1] < 5e-4 and r["out_abs"][2] < 5e-2 and r["out_abs"][3] < 5e-5, r
+        from gpu_util import parity
+        for nm, val, bnd in zip(("x", "v", "C", "F"), r["out_abs"], (2e-7, 1.5e-6, 7e-5, 1.2e-6)):      # measured 6e-8 | 4.5e-7 | 2.2e-5 | 3.6e-7
+            parity(f"3 sharded substeps, world={world}, cap={cap}, rank {r['rank']}, vs unsharded model (abs)", nm, val, bnd)
         assert max(r["out_err"]) < 1e-4, r
         assert max(r["grad_err"]) < 2e-3, r          # stated gradient tolerance, SURVEY.md §8d
 
