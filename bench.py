@@ -78,10 +78,13 @@ def algorithmic_bytes(kernel: str, rt, D) -> float:
     return table.get(base, 0.0)
 
 
-def kernel_rooflines(full, rt, D):
+def kernel_rooflines(full, rt, D, pmc=None, pmc_mfma=None):
     """Per-kernel roofline figures of the profiled frame (HIP-event durations of every launch; the views of the frame run
     on concurrent streams, so the render-side durations include some overlap): algorithmic bytes or flops per launch over
-    the mean launch duration, against 8 TB/s HBM or the 157.3 TFLOP/s f32-MFMA peak."""
+    the mean launch duration, against 8 TB/s HBM or the 157.3 TFLOP/s f32-MFMA peak.
+    pmc / pmc_mfma (profiles/pmc_traffic.json, metric workload on one GPU only): the counter-measured HBM bytes per launch of
+    the committed rocprofv3 passes next to the algorithmic figure (`traffic_over_algorithmic` well above 1 = wasted re-reads
+    or scratch traffic), and for the constitutive kernels the fraction by the flops they execute - all marked static."""
     by = {}
     for name, (calls, ms) in full.items():
         b = name.split("<")[0]
@@ -90,17 +93,41 @@ def kernel_rooflines(full, rt, D):
     out = []
     for b, (calls, ms) in sorted(by.items(), key=lambda kv: -kv[1][1])[:12]:
         avg_s = ms / calls / 1e3
+        ab = algorithmic_bytes(b, rt, D)
         if b in MATERIAL_FLOPS:
             fl = MATERIAL_FLOPS[b] * rt.n_local
-            out.append({"kernel": b, "bound": "mfma", "achieved": round(fl / avg_s / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s",
-                        "frac": round(fl / avg_s / 1e12 / 157.3, 4), "avg_us": round(avg_s * 1e6, 1), "launches": calls})
+            row = {"kernel": b, "bound": "mfma", "achieved": round(fl / avg_s / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s",
+                   "frac": round(fl / avg_s / 1e12 / 157.3, 4), "avg_us": round(avg_s * 1e6, 1), "launches": calls}
+            if pmc_mfma and b in pmc_mfma:
+                row["frac_of_executed_flops"] = round(pmc_mfma[b]["mfma_flops"] / avg_s / 1e12 / 157.3, 4)
+                row["mfma_busy_pct_of_simd_cycles_static"] = pmc_mfma[b]["mfma_busy_pct_of_simd_cycles"]
         else:
-            ab = algorithmic_bytes(b, rt, D)
             if ab <= 0:
                 continue
-            out.append({"kernel": b, "bound": "hbm", "achieved": round(ab / avg_s / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                        "frac": round(ab / avg_s / 1e9 / 8000.0, 4), "avg_us": round(avg_s * 1e6, 1), "launches": calls})
+            row = {"kernel": b, "bound": "hbm", "achieved": round(ab / avg_s / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                   "frac": round(ab / avg_s / 1e9 / 8000.0, 4), "avg_us": round(avg_s * 1e6, 1), "launches": calls}
+        if pmc and b in pmc and ab > 0:
+            row["traffic_static"] = pmc[b]["hbm_bytes_per_launch"]
+            row["algorithmic_bytes_per_launch"] = round(ab)
+            row["traffic_over_algorithmic"] = round(pmc[b]["hbm_bytes_per_launch"] / ab, 2)
+        out.append(row)
     return out
+
+
+def frame_roofline(full, rt, D, frame_s):
+    """The whole frame against both roofs (SURVEY §8d accounting): algorithmic HBM bytes and flops of every launch of one profiled
+    frame, summed, over the measured frame time."""
+    nbytes = flops = 0.0
+    for name, (calls, _ms) in full.items():
+        b = name.split("<")[0]
+        nbytes += algorithmic_bytes(b, rt, D) * calls
+        flops += MATERIAL_FLOPS.get(b, 0.0) * rt.n_local * calls
+    return {"algorithmic_GB_per_frame": round(nbytes / 1e9, 3), "algorithmic_GFLOP_per_frame": round(flops / 1e9, 2),
+            "achieved_TB_per_s": round(nbytes / frame_s / 1e12, 3), "frac_of_hbm_peak": round(nbytes / frame_s / 8e12, 4),
+            "achieved_TFLOP_per_s": round(flops / frame_s / 1e12, 2), "frac_of_f32_mfma_peak": round(flops / frame_s / 157.3e12, 4),
+            "note": "bytes = sum over the frame's launches of the per-kernel algorithmic figures of DESIGN.md section 4 (kernels without "
+                    "one - the small binning / planning launches - count 0); flops = the constitutive nets' (SURVEY 8d: forward 11 008, "
+                    "reverse 3 x that per particle and net); both over ms_per_step of the timed region"}
 
 
 def main():
@@ -424,7 +451,10 @@ def main():
             "timed_region_s": round(elapsed, 4),
             "view_stats": vstats,
             "shard_cost_model": cost if world > 1 else None,
-            "kernel_rooflines": kernel_rooflines(full, rt, Dacc),
+            "kernel_rooflines": kernel_rooflines(full, rt, Dacc, *((pmc, pmc_mfma) if (args.workload == "metric" and world == 1) else (None, None))),
+            "kernel_rooflines_static_note": "traffic_static / frac_of_executed_flops / mfma_busy_pct: copied from profiles/pmc_traffic.json "
+                                            "(rocprofv3 --pmc passes of this workload and build), not measured by this run",
+            "roofline_frame": frame_roofline(full, rt, Dacc, elapsed / args.steps),
             "frame_ms_gpu": {"median": round(per_frame[len(per_frame) // 2], 3), "p10": round(per_frame[len(per_frame) // 10], 3),
                              "p90": round(per_frame[(9 * len(per_frame)) // 10], 3)},
             "rates": rates,

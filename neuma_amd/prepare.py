@@ -15,6 +15,7 @@ from typing import Optional
 import torch
 
 from . import io as nio
+from .extras import mesh_sampling as mesh      # (outside the section-8 scope: see its header)
 from .binding import prepare_bindings
 
 
@@ -47,8 +48,8 @@ def prepare_simulation_data(save_dir: Path, kernels_path: Path, particles_path: 
         particles_downsample_factor = 1
     elif mesh_path is not None:
         print(f"Sampling particles inside mesh [{mesh_path}] ({mesh_sample_mode}, resolution {mesh_sample_resolution}) ...")
-        reader = nio.read_obj_mesh if Path(mesh_path).suffix.lower() == ".obj" else nio.read_ply_mesh
-        particles = nio.sample_mesh_points(*reader(mesh_path), mode=mesh_sample_mode, resolution=int(mesh_sample_resolution))
+        reader = mesh.read_obj_mesh if Path(mesh_path).suffix.lower() == ".obj" else mesh.read_ply_mesh
+        particles = mesh.sample_mesh_points(*reader(mesh_path), mode=mesh_sample_mode, resolution=int(mesh_sample_resolution))
         particles_downsample_factor = 1
     else:
         raise ValueError("Either 'particles_path' or 'mesh_path' must be provided.")

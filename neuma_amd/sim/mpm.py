@@ -428,13 +428,14 @@ class MPMInitData(object):
         if not pcd_path.is_file():
             raise FileNotFoundError(f"neither {cache} nor {pcd_path} exists")
         from .. import io as nio
+        from ..extras import mesh_sampling as mesh      # (outside the section-8 scope: see its header)
         p_x = nio.load_particles_ply(pcd_path)
         if sort is not None:
             p_x = p_x[np.argsort(-p_x[:, sort], kind="stable")]
         meshes = sorted(pcd_path.parent.glob("mesh.*"))
         if len(meshes) == 1:
-            reader = nio.read_obj_mesh if meshes[0].suffix.lower() == ".obj" else nio.read_ply_mesh
-            vol = abs(nio.mesh_volume(*reader(meshes[0]))) / p_x.shape[0]
+            reader = mesh.read_obj_mesh if meshes[0].suffix.lower() == ".obj" else mesh.read_ply_mesh
+            vol = abs(mesh.mesh_volume(*reader(meshes[0]))) / p_x.shape[0]
         else:
             from scipy.spatial import ConvexHull
             vol = float(ConvexHull(p_x).volume) / p_x.shape[0]

@@ -10,8 +10,10 @@ Follows /root/reference/modules/nclaw/sim/mpm.py:
                                autograd over the same forward, which is what the Warp tape computes.
   MPMModelBuilder.parse_cfg 507-528 (dx = 1/G, inv_dx = G)
 
-Parity unpinned: the reference executes these only through warp-lang (absent), and ships no
-tests/vectors.  Checked by invariants in tests/test_oracle_mpm.py.
+Parity PINNED (since round 2): the reference executes these only through warp-lang (absent here) and ships no vectors, so the
+fixtures were made by EXECUTING the reference's own kernel bodies under a scalar stand-in for the ~20 wp.* names they use
+(tests/golden/gen_mpm_golden.py + warp_scalar.py -> tests/golden/mpm_step_*.npz, mpm_grad_*.npz, mpm_rollout.npz, mpm_init.npz);
+tests/test_oracle_pinned.py holds this file to them (fp64 run: 1e-11), tests/test_oracle_mpm.py adds invariants.
 
 Semantic details kept from the reference:
   * base = int(x*inv_dx - 0.5) is a C cast (truncation toward zero), not floor  (mpm.py:336-339)

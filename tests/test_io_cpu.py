@@ -188,7 +188,7 @@ def test_init_and_lora_checkpoint_formats(tmp_path):
 
 
 def test_mesh_sampling_and_init_frame_steps(tmp_path):
-    """io.sample_mesh_points (prepare.py's particle_data.mesh_path) on a closed box, and the camera readers' `steps` entry with
+    """extras.mesh_sampling.sample_mesh_points (prepare.py's particle_data.mesh_path; outside the hot-path scope) on a closed box, and the camera readers' `steps` entry with
     an init_frame (dataset_readers.py:230, 329: only that frame)."""
     import json
     import numpy as np
@@ -196,10 +196,11 @@ def test_mesh_sampling_and_init_frame_steps(tmp_path):
     v = np.array([[0, 0, 0], [2, 0, 0], [2, 1, 0], [0, 1, 0], [0, 0, 1], [2, 0, 1], [2, 1, 1], [0, 1, 1]], float)
     t = np.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4], [2, 3, 7], [2, 7, 6], [1, 2, 6], [1, 6, 5], [3, 0, 4], [3, 4, 7]])
     p = np.array([[1.0, 0.5, 0.5], [2.5, 0.5, 0.5], [0.2, 0.9, 0.1], [1.0, 0.5, -0.1], [1.0, 0.5, 1.1]])
-    assert nio.points_in_mesh(p, v, t).tolist() == [True, False, True, False, False]
-    grid = nio.sample_mesh_points(v, t, "volumetric", 10)
+    from neuma_amd.extras import mesh_sampling as mesh
+    assert mesh.points_in_mesh(p, v, t).tolist() == [True, False, True, False, False]
+    grid = mesh.sample_mesh_points(v, t, "volumetric", 10)
     assert len(grid) == 10 * 5 * 5 and grid.min() > 0 and (grid.max(0) < [2, 1, 1]).all()
-    rnd = nio.sample_mesh_points(v, t, "uniform", 8)
+    rnd = mesh.sample_mesh_points(v, t, "uniform", 8)
     assert len(rnd) == 8 ** 3                                        # the box fills its own bounding box
     # NeuMA-Synthetic layout: frames 0, 3, 7 of one view; init_frame = 3 -> steps == [3] (what dataset.steps / evaluate rely on)
     root = tmp_path / "scene"
