@@ -201,8 +201,20 @@ def main():
     lib = _lib.lib()
 
     scene = synth.make_scene(args.workload)
-    from neuma_amd.sim.shard import shard_cost_model
-    cost = shard_cost_model(int(scene.x0.shape[0]), world, int(scene.cfg["S"]))
+    from neuma_amd.sim.shard import shard_cost_model, time_all_reduce_us
+    measured = None
+    if world > 1 and args.shard_sim == "auto" and os.environ.get("NEUMA_SHARD_CALIBRATE", "1") != "0":
+        # start-up calibration: the cost model's inputs measured on THIS box at THIS world size - a few roll-outs at N and at
+        # N / world particles, ~20 small all-reduces - instead of the one-GPU table and an assumed xGMI latency.  Every rank
+        # measures; the maxima are used everywhere, so that all ranks take the same decision
+        from neuma_amd.harness import measure_substep_us
+        n_all = int(scene.x0.shape[0])
+        vals = torch.tensor([measure_substep_us(args.workload, n_all, dev), measure_substep_us(args.workload, -(-n_all // world), dev),
+                             time_all_reduce_us(None, dev, count=1 << 16)], dtype=torch.float64, device=dev)
+        dist.all_reduce(vals, op=dist.ReduceOp.MAX)
+        measured = {"substep_us_full": round(float(vals[0]), 1), "substep_us_shard": round(float(vals[1]), 1),
+                    "allreduce_us": round(float(vals[2]), 1), "allreduce_floats": 1 << 16}
+    cost = shard_cost_model(int(scene.x0.shape[0]), world, int(scene.cfg["S"]), measured)
     shard_sim = world > 1 and (args.shard_sim == "on" or (args.shard_sim == "auto" and cost["shard"]))
     if world == 1 and args.shard_sim == "on" and os.environ.get("NEUMA_SHARD_FORCE") == "1":
         # overhead measurement on one GPU: a one-rank RCCL group, every collective of the sharded substep is issued
@@ -439,6 +451,7 @@ def main():
                        "start_state": rt.state_kind,
                        "touched_grid_nodes": int(rt.touched_nodes), "gaussian_tile_pairs_per_view": int(D)},
             "world": world, "backend": ({"nccl": "rccl"}.get(backend, backend) if world > 1 else None),
+            "shard_collectives": getattr(getattr(rt.model, "exchange", None), "link_backend", None),
             "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
             "devices": devices,
             "roofline": roof,

@@ -321,6 +321,27 @@ int nm_rollout_backward_sharded(nm_mpm* h, int32_t n, const nm_rollout_cfg* cfg,
                                 int32_t cap_shared, const void* shard_ws, size_t shard_ws_bytes, void* stream);
 int nm_rollout_shard_status(const void* shard_ws, int32_t* status_host, void* stream);
 
+/* Library-owned RCCL communicator (round 4; no reference counterpart - the reference is single-device).
+ * With it the sharded roll-out's collectives are issued by the library itself, on the caller's stream, from the loop in
+ * nm_rollout_forward_sharded / nm_rollout_backward_sharded: nm_rccl_comm fills an nm_comm whose two functions call
+ * ncclAllGather / ncclAllReduce.  librccl is looked up with dlopen on first use (the copy already in the process - torch's -
+ * first, then librccl.so.1): no link-time dependency; without RCCL these calls return NM_ERR_INVALID.
+ *   nm_rccl_unique_id   rank 0 fills 128 bytes (ncclUniqueId) and hands them to the other ranks by any means
+ *                       (neuma_amd/sim/shard.py: one torch.distributed broadcast)
+ *   nm_rccl_create      collective over the group: ncclCommInitRank on the current HIP device
+ *   nm_rccl_time_all_reduce  mean microseconds of `reps` in-place all-reduces of `count` floats (after `warm` untimed ones):
+ *                       the start-up calibration of the shard cost model; collective, synchronises the stream
+ *   nm_rccl_library     which librccl was bound ("" if none) */
+typedef struct nm_rccl nm_rccl;
+const char* nm_rccl_library(void);
+int nm_rccl_unique_id(void* id128);
+int nm_rccl_create(const void* id128, int32_t world, int32_t rank, nm_rccl** out);
+int nm_rccl_destroy(nm_rccl* c);
+int nm_rccl_comm(nm_rccl* c, nm_comm* out);
+int nm_rccl_all_reduce_sum_f32(nm_rccl* c, float* buf, int64_t count, void* stream);
+int nm_rccl_all_gather_i32(nm_rccl* c, const int32_t* send, int32_t* recv, int64_t count, void* stream);
+int nm_rccl_time_all_reduce(nm_rccl* c, float* buf, int64_t count, int32_t warm, int32_t reps, float* us_out, void* stream);
+
 /* ------------------------------------------------------------------ Particle-GS binding (modules/tune/utils.py) */
 
 /* torch.sparse.mm(bindings, X) of compute_bindings_xyz / compute_bindings_F, tune/utils.py:424-472,

@@ -136,6 +136,14 @@ SIGNATURES = {
                                               C.POINTER(nm_mlp), _P, _P, _P, _P, _P, _P, _P, _SZ, C.POINTER(nm_comm), _I32, _I32,
                                               _P, _SZ, _P]),
     "nm_rollout_shard_status": (C.c_int, [_P, _P, _P]),
+    "nm_rccl_library": (C.c_char_p, []),
+    "nm_rccl_unique_id": (C.c_int, [_P]),
+    "nm_rccl_create": (C.c_int, [_P, _I32, _I32, C.POINTER(_P)]),
+    "nm_rccl_destroy": (C.c_int, [_P]),
+    "nm_rccl_comm": (C.c_int, [_P, C.POINTER(nm_comm)]),
+    "nm_rccl_all_reduce_sum_f32": (C.c_int, [_P, _P, _I64, _P]),
+    "nm_rccl_all_gather_i32": (C.c_int, [_P, _P, _P, _I64, _P]),
+    "nm_rccl_time_all_reduce": (C.c_int, [_P, _P, _I64, _I32, _I32, C.POINTER(C.c_float), _P]),
 }
 
 _lib = None

@@ -132,7 +132,7 @@ struct ScatterLds {
   int cnt[NM_WT_CAP + 8];    // particles per stencil origin -> exclusive offsets (+ total as sentinel)
   short run_cell[NM_SC_T];   // compacted list of non-empty origin cells (<= one per particle)
   short ainv[3][NM_SC_T];    // axis compression: compressed coordinate -> grid coordinate
-  int red[32];               // block reductions / broadcasts
+  int red[80];               // block reductions / broadcasts; fp64 path: 8 group rows of 8 ints + the jump list
 };
 
 // Fallback for a workgroup whose 256 particles neither fit one tile nor compress into one (the particle order left the
@@ -279,10 +279,10 @@ __device__ __forceinline__ void wave_scatter(const MpmK& K, bool en, const int* 
 // per-offset barriers (6 workgroup barriers instead of ~45), and a node sum is rounded once (double -> float at the flush)
 // instead of once per addend.
 // A chunk of the particle list that the space-filling curve leaves and re-enters (bounding box > tile) is cut at the jumps -
-// consecutive particles more than two cells apart - into up to four GROUPS, each with a box of its own inside the same tile
+// consecutive particles more than two cells apart - into up to eight GROUPS, each with a box of its own inside the same tile
 // memory; what still does not fit (an arbitrary order) goes particle by particle to global atomics: any order is correct.
 #define NM_F64_PS (NM_WT_CAP + 8)      // plane stride in doubles (+8: the four channels of a node sit in different banks at the flush)
-#define NM_F64_MAXG 4
+#define NM_F64_MAXG 8
 template <int NCH, class ContribF>
 __device__ __forceinline__ void wg_scatter_f64(const MpmK& K, bool en, int lp, const int* base, float4* __restrict__ grid, int* flags,
                                                int* list, int* count, int epoch, ScatterLds& L, ContribF contrib) {
@@ -320,7 +320,7 @@ __device__ __forceinline__ void wg_scatter_f64(const MpmK& K, bool en, int lp, c
   if (total > NM_WT_CAP) {
     // ---- cut the chunk at its jumps
     int* pk = L.cnt;                 // stencil origins by position in the chunk, three arrays of NM_SC_T (-1: disabled)
-    int* jl = L.red + 24;            // [0] number of jumps, [1..3] their positions
+    int* jl = L.red + NM_F64_MAXG * 8;   // [0] number of jumps, [1..] their positions
 #pragma unroll
     for (int a = 0; a < 3; ++a) pk[a * NM_SC_T + lp] = en ? base[a] : -1;
     if (tid == 0) jl[0] = 0;
@@ -375,7 +375,7 @@ __device__ __forceinline__ void wg_scatter_f64(const MpmK& K, bool en, int lp, c
         if (q < tid) off += v_;
       }
       // (written after the loop's reads of THIS thread; other threads read only rows <= their own id, row tid is ours)
-      int* row = L.red;    // red[0..31]: 4 groups x (o[3], n[3], off, end)
+      int* row = L.red;    // red[0..63]: 8 groups x (o[3], n[3], off, end)
 #pragma unroll
       for (int a = 0; a < 3; ++a) { row[tid * 8 + a] = o_[a]; row[tid * 8 + 3 + a] = n_[a]; }
       row[tid * 8 + 6] = off;

@@ -125,10 +125,11 @@ class _FrameTail(torch.autograd.Function):
         return None, dx * g, None, None, None, None
 
 
-def _tail_forward(rt, p_cur, Fc, weight, jobs, streams):
+def _tail_forward(rt, p_cur, Fc, weight, jobs, streams, gt=None, step=None):
     """Binding + covariance push-forward (one launch), then per render job rasterizer forward + pixel loss (value and dL/dimage
-    in one pass).  p_cur (N, 3), Fc (N, 9): contiguous fp32, outside autograd.  Returns (loss, records, dL/dimage per job,
-    tensors the records point into)."""
+    in one pass).  p_cur (N, 3), Fc (N, 9): contiguous fp32, outside autograd.  gt / step: the ground-truth images and the
+    dataset step of THIS frame (multi-frame epochs; default: the runtime's single frame).  Returns (loss, records, dL/dimage
+    per job, tensors the records point into)."""
     from . import _lib as L
     from .render import get_rasterizer, raster_forward_raw
     lib, dev = L.lib(), p_cur.device
@@ -147,12 +148,13 @@ def _tail_forward(rt, p_cur, Fc, weight, jobs, streams):
     recs, grads, parts = [], [], []
 
     def job(vi, rows, part):
-        rast = get_rasterizer(rt.camera_at(vi), rt.gaussians.active_sh_degree, False, rt.background, tile_rows=rows)
+        rast = get_rasterizer(rt.camera_at(vi) if step is None else rt.camera_at(vi, step), rt.gaussians.active_sh_degree, False,
+                              rt.background, tile_rows=rows)
         img, _, rec = raster_forward_raw(rast._cam, means3D, sh, cp, rt._opacity, cov)
         h, w = int(img.shape[-2]), int(img.shape[-1])
         r0, r1 = (0, 0) if rows is None else (rows[0] * 16, min(h, rows[1] * 16))
         gimg = torch.empty_like(img)
-        L.check(lib.nm_pixel_loss(kind, float(weight), h, w, r0, r1, L.ptr(img), L.ptr(rt.gt[vi]), L.ptr(part), L.ptr(gimg),
+        L.check(lib.nm_pixel_loss(kind, float(weight), h, w, r0, r1, L.ptr(img), L.ptr((rt.gt if gt is None else gt)[vi]), L.ptr(part), L.ptr(gimg),
                                   L.stream_ptr(dev)), "nm_pixel_loss")
         recs.append(rec); grads.append(gimg); parts.append(part)
 
@@ -369,6 +371,217 @@ def _frame_backward(rt, fs, g=None):
     return [v.view(sh) for v, sh in zip(gba.split(sizes), shapes)]
 
 
+class _EpochState(object):
+    """What the forward half of a native multi-frame epoch keeps for its reverse sweep."""
+    __slots__ = ("frames", "states", "eff", "n", "S", "adj", "side", "loss_parts", "peak_note")
+
+
+def _epoch_forward(rt, gt_frames, weights, views=None, frame_steps=None, start=None, overlap: bool = True):
+    """Forward half of a whole BPTT epoch of a one-GPU runtime, outside autograd (finetune.py:331-392): F frames of S substeps,
+    the state flowing from frame to frame, and per frame binding against the DETACHED previous frame (de_x_prev, g_prev:
+    finetune.py:392-393) + V renders + decayed pixel loss.  The counterpart, for the reference's real unit of work, of
+    _frame_forward: the same library calls per frame (nm_rollout_forward on consecutive records of ONE checkpoint buffer - frame
+    f's record 0 IS frame f-1's last record, nothing is copied -, nm_bind_frame, rasterizer + loss), no autograd nodes, no
+    engine thread.  overlap: frame f's binding / renders / loss run on a second HIP stream while frame f+1 simulates.
+    weights[f]: the frame's loss weight (decay_rate ** ((f) // decay_steps)), None = the frame is excluded (exclude_steps:
+    simulated, not rendered, and - as in the reference - it does not become the next frame's de_x_prev / g_prev).
+    Returns (loss, _EpochState)."""
+    import ctypes as C
+    from . import _lib as L
+    from . import rollout as R
+    lib, dev = L.lib(), rt.device
+    sim = rt.sim_fused
+    n, S, nf = rt.n_local, int(sim.substeps), len(weights)
+    main = torch.cuda.current_stream(dev)
+    stream = L.stream_ptr(dev)
+    _, st, jf, _jb, woff, _goff, _sizes, _shapes, _gtot, nw = _frame_static(rt)
+    eff = torch.empty(2 * nw, dtype=torch.float32, device=dev)
+    base = eff.data_ptr()
+    for i in range(6):
+        jf[i].o0 = base + 4 * woff[i]
+    L.check(lib.nm_lora_merge_layers(6, jf, stream), "nm_lora_merge_layers")
+    states = torch.empty(nf * S + 1, 33 * n, dtype=torch.float32, device=dev)
+    start = (rt.x0, rt.v0, rt.C0, rt.F0) if start is None else start
+    torch.cat([t.detach().float().reshape(-1) for t in start], out=states[0][:24 * n])
+    if sim._cache_blocks is None:      # size the grid cache from what the scene touches (one throw-away roll-out, one host sync)
+        with torch.no_grad():
+            rt.rollout(*start)
+    cache_blocks = int(sim.grid_cache_blocks())
+    ws_bytes = int(lib.nm_rollout_workspace(n, S))
+    gc_bytes = int(lib.nm_rollout_gridcache_bytes(S, cache_blocks)) if cache_blocks > 0 else 0
+    svd_bytes, act_bytes = int(lib.nm_rollout_svdcache_bytes(n, S)), int(lib.nm_rollout_actcache_bytes(n, S))
+    ws = rt._scratch("ws", ws_bytes)
+    budget = R._ACT_CACHE_GB * (1 << 30)
+    adj = L.SVD_ADJOINT[sim.svd_adjoint]
+    w0, w1 = R._WSZ[0], R._WSZ[0] + R._WSZ[1]
+    mle = L.nm_mlp(base, base + 4 * w0, base + 4 * w1)
+    pb = base + 4 * nw
+    mlp = L.nm_mlp(pb, pb + 4 * w0, pb + 4 * w1)
+    views = list(range(rt.V)) if views is None else list(views)
+    jobs = [(vi, None) for vi in views]
+    streams = rt._frame_streams(jobs) if len(jobs) > 1 else None
+    side = None
+    if overlap:
+        side = getattr(rt, "_render_stream", None)
+        if side is None:
+            side = rt._render_stream = torch.cuda.Stream(device=dev)
+    unit = rt._unit_frame()
+    de_prev = start[0].detach().float().contiguous() if unit else ((start[0] - rt.center) / rt.size).detach().float().contiguous()
+    g_prev = rt.gaussians.get_xyz.detach().float().contiguous()
+    rt._cov6 = rt._cov.detach().float().reshape(-1, 6).contiguous()
+    rt._tail_key = None                 # (the single-frame constants are rebuilt by the next frame())
+    es = _EpochState()
+    es.frames, es.loss_parts = [], []
+    cached = recomputed = 0
+    rec_bytes = 33 * n * 4
+    for f in range(nf):
+        gcache = torch.empty(gc_bytes, dtype=torch.uint8, device=dev) if gc_bytes > 0 else None
+        svdc = actc = None
+        if R._SVD_CACHE and R._ACT_LIVE[0] + svd_bytes <= budget:
+            svdc = R._Lease(svd_bytes, dev, True)
+        if R._ACT_CACHE != '0' and (R._ACT_CACHE == '1' or R._ACT_LIVE[0] + act_bytes <= budget):
+            actc = R._Lease(act_bytes, dev, True)
+        cached += actc is not None
+        recomputed += actc is None
+        cfg = L.nm_rollout_cfg(S, float(sim.plasticity.alpha), cache_blocks if gcache is not None else 0, 0, adj,
+                               svdc.t.data_ptr() if svdc is not None else None, actc.t.data_ptr() if actc is not None else None)
+        sptr = states.data_ptr() + f * S * rec_bytes
+        gptr = gcache.data_ptr() if gcache is not None else None
+        L.check(lib.nm_rollout_forward(rt.model.handle(), n, C.byref(cfg), C.byref(st), C.byref(mle), C.byref(mlp), sptr, gptr,
+                                       ws.data_ptr(), ws_bytes, stream), "nm_rollout_forward")
+        status = ev = None
+        if gcache is not None and R._CACHE_STATUS:
+            status, ev = torch.empty(S, dtype=torch.int32, pin_memory=True), torch.cuda.Event()
+            L.check(lib.nm_rollout_cache_status(gptr, C.byref(cfg), C.c_void_p(status.data_ptr()), stream), "nm_rollout_cache_status")
+            ev.record()
+        fr = {"gcache": gcache, "svdc": svdc, "actc": actc, "status": status, "ev": ev, "cache_blocks": cache_blocks if gcache is not None else 0,
+              "tail": None}
+        es.frames.append(fr)
+        if weights[f] is None:
+            continue
+        last = states[(f + 1) * S]
+        x, Fl = last[:3 * n].view(n, 3), last[15 * n:24 * n].view(n, 9)
+        if side is not None:
+            side.wait_stream(main)
+        with torch.cuda.stream(side) if side is not None else _NullCtx():
+            p_cur = x if unit else ((x - rt.center) / rt.size).contiguous()
+            rt._de_x_prev, rt._g_prev = de_prev, g_prev
+            loss_f, recs, grads, keep = _tail_forward(rt, p_cur, Fl, float(weights[f]), jobs, streams,
+                                                      gt={vi: gt_frames[f][i] for i, vi in enumerate(views)},      # (gt_frames[f][i] belongs to views[i])
+                                                      step=None if frame_steps is None else frame_steps[f])
+            es.loss_parts.append(loss_f)
+            fr["tail"] = (recs, grads, keep, p_cur)
+            de_prev, g_prev = p_cur, keep[0]          # (detached by construction: nothing here is in a graph)
+    if side is not None:
+        main.wait_stream(side)
+    loss = torch.stack(es.loss_parts).sum() if es.loss_parts else torch.zeros((), dtype=torch.float32, device=dev)
+    es.states, es.eff, es.n, es.S, es.adj, es.side = states, eff, n, S, adj, side
+    es.peak_note = {"frames_with_activation_cache": int(cached), "frames_recomputing": int(recomputed),
+                    "activation_cache_budget_GB": float(R._ACT_CACHE_GB)}
+    es.frames[0]["streams"] = streams
+    return loss, es
+
+
+class _NullCtx(object):
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+def _epoch_backward(rt, es):
+    """Reverse sweep of _epoch_forward (the one loss.backward() of finetune.py:413-414): frame by frame from the last, the
+    rasterizer adjoints + B^T of frame f (on the second stream, under the roll-out adjoint of frame f + 1), dL/dx_f added to what
+    flows back from frame f + 1, nm_rollout_backward, the LoRA weight gradients summed over the frames, one
+    nm_lora_merge_layers_bwd at the end.  Returns the twelve gradients (B, A per layer)."""
+    import ctypes as C
+    from . import _lib as L
+    from . import rollout as R
+    lib, dev = L.lib(), rt.device
+    n, S, nf = es.n, es.S, len(es.frames)
+    sim = rt.sim_fused
+    _, st, _jf, jb, woff, goff, sizes, shapes, gtot, nw = _frame_static(rt)
+    main = torch.cuda.current_stream(dev)
+    stream = L.stream_ptr(dev)
+    side = es.side
+    streams = es.frames[0].get("streams")
+    base = es.eff.data_ptr()
+    w0, w1 = R._WSZ[0], R._WSZ[0] + R._WSZ[1]
+    mle = L.nm_mlp(base, base + 4 * w0, base + 4 * w1)
+    pb = base + 4 * nw
+    mlp = L.nm_mlp(pb, pb + 4 * w0, pb + 4 * w1)
+    ws_bytes = int(lib.nm_rollout_workspace(n, S))
+    ws = rt._scratch("ws", ws_bytes)
+    bufs = [torch.zeros(24 * n, dtype=torch.float32, device=dev), torch.empty(24 * n, dtype=torch.float32, device=dev)]
+    gw_tot = torch.zeros(2 * nw, dtype=torch.float32, device=dev)
+    gw = torch.empty(2 * nw, dtype=torch.float32, device=dev)
+    rec_bytes = 33 * n * 4
+    unit = rt._unit_frame()
+
+    def tail_bwd(f):
+        """dL/dx of frame f's renders (None: the frame was excluded), enqueued on the second stream."""
+        fr = es.frames[f]
+        if fr["tail"] is None:
+            return None
+        recs, grads, keep, _p = fr["tail"]
+        if side is not None:
+            side.wait_stream(main)
+        with torch.cuda.stream(side) if side is not None else _NullCtx():
+            dx = torch.empty(n, 3, dtype=torch.float32, device=dev)
+            _tail_backward(rt, recs, grads, streams, dx)
+            if not unit:
+                dx.div_(rt.size)
+            ev = torch.cuda.Event()
+            ev.record()
+        fr["tail"] = None
+        return dx, ev
+
+    pending = tail_bwd(nf - 1)
+    cur = 0
+    for f in range(nf - 1, -1, -1):
+        fr = es.frames[f]
+        glast, gfirst = bufs[cur], bufs[cur ^ 1]
+        nxt = tail_bwd(f - 1) if f > 0 else None        # (runs under this frame's roll-out adjoint)
+        if pending is not None:
+            dx, ev = pending
+            main.wait_event(ev)
+            glast[:3 * n].add_(dx.view(-1))
+            dx.record_stream(main)
+        verified = 0
+        if fr["gcache"] is not None and fr["ev"] is not None:
+            if R._CACHE_WAIT and not fr["ev"].query():
+                fr["ev"].synchronize()
+            if fr["ev"].query():
+                verified = int(min(fr["status"].tolist()) >= 0)
+        svdc, actc = fr["svdc"], fr["actc"]
+        cfg = L.nm_rollout_cfg(S, float(sim.plasticity.alpha), fr["cache_blocks"], verified, es.adj,
+                               svdc.t.data_ptr() if svdc is not None else None, actc.t.data_ptr() if actc is not None else None, 0)
+        gbase = gw.data_ptr()
+        L.check(lib.nm_rollout_backward(rt.model.handle(), n, C.byref(cfg), C.byref(st), C.byref(mle), C.byref(mlp),
+                                        es.states.data_ptr() + f * S * rec_bytes,
+                                        fr["gcache"].data_ptr() if fr["gcache"] is not None else None, glast.data_ptr(), gfirst.data_ptr(),
+                                        gbase, gbase + 4 * nw, ws.data_ptr(), ws_bytes, stream), "nm_rollout_backward")
+        for lease in (svdc, actc):
+            if lease is not None:
+                lease.release()
+        fr["gcache"] = fr["svdc"] = fr["actc"] = None
+        torch.nan_to_num_(gfirst, 0.0, 0.0, 0.0)       # interface.py:65-74 at the boundary between two frames' roll-outs
+        gw_tot.add_(gw)
+        pending = nxt
+        cur ^= 1
+    gba = torch.empty(gtot, dtype=torch.float32, device=dev)
+    ob, gbase = gba.data_ptr(), gw_tot.data_ptr()
+    for i in range(6):
+        j = jb[i]
+        j.W = gbase + 4 * woff[i]
+        j.o0 = ob + 4 * goff[i]
+        j.o1 = ob + 4 * (goff[i] + sizes[2 * i])
+    L.check(lib.nm_lora_merge_layers_bwd(6, jb, stream), "nm_lora_merge_layers_bwd")
+    es.frames, es.states = [], None
+    return [v.view(sh) for v, sh in zip(gba.split(sizes), shapes)]
+
+
 class _Frame(torch.autograd.Function):
     """The whole frame of a one-GPU runtime as ONE autograd node over the LoRA factors (_frame_forward / _frame_backward): the
     same library calls, kernels and results as the composition LoRA merge -> _Rollout -> _FrameTail that it replaces; what goes
@@ -389,6 +602,31 @@ class _Frame(torch.autograd.Function):
         grads = _frame_backward(ctx.rt, ctx.fs, g)
         ctx.fs = None
         return (None, None, None, None) + tuple(grads)
+
+
+def measure_substep_us(workload: str, num_particles: int, device, reps: int = 5) -> float:
+    """Microseconds per substep (forward + backward) of the fused roll-out of `workload` scaled to `num_particles`, measured on
+    this GPU: one input of sim.shard.shard_cost_model at start-up (bench.py --shard-sim auto) - what the one-GPU table
+    SUBSTEP_US used to stand for."""
+    import time
+    scene = synth.make_scene(workload, override=dict(N=int(num_particles), K=1000))
+    rt = SceneRuntime(scene, device)
+    params = rt.parameters()
+
+    def once():
+        for p in params:
+            p.grad = None
+        o = rt.rollout(*rt.start)
+        (o[0].sum() + o[3].sum()).backward()
+
+    for _ in range(3):
+        once()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        once()
+    torch.cuda.synchronize(device)
+    return 1e6 * (time.perf_counter() - t0) / reps / rt.S
 
 
 def make_material_cfg(alpha=1e-3):
@@ -711,6 +949,27 @@ class SceneRuntime(object):
         if self.world > 1:
             self._collect_stripe_work(jobs)
         return FrameResult(loss.detach(), x.detach(), F.detach())
+
+    def epoch(self, gt_frames, weights, views=None, frame_steps=None, overlap: bool = True, backward: bool = True):
+        """One BPTT epoch natively (finetune.py:331-414): len(weights) frames of S substeps from (x0, v0, C0, F0), per frame binding
+        + renders of `views` + weights[f] * pixel loss against gt_frames[f][i] (None: frame excluded), then the whole reverse
+        sweep; the LoRA gradients are ADDED to .grad like loss.backward() would.  Two plain calls (_epoch_forward /
+        _epoch_backward), no autograd graph: what train.video_loss + loss.backward() compute through one node per frame.
+        Returns the (detached) loss.  Needs the configuration frame()'s two-call path needs (_lean_ok)."""
+        if not self._lean_ok():
+            raise RuntimeError("the native epoch needs a one-GPU runtime with LoRA on all six layers as the only trainable tensors "
+                               "(SceneRuntime._lean_ok); use train.video_loss otherwise")
+        ba = [t for l in self._lora_layers for t in (l.lora_B, l.lora_A)]
+        with torch.no_grad():
+            loss, es = _epoch_forward(self, gt_frames, weights, views, frame_steps, None, overlap)
+            self.last_epoch_note = es.peak_note
+            if backward:
+                for p, gr in zip(ba, _epoch_backward(self, es)):
+                    if p.grad is None:
+                        p.grad = gr
+                    else:
+                        p.grad.add_(gr)
+        return loss
 
     @property
     def _lean_jobs(self):

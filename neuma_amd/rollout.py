@@ -104,8 +104,21 @@ class _ShardLink(object):
                 self.error = e
                 return 1
 
-        self._cbs = (L.COMM_ALL_GATHER(all_gather), L.COMM_ALL_REDUCE(all_reduce))      # keep the thunks alive
-        self.comm = L.nm_comm(exchange.world, exchange.rank, self._cbs[0], self._cbs[1], None)
+        rccl = exchange.library_comm() if hasattr(exchange, "library_comm") else None
+        if rccl is not None:
+            # the library's own communicator: ncclAllGather / ncclAllReduce issued from the C loop, no Python in between
+            self._cbs = None
+            self.comm = L.nm_comm()
+            L.check(L.lib().nm_rccl_comm(rccl, C.byref(self.comm)), "nm_rccl_comm")
+            self.backend = "rccl (library-owned communicator)"
+        else:
+            self._cbs = (L.COMM_ALL_GATHER(all_gather), L.COMM_ALL_REDUCE(all_reduce))      # keep the thunks alive
+            self.comm = L.nm_comm(exchange.world, exchange.rank, self._cbs[0], self._cbs[1], None)
+            self.backend = "torch.distributed callbacks"
+        try:
+            exchange.link_backend = self.backend
+        except AttributeError:
+            pass
 
     def check(self, rc: int, what: str):
         if rc and self.error is not None:

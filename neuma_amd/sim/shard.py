@@ -88,18 +88,51 @@ def substep_us(n: int) -> float:
     return pts[-1][1] * n / pts[-1][0]
 
 
-def shard_cost_model(num_particles: int, world: int, substeps: int) -> dict:
+def shard_cost_model(num_particles: int, world: int, substeps: int, measured: Optional[dict] = None) -> dict:
     """Estimated simulation time of one frame (S substeps, forward + backward) on `world` GPUs with the simulation replicated
     (every rank steps all particles) and particle-sharded (every rank steps N / world of them and pays, per substep and
     direction, one all-reduce of the exchange blocks, plus per frame the all-gather of x and F, the all-gather of the block
     neighbourhoods and the reduction of the LoRA gradients).  `shard` = the sharded estimate is smaller by at least
-    SHARD_MARGIN (10 %): the all-reduce latency in it is an assumption until a multi-GPU box has been measured, and a
-    predicted gain inside that uncertainty is not worth the extra collectives on the critical path."""
-    rep = substeps * substep_us(num_particles)
-    ar = allreduce_us(world)
+    SHARD_MARGIN (10 %).
+    measured (calibrate(), bench.py at start-up): {"substep_us_full", "substep_us_shard", "allreduce_us", "machinery_us"} taken on
+    THIS box at the real world size replace the table / the assumed all-reduce latency; without it the model runs on the
+    one-GPU table below and an ASSUMED xGMI latency (`allreduce_us_assumed`), which is all that exists until a multi-GPU box
+    has been measured."""
+    m = measured or {}
+    rep = substeps * float(m.get("substep_us_full", substep_us(num_particles)))
+    ar = float(m["allreduce_us"]) if "allreduce_us" in m else allreduce_us(world)
+    mach = float(m.get("machinery_us", MACHINERY_US))
     per_frame = 4.0 * ar if world > 1 else 0.0                     # x, F, neighbourhoods, parameter gradients
-    sh = substeps * (substep_us(-(-num_particles // world)) + MACHINERY_US + 2.0 * ar) + per_frame
-    return {"replicated_us": rep, "sharded_us": sh, "allreduce_us_assumed": ar, "shard": world > 1 and sh < (1.0 - SHARD_MARGIN) * rep}
+    sh = substeps * (float(m.get("substep_us_shard", substep_us(-(-num_particles // world)))) + mach + 2.0 * ar) + per_frame
+    out = {"replicated_us": rep, "sharded_us": sh, "shard": world > 1 and sh < (1.0 - SHARD_MARGIN) * rep,
+           "inputs": "measured at start-up" if measured else "one-GPU table + assumed all-reduce latency"}
+    out["allreduce_us" if "allreduce_us" in m else "allreduce_us_assumed"] = ar
+    if measured:
+        out["measured"] = dict(measured)
+    return out
+
+
+def time_all_reduce_us(group, device, count: int = 1 << 16, reps: int = 20, rccl=None) -> float:
+    """Mean microseconds of one in-place all-reduce (sum) of `count` floats over `group` - the latency term of the cost model,
+    measured at the real world size: through the library's communicator when there is one (nm_rccl_time_all_reduce), else
+    through torch.distributed with HIP events (gloo: host time).  Collective."""
+    import time
+    import torch.distributed as dist
+    buf = torch.zeros(count, dtype=torch.float32, device=device)
+    if rccl is not None:
+        us = C.c_float(0.0)
+        L.check(L.lib().nm_rccl_time_all_reduce(rccl, L.ptr(buf), count, 5, reps, C.byref(us), L.stream_ptr(device)), "nm_rccl_time_all_reduce")
+        return float(us.value)
+    for _ in range(5):
+        dist.all_reduce(buf, group=group)
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dist.all_reduce(buf, group=group)
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
+    return 1e6 * (time.perf_counter() - t0) / reps
 
 
 def explain_status(bits: int) -> str:
@@ -188,6 +221,31 @@ class GridExchange(object):
         self.generation = 0
         self._mine = self._gathered = self._ws = self._buf = self._scratch_shared = None
         self._watched = []          # (pinned int32, event) of fused sharded roll-outs whose status word has not been examined
+        self._rccl = None           # library-owned RCCL communicator (library_comm): None = not tried yet, False = not available
+
+    def library_comm(self):
+        """The library's own RCCL communicator for this group (csrc/nm_rccl.hip), created on first use: rank 0's ncclUniqueId
+        goes round through ONE torch.distributed broadcast, every rank runs ncclCommInitRank.  With it the fused sharded
+        roll-out issues its collectives from the C loop on the stream (rollout._ShardLink); None when the group's backend is
+        not nccl (the gloo tests keep the callback table) or NEUMA_COMM=python asks for the callbacks."""
+        import os
+        import torch.distributed as dist
+        if self._rccl is None:
+            self._rccl = False
+            if os.environ.get("NEUMA_COMM", "rccl") != "python" and str(dist.get_backend(self.group)) == "nccl":
+                lib = L.lib()
+                idt = torch.zeros(128, dtype=torch.uint8)
+                if self.rank == 0:
+                    L.check(lib.nm_rccl_unique_id(C.c_void_p(idt.data_ptr())), "nm_rccl_unique_id")
+                dev_id = idt.to(self.device)
+                src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+                dist.broadcast(dev_id, src=src, group=self.group)
+                idt = dev_id.cpu()
+                h = C.c_void_p()
+                with torch.cuda.device(self.device):
+                    L.check(lib.nm_rccl_create(C.c_void_p(idt.data_ptr()), self.world, self.rank, C.byref(h)), "nm_rccl_create")
+                self._rccl = h
+        return self._rccl or None
 
     # -- sizing (first substep only: two host reads + two tiny collectives)
     def _ensure_sized(self) -> None:

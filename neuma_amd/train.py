@@ -101,6 +101,23 @@ def fetch_scheduler(config):
     raise ValueError(f"Scheduler {t} not supported.")
 
 
+def native_epoch_ok(rt) -> bool:
+    """The runtime can run an epoch natively (SceneRuntime.epoch): one GPU, LoRA factors the only trainable tensors;
+    NEUMA_NATIVE_EPOCH=0 keeps the composition of autograd nodes (video_loss)."""
+    import os
+    return (os.environ.get("NEUMA_NATIVE_EPOCH", "1") != "0" and hasattr(rt, "epoch") and getattr(rt, "world", 1) == 1
+            and callable(getattr(rt, "_lean_ok", None)) and rt._lean_ok())
+
+
+def epoch_weights(c, decay_rate: float):
+    """(weights, frame_steps) of an epoch as video_loss applies them: weights[f] = decay_rate ** (f // decay_steps) for frame
+    f = cur_step - 1, None for a frame whose dataset id is in exclude_steps (finetune.py:369-372, 386-389)."""
+    nframes = int(c["num_frames"])
+    frame_ids = list(c["steps"]) if c.get("steps") is not None else list(range(nframes + 1))
+    weights = [None if frame_ids[cs] in c["exclude_steps"] else decay_rate ** ((cs - 1) // c["decay_steps"]) for cs in range(1, nframes + 1)]
+    return weights, [frame_ids[cs] for cs in range(1, nframes + 1)]
+
+
 def _flush(rt) -> None:
     """Before an optimizer step: wait for the runtime's deferred status words (a render whose lists overflowed composited the
     background only; a sharded substep whose exchange was incomplete summed too little) and raise instead of stepping on them."""
@@ -248,10 +265,16 @@ def finetune_constitutive(rt, gt_frames: List[List[torch.Tensor]], cfg: Optional
                 for g in opt.param_groups:
                     g["lr"] = lr * float(epoch) / c["warmup_step"]
         decay_rate = rollout_decay_rate(c, epoch)
-        loss_rgb = video_loss(rt, gt_frames, c, decay_rate, views, overlap_render=bool(c.get("overlap_render", False)))
         if not c["accumulate_grads_like_reference"]:
             e_opt.zero_grad(set_to_none=True); p_opt.zero_grad(set_to_none=True)
-        loss_rgb.backward()
+        if native_epoch_ok(rt):
+            # the whole epoch - F frames forward, one reverse sweep - as two plain calls into the library (harness._epoch_forward /
+            # _epoch_backward): what video_loss + loss.backward() compute through one autograd node per frame
+            ew, esteps = epoch_weights(c, decay_rate)
+            loss_rgb = rt.epoch(gt_frames, ew, views=views, frame_steps=esteps)
+        else:
+            loss_rgb = video_loss(rt, gt_frames, c, decay_rate, views, overlap_render=bool(c.get("overlap_render", False)))
+            loss_rgb.backward()
         _flush(rt)      # deferred reports (rasterizer capacity, sharded exchanges) raise HERE, before the gradients are used
         e_gn = clip_grad_norm_(E.parameters(), max_norm=c["elasticity_grad_max_norm"], error_if_nonfinite=True)
         e_opt.step()

@@ -320,7 +320,7 @@ def gpu_stripes_frame(rank, world, port, q, name="tiny"):
         q.put({"rank": rank, "error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()})
 
 
-def gpu_nccl_one_rank(rank, world, port, q, name="tiny"):
+def gpu_nccl_one_rank(rank, world, port, q, name="tiny", comm="rccl"):
     """world = 1 on the RCCL backend ("nccl"): the collectives of both multi-GPU modes issued for real - the frame's K x 3
     gradient all-reduce (_AllReduceSum) and the fused sharded roll-out's callbacks on views of its device workspace
     (_ShardLink: one all-gather per roll-out, one all-reduce per substep and direction) - against the plain frame."""
@@ -329,6 +329,7 @@ def gpu_nccl_one_rank(rank, world, port, q, name="tiny"):
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
         os.environ["NEUMA_SHARD_FORCE"] = "1"
+        os.environ["NEUMA_COMM"] = comm          # "rccl": the library's own communicator; "python": the callback table
         dev = torch.device("cuda", 0)
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         from neuma_amd import synth
@@ -350,7 +351,12 @@ def gpu_nccl_one_rank(rank, world, port, q, name="tiny"):
         res = {"rank": rank, "backend": dist.get_backend(), "loss": float(r1.loss), "ref_loss": float(r0.loss),
                "x_err": _err(r1.x, r0.x), "F_err": _err(r1.F, r0.F), "v0_err": _err(rt.v0.grad, ref.v0.grad),
                "grad_err": [_err(a.grad, b.grad) for a, b in zip(rt.parameters(), ref.parameters())],
-               "cap_frame": int(rt.model.exchange.cap_frame), "cap_dil": int(rt.model.exchange.cap_dil)}
+               "cap_frame": int(rt.model.exchange.cap_frame), "cap_dil": int(rt.model.exchange.cap_dil),
+               "link": getattr(rt.model.exchange, "link_backend", None)}
+        from neuma_amd import _lib as L
+        from neuma_amd.sim.shard import time_all_reduce_us
+        res["rccl_library"] = (L.lib().nm_rccl_library() or b"").decode()
+        res["allreduce_us"] = time_all_reduce_us(None, dev, count=1 << 16, rccl=rt.model.exchange.library_comm())
         # the stripe mode's collective: identity forward, all-reduce(sum) of the gradient backward
         g = torch.randn(1000, 3, device=dev)
         y = torch.randn(1000, 3, device=dev, requires_grad=True)

@@ -127,11 +127,19 @@ def test_device_shared_block_rule_equals_the_host_statement(world, cap):
             assert np.array_equal(out[2:2 + len(ids)], ids)
 
 
-def test_one_rank_on_the_rccl_backend_runs_both_multi_gpu_collective_paths():
-    """backend "nccl" (= RCCL), world = 1: the fused sharded roll-out with its callbacks on device-workspace views and the
-    stripe mode's gradient all-reduce, against the unsharded frame."""
-    (r,) = _run(shard_worker.gpu_nccl_one_rank, 1)
+@pytest.mark.parametrize("comm", ["rccl", "python"])
+def test_one_rank_on_the_rccl_backend_runs_both_multi_gpu_collective_paths(comm):
+    """backend "nccl" (= RCCL), world = 1: the fused sharded roll-out and the stripe mode's gradient all-reduce, against the
+    unsharded frame.  comm = "rccl" (default): the roll-out's collectives are ncclAllGather / ncclAllReduce issued by the
+    library itself from its C loop, through the communicator it owns (csrc/nm_rccl.hip; librccl bound with dlopen);
+    "python": the nm_comm callback table on device-workspace views (what the gloo tests use)."""
+    (r,) = _run(shard_worker.gpu_nccl_one_rank, 1, "tiny", comm)
     assert r["backend"] == "nccl" and r["allreduce_ok"]
+    if comm == "rccl":
+        assert r["link"].startswith("rccl") and "librccl" in r["rccl_library"], r
+        assert 0.0 < r["allreduce_us"] < 1e4, r
+    else:
+        assert r["link"].startswith("torch.distributed"), r
     assert abs(r["loss"] - r["ref_loss"]) <= 1e-4 * abs(r["ref_loss"]) + 1e-9, r
     assert r["x_err"] < 1e-5 and r["F_err"] < 1e-5 and r["v0_err"] < 5e-3, r
     assert max(r["grad_err"]) < 5e-3, r

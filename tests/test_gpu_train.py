@@ -199,3 +199,52 @@ def test_loss_differences_between_equivalent_paths_are_rasterizer_cut_off_events
     # one Gaussian at the alpha threshold contributes at most (1/255) * T * colour, colour <~ 1.5 with the SH offset
     assert worst_flip <= 1.5 / 255 + 1e-6, worst_flip
     assert flips <= max(8, npix // 2000), (flips, npix)
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_native_epoch_matches_the_composition_of_autograd_nodes(overlap):
+    """SceneRuntime.epoch (harness._epoch_forward / _epoch_backward: the whole BPTT epoch of finetune.py:331-414 as two plain
+    calls - consecutive roll-outs on one checkpoint buffer, per frame binding against the detached previous frame + renders +
+    decayed loss, one reverse sweep with the LoRA gradients summed over the frames) against train.video_loss + loss.backward()
+    (one autograd node per frame and operator): same loss, same twelve LoRA gradients - with a decay schedule, an excluded
+    frame, and the render of frame f overlapped with the simulation of frame f + 1."""
+    from neuma_amd import synth
+    from neuma_amd.harness import SceneRuntime
+    from neuma_amd.train import DEFAULT_CFG, simulate_video, video_loss, epoch_weights, native_epoch_ok
+    scene = synth.make_scene("tiny", override=dict(S=4, V=2))
+    torch.manual_seed(0)
+    F0 = torch.diag(torch.tensor([1.3, 0.75, 1.0])).to(dev())
+    true = SceneRuntime(scene, dev(), fused=True)
+    true.F0 = F0.repeat(true.N, 1, 1).contiguous()
+    for net in (true.elasticity, true.plasticity):
+        for lin in (net.layers[0].fc, net.layers[1].fc, net.final_layer.fc):
+            lin.lora_B.data.mul_(40.0)
+    frames = 5
+    gt = simulate_video(true, frames)
+    c = dict(DEFAULT_CFG, num_frames=frames, decay_steps=2, exclude_steps=(3,))
+    decay = 0.7
+    rt = SceneRuntime(scene, dev(), fused=True)
+    rt.F0 = true.F0.clone()
+    assert native_epoch_ok(rt)
+    views = [0, 1]
+    for p in rt.parameters():
+        p.grad = None
+    ref_loss = video_loss(rt, gt, c, decay, views)
+    ref_loss.backward()
+    ref = [p.grad.clone() for p in rt.parameters()]
+    for p in rt.parameters():
+        p.grad = None
+    w, steps = epoch_weights(c, decay)
+    assert w[2] is None and abs(w[4] - decay ** 2) < 1e-12 and w[0] == 1.0
+    loss = rt.epoch(gt, w, views=views, frame_steps=steps, overlap=overlap)
+    got = [p.grad.clone() for p in rt.parameters()]
+    assert abs(float(loss) - float(ref_loss)) <= 2e-4 * abs(float(ref_loss)) + 1e-12, (float(loss), float(ref_loss))
+    for a, b in zip(got, ref):
+        assert torch.isfinite(a).all()
+        # (render gradients of this small scene carry ~1e-3 of atomics-order noise between two runs of the SAME path)
+        assert float((a - b).abs().max()) <= 5e-3 * float(b.abs().max()) + 1e-12
+    # a second epoch accumulates into .grad like loss.backward() does
+    rt.epoch(gt, w, views=views, frame_steps=steps, overlap=overlap)
+    for a, b in zip([p.grad for p in rt.parameters()], ref):
+        assert float((a - 2 * b).abs().max()) <= 1e-2 * float(b.abs().max()) + 1e-12
+    assert rt.last_epoch_note["frames_with_activation_cache"] + rt.last_epoch_note["frames_recomputing"] == frames

@@ -8,7 +8,7 @@ if variant:
     src = "neuma_amd/csrc"
     out = f"/tmp/libneuma_rb{variant}.so"
     files = " ".join(f"{src}/{f}" for f in ("nm_api.hip", "nm_mpm.hip", "nm_shard.hip", "nm_material.hip", "nm_bind.hip", "nm_bindbuild.hip",
-                                             "nm_raster.hip", "nm_rollout.hip"))
+                                             "nm_raster.hip", "nm_rollout.hip", "nm_rccl.hip"))
     subprocess.run(f"/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -DNM_RB_VARIANT={variant} {extra} -Iinclude "
                    f"-shared {files} -o {out}", shell=True, check=True)
     os.environ["NEUMA_HIP_LIB"] = out
