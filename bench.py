@@ -130,6 +130,46 @@ def frame_roofline(full, rt, D, frame_s):
                     "reverse 3 x that per particle and net); both over ms_per_step of the timed region"}
 
 
+def measure_epoch(rt, frames: int, single_frame_fps: float, reps: int = 3) -> dict:
+    """Frames/s inside a native BPTT epoch of `frames` frames (SceneRuntime.epoch), peak device memory while it runs, and whether
+    the roll-outs' activation caches stayed inside their budget (frames beyond it recompute)."""
+    import torch
+    from neuma_amd.train import simulate_video
+    dev = rt.device
+    with torch.no_grad():
+        gt = simulate_video(rt, frames)
+    weights = [1.0] * frames
+    params = rt.parameters()
+
+    def once():
+        for p in params:
+            p.grad = None
+        return rt.epoch(gt, weights)
+
+    once()
+    torch.cuda.synchronize(dev)
+    torch.cuda.reset_peak_memory_stats(dev)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        loss = once()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    rt.flush()
+    G = int(rt.scene.cfg["G"])
+    nb = ((G + 2 + 3) // 4) ** 3
+    lib_bytes = 3 * nb * 1024 + 4 * nb * 7 + 48 * rt.n_local      # the MPM handle: three node arrays, flags / lists, reverse-substep scratch
+    fps = frames * reps / dt
+    note = dict(getattr(rt, "last_epoch_note", {}) or {})
+    return {"frames": frames, "substeps_per_frame": int(rt.S), "views_per_frame": int(rt.V), "epochs_timed": reps,
+            "frames_per_s": round(fps, 2), "ms_per_frame": round(1e3 / fps, 4), "single_frame_frames_per_s": round(single_frame_fps, 2),
+            "ratio_to_single_frame": round(fps / single_frame_fps, 3),
+            "peak_hbm_GB": round((torch.cuda.max_memory_allocated(dev) + lib_bytes) / 2 ** 30, 2),
+            "peak_hbm_note": "torch allocator peak (checkpoints 132 B / particle / substep, SVD + activation caches, grid cache records, "
+                             "rasterizer state kept per frame and view, ground-truth frames) + the library's own allocations; the "
+                             "reference needs an 80 GB A100 for this (README.md:202, SURVEY App. E)",
+            "activation_cache": note, "loss": float(loss)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -146,6 +186,11 @@ def main():
                          "auto = whichever sim.shard.shard_cost_model estimates faster for this workload and world size "
                          "(measured per-substep latency at N / world particles + exchange machinery + assumed xGMI "
                          "all-reduce latency, DESIGN.md section 6)")
+    ap.add_argument("--epoch-frames", type=int, default=19,
+                    help="also measure a native multi-frame BPTT epoch (SceneRuntime.epoch; finetune.py:331-414 - the reference's "
+                         "real unit of work) of this many frames at the workload's S and V, and a 400 x 1 x 1 epoch at bb size, "
+                         "as a SECONDARY object `epoch` of the result line (one GPU only; 0 = skip).  19 x 20 x 3 = "
+                         "configs/realworld/finetune-burger.yaml:107-113, 400 x 1 x 1 = configs/synthetic/finetune-bb.yaml:103-107")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -409,6 +454,29 @@ def main():
                  "renders_per_s_fwd": round(1e3 / t_rf, 1), "renders_per_s_fwdbwd": round(1e3 / t_rfb, 1),
                  "note": "full-image renders (1 view incl. loss) and whole-particle-set substeps on one GPU"}
 
+    epoch = None
+    if rank == 0 and world == 1 and args.epoch_frames > 0 and not args.per_op:
+        try:
+            epoch = {"unit": "frames/s inside one epoch = F frames forward (state flowing from frame to frame, renders of frame f under "
+                             "the simulation of frame f+1) + one reverse sweep; finetune.py:331-414",
+                     args.workload: measure_epoch(rt, args.epoch_frames, fps)}
+            if args.workload != "bb":
+                rt_bb = SceneRuntime(synth.make_scene("bb"), dev)
+                rt_bb.make_ground_truth()
+                for _ in range(20):
+                    rt_bb.frame()
+                torch.cuda.synchronize(dev)
+                t0b = time.perf_counter()
+                for _ in range(200):
+                    rt_bb.frame()
+                torch.cuda.synchronize(dev)
+                epoch["bb"] = measure_epoch(rt_bb, 400, 200.0 / (time.perf_counter() - t0b))
+                del rt_bb
+        except Exception as e:  # secondary measurement: never takes the headline down
+            import traceback
+            print(f"[bench] epoch measurement failed: {e}\n{traceback.format_exc()}", file=sys.stderr)
+            epoch = {"error": f"{type(e).__name__}: {e}"}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N=1 only
         try:
@@ -456,6 +524,7 @@ def main():
             "devices": devices,
             "roofline": roof,
             "cpu_baseline": cpu,
+            "epoch": epoch,
             "kernel_breakdown_ms_per_frame": {k: round(v[1], 3) for k, v in sorted(full.items(), key=lambda kv: -kv[1][1])[:12]},
             "kernel_time_fraction_of_frame": round(total_ms / (1e3 * elapsed / args.steps), 3),
             "kernel_time_note": "sum of the HIP-event durations of every launch of ONE profiled frame (its views rendered one after "

@@ -60,13 +60,16 @@ def dilate_blocks_host(ids, nb: int):
 
 # ---------------------------------------------------------------- replicate or shard the simulation? (bench.py --shard-sim auto)
 # Measured on 1x MI355X, fused roll-out, forward + backward, microseconds per substep at N particles (tools/exp_shard_overhead.py
-# <workload> <N>; profiles/r03_shard_overhead.txt).  Between the points: linear in N.  The small sizes are latency floors - a
-# substep is ~12 dependent launches - which is why dividing 100k particles by 8 buys 2.1x, not 8x.
-SUBSTEP_US = ((12_500, 108.0), (25_000, 167.0), (50_000, 159.0), (100_000, 232.0), (1_000_000, 2400.0))
+# <workload> <N>; profiles/r04_shard_overhead.txt - round 4: monotone since the scatter kernels cut a chunk of the particle
+# list at its jumps instead of falling back to per-wave boxes, which had cost 84 us per scatter at 25 000 particles).  Between
+# the points: linear in N.  The small sizes are latency floors - a substep is ~7 dependent launches - which is why dividing
+# 100k particles by 8 buys 2.4x, not 8x.  bench.py --shard-sim auto no longer decides from this table when it runs on several
+# GPUs: it measures both sizes and the all-reduce at start-up (shard_cost_model(measured=...)); the table is the fallback.
+SUBSTEP_US = ((12_500, 94.0), (25_000, 117.0), (50_000, 147.5), (100_000, 223.0), (1_000_000, 1700.0))
 SHARD_MARGIN = 0.10
-MACHINERY_US = 23.0      # measured with a one-rank RCCL group: 2 pack launches + 2 all-reduce calls per substep, fwd + bwd
-#                          (profiles/r03c_shard_overhead.txt; the 12.5 us of the mid-round table compared against an unsharded
-#                          reverse sweep that ran unverified)
+MACHINERY_US = 7.0       # measured with a one-rank RCCL group and the library-owned communicator (csrc/nm_rccl.hip): 2 pack launches
+#                          + 2 ncclAllReduce per substep, fwd + bwd (profiles/r04_shard_overhead.txt: +4.5 forward, +5..7 both; with
+#                          the Python callback table of round 3 it was 23; at 1 M particles / 256^3 the packs grow to ~100 us)
 # NOT measured (no multi-GPU box so far): latency of one all-reduce of <= 1 MiB over xGMI at `world` ranks.  Assumption: a ring /
 # tree step costs ~6 us and RCCL's launch ~10 us.  NEUMA_XGMI_ALLREDUCE_US overrides the per-collective figure.
 def allreduce_us(world: int) -> float:
