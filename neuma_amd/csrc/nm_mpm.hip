@@ -445,8 +445,18 @@ __device__ __forceinline__ void wg_scatter_f64(const MpmK& K, bool en, int lp, c
   __syncthreads();
   SC_PH(2)
   const int ny = gn[1], nz = gn[2];
-  if (en) {
-    double* a0 = acc + goff + ((base[0] - go[0]) * ny + (base[1] - go[1])) * nz + (base[2] - go[2]);
+  {
+    // Lanes l and l ^ 16 hold two CONSECUTIVE particles (scatter_particle) - in a cell-ordered list usually two members of one
+    // cell, i.e. the same 27 nodes.  Such a pair adds its values once: v + v(lane ^ 16) by a row swap (v_permlane16_swap, two
+    // instructions), issued by the even row; a pair that straddles two cells (or holds a disabled particle) adds separately.
+    // Half the atomic lanes for three VALU instructions per value; the decision is per pair, so a stale order only loses the
+    // saving, never a contribution.
+    const int ci = goff + ((base[0] - go[0]) * ny + (base[1] - go[1])) * nz + (base[2] - go[2]);
+    const int key = en ? ci : -1 - lane;        // (never equal to the partner's)
+    auto rk = __builtin_amdgcn_permlane16_swap((unsigned)key, (unsigned)key, false, false);
+    const bool paired = en && !NM_DBG_BIT(K, 128) && (int)rk[0] == (int)rk[1];      // the two rows of the pair hold the same cell
+    const bool issue = en && !(paired && (lane & 16));
+    double* a0 = acc + ci;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -455,10 +465,19 @@ __device__ __forceinline__ void wg_scatter_f64(const MpmK& K, bool en, int lp, c
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           const float4 c = contrib(i, j, k);
-          unsafeAtomicAdd(row + k, (double)c.x);
-          unsafeAtomicAdd(row + NM_F64_PS + k, (double)c.y);
-          unsafeAtomicAdd(row + 2 * NM_F64_PS + k, (double)c.z);
-          if (NCH == 4) unsafeAtomicAdd(row + 3 * NM_F64_PS + k, (double)c.w);
+          float v[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+          for (int ch = 0; ch < NCH; ++ch) {
+            auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[ch]), __float_as_uint(v[ch]), false, false);
+            const float both = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            v[ch] = paired ? both : v[ch];
+          }
+          if (issue) {
+            unsafeAtomicAdd(row + k, (double)v[0]);
+            unsafeAtomicAdd(row + NM_F64_PS + k, (double)v[1]);
+            unsafeAtomicAdd(row + 2 * NM_F64_PS + k, (double)v[2]);
+            if (NCH == 4) unsafeAtomicAdd(row + 3 * NM_F64_PS + k, (double)v[3]);
+          }
         }
       }
   }
