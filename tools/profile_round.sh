@@ -3,7 +3,7 @@
 tag=${1:-rXX}
 R=$PWD; O=$R/gpurun_out/$tag; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+CMD="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --epoch-frames 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $CMD > $O/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $CMD > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- $CMD > $O/write.log 2>&1
@@ -13,8 +13,8 @@ cd $R
 python tools/timeline.py /tmp/tl_$tag 20 > $O/rollout_timeline.md
 # keep only the small summaries (the merge back is capped at 64 MiB)
 find $O -name "*kernel_trace.csv" -size +8M -delete
-for w in metric bb jd sf burger stress; do python bench.py --workload $w --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_$w.json; done
-python bench.py --state deformed --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_metric_deformed.json
-python bench.py --state impact --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_metric_impact.json
+for w in metric bb jd sf burger stress; do python bench.py --workload $w --no-cpu-baseline --epoch-frames 0 2>/dev/null | tail -1 > $O/bench_$w.json; done
+python bench.py --state deformed --no-cpu-baseline --epoch-frames 0 2>/dev/null | tail -1 > $O/bench_metric_deformed.json
+python bench.py --state impact --no-cpu-baseline --epoch-frames 0 2>/dev/null | tail -1 > $O/bench_metric_impact.json
 python bench.py 2>/dev/null | tail -1 > $O/bench_metric_cpu.json
 du -sh $O
