@@ -89,6 +89,27 @@ __device__ __forceinline__ float sel3(const float* a, int i) { return i == 0 ? a
 // FILL (passive extra sets, mpm.py:260-277): a stencil node in a block the scattering particles did not touch reads what the
 // reference's dense grid_op sweep leaves there - BC(g dt) of an empty node (mpm.py:384-385 / 413-414) - instead of the
 // block-sparse grid's zero; `flags[block] == epoch` marks the blocks this substep built.
+// the loads of a particle's g2p that do not depend on its stencil (issued as a block; g2p_in_load of the NEXT round of a
+// constitutive wave is issued before the current round's MLP, so that its HBM round trip hides behind it)
+struct G2pIn {
+  int e;
+  float x[3];
+  float clip;
+  M3 F;
+};
+__device__ __forceinline__ G2pIn g2p_in_load(int p, const float* __restrict__ clip, const int* __restrict__ enabled, const float* x,
+                                             const float* F) {
+  G2pIn in;
+  in.e = enabled[p];
+  in.x[0] = x[3 * p]; in.x[1] = x[3 * p + 1]; in.x[2] = x[3 * p + 2];
+  in.clip = clip[p];
+  in.F = m3_load(F + 9 * p);
+  return in;
+}
+template <bool UNROLL, bool FILL = false>
+__device__ __forceinline__ void g2p_particle(const MpmK& K, int p, const G2pIn& in, const float* x,
+                                             const float4* __restrict__ gv, float* xn, float* vn, float* Cn, M3& Fo,
+                                             const int* __restrict__ flags = nullptr, int epoch = 0, bool fresh = false);
 template <bool UNROLL, bool FILL = false>
 __device__ __forceinline__ void g2p_particle(const MpmK& K, int p, const float* __restrict__ clip, const int* __restrict__ enabled,
                                              const float* x, const float* v, const float* C, const float* F,
@@ -96,10 +117,17 @@ __device__ __forceinline__ void g2p_particle(const MpmK& K, int p, const float* 
                                              const int* __restrict__ flags = nullptr, int epoch = 0, bool fresh = false) {
   // (every load that does not depend on the stencil is issued before `enabled` is looked at: a wave of the constitutive kernels
   //  is alone on its SIMD, and enabled -> x -> gathers -> F were four round trips in a row)
-  const int e_ = enabled[p];
-  float xp[3] = {x[3 * p], x[3 * p + 1], x[3 * p + 2]};
-  const float clip_p = clip[p];
-  const M3 Fp = m3_load(F + 9 * p);
+  const G2pIn in = g2p_in_load(p, clip, enabled, x, F);
+  g2p_particle<UNROLL, FILL>(K, p, in, x, gv, xn, vn, Cn, Fo, flags, epoch, fresh);
+}
+template <bool UNROLL, bool FILL>
+__device__ __forceinline__ void g2p_particle(const MpmK& K, int p, const G2pIn& in, const float* x,
+                                             const float4* __restrict__ gv, float* xn, float* vn, float* Cn, M3& Fo,
+                                             const int* __restrict__ flags, int epoch, bool fresh) {
+  const int e_ = in.e;
+  float xp[3] = {in.x[0], in.x[1], in.x[2]};
+  const float clip_p = in.clip;
+  const M3 Fp = in.F;
   if (e_ == 0) {
     if (fresh && xn != x) {
       Fo = m3_ident();

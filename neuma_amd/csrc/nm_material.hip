@@ -621,12 +621,19 @@ __global__ void __launch_bounds__(256) k_material_fwd_pair(int n, int q, float a
   float* zb = sZ[wave];
   float* yb = sY[wave];
   const int pbeg = min(n, (blockIdx.x * 4 + wave) * q), pend = min(n, pbeg + q);
+  // the stencil-independent loads of a round's particles (enabled, x, clip, F) are issued one round ahead: the wave is alone on
+  // its SIMD, so a round that starts with its own loads spends their whole HBM round trip (~2 us) doing nothing
+  G2pIn nxt{};
+  if (pbeg + lane < pend) nxt = g2p_in_load(pbeg + lane, gf.clip, gf.enabled, gf.x, gf.F);
   for (int c0 = pbeg; c0 < pend; c0 += 64) {
     const int p = c0 + lane;
     const bool valid = p < pend;
     const int ntile = (min(64, pend - c0) + 15) >> 4;
     M3 Ftr = m3_ident();
-    if (valid) g2p_particle<true>(gf.K, p, gf.clip, gf.enabled, gf.x, gf.v, gf.C, gf.F, gf.gv, gf.xn, gf.vn, gf.Cn, Ftr, nullptr, 0, true);
+    const G2pIn cur = nxt;
+    if (p + 64 < pend) nxt = g2p_in_load(p + 64, gf.clip, gf.enabled, gf.x, gf.F);
+    NM_SB();
+    if (valid) g2p_particle<true>(gf.K, p, cur, gf.x, gf.gv, gf.xn, gf.vn, gf.Cn, Ftr, nullptr, 0, true);
     const M3 Fn = material_fwd_round<NM_PLASTICITY, ACT>(Ftr, valid, n, p, c0, ntile, lane, alpha, sPp, sPp + 16 * 64,
                                                          sPp + 16 * 64 + 64 * 64, zb, yb, svd_p, act_p);
     if (valid) m3_store(F_next + 9 * p, Fn);
@@ -787,34 +794,51 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
     for (int b = 0; b < 4; ++b) gW1[a][b] = zero;
   }
   const int pbeg = min(n, (blockIdx.x * 4 + wave) * q), pend = min(n, pbeg + q);   // see nm_wave_quota
+  // A round's loads - F, dL/dout, trial C', the SVD factors, the activation record of its first tile - are issued ONE ROUND AHEAD
+  // (round 4): the wave is alone on its SIMD, and a round that started with its own loads sat through their whole HBM round trip
+  // (the first record "took 8 k cycles to arrive", §5) four times per pair launch.  Loads are issued in the order they are
+  // needed (vmcnt retires in order); `enabled` gates nothing any more - a disabled particle's values are replaced afterwards.
+  struct RoundIn {
+    int en_p;
+    M3 Fp, go, T, U, V;
+    float s[3];
+    f4 nx[ACT ? NM_ACT_SLOTS : 1];
+  };
+  auto load_round = [&](int c0_, RoundIn& o) {
+    const int p_ = c0_ + lane;
+    const bool valid_ = p_ < pend;
+    o.en_p = (fz.trial_C && valid_) ? fz.enabled[p_] : 0;
+    o.Fp = valid_ ? m3_load(F + 9 * p_) : m3_ident();
+    o.go = valid_ ? m3_load(gout + 9 * p_) : m3_zero();
+    o.T = (fz.trial_C && valid_) ? m3_load(fz.trial_C + 9 * p_) : m3_zero();
+    if (fz.svd_in) {        // (workgroup-uniform)
+      if (valid_) svd_load(fz.svd_in, n, p_, o.U, o.s, o.V);
+      else { o.U = m3_ident(); o.V = m3_ident(); o.s[0] = o.s[1] = o.s[2] = 1.f; }
+    }
+    if (ACT) {
+      const f4* at_ = a.act + (size_t)(c0_ >> 4) * NM_ACT_SLOTS * 64 + lane;
+#pragma unroll
+      for (int k = 0; k < NM_ACT_SLOTS; ++k) o.nx[k] = __builtin_nontemporal_load(&at_[k * 64]);
+    }
+  };
+  RoundIn ahead;
+  if (pbeg < pend) load_round(pbeg, ahead);
   for (int c0 = pbeg; c0 < pend; c0 += 64) {
     const int p = c0 + lane;
     const bool valid = p < pend;
     const int ntile = (min(64, pend - c0) + 15) >> 4;
-    // The round's loads are issued in the order they are needed - F, dL/dout, trial C', the SVD factors, and only then the
-    // activation record of the round's first tile (vmcnt retires in order: with the 17 KB record in front, the feature
-    // computation waited for all of it: +6 k cycles per round).  Tile ct + 1's record is requested during tile ct.
     f4 nx[ACT ? NM_ACT_SLOTS : 1];
     const f4* act_tile = ACT ? a.act + (size_t)(c0 >> 4) * NM_ACT_SLOTS * 64 + lane : nullptr;
-    // (F, dL/dout and C' are requested before `enabled` is looked at: behind a branch on it they were a second round trip)
-    const int en_p = (fz.trial_C && valid) ? fz.enabled[p] : 0;
-    M3 Fp = valid ? m3_load(F + 9 * p) : m3_ident();
-    M3 go = valid ? m3_load(gout + 9 * p) : m3_zero();
-    M3 T = (fz.trial_C && valid) ? m3_load(fz.trial_C + 9 * p) : m3_zero();
-    const bool trial = en_p != 0;
+    M3 Fp = ahead.Fp, go = ahead.go, T = ahead.T;
+    M3 R, U = ahead.U, V = ahead.V;
+    float z[13], s[3] = {ahead.s[0], ahead.s[1], ahead.s[2]};
+    const bool trial = ahead.en_p != 0;
+#pragma unroll
+    for (int k = 0; k < (ACT ? NM_ACT_SLOTS : 1); ++k) nx[k] = ahead.nx[k];
+    if (c0 + 64 < pend) load_round(c0 + 64, ahead);      // (wave-uniform)
+    NM_SB();
     // roll-out: the forward pass fed the plasticity net I for a disabled particle (the fresh state of its next row, nm_grid.h)
     if (fz.trial_C && !trial) { Fp = m3_ident(); T = m3_zero(); }
-    M3 R, U, V;
-    float z[13], s[3];
-    if (fz.svd_in) {        // (workgroup-uniform)
-      if (valid) svd_load(fz.svd_in, n, p, U, s, V);
-      else { U = m3_ident(); V = m3_ident(); s[0] = s[1] = s[2] = 1.f; }
-    }
-    if (ACT) {
-#pragma unroll
-      for (int k = 0; k < NM_ACT_SLOTS; ++k) nx[k] = __builtin_nontemporal_load(&act_tile[k * 64]);
-    }
-    NM_SB();
     if (trial) {   // roll-out: input is the trial F = (I + dt C') F of mpm.py:489
 #pragma unroll
       for (int i = 0; i < 9; ++i) T.m[i] *= fz.dt;

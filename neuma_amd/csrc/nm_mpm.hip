@@ -953,8 +953,11 @@ __global__ void __launch_bounds__(256) k_grid_op(MpmK K, const float4* __restric
   // slot / xbuf (sharded roll-out): a block with slot[b] >= 0 takes its {mv, m} - summed over the ranks - from the exchange
   // buffer instead of this rank's grid (the unpack step of the exchange, fused)
   if (skip_hdr && *skip_hdr >= 0) return;
-  const int cnt = *count;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // (the wave's first list entry is requested together with the count - the list holds one word per block of the grid, any
+  //  index below nblocks is readable -: count -> list -> node was three dependent round trips for a 5 us kernel)
+  const int b_first = (int)(blockIdx.x * 4 + wave) < K.nb * K.nb * K.nb ? list[blockIdx.x * 4 + wave] : 0;
+  const int cnt = *count;
   if (dropped.list) {   // a block of the previous list that is not in this substep's (no stamp of this epoch) reads as empty again
     const int pc = *dropped.count;
     for (int li = blockIdx.x * 4 + wave; li < pc; li += gridDim.x * 4) {
@@ -968,7 +971,7 @@ __global__ void __launch_bounds__(256) k_grid_op(MpmK K, const float4* __restric
     if (!save && status) atomicOr(status, 4);   // sharded substeps cannot fall back to a recompute: tell the caller
   }
   for (int li = blockIdx.x * 4 + wave; li < cnt; li += gridDim.x * 4) {
-    int b = list[li];
+    int b = li == blockIdx.x * 4 + wave ? b_first : list[li];
     int i, j, k;
     block_coords(b, K.nb, lane, i, j, k);
     int node = (b << 6) + lane;
@@ -1000,14 +1003,15 @@ __global__ void __launch_bounds__(256) k_grid_op_bwd(MpmK K, const float4* __res
                                                      const int* __restrict__ list, const int* __restrict__ count,
                                                      GridRec stamp, int stamp_epoch, int* __restrict__ flags,
                                                      const int* __restrict__ slot, const float4* __restrict__ xbuf) {
-  const int cnt = *count;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b_first = (int)(blockIdx.x * 4 + wave) < K.nb * K.nb * K.nb ? list[blockIdx.x * 4 + wave] : 0;      // (with the count, not behind it: see k_grid_op)
+  const int cnt = *count;
   if (stamp.hdr) {
     const int sc = stamp.hdr[0];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < sc; i += gridDim.x * blockDim.x) flags[stamp.list[i]] = stamp_epoch;
   }
   for (int li = blockIdx.x * 4 + wave; li < cnt; li += gridDim.x * 4) {
-    int b = list[li];
+    int b = li == blockIdx.x * 4 + wave ? b_first : list[li];
     int i, j, k;
     block_coords(b, K.nb, lane, i, j, k);
     int node = (b << 6) + lane;
