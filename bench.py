@@ -130,7 +130,7 @@ def frame_roofline(full, rt, D, frame_s):
                     "reverse 3 x that per particle and net); both over ms_per_step of the timed region"}
 
 
-def measure_epoch(rt, frames: int, single_frame_fps: float, reps: int = 3) -> dict:
+def measure_epoch(rt, frames: int, single_frame_fps: float, reps: int = 5) -> dict:
     """Frames/s inside a native BPTT epoch of `frames` frames (SceneRuntime.epoch), peak device memory while it runs, and whether
     the roll-outs' activation caches stayed inside their budget (frames beyond it recompute)."""
     import torch
@@ -146,14 +146,16 @@ def measure_epoch(rt, frames: int, single_frame_fps: float, reps: int = 3) -> di
             p.grad = None
         return rt.epoch(gt, weights)
 
-    once()
+    once(); once()
     torch.cuda.synchronize(dev)
     torch.cuda.reset_peak_memory_stats(dev)
-    t0 = time.perf_counter()
+    times = []
     for _ in range(reps):
+        t0 = time.perf_counter()
         loss = once()
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
+        torch.cuda.synchronize(dev)
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times)[len(times) // 2] * reps        # median epoch (a fresh process now and then pays for device memory inside one)
     rt.flush()
     G = int(rt.scene.cfg["G"])
     nb = ((G + 2 + 3) // 4) ** 3
@@ -161,7 +163,7 @@ def measure_epoch(rt, frames: int, single_frame_fps: float, reps: int = 3) -> di
     fps = frames * reps / dt
     note = dict(getattr(rt, "last_epoch_note", {}) or {})
     return {"frames": frames, "substeps_per_frame": int(rt.S), "views_per_frame": int(rt.V), "epochs_timed": reps,
-            "frames_per_s": round(fps, 2), "ms_per_frame": round(1e3 / fps, 4), "single_frame_frames_per_s": round(single_frame_fps, 2),
+            "frames_per_s": round(fps, 2), "ms_per_frame": round(1e3 / fps, 4), "epoch_ms_each": [round(1e3 * t, 2) for t in times], "single_frame_frames_per_s": round(single_frame_fps, 2),
             "ratio_to_single_frame": round(fps / single_frame_fps, 3),
             "peak_hbm_GB": round((torch.cuda.max_memory_allocated(dev) + lib_bytes) / 2 ** 30, 2),
             "peak_hbm_note": "torch allocator peak (checkpoints 132 B / particle / substep, SVD + activation caches, grid cache records, "

@@ -960,6 +960,8 @@ class SceneRuntime(object):
             raise RuntimeError("the native epoch needs a one-GPU runtime with LoRA on all six layers as the only trainable tensors "
                                "(SceneRuntime._lean_ok); use train.video_loss otherwise")
         ba = [t for l in self._lora_layers for t in (l.lora_B, l.lora_A)]
+        from . import rollout as R
+        R._POOL_CAP[0] = max(R._POOL_CAP[0], len(weights))      # every frame's cache buffers go back to the pool, not to the allocator
         with torch.no_grad():
             loss, es = _epoch_forward(self, gt_frames, weights, views, frame_steps, None, overlap)
             self.last_epoch_note = es.peak_note

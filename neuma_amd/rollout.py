@@ -27,6 +27,7 @@ _FWD_PAIR = __import__('os').environ.get('NEUMA_FWD_PAIR')
 _FWD_PAIR_SET = [False]
 _ACT_CACHE_GB = float(__import__('os').environ.get('NEUMA_ACT_CACHE_GB', '48'))
 _ACT_LIVE = [0]         # bytes of activation cache held by live roll-out nodes
+_POOL_CAP = [4]         # idle buffers kept per size (a multi-frame epoch raises it to its number of frames: harness.SceneRuntime.epoch)
 _POOL = {}              # (device, bytes) -> idle cache buffers.  The caches are GB-sized: handing them back to the caching
                         # allocator every frame makes it release and re-acquire device memory now and then (tens of
                         # milliseconds inside a training loop), so a node returns them here after its backward pass
@@ -47,7 +48,7 @@ class _Lease(object):
     def release(self):
         if self.t is not None:
             free = _POOL.setdefault(self.key, [])
-            if len(free) < 4:
+            if len(free) < _POOL_CAP[0]:
                 free.append(self.t)
             self._forget()
 
