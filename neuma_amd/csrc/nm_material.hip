@@ -614,17 +614,19 @@ __global__ void __launch_bounds__(256) k_material_fwd_pair(int n, int q, float a
   float (*sZ)[64 * 17] = reinterpret_cast<float (*)[64 * 17]>(sBuf);
   float (*sY)[64 * 9] = reinterpret_cast<float (*)[64 * 9]>(sBuf + 4 * 64 * 17);
   if (NM_PROLOGUE_SPLIT(pro)) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int pbeg = min(n, (blockIdx.x * 4 + wave) * q), pend = min(n, pbeg + q);
+  // the stencil-independent loads of a round's particles (enabled, x, clip, F) are issued one round ahead - the first round's in
+  // front of the weight staging -: the wave is alone on its SIMD, so a round that starts with its own loads spends their whole
+  // HBM round trip (~2 us) doing nothing
+  G2pIn nxt{};
+  if (pbeg + lane < pend) nxt = g2p_in_load(pbeg + lane, gf.clip, gf.enabled, gf.x, gf.F);
+  NM_SB();
   stage_permuted<NM_PERM_FWD>(wperm_p, sPp);
   stage_permuted<NM_PERM_FWD>(wperm_e, sPe);
   __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float* zb = sZ[wave];
   float* yb = sY[wave];
-  const int pbeg = min(n, (blockIdx.x * 4 + wave) * q), pend = min(n, pbeg + q);
-  // the stencil-independent loads of a round's particles (enabled, x, clip, F) are issued one round ahead: the wave is alone on
-  // its SIMD, so a round that starts with its own loads spends their whole HBM round trip (~2 us) doing nothing
-  G2pIn nxt{};
-  if (pbeg + lane < pend) nxt = g2p_in_load(pbeg + lane, gf.clip, gf.enabled, gf.x, gf.F);
   for (int c0 = pbeg; c0 < pend; c0 += 64) {
     const int p = c0 + lane;
     const bool valid = p < pend;
@@ -758,41 +760,7 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
   const BwdFuse fz = a.fz;
   BwdLds& L = *reinterpret_cast<BwdLds*>(smem_raw);
   NM_PH_DECL
-  if (wperm) {
-    static_assert(offsetof(BwdLds, Z) == NM_PERM_ALL * sizeof(float), "P0..Q2 must be contiguous in operand order");
-    if (ACT) {      // only the first layer is recomputed: its operands + the transposed ones
-      stage_permuted<16 * 64>(wperm, L.P0);
-      stage_permuted<NM_PERM_ALL - NM_PERM_FWD>(wperm + NM_PERM_FWD, L.Q0);
-    } else {
-      stage_permuted<NM_PERM_ALL>(wperm, L.P0);
-    }
-    __syncthreads();
-  } else {
-    float* raw = &L.Z[0][0];   // the per-wave buffers (>= 22 016 floats) are free until the main loop
-    stage_raw_weights(w0, w1, w2, raw);
-    __syncthreads();
-    stage_fwd_weights(raw, L.P0, L.P1, L.P2);
-    stage_bwd_weights(raw, L.Q0, L.Q1, L.Q2);
-    __syncthreads();
-  }
-  NM_PH(0)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int j = lane & 15, g = lane >> 4;
-  float* zb = L.Z[wave];
-  float* gyb = L.GY[wave];
-  float* yb = L.Y[wave];
-  float* gzb = L.GZ[wave];
-  float* ta = L.TA[wave];
-  float* tb = L.TB[wave];
-  float* tc = L.TC[wave];
-  const f4 zero = {0.f, 0.f, 0.f, 0.f};
-  f4 gW1[4][4], gW0[4], gW2[4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    gW0[a] = zero; gW2[a] = zero;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) gW1[a][b] = zero;
-  }
   const int pbeg = min(n, (blockIdx.x * 4 + wave) * q), pend = min(n, pbeg + q);   // see nm_wave_quota
   // A round's loads - F, dL/dout, trial C', the SVD factors, the activation record of its first tile - are issued ONE ROUND AHEAD
   // (round 4): the wave is alone on its SIMD, and a round that started with its own loads sat through their whole HBM round trip
@@ -821,8 +789,44 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
       for (int k = 0; k < NM_ACT_SLOTS; ++k) o.nx[k] = __builtin_nontemporal_load(&at_[k * 64]);
     }
   };
+  // ... and the FIRST round's are issued here, in front of the weight staging: its round trip hides theirs
   RoundIn ahead;
   if (pbeg < pend) load_round(pbeg, ahead);
+  NM_SB();
+  if (wperm) {
+    static_assert(offsetof(BwdLds, Z) == NM_PERM_ALL * sizeof(float), "P0..Q2 must be contiguous in operand order");
+    if (ACT) {      // only the first layer is recomputed: its operands + the transposed ones
+      stage_permuted<16 * 64>(wperm, L.P0);
+      stage_permuted<NM_PERM_ALL - NM_PERM_FWD>(wperm + NM_PERM_FWD, L.Q0);
+    } else {
+      stage_permuted<NM_PERM_ALL>(wperm, L.P0);
+    }
+    __syncthreads();
+  } else {
+    float* raw = &L.Z[0][0];   // the per-wave buffers (>= 22 016 floats) are free until the main loop
+    stage_raw_weights(w0, w1, w2, raw);
+    __syncthreads();
+    stage_fwd_weights(raw, L.P0, L.P1, L.P2);
+    stage_bwd_weights(raw, L.Q0, L.Q1, L.Q2);
+    __syncthreads();
+  }
+  NM_PH(0)
+  const int j = lane & 15, g = lane >> 4;
+  float* zb = L.Z[wave];
+  float* gyb = L.GY[wave];
+  float* yb = L.Y[wave];
+  float* gzb = L.GZ[wave];
+  float* ta = L.TA[wave];
+  float* tb = L.TB[wave];
+  float* tc = L.TC[wave];
+  const f4 zero = {0.f, 0.f, 0.f, 0.f};
+  f4 gW1[4][4], gW0[4], gW2[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    gW0[a] = zero; gW2[a] = zero;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) gW1[a][b] = zero;
+  }
   for (int c0 = pbeg; c0 < pend; c0 += 64) {
     const int p = c0 + lane;
     const bool valid = p < pend;
