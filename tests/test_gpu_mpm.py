@@ -67,7 +67,7 @@ def test_backward_one_step(bc):
     og = torch.autograd.grad(ol, oins)
     names = ["x", "v", "C", "F", "stress"]
     for nme, a, b in zip(names, grads, og):
-        parity(f"one-step adjoint N=4096 G=32 {bc} vs fp64 autograd of the oracle", f"dL/d{nme} (rel)", rel_max(a, b), 5e-6)      # measured <= 6e-7
+        parity(f"one-step adjoint N=4096 G=32 {bc} vs fp64 autograd of the oracle", f"dL/d{nme} (rel)", rel_max(a, b), 8e-6)      # measured: dL/dx 2.5e-6, the others <= 4e-7
         assert torch.isfinite(a).all()
     assert (grads[0].cpu()[en == 0] == 0).all() and (grads[4].cpu()[en == 0] == 0).all()
 
