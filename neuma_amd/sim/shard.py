@@ -246,8 +246,20 @@ class GridExchange(object):
                 idt = dev_id.cpu()
                 h = C.c_void_p()
                 with torch.cuda.device(self.device):
-                    L.check(lib.nm_rccl_create(C.c_void_p(idt.data_ptr()), self.world, self.rank, C.byref(h)), "nm_rccl_create")
-                self._rccl = h
+                    rc = lib.nm_rccl_create(C.c_void_p(idt.data_ptr()), self.world, self.rank, C.byref(h))
+                # every rank uses the library's communicator or none does: a rank on which it could not be created (no RCCL
+                # to bind, ncclCommInitRank failed) must not leave the others waiting inside a collective it never issues
+                ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=self.device)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+                if int(ok.item()) == 1:
+                    self._rccl = h
+                else:
+                    import warnings
+                    why = (lib.nm_last_error() or b"").decode() if rc else "another rank could not create it"
+                    warnings.warn(f"library-owned RCCL communicator not available ({why}): the sharded roll-out's collectives go "
+                                  f"through torch.distributed callbacks")
+                    if rc == 0:
+                        lib.nm_rccl_destroy(h)
         return self._rccl or None
 
     # -- sizing (first substep only: two host reads + two tiny collectives)
