@@ -463,6 +463,9 @@ def main():
                              "the simulation of frame f+1) + one reverse sweep; finetune.py:331-414",
                      args.workload: measure_epoch(rt, args.epoch_frames, fps)}
             if args.workload != "bb":
+                from neuma_amd import rollout as _R
+                _R._POOL.clear()                 # (the first epoch's pooled cache buffers would count towards the second one's peak)
+                torch.cuda.empty_cache()
                 rt_bb = SceneRuntime(synth.make_scene("bb"), dev)
                 rt_bb.make_ground_truth()
                 for _ in range(20):
