@@ -446,16 +446,16 @@ __device__ __forceinline__ void wg_scatter_f64(const MpmK& K, bool en, int lp, c
   SC_PH(2)
   const int ny = gn[1], nz = gn[2];
   {
-    // Lanes l and l ^ 16 hold two CONSECUTIVE particles (scatter_particle) - in a cell-ordered list usually two members of one
-    // cell, i.e. the same 27 nodes.  Such a pair adds its values once: v + v(lane ^ 16) by a row swap (v_permlane16_swap, two
-    // instructions), issued by the even row; a pair that straddles two cells (or holds a disabled particle) adds separately.
-    // Half the atomic lanes for three VALU instructions per value; the decision is per pair, so a stale order only loses the
-    // saving, never a contribution.
+    // Lanes l and l ^ 1 hold two CONSECUTIVE particles (scatter_particle) - in a cell-ordered list usually two members of one
+    // cell, i.e. the same 27 nodes.  Such a pair adds its values once: v + v(lane ^ 1) by a quad-permute DPP move (one or two
+    // instructions; the row swap of the first version cost five with its register copies, and the merge was half of the
+    // phase's instructions), issued by the even lane; a pair that straddles two cells (or holds a disabled particle) adds
+    // separately.  Half the atomic lanes; the decision is per pair, so a stale order only loses the saving, never a contribution.
     const int ci = goff + ((base[0] - go[0]) * ny + (base[1] - go[1])) * nz + (base[2] - go[2]);
     const int key = en ? ci : -1 - lane;        // (never equal to the partner's)
-    auto rk = __builtin_amdgcn_permlane16_swap((unsigned)key, (unsigned)key, false, false);
-    const bool paired = en && !NM_DBG_BIT(K, 128) && (int)rk[0] == (int)rk[1];      // the two rows of the pair hold the same cell
-    const bool issue = en && !(paired && (lane & 16));
+    const int pkey = __builtin_amdgcn_update_dpp(0, key, 0xB1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]: lane ^ 1
+    const bool paired = en && !NM_DBG_BIT(K, 128) && pkey == key;      // both lanes of the pair hold the same cell
+    const bool issue = en && !(paired && (lane & 1));
     double* a0 = acc + ci;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -468,9 +468,8 @@ __device__ __forceinline__ void wg_scatter_f64(const MpmK& K, bool en, int lp, c
           float v[4] = {c.x, c.y, c.z, c.w};
 #pragma unroll
           for (int ch = 0; ch < NCH; ++ch) {
-            auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[ch]), __float_as_uint(v[ch]), false, false);
-            const float both = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-            v[ch] = paired ? both : v[ch];
+            const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[ch]), 0xB1, 0xf, 0xf, true));
+            v[ch] = paired ? v[ch] + other : v[ch];
           }
           if (issue) {
             unsafeAtomicAdd(row + k, (double)v[0]);
@@ -860,13 +859,14 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, int lp, const
   SC_STORE(sc_pass)
 }
 
-// Which particle of its workgroup a thread of the scatter kernels takes.  fp64-atomic mode: thread t takes particle
-// 16 (t % 16) + t / 16, so that the sixteen lanes one LDS cycle serves hold particles sixteen apart in the (cell-ordered)
-// list - sixteen different cells, no same-address serialisation inside the atomic instruction (2x on the atomic phase,
-// tools/ubench_lds_int.hip).  The sort path re-orders the particles in LDS anyway and keeps thread = particle.
+// Which particle of its workgroup a thread of the scatter kernels takes.  fp64-atomic mode: lanes 2m and 2m + 1 take two
+// CONSECUTIVE particles (they usually share a cell and then add once, wg_scatter_f64), and the eight pairs inside a group of 16
+// lanes - what one LDS cycle serves - are 32 particles apart in the (cell-ordered) list: different cells, no same-address
+// serialisation inside the atomic instruction (2x on the atomic phase, tools/ubench_lds_int.hip).  The sort path re-orders
+// the particles in LDS anyway and keeps thread = particle.
 __device__ __forceinline__ int scatter_particle(const MpmK& K, int t) {
   static_assert(NM_SC_T == 256, "the permutation is written for 256-particle workgroups");
-  return (K.smode == 1 && !NM_DBG_BIT(K, 64)) ? (((t & 15) << 4) | (t >> 4)) : t;
+  return (K.smode == 1 && !NM_DBG_BIT(K, 64)) ? ((((t & 15) >> 1) << 5) | ((t >> 4) << 1) | (t & 1)) : t;
 }
 
 // ---------------------------------------------------------------- kernels
