@@ -72,6 +72,7 @@ static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
                                       // chip-load of work (256 CUs x 8 workgroups x 1024 entries)
 
 struct PairLog { uint32_t cell, rank, id, mask; };
+#define NM_BC_OWN 2048       // k_bin_count: pairs of a wave whose owner lane is tabulated (beyond: binary search)
 // Compositing record of one Gaussian (k_preprocess): everything the per-tile loops need, in one 64-byte line that a wave
 // fetches with SCALAR loads - the operands are the same for all 64 lanes (one Gaussian against 64 pixels), so they belong in
 // SGPRs, not in LDS: as wave-uniform LDS broadcasts (36 B per wave and Gaussian, 24 waves per CU on one LDS pipe) they were
@@ -420,6 +421,16 @@ __device__ __forceinline__ int slab_of(float z, uint32_t zmin_bits, uint32_t zma
   return min(NM_NS - 1, max(0, s));
 }
 
+#ifdef NM_PHASES
+__device__ unsigned long long g_bc_phase[8];
+extern "C" int nm_debug_bincount(unsigned long long* out, int reset) {
+  if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; return hipMemcpyToSymbol(HIP_SYMBOL(g_bc_phase), z, sizeof(z)) == hipSuccess ? 0 : -2; }
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bc_phase), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+#define BC_T(i) { const long long t1_ = clock64(); bc_acc[i] += t1_ - bc_t0; bc_t0 = t1_; }
+#else
+#define BC_T(i)
+#endif
 // Count pass of the binning: one thread per Gaussian.  For every 64x64-pixel bin its 3-sigma tile rectangle (clipped to this
 // rank's tile rows) overlaps, the exact conic test is run on the bin's 16 tiles; a pair with a non-empty tile mask takes a
 // rank in its (bin, depth slab) cell (one integer atomic on the cell's counter) and is appended to the pair log (slots of a
@@ -433,6 +444,9 @@ __global__ void __launch_bounds__(256) k_bin_count(RK k, int K, int nbx, const i
   __shared__ TileCull s_tc[4][64];
   __shared__ int4 s_geo[4][64], s_bin[4][64];
   const int lane = threadIdx.x & 63;
+#ifdef NM_PHASES
+  long long bc_t0 = clock64(), bc_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   uint32_t zlo = 0x7f800000u, zhi = 0u;
   for (int q = threadIdx.x; q < nrange; q += 256) { const uint2 z = zrange[q]; zlo = min(zlo, z.x); zhi = max(zhi, z.y); }
 #pragma unroll
@@ -444,6 +458,7 @@ __global__ void __launch_bounds__(256) k_bin_count(RK k, int K, int nbx, const i
   __syncthreads();
   zlo = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
   zhi = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
+  BC_T(0)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   int x0 = 0, y0 = 0, x1 = 0, y1 = 0, slab = 0;
   TileCull tc = {0.f, 0.f, 1.f, 0.f, 1.f, 0.f, 0.f, -1.f};
@@ -466,6 +481,7 @@ __global__ void __launch_bounds__(256) k_bin_count(RK k, int K, int nbx, const i
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
   const int wave_total = __shfl(incl, 63, 64);
+  BC_T(1)
   // ONE reservation per workgroup: every returning atomic on this one word queues behind all the others (~12 ns each;
   // one per wave was 3 k of them per view)
   __shared__ uint32_t s_wtot[4], s_wgbase;
@@ -478,6 +494,7 @@ __global__ void __launch_bounds__(256) k_bin_count(RK k, int K, int nbx, const i
   __syncthreads();
   uint32_t base = s_wgbase;
   for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += s_wtot[w];
+  BC_T(2)
   // ---- the wave's pairs are spread over its lanes, one pair per lane and round: a thread that walked the bins of ITS
   //      Gaussian waited for one returning atomic per bin, one after the other (up to 25 round trips, and the wave waits
   //      for its longest lane: 146 us).  Now 64 atomics are in flight per round, the rounds are balanced, and the log is
@@ -487,13 +504,33 @@ __global__ void __launch_bounds__(256) k_bin_count(RK k, int K, int nbx, const i
   s_tc[wv][lane] = tc;
   s_geo[wv][lane] = make_int4(x0, y0, x1, y1);
   s_bin[wv][lane] = make_int4(bx0, by0, nbw, slab);
+  // Round 4 (phase counters, tools/exp_bincount_phases.py: owner search 23 % of a wave's cycles, waiting for the rank atomic 38 %):
+  //  * the owner lane of every pair is tabulated once per wave (each lane writes its own index over its stretch of the wave's
+  //    pair sequence) instead of being searched for per pair - six dependent LDS reads per pair and round;
+  //  * a round's log entry is written one round LATER, behind the next round's atomic: the returning atomic's round trip (several
+  //    us when a view's 1.15 M of them are in flight) then runs under the next round's tile tests instead of in front of them.
+  __shared__ unsigned char s_owner[4][NM_BC_OWN];
+  for (int q = 0; q < mine; ++q) {
+    const int at_ = incl - mine + q;
+    if (at_ < NM_BC_OWN) s_owner[wv][at_] = (unsigned char)lane;
+  }
   __builtin_amdgcn_wave_barrier();
-  for (int p0 = 0; p0 < wave_total; p0 += 64) {
+  BC_T(3)
+  // (two entries in flight, alternating: a register COPY of an entry whose atomic has not returned would wait for it)
+  auto round = [&](int p0, PairLog& e, long long& at) {
     const int pr = p0 + lane;
+    at = -1;
+    e.cell = 0xffffffffu; e.rank = 0u; e.id = 0u; e.mask = 0u;
     if (pr < wave_total) {
-      int lo_ = 0, hi_ = 64;                       // owner: the last lane whose exclusive prefix is <= pr
+      int lo_;
+      if (pr < NM_BC_OWN) {
+        lo_ = (int)s_owner[wv][pr];
+      } else {                                     // (a wave with more pairs than the table holds: search)
+        lo_ = 0;
+        int hi_ = 64;
 #pragma unroll
-      for (int it = 0; it < 6; ++it) { const int mid = (lo_ + hi_) >> 1; if (s_excl[wv][mid] <= pr) lo_ = mid; else hi_ = mid; }
+        for (int it = 0; it < 6; ++it) { const int mid = (lo_ + hi_) >> 1; if (s_excl[wv][mid] <= pr) lo_ = mid; else hi_ = mid; }
+      }
       const int q = pr - s_excl[wv][lo_];
       const int4 g = s_geo[wv][lo_], bn = s_bin[wv][lo_];
       const TileCull t = s_tc[wv][lo_];
@@ -502,16 +539,35 @@ __global__ void __launch_bounds__(256) k_bin_count(RK k, int K, int nbx, const i
       for (int ty = max(g.y, by * NM_BT); ty < min(g.w, by * NM_BT + NM_BT); ++ty)
         for (int tx = max(g.x, bx * NM_BT); tx < min(g.z, bx * NM_BT + NM_BT); ++tx)
           m |= tile_contributes(t, tx, ty) ? (1u << ((ty - by * NM_BT) * NM_BT + (tx - bx * NM_BT))) : 0u;
-      PairLog e;
-      e.cell = 0xffffffffu; e.rank = 0u; e.id = (uint32_t)(blockIdx.x * blockDim.x + (wv << 6) + lo_); e.mask = m;
+      e.id = (uint32_t)(blockIdx.x * blockDim.x + (wv << 6) + lo_); e.mask = m;
       if (m) {
         e.cell = (uint32_t)((by * nbx + bx) * NM_NS + bn.w);
         e.rank = atomicAdd(&pad[(size_t)e.cell * NM_PAD], 1u);
       }
-      const long long at = (long long)base + pr;
-      if (at < cap) log[at] = e;
+      at = (long long)base + pr;
     }
+  };
+  PairLog ea, eb;
+  long long ata = -1, atb = -1;
+  for (int p0 = 0; p0 < wave_total; p0 += 128) {
+    round(p0, ea, ata);
+    BC_T(4)
+    if (atb >= 0 && atb < cap) log[atb] = eb;      // the PREVIOUS round's entry: its atomic has had a round to return
+    atb = -1;
+    BC_T(5)
+    if (p0 + 64 < wave_total) {
+      round(p0 + 64, eb, atb);
+      BC_T(4)
+    }
+    if (ata >= 0 && ata < cap) log[ata] = ea;
+    BC_T(5)
   }
+  if (atb >= 0 && atb < cap) log[atb] = eb;
+  BC_T(6)
+#ifdef NM_PHASES
+  if (lane == 0) for (int q = 0; q < 7; ++q) atomicAdd(&g_bc_phase[q], (unsigned long long)bc_acc[q]);
+  if (lane == 0) atomicAdd(&g_bc_phase[7], 1ull);
+#endif
 }
 
 // padded counters -> compact array; per-bin totals (one workgroup per bin, one thread per depth slab)
