@@ -169,7 +169,15 @@ def cpu_rows(rank, world, port, q):
             p2.grad = torch.ones(2, 2)              # the other rank has no gradient for p2 yet
         reduce_param_grads([p, p2])
         ok_par = bool(torch.allclose(p.grad, torch.full((4,), float(scale))) and torch.allclose(p2.grad, torch.ones(2, 2)))
-        q.put({"rank": rank, "ok": [ok_fwd, ok_bwd, ok_sum, ok_par]})
+        # start-up calibration of the shard decision (bench.py): the all-reduce timer through torch.distributed (gloo here), and
+        # the decision taken from the maxima over the ranks - every rank must decide alike
+        from neuma_amd.sim.shard import time_all_reduce_us, shard_cost_model
+        ar = time_all_reduce_us(None, "cpu", count=1 << 10, reps=3)
+        vals = torch.tensor([223.0 + rank, 147.5 - rank, ar], dtype=torch.float64)
+        dist.all_reduce(vals, op=dist.ReduceOp.MAX)
+        cost = shard_cost_model(100_000, world, 20, dict(substep_us_full=float(vals[0]), substep_us_shard=float(vals[1]), allreduce_us=float(vals[2])))
+        ok_cal = bool(ar > 0.0 and cost["inputs"] == "measured at start-up" and float(vals[0]) == 223.0 + world - 1)
+        q.put({"rank": rank, "ok": [ok_fwd, ok_bwd, ok_sum, ok_par, ok_cal], "decision": bool(cost["shard"]), "sharded_us": cost["sharded_us"]})
         dist.destroy_process_group()
     except Exception as e:
         import traceback

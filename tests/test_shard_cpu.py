@@ -30,6 +30,8 @@ def test_two_rank_gloo_gather_rows_and_param_grads():
     for r in res:
         assert "error" not in r, r
         assert all(r["ok"]), r
+    # the calibrated shard decision is the same on both ranks (it is taken from the maxima over the ranks)
+    assert res[0]["decision"] == res[1]["decision"] and res[0]["sharded_us"] == res[1]["sharded_us"]
 
 
 def _run(target, world):
