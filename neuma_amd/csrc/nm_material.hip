@@ -1154,6 +1154,20 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
   // private LDS region (the weights and per-wave buffers are dead by now), then the workgroup sums the four copies.
   // (LDS float atomics would serialise here: ds_add_f32 sustains ~0.3 lanes/clk/CU on gfx950, i.e. ~70k cycles for the
   // 24 576 lane-adds, against ~3k for this.)
+  // want_w == 2: add to the partial this workgroup wrote in earlier launches (the roll-out sums over substeps and
+  // reduces once); the order of additions is fixed, so the result stays deterministic.  All of a thread's old values are
+  // requested HERE, in front of the LDS staging: the rolled read-add-write loop this replaces paid one L2 round trip per
+  // iteration - 22 in a row at the end of every net, with nothing else left on the SIMD to hide them (round 5: the
+  // ~15 k cycles per net that no phase counter covered).
+  constexpr int WPER = (NM_WTOT + 255) / 256;
+  float* dst = wpart + (size_t)blockIdx.x * NM_WTOT;
+  float prev[WPER];
+#pragma unroll
+  for (int k = 0; k < WPER; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    prev[k] = (want_w == 2 && i < NM_WTOT) ? dst[i] : 0.f;
+  }
+  NM_SB();
   __syncthreads();
   static_assert(sizeof(BwdLds) >= 4 * NM_WTOT * sizeof(float), "four weight-gradient copies must fit");
   float* red = reinterpret_cast<float*>(smem_raw) + wave * NM_WTOT;
@@ -1175,13 +1189,14 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
       if (row < 9) red[NM_W0 + NM_W1 + row * 64 + 16 * ctp + j] = gW2[ctp][r];
     }
   __syncthreads();
-  // want_w == 2: add to the partial this workgroup wrote in earlier launches (the roll-out sums over substeps and
-  // reduces once); the order of additions is fixed, so the result stays deterministic
   const float* all = reinterpret_cast<const float*>(smem_raw);
-  float* dst = wpart + (size_t)blockIdx.x * NM_WTOT;
-  for (int i = threadIdx.x; i < NM_WTOT; i += blockDim.x) {
-    float v = (all[i] + all[NM_WTOT + i]) + (all[2 * NM_WTOT + i] + all[3 * NM_WTOT + i]);
-    dst[i] = want_w == 2 ? dst[i] + v : v;
+#pragma unroll
+  for (int k = 0; k < WPER; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    if (i < NM_WTOT) {
+      const float v = (all[i] + all[NM_WTOT + i]) + (all[2 * NM_WTOT + i] + all[3 * NM_WTOT + i]);
+      dst[i] = prev[k] + v;      // (prev = 0 unless want_w == 2; x + 0 is exact)
+    }
   }
 }
 
