@@ -249,10 +249,27 @@ __device__ __forceinline__ void stage_fwd_weights(const float* raw, float* P0, f
     P1[NM_WIDX(idx)] = w1[(16 * rt + (l & 15)) * NM_RLD + 16 * rtp + 4 * (l >> 4) + reg];
   }
 }
-// Prepared weights (nm_material_prepare): P0 | P1 | P2 in MFMA operand order for the forward kernels (NM_PERM_FWD floats,
-// staged into LDS with a straight 16-byte copy), then the reverse kernels' weight vectors (NM_WVEC floats, see "backward").
+__device__ __forceinline__ void stage_bwd_weights(const float* raw, float* Q0, float* Q1, float* Q2) {
+  const float *w0 = raw, *w1 = raw + NM_RAW1, *w2 = raw + NM_RAW2;
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < 12 * 64; idx += blockDim.x) {
+    int l = idx & 63, op = idx >> 6, ks = op >> 2, rt = op & 3, row = 4 * ks + (l >> 4);
+    Q2[NM_WIDX(idx)] = row < 9 ? w2[row * NM_RLD + 16 * rt + (l & 15)] : 0.f;
+  }
+  for (int idx = tid; idx < 16 * 64; idx += blockDim.x) {
+    int l = idx & 63, op = idx >> 6, reg = op & 3, rtp = op >> 2, col = l & 15;
+    Q0[NM_WIDX(idx)] = col < 13 ? w0[(16 * rtp + 4 * (l >> 4) + reg) * 13 + col] : 0.f;
+  }
+  for (int idx = tid; idx < 64 * 64; idx += blockDim.x) {
+    int l = idx & 63, op = idx >> 6, rt = op & 3, reg = (op >> 2) & 3, rtp = op >> 4;
+    Q1[NM_WIDX(idx)] = w1[(16 * rtp + 4 * (l >> 4) + reg) * NM_RLD + 16 * rt + (l & 15)];
+  }
+}
+
+// Weights already in MFMA operand order (nm_material_prepare): P0 | P1 | P2 | Q0 | Q1 | Q2, NM_PERM_FWD floats for the
+// forward operands, NM_PERM_ALL with the transposed ones.  Staging is then a straight 16-byte copy.
 #define NM_PERM_FWD (16 * 64 + 64 * 64 + 16 * 64)
-#define NM_PERM_ALL (NM_PERM_FWD + 188 * 64)
+#define NM_PERM_ALL (NM_PERM_FWD + 16 * 64 + 64 * 64 + 12 * 64)
 template <int NFLOAT>
 __device__ __forceinline__ void stage_permuted(const float* __restrict__ wperm, float* dst) {
   constexpr int NV = NFLOAT / 4, PER = (NV + 255) / 256;
@@ -268,33 +285,20 @@ __device__ __forceinline__ void stage_permuted(const float* __restrict__ wperm, 
     if (i < NV) reinterpret_cast<float4*>(dst)[i] = v[k];
   }
 }
-// one workgroup: raw (out,in) weights -> prepared form in global memory (once per roll-out and net)
+// one workgroup: raw (out,in) weights -> operand order in global memory (once per roll-out and net)
 __global__ void __launch_bounds__(256) k_permute_weights(const float* __restrict__ w0, const float* __restrict__ w1,
                                                          const float* __restrict__ w2, float* __restrict__ wperm,
                                                          const float* __restrict__ w0b, const float* __restrict__ w1b,
                                                          const float* __restrict__ w2b, float* __restrict__ wpermb) {
   __shared__ float raw[NM_RAWTOT];
   if (blockIdx.x == 1) { w0 = w0b; w1 = w1b; w2 = w2b; wperm = wpermb; }     // (second net of a roll-out: same launch)
-  __shared__ float perm[NM_PERM_FWD];
+  __shared__ float perm[NM_PERM_ALL];
   stage_raw_weights(w0, w1, w2, raw);
   __syncthreads();
   stage_fwd_weights(raw, perm, perm + 16 * 64, perm + 16 * 64 + 64 * 64);
+  stage_bwd_weights(raw, perm + NM_PERM_FWD, perm + NM_PERM_FWD + 16 * 64, perm + NM_PERM_FWD + 16 * 64 + 64 * 64);
   __syncthreads();
-  for (int i = threadIdx.x; i < NM_PERM_FWD; i += 256) wperm[i] = perm[i];
-  // the reverse kernels' weight vectors (sections: NM_WV_* below), vector v of lane l at ((v / 4) * 64 + l) * 4 + v % 4
-  const float *r0 = raw, *r1 = raw + NM_RAW1, *r2 = raw + NM_RAW2;
-  for (int idx = threadIdx.x; idx < 188 * 64; idx += 256) {
-    const int v = 4 * (idx >> 8) + (idx & 3), l = (idx >> 2) & 63;
-    const int g = l >> 4, rr = (l >> 2) & 3, cc = l & 3;     // row-split forms: lane = (K quarter g, output 4 rr + cc)
-    float x = 0.f;
-    if (v < 64) x = r1[v * NM_RLD + l];
-    else if (v < 80) { const int an = v - 64, k = 16 * g + 4 * (an >> 2) + (an & 3), col = 4 * rr + cc; x = col < 13 ? r0[k * 13 + col] : 0.f; }
-    else if (v < 96) { if (v - 80 < 13) x = r0[l * 13 + (v - 80)]; }
-    else if (v < 108) { if (v - 96 < 9) x = r2[(v - 96) * NM_RLD + l]; }
-    else if (v < 172) x = r1[l * NM_RLD + (v - 108)];
-    else { const int an = v - 172, k = 16 * g + 4 * (an >> 2) + (an & 3), row = 4 * rr + cc; x = row < 9 ? r2[row * NM_RLD + k] : 0.f; }
-    wperm[NM_PERM_FWD + idx] = x;
-  }
+  for (int i = threadIdx.x; i < NM_PERM_ALL; i += 256) wperm[i] = perm[i];
 }
 
 // invariants of meta.py:197-213 for one particle: z[13], R = U V^T (also returns U, V, sigma)
@@ -377,20 +381,23 @@ __device__ __forceinline__ void a_chain(AGroup<G>& cur, const float* __restrict_
 
 // three-layer MLP on one 16-particle column tile; B operand of layer 0 comes from zrow (LDS, [particle][17]).
 // `first` holds the first A group of layer 0 (a_fetch<8>(first, P0, lane, 0), issued by the caller ahead of time).
-// ACT_OUT (activation cache of the fused roll-out): the second hidden layer's activations h2 and GELU derivatives g2 leave the
-// kernel as the records the reverse sweep's 4-particle mini-tiles consume (k_material_bwd4 below): per group of four
-// consecutive particles two float4 per lane, lane = hidden feature, component i = particle 4 q + i.  The accumulator layout
-// here is the opposite way round (lane = particle, registers = features), so the 16 x 64 block goes through two per-wave LDS
-// transposes ([feature][16 particles + pad], tA / tB) in the shadow of the last MFMA chain.
+// WITH_GRAD (reverse sweep): keeps the GELU derivatives, and the hidden activations go to LDS transposed
+// ([feature][16 particles + pad], th1 / th2) in the shadow of the next layer's MFMAs - the weight-gradient products read
+// them from there much later, so neither the writes nor the reads are ever waited for.
 struct MlpFwd {
+  f4 g1[4], g2[4];
   f4 y;
 };
-template <bool ACT_OUT>
+template <bool WITH_GRAD>
 __device__ __forceinline__ void mlp_forward_tile(const float* __restrict__ P0, const float* __restrict__ P1,
                                                  const float* __restrict__ P2, const float* zin /* 4 B operands of layer 0 */,
-                                                 int lane, AGroup<8>& first, MlpFwd& o, float* tA = nullptr, float* tB = nullptr,
-                                                 f4* __restrict__ act = nullptr /* the tile's first quad record */,
-                                                 int nquad = 4 /* quads of the tile that exist (the last tile of the array) */) {
+                                                 int lane, AGroup<8>& first, MlpFwd& o, float* th1 = nullptr, float* th2 = nullptr,
+                                                 f4* __restrict__ act = nullptr) {
+  // act != NULL (activation cache of the fused roll-out, WITH_GRAD only): the second hidden layer's activations and GELU
+  // derivatives and the output are written out in the accumulator layout itself - NM_ACT_SLOTS x 64 lanes x 16 B, slots
+  // h2[0..3], g2[4..7], y[8] - in the shadow of the last MFMA chain; the reverse sweep loads them back and recomputes only
+  // the first layer (16 of the forward pass's 96 MFMAs, half of its GELUs).  The whole record (17 slots) was measured too:
+  // the reverse sweep's tile loops then ask for 5.3 TB/s and the forward kernels write twice as much - slower overall.
   const f4 zero = {0.f, 0.f, 0.f, 0.f};
   const int j = lane & 15, g = lane >> 4;
   f4 a1[4] = {zero, zero, zero, zero};
@@ -407,13 +414,24 @@ __device__ __forceinline__ void mlp_forward_tile(const float* __restrict__ P0, c
       nm_gelu_both2((f2){a1[rt][2 * pr], a1[rt][2 * pr + 1]}, h, dh);
       hb[4 * rt + 2 * pr] = h[0];
       hb[4 * rt + 2 * pr + 1] = h[1];
+      if (WITH_GRAD) {
+        o.g1[rt][2 * pr] = dh[0];
+        o.g1[rt][2 * pr + 1] = dh[1];
+      }
     }
   f4 a2[4] = {zero, zero, zero, zero};
-  a_chain<64, 8, 3, 2>(w1g, P1, lane, hb, a2);
+  a_chain<64, 8, 3, 2>(w1g, P1, lane, hb, a2, [&]() {
+    if (WITH_GRAD && th1) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) th1[(16 * rt + 4 * g + r) * 17 + j] = hb[4 * rt + r];
+      __builtin_amdgcn_wave_barrier();   // (other lanes read these words: keep the compiler from reordering around them)
+    }
+  });
   AGroup<8> w2g;
   a_fetch<8>(w2g, P2, lane, 0);
   NM_SB();
-  f4 g2[4];
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
@@ -422,47 +440,32 @@ __device__ __forceinline__ void mlp_forward_tile(const float* __restrict__ P0, c
       nm_gelu_both2((f2){a2[rt][2 * pr], a2[rt][2 * pr + 1]}, h, dh);
       hb[4 * rt + 2 * pr] = h[0];
       hb[4 * rt + 2 * pr + 1] = h[1];
-      if (ACT_OUT) {
-        g2[rt][2 * pr] = dh[0];
-        g2[rt][2 * pr + 1] = dh[1];
+      if (WITH_GRAD) {
+        o.g2[rt][2 * pr] = dh[0];
+        o.g2[rt][2 * pr + 1] = dh[1];
       }
     }
   f4 yy[2] = {zero, zero};
   a_chain<16, 8, 1, 0>(w2g, P2, lane, hb, yy, [&]() {
-    if (ACT_OUT) {
+    if (WITH_GRAD && th2) {
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          tA[(16 * rt + 4 * g + r) * 17 + j] = hb[4 * rt + r];
-          tB[(16 * rt + 4 * g + r) * 17 + j] = g2[rt][r];
-        }
-      __builtin_amdgcn_wave_barrier();   // (other lanes read these words: keep the compiler from reordering around them)
+        for (int r = 0; r < 4; ++r) th2[(16 * rt + 4 * g + r) * 17 + j] = hb[4 * rt + r];
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (WITH_GRAD && act) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        __builtin_nontemporal_store((f4){hb[4 * rt], hb[4 * rt + 1], hb[4 * rt + 2], hb[4 * rt + 3]}, &act[rt * 64 + lane]);
+        __builtin_nontemporal_store(o.g2[rt], &act[(4 + rt) * 64 + lane]);
+      }
     }
   });
   o.y = yy[0] + yy[1];
-  if (ACT_OUT) {
-    // lane = feature now: four particles' values per quad record (the previous tile's reads of tA / tB were issued before
-    // this tile's writes - one wave, LDS in order)
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      f4 H, G;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        H[i] = tA[lane * 17 + 4 * m + i];
-        G[i] = tB[lane * 17 + 4 * m + i];
-      }
-      if (m < nquad) {     // (wave-uniform)
-        __builtin_nontemporal_store(H, &act[(2 * m) * 64 + lane]);
-        __builtin_nontemporal_store(G, &act[(2 * m + 1) * 64 + lane]);
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
+  if (WITH_GRAD && act) __builtin_nontemporal_store(o.y, &act[8 * 64 + lane]);
 }
-// activation cache of one net and substep: ceil(n / 4) quad records of 2 x 64 float4 (h2 | g2), then the net's raw output y
-// (9 floats per particle, component-major like the SVD cache) - 548 B per particle
-#define NM_ACT_QUAD 512      // floats per quad record
+#define NM_ACT_SLOTS 9       // f4 slots per lane and 16-particle tile in the activation cache: h2[4], g2[4], y
 
 // ---------------------------------------------------------------- forward
 // Work split of the constitutive kernels: one workgroup (4 waves, one per SIMD) per CU, each wave owns q consecutive
@@ -484,8 +487,7 @@ static inline void nm_wave_quota(int n, int& grid, int& q) {
 template <int KIND, bool ACT>
 __device__ __forceinline__ M3 material_fwd_round(const M3& Fp, bool valid, int n, int p, int c0, int ntile, int lane, float alpha,
                                                  const float* sP0, const float* sP1, const float* sP2, float* zb, float* yb,
-                                                 float* __restrict__ svd_out, f4* __restrict__ act_out, float* tA = nullptr,
-                                                 float* tB = nullptr) {
+                                                 float* __restrict__ svd_out, f4* __restrict__ act_out) {
   const int j = lane & 15, g = lane >> 4;
   M3 R, U, V;
   float z[13], s[3];
@@ -510,8 +512,8 @@ __device__ __forceinline__ M3 material_fwd_round(const M3& Fp, bool valid, int n
       AGroup<8> first;
       a_fetch<8>(first, sP0, lane, 0);
       if (ACT)
-        mlp_forward_tile<true>(sP0, sP1, sP2, zin[ct], lane, first, m, tA, tB, act_out + (size_t)((c0 >> 2) + 4 * ct) * (NM_ACT_QUAD / 4),
-                               ((n + 3) >> 2) - ((c0 >> 2) + 4 * ct));
+        mlp_forward_tile<true>(sP0, sP1, sP2, zin[ct], lane, first, m, nullptr, nullptr,
+                               act_out + (size_t)((c0 >> 4) + ct) * NM_ACT_SLOTS * 64);
       else
         mlp_forward_tile<false>(sP0, sP1, sP2, zin[ct], lane, first, m);
       yv[ct] = m.y;
@@ -530,11 +532,6 @@ __device__ __forceinline__ M3 material_fwd_round(const M3& Fp, bool valid, int n
   M3 X;
 #pragma unroll
   for (int i = 0; i < 9; ++i) X.m[i] = yb[lane * 9 + i];
-  if (ACT && valid) {      // the net's raw output, behind the quad records (the reverse sweep's epilogue needs it per particle)
-    float* __restrict__ ay = reinterpret_cast<float*>(act_out) + (size_t)((n + 3) >> 2) * NM_ACT_QUAD;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) __builtin_nontemporal_store(X.m[i], &ay[(size_t)i * n + p]);
-  }
   M3 Xs;
 #pragma unroll
   for (int r = 0; r < 3; ++r)
@@ -564,7 +561,6 @@ __global__ void __launch_bounds__(256) k_material_fwd(int n, int q, float alpha,
   static_assert(4 * 64 * 17 + 4 * 64 * 9 >= NM_RAWTOT, "raw weights must fit the per-wave buffers");
   float (*sZ)[64 * 17] = reinterpret_cast<float (*)[64 * 17]>(sBuf);
   float (*sY)[64 * 9] = reinterpret_cast<float (*)[64 * 9]>(sBuf + 4 * 64 * 17);
-  __shared__ float sT[ACT ? 4 * 2 * 64 * 17 : 1];      // per wave: two [feature][16 + 1] transposes of the activation records
   NM_PH_DECL
   // roll-out: the clear of the MPM substep that follows (nm_grid.h) - on workgroups of its own when CUs are to spare
   if (NM_PROLOGUE_SPLIT(pro)) return;
@@ -595,8 +591,7 @@ __global__ void __launch_bounds__(256) k_material_fwd(int n, int q, float alpha,
       Fp = m3_load(F + 9 * p);
     }
     NM_PH(1)
-    const M3 o = material_fwd_round<KIND, ACT>(Fp, valid, n, p, c0, ntile, lane, alpha, sP0, sP1, sP2, zb, yb, svd_out, act_out,
-                                               ACT ? sT + wave * 2 * 64 * 17 : nullptr, ACT ? sT + wave * 2 * 64 * 17 + 64 * 17 : nullptr);
+    const M3 o = material_fwd_round<KIND, ACT>(Fp, valid, n, p, c0, ntile, lane, alpha, sP0, sP1, sP2, zb, yb, svd_out, act_out);
     if (valid) m3_store(out + 9 * p, o);
     NM_PH(2)
   }
@@ -618,11 +613,8 @@ __global__ void __launch_bounds__(256) k_material_fwd_pair(int n, int q, float a
   __shared__ __attribute__((aligned(16))) float sBuf[4 * 64 * 17 + 4 * 64 * 9];
   float (*sZ)[64 * 17] = reinterpret_cast<float (*)[64 * 17]>(sBuf);
   float (*sY)[64 * 9] = reinterpret_cast<float (*)[64 * 9]>(sBuf + 4 * 64 * 17);
-  __shared__ float sT[ACT ? 4 * 2 * 64 * 17 : 1];
   if (NM_PROLOGUE_SPLIT(pro)) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float* tA = ACT ? sT + wave * 2 * 64 * 17 : nullptr;
-  float* tB = ACT ? tA + 64 * 17 : nullptr;
   const int pbeg = min(n, (blockIdx.x * 4 + wave) * q), pend = min(n, pbeg + q);
   // the stencil-independent loads of a round's particles (enabled, x, clip, F) are issued one round ahead - the first round's in
   // front of the weight staging -: the wave is alone on its SIMD, so a round that starts with its own loads spends their whole
@@ -645,19 +637,16 @@ __global__ void __launch_bounds__(256) k_material_fwd_pair(int n, int q, float a
     NM_SB();
     if (valid) g2p_particle<true>(gf.K, p, cur, gf.x, gf.gv, gf.xn, gf.vn, gf.Cn, Ftr, nullptr, 0, true);
     const M3 Fn = material_fwd_round<NM_PLASTICITY, ACT>(Ftr, valid, n, p, c0, ntile, lane, alpha, sPp, sPp + 16 * 64,
-                                                         sPp + 16 * 64 + 64 * 64, zb, yb, svd_p, act_p, tA, tB);
+                                                         sPp + 16 * 64 + 64 * 64, zb, yb, svd_p, act_p);
     if (valid) m3_store(F_next + 9 * p, Fn);
     const M3 S = material_fwd_round<NM_ELASTICITY, ACT>(Fn, valid, n, p, c0, ntile, lane, 0.f, sPe, sPe + 16 * 64,
-                                                        sPe + 16 * 64 + 64 * 64, zb, yb, svd_e, act_e, tA, tB);
+                                                        sPe + 16 * 64 + 64 * 64, zb, yb, svd_e, act_e);
     if (valid) m3_store(stress_next + 9 * p, S);
   }
 }
 
-// floats of one net's activation cache for n particles: quad records, then y (rounded up to whole 256-byte lines)
-size_t nm_material_act_floats(int32_t n) {
-  const size_t nn = n > 0 ? n : 1;
-  return (((nn + 3) / 4) * NM_ACT_QUAD + 9 * nn + 63) / 64 * 64;
-}
+// floats of one net's activation cache for n particles (one record per 16-particle tile)
+size_t nm_material_act_floats(int32_t n) { return (size_t)nm_div_up(n > 0 ? n : 1, 16) * NM_ACT_SLOTS * 64 * 4; }
 
 // internal (fused roll-out): wperm != NULL -> weights come pre-permuted from nm_material_prepare
 int nm_material_fwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* wperm, float* out,
@@ -729,86 +718,6 @@ extern "C" int nm_material_fwd(int32_t n, int32_t kind, float alpha, const float
 }
 
 // ---------------------------------------------------------------- backward
-// Round 5: the reverse sweep runs on 4-PARTICLE MINI-TILES with v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 blocks per
-// instruction, K = 1), not on 16-particle tiles of v_mfma_f32_16x16x4_f32.  Measured (tools/ubench_mfma4.hip, one wave per
-// SIMD): 8.4 cycles per instruction whatever the accumulator dependence = the same flops per cycle as the 16x16x4 form.
-// What the small tile buys:
-//   * the layouts line up.  A layer is D[b][i][n] += A[i] * B[b][n] with i = particle (4), 16 blocks b x 4 columns n = the
-//     64 output features, B = the weight column of input feature k in a REGISTER (lane l = W[l][k]) and A = the activation
-//     of feature k for the four particles, taken from block abid of one register by the instruction's A-broadcast
-//     (cbsz = 4).  The result holds, per register i, particle i's feature vector across the 64 lanes - exactly the operand
-//     the weight-gradient products need (gW[l][4c+i'] += h[4c+i'][p] * d[l][p] is ONE instruction per particle p and column
-//     group c, A = h's register with abid = c, B = d's register): the 136 LDS transpose accesses per 16 particles of the
-//     16x16x4 kernel (40 us of its 95 at the metric workload went to the weight-gradient phases) are gone, as is the padding
-//     (K = 13 and N = 9 cost 13 and 9 instructions, not 16), and the weights never touch LDS;
-//   * between layers the activations need lane <-> register transposed inside every quad: 8 DPP moves + 8 selects;
-//   * the narrow layers (64 -> 9 forward, 64 -> 13 backward) split K over the four 16-lane rows (cbsz = 2: every row takes
-//     the A block of its own K quarter) and add the rows with two permlane swaps;
-//   * work is dealt in units of 4 particles: 100 000 particles are 24.4 mini-tiles per SIMD -> 25, where the 16-particle
-//     tile gave 6.1 -> 7 tiles (28 mini-tiles' worth, 131 of 1024 waves without work).
-// Weight vectors ("wvec", k_permute_weights): one 64-float vector per register, stored in groups of four interleaved per
-// lane (float4 per lane and group: a wave fetches four registers with one 16-byte LDS read).  Sections, in vectors:
-#define NM_WV_B1 0      // 64: W1 rows             lane l -> W1[k][l]
-#define NM_WV_B0 64     // 16: W0^T, row-split     vector 4a+n, lane (g, r, c) -> W0[16g+4a+n][4r+c]
-#define NM_WV_F0 80     // 13 (+3): W0 columns     lane l -> W0[l][k]
-#define NM_WV_B2 96     //  9 (+3): W2 rows        lane l -> W2[k][l]
-#define NM_WV_ACT 108   //      ... what the reverse kernels need with the activation cache
-#define NM_WV_F1 108    // 64: W1 columns          lane l -> W1[l][k]                                   (recompute mode)
-#define NM_WV_F2 172    // 16: W2, row-split form  vector 4a+n, lane (g, r, c) -> W2[4r+c][16g+4a+n]    (recompute mode)
-#define NM_WV_N 188
-#define NM_WVEC (NM_WV_N * 64)
-static_assert(NM_PERM_ALL == NM_PERM_FWD + NM_WVEC, "prepared-weight buffer = forward operands + weight vectors");
-
-template <int CBSZ>
-__device__ __forceinline__ f4 mf4(float a, float b, f4 c, int abid) {     // abid folds to a constant after unrolling
-  switch (abid) {
-#define NM_C(I) case I: return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, CBSZ, I, 0);
-    NM_C(0) NM_C(1) NM_C(2) NM_C(3)
-    default: break;
-  }
-  if (CBSZ == 4) {
-    switch (abid) {
-      NM_C(4) NM_C(5) NM_C(6) NM_C(7) NM_C(8) NM_C(9) NM_C(10) NM_C(11) NM_C(12) NM_C(13) NM_C(14) NM_C(15)
-#undef NM_C
-      default: break;
-    }
-  }
-  return c;
-}
-__device__ __forceinline__ float dpp_x1(float v) {   // lane l <- lane l ^ 1
-  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float dpp_x2(float v) {   // lane l <- lane l ^ 2
-  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true));
-}
-// out[r] at lane l = in[l & 3] ... precisely: out[r] at lane (quad, l) = in[l] at lane (quad, r) - register index and lane
-// index within the quad trade places (two butterfly steps, one per bit)
-__device__ __forceinline__ f4 quad_transpose(const f4 v, bool o0, bool o1) {
-  f4 s, t;
-  const float x0 = dpp_x1(v[1]), x1 = dpp_x1(v[0]), x2 = dpp_x1(v[3]), x3 = dpp_x1(v[2]);
-  s[0] = o0 ? x0 : v[0]; s[1] = o0 ? v[1] : x1; s[2] = o0 ? x2 : v[2]; s[3] = o0 ? v[3] : x3;
-  const float y0 = dpp_x2(s[2]), y1 = dpp_x2(s[3]), y2 = dpp_x2(s[0]), y3 = dpp_x2(s[1]);
-  t[0] = o1 ? y0 : s[0]; t[1] = o1 ? y1 : s[1]; t[2] = o1 ? s[2] : y2; t[3] = o1 ? s[3] : y3;
-  return t;
-}
-// sum over the four 16-lane rows (result in every row)
-__device__ __forceinline__ float rows_sum(float v) {
-  typedef unsigned u2 __attribute__((ext_vector_type(2)));
-  const unsigned x = __float_as_uint(v);
-  const u2 r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
-  const float s = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  const unsigned y = __float_as_uint(s);
-  const u2 q = __builtin_amdgcn_permlane32_swap(y, y, false, false);
-  return __uint_as_float(q[0]) + __uint_as_float(q[1]);
-}
-__device__ __forceinline__ void gelu4(const f4 x, f4& h, f4& dh) {
-  f2 h0, d0, h1, d1;
-  nm_gelu_both2((f2){x[0], x[1]}, h0, d0);
-  nm_gelu_both2((f2){x[2], x[3]}, h1, d1);
-  h = (f4){h0[0], h0[1], h1[0], h1[1]};
-  dh = (f4){d0[0], d0[1], d1[0], d1[1]};
-}
-
 // optional fusions used by the roll-out's reverse sweep
 struct BwdFuse {
   const float* trial_C;   // != NULL: F_in = (I + dt * trial_C) F for enabled particles (replaces a separate trial-F pass)
@@ -819,24 +728,21 @@ struct BwdFuse {
   const float* svd_in;    // != NULL: U | sigma | V of the input as the forward kernel left them (svd_store layout)
 };
 struct BwdLds {
-  float Z[4][64 * 17];        // features [particle][17] (columns 13..15 zero)
-  float GY[4][64 * 13 + 16];  // ybar     [particle][13] (rows 9..12 zero; + slack for the lanes of blocks nobody selects)
-  float GZ[4][4 * 64 * 13];   // zbar     [K quarter][particle][13]: the four row partials of (f), summed by the epilogue
-  float Y[4][64 * 9];         // forward y (recompute mode)
-  float WV[NM_WVEC];          // the net's weight vectors (NM_WV_ACT * 64 floats of it with the activation cache)
+  float P0[16 * 64], P1[64 * 64], P2[16 * 64];
+  float Q0[16 * 64], Q1[64 * 64], Q2[12 * 64];
+  float Z[4][64 * 17];    // features [particle][17]
+  float GY[4][64 * 13];   // ybar     [particle][13] (rows 9..12 zero)
+  float Y[4][64 * 9];     // forward y
+  float GZ[4][64 * 13];   // zbar     [particle][13]
+  float TA[4][64 * 17];   // [feature][16 particles + pad]: pre2bar
+  float TB[4][64 * 17];   //   h2, then pre1bar
+  float TC[4][64 * 17];   //   h1
 };
-// the four waves' weight-gradient copies at the end: W0 and W1 transposed with padded rows ([in][out + 1]: the accumulators
-// hold one OUTPUT row per lane), W2 plain
-#define NM_RED_W1 (13 * 65)
-#define NM_RED_W2 (13 * 65 + 64 * 65)
-#define NM_RED_TOT (13 * 65 + 64 * 65 + 9 * 64)
-#define NM_BWD_LDS (sizeof(BwdLds) > 4 * NM_RED_TOT * sizeof(float) ? sizeof(BwdLds) : 4 * NM_RED_TOT * sizeof(float))
-static_assert(offsetof(BwdLds, WV) >= 4 * NM_RED_TOT * sizeof(float), "the weight-gradient copies must not reach the staged weight vectors");
 
 struct BwdArgs {
   int n, q;
   float alpha;
-  const float *F, *wvec, *gout;
+  const float *F, *w0, *w1, *w2, *wperm, *gout;
   float *gF, *wpart;
   int want_w;
   BwdFuse fz;
@@ -848,35 +754,23 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
   const int n = a.n, q = a.q, want_w = a.want_w;
   const float alpha = a.alpha;
   const float* __restrict__ F = a.F;
-  const float* __restrict__ wvec = a.wvec;
+  const float *__restrict__ w0 = a.w0, *__restrict__ w1 = a.w1, *__restrict__ w2 = a.w2, *__restrict__ wperm = a.wperm;
   const float* __restrict__ gout = a.gout;
   float *__restrict__ gF = a.gF, *__restrict__ wpart = a.wpart;
   const BwdFuse fz = a.fz;
   BwdLds& L = *reinterpret_cast<BwdLds*>(smem_raw);
   NM_PH_DECL
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int bq = lane >> 2, iq = lane & 3;
-  const bool o0 = lane & 1, o1 = lane & 2;
-  const int pbeg = min(n, (blockIdx.x * 4 + wave) * q), pend = min(n, pbeg + q);   // q is a multiple of 4 (nm_bwd_quota)
-  const float* __restrict__ act_y = ACT ? reinterpret_cast<const float*>(a.act) + (size_t)((n + 3) >> 2) * NM_ACT_QUAD : nullptr;
-  // A round's loads - F, dL/dout, trial C', the SVD factors, y and the records of its first two mini-tiles - are issued ONE ROUND
-  // AHEAD: the wave is alone on its SIMD, and a round that starts with its own loads sits through their whole HBM round trip.
-  // Loads are issued in the order they are needed (vmcnt retires in order); `enabled` gates nothing - a disabled particle's
-  // values are replaced afterwards.
-  struct Rec {
-    f4 h2, g2;
-  };
+  const int pbeg = min(n, (blockIdx.x * 4 + wave) * q), pend = min(n, pbeg + q);   // see nm_wave_quota
+  // A round's loads - F, dL/dout, trial C', the SVD factors, the activation record of its first tile - are issued ONE ROUND AHEAD
+  // (round 4): the wave is alone on its SIMD, and a round that started with its own loads sat through their whole HBM round trip
+  // (the first record "took 8 k cycles to arrive", §5) four times per pair launch.  Loads are issued in the order they are
+  // needed (vmcnt retires in order); `enabled` gates nothing any more - a disabled particle's values are replaced afterwards.
   struct RoundIn {
     int en_p;
     M3 Fp, go, T, U, V;
     float s[3];
-    float y[ACT ? 9 : 1];
-    Rec r0, r1;
-  };
-  auto load_rec = [&](int quad, Rec& r) {
-    const f4* at_ = a.act + (size_t)quad * (NM_ACT_QUAD / 4) + lane;
-    r.h2 = __builtin_nontemporal_load(&at_[0]);
-    r.g2 = __builtin_nontemporal_load(&at_[64]);
+    f4 nx[ACT ? NM_ACT_SLOTS : 1];
   };
   auto load_round = [&](int c0_, RoundIn& o) {
     const int p_ = c0_ + lane;
@@ -890,81 +784,61 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
       else { o.U = m3_ident(); o.V = m3_ident(); o.s[0] = o.s[1] = o.s[2] = 1.f; }
     }
     if (ACT) {
+      const f4* at_ = a.act + (size_t)(c0_ >> 4) * NM_ACT_SLOTS * 64 + lane;
 #pragma unroll
-      for (int c = 0; c < 9; ++c) o.y[c] = valid_ ? __builtin_nontemporal_load(&act_y[(size_t)c * n + p_]) : 0.f;
-      load_rec(c0_ >> 2, o.r0);                              // (c0_ < pend: the round exists)
-      if (c0_ + 4 < pend) load_rec((c0_ >> 2) + 1, o.r1);
+      for (int k = 0; k < NM_ACT_SLOTS; ++k) o.nx[k] = __builtin_nontemporal_load(&at_[k * 64]);
     }
   };
-  // ... and the FIRST round's are issued here, in front of the weight vectors: their round trip hides behind these
+  // ... and the FIRST round's are issued here, in front of the weight staging: its round trip hides theirs
   RoundIn ahead;
   if (pbeg < pend) load_round(pbeg, ahead);
   NM_SB();
-  // the net's weights, one register per input feature: the workgroup copies the vectors to LDS once (every wave fetching
-  // them from L2 by itself kept the CU's vector-memory pipe busy for ~9 k cycles per net), a wave then picks up four
-  // registers per 16-byte read
-  {
-    constexpr int NV4 = (ACT ? NM_WV_ACT : NM_WV_N) * 16, PER = (NV4 + 255) / 256;
-    float4 v[PER];
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      const int i = threadIdx.x + 256 * k;
-      v[k] = i < NV4 ? reinterpret_cast<const float4*>(wvec)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  if (wperm) {
+    static_assert(offsetof(BwdLds, Z) == NM_PERM_ALL * sizeof(float), "P0..Q2 must be contiguous in operand order");
+    if (ACT) {      // only the first layer is recomputed: its operands + the transposed ones
+      stage_permuted<16 * 64>(wperm, L.P0);
+      stage_permuted<NM_PERM_ALL - NM_PERM_FWD>(wperm + NM_PERM_FWD, L.Q0);
+    } else {
+      stage_permuted<NM_PERM_ALL>(wperm, L.P0);
     }
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      const int i = threadIdx.x + 256 * k;
-      if (i < NV4) reinterpret_cast<float4*>(L.WV)[i] = v[k];
-    }
-  }
-  __syncthreads();
-  float wF0[16], wB2[12], wB1[64], wB0[16], wF1[ACT ? 4 : 64], wF2[ACT ? 4 : 16];
-  auto fetch4 = [&](float* dst, int vec0) {
-    const f4 t = *reinterpret_cast<const f4*>(&L.WV[((vec0 >> 2) * 64 + lane) * 4]);
-    dst[0] = t[0]; dst[1] = t[1]; dst[2] = t[2]; dst[3] = t[3];
-  };
-#pragma unroll
-  for (int k = 0; k < 64; k += 4) fetch4(wB1 + k, NM_WV_B1 + k);
-#pragma unroll
-  for (int k = 0; k < 16; k += 4) fetch4(wB0 + k, NM_WV_B0 + k);
-#pragma unroll
-  for (int k = 0; k < 16; k += 4) fetch4(wF0 + k, NM_WV_F0 + k);
-#pragma unroll
-  for (int k = 0; k < 12; k += 4) fetch4(wB2 + k, NM_WV_B2 + k);
-  if (!ACT) {
-#pragma unroll
-    for (int k = 0; k < 64; k += 4) fetch4(wF1 + k, NM_WV_F1 + k);
-#pragma unroll
-    for (int k = 0; k < 16; k += 4) fetch4(wF2 + k, NM_WV_F2 + k);
+    __syncthreads();
+  } else {
+    float* raw = &L.Z[0][0];   // the per-wave buffers (>= 22 016 floats) are free until the main loop
+    stage_raw_weights(w0, w1, w2, raw);
+    __syncthreads();
+    stage_fwd_weights(raw, L.P0, L.P1, L.P2);
+    stage_bwd_weights(raw, L.Q0, L.Q1, L.Q2);
+    __syncthreads();
   }
   NM_PH(0)
+  const int j = lane & 15, g = lane >> 4;
   float* zb = L.Z[wave];
   float* gyb = L.GY[wave];
   float* yb = L.Y[wave];
   float* gzb = L.GZ[wave];
+  float* ta = L.TA[wave];
+  float* tb = L.TB[wave];
+  float* tc = L.TC[wave];
   const f4 zero = {0.f, 0.f, 0.f, 0.f};
-  // weight-gradient accumulators: gW1[c] register i' at lane l = dW1[l][4c+i'], gW0[r] likewise (input columns 4r+i' < 13),
-  // gW2[r] register i' at lane l = dW2[4r+i'][l]
-  f4 gW1[16], gW0[4], gW2[3];
+  f4 gW1[4][4], gW0[4], gW2[4];
 #pragma unroll
-  for (int c = 0; c < 16; ++c) gW1[c] = zero;
+  for (int a = 0; a < 4; ++a) {
+    gW0[a] = zero; gW2[a] = zero;
 #pragma unroll
-  for (int c = 0; c < 4; ++c) gW0[c] = zero;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) gW2[c] = zero;
-
+    for (int b = 0; b < 4; ++b) gW1[a][b] = zero;
+  }
   for (int c0 = pbeg; c0 < pend; c0 += 64) {
     const int p = c0 + lane;
     const bool valid = p < pend;
-    const int nmini = (min(64, pend - c0) + 3) >> 2;
+    const int ntile = (min(64, pend - c0) + 15) >> 4;
+    f4 nx[ACT ? NM_ACT_SLOTS : 1];
+    const f4* act_tile = ACT ? a.act + (size_t)(c0 >> 4) * NM_ACT_SLOTS * 64 + lane : nullptr;
     M3 Fp = ahead.Fp, go = ahead.go, T = ahead.T;
     M3 R, U = ahead.U, V = ahead.V;
     float z[13], s[3] = {ahead.s[0], ahead.s[1], ahead.s[2]};
-    float yv[9];
-#pragma unroll
-    for (int c = 0; c < 9; ++c) yv[c] = ACT ? ahead.y[c] : 0.f;
-    Rec ra = ahead.r0, rb = ahead.r1;
     const bool trial = ahead.en_p != 0;
+#pragma unroll
+    for (int k = 0; k < (ACT ? NM_ACT_SLOTS : 1); ++k) nx[k] = ahead.nx[k];
     if (c0 + 64 < pend) load_round(c0 + 64, ahead);      // (wave-uniform)
     NM_SB();
     // roll-out: the forward pass fed the plasticity net I for a disabled particle (the fresh state of its next row, nm_grid.h)
@@ -979,7 +853,7 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
     else nm_features(Fp, z, R, U, V, s);
 #pragma unroll
     for (int c = 0; c < 13; ++c) zb[lane * 17 + c] = z[c];
-    zb[lane * 17 + 13] = 0.f; zb[lane * 17 + 14] = 0.f; zb[lane * 17 + 15] = 0.f; zb[lane * 17 + 16] = 0.f;
+    zb[lane * 17 + 13] = 0.f; zb[lane * 17 + 14] = 0.f; zb[lane * 17 + 15] = 0.f;
     // ybar = sym(Xbar):  elasticity Xbar = R^T g F ; plasticity Xbar = alpha R^T g
     M3 Rtg = m3_mul_tn(R, go);
     M3 Xb;
@@ -996,124 +870,218 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
     __builtin_amdgcn_wave_barrier();
     NM_PH(1)
 
-    // one mini-tile: particles c0 + 4 m .. + 3.  Register i of every f4 below = particle i, lane = feature (16 blocks x 4).
-    auto step = [&](int m, const Rec& rec) {
-      // A operands from the round's LDS rows: for the layer chains lane (block b, i) = value b of particle i ...
-      const float zA = zb[(4 * m + iq) * 17 + bq];
-      const float gyA = gyb[(4 * m + iq) * 13 + min(bq, 12)];
-      // ... and for the weight-gradient products one register per particle, lane l = value l (blocks >= 4 are never selected)
-      float zV[4], gyV[4];
-      if (want_w) {
+#pragma unroll 1
+    for (int ct = 0; ct < ntile; ++ct) {
+      // Order of the phases: every LDS operand is written at least one MFMA chain before it is read, and the first
+      // operands of a phase are fetched before the chain in front of it starts - no LDS round trip is waited for.
+      //   forward recompute (h1 -> TC under layer 1, h2 -> TB under layer 2)
+      //   (b) h2bar = W2^T ybar, pre2bar = h2bar * gelu'(pre2)        [fetch (a)]
+      //   (a) W2bar += ybar h2^T            (TB)                      [pre2bar -> TA ; fetch (d)]
+      //   (d) h1bar = W1^T pre2bar, pre1bar = h1bar * gelu'(pre1)      [fetch (c)]
+      //   (c) W1bar += pre2bar h1^T         (TA, TC)                  [pre1bar -> TB ; fetch (f)]
+      //   (f) zbar = W0^T pre1bar                                      [fetch (e)]
+      //   (e) W0bar += pre1bar z^T          (TB, Z)
+      MlpFwd m;
+      if (ACT) {
+        // first layer recomputed (16 MFMAs + 16 GELU pairs), second layer's activations, derivatives and the output loaded
+        f4 h2[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          zV[i] = zb[(4 * m + i) * 17 + min(lane, 16)];
-          gyV[i] = gyb[(4 * m + i) * 13 + min(lane, 12)];
+        for (int rt = 0; rt < 4; ++rt) { h2[rt] = nx[rt]; m.g2[rt] = nx[4 + rt]; }
+        m.y = nx[8];
+        if (ct + 1 < ntile) {
+#pragma unroll
+          for (int k = 0; k < 5; ++k) nx[k] = __builtin_nontemporal_load(&act_tile[((size_t)(ct + 1) * NM_ACT_SLOTS + k) * 64]);
         }
+        float zin[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) zin[ks] = zb[(ct * 16 + j) * 17 + 4 * ks + g];
+        AGroup<8> first;
+        a_fetch<8>(first, L.P0, lane, 0);
+        const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        f4 a1[4] = {zero4, zero4, zero4, zero4};
+        a_chain<16, 8, 3, 2>(first, L.P0, lane, zin, a1, [&]() {
+          if (want_w) {       // h2 -> TB, transposed, as the recompute path leaves it (in the shadow of the layer-0 chain)
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) tb[(16 * rt + 4 * g + r) * 17 + j] = h2[rt][r];
+            __builtin_amdgcn_wave_barrier();
+          }
+        });
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            f2 h, dh;
+            nm_gelu_both2((f2){a1[rt][2 * pr], a1[rt][2 * pr + 1]}, h, dh);
+            m.g1[rt][2 * pr] = dh[0];
+            m.g1[rt][2 * pr + 1] = dh[1];
+            if (want_w) {     // h1 -> TC
+              tc[(16 * rt + 4 * g + 2 * pr) * 17 + j] = h[0];
+              tc[(16 * rt + 4 * g + 2 * pr + 1) * 17 + j] = h[1];
+            }
+          }
+        __builtin_amdgcn_wave_barrier();
+      } else {
+        float zin[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) zin[ks] = zb[(ct * 16 + j) * 17 + 4 * ks + g];
+        AGroup<8> first;
+        a_fetch<8>(first, L.P0, lane, 0);
+        mlp_forward_tile<true>(L.P0, L.P1, L.P2, zin, lane, first, m, want_w ? tc : nullptr, want_w ? tb : nullptr);
       }
-      f4 h2, g2;
-      if (ACT) { h2 = rec.h2; g2 = rec.g2; }
-      // layer 0 (always recomputed: 13 instructions)
-      f4 a1 = zero;
 #pragma unroll
-      for (int k = 0; k < 13; ++k) a1 = mf4<4>(zA, wF0[k], a1, k);
-      f4 h1, g1;
-      gelu4(a1, h1, g1);
-      if (!ACT) {
-        const f4 t1 = quad_transpose(h1, o0, o1);
-        f4 a2 = zero;
-#pragma unroll
-        for (int b = 0; b < 16; ++b)
-#pragma unroll
-          for (int nn = 0; nn < 4; ++nn) a2 = mf4<4>(t1[nn], wF1[4 * b + nn], a2, b);
-        gelu4(a2, h2, g2);
-        const f4 t2 = quad_transpose(h2, o0, o1);
-        f4 y4 = zero;
-#pragma unroll
-        for (int aa = 0; aa < 4; ++aa)
-#pragma unroll
-          for (int nn = 0; nn < 4; ++nn) y4 = mf4<2>(t2[nn], wF2[4 * aa + nn], y4, aa);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) y4[i] = rows_sum(y4[i]);
-        if (lane < 9) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) yb[(4 * m + i) * 9 + lane] = y4[i];
-        }
+      for (int r = 0; r < 4; ++r) {
+        int row = 4 * g + r;
+        if (row < 9) yb[(ct * 16 + j) * 9 + row] = m.y[r];
       }
       NM_PH(2)
-      // (b) h2bar = W2^T ybar, pre2bar = h2bar * gelu'(pre2)
-      f4 d2 = zero;
+      const float* gyt = gyb + ct * 16 * 13;  // [particle][13]
+      // ---- (b)
+      f4 d2[4] = {zero, zero, zero, zero};
+      float w2a[2], w2b[2][4];     // (a): A = ybar [yrow][particle], B = h2 [particle][feature] via TB
+      {
+        AGroup<4> q2g;
+        a_fetch<4>(q2g, L.Q2, lane, 0);
+        float b[3];
 #pragma unroll
-      for (int r = 0; r < 9; ++r) d2 = mf4<4>(gyA, wB2[r], d2, r);
-      d2 *= g2;
-      // (a) W2bar += ybar h2^T : per particle and row group
+        for (int ks = 0; ks < 3; ++ks) b[ks] = gyt[j * 13 + 4 * ks + g];
+        if (want_w) {
+          w2a[0] = j < 9 ? gyt[g * 13 + j] : 0.f;
+#pragma unroll
+          for (int ctp = 0; ctp < 4; ++ctp) w2b[0][ctp] = tb[(16 * ctp + j) * 17 + g];
+        }
+        a_chain<12, 4, 3, 2>(q2g, L.Q2, lane, b, d2);
+      }
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) d2[rt] *= m.g2[rt];      // (vector form: packs into v_pk_mul_f32)
+      NM_PH(4)
+      AGroup<8> q1g;
+      a_fetch<8>(q1g, L.Q1, lane, 0);
+      NM_SB();
+      // ---- (a)
       if (want_w) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-          for (int r = 0; r < 3; ++r) gW2[r] = mf4<4>(gyV[i], h2[i], gW2[r], r);
+          for (int r = 0; r < 4; ++r) ta[(16 * rt + 4 * g + r) * 17 + j] = d2[rt][r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int c = ks & 1, nx = c ^ 1;
+          if (ks < 3) {
+            w2a[nx] = j < 9 ? gyt[(4 * (ks + 1) + g) * 13 + j] : 0.f;
+#pragma unroll
+            for (int ctp = 0; ctp < 4; ++ctp) w2b[nx][ctp] = tb[(16 * ctp + j) * 17 + 4 * (ks + 1) + g];
+          }
+          NM_SB();
+#pragma unroll
+          for (int ctp = 0; ctp < 4; ++ctp) gW2[ctp] = NM_MFMA(w2a[c], w2b[c][ctp], gW2[ctp]);
+          NM_SB();
+        }
       }
       NM_PH(3)
-      // (d) h1bar = W1^T pre2bar, pre1bar = h1bar * gelu'(pre1)
-      const f4 td2 = quad_transpose(d2, o0, o1);
-      f4 d1 = zero;
+      if (ACT && ct + 1 < ntile) {      // second half of the next tile's record
 #pragma unroll
-      for (int b = 0; b < 16; ++b)
+        for (int k = 5; k < NM_ACT_SLOTS; ++k) nx[k] = __builtin_nontemporal_load(&act_tile[((size_t)(ct + 1) * NM_ACT_SLOTS + k) * 64]);
+      }
+      // ---- (d)
+      f4 d1[4] = {zero, zero, zero, zero};
+      float w1a[2][4], w1b[2][4];  // (c): A = pre2bar via TA, B = h1 via TC
+      {
+        float b[16];
 #pragma unroll
-        for (int nn = 0; nn < 4; ++nn) d1 = mf4<4>(td2[nn], wB1[4 * b + nn], d1, b);
-      d1 *= g1;
-      NM_PH(4)
-      // (c) W1bar += pre2bar h1^T : per particle and column group
+        for (int rtp = 0; rtp < 4; ++rtp)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) b[4 * rtp + reg] = d2[rtp][reg];
+        if (want_w) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            w1b[0][t] = tc[(16 * t + j) * 17 + g];
+            w1a[0][t] = ta[(16 * t + j) * 17 + g];
+          }
+        }
+        a_chain<64, 8, 3, 2>(q1g, L.Q1, lane, b, d1);
+      }
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) d1[rt] *= m.g1[rt];
+      NM_PH(6)
+      AGroup<8> q0g;
+      a_fetch<8>(q0g, L.Q0, lane, 0);
+      NM_SB();
+      // ---- (c)
       if (want_w) {
+        // TB (h2) was last read by (a), whose reads were issued long before these writes (one wave: LDS is in order)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-          for (int c = 0; c < 16; ++c) gW1[c] = mf4<4>(h1[i], d2[i], gW1[c], c);
+          for (int r = 0; r < 4; ++r) tb[(16 * rt + 4 * g + r) * 17 + j] = d1[rt][r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int c = ks & 1, nx = c ^ 1;
+          if (ks < 3) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              w1b[nx][t] = tc[(16 * t + j) * 17 + 4 * (ks + 1) + g];
+              w1a[nx][t] = ta[(16 * t + j) * 17 + 4 * (ks + 1) + g];
+            }
+          }
+          NM_SB();
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int ctp = 0; ctp < 4; ++ctp) gW1[rt][ctp] = NM_MFMA(w1a[c][rt], w1b[c][ctp], gW1[rt][ctp]);
+          NM_SB();
+        }
       }
       NM_PH(5)
-      // (f) zbar = W0^T pre1bar (K split over the four rows, then summed)
-      const f4 td1 = quad_transpose(d1, o0, o1);
-      f4 dz = zero;
+      // ---- (f)
+      f4 dzz[2] = {zero, zero};
+      float w0b[2], w0a[2][4];     // (e): A = pre1bar via TB, B = z [particle][z idx] straight from Z
+      {
+        float b[16];
 #pragma unroll
-      for (int aa = 0; aa < 4; ++aa)
+        for (int rtp = 0; rtp < 4; ++rtp)
 #pragma unroll
-        for (int nn = 0; nn < 4; ++nn) dz = mf4<2>(td1[nn], wB0[4 * aa + nn], dz, aa);
-      // (the four rows hold the partial sums of their K quarters: stored as they are - the epilogue adds four values per
-      //  component once per round, which is cheaper than two cross-row swaps per register and mini-tile)
-      if ((lane & 15) < 13) {
+          for (int reg = 0; reg < 4; ++reg) b[4 * rtp + reg] = d1[rtp][reg];
+        if (want_w) {
+          w0b[0] = zb[(ct * 16 + g) * 17 + j];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) gzb[((lane >> 4) * 64 + 4 * m + i) * 13 + (lane & 15)] = dz[i];
+          for (int rt = 0; rt < 4; ++rt) w0a[0][rt] = tb[(16 * rt + j) * 17 + g];
+        }
+        a_chain<16, 8, 1, 0>(q0g, L.Q0, lane, b, dzz);
       }
-      // (e) W0bar += pre1bar z^T
+      const f4 dza = dzz[0] + dzz[1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = 4 * g + r;
+        if (row < 13) gzb[(ct * 16 + j) * 13 + row] = dza[r];
+      }
+      // ---- (e)
       if (want_w) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int ks = 0; ks < 4; ++ks) {
+          const int c = ks & 1, nx = c ^ 1;
+          if (ks < 3) {
+            w0b[nx] = zb[(ct * 16 + 4 * (ks + 1) + g) * 17 + j];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) gW0[r] = mf4<4>(zV[i], d1[i], gW0[r], r);
+            for (int rt = 0; rt < 4; ++rt) w0a[nx][rt] = tb[(16 * rt + j) * 17 + 4 * (ks + 1) + g];
+          }
+          NM_SB();
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) gW0[rt] = NM_MFMA(w0a[c][rt], w0b[c], gW0[rt]);
+          NM_SB();
+        }
+        // the next tile's forward pass overwrites TC / TB only after two of its own chains: in order behind these reads
       }
-      NM_PH(6)
-    };
-    // Two mini-tiles per trip; the records of the NEXT trip are requested at the top of this one.  (The compiler closes a
-    // loop whose loads feed the next iteration with s_waitcnt vmcnt(0) at the back edge: a record requested inside the step
-    // that consumes its predecessor was waited for ONE step - 1.2 us - after its request, i.e. every trip sat out most of an
-    // HBM round trip: a third of the wave's cycles parked.  Requested here the loads have two whole steps.)
-#pragma unroll 1
-    for (int m = 0; m < nmini; m += 2) {
-      Rec na = ra, nb = rb;
-      if (ACT) {
-        if (m + 2 < nmini) load_rec((c0 >> 2) + m + 2, na);      // (wave-uniform)
-        if (m + 3 < nmini) load_rec((c0 >> 2) + m + 3, nb);
-      }
-      NM_SB();
-      step(m, ra);
-      if (m + 1 < nmini) step(m + 1, rb);
-      ra = na; rb = nb;
     }
     __builtin_amdgcn_wave_barrier();
 
     // per-particle epilogue: gradients through R X F^T / F + alpha R X and through the invariants
     M3 X;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) X.m[i] = ACT ? yv[i] : yb[lane * 9 + i];
+    for (int i = 0; i < 9; ++i) X.m[i] = yb[lane * 9 + i];
     M3 Xs;
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -1121,8 +1089,7 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
       for (int c = 0; c < 3; ++c) Xs.m[3 * r + c] = 0.5f * (X.m[3 * r + c] + X.m[3 * c + r]);
     float zbv[13];
 #pragma unroll
-    for (int c = 0; c < 13; ++c)
-      zbv[c] = (gzb[lane * 13 + c] + gzb[(64 + lane) * 13 + c]) + (gzb[(128 + lane) * 13 + c] + gzb[(192 + lane) * 13 + c]);
+    for (int c = 0; c < 13; ++c) zbv[c] = gzb[lane * 13 + c];
     M3 Fb, Rb;
     if (KIND == NM_ELASTICITY) {
       M3 gFm = m3_mul(go, Fp);        // g F
@@ -1183,10 +1150,15 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
   NM_PH_STORE
 
   if (!want_w) return;   // (workgroup-uniform)
+  // combine the four waves' weight-gradient accumulators: every wave stores its own copy in plain (out,in) layout to a
+  // private LDS region (the weights and per-wave buffers are dead by now), then the workgroup sums the four copies.
+  // (LDS float atomics would serialise here: ds_add_f32 sustains ~0.3 lanes/clk/CU on gfx950, i.e. ~70k cycles for the
+  // 24 576 lane-adds, against ~3k for this.)
   // want_w == 2: add to the partial this workgroup wrote in earlier launches (the roll-out sums over substeps and
   // reduces once); the order of additions is fixed, so the result stays deterministic.  All of a thread's old values are
-  // requested HERE, in front of the LDS staging: a rolled read-add-write loop pays one L2 round trip per iteration - 22 in a
-  // row at the end of every net, with nothing else left on the SIMD to hide them (8.8 us of round 4's 103.8 per pair launch).
+  // requested HERE, in front of the LDS staging: the rolled read-add-write loop this replaces paid one L2 round trip per
+  // iteration - 22 in a row at the end of every net, with nothing else left on the SIMD to hide them (round 5: the
+  // ~15 k cycles per net that no phase counter covered).
   constexpr int WPER = (NM_WTOT + 255) / 256;
   float* dst = wpart + (size_t)blockIdx.x * NM_WTOT;
   float prev[WPER];
@@ -1196,36 +1168,33 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
     prev[k] = (want_w == 2 && i < NM_WTOT) ? dst[i] : 0.f;
   }
   NM_SB();
-  // combine the four waves' accumulators: every wave stores its own copy to a private LDS region (the per-wave buffers are
-  // dead by now), then the workgroup sums the four copies.  (LDS float atomics would serialise: ds_add_f32 sustains ~0.3
-  // lanes/clk/CU on gfx950.)
   __syncthreads();
-  float* red = reinterpret_cast<float*>(smem_raw) + wave * NM_RED_TOT;
+  static_assert(sizeof(BwdLds) >= 4 * NM_WTOT * sizeof(float), "four weight-gradient copies must fit");
+  float* red = reinterpret_cast<float*>(smem_raw) + wave * NM_WTOT;
 #pragma unroll
-  for (int c = 0; c < 16; ++c)
+  for (int rt = 0; rt < 4; ++rt) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) red[NM_RED_W1 + (4 * c + i) * 65 + lane] = gW1[c][i];
+    for (int r = 0; r < 4; ++r) {
+      int row = 16 * rt + 4 * g + r;
+      if (j < 13) red[row * 13 + j] = gW0[rt][r];
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
+      for (int ctp = 0; ctp < 4; ++ctp) red[NM_W0 + row * 64 + 16 * ctp + j] = gW1[rt][ctp][r];
+    }
+  }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (4 * r + i < 13) red[(4 * r + i) * 65 + lane] = gW0[r][i];
+  for (int ctp = 0; ctp < 4; ++ctp)
 #pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (4 * r + i < 9) red[NM_RED_W2 + (4 * r + i) * 64 + lane] = gW2[r][i];
+    for (int r = 0; r < 4; ++r) {
+      int row = 4 * g + r;
+      if (row < 9) red[NM_W0 + NM_W1 + row * 64 + 16 * ctp + j] = gW2[ctp][r];
+    }
   __syncthreads();
   const float* all = reinterpret_cast<const float*>(smem_raw);
 #pragma unroll
   for (int k = 0; k < WPER; ++k) {
     const int i = threadIdx.x + 256 * k;
     if (i < NM_WTOT) {
-      int src;      // plain (out, in) index i -> position in a wave's copy
-      if (i < NM_W0) { const int o = i / 13; src = (i - 13 * o) * 65 + o; }
-      else if (i < NM_W0 + NM_W1) { const int jj = i - NM_W0; src = NM_RED_W1 + (jj & 63) * 65 + (jj >> 6); }
-      else src = NM_RED_W2 + (i - NM_W0 - NM_W1);
-      const float v = (all[src] + all[NM_RED_TOT + src]) + (all[2 * NM_RED_TOT + src] + all[3 * NM_RED_TOT + src]);
+      const float v = (all[i] + all[NM_WTOT + i]) + (all[2 * NM_WTOT + i] + all[3 * NM_WTOT + i]);
       dst[i] = prev[k] + v;      // (prev = 0 unless want_w == 2; x + 0 is exact)
     }
   }
@@ -1241,8 +1210,8 @@ __global__ void __launch_bounds__(256, 1) k_material_bwd(BwdArgs a, GridPrologue
 
 // Roll-out reverse sweep: the elasticity adjoint of substep t and the plasticity adjoint of substep t-1 in ONE launch.  The
 // second only needs the first's dL/dF of the same particle (a wave owns the same particles in both), so the pair saves a
-// launch boundary - and these boundaries are expensive: the waves own a SIMD's whole register file, so the neighbouring
-// kernels cannot overlap their ramp-up / drain (~5 us).  `pro` is the grid prologue of substep t-1.
+// launch boundary - and k_material_bwd's boundaries are expensive: its waves own a SIMD's whole register file, so the
+// neighbouring kernels cannot overlap its ramp-up / drain (~5 us).  `pro` is the grid prologue of substep t-1.
 template <bool ACT>
 __global__ void __launch_bounds__(256, 1) k_material_bwd_pair(BwdArgs e, BwdArgs p, GridPrologue pro) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1286,75 +1255,61 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
   }
 }
 
-// Work split of the reverse kernels: one workgroup (4 waves, one per SIMD) per CU, each wave owns q consecutive particles,
-// q = the per-wave share rounded up to whole mini-tiles (4 particles).
-static inline void nm_bwd_quota(int n, int& grid, int& q) {
-  const int waves = NM_BWD_GRID * 4;
-  q = (n + waves - 1) / waves;
-  q = ((q + 3) / 4) * 4;
-  if (q < 4) q = 4;
-  grid = nm_div_up(n, 4 * (int64_t)q);
-  if (grid < 1) grid = 1;
-}
-// workgroups of a reverse launch: the particle workgroups + - when a grid prologue rides along and at least four CUs are to
-// spare - up to NM_PRO_WGS that only run the prologue
-static inline int nm_bwd_launch_grid(int grid, bool prologue) {
-  const int spare = NM_BWD_GRID - grid;
-  return (prologue && spare >= 4) ? grid + (spare < NM_PRO_WGS ? spare : NM_PRO_WGS) : grid;
-}
-
 // internal (also used by the fused roll-out): launch the backward kernel only.  wmode 0: no weight gradients,
 // 1: write this launch's per-workgroup partial sums to wpart, 2: add them to wpart.
 static int bwd_attr_once() {
   static bool attr_set = false;
   if (!attr_set) {
-    const int bytes = (int)NM_BWD_LDS;
-    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd<NM_ELASTICITY, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd<NM_PLASTICITY, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd_pair<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd<NM_ELASTICITY, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd<NM_PLASTICITY, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd_pair<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd<NM_ELASTICITY, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)sizeof(BwdLds)));
+    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd<NM_PLASTICITY, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)sizeof(BwdLds)));
+    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd_pair<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)sizeof(BwdLds)));
+    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd<NM_ELASTICITY, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)sizeof(BwdLds)));
+    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd<NM_PLASTICITY, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)sizeof(BwdLds)));
+    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd_pair<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)sizeof(BwdLds)));
     attr_set = true;
   }
   return NM_OK;
 }
-static BwdArgs bwd_args(int32_t n, int q, float alpha, const float* F, const float* wperm, const float* gout, float* gF, float* wpart,
-                        int wmode, const float* trial_C, const int* enabled, float dt, int flags, const float* svd_in = nullptr,
-                        const float* act = nullptr) {
+static BwdArgs bwd_args(int32_t n, int q, float alpha, const float* F, const nm_mlp* w, const float* wperm, const float* gout,
+                        float* gF, float* wpart, int wmode, const float* trial_C, const int* enabled, float dt, int flags,
+                        const float* svd_in = nullptr, const float* act = nullptr) {
   BwdArgs a;
   a.n = n; a.q = q; a.alpha = alpha; a.F = F;
-  a.wvec = wperm + NM_PERM_FWD; a.gout = gout; a.gF = gF; a.wpart = wpart; a.want_w = wmode;
+  a.w0 = w ? w->w0 : nullptr; a.w1 = w ? w->w1 : nullptr; a.w2 = w ? w->w2 : nullptr;
+  a.wperm = wperm; a.gout = gout; a.gF = gF; a.wpart = wpart; a.want_w = wmode;
   a.fz.trial_C = trial_C; a.fz.enabled = enabled; a.fz.dt = dt; a.fz.add_to_gF = flags & 1; a.fz.polar = (flags >> 1) & 1;
   a.fz.svd_in = svd_in;
   a.act = reinterpret_cast<const f4*>(act);
   return a;
 }
 
-// wperm: the net's prepared weights (nm_material_prepare), required
 int nm_material_bwd_launch(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* wperm,
                            const float* gout, float* gF, float* wpart, int wmode, const float* trial_C, const int* enabled,
                            float dt, int add_to_gF, const GridPrologue* pro, void* stream, const float* svd_in, const float* act) {
-  (void)w;
-  NM_REQUIRE(wperm, "prepared weights missing");
   GridPrologue gp;
   if (pro) gp = *pro; else { memset(&gp, 0, sizeof(gp)); }
   hipStream_t s = (hipStream_t)stream;
   int grid, q;
-  nm_bwd_quota(n, grid, q);
+  nm_wave_quota(n, grid, q);
   gp.mat_grid = grid;
-  const int launch = nm_bwd_launch_grid(grid, pro != nullptr);
+  const int launch = (pro && grid + NM_PRO_WGS <= NM_BWD_GRID) ? grid + NM_PRO_WGS : grid;
   int rc = bwd_attr_once();
   if (rc) return rc;
-  BwdArgs a = bwd_args(n, q, alpha, F, wperm, gout, gF, wpart, wmode, trial_C, enabled, dt, add_to_gF, svd_in, act);
+  BwdArgs a = bwd_args(n, q, alpha, F, w, wperm, gout, gF, wpart, wmode, trial_C, enabled, dt, add_to_gF, svd_in, act);
   if (kind == NM_ELASTICITY && act)
-    NM_LAUNCH((k_material_bwd<NM_ELASTICITY, true>), dim3(launch), dim3(256), NM_BWD_LDS, s, a, gp);
+    NM_LAUNCH((k_material_bwd<NM_ELASTICITY, true>), dim3(launch), dim3(256), sizeof(BwdLds), s, a, gp);
   else if (kind == NM_ELASTICITY)
-    NM_LAUNCH((k_material_bwd<NM_ELASTICITY, false>), dim3(launch), dim3(256), NM_BWD_LDS, s, a, gp);
+    NM_LAUNCH((k_material_bwd<NM_ELASTICITY, false>), dim3(launch), dim3(256), sizeof(BwdLds), s, a, gp);
   else if (act)
-    NM_LAUNCH((k_material_bwd<NM_PLASTICITY, true>), dim3(launch), dim3(256), NM_BWD_LDS, s, a, gp);
+    NM_LAUNCH((k_material_bwd<NM_PLASTICITY, true>), dim3(launch), dim3(256), sizeof(BwdLds), s, a, gp);
   else
-    NM_LAUNCH((k_material_bwd<NM_PLASTICITY, false>), dim3(launch), dim3(256), NM_BWD_LDS, s, a, gp);
+    NM_LAUNCH((k_material_bwd<NM_PLASTICITY, false>), dim3(launch), dim3(256), sizeof(BwdLds), s, a, gp);
   NM_LAUNCH_CHECK();
   return NM_OK;
 }
@@ -1366,30 +1321,28 @@ int nm_material_bwd_pair_launch(int32_t n, const float* F_e, const nm_mlp* we, c
                                 const float* wperm_p, float* gFtrial, float* wpart_p, int wmode_p, const float* trial_C,
                                 const int* enabled, float dt, int polar, const GridPrologue* pro, void* stream,
                                 const float* svd_in_e, const float* svd_in_p, const float* act_e, const float* act_p) {
-  (void)we; (void)wp;
-  NM_REQUIRE(wperm_e && wperm_p, "prepared weights missing");
   GridPrologue gp;
   if (pro) gp = *pro; else { memset(&gp, 0, sizeof(gp)); }
   hipStream_t s = (hipStream_t)stream;
   int grid, q;
-  nm_bwd_quota(n, grid, q);
+  nm_wave_quota(n, grid, q);
   gp.mat_grid = grid;
-  const int launch = nm_bwd_launch_grid(grid, pro != nullptr);
+  const int launch = (pro && grid + NM_PRO_WGS <= NM_BWD_GRID) ? grid + NM_PRO_WGS : grid;
   int rc = bwd_attr_once();
   if (rc) return rc;
-  BwdArgs e = bwd_args(n, q, 0.f, F_e, wperm_e, gS, gF, wpart_e, wmode_e, nullptr, nullptr, 0.f, 1 | (polar ? 2 : 0), svd_in_e, act_e);
-  BwdArgs p = bwd_args(n, q, alpha_p, F_p, wperm_p, gF, gFtrial, wpart_p, wmode_p, trial_C, enabled, dt, polar ? 2 : 0, svd_in_p, act_p);
+  BwdArgs e = bwd_args(n, q, 0.f, F_e, we, wperm_e, gS, gF, wpart_e, wmode_e, nullptr, nullptr, 0.f, 1 | (polar ? 2 : 0), svd_in_e, act_e);
+  BwdArgs p = bwd_args(n, q, alpha_p, F_p, wp, wperm_p, gF, gFtrial, wpart_p, wmode_p, trial_C, enabled, dt, polar ? 2 : 0, svd_in_p, act_p);
   if (act_e && act_p)
-    NM_LAUNCH(k_material_bwd_pair<true>, dim3(launch), dim3(256), NM_BWD_LDS, s, e, p, gp);
+    NM_LAUNCH(k_material_bwd_pair<true>, dim3(launch), dim3(256), sizeof(BwdLds), s, e, p, gp);
   else
-    NM_LAUNCH(k_material_bwd_pair<false>, dim3(launch), dim3(256), NM_BWD_LDS, s, e, p, gp);
+    NM_LAUNCH(k_material_bwd_pair<false>, dim3(launch), dim3(256), sizeof(BwdLds), s, e, p, gp);
   NM_LAUNCH_CHECK();
   return NM_OK;
 }
 // internal: gw (+)= sum of the per-workgroup partials of a launch over n particles
 int nm_material_wgrad_reduce(const float* wpart, int32_t n, float* gw0, float* gw1, float* gw2, int accumulate, void* stream) {
   int grid, q;
-  nm_bwd_quota(n, grid, q);
+  nm_wave_quota(n, grid, q);
   NM_LAUNCH(k_wgrad_reduce, dim3(nm_div_up(NM_WTOT, 64)), dim3(256), 0, (hipStream_t)stream, wpart, grid, gw0, gw1, gw2,
                      accumulate, (const float*)nullptr, (float*)nullptr);
   NM_LAUNCH_CHECK();
@@ -1398,18 +1351,16 @@ int nm_material_wgrad_reduce(const float* wpart, int32_t n, float* gw0, float* g
 // both nets of a roll-out (gw_a, gw_b: w0 | w1 | w2 back to back, overwritten) in one launch
 int nm_material_wgrad_reduce2(const float* wpart_a, const float* wpart_b, int32_t n, float* gw_a, float* gw_b, void* stream) {
   int grid, q;
-  nm_bwd_quota(n, grid, q);
+  nm_wave_quota(n, grid, q);
   NM_LAUNCH(k_wgrad_reduce, dim3(nm_div_up(NM_WTOT, 64), 2), dim3(256), 0, (hipStream_t)stream, wpart_a, grid, gw_a, gw_a + NM_W0,
             gw_a + NM_W0 + NM_W1, 0, wpart_b, gw_b);
   NM_LAUNCH_CHECK();
   return NM_OK;
 }
 
-// per-workgroup weight-gradient partials, then room for the net's prepared weights (the stand-alone operator prepares them
-// itself: one more small launch in front of the reverse kernel)
 extern "C" size_t nm_material_bwd_workspace(int32_t n) {
   (void)n;
-  return ((size_t)NM_BWD_GRID * NM_WTOT + NM_PERM_ALL) * sizeof(float);
+  return (size_t)NM_BWD_GRID * NM_WTOT * sizeof(float);
 }
 
 extern "C" int nm_material_bwd(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* gout,
@@ -1438,16 +1389,13 @@ extern "C" int nm_material_bwd_ex(int32_t n, int32_t kind, float alpha, const fl
     return NM_OK;
   }
   NM_REQUIRE(F && gout && gF && w && w->w0 && w->w1 && w->w2, "null pointer");
-  if (!workspace || workspace_bytes < nm_material_bwd_workspace(n)) {
+  if (want_w && (!workspace || workspace_bytes < nm_material_bwd_workspace(n))) {
     nm_set_error("material backward workspace too small: need %zu bytes, got %zu", nm_material_bwd_workspace(n),
                  workspace_bytes);
     return NM_ERR_WORKSPACE;
   }
-  float* wperm = (float*)workspace + (size_t)NM_BWD_GRID * NM_WTOT;
-  int rc = nm_material_prepare(w, wperm, stream);
-  if (rc) return rc;
-  rc = nm_material_bwd_launch(n, kind, alpha, F, w, wperm, gout, gF, (float*)workspace, want_w, nullptr, nullptr, 0.f,
-                              (flags & NM_BWD_POLAR_ADJOINT) ? 2 : 0, nullptr, stream);
+  int rc = nm_material_bwd_launch(n, kind, alpha, F, w, nullptr, gout, gF, (float*)workspace, want_w, nullptr, nullptr, 0.f,
+                                  (flags & NM_BWD_POLAR_ADJOINT) ? 2 : 0, nullptr, stream);
   if (rc) return rc;
   if (want_w) return nm_material_wgrad_reduce((const float*)workspace, n, gw0, gw1, gw2, accumulate, stream);
   return NM_OK;

@@ -52,18 +52,16 @@ class MaterialFunction(autograd.Function):
         gF = torch.empty_like(Fc)
         lib = L.lib()
         mlp = L.nm_mlp(L.ptr(w0), L.ptr(w1), L.ptr(w2))
-        # scratch: per-workgroup weight-gradient partials + the net's prepared weights (the reverse kernel reads its weights in
-        # its own register order; the stand-alone operator prepares them in front of every call, the fused roll-out once)
-        nbytes = int(lib.nm_material_bwd_workspace(n))
-        ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=Fc.device)
         if ctx.need_w:
             gw0, gw1, gw2 = torch.empty_like(w0), torch.empty_like(w1), torch.empty_like(w2)
+            nbytes = int(lib.nm_material_bwd_workspace(n))
+            ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=Fc.device)
             L.check(lib.nm_material_bwd_ex(n, ctx.kind, ctx.alpha, L.ptr(Fc), C.byref(mlp), L.ptr(g), L.ptr(gF), L.ptr(gw0),
                                            L.ptr(gw1), L.ptr(gw2), ctx.flags, L.ptr(ws), nbytes, L.stream_ptr(Fc.device)), "nm_material_bwd_ex")
         else:
             gw0 = gw1 = gw2 = None
             L.check(lib.nm_material_bwd_ex(n, ctx.kind, ctx.alpha, L.ptr(Fc), C.byref(mlp), L.ptr(g), L.ptr(gF), None, None, None,
-                                           ctx.flags, L.ptr(ws), nbytes, L.stream_ptr(Fc.device)), "nm_material_bwd_ex")
+                                           ctx.flags, None, 0, L.stream_ptr(Fc.device)), "nm_material_bwd_ex")
         return gF, gw0, gw1, gw2, None, None, None
 
 

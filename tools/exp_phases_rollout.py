@@ -27,10 +27,8 @@ torch.cuda.synchronize()
 fn = lib.nm_debug_phases; fn.argtypes = [C.c_void_p, C.c_int]
 buf = np.zeros(8 * 2048, dtype=np.int64)
 print("rc", fn(buf.ctypes.data, 8 * 2048), "act cache:", os.environ.get("NEUMA_ACT_CACHE", "auto"))
-b = buf.reshape(2048, 8)
-b = b[b.sum(1) > 0]
-print("waves with work", len(b))
-names = ["weight vectors -> registers", "svd+feat+ybar (per round)", "layer 0 + GELU (+ fwd recompute)", "(b) h2bar + (a) W2 grad", "(d) transpose + h1bar", "(c) W1 grad", "(f) zbar + (e) W0 grad", "epilogue (per round)"]
+b = buf.reshape(2048, 8)[:893]
+names = ["stage weights", "svd+feat+ybar", "fwd recompute / act", "(a) W2 grad", "(b) h2bar", "(c) W1 grad", "(d) h1bar", "(e,f)+epilogue"]
 for i, nm in enumerate(names):
     print(f"{nm:20s} mean {b[:, i].mean():9.0f} median {np.median(b[:, i]):9.0f} max {b[:, i].max():9.0f}")
 print("total mean", b.sum(1).mean(), "max", b.sum(1).max())
