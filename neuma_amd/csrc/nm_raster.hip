@@ -623,18 +623,38 @@ __global__ void __launch_bounds__(NM_NS) k_cell_offsets(int nbin, const uint32_t
   }
 }
 
-// Fill pass: replay of the pair log - no atomics, no geometry: slot = cell offset + rank
+// Fill pass: replay of the pair log - no atomics, no geometry: slot = cell offset + rank.  A thread takes its entries four at
+// a time: all four log reads are requested together, then the eight dependent reads (cell offset, depth), then the stores - the
+// rolled loop (one entry per trip: log -> offset / depth -> store) was two HBM round trips per entry, three to five entries per
+// thread, one after the other (35 us per view for 28 MB of traffic).
 __global__ void __launch_bounds__(256) k_bin_fill(const uint32_t* __restrict__ hdr, const PairLog* __restrict__ log,
                                                   const uint32_t* __restrict__ off, const float* __restrict__ depth,
                                                   unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals, long long cap) {
   const long long n = min((long long)hdr[2], cap);
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
-    const PairLog q = log[e];
-    if (q.cell == 0xffffffffu) continue;     // dead entry: no tile of that bin passed the conic test
-    const long long slot = (long long)off[q.cell] + q.rank;
-    if (slot < cap) {
-      keys[slot] = ((unsigned long long)__float_as_uint(depth[q.id]) << 32) | (unsigned long long)q.id;
-      vals[slot] = q.mask;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long e0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; e0 < n; e0 += 4 * stride) {
+    PairLog q[4];
+    uint32_t o[4], d[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long e = e0 + u * stride;
+      q[u].cell = 0xffffffffu;
+      if (e < n) q[u] = log[e];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool liv = q[u].cell != 0xffffffffu;      // (dead entry: no tile of that bin passed the conic test)
+      o[u] = liv ? off[q[u].cell] : 0u;
+      d[u] = liv ? __float_as_uint(depth[q[u].id]) : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (q[u].cell == 0xffffffffu) continue;
+      const long long slot = (long long)o[u] + q[u].rank;
+      if (slot < cap) {
+        keys[slot] = ((unsigned long long)d[u] << 32) | (unsigned long long)q[u].id;
+        vals[slot] = q[u].mask;
+      }
     }
   }
 }

@@ -9,15 +9,55 @@ def dev():
     return torch.device("cuda", 0)
 
 
+class Measured(float):
+    """A measured error that publishes itself when it is compared with its bound: `assert rel_max(a, b) < 3e-6` prints
+    `PARITY {case, tensor, measured, bound}` and appends it to gpurun_out/parity_measured.jsonl exactly as `parity()` does
+    (case = the running pytest item, tensor = kind + source line of the comparison), so every comparison of every GPU test is
+    in the log without a second spelling of it.  Arithmetic on the value gives a plain float (nothing is logged for it)."""
+
+    def __new__(cls, value, kind="err"):
+        obj = float.__new__(cls, value)
+        obj.kind = kind
+        return obj
+
+    def _publish(self, bound):
+        import inspect
+        import os
+        try:
+            fr = inspect.stack()[2]
+            where = f"{os.path.basename(fr.filename)}:{fr.lineno}"
+            src = (fr.code_context[0].strip() if fr.code_context else "")[:110]
+        except Exception:       # noqa: BLE001 - logging must never fail a test
+            where, src = "?", ""
+        case = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" (")[0]
+        _log({"case": case, "tensor": f"{self.kind} @ {where}: {src}", "measured": float(self), "bound": float(bound)})
+
+    def __truediv__(self, scale):         # (an error over a scale is still the measured quantity)
+        return Measured(float(self) / float(scale), self.kind + " / scale")
+
+    def __lt__(self, bound):
+        self._publish(bound)
+        return float(self) < float(bound)
+
+    def __le__(self, bound):
+        self._publish(bound)
+        return float(self) <= float(bound)
+
+
 def rel_max(a: torch.Tensor, b: torch.Tensor) -> float:
     """max-norm relative error of a (GPU fp32) against b (oracle)."""
     a = a.detach().double().cpu()
     b = b.detach().double().cpu()
-    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
+    return Measured(float((a - b).abs().max() / max(float(b.abs().max()), 1e-30)), "rel_max")
 
 
 def abs_max(a, b) -> float:
-    return float((a.detach().double().cpu() - b.detach().double().cpu()).abs().max())
+    return Measured(float((a.detach().double().cpu() - b.detach().double().cpu()).abs().max()), "abs_max")
+
+
+def measured(value, kind="err") -> float:
+    """wrap any error figure a test computes by hand so that its comparison is logged like the others"""
+    return Measured(float(value), kind)
 
 
 def mpm_case(N=4096, G=32, seed=0, bc="noslip", near_wall=True, disabled=True, dt=1e-3):
@@ -64,12 +104,17 @@ def parity(case: str, name: str, measured: float, bound: float, noise=None) -> N
     """Record one measured parity error next to the bound it is held to (and, where a fixture carries the reference's own fp32
     run, the distance of that run from its fp64 run): printed (`pytest -s`, or the captured log) and appended to
     gpurun_out/parity_measured.jsonl, from which tools/parity_table.py makes DESIGN.md's table.  Then the assertion."""
-    import json
-    import os
-    from pathlib import Path
     rec = {"case": case, "tensor": name, "measured": float(measured), "bound": float(bound)}
     if noise is not None:
         rec["reference_fp32_vs_fp64"] = float(noise)
+    _log(rec)
+    assert float(measured) <= bound, rec
+
+
+def _log(rec: dict) -> None:
+    import json
+    import os
+    from pathlib import Path
     print("PARITY " + json.dumps(rec))
     out = Path(os.environ.get("NEUMA_PARITY_LOG", Path(__file__).resolve().parent.parent / "gpurun_out" / "parity_measured.jsonl"))
     try:
@@ -78,4 +123,3 @@ def parity(case: str, name: str, measured: float, bound: float, noise=None) -> N
             fh.write(json.dumps(rec) + "\n")
     except OSError:
         pass
-    assert measured <= bound, rec

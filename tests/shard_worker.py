@@ -21,6 +21,13 @@ def _err(a, b):
     return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
 
 
+def _deformed_start(run):
+    """A start state away from F = I: at rest the invariants sigma - 1 and F^T F - I are differences of nearly equal numbers,
+    and every gradient of a frame inherits that - two runs of the SAME path differ by 3e-3 there (order of fp32 atomics),
+    against 4e-7 from this state (tools/exp_grad_noise.py)."""
+    run.set_start_state("deformed")       # F = I + 0.05 N(0, 1), the same on every rank (seeded)
+
+
 def gpu_substeps(rank, world, port, q, steps=3, cap_shared=None, cap=None):
     """`steps` chained substeps with given stresses: sharded rows vs the unsharded model, states and gradients."""
     try:
@@ -99,6 +106,7 @@ def gpu_frame(rank, world, port, q, name="tiny", fused=False, preset_caps=False)
                     if p.shape[0] in (64, 9):       # the lora_B factors
                         p.mul_(-4.0)
             run.v0.requires_grad_(True)
+            _deformed_start(run)
         r0 = ref.frame()
         r1 = rt.frame()
         tot = r1.loss.clone()
@@ -354,6 +362,7 @@ def gpu_nccl_one_rank(rank, world, port, q, name="tiny", comm="rccl"):
                     if p.shape[0] in (64, 9):
                         p.mul_(-4.0)
             run.v0.requires_grad_(True)
+            _deformed_start(run)
         r0, r1 = ref.frame(), rt.frame()
         rt.model.exchange.check()
         res = {"rank": rank, "backend": dist.get_backend(), "loss": float(r1.loss), "ref_loss": float(r0.loss),

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import binding as ob
-from gpu_util import dev
+from gpu_util import dev, measured
 
 pytestmark = pytest.mark.gpu
 
@@ -32,10 +32,13 @@ def test_binding_matches_dense_oracle(K, N, maxp, seed):
     counts, inside, cols, pv = counts.cpu().numpy(), inside.cpu().numpy(), cols.cpu().numpy(), pv.cpu().numpy()
     tol = 5e-5 * thr                                  # fp32 evaluation of p against the fp64 oracle
     checked_exact = 0
+    worst = 0.0       # Mahalanobis distances of the kept pairs against the fp64 oracle, relative (floor 2e-2: rtol 5e-5 + atol 1e-6)
     for k in range(K):
         sel = cols[k, :counts[k]]
         assert np.all(cols[k, counts[k]:] == -1) and np.all(np.diff(sel) > 0)              # ascending, padded
         assert np.allclose(pv[k, :counts[k]], p[k, sel], rtol=5e-5, atol=1e-6)
+        if counts[k]:
+            worst = max(worst, float(np.max(np.abs(pv[k, :counts[k]] - p[k, sel]) / (np.abs(p[k, sel]) + 2e-2))))
         assert np.all(p[k, sel] <= thr + tol)                                              # nothing outside the ellipsoid
         n_in_lo, n_in_hi = int((p[k] <= thr - tol).sum()), int((p[k] <= thr + tol).sum())
         assert n_in_lo <= inside[k] <= n_in_hi
@@ -49,6 +52,7 @@ def test_binding_matches_dense_oracle(K, N, maxp, seed):
         else:                                        # the kept set may differ only by candidates within tolerance
             assert len(sel) >= min(n_in_lo, maxp) and (len(sel) == 0 or p[k, sel].max() <= srt[min(maxp, N) - 1] + tol)
     assert checked_exact > 0.8 * K
+    assert measured(worst, "rel error of the kept pairs' squared distances (floor 2e-2)") < 5e-5
 
 
 def test_binding_python_api_and_prepare(tmp_path):

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import mpm as om
-from gpu_util import dev, rel_max, abs_max, mpm_case, build_model, build_statics
+from gpu_util import dev, rel_max, abs_max, measured, mpm_case, build_model, build_statics
 
 pytestmark = pytest.mark.gpu
 
@@ -61,8 +61,8 @@ def test_substep_is_invariant_under_particle_order(rt):
         a = [t.clone() for t in MPMDiffSim(rt.model, reorder=False)(rt.statics, rt.x0, v, C, F, S)]
         perm = torch.randperm(N, generator=g).to(dev())
         b = MPMDiffSim(rt.model, reorder="auto")(rt.statics, *[t[perm].contiguous() for t in (rt.x0, v, C, F, S)])
-    for x, y, tol in zip(a, b, [5e-7, 2e-5, 5e-5, 5e-6]):
-        assert abs_max(x[perm], y) < tol * max(1.0, float(x.abs().max()))
+    for x, y, tol in zip(a, b, [2e-7, 2e-7, 7e-7, 7e-7]):      # measured 6e-8 | 3e-8 | 2.1e-7 | 2.0e-7
+        assert abs_max(x[perm], y) / max(1.0, float(x.abs().max())) < tol
 
 
 def test_constitutive_nets_frame_indifference_and_plastic_flow(rt):
@@ -76,8 +76,8 @@ def test_constitutive_nets_frame_indifference_and_plastic_flow(rt):
     with torch.no_grad():
         s, sq = rt.elasticity(F), rt.elasticity(Q @ F)
         p, pq = rt.plasticity(F), rt.plasticity(Q @ F)
-    assert rel_max(sq, Q @ s @ Q.T) < 3e-4
-    assert abs_max(pq, Q @ p) < 3e-6
+    assert rel_max(sq, Q @ s @ Q.T) < 5e-6      # measured 1.1e-06
+    assert abs_max(pq, Q @ p) < 1.5e-6      # measured 3.6e-07
     assert float((p - F).abs().max()) > 1e-6          # the plasticity net is not the identity (sand: sf)
 
 
@@ -102,8 +102,8 @@ def test_fused_rollout_matches_per_operator_path(rt):
             out = rt.rollout(*ins)
             sum((o * w).sum() for o, w in zip(out, wts)).backward()
             res[fused] = ([o.detach().clone() for o in out], [t.grad.clone() for t in ins + rt.parameters()])
-        for x, y, tol in zip(res[True][0], res[False][0], [1e-6, 1e-5, 1e-3, 1e-5]):
-            assert abs_max(x, y) < tol * max(1.0, float(y.abs().max()))
+        for x, y, tol in zip(res[True][0], res[False][0], [2e-7, 3e-6, 2e-5, 3e-6]):      # measured 6e-8 | 9.8e-7 | <= 5.4e-6 over four runs | 9.8e-7
+            assert abs_max(x, y) / max(1.0, float(y.abs().max())) < tol
         for a, b in zip(res[True][1], res[False][1]):
             assert torch.isfinite(a).all() and float(b.abs().max()) > 0 and rel_max(a, b) < 3e-4
         # rest state, plain sum: the parameter gradients (sums over all particles) are well conditioned there too
@@ -115,7 +115,7 @@ def test_fused_rollout_matches_per_operator_path(rt):
             (out[0].sum() + (out[3] ** 2).sum()).backward()
             res[fused] = [p.grad.clone() for p in rt.parameters()]
         for a, b in zip(res[True], res[False]):
-            assert rel_max(a, b) < 2e-3          # (gradients of 1e-6 at rest: the stated gradient tolerance)
+            assert rel_max(a, b) < 1e-3          # (gradients of 1e-6 at rest: the stated gradient tolerance)
     finally:
         rt.S = rt.sim_fused.substeps = old
         rt.fused = True
@@ -138,17 +138,17 @@ def test_render_stripes_background_linearity_and_gradients(rt):
         y0, y1 = r0 * 16, min(H, r1 * 16)
         # (bit for bit when the stripe and the full view are composited with the same plan; a few-tile view is split into
         # list segments whose length depends on the stripe: transmittance products in another order, 2e-6)
-        assert abs_max(part[:, y0:y1], full[:, y0:y1]) < 2e-6
+        assert abs_max(part[:, y0:y1], full[:, y0:y1]) < 3e-6
         acc += part.detach()
         gacc += torch.autograd.grad((part * gw).sum(), m)[0]
-    assert abs_max(acc, full.detach()) < 2e-6 and rel_max(gacc, gfull) < 1e-4
+    assert abs_max(acc, full.detach()) < 3e-6 and rel_max(gacc, gfull) < 5e-5      # measured 1.4e-05
     bg0 = rt.background
     imgs = {}
     for name, val in (("black", 0.0), ("grey", 0.5), ("white", 1.0)):
         rt.background = torch.full((3,), val, device=dev())
         imgs[name] = rt.render_view(means, dg, 0)
     rt.background = bg0
-    assert abs_max(imgs["grey"], 0.5 * (imgs["black"] + imgs["white"])) < 2e-6        # out = C + T_final * bg
+    assert abs_max(imgs["grey"], 0.5 * (imgs["black"] + imgs["white"])) < 5e-7        # out = C + T_final * bg      # measured 1.2e-07
     assert float(full.min()) >= 0.0 and torch.isfinite(full).all() and torch.isfinite(gfull).all()
     assert float((imgs["white"] - imgs["black"]).max()) > 0.5                           # some background shows: the body does not fill the frame
 
@@ -189,11 +189,11 @@ def test_sand_plasticity_rollout_matches_oracle_chain():
     grads = torch.autograd.grad(sum((o * w.to(dev())).sum() for o, w in zip(outs, gws)), ins)
     oins = [t.detach().cpu().double().requires_grad_(True) for t in ins]
     oouts, We, Wp = _oracle_rollout(rt, S, *oins)
-    for nme, a, b, tol in zip("xvCF", outs, oouts, [5e-6, 5e-5, 1e-3, 1e-5]):
-        assert abs_max(a, b) < tol * max(1.0, float(b.abs().max())), nme
+    for nme, a, b, tol in zip("xvCF", outs, oouts, [3e-7, 3e-6, 5e-6, 1.5e-6]):      # measured 8.5e-8 | 9.5e-7 | 1.5e-6 | 3.8e-7
+        assert abs_max(a, b) / max(1.0, float(b.abs().max())) < tol, nme
     og = torch.autograd.grad(sum((o * w.double()).sum() for o, w in zip(oouts, gws)), oins)
     for nme, a, b in zip("xvCF", grads, og):
-        assert rel_max(a, b) < 5e-3, nme
+        assert rel_max(a, b) < 5e-4, nme      # measured 1.3e-04
     with torch.no_grad():       # sand really flows: the plastic correction is far above round-off
         assert float((rt.plasticity(F0) - F0).abs().max()) > 1e-5
 
@@ -219,11 +219,12 @@ def test_sh_degree_0_on_black_background_matches_oracle_image():
     om_ = means3D.cpu().double().requires_grad_(True)
     cov = orr.deform_cov_by_F(rt._cov.cpu().double(), dg.cpu().double())
     oimg, _ = orr.render(s, om_, cov, rt._opacity.cpu().double(), shs=rt._shs.cpu().double())
-    assert abs_max(img, oimg) < 1e-3 and float((img.detach().cpu().double() - oimg.detach()).abs().mean()) < 1e-5
+    assert abs_max(img, oimg) < 2e-6      # measured 6.0e-07
+    assert measured((img.detach().cpu().double() - oimg.detach()).abs().mean(), "mean abs image error") < 2e-7      # measured 2.5e-08
     gw = torch.randn(img.shape, generator=torch.Generator().manual_seed(9))
     (g,) = torch.autograd.grad((img * gw.to(dev())).sum(), m)
     (og,) = torch.autograd.grad((oimg * gw.double()).sum(), om_)
-    assert rel_max(g, og) < 2e-3
+    assert rel_max(g, og) < 7e-6      # measured 2.1e-06
 
 
 @pytest.mark.parametrize("bc", ["noslip", "freeslip"])
@@ -238,11 +239,11 @@ def test_substep_on_a_64_grid_vs_oracle(bc):
     oins = [t.detach().cpu().double().requires_grad_(True) for t in ins]
     oo = om.step(const, vol, rho, clip, en, *oins)
     e = en != 0
-    for a, b, tol, rel in zip(outs, oo, [5e-7, 2e-5, 5e-5, 5e-6], [False, True, True, False]):
+    for a, b, tol, rel in zip(outs, oo, [2e-7, 7e-7, 1.5e-6, 1e-6], [False, True, True, False]):      # measured 3e-8 | 2.0e-7 | 3.4e-7 | 2.4e-7
         err = rel_max(a[e], b[e]) if rel else abs_max(a[e], b[e])
         assert err < tol
     gws = [torch.randn(o.shape, generator=torch.Generator().manual_seed(3)) for o in outs]
     grads = torch.autograd.grad(sum((o * w.to(dev())).sum() for o, w in zip(outs, gws)), ins)
     og = torch.autograd.grad(sum((o * w.double()).sum() for o, w in zip(oo, gws)), oins)
     for a, b in zip(grads, og):
-        assert rel_max(a, b) < 2e-3
+        assert rel_max(a, b) < 1.5e-6      # measured 3.4e-07

@@ -57,8 +57,8 @@ def test_step_is_invariant_under_particle_order_at_100k(rt):
         # once through the kernels' own fall-back paths (per-wave boxes, global atomics), once through the transparent re-ordering
         for reorder in (False, "auto"):
             b = MPMDiffSim(rt.model, reorder=reorder)(rt.statics, *shuffled)
-            for x, y, tol in zip(a, b, [5e-7, 2e-5, 5e-5, 5e-6]):
-                assert abs_max(x[perm], y) < tol * max(1.0, float(x.abs().max())), reorder
+            for x, y, tol in zip(a, b, [2e-7, 2e-7, 1.5e-6, 7e-7]):      # measured 6e-8 | 6e-8 | 4.5e-7 | 1.9e-7
+                assert abs_max(x[perm], y) / max(1.0, float(x.abs().max())) < tol, reorder
 
 
 def test_constitutive_nets_are_frame_indifferent_at_100k(rt):
@@ -74,8 +74,8 @@ def test_constitutive_nets_are_frame_indifferent_at_100k(rt):
     with torch.no_grad():
         s, sq = rt.elasticity(F), rt.elasticity(Q @ F)
         p, pq = rt.plasticity(F), rt.plasticity(Q @ F)
-    assert rel_max(sq, Q @ s @ Q.T) < 2e-4
-    assert abs_max(pq, Q @ p) < 2e-6
+    assert rel_max(sq, Q @ s @ Q.T) < 2e-6      # measured 6.1e-07
+    assert abs_max(pq, Q @ p) < 1e-6      # measured 2.4e-07
 
 
 def test_render_1080p_stripes_background_linearity_and_gradient_consistency(rt):
@@ -96,18 +96,18 @@ def test_render_1080p_stripes_background_linearity_and_gradient_consistency(rt):
         y0, y1 = r0 * 16, min(H, r1 * 16)
         # (bit for bit when the stripe and the full view are composited with the same plan; a few-tile view is split into
         # list segments whose length depends on the stripe: transmittance products in another order, 2e-6)
-        assert abs_max(part[:, y0:y1], full[:, y0:y1]) < 2e-6
+        assert abs_max(part[:, y0:y1], full[:, y0:y1]) < 2e-7      # measured 0.0e+00
         acc += part.detach()
         (gp,) = torch.autograd.grad((part * gw).sum(), m)
         gacc += gp
-    assert abs_max(acc, full.detach()) < 2e-6
+    assert abs_max(acc, full.detach()) < 2e-7      # measured 0.0e+00
     assert rel_max(gacc, gfull) < 1e-4
     # out = C + T_final * bg is affine in the background colour
     bg0 = rt.background
     rt.background = torch.zeros(3, device=dev()); black = rt.render_view(means, dg, 0)
     rt.background = torch.full((3,), 0.5, device=dev()); grey = rt.render_view(means, dg, 0)
     rt.background = bg0
-    assert abs_max(grey, 0.5 * (black + full.detach())) < 2e-6
+    assert abs_max(grey, 0.5 * (black + full.detach())) < 5e-7      # measured 1.2e-07
     assert float(full.min()) >= 0.0 and torch.isfinite(full).all() and torch.isfinite(gfull).all()
 
 
@@ -130,10 +130,10 @@ def test_fused_rollout_matches_per_operator_path_at_100k(rt):
             out = rt.rollout(*ins)
             sum((o * w).sum() for o, w in zip(out, wts)).backward()
             res[fused] = ([o.detach().clone() for o in out], [t.grad.clone() for t in ins + rt.parameters()])
-        for x, y, tol in zip(res[True][0], res[False][0], [1e-6, 1e-5, 1e-3, 1e-5]):
-            assert abs_max(x, y) < tol * max(1.0, float(y.abs().max()))
+        for x, y, tol in zip(res[True][0], res[False][0], [2e-7, 3e-6, 1.5e-5, 3e-6]):      # measured 6e-8 | 8.3e-7 | 4.9e-6 | 8.3e-7
+            assert abs_max(x, y) / max(1.0, float(y.abs().max())) < tol
         for a, b in zip(res[True][1], res[False][1]):
-            assert torch.isfinite(a).all() and rel_max(a, b) < 3e-4
+            assert torch.isfinite(a).all() and rel_max(a, b) < 1e-4      # measured 2.8e-05
     finally:
         rt.S = old
         rt.sim_fused.substeps = old
@@ -192,4 +192,4 @@ def test_million_particles_on_a_256_grid():
             stress = E(Fs)
             xs, vs, Cs, Fs = sims(st, xs, vs, Cs, Fs, stress)
             Fs = P(Fs)
-    assert abs_max(out[0], xs) < 5e-6 and abs_max(out[3], Fs) < 1e-5
+    assert abs_max(out[0], xs) < 5e-7 and abs_max(out[3], Fs) < 5e-6      # measured 6.0e-08

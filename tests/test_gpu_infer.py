@@ -93,7 +93,7 @@ def test_two_objects_with_spans_match_the_oracle_chain():
         F = torch.cat([omat.plasticity(F[:n1], W[1][0], 1e-3), omat.plasticity(F[n1:], W[1][1], 1e-3)])
         en = enabled(step)
         fr = frames[step]
-        assert abs_max(fr["x"], x) < 2e-6 and abs_max(fr["F"], F) < 5e-6, step
+        assert abs_max(fr["x"], x) < 5e-7 and abs_max(fr["F"], F) < 7e-7, step      # measured 1.1e-07
     # object 2 did not move before it was enabled (its first enabled step is step 4: update(step=3) happens after step 3)
     assert abs_max(frames[3]["x"][n1:], torch.tensor(o2.init_data.pos)) == 0.0
     assert abs_max(frames[5]["x"][n1:], torch.tensor(o2.init_data.pos)) > 1e-5
@@ -106,7 +106,7 @@ def test_two_objects_with_spans_match_the_oracle_chain():
         dk1 = (p[:n1] - p_prev[:n1])[torch.tensor(idx1)].mean(1)
         dk2 = (p[n1:] - p_prev[n1:])[torch.tensor(idx2)].mean(1)
         k = k + torch.cat([dk1, dk2])
-        assert abs_max(frames[step]["means3D"], k) < 1e-5
+        assert abs_max(frames[step]["means3D"], k) < 5e-7      # measured 1.0e-07
         p_prev = p
 
     # ---- images: frame 0 = un-deformed Gaussians (deform_grad None); last frame against the oracle rasterizer
@@ -122,7 +122,7 @@ def test_two_objects_with_spans_match_the_oracle_chain():
         s = orr.Settings(64, 96, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), torch.ones(3, dtype=torch.float64), 1.0,
                          cam.world_view_transform.double().cpu(), cam.full_proj_transform.double().cpu(), 0, cam.camera_center.double().cpu())
         ref = orr.render(s, fr["means3D"].double().cpu(), cov, op, shs=sh)[0]
-        assert abs_max(fr["images"][0], ref) < 2e-3
+        assert abs_max(fr["images"][0], ref) < 2e-6      # measured 6.3e-07
 
 
 def test_scene_round_trips_through_the_on_disk_formats(tmp_path):
@@ -170,4 +170,4 @@ def test_scene_round_trips_through_the_on_disk_formats(tmp_path):
             cam = nio.DiskCamera(cams["cam_infos"][vi], device=d)
             m3 = compute_bindings_xyz(x, x_disk, g2.get_xyz, b2)
             img = diff_rasterization(m3, compute_bindings_F(F, b2), g2, cam, rt.background)
-            assert abs_max(img, ref) < 2e-4
+            assert abs_max(img, ref) < 1e-4      # measured 3.1e-05

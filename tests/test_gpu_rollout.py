@@ -52,25 +52,25 @@ def test_fused_rollout_equals_per_operator_path_and_oracle():
         grads = torch.autograd.grad(loss, ins + params)
         res[fused] = ([o.detach() for o in outs], grads)
     for a, b in zip(res[True][0], res[False][0]):
-        assert abs_max(a, b) < 1e-5 * max(1.0, float(b.abs().max()))
+        assert abs_max(a, b) / max(1.0, float(b.abs().max())) < 5e-6      # measured 1.1e-06
     for a, b in zip(res[True][1], res[False][1]):
-        assert rel_max(a, b) < 1e-3
+        assert rel_max(a, b) < 1e-5      # measured 3.3e-06
     oins = [t.detach().cpu().double().requires_grad_(True) for t in (rt.x0, rt.v0, rt.C0, F0)]
     oouts, We, Wp = _oracle_rollout(rt, S, *oins)
-    for nme, a, b, tol in zip("xvCF", res[True][0], oouts, [5e-6, 5e-5, 1e-3, 1e-5]):
-        assert abs_max(a, b) < tol * max(1.0, float(b.abs().max())), nme
+    for nme, a, b, tol in zip("xvCF", res[True][0], oouts, [3e-7, 3e-6, 1.5e-5, 1.5e-6]):      # measured 8.6e-8 | 7.5e-7 | 4.6e-6 | 3.7e-7
+        assert abs_max(a, b) / max(1.0, float(b.abs().max())) < tol, nme
     ol = sum((o * w.double()).sum() for o, w in zip(oouts, gws))
     og = torch.autograd.grad(ol, oins + We + Wp)
     for nme, a, b in zip("xvCF", res[True][1][:4], og[:4]):
-        assert rel_max(a, b) < 5e-3, nme
+        assert rel_max(a, b) < 7e-5, nme      # measured 1.9e-05
     # LoRA factor gradients from the effective-weight gradients (chain rule through W + s B A)
     k = 0
     for net, dW in ((rt.elasticity, og[4:7]), (rt.plasticity, og[7:10])):
         for lin, d in zip((net.layers[0].fc, net.layers[1].fc, net.final_layer.fc), dW):
             gA_ref = lin.scaling * lin.lora_B.detach().cpu().double().T @ d
             gB_ref = lin.scaling * d @ lin.lora_A.detach().cpu().double().T
-            assert rel_max(res[True][1][4 + k], gA_ref) < 1e-2, (k, "A")
-            assert rel_max(res[True][1][5 + k], gB_ref) < 1e-2, (k, "B")
+            assert rel_max(res[True][1][4 + k], gA_ref) < 1.5e-5, (k, "A")      # measured 3.7e-06
+            assert rel_max(res[True][1][5 + k], gB_ref) < 1e-5, (k, "B")      # measured 3.3e-06
             k += 2
 
 
@@ -99,7 +99,7 @@ def test_nonfinite_substep_gradients_are_zeroed_like_the_per_operator_path():
     poisoned = 0
     for a, b in zip(res[True], res[False]):
         assert torch.isfinite(a).all() and torch.isfinite(b).all()
-        assert rel_max(a, b) < 2e-3
+        assert rel_max(a, b) < 1.5e-5      # measured 3.4e-06
     # the poison really did reach the neighbours of the two particles through the grid adjoint: against a run with the two
     # entries replaced by zeros, the gradients of more than those two particles differ
     clean = [w.clone() for w in gws]
@@ -116,7 +116,8 @@ def test_nonfinite_substep_gradients_are_zeroed_like_the_per_operator_path():
 def test_frame_forward_backward_finite_and_consistent():
     rt = _runtime("tiny", fused=True)
     rt.make_ground_truth()
-    r1 = rt.frame()
+    rt.set_start_state("deformed")      # (at F = I the LoRA gradients of this scene are rounding residue: two runs of the SAME
+    r1 = rt.frame()                     #  path differ by 3e-3 there, 4e-7 from a deformed state - tools/exp_grad_noise.py)
     g1 = [p.grad.clone() for p in rt.parameters()]
     assert torch.isfinite(r1.loss) and float(r1.loss) > 0
     assert all(torch.isfinite(g).all() for g in g1) and any(float(g.abs().max()) > 0 for g in g1)
@@ -127,7 +128,7 @@ def test_frame_forward_backward_finite_and_consistent():
     g2 = [p.grad.clone() for p in rt.parameters()]
     assert abs(float(r1.loss) - float(r2.loss)) < 1e-5 * max(1.0, abs(float(r2.loss)))
     for a, b in zip(g1, g2):
-        assert rel_max(a, b) < 2e-2
+        assert rel_max(a, b) < 5e-6      # measured 1.3e-06
     # striped (multi-rank style) loss pieces add up to the full loss
     from neuma_amd.harness import stripe_plan
     rt.fused = True
@@ -174,10 +175,10 @@ def test_one_node_frame_equals_the_composition_of_nodes(scene, over, monkeypatch
         for mode in ("direct", "graph"):
             r1, g1 = res[mode]
             assert torch.isfinite(r1.loss) and abs(float(r1.loss) - float(r0.loss)) < 1e-6 * max(1.0, abs(float(r0.loss)))
-            assert rel_max(r1.x, r0.x) < 1e-6 and rel_max(r1.F, r0.F) < 1e-5 and r1.F.shape == r0.F.shape
+            assert rel_max(r1.x, r0.x) < 3e-7 and rel_max(r1.F, r0.F) < 7e-7 and r1.F.shape == r0.F.shape      # measured 9.7e-08
             assert len(g1) == 12 and any(float(g.abs().max()) > 0 for g in g1)
             for a, b in zip(g1, g0):
-                assert a.shape == b.shape and torch.isfinite(a).all() and rel_max(a, b) < 2e-5, mode
+                assert a.shape == b.shape and torch.isfinite(a).all() and rel_max(a, b) < 1e-5, mode      # measured 3.0e-06
 
 
 def test_frame_image_matches_oracle_render():
@@ -196,7 +197,7 @@ def test_frame_image_matches_oracle_render():
                      rt.gaussians.active_sh_degree, cam.camera_center.cpu().double())
     cov = orr.deform_cov_by_F(rt._cov.cpu().double(), dg.cpu().double())
     oimg, _ = orr.render(s, means3D.cpu().double(), cov, rt._opacity.cpu().double(), shs=rt._shs.cpu().double())
-    assert abs_max(img, oimg) < 1e-3
+    assert abs_max(img, oimg) < 3e-6      # measured 7.9e-07
 
 
 def test_grid_cache_restores_the_same_grid_as_the_recompute():
@@ -238,7 +239,7 @@ def test_grid_cache_restores_the_same_grid_as_the_recompute():
     for tag in ("ample", "verified", "unverified", "overflow", "auto"):
         for a, b in zip(res[tag], res["off"]):
             assert torch.isfinite(a).all()
-            assert rel_max(a, b) < 2e-4, tag
+            assert rel_max(a, b) < 2e-5, tag      # measured 6.7e-06
 
 
 def test_grid_cache_per_step_api_matches_plain_backward():
@@ -284,7 +285,7 @@ def test_grid_cache_per_step_api_matches_plain_backward():
         torch.cuda.synchronize()
         outs[tag] = [nx, nv, nC, nF] + gc
     for a, b in zip(outs["cached"], outs["plain"]):
-        assert rel_max(a, b) < 1e-4
+        assert rel_max(a, b) < 7e-6      # measured 2.1e-06
 
 
 def test_rollout_reorders_shuffled_particles_transparently():
@@ -317,11 +318,11 @@ def test_rollout_reorders_shuffled_particles_transparently():
     o_sh, g_sh = run(shuf)
     assert torch.is_tensor(rt.sim_fused._perm) and rt.sim_fused._perm.numel() == N
     for a, b in zip(o_sh, o_ref):
-        assert abs_max(a, b[shuf]) < 1e-5 * max(1.0, float(b.abs().max()))
+        assert abs_max(a, b[shuf]) / max(1.0, float(b.abs().max())) < 3e-6      # measured 8.4e-07
     for a, b in zip(g_sh[:4], g_ref[:4]):
-        assert rel_max(a, b[shuf]) < 1e-3
+        assert rel_max(a, b[shuf]) < 1.5e-6      # measured 5.0e-07
     for a, b in zip(g_sh[4:], g_ref[4:]):
-        assert rel_max(a, b) < 1e-3
+        assert rel_max(a, b) < 7e-6      # measured 1.9e-06
 
 
 def test_long_rollout_keeps_the_active_block_list_consistent():
@@ -380,7 +381,7 @@ def test_svd_and_activation_caches_do_not_change_the_reverse_sweep():
         for a, b in zip(res[mode][0], res["recompute"][0]):
             assert rel_max(a, b) < 1e-5, mode           # the forward pass itself does not change (fp32 atomics order: not bitwise)
         for a, b in zip(res[mode][1], res["recompute"][1]):
-            assert torch.isfinite(a).all() and rel_max(a, b) < 2e-4, mode
+            assert torch.isfinite(a).all() and rel_max(a, b) < 7e-6, mode      # measured 2.1e-06
 
 
 def test_forward_pair_launch_equals_one_launch_per_net():
@@ -412,7 +413,7 @@ def test_forward_pair_launch_equals_one_launch_per_net():
     for a, b in zip(res[1][0], res[0][0]):
         assert torch.isfinite(a).all() and rel_max(a, b) < 2e-5
     for a, b in zip(res[1][1], res[0][1]):
-        assert torch.isfinite(a).all() and rel_max(a, b) < 2e-4
+        assert torch.isfinite(a).all() and rel_max(a, b) < 1e-5      # measured 2.7e-06
 
 
 def test_disabled_particles_get_the_reference_rows_in_the_fused_and_the_per_operator_path():
@@ -442,11 +443,11 @@ def test_disabled_particles_get_the_reference_rows_in_the_fused_and_the_per_oper
     for fused in (True, False):
         x, v, C, F = res[fused][0]
         assert float(x[lo:hi].abs().max()) == 0 and float(v[lo:hi].abs().max()) == 0 and float(C[lo:hi].abs().max()) == 0, fused
-        assert abs_max(F[lo:hi], FI) < 1e-6, fused
+        assert abs_max(F[lo:hi], FI) < 2e-7, fused      # measured 0.0e+00
         for gi in res[fused][1][:4]:
             assert float(gi[lo:hi].abs().max()) == 0, fused          # nothing flows back into a disabled particle's inputs
-    for nme, a, b, tol in zip("xvCF", res[True][0], res[False][0], [5e-6, 5e-5, 1e-3, 1e-5]):
-        assert abs_max(a, b) < tol * max(1.0, float(b.abs().max())), nme
+    for nme, a, b, tol in zip("xvCF", res[True][0], res[False][0], [2e-7, 7e-7, 5e-6, 7e-7]):      # measured 6e-8 | 1.8e-7 | 1.2e-6 | 2.1e-7
+        assert abs_max(a, b) / max(1.0, float(b.abs().max())) < tol, nme
     for a, b in zip(res[True][1], res[False][1]):
-        assert rel_max(a, b) < 2e-3
+        assert rel_max(a, b) < 2e-5      # measured 6.7e-06
     rt.statics.enabled.fill_(1)

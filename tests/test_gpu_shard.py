@@ -48,8 +48,9 @@ def test_sharded_substeps_match_the_unsharded_model(world, cap):
         from gpu_util import parity
         for nm, val, bnd in zip(("x", "v", "C", "F"), r["out_abs"], (2e-7, 1.5e-6, 7e-5, 1.2e-6)):      # measured 6e-8 | 4.5e-7 | 2.2e-5 | 3.6e-7
             parity(f"3 sharded substeps, world={world}, cap={cap}, rank {r['rank']}, vs unsharded model (abs)", nm, val, bnd)
-        assert max(r["out_err"]) < 1e-4, r
-        assert max(r["grad_err"]) < 2e-3, r          # stated gradient tolerance, SURVEY.md §8d
+        from gpu_util import measured
+        assert measured(max(r["out_err"]), "rel_max states, 3 sharded substeps") < 2e-6, r      # measured 5.9e-07
+        assert measured(max(r["grad_err"]), "rel_max gradients, 3 sharded substeps") < 3e-6, r          # stated gradient tolerance, SURVEY.md §8d
 
 
 def test_capacity_overflow_is_reported_on_every_rank():
@@ -72,11 +73,13 @@ def test_sharded_frame_matches_the_single_process_frame(world, fused, preset):
     the frame-level capacities used to be sized from an empty grid then."""
     res = _run(shard_worker.gpu_frame, world, "tiny", fused, preset)
     for r in res:
-        assert abs(r["loss"] - r["ref_loss"]) <= 1e-3 * abs(r["ref_loss"]) + 1e-9, r
-        assert r["x_err"] < 1e-5 and r["F_err"] < 1e-5, r
-        # render gradients of this small scene carry ~1e-3 of atomics-order noise even between two unsharded runs
-        assert r["v0_err"] < 5e-3, r
-        assert max(r["grad_err"]) < 2e-3 and min(r["grad_mag"]) > 1e-9, r
+        from gpu_util import measured
+        assert measured(abs(r["loss"] - r["ref_loss"]) / abs(r["ref_loss"]), "rel loss, sharded frame") <= 1e-6, r      # measured 2.4e-07
+        assert measured(r["x_err"], "rel_max x") < 7e-7 and measured(r["F_err"], "rel_max F") < 7e-7, r      # measured 2.0e-7
+        # (deformed start state: at F = I the gradients of this small scene carry 3e-3 of atomics-order noise even between two
+        #  runs of the same unsharded path - tools/exp_grad_noise.py)
+        assert measured(r["v0_err"], "rel_max dL/dv0") < 7e-6, r      # measured 2.2e-06
+        assert measured(max(r["grad_err"]), "rel_max LoRA gradients") < 1e-5 and min(r["grad_mag"]) > 1e-9, r      # measured 2.7e-06
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -85,9 +88,10 @@ def test_striped_frame_with_replicated_simulation_matches_the_single_process_fra
     for the metric workload): summed loss, state and every rank's LoRA gradients against the one-GPU frame."""
     res = _run(shard_worker.gpu_stripes_frame, world, "tiny")
     for r in res:
-        assert abs(r["loss"] - r["ref_loss"]) <= 1e-5 * abs(r["ref_loss"]) + 1e-12, r
-        assert r["x_err"] < 1e-6, r
-        assert max(r["grad_err"]) < 1e-4 and min(r["grad_mag"]) > 0, r
+        from gpu_util import measured
+        assert measured(abs(r["loss"] - r["ref_loss"]) / abs(r["ref_loss"]), "rel loss, striped frame") <= 3e-6, r      # measured 3.9e-07
+        assert measured(r["x_err"], "rel_max x") < 3e-7, r      # measured 9.7e-08
+        assert measured(max(r["grad_err"]), "rel_max LoRA gradients") < 5e-6 and min(r["grad_mag"]) > 0, r      # measured 6.5e-07
         assert r["lean"], r          # (the ranks ran the two-call frame: harness._frame_forward / _frame_backward)
 
 
@@ -140,9 +144,11 @@ def test_one_rank_on_the_rccl_backend_runs_both_multi_gpu_collective_paths(comm)
         assert 0.0 < r["allreduce_us"] < 1e4, r
     else:
         assert r["link"].startswith("torch.distributed"), r
-    assert abs(r["loss"] - r["ref_loss"]) <= 1e-4 * abs(r["ref_loss"]) + 1e-9, r
-    assert r["x_err"] < 1e-5 and r["F_err"] < 1e-5 and r["v0_err"] < 5e-3, r
-    assert max(r["grad_err"]) < 5e-3, r
+    from gpu_util import measured
+    assert measured(abs(r["loss"] - r["ref_loss"]) / abs(r["ref_loss"]), "rel loss, one-rank RCCL frame") <= 1.5e-6, r      # measured 4.0e-07
+    assert measured(r["x_err"], "rel_max x") < 7e-7 and measured(r["F_err"], "rel_max F") < 7e-7, r      # measured 2.0e-7
+    assert measured(r["v0_err"], "rel_max dL/dv0") < 2e-6, r      # measured 5.1e-07
+    assert measured(max(r["grad_err"]), "rel_max LoRA gradients") < 5e-6, r      # measured 1.5e-06
     assert r["cap_frame"] >= 64 and r["cap_dil"] > 64
 
 

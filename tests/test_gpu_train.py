@@ -2,7 +2,7 @@
 import pytest
 import torch
 
-from gpu_util import dev
+from gpu_util import dev, measured
 
 pytestmark = pytest.mark.gpu
 
@@ -159,8 +159,8 @@ def test_render_on_a_second_stream_changes_the_schedule_not_the_result():
         res[overlap] = (float(L), torch.cat([p.grad.reshape(-1) for p in rt.parameters()]).clone())
     assert res[False][0] > 1e-7
     # same kernels, different interleaving: equal up to the order of fp32 atomics (which can flip a rasterizer cut-off for a pixel)
-    assert abs(res[True][0] - res[False][0]) < 2e-3 * res[False][0]
-    assert float((res[True][1] - res[False][1]).norm()) < 5e-3 * float(res[False][1].norm())
+    assert measured(abs(res[True][0] - res[False][0]) / res[False][0], "rel loss, render on a second stream") < 3e-6      # measured 0 .. 8.7e-7 over four runs (a loss of 7e-6: 4e-12 absolute)
+    assert measured(float((res[True][1] - res[False][1]).norm()) / float(res[False][1].norm()), "rel 2-norm of all gradients") < 1e-5
 
 
 def test_loss_differences_between_equivalent_paths_are_rasterizer_cut_off_events():
@@ -238,13 +238,12 @@ def test_native_epoch_matches_the_composition_of_autograd_nodes(overlap):
     assert w[2] is None and abs(w[4] - decay ** 2) < 1e-12 and w[0] == 1.0
     loss = rt.epoch(gt, w, views=views, frame_steps=steps, overlap=overlap)
     got = [p.grad.clone() for p in rt.parameters()]
-    assert abs(float(loss) - float(ref_loss)) <= 2e-4 * abs(float(ref_loss)) + 1e-12, (float(loss), float(ref_loss))
+    assert measured(abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)), "rel loss") <= 5e-5, (float(loss), float(ref_loss))      # measured 3e-7 .. 5e-7, once 1.4e-5 (a rasterizer cut-off flipped for a pixel: a jump, not a rounding error)
     for a, b in zip(got, ref):
         assert torch.isfinite(a).all()
-        # (render gradients of this small scene carry ~1e-3 of atomics-order noise between two runs of the SAME path)
-        assert float((a - b).abs().max()) <= 5e-3 * float(b.abs().max()) + 1e-12
+        assert measured(float((a - b).abs().max()) / (float(b.abs().max()) + 1e-30), "rel_max LoRA grad") <= 2.5e-4      # measured <= 4.1e-5 in five of seven runs, 7.5e-5 in the two where a rasterizer cut-off flipped for a pixel (rel loss 1.4e-5)
     # a second epoch accumulates into .grad like loss.backward() does
     rt.epoch(gt, w, views=views, frame_steps=steps, overlap=overlap)
     for a, b in zip([p.grad for p in rt.parameters()], ref):
-        assert float((a - 2 * b).abs().max()) <= 1e-2 * float(b.abs().max()) + 1e-12
+        assert measured(float((a - 2 * b).abs().max()) / (float(b.abs().max()) + 1e-30), "rel_max LoRA grad, two epochs") <= 3e-4      # measured <= 8.7e-5 over four runs
     assert rt.last_epoch_note["frames_with_activation_cache"] + rt.last_epoch_note["frames_recomputing"] == frames
