@@ -130,22 +130,45 @@ def frame_roofline(full, rt, D, frame_s):
                     "reverse 3 x that per particle and net); both over ms_per_step of the timed region"}
 
 
-def measure_epoch(rt, frames: int, single_frame_fps: float, reps: int = 5) -> dict:
+def measure_epoch(rt, frames: int, single_frame_fps: float, reps: int = 5, recompute: bool = False) -> dict:
     """Frames/s inside a native BPTT epoch of `frames` frames (SceneRuntime.epoch), peak device memory while it runs, and whether
     the roll-outs' activation caches stayed inside their budget (frames beyond it recompute)."""
     import torch
     from neuma_amd.train import simulate_video
     dev = rt.device
-    with torch.no_grad():
-        gt = simulate_video(rt, frames)
+    # ground truth = the video of a PERTURBED start (initial velocities + 0.02 N(0,1), as SceneRuntime.make_ground_truth does for
+    # the single frame): with the runtime's own roll-out as the target the loss is 1e-9 and every gradient of the reverse sweep
+    # is ~0 - nothing in the kernels branches on that, but a measurement should not depend on it
+    v_keep = rt.v0
+    try:
+        g = torch.Generator().manual_seed(2)
+        rt.v0 = (rt.v0.detach() + (0.02 * torch.randn(rt.v0.shape, generator=g)).to(dev)).contiguous()
+        with torch.no_grad():
+            gt = simulate_video(rt, frames)
+    finally:
+        rt.v0 = v_keep
     weights = [1.0] * frames
     params = rt.parameters()
+
+    from neuma_amd import rollout as _R
+    keep_mode = _R._ACT_CACHE
+    if recompute:
+        _R._ACT_CACHE = '0'          # what NEUMA_ACT_CACHE=0 sets: no activation cache, the reverse sweep recomputes the MLPs
 
     def once():
         for p in params:
             p.grad = None
         return rt.epoch(gt, weights)
 
+    try:
+        return _measure_epoch_body(rt, frames, single_frame_fps, reps, once, recompute)
+    finally:
+        _R._ACT_CACHE = keep_mode
+
+
+def _measure_epoch_body(rt, frames, single_frame_fps, reps, once, recompute):
+    import torch
+    dev = rt.device
     once(); once()
     torch.cuda.synchronize(dev)
     torch.cuda.reset_peak_memory_stats(dev)
@@ -169,6 +192,7 @@ def measure_epoch(rt, frames: int, single_frame_fps: float, reps: int = 5) -> di
             "peak_hbm_note": "torch allocator peak (checkpoints 132 B / particle / substep, SVD + activation caches, grid cache records, "
                              "rasterizer state kept per frame and view, ground-truth frames) + the library's own allocations; the "
                              "reference needs an 80 GB A100 for this (README.md:202, SURVEY App. E)",
+            "mode": "recompute (NEUMA_ACT_CACHE=0)" if recompute else "activation cache auto (budget = half of the free HBM unless NEUMA_ACT_CACHE_GB)",
             "activation_cache": note, "loss": float(loss)}
 
 
@@ -462,9 +486,14 @@ def main():
             epoch = {"unit": "frames/s inside one epoch = F frames forward (state flowing from frame to frame, renders of frame f under "
                              "the simulation of frame f+1) + one reverse sweep; finetune.py:331-414",
                      args.workload: measure_epoch(rt, args.epoch_frames, fps)}
+            from neuma_amd import rollout as _R
+            _R._POOL.clear()                 # (the pooled cache buffers of one measurement would count towards the next one's peak)
+            torch.cuda.empty_cache()
+            # the same epoch without the activation cache: the speed / memory trade as a measured pair (the reference: "an 80 GB
+            # A100", README.md:202; experiments/finetune.py:331-414)
+            epoch[args.workload + " recompute"] = measure_epoch(rt, args.epoch_frames, fps, reps=3, recompute=True)
             if args.workload != "bb":
-                from neuma_amd import rollout as _R
-                _R._POOL.clear()                 # (the first epoch's pooled cache buffers would count towards the second one's peak)
+                _R._POOL.clear()
                 torch.cuda.empty_cache()
                 rt_bb = SceneRuntime(synth.make_scene("bb"), dev)
                 rt_bb.make_ground_truth()

@@ -32,28 +32,39 @@ static struct RcclApi {
   fnAllGather all_gather = nullptr;
   fnGetErrorString error_string = nullptr;
   char path[64] = "";
+  char err[256] = "-";        // why RCCL could not be bound (recorded once by rccl_load)
 } g_rccl;
 static std::once_flag g_rccl_once;
 
 static void rccl_load() {
   const char* names[] = {"librccl.so.1", "librccl.so"};
+  // (dlerror() clears its state when read: the text of the failure that matters - the last real dlopen, or the first missing
+  //  symbol - is recorded HERE, once, and rccl_ready() prints the stored copy)
+  snprintf(g_rccl.err, sizeof(g_rccl.err), "-");
   for (int pass = 0; pass < 2 && !g_rccl.dl; ++pass)
     for (const char* nm : names) {
       g_rccl.dl = dlopen(nm, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
       if (g_rccl.dl) { snprintf(g_rccl.path, sizeof(g_rccl.path), "%s%s", nm, pass == 0 ? " (already loaded)" : ""); break; }
+      const char* e = dlerror();
+      if (pass == 1 && e) snprintf(g_rccl.err, sizeof(g_rccl.err), "%s", e);
     }
   if (!g_rccl.dl) return;
+  dlerror();      // (clear: the RTLD_NOLOAD misses of the first pass are not errors)
   g_rccl.get_unique_id = (fnGetUniqueId)dlsym(g_rccl.dl, "ncclGetUniqueId");
   g_rccl.comm_init_rank = (fnCommInitRank)dlsym(g_rccl.dl, "ncclCommInitRank");
   g_rccl.comm_destroy = (fnCommDestroy)dlsym(g_rccl.dl, "ncclCommDestroy");
   g_rccl.all_reduce = (fnAllReduce)dlsym(g_rccl.dl, "ncclAllReduce");
   g_rccl.all_gather = (fnAllGather)dlsym(g_rccl.dl, "ncclAllGather");
   g_rccl.error_string = (fnGetErrorString)dlsym(g_rccl.dl, "ncclGetErrorString");
+  if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.comm_destroy || !g_rccl.all_reduce || !g_rccl.all_gather) {
+    const char* e = dlerror();
+    snprintf(g_rccl.err, sizeof(g_rccl.err), "%s: %s", g_rccl.path, e ? e : "a collective entry point is missing");
+  }
 }
 static int rccl_ready() {
   std::call_once(g_rccl_once, rccl_load);
   if (!g_rccl.dl || !g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.comm_destroy || !g_rccl.all_reduce || !g_rccl.all_gather) {
-    nm_set_error("RCCL is not available in this process (dlopen librccl.so.1 failed or a symbol is missing): %s", dlerror() ? dlerror() : "-");
+    nm_set_error("RCCL is not available in this process (dlopen librccl.so.1 failed or a symbol is missing): %s", g_rccl.err);
     return NM_ERR_INVALID;
   }
   return NM_OK;

@@ -236,8 +236,24 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
 // grid blocks several ranks touch have to be summed (include/neuma_hip.h, "Particle-sharded substep"), and the loop -
 // launches and collectives alike - runs here, in the library, on the caller's stream.  The collectives are the caller's
 // (nm_comm: torch.distributed over RCCL in production, gloo in the tests); the library owns everything between them.
+// The status word of a sharded roll-out is made THE SAME ON EVERY RANK before anybody reads it: bits 1 and 2 come from the
+// gathered lists and already are, but bit 8 (a block left the neighbourhood its rank announced) and bit 4 (a grid cache
+// record overflowed) are raised by the rank it happens to - and a rank that alone raises, resets its capacities and re-runs
+// the frame enters collectives the others are not in.  One 4-float all-reduce at the end of the forward sweep (a flag per
+// bit, summed) costs one small collective per roll-out; every rank then reports, and recovers, together.
+__global__ void k_status_to_flags(const int32_t* __restrict__ status, float* __restrict__ flags) {
+  if (threadIdx.x < 4) flags[threadIdx.x] = ((status[0] >> threadIdx.x) & 1) ? 1.f : 0.f;
+}
+__global__ void k_flags_to_status(const float* __restrict__ flags, int32_t* __restrict__ status) {
+  if (threadIdx.x == 0) {
+    int bits = status[0];
+    for (int b = 0; b < 4; ++b) bits |= flags[b] > 0.f ? (1 << b) : 0;
+    status[0] = bits;
+  }
+}
+
 struct ShardWs {
-  int32_t* status;   // capacity / neighbourhood bits of the roll-out (see nm_rollout_shard_status)
+  int32_t* status;   // capacity / neighbourhood bits of the roll-out (see nm_rollout_shard_status); [16..19] as floats: the flags
   int32_t* mine;     // this rank's neighbourhood list: [0] count, [1..cap] block ids
   int32_t* gathered; // world x (1 + cap)
   int32_t* shared;   // the frame's exchange list: 2 + 2 * cap_shared (kept for the reverse sweep)
@@ -368,6 +384,17 @@ extern "C" int nm_rollout_forward_sharded(nm_mpm* h, int32_t n, const nm_rollout
   }
   nm_mpm_set_fresh_rows(h, 0);
   const int rc2 = nm_shard_slots(h, sw.shared, cap_shared, 0, stream);      // the handle's slot map is clean between roll-outs
+  if (!rc && !rc2) {      // the status word, OR-ed over the ranks (see k_status_to_flags)
+    float* flags = reinterpret_cast<float*>(sw.status + 16);
+    NM_LAUNCH(k_status_to_flags, dim3(1), dim3(64), 0, (hipStream_t)stream, (const int32_t*)sw.status, flags);
+    NM_LAUNCH_CHECK();
+    if (comm->all_reduce_sum_f32(comm->user, flags, 4, stream)) {
+      nm_set_error("nm_comm.all_reduce_sum_f32 failed (status word)");
+      return NM_ERR_INVALID;
+    }
+    NM_LAUNCH(k_flags_to_status, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)flags, sw.status);
+    NM_LAUNCH_CHECK();
+  }
   return rc ? rc : rc2;
 }
 

@@ -269,12 +269,8 @@ def _frame_forward(rt, weight, jobs, streams):
     _, ws_bytes, gc_bytes, svd_bytes, act_bytes = sz
     ws = rt._scratch("ws", ws_bytes)
     gcache = torch.empty(gc_bytes, dtype=torch.uint8, device=dev) if gc_bytes > 0 else None
-    budget = R._ACT_CACHE_GB * (1 << 30)
-    svdc = actc = None
-    if R._SVD_CACHE and R._ACT_LIVE[0] + svd_bytes <= budget:
-        svdc = R._Lease(svd_bytes, dev, True)
-    if R._ACT_CACHE != '0' and (R._ACT_CACHE == '1' or R._ACT_LIVE[0] + act_bytes <= budget):
-        actc = R._Lease(act_bytes, dev, True)
+    svdc = R.lease_cache(svd_bytes, dev) if R._SVD_CACHE else None
+    actc = R.lease_cache(act_bytes, dev, force=R._ACT_CACHE == '1') if R._ACT_CACHE != '0' else None
     adj = L.SVD_ADJOINT[sim.svd_adjoint]
     cfg = L.nm_rollout_cfg(S, float(sim.plasticity.alpha), cache_blocks if gcache is not None else 0, 0, adj,
                            svdc.t.data_ptr() if svdc is not None else None, actc.t.data_ptr() if actc is not None else None)
@@ -371,6 +367,18 @@ def _frame_backward(rt, fs, g=None):
     return [v.view(sh) for v, sh in zip(gba.split(sizes), shapes)]
 
 
+def _gt_image(rt, img, vi):
+    """A ground-truth frame as nm_pixel_loss reads it: (3, H, W) fp32, contiguous, on the runtime's device (train.video_loss
+    accepted slices / other dtypes through torch ops; the native epoch hands the pointer to the library)."""
+    cam = rt.cameras[vi]
+    want = (3, int(cam.image_height), int(cam.image_width))
+    if tuple(img.shape) != want:
+        raise ValueError(f"ground-truth image of view {vi} has shape {tuple(img.shape)}, the render is {want}")
+    if img.device != rt.device or img.dtype != torch.float32 or not img.is_contiguous():
+        img = img.to(rt.device).float().contiguous()
+    return img
+
+
 class _EpochState(object):
     """What the forward half of a native multi-frame epoch keeps for its reverse sweep."""
     __slots__ = ("frames", "states", "eff", "n", "S", "adj", "side", "loss_parts", "peak_note")
@@ -411,7 +419,12 @@ def _epoch_forward(rt, gt_frames, weights, views=None, frame_steps=None, start=N
     gc_bytes = int(lib.nm_rollout_gridcache_bytes(S, cache_blocks)) if cache_blocks > 0 else 0
     svd_bytes, act_bytes = int(lib.nm_rollout_svdcache_bytes(n, S)), int(lib.nm_rollout_actcache_bytes(n, S))
     ws = rt._scratch("ws", ws_bytes)
-    budget = R._ACT_CACHE_GB * (1 << 30)
+    # every frame's pair of caches goes back to the pool after the reverse sweep and is found there by the next epoch (GB-sized
+    # buffers: handing them to the caching allocator makes it release and re-acquire device memory inside the training loop);
+    # the cap is per buffer size, so an epoch at another N or S, a single frame or an evaluation render keeps the default
+    for nb_ in (svd_bytes, act_bytes):
+        if nb_ > 0:
+            R._POOL_CAPS[(str(dev), int(nb_))] = max(R._POOL_CAPS.get((str(dev), int(nb_)), R._POOL_CAP[0]), nf)
     adj = L.SVD_ADJOINT[sim.svd_adjoint]
     w0, w1 = R._WSZ[0], R._WSZ[0] + R._WSZ[1]
     mle = L.nm_mlp(base, base + 4 * w0, base + 4 * w1)
@@ -436,11 +449,8 @@ def _epoch_forward(rt, gt_frames, weights, views=None, frame_steps=None, start=N
     rec_bytes = 33 * n * 4
     for f in range(nf):
         gcache = torch.empty(gc_bytes, dtype=torch.uint8, device=dev) if gc_bytes > 0 else None
-        svdc = actc = None
-        if R._SVD_CACHE and R._ACT_LIVE[0] + svd_bytes <= budget:
-            svdc = R._Lease(svd_bytes, dev, True)
-        if R._ACT_CACHE != '0' and (R._ACT_CACHE == '1' or R._ACT_LIVE[0] + act_bytes <= budget):
-            actc = R._Lease(act_bytes, dev, True)
+        svdc = R.lease_cache(svd_bytes, dev) if R._SVD_CACHE else None
+        actc = R.lease_cache(act_bytes, dev, force=R._ACT_CACHE == '1') if R._ACT_CACHE != '0' else None
         cached += actc is not None
         recomputed += actc is None
         cfg = L.nm_rollout_cfg(S, float(sim.plasticity.alpha), cache_blocks if gcache is not None else 0, 0, adj,
@@ -467,7 +477,7 @@ def _epoch_forward(rt, gt_frames, weights, views=None, frame_steps=None, start=N
             p_cur = x if unit else ((x - rt.center) / rt.size).contiguous()
             rt._de_x_prev, rt._g_prev = de_prev, g_prev
             loss_f, recs, grads, keep = _tail_forward(rt, p_cur, Fl, float(weights[f]), jobs, streams,
-                                                      gt={vi: gt_frames[f][i] for i, vi in enumerate(views)},      # (gt_frames[f][i] belongs to views[i])
+                                                      gt={vi: _gt_image(rt, gt_frames[f][i], vi) for i, vi in enumerate(views)},      # (gt_frames[f][i] belongs to views[i])
                                                       step=None if frame_steps is None else frame_steps[f])
             es.loss_parts.append(loss_f)
             fr["tail"] = (recs, grads, keep, p_cur)
@@ -477,7 +487,7 @@ def _epoch_forward(rt, gt_frames, weights, views=None, frame_steps=None, start=N
     loss = torch.stack(es.loss_parts).sum() if es.loss_parts else torch.zeros((), dtype=torch.float32, device=dev)
     es.states, es.eff, es.n, es.S, es.adj, es.side = states, eff, n, S, adj, side
     es.peak_note = {"frames_with_activation_cache": int(cached), "frames_recomputing": int(recomputed),
-                    "activation_cache_budget_GB": float(R._ACT_CACHE_GB)}
+                    "activation_cache_budget_GB": round(R.act_cache_budget(dev) / 2 ** 30, 1)}
     es.frames[0]["streams"] = streams
     return loss, es
 
@@ -960,8 +970,6 @@ class SceneRuntime(object):
             raise RuntimeError("the native epoch needs a one-GPU runtime with LoRA on all six layers as the only trainable tensors "
                                "(SceneRuntime._lean_ok); use train.video_loss otherwise")
         ba = [t for l in self._lora_layers for t in (l.lora_B, l.lora_A)]
-        from . import rollout as R
-        R._POOL_CAP[0] = max(R._POOL_CAP[0], len(weights))      # every frame's cache buffers go back to the pool, not to the allocator
         with torch.no_grad():
             loss, es = _epoch_forward(self, gt_frames, weights, views, frame_steps, None, overlap)
             self.last_epoch_note = es.peak_note

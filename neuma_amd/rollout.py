@@ -19,18 +19,57 @@ _SVD_CACHE = __import__('os').environ.get('NEUMA_SVD_CACHE', '1') != '0'
 _CACHE_WAIT = __import__('os').environ.get('NEUMA_CACHE_WAIT', '1') != '0'
 # activation cache of the fused roll-out (1.2 KB per particle and substep; nm_rollout_cfg.act_cache): the forward kernels keep
 # the second hidden layer of the MLPs, the reverse sweep loads it instead of recomputing (metric workload: 127.5 -> 132.3 frames/s,
-# 2.3 GB per 20-substep node).  'auto' (default): on while the caches of all live roll-out nodes stay below
-# NEUMA_ACT_CACHE_GB (default 48); '1': always; '0': never (recompute, the reference's memory profile)
+# 2.3 GB per 20-substep node).  'auto' (default): on while the caches of all live roll-out nodes stay inside the budget
+# (act_cache_budget: NEUMA_ACT_CACHE_GB if set, else half of the device memory that is free when the first cache is asked
+# for); '1': always; '0': never (recompute, the reference's memory profile)
 _ACT_CACHE = __import__('os').environ.get('NEUMA_ACT_CACHE', 'auto')
 # NEUMA_FWD_PAIR=0: one launch per net in the forward sweep instead of plasticity(t) + elasticity(t+1) in one (A/B runs)
 _FWD_PAIR = __import__('os').environ.get('NEUMA_FWD_PAIR')
 _FWD_PAIR_SET = [False]
-_ACT_CACHE_GB = float(__import__('os').environ.get('NEUMA_ACT_CACHE_GB', '48'))
+_ACT_CACHE_GB = __import__('os').environ.get('NEUMA_ACT_CACHE_GB')       # None: derived from the free device memory, once
+_BUDGET = {}            # device -> bytes
 _ACT_LIVE = [0]         # bytes of activation cache held by live roll-out nodes
-_POOL_CAP = [4]         # idle buffers kept per size (a multi-frame epoch raises it to its number of frames: harness.SceneRuntime.epoch)
+_POOL_CAP = [4]         # idle buffers kept per size ...
+_POOL_CAPS = {}         # ... unless the size has a cap of its own: (device, bytes) -> idle buffers kept (a multi-frame epoch
+                        # keeps one pair of caches per frame between epochs: harness.SceneRuntime.epoch)
 _POOL = {}              # (device, bytes) -> idle cache buffers.  The caches are GB-sized: handing them back to the caching
                         # allocator every frame makes it release and re-acquire device memory now and then (tens of
                         # milliseconds inside a training loop), so a node returns them here after its backward pass
+
+
+def act_cache_budget(device) -> int:
+    """Bytes the SVD / activation caches of all live roll-out nodes may hold together: NEUMA_ACT_CACHE_GB, or half of what
+    torch.cuda.mem_get_info reports free at the first call (MI355X, 288 GB: ~135 GB; the rest is for the checkpoints, the
+    grid cache records, the rasterizer state kept per frame and view and the caller's own tensors)."""
+    key = str(device)
+    b = _BUDGET.get(key)
+    if b is None:
+        if _ACT_CACHE_GB is not None:
+            b = int(float(_ACT_CACHE_GB) * (1 << 30))
+        else:
+            idle = sum(k[1] * len(v) for k, v in _POOL.items() if k[0] == key)
+            b = (int(torch.cuda.mem_get_info(device)[0]) + idle) // 2
+        _BUDGET[key] = b
+    return b
+
+
+def lease_cache(nbytes: int, device, force: bool = False):
+    """A cache buffer of nbytes for one roll-out node, or None when the budget does not allow it (the node then recomputes).
+    Idle pooled buffers of OTHER sizes count as held - they are device memory outside torch's caching allocator - and are
+    dropped when they are what stands in the way (an epoch at another N or S left them behind)."""
+    nbytes = int(nbytes)
+    if nbytes <= 0:
+        return None
+    key = (str(device), nbytes)
+    if not force:
+        budget = act_cache_budget(device)
+        others = sum(k[1] * len(v) for k, v in _POOL.items() if k[0] == key[0] and k != key)
+        if _ACT_LIVE[0] + nbytes > budget:
+            return None
+        if _ACT_LIVE[0] + others + nbytes > budget:
+            for k in [k for k in _POOL if k[0] == key[0] and k != key]:
+                del _POOL[k]
+    return _Lease(nbytes, device, True)
 
 
 class _Lease(object):
@@ -48,7 +87,7 @@ class _Lease(object):
     def release(self):
         if self.t is not None:
             free = _POOL.setdefault(self.key, [])
-            if len(free) < _POOL_CAP[0]:
+            if len(free) < _POOL_CAPS.get(self.key, _POOL_CAP[0]):
                 free.append(self.t)
             self._forget()
 
@@ -150,20 +189,15 @@ class _Rollout(autograd.Function):
         gc_bytes = int(lib.nm_rollout_gridcache_bytes(S, cache_blocks)) if (cache_blocks > 0 and ex is None) else 0
         gcache = torch.empty(gc_bytes, dtype=torch.uint8, device=dev) if gc_bytes > 0 else None
         # SVD cache (U, sigma, V of both nets' inputs per substep, 168 B/particle/substep) and activation cache (1.2 KB): only
-        # when a backward pass can follow, and only while the caches of all live roll-out nodes together stay below
-        # NEUMA_ACT_CACHE_GB - a BPTT loop over hundreds of frames falls back to the recompute (the reference's memory
+        # when a backward pass can follow, and only while the caches of all live roll-out nodes together stay inside the
+        # budget (act_cache_budget) - a BPTT loop over hundreds of frames falls back to the recompute (the reference's memory
         # profile) instead of running out of memory
-        budget = _ACT_CACHE_GB * (1 << 30)
         svdc = None
         if _SVD_CACHE and n > 0 and any(ctx.needs_input_grad):
-            svd_bytes = int(lib.nm_rollout_svdcache_bytes(n, S))
-            if _ACT_LIVE[0] + svd_bytes <= budget:
-                svdc = _Lease(svd_bytes, dev, True)
+            svdc = lease_cache(int(lib.nm_rollout_svdcache_bytes(n, S)), dev)
         actc = None
         if _ACT_CACHE != '0' and n > 0 and any(ctx.needs_input_grad):
-            act_bytes = int(lib.nm_rollout_actcache_bytes(n, S))
-            if _ACT_CACHE == '1' or _ACT_LIVE[0] + act_bytes <= budget:
-                actc = _Lease(act_bytes, dev, True)
+            actc = lease_cache(int(lib.nm_rollout_actcache_bytes(n, S)), dev, force=_ACT_CACHE == '1')
         cfg = L.nm_rollout_cfg(S, float(alpha), cache_blocks if gcache is not None else 0, 0, int(svd_adjoint),
                                L.ptr(svdc.t) if svdc is not None else None, L.ptr(actc.t) if actc is not None else None)
         ctx.svdc, ctx.actc = svdc, actc

@@ -238,15 +238,23 @@ class GridExchange(object):
             if os.environ.get("NEUMA_COMM", "rccl") != "python" and str(dist.get_backend(self.group)) == "nccl":
                 lib = L.lib()
                 idt = torch.zeros(128, dtype=torch.uint8)
+                rc0 = 0
                 if self.rank == 0:
-                    L.check(lib.nm_rccl_unique_id(C.c_void_p(idt.data_ptr())), "nm_rccl_unique_id")
+                    # a failure here (librccl cannot be bound, ncclGetUniqueId failed) must not raise: the other ranks are on their
+                    # way into the broadcast below.  Rank 0 sends zeros, skips its own create and the MIN all-reduce makes every
+                    # rank fall back to the callback table together
+                    rc0 = int(lib.nm_rccl_unique_id(C.c_void_p(idt.data_ptr())))
+                    if rc0:
+                        idt.zero_()
                 dev_id = idt.to(self.device)
                 src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
                 dist.broadcast(dev_id, src=src, group=self.group)
                 idt = dev_id.cpu()
                 h = C.c_void_p()
-                with torch.cuda.device(self.device):
-                    rc = lib.nm_rccl_create(C.c_void_p(idt.data_ptr()), self.world, self.rank, C.byref(h))
+                rc = rc0
+                if rc == 0:
+                    with torch.cuda.device(self.device):
+                        rc = lib.nm_rccl_create(C.c_void_p(idt.data_ptr()), self.world, self.rank, C.byref(h))
                 # every rank uses the library's communicator or none does: a rank on which it could not be created (no RCCL
                 # to bind, ncclCommInitRank failed) must not leave the others waiting inside a collective it never issues
                 ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=self.device)
@@ -261,6 +269,18 @@ class GridExchange(object):
                     if rc == 0:
                         lib.nm_rccl_destroy(h)
         return self._rccl or None
+
+    def close(self) -> None:
+        """Release the library-owned communicator (one ncclComm per model.shard(); also run when the exchange is collected)."""
+        h, self._rccl = self._rccl, False
+        if h:
+            try:
+                L.lib().nm_rccl_destroy(h)
+            except Exception:       # noqa: BLE001 - interpreter shutdown: the library may already be gone
+                pass
+
+    def __del__(self):
+        self.close()
 
     # -- sizing (first substep only: two host reads + two tiny collectives)
     def _ensure_sized(self) -> None:
@@ -392,6 +412,15 @@ class GridExchange(object):
             ev.synchronize()
             bits |= int(host[0])
         self._watched = []
+        if self.world > 1:
+            # the per-operator substeps' word is this rank's own (bit 8 / bit 4 are raised by the rank it happens to): every
+            # rank must reach the same verdict, or the one that raises re-probes capacities in collectives nobody else is in.
+            # (Every rank calls check(wait=True) at the same point - once per backward pass / frame; fused roll-outs have
+            #  already OR-ed their word over the ranks on the device, nm_rollout_forward_sharded.)
+            import torch.distributed as dist
+            flags = torch.tensor([(bits >> b) & 1 for b in range(4)], dtype=torch.int32, device=self.device)
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
+            bits = sum(int(f) << b for b, f in enumerate(flags.tolist()))
         self.generation += 1
         if bits:
             self.status.zero_()

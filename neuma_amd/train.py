@@ -141,7 +141,8 @@ DEFAULT_CFG = dict(   # experiments/configs/synthetic/finetune-bb.yaml:61-107 (s
     warmup_step=0, decay_init=0.5, decay_final=1.0, decay_steps=80, lambda_max_decay=0.33,
     num_epochs=1000, num_frames=400, exclude_steps=(), steps=None, num_lora_ckpts=3, resume=False,
     accumulate_grads_like_reference=True,   # finetune.py:331-484 has no zero_grad: gradients add up across epochs
-    overlap_render=False,   # not in the reference: render frame f on a second stream while frame f+1 simulates (see video_loss)
+    overlap_render=None,    # not in the reference: render frame f on a second stream while frame f+1 simulates.  None = the
+                            # path's own default (native epoch: on; video_loss's autograd nodes: off); True / False force it on both
 )
 
 
@@ -271,9 +272,11 @@ def finetune_constitutive(rt, gt_frames: List[List[torch.Tensor]], cfg: Optional
             # the whole epoch - F frames forward, one reverse sweep - as two plain calls into the library (harness._epoch_forward /
             # _epoch_backward): what video_loss + loss.backward() compute through one autograd node per frame
             ew, esteps = epoch_weights(c, decay_rate)
-            loss_rgb = rt.epoch(gt_frames, ew, views=views, frame_steps=esteps)
+            # (renders on a second stream under the next frame's simulation unless the configuration says otherwise: same
+            #  results, tests/test_gpu_train.py::test_native_epoch...[False / True])
+            loss_rgb = rt.epoch(gt_frames, ew, views=views, frame_steps=esteps, overlap=True if c.get("overlap_render") is None else bool(c["overlap_render"]))
         else:
-            loss_rgb = video_loss(rt, gt_frames, c, decay_rate, views, overlap_render=bool(c.get("overlap_render", False)))
+            loss_rgb = video_loss(rt, gt_frames, c, decay_rate, views, overlap_render=bool(c.get("overlap_render") or False))
             loss_rgb.backward()
         _flush(rt)      # deferred reports (rasterizer capacity, sharded exchanges) raise HERE, before the gradients are used
         e_gn = clip_grad_norm_(E.parameters(), max_norm=c["elasticity_grad_max_norm"], error_if_nonfinite=True)

@@ -386,7 +386,7 @@ def gpu_nccl_one_rank(rank, world, port, q, name="tiny", comm="rccl"):
         q.put({"rank": rank, "error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()})
 
 
-def gpu_neighbourhood_miss(rank, world, port, q, cells=9.0):
+def gpu_neighbourhood_miss(rank, world, port, q, cells=9.0, only_rank=None):
     """A body that crosses more than a block (4 cells) within one roll-out leaves the neighbourhood its rank announced at the
     first substep: every rank must see status bit 8 (exchange.check() raises), never a silently wrong sum."""
     try:
@@ -397,15 +397,28 @@ def gpu_neighbourhood_miss(rank, world, port, q, cells=9.0):
         rt = SceneRuntime(synth.make_scene("tiny"), dev, rank=rank, world=world, shard_sim=True, fused=True)
         rw = rt.rows
         speed = float(cells) / (rt.S * float(rt.scene.cfg["dt"]) * float(rt.scene.cfg["G"]))     # grid cells crossed per roll-out
-        v = torch.zeros_like(rt.v0[rw]); v[:, 0] = speed
+        v = torch.zeros_like(rt.v0[rw])
+        if only_rank is None or rank == only_rank:      # only_rank: ONE rank's particles leave - the others must hear of it
+            v[:, 0] = speed
         with torch.no_grad():
             rt.rollout(rt.x0[rw], v, rt.C0[rw], rt.F0[rw])
         moved = float(speed) * rt.S * float(rt.scene.cfg["dt"]) * float(rt.scene.cfg["G"])
+        res = {"rank": rank, "cells": moved}
         try:
             rt.model.exchange.check()
-            q.put({"rank": rank, "raised": False, "cells": moved})
+            res["raised"] = False
         except Exception as e:
-            q.put({"rank": rank, "raised": True, "text": str(e), "cells": moved})
+            res.update(raised=True, text=str(e))
+        # ... and every rank recovers together: the next roll-out re-probes the frame-level capacities (collectives that only
+        # work if ALL ranks forgot them) and completes
+        with torch.no_grad():
+            rt.rollout(rt.x0[rw], torch.zeros_like(v), rt.C0[rw], rt.F0[rw])
+        try:
+            rt.model.exchange.check()
+            res["rerun_ok"] = True
+        except Exception as e:
+            res.update(rerun_ok=False, rerun_text=str(e))
+        q.put(res)
         dist.destroy_process_group()
     except Exception as e:
         import traceback

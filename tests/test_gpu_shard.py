@@ -159,6 +159,11 @@ def test_a_particle_leaving_its_announced_neighbourhood_is_reported_on_every_ran
     res = _run(shard_worker.gpu_neighbourhood_miss, 2, 1.5)        # a normal speed: nothing to report
     for r in res:
         assert r["cells"] < 2 and not r["raised"], r
+    # ONE rank's body leaves (status bit 8 is raised by the rank it happens to): the roll-out OR-s the word over the ranks, so
+    # both raise, both forget their frame-level capacities, and the re-run - whose capacity probe is a collective - completes
+    res = _run(shard_worker.gpu_neighbourhood_miss, 2, 40.0, 1, timeout=240)
+    for r in res:
+        assert r["raised"] and "neighbourhood" in r["text"] and r["rerun_ok"], r
 
 
 def test_device_neighbourhood_list_equals_the_host_statement():
