@@ -366,6 +366,7 @@ def main():
     per_frame = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     lib.nm_prof_enable(0, None)
     dom = prof_table(lib)
+    elapsed_local = elapsed
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -480,6 +481,46 @@ def main():
                  "renders_per_s_fwd": round(1e3 / t_rf, 1), "renders_per_s_fwdbwd": round(1e3 / t_rfb, 1),
                  "note": "full-image renders (1 view incl. loss) and whole-particle-set substeps on one GPU"}
 
+    # ---- N > 1: what every rank spent where, so that a scaling run explains itself (one line per rank on stderr + `per_rank`)
+    per_rank = None
+    if world > 1:
+        from neuma_amd.sim.shard import all_reduce_sum_, gather_rows
+
+        def coll_us(fn, reps=20):
+            for _ in range(3):
+                fn()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(dev); dist.barrier()
+            a.record()
+            for _ in range(reps):
+                fn()
+            b.record(); torch.cuda.synchronize(dev)
+            return round(1e3 * a.elapsed_time(b) / reps, 1)
+
+        colls = {}
+        k3 = torch.zeros(rt.bindings.K, 3, dtype=torch.float32, device=dev)
+        colls["all_reduce_K_x_3_us"] = coll_us(lambda: all_reduce_sum_(k3, group))           # the frame's gradient all-reduce
+        lora = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
+        colls["all_reduce_lora_grads_us"] = coll_us(lambda: all_reduce_sum_(lora, group))    # reduce_param_grads (sharded simulation)
+        if rt.shard_sim:
+            xl = rt.start[0][rt.rows].contiguous()
+            Fl = rt.start[3][rt.rows].contiguous()
+            with torch.no_grad():
+                colls["gather_rows_x_us"] = coll_us(lambda: gather_rows(xl, rt.N, group))
+                colls["gather_rows_F_us"] = coll_us(lambda: gather_rows(Fl, rt.N, group))
+        jobs_now = getattr(rt, "_last_jobs", None)
+        mine = {"rank": rank, "ms_per_frame": round(1e3 * elapsed_local / args.steps, 4), "particles": int(rt.n_local),
+                "shard_sim": bool(rt.shard_sim), "rates": rates, "collectives": colls,
+                "dominant_kernel_us": (round(1e3 * sum(v[1] for v in dom.values()) / max(1, sum(v[0] for v in dom.values())), 2) if dom else None),
+                "render_jobs": jobs_now}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_rank = gathered
+        if rank == 0:
+            for g in gathered:
+                print(f"[bench] rank {g['rank']}: {g['ms_per_frame']} ms/frame, {g['particles']} particles, "
+                      f"rates {g['rates']}, collectives {g['collectives']}", file=sys.stderr)
+
     epoch = None
     if rank == 0 and world == 1 and args.epoch_frames > 0 and not args.per_op:
         try:
@@ -567,6 +608,7 @@ def main():
             "timed_region_s": round(elapsed, 4),
             "view_stats": vstats,
             "shard_cost_model": cost if world > 1 else None,
+            "per_rank": per_rank,
             "kernel_rooflines": kernel_rooflines(full, rt, Dacc, *((pmc, pmc_mfma) if (args.workload == "metric" and world == 1) else (None, None))),
             "kernel_rooflines_static_note": "traffic_static / frac_of_executed_flops / mfma_busy_pct: copied from profiles/pmc_traffic.json "
                                             "(rocprofv3 --pmc passes of this workload and build), not measured by this run",
@@ -580,6 +622,8 @@ def main():
         out = None
     if dist.is_initialized():
         dist.barrier()
+        from neuma_amd.sim.shard import close_library_comms
+        close_library_comms()
         dist.destroy_process_group()
     if out is not None:
         # RCCL writes its version banner to the C stdout buffer; push it out first so that the JSON is the last line

@@ -85,9 +85,11 @@ class _AllReduceSum(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        import torch.distributed as dist
+        from .sim.shard import all_reduce_sum_
         g = g.contiguous()
-        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
+        if not g.is_cuda:
+            g = g.clone()
+        all_reduce_sum_(g, ctx.group)
         return g, None
 
 
@@ -201,7 +203,8 @@ def _tail_backward(rt, recs, grads, streams, dx_out):
     if total is None:       # a rank without render jobs (more ranks than tile rows): zeros, and it still joins the all-reduce
         total = torch.zeros(rt.bindings.K, 3, dtype=torch.float32, device=dev)
     if rt.world > 1 and dist.is_available() and dist.is_initialized() and dist.get_world_size(rt.group) > 1:
-        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=rt.group)        # the frame's one K x 3 all-reduce
+        from .sim.shard import all_reduce_sum_
+        all_reduce_sum_(total, rt.group)        # the frame's one K x 3 all-reduce (ncclAllReduce on the library's communicator)
     b = rt.bindings
     L.check(lib.nm_spmm_csr(b.N, 3, L.ptr(b.t_rowptr), L.ptr(b.t_col), L.ptr(b.t_val), L.ptr(total), L.ptr(dx_out), L.stream_ptr(dev)),
             "nm_spmm_csr")
@@ -1114,7 +1117,8 @@ class SceneRuntime(object):
             r0, r1 = rows if rows is not None else (0, self.tile_rows)
             t = walk.view(-1, gx)[r0:r1].float()
             Wv[vi, r0:r1] = t.sum(1) + 32.0 * (t > 0).float().sum(1)
-        dist.all_reduce(W, op=dist.ReduceOp.SUM, group=self.group)
+        from .sim.shard import all_reduce_sum_
+        all_reduce_sum_(W, self.group)
         host = torch.empty(self.V * self.tile_rows + 1, dtype=torch.float32, pin_memory=True)
         host.copy_(W, non_blocking=True)
         ev = torch.cuda.Event()

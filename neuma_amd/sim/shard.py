@@ -227,60 +227,17 @@ class GridExchange(object):
         self._rccl = None           # library-owned RCCL communicator (library_comm): None = not tried yet, False = not available
 
     def library_comm(self):
-        """The library's own RCCL communicator for this group (csrc/nm_rccl.hip), created on first use: rank 0's ncclUniqueId
-        goes round through ONE torch.distributed broadcast, every rank runs ncclCommInitRank.  With it the fused sharded
-        roll-out issues its collectives from the C loop on the stream (rollout._ShardLink); None when the group's backend is
-        not nccl (the gloo tests keep the callback table) or NEUMA_COMM=python asks for the callbacks."""
-        import os
-        import torch.distributed as dist
+        """The library's own RCCL communicator for this group (library_comm_for: one per process group, shared with the per-frame
+        collectives).  With it the fused sharded roll-out issues its collectives from the C loop on the stream
+        (rollout._ShardLink); None when the group's backend is not nccl (the gloo tests keep the callback table) or
+        NEUMA_COMM=python asks for the callbacks."""
         if self._rccl is None:
-            self._rccl = False
-            if os.environ.get("NEUMA_COMM", "rccl") != "python" and str(dist.get_backend(self.group)) == "nccl":
-                lib = L.lib()
-                idt = torch.zeros(128, dtype=torch.uint8)
-                rc0 = 0
-                if self.rank == 0:
-                    # a failure here (librccl cannot be bound, ncclGetUniqueId failed) must not raise: the other ranks are on their
-                    # way into the broadcast below.  Rank 0 sends zeros, skips its own create and the MIN all-reduce makes every
-                    # rank fall back to the callback table together
-                    rc0 = int(lib.nm_rccl_unique_id(C.c_void_p(idt.data_ptr())))
-                    if rc0:
-                        idt.zero_()
-                dev_id = idt.to(self.device)
-                src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
-                dist.broadcast(dev_id, src=src, group=self.group)
-                idt = dev_id.cpu()
-                h = C.c_void_p()
-                rc = rc0
-                if rc == 0:
-                    with torch.cuda.device(self.device):
-                        rc = lib.nm_rccl_create(C.c_void_p(idt.data_ptr()), self.world, self.rank, C.byref(h))
-                # every rank uses the library's communicator or none does: a rank on which it could not be created (no RCCL
-                # to bind, ncclCommInitRank failed) must not leave the others waiting inside a collective it never issues
-                ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=self.device)
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
-                if int(ok.item()) == 1:
-                    self._rccl = h
-                else:
-                    import warnings
-                    why = (lib.nm_last_error() or b"").decode() if rc else "another rank could not create it"
-                    warnings.warn(f"library-owned RCCL communicator not available ({why}): the sharded roll-out's collectives go "
-                                  f"through torch.distributed callbacks")
-                    if rc == 0:
-                        lib.nm_rccl_destroy(h)
+            self._rccl = library_comm_for(self.group, self.device) or False
         return self._rccl or None
 
     def close(self) -> None:
-        """Release the library-owned communicator (one ncclComm per model.shard(); also run when the exchange is collected)."""
-        h, self._rccl = self._rccl, False
-        if h:
-            try:
-                L.lib().nm_rccl_destroy(h)
-            except Exception:       # noqa: BLE001 - interpreter shutdown: the library may already be gone
-                pass
-
-    def __del__(self):
-        self.close()
+        """Forget the communicator (it belongs to the process group's cache: close_library_comms() releases it)."""
+        self._rccl = False
 
     # -- sizing (first substep only: two host reads + two tiny collectives)
     def _ensure_sized(self) -> None:
@@ -473,6 +430,96 @@ class GridExchange(object):
         L.check(lib.nm_mpm_backward_finish(h, n, C.byref(st), C.byref(cur), C.byref(gcur), s), "nm_mpm_backward_finish")
 
 
+# ---------------------------------------------------------------- the library's RCCL communicator, one per process group
+_LIB_COMMS = {}        # id(group) -> ctypes handle | False (tried, not available)
+
+
+def library_comm_for(group, device):
+    """The library-owned RCCL communicator of a torch.distributed group (csrc/nm_rccl.hip), created on first use: rank 0's
+    ncclUniqueId goes round through ONE torch.distributed broadcast, every rank runs ncclCommInitRank.  None when the group's
+    backend is not nccl (the gloo tests) or NEUMA_COMM=python asks for torch.distributed.  Collective: every rank of the group
+    must make its first call at the same point.  Used by the sharded roll-out (its C loop issues the collectives itself) and by
+    the per-frame collectives below, so that a multi-GPU frame makes no torch.distributed call at all."""
+    import os
+    import torch.distributed as dist
+    key = id(group) if group is not None else 0
+    h = _LIB_COMMS.get(key)
+    if h is None:
+        h = False
+        if os.environ.get("NEUMA_COMM", "rccl") != "python" and str(dist.get_backend(group)) == "nccl":
+            lib = L.lib()
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+            idt = torch.zeros(128, dtype=torch.uint8)
+            rc0 = 0
+            if rank == 0:
+                # a failure here (librccl cannot be bound, ncclGetUniqueId failed) must not raise: the other ranks are on their
+                # way into the broadcast below.  Rank 0 sends zeros, skips its own create and the MIN all-reduce makes every
+                # rank fall back to torch.distributed together
+                rc0 = int(lib.nm_rccl_unique_id(C.c_void_p(idt.data_ptr())))
+                if rc0:
+                    idt.zero_()
+            dev_id = idt.to(device)
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast(dev_id, src=src, group=group)
+            idt = dev_id.cpu()
+            hh = C.c_void_p()
+            rc = rc0
+            if rc == 0:
+                with torch.cuda.device(device):
+                    rc = lib.nm_rccl_create(C.c_void_p(idt.data_ptr()), world, rank, C.byref(hh))
+            # every rank uses the library's communicator or none does: a rank on which it could not be created must not leave
+            # the others waiting inside a collective it never issues
+            ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if int(ok.item()) == 1:
+                h = hh
+            else:
+                import warnings
+                why = (lib.nm_last_error() or b"").decode() if rc else "another rank could not create it"
+                warnings.warn(f"library-owned RCCL communicator not available ({why}): collectives go through torch.distributed")
+                if rc == 0:
+                    lib.nm_rccl_destroy(hh)
+        _LIB_COMMS[key] = h
+    return h or None
+
+
+def close_library_comms() -> None:
+    """Release every library-owned communicator of this process (call before dist.destroy_process_group())."""
+    for key, h in list(_LIB_COMMS.items()):
+        if h:
+            try:
+                L.lib().nm_rccl_destroy(h)
+            except Exception:       # noqa: BLE001 - interpreter shutdown
+                pass
+        del _LIB_COMMS[key]
+
+
+def all_reduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place sum of a contiguous fp32 CUDA tensor over the ranks: ncclAllReduce on the library's communicator, issued on the
+    current stream (no torch.distributed call, no stream hop); torch.distributed when there is no such communicator (gloo,
+    NEUMA_COMM=python, CPU tensors, other dtypes)."""
+    import torch.distributed as dist
+    h = library_comm_for(group, t.device) if (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()) else None
+    if h is not None:
+        L.check(L.lib().nm_rccl_all_reduce_sum_f32(h, L.ptr(t), t.numel(), L.stream_ptr(t.device)), "nm_rccl_all_reduce_sum_f32")
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def all_gather_rows_(out: torch.Tensor, mine: torch.Tensor, group=None) -> torch.Tensor:
+    """out (world x chunk rows) <- every rank's `mine` (chunk rows), 4-byte elements: ncclAllGather on the library's communicator
+    (the bit patterns travel as int32) or dist.all_gather_into_tensor."""
+    import torch.distributed as dist
+    ok = mine.is_cuda and mine.element_size() == 4 and mine.is_contiguous() and out.is_contiguous()
+    h = library_comm_for(group, mine.device) if ok else None
+    if h is not None:
+        L.check(L.lib().nm_rccl_all_gather_i32(h, L.ptr(mine), L.ptr(out), mine.numel(), L.stream_ptr(mine.device)), "nm_rccl_all_gather_i32")
+    else:
+        dist.all_gather_into_tensor(out, mine, group=group)
+    return out
+
+
 # ---------------------------------------------------------------- particle rows <-> all rows
 class _GatherRows(torch.autograd.Function):
     """Forward: all-gather the ranks' row blocks into the full (N, ...) tensor.  Backward: this rank's rows of the
@@ -491,7 +538,7 @@ class _GatherRows(torch.autograd.Function):
         padded = local.new_zeros((chunk,) + tail)
         padded[:hi - lo] = local
         out = local.new_empty((world * chunk,) + tail)
-        dist.all_gather_into_tensor(out, padded, group=group)
+        all_gather_rows_(out, padded, group)
         ctx.meta = (group, lo, hi, summed)
         if chunk * world == num_rows:
             return out
@@ -505,7 +552,7 @@ class _GatherRows(torch.autograd.Function):
         group, lo, hi, summed = ctx.meta
         if not summed:
             grad = grad.contiguous().clone()
-            dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
+            all_reduce_sum_(grad, group)
         return grad[lo:hi].contiguous(), None, None, None
 
 
@@ -529,7 +576,7 @@ def reduce_param_grads(params: Iterable[torch.nn.Parameter], group=None) -> None
     if not grads:
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    all_reduce_sum_(flat, group)
     off = 0
     for g in grads:
         g.copy_(flat[off:off + g.numel()].view_as(g))

@@ -102,36 +102,88 @@ inline void grid_velocity(const ref_sim_cfg& c, int i, int j, int k, const float
   }
 }
 
+// Scatter without one lock-prefixed add per (particle, node): every OpenMP thread owns a contiguous range of the particle list
+// (spatially coherent: the scenes keep their particles in cell order), sums its contributions in a private dense box around
+// that range's stencils and flushes each touched box node to the shared grid ONCE (atomic: neighbouring threads' boxes
+// overlap by a cell or two).  A range whose box would be large - an unordered particle list - adds to the grid directly.
+struct ThreadBox {
+  int lo[3], n[3];
+  bool local;
+  std::vector<float> acc;
+  template <int NCH>
+  void open(const ref_sim_cfg& c, const int32_t* en, const float* x, int p0, int p1) {
+    int hi[3] = {-1, -1, -1};
+    lo[0] = lo[1] = lo[2] = 1 << 30;
+    for (int p = p0; p < p1; ++p) {
+      if (en[p] == 0) continue;
+      Stencil s;
+      make_stencil(c, x + 3 * p, s);
+      for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], s.b[a]); hi[a] = std::max(hi[a], s.b[a] + 2); }
+    }
+    size_t vol = 1;
+    for (int a = 0; a < 3; ++a) { n[a] = hi[a] >= lo[a] ? hi[a] - lo[a] + 1 : 0; vol *= (size_t)n[a]; }
+    local = vol > 0 && vol <= ((size_t)1 << 18);
+    if (local) acc.assign(vol * NCH, 0.f);
+  }
+  inline float* at(int i, int j, int k, int nch) { return &acc[(((size_t)(i - lo[0]) * n[1] + (j - lo[1])) * n[2] + (k - lo[2])) * nch]; }
+};
+
 void p2g(const ref_sim_cfg& c, int N, const float* vol, const float* rho, const int32_t* en, const float* x, const float* v,
          const float* C, const float* S, float* gmv, float* gm) {
   const float inv_dx = (float)c.G, dx = 1.0f / (float)c.G;
   const size_t G = c.G;
-#pragma omp parallel for schedule(static)
-  for (int p = 0; p < N; ++p) {
-    if (en[p] == 0) continue;
-    Stencil s;
-    make_stencil(c, x + 3 * p, s);
-    const float pm = vol[p] * rho[p];
-    const float ks = -c.dt * vol[p] * 4.0f * inv_dx * inv_dx;
-    float A[9];
-    for (int i = 0; i < 9; ++i) A[i] = ks * S[9 * p + i] + pm * C[9 * p + i];
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j)
-        for (int k = 0; k < 3; ++k) {
-          const int ni = s.b[0] + i, nj = s.b[1] + j, nk = s.b[2] + k;
-          if (!node_ok(c, ni, nj, nk)) continue;
-          const float d[3] = {((float)i - s.f[0]) * dx, ((float)j - s.f[1]) * dx, ((float)k - s.f[2]) * dx};
-          const float w = s.w[0][i] * s.w[1][j] * s.w[2][k];
-          const size_t n = (ni * G + nj) * G + nk;
-          for (int a = 0; a < 3; ++a) {
-            float val = w * (pm * v[3 * p + a] + A[3 * a] * d[0] + A[3 * a + 1] * d[1] + A[3 * a + 2] * d[2]);
+#pragma omp parallel
+  {
+    const int T = omp_get_num_threads(), t = omp_get_thread_num();
+    const int p0 = (int)((int64_t)N * t / T), p1 = (int)((int64_t)N * (t + 1) / T);
+    static thread_local ThreadBox box;
+    box.open<4>(c, en, x, p0, p1);
+    for (int p = p0; p < p1; ++p) {
+      if (en[p] == 0) continue;
+      Stencil s;
+      make_stencil(c, x + 3 * p, s);
+      const float pm = vol[p] * rho[p];
+      const float ks = -c.dt * vol[p] * 4.0f * inv_dx * inv_dx;
+      float A[9];
+      for (int i = 0; i < 9; ++i) A[i] = ks * S[9 * p + i] + pm * C[9 * p + i];
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+          for (int k = 0; k < 3; ++k) {
+            const int ni = s.b[0] + i, nj = s.b[1] + j, nk = s.b[2] + k;
+            if (!node_ok(c, ni, nj, nk)) continue;
+            const float d[3] = {((float)i - s.f[0]) * dx, ((float)j - s.f[1]) * dx, ((float)k - s.f[2]) * dx};
+            const float w = s.w[0][i] * s.w[1][j] * s.w[2][k];
+            float val[4];
+            for (int a = 0; a < 3; ++a) val[a] = w * (pm * v[3 * p + a] + A[3 * a] * d[0] + A[3 * a + 1] * d[1] + A[3 * a + 2] * d[2]);
+            val[3] = w * pm;
+            if (box.local) {
+              float* q = box.at(ni, nj, nk, 4);
+              for (int a = 0; a < 4; ++a) q[a] += val[a];
+            } else {
+              const size_t n = (ni * G + nj) * G + nk;
+              for (int a = 0; a < 3; ++a) {
 #pragma omp atomic
-            gmv[3 * n + a] += val;
+                gmv[3 * n + a] += val[a];
+              }
+#pragma omp atomic
+              gm[n] += val[3];
+            }
           }
-          float mval = w * pm;
+    }
+    if (box.local)
+      for (int i = 0; i < box.n[0]; ++i)
+        for (int j = 0; j < box.n[1]; ++j)
+          for (int k = 0; k < box.n[2]; ++k) {
+            const float* q = box.at(box.lo[0] + i, box.lo[1] + j, box.lo[2] + k, 4);
+            if (q[3] == 0.f && q[0] == 0.f && q[1] == 0.f && q[2] == 0.f) continue;
+            const size_t n = ((size_t)(box.lo[0] + i) * G + (box.lo[1] + j)) * G + (box.lo[2] + k);
+            for (int a = 0; a < 3; ++a) {
 #pragma omp atomic
-          gm[n] += mval;
-        }
+              gmv[3 * n + a] += q[a];
+            }
+#pragma omp atomic
+            gm[n] += q[3];
+          }
   }
 }
 
@@ -218,9 +270,14 @@ void ref_mpm_backward(const ref_sim_cfg* cp, int32_t N, const float* vol, const 
   memset(ggv, 0, cells * 3 * sizeof(float));
   p2g(c, N, vol, rho, en, x, v, C, S, gmv, gm);
   grid_op(c, gmv, gm, gv);
-  // --- g2p adjoint
-#pragma omp parallel for schedule(static)
-  for (int p = 0; p < N; ++p) {
+  // --- g2p adjoint (the scatter of the node-velocity adjoint through a private box per thread, like p2g)
+#pragma omp parallel
+  {
+  const int T_ = omp_get_num_threads(), t_ = omp_get_thread_num();
+  const int q0 = (int)((int64_t)N * t_ / T_), q1 = (int)((int64_t)N * (t_ + 1) / T_);
+  static thread_local ThreadBox box;
+  box.open<3>(c, en, x, q0, q1);
+  for (int p = q0; p < q1; ++p) {
     for (int a = 0; a < 3; ++a) gx[3 * p + a] = 0.f;
     for (int i = 0; i < 9; ++i) gF[9 * p + i] = 0.f;
     if (en[p] == 0) continue;
@@ -258,10 +315,15 @@ void ref_mpm_backward(const ref_sim_cfg* cp, int32_t N, const float* vol, const 
             Cd[a] = Ct[3 * a] * d[0] + Ct[3 * a + 1] * d[1] + Ct[3 * a + 2] * d[2];
             Ctg[a] = Ct[a] * g[0] + Ct[3 + a] * g[1] + Ct[6 + a] * g[2];
           }
-          for (int a = 0; a < 3; ++a) {
-            float val = w * vt[a] + kap * w * Cd[a];
+          if (box.local) {
+            float* q = box.at(ni, nj, nk, 3);
+            for (int a = 0; a < 3; ++a) q[a] += w * vt[a] + kap * w * Cd[a];
+          } else {
+            for (int a = 0; a < 3; ++a) {
+              float val = w * vt[a] + kap * w * Cd[a];
 #pragma omp atomic
-            ggv[3 * n + a] += val;
+              ggv[3 * n + a] += val;
+            }
           }
           const float dLdw = vt[0] * g[0] + vt[1] * g[1] + vt[2] * g[2] + kap * (g[0] * Cd[0] + g[1] * Cd[1] + g[2] * Cd[2]);
           const float gw[3] = {s.dw[0][i] * s.w[1][j] * s.w[2][k] * inv_dx, s.w[0][i] * s.dw[1][j] * s.w[2][k] * inv_dx,
@@ -269,6 +331,19 @@ void ref_mpm_backward(const ref_sim_cfg* cp, int32_t N, const float* vol, const 
           for (int a = 0; a < 3; ++a) xb[a] += dLdw * gw[a] - kap * w * Ctg[a];
         }
     for (int a = 0; a < 3; ++a) gx[3 * p + a] = xb[a];
+  }
+  if (box.local)
+    for (int i = 0; i < box.n[0]; ++i)
+      for (int j = 0; j < box.n[1]; ++j)
+        for (int k = 0; k < box.n[2]; ++k) {
+          const float* q = box.at(box.lo[0] + i, box.lo[1] + j, box.lo[2] + k, 3);
+          if (q[0] == 0.f && q[1] == 0.f && q[2] == 0.f) continue;
+          const size_t n = ((size_t)(box.lo[0] + i) * G + (box.lo[1] + j)) * G + (box.lo[2] + k);
+          for (int a = 0; a < 3; ++a) {
+#pragma omp atomic
+            ggv[3 * n + a] += q[a];
+          }
+        }
   }
   // --- grid_op adjoint: ggv {vbar} -> ggm {mvbar xyz, mbar}
 #pragma omp parallel for schedule(static)
@@ -866,10 +941,16 @@ void ref_raster_backward(ref_raster_state* st, const float* gimg, float* dmeans3
   const ref_cam& cam = st->cam;
   const int W = cam.W, H = cam.H, K = st->K, gx = st->gx, ntiles = st->gx * st->gy;
   std::vector<float> dxy(2 * (size_t)K, 0.f), dcon(3 * (size_t)K, 0.f), drgb(3 * (size_t)K, 0.f), dop((size_t)K, 0.f);
+  // A tile's 256 pixels are walked by ONE thread: their contributions to a Gaussian are summed in a tile-private table (one
+  // row of 9 per list entry) and leave it with one atomic set per (tile, Gaussian) - not one per (pixel, Gaussian): the
+  // lock-prefixed float adds were most of this function's time, and the only thing in it that did not scale with the cores.
 #pragma omp parallel for schedule(dynamic, 1)
   for (int t = 0; t < ntiles; ++t) {
     const int tx0 = (t % gx) * 16, ty0 = (t / gx) * 16;
     const int b0 = st->tile_start[t];
+    static thread_local std::vector<float> loc;
+    const int nlist = st->tile_start[t + 1] - b0;
+    loc.assign((size_t)9 * nlist, 0.f);
     for (int py = ty0; py < std::min(ty0 + 16, H); ++py)
       for (int px = tx0; px < std::min(tx0 + 16, W); ++px) {
         const size_t pix = (size_t)py * W + px;
@@ -893,9 +974,7 @@ void ref_raster_backward(ref_raster_state* st, const float* gimg, float* dmeans3
             accum[ch] = last_alpha * last_c[ch] + (1.f - last_alpha) * accum[ch];
             last_c[ch] = c;
             dL_dalpha += (c - accum[ch]) * g[ch];
-            float v = alpha * T * g[ch];
-#pragma omp atomic
-            drgb[3 * k + ch] += v;
+            loc[9 * (size_t)(e - b0) + ch] += alpha * T * g[ch];
           }
           dL_dalpha *= T;
           last_alpha = alpha;
@@ -906,20 +985,24 @@ void ref_raster_backward(ref_raster_state* st, const float* gimg, float* dmeans3
           const float v0 = dL_dG * gdx, v1 = dL_dG * gdy;
           const float c0 = -0.5f * Gv * dx * dx * dL_dG, c1 = -Gv * dx * dy * dL_dG, c2 = -0.5f * Gv * dy * dy * dL_dG;
           const float o = Gv * dL_dalpha;
-#pragma omp atomic
-          dxy[2 * k] += v0;
-#pragma omp atomic
-          dxy[2 * k + 1] += v1;
-#pragma omp atomic
-          dcon[3 * k] += c0;
-#pragma omp atomic
-          dcon[3 * k + 1] += c1;
-#pragma omp atomic
-          dcon[3 * k + 2] += c2;
-#pragma omp atomic
-          dop[k] += o;
+          float* row = &loc[9 * (size_t)(e - b0)];
+          row[3] += v0; row[4] += v1; row[5] += c0; row[6] += c1; row[7] += c2; row[8] += o;
         }
       }
+    for (int e = 0; e < nlist; ++e) {
+      const float* row = &loc[9 * (size_t)e];
+      bool any = false;
+      for (int q = 0; q < 9; ++q) any = any || row[q] != 0.f;
+      if (!any) continue;
+      const int k = st->list[b0 + e];
+      float* dst[9] = {&drgb[3 * k], &drgb[3 * k + 1], &drgb[3 * k + 2], &dxy[2 * k], &dxy[2 * k + 1],
+                       &dcon[3 * k], &dcon[3 * k + 1], &dcon[3 * k + 2], &dop[k]};
+      for (int q = 0; q < 9; ++q) {
+        const float v = row[q];
+#pragma omp atomic
+        *dst[q] += v;
+      }
+    }
   }
   const float fx = W / (2.0f * cam.tanfovx), fy = H / (2.0f * cam.tanfovy);
   const float* V = cam.view; const float* P = cam.proj;

@@ -119,6 +119,23 @@ def run_frame(cs: CpuScene, substeps=None, views=None, gt=None, timings=None):
     return loss, gWe, gWp, images
 
 
+def cpu_quota():
+    """CPUs the container may actually use: the cgroup's CPU bandwidth limit (v2 cpu.max, v1 cpu.cfs_quota_us / cfs_period_us),
+    or None when there is none.  The MI355X boxes of this build show 256 CPUs (2 x EPYC 9575F) to a container whose quota is
+    16: threads beyond a small multiple of the quota only take turns - and, spinning at OpenMP barriers, burn the quota."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def time_frame_sample(scene, rt=None, max_seconds: float = 30.0):
     """The `cpu_baseline` JSON object of bench.py: the workload's frame on all host cores (bounded sample when a whole frame
     would take longer than ~max_seconds), plus the mandatory un-sampled BouncyBall (bb) frame of SURVEY.md §8d."""
@@ -131,7 +148,9 @@ def time_frame_sample(scene, rt=None, max_seconds: float = 30.0):
     cb = CpuScene(bb, synth.load_base_weights(bb.cfg["mat"]))
     # thread count: all usable cores is not automatically the fastest (cgroup CPU quotas, NUMA, 27 atomics per particle on a
     # shared grid) - time the bb frame at every power of two up to the usable count and keep the best for everything below
-    cand = sorted({min(usable, 1 << k) for k in range(0, 11)} | {usable})
+    quota = cpu_quota()
+    limit = usable if quota is None else max(1, min(usable, int(math.ceil(4 * quota))))      # (beyond 4x the quota: pure time slicing)
+    cand = sorted({min(limit, 1 << k) for k in range(0, 11)} | {limit} | ({min(limit, int(math.ceil(quota))), min(limit, int(math.ceil(2 * quota)))} if quota else set()))
     cref.set_threads(cand[-1])
     run_frame(cb)                                            # warm-up (thread pool, page faults)
     sweep = {}
@@ -142,7 +161,10 @@ def time_frame_sample(scene, rt=None, max_seconds: float = 30.0):
         sweep[n] = time.perf_counter() - t0
     best = min(sweep, key=sweep.get)
     cref.set_threads(best)
-    out = {"unit": "frames/s", "cores": best, "host_cpus": host, "usable_cpus": usable, "kind": "port",
+    out = {"unit": "frames/s", "cores": best, "host_cpus": host, "usable_cpus": usable,
+           "cgroup_cpu_quota": None if quota is None else round(quota, 2), "kind": "port",
+           "cores_note": "threads of the fastest run; the container's CPU time is capped by cgroup_cpu_quota CPUs (cpu.max), whatever "
+                         "host_cpus / the affinity mask show - that quota, not the socket, is 'all host cores' here",
            "thread_sweep_bb_ms": {str(k): round(1e3 * v, 1) for k, v in sweep.items()},
            "label": "CPU restatement of the reference algorithm (C++/OpenMP, dense grid, 3 MPM kernels + recompute, per-pixel rasterizer)"}
     t0 = time.perf_counter()
@@ -159,7 +181,7 @@ def time_frame_sample(scene, rt=None, max_seconds: float = 30.0):
     # minimal sample (1 substep + binding + 1 view, fwd + bwd) at the bb-optimal thread count and at (half of) all usable
     # cores: a 100k-particle scene can use more threads than the 8k-particle one
     trials = {}
-    for n in sorted({best, usable, max(1, usable // 2)}):
+    for n in sorted({best, limit, max(1, limit // 2)}):
         cref.set_threads(n)
         tmn = {}
         run_frame(cs, substeps=1, views=[0], timings=tmn)

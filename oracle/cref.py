@@ -34,6 +34,10 @@ def lib():
     if _lib is None:
         if not LIB.exists():
             build()
+        # idle OpenMP threads sleep instead of spinning: under a cgroup CPU quota (the GPU boxes: 16 of 256 visible CPUs) spinning
+        # waiters spend the quota the working threads need (a 256-thread frame took 95x a 32-thread one)
+        os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+        os.environ.setdefault("GOMP_SPINCOUNT", "0")
         h = C.CDLL(str(LIB))
         h.ref_num_threads.restype = C.c_int
         h.ref_raster_forward.restype = _P
