@@ -97,6 +97,10 @@ struct State {
   uint32_t* vals;              // tile mask of the pair: bit (ty % 4) * 4 + (tx % 4) set iff the Gaussian can reach that tile of the bin
   PairLog* log;                // the count pass's pair log (cap entries; dead after the fill pass)
   uint32_t* bin_total;
+  // binning by depth-ordered chunks (k_bin_count2): the Gaussian sort's keys / dummy values, its slab counters | cursors |
+  // header (one zeroed block) and offsets, per (chunk, bin) counts and offsets
+  unsigned long long* gkeys; uint32_t* gvals; uint32_t* slab_blk; uint32_t* slab_off; uint32_t* hist; uint32_t* coff;
+  int nchunk;
   float* final_T; uint32_t* n_contrib;
   // split compositing (k_split_plan): tiles of a view that leaves most of the chip idle are composited in list segments
   uint32_t* tile_rec;  // per tile: index of its first segment record, 0xFFFFFFFF = composited whole by k_render
@@ -152,6 +156,13 @@ static State carve_state(void* base, void* scratch, int W, int H, int k, int64_t
   t.zrange = (uint2*)(q + so); so += al256((K / 256 + 1) * sizeof(uint2));
   t.log = (PairLog*)(q + so); so += al256(cp * sizeof(PairLog));
   t.bin_total = (uint32_t*)(q + so); so += al256(((size_t)t.nbx * t.nby + 1) * sizeof(uint32_t));
+  t.nchunk = (int)((K + 255) / 256);
+  t.gkeys = (unsigned long long*)(q + so); so += al256(K * sizeof(unsigned long long));
+  t.gvals = (uint32_t*)(q + so); so += al256(K * sizeof(uint32_t));
+  t.slab_blk = (uint32_t*)(q + so); so += al256((2 * 1024 * 8 + 64) * sizeof(uint32_t));      // counts | cursors (NM_GS x NM_GSUB each) | hdr2
+  t.slab_off = (uint32_t*)(q + so); so += al256((1024 + 1) * sizeof(uint32_t));
+  t.hist = (uint32_t*)(q + so); so += al256((size_t)t.nchunk * t.nbx * t.nby * sizeof(uint32_t));
+  t.coff = (uint32_t*)(q + so); so += al256(((size_t)t.nchunk * t.nbx * t.nby + 1) * sizeof(uint32_t));
   t.tile_cnt = (uint32_t*)(q + so); so += al256(ntile * sizeof(uint32_t));
   t.tile_mode = (uint32_t*)(q + so); so += al256(ntile * sizeof(uint32_t));
   t.seg_raw = (float4*)(q + so); so += al256(it * NM_TPB * sizeof(float4));
@@ -238,6 +249,58 @@ __device__ __forceinline__ float tile_min_q(const TileCull& t, int tx, int ty) {
 // k_count_pairs (statistics) evaluate this same function on the same inputs, so they always agree.
 __device__ __forceinline__ bool tile_contributes(const TileCull& t, int tx, int ty) {
   return !(tile_min_q(t, tx, ty) > t.qmax);
+}
+
+// The same decision for the FOUR tiles of a tile row at once (round 5: the per-tile form above was 79 of the count pass's 105
+// us - ~60 VALU operations per tile, 8.5 tiles per (Gaussian, bin) pair on average and as many loop trips as the wave's
+// largest rectangle).  The region {q <= qmax} is an ellipse; cut by the row's strip y0 <= y <= y1 it stays convex, so the
+// tiles of the row it touches are exactly those whose x range meets the x extent [xa, xb] of that cut.  The right end of the
+// ellipse's horizontal chord at height dy, (-cb dy + sqrt(ca qmax - det dy^2)) / ca, is concave in dy: its maximum over the
+// strip sits at the ellipse's right extreme point clamped into the strip (likewise the minimum of the left end) - two square
+// roots per row instead of four edge minimisations per tile, the same number of operations for every lane.  The extent is
+// widened by NM_ROW_EPS pixels (the per-pixel evaluation decides; a superset costs a candidate, a subset an error).
+struct RowCull {
+  float mx, my, ca, cb, cc, qmax, dye, cbcc_dxe;      // dye: half extent in y; cbcc_dxe = (cb / cc) * (half extent in x)
+};
+#define NM_ROW_EPS 0.01f
+__device__ __forceinline__ RowCull make_row_cull(float mx, float my, const float4& co) {
+#pragma clang fp contract(off)
+  RowCull r;
+  r.mx = mx; r.my = my; r.ca = co.x; r.cb = co.y; r.cc = co.z;
+  r.qmax = 2.f * (__logf(255.f * co.w) + 0.01f);       // (as in make_tile_cull)
+  const float det = co.x * co.z - co.y * co.y;
+  const bool ok = det > 0.f && r.qmax > 0.f && co.x > 0.f && co.z > 0.f;
+  const float dxe = ok ? __builtin_amdgcn_sqrtf(r.qmax * co.z / det) : 0.f;
+  r.dye = ok ? __builtin_amdgcn_sqrtf(r.qmax * co.x / det) : -1.f;          // (-1: nothing passes)
+  r.cbcc_dxe = ok ? (co.y / co.z) * dxe : 0.f;
+  return r;
+}
+// tile mask (bit (ty % 4) * 4 + (tx % 4)) of bin (bx, by) for a Gaussian whose 3-sigma tile rectangle is [g.x, g.z) x [g.y, g.w)
+__device__ __forceinline__ uint32_t bin_tile_mask(const RowCull& r, const int4& g, int bx, int by) {
+#pragma clang fp contract(off)
+  uint32_t m = 0u;
+  const float det = r.ca * r.cc - r.cb * r.cb, inv_ca = 1.f / r.ca, caq = r.ca * r.qmax;
+  const int c0 = bx * NM_BT, c_lo = max(g.x, c0), c_hi = min(g.z, c0 + NM_BT) - 1;      // columns of the bin inside the rectangle
+#pragma unroll
+  for (int q = 0; q < NM_BT; ++q) {
+    const int ty = by * NM_BT + q;
+    const float y0 = (float)(ty * NM_TILE) - r.my, y1 = y0 + (float)(NM_TILE - 1);
+    const float lo = fmaxf(y0, -r.dye), hi = fminf(y1, r.dye);
+    const bool row_ok = ty >= g.y && ty < g.w && !(lo > hi);          // (dye = -1 makes lo > hi)
+    const float dyR = fminf(fmaxf(-r.cbcc_dxe, lo), hi), dyL = fminf(fmaxf(r.cbcc_dxe, lo), hi);
+    const float sR = __builtin_amdgcn_sqrtf(fmaxf(0.f, caq - det * dyR * dyR));
+    const float sL = __builtin_amdgcn_sqrtf(fmaxf(0.f, caq - det * dyL * dyL));
+    const float xb = r.mx + (sR - r.cb * dyR) * inv_ca + NM_ROW_EPS;
+    const float xa = r.mx - (sL + r.cb * dyL) * inv_ca - NM_ROW_EPS;
+    // tile tx covers x in [16 tx, 16 tx + 15]: touched iff 16 tx <= xb and 16 tx + 15 >= xa
+    const int ta = max(c_lo, (int)ceilf((xa - (float)(NM_TILE - 1)) * (1.f / NM_TILE)));
+    const int tb = min(c_hi, (int)floorf(xb * (1.f / NM_TILE)));
+    if (row_ok && ta <= tb) {
+      const uint32_t bits = ((2u << (tb - c0)) - 1u) & ~((1u << (ta - c0)) - 1u);
+      m |= bits << (q * NM_BT);
+    }
+  }
+  return m;
 }
 
 #define SH_C0 0.28209479177387814f
@@ -441,7 +504,7 @@ __global__ void __launch_bounds__(256) k_bin_count(RK k, int K, int nbx, const i
                                                    PairLog* __restrict__ log, uint32_t* __restrict__ hdr, long long cap) {
   __shared__ uint32_t s_lo[4], s_hi[4];
   __shared__ int s_excl[4][64];
-  __shared__ TileCull s_tc[4][64];
+  __shared__ RowCull s_tc[4][64];
   __shared__ int4 s_geo[4][64], s_bin[4][64];
   const int lane = threadIdx.x & 63;
 #ifdef NM_PHASES
@@ -461,14 +524,14 @@ __global__ void __launch_bounds__(256) k_bin_count(RK k, int K, int nbx, const i
   BC_T(0)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   int x0 = 0, y0 = 0, x1 = 0, y1 = 0, slab = 0;
-  TileCull tc = {0.f, 0.f, 1.f, 0.f, 1.f, 0.f, 0.f, -1.f};
+  RowCull tc = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f, -1.f, 0.f};
   bool live = i < K && radii[i] > 0;
   if (live) {
     const float2 p = xy[i];
     get_rect(k, p.x, p.y, radii[i], x0, y0, x1, y1, k.ty0, k.ty1);
     live = (x1 - x0) * (y1 - y0) != 0;
     if (live) {
-      tc = make_tile_cull(p.x, p.y, conop[i]);
+      tc = make_row_cull(p.x, p.y, conop[i]);
       slab = slab_of(depth[i], zlo, zhi);
     }
   }
@@ -533,12 +596,9 @@ __global__ void __launch_bounds__(256) k_bin_count(RK k, int K, int nbx, const i
       }
       const int q = pr - s_excl[wv][lo_];
       const int4 g = s_geo[wv][lo_], bn = s_bin[wv][lo_];
-      const TileCull t = s_tc[wv][lo_];
+      const RowCull t = s_tc[wv][lo_];
       const int by = bn.y + q / bn.z, bx = bn.x + q % bn.z;
-      uint32_t m = 0;
-      for (int ty = max(g.y, by * NM_BT); ty < min(g.w, by * NM_BT + NM_BT); ++ty)
-        for (int tx = max(g.x, bx * NM_BT); tx < min(g.z, bx * NM_BT + NM_BT); ++tx)
-          m |= tile_contributes(t, tx, ty) ? (1u << ((ty - by * NM_BT) * NM_BT + (tx - bx * NM_BT))) : 0u;
+      const uint32_t m = bin_tile_mask(t, g, bx, by);
       e.id = (uint32_t)(blockIdx.x * blockDim.x + (wv << 6) + lo_); e.mask = m;
       if (m) {
         e.cell = (uint32_t)((by * nbx + bx) * NM_NS + bn.w);
@@ -793,6 +853,307 @@ __global__ void __launch_bounds__(256) k_cell_sort(int ncell, const uint32_t* __
   }
 }
 
+
+// ---------------------------------------------------------------- binning by depth-ordered chunks (round 5; default)
+// The (bin, depth slab) cells above exist so that the per-bin depth sort decomposes into small pieces - at the price of one
+// returning GLOBAL atomic per (Gaussian, bin) pair (1.15 M per metric view on 13 k cell counters), a 4 MB counter array to
+// clear and read back, and a sort of 1.15 M pairs.  This path sorts the GAUSSIANS first (200 k keys instead of 1.15 M pairs):
+//   k_slab_hist / k_slab_scatter   counting sort of the visible Gaussians into NM_GS depth slabs (keys = depth bits | id)
+//   k_cell_sort (reused)           every slab sorted by (depth, id): the Gaussians are now in exact compositing order
+//   k_bin_count2                   a workgroup takes 256 CONSECUTIVE Gaussians of that order.  Pairs are found as before (exact
+//                                  tile masks), but ranked inside the workgroup: per bin a 256-bit membership mask in LDS (one
+//                                  LDS atomic OR per pair), rank of a pair = set bits below its Gaussian - stable, no global
+//                                  atomics, and the workgroup's pairs leave for the log already grouped by bin
+//   k_col_sum / k_col_scan         per bin: exclusive scan of the chunks' counts (the (chunk, bin) segments of a bin follow each
+//                                  other in depth order, and each is in depth order inside) + the bins' list offsets
+//   k_bin_fill (reused)            slot = segment offset + rank: the bin lists come out SORTED - no sort of pairs at all.
+// keys / vals / off[bin * NM_NS] / hdr[2], hdr[3] hold exactly what the cell path leaves there (same order: depth, then id).
+#define NM_GS 1024            // depth slabs of the Gaussian sort
+#define NM_GSUB 8             // counters per slab (by workgroup index): 200 k atomics on 1024 words queue up ~200 deep per word
+#define NM_B2_MAXBIN 2048     // bins a view may have for this path (LDS: 32 B of mask per bin); larger images use the cells
+#define NM_B2_STASH 384       // pairs per wave whose (bin, Gaussian, mask) are kept in LDS between the two walks
+#define NM_B2_OWN 1024        // pairs per wave whose owner lane is tabulated (beyond: binary search)
+__device__ __forceinline__ int gslab_of(float z, uint32_t zmin_bits, uint32_t zmax_bits) {
+  const float zmin = __uint_as_float(zmin_bits), zmax = __uint_as_float(zmax_bits);
+  const float span = zmax - zmin;
+  if (!(span > 0.f)) return 0;
+  const int sl = (int)((z - zmin) / span * (float)NM_GS);
+  return min(NM_GS - 1, max(0, sl));
+}
+__device__ __forceinline__ void wg_depth_range(const uint2* __restrict__ zrange, int nrange, uint32_t* s_lo, uint32_t* s_hi,
+                                               uint32_t& zlo, uint32_t& zhi) {
+  const int lane = threadIdx.x & 63;
+  zlo = 0x7f800000u; zhi = 0u;
+  for (int q = threadIdx.x; q < nrange; q += 256) { const uint2 z = zrange[q]; zlo = min(zlo, z.x); zhi = max(zhi, z.y); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    zlo = min(zlo, (uint32_t)__shfl_xor((int)zlo, o, 64));
+    zhi = max(zhi, (uint32_t)__shfl_xor((int)zhi, o, 64));
+  }
+  if (lane == 0) { s_lo[threadIdx.x >> 6] = zlo; s_hi[threadIdx.x >> 6] = zhi; }
+  __syncthreads();
+  zlo = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
+  zhi = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
+}
+__device__ __forceinline__ bool gaussian_live(const RK& k, int i, int K, const int* __restrict__ radii, const float2* __restrict__ xy) {
+  if (i >= K) return false;
+  const int r = radii[i];
+  if (r <= 0) return false;
+  const float2 p = xy[i];
+  int x0, y0, x1, y1;
+  get_rect(k, p.x, p.y, r, x0, y0, x1, y1, k.ty0, k.ty1);
+  return (x1 - x0) * (y1 - y0) != 0;
+}
+__global__ void __launch_bounds__(256) k_slab_hist(RK k, int K, const int* __restrict__ radii, const float2* __restrict__ xy,
+                                                   const float* __restrict__ depth, const uint2* __restrict__ zrange, int nrange,
+                                                   uint32_t* __restrict__ slab_cnt) {
+  __shared__ uint32_t s_lo[4], s_hi[4];
+  __shared__ uint32_t s_h[NM_GS];
+  uint32_t zlo, zhi;
+  for (int q = threadIdx.x; q < NM_GS; q += 256) s_h[q] = 0u;
+  wg_depth_range(zrange, nrange, s_lo, s_hi, zlo, zhi);      // (its barrier also publishes the zeroed histogram)
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (gaussian_live(k, i, K, radii, xy)) atomicAdd(&s_h[gslab_of(depth[i], zlo, zhi)], 1u);
+  __syncthreads();
+  for (int q = threadIdx.x; q < NM_GS; q += 256)
+    if (s_h[q]) atomicAdd(&slab_cnt[q * NM_GSUB + (blockIdx.x & (NM_GSUB - 1))], s_h[q]);
+}
+// every workgroup scans the NM_GS counters for itself (cheaper than a launch in between); workgroup 0 publishes the offsets
+__global__ void __launch_bounds__(256) k_slab_scatter(RK k, int K, const int* __restrict__ radii, const float2* __restrict__ xy,
+                                                      const float* __restrict__ depth, const uint2* __restrict__ zrange, int nrange,
+                                                      const uint32_t* __restrict__ slab_cnt, uint32_t* __restrict__ slab_cur,
+                                                      uint32_t* __restrict__ slab_off, unsigned long long* __restrict__ gkeys,
+                                                      uint32_t* __restrict__ hdr2) {
+  __shared__ uint32_t s_lo[4], s_hi[4];
+  __shared__ uint32_t s_off[NM_GS + 1], s_w[4], s_m[4];
+  uint32_t zlo, zhi;
+  wg_depth_range(zrange, nrange, s_lo, s_hi, zlo, zhi);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // thread t: slabs 4 t .. 4 t + 3, NM_GSUB counters each (32 consecutive words)
+  uint32_t c[NM_GS / 256], sum = 0u, big = 0u;
+  const int sub = blockIdx.x & (NM_GSUB - 1);
+  uint32_t mine_before[NM_GS / 256];      // counters of this slab in front of this workgroup's own sub-counter
+#pragma unroll
+  for (int q = 0; q < NM_GS / 256; ++q) {
+    const uint4* cp = reinterpret_cast<const uint4*>(slab_cnt + (size_t)(threadIdx.x * (NM_GS / 256) + q) * NM_GSUB);
+    const uint4 a = cp[0], b = cp[1];
+    const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t tot = 0u, bef = 0u;
+#pragma unroll
+    for (int u = 0; u < NM_GSUB; ++u) { bef += u < sub ? v[u] : 0u; tot += v[u]; }
+    c[q] = tot; mine_before[q] = bef; sum += tot; big = max(big, tot);
+  }
+  uint32_t incl = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += y; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) big = max(big, (uint32_t)__shfl_xor((int)big, o, 64));
+  if (lane == 63) s_w[wave] = incl;
+  if (lane == 0) s_m[wave] = big;
+  __syncthreads();
+  uint32_t before = incl - sum;
+  for (int w = 0; w < wave; ++w) before += s_w[w];
+  __shared__ uint32_t s_sub[NM_GS];       // where this workgroup's sub-counter starts inside the slab
+#pragma unroll
+  for (int q = 0; q < NM_GS / 256; ++q) {
+    s_off[threadIdx.x * (NM_GS / 256) + q] = before;
+    s_sub[threadIdx.x * (NM_GS / 256) + q] = before + mine_before[q];
+    before += c[q];
+  }
+  if (threadIdx.x == 255) s_off[NM_GS] = before;
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    for (int q = threadIdx.x; q <= NM_GS; q += 256) slab_off[q] = s_off[q];
+    if (threadIdx.x == 0) { hdr2[0] = s_off[NM_GS]; hdr2[3] = 0u; hdr2[6] = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3])); }
+  }
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (gaussian_live(k, i, K, radii, xy)) {
+    const float z = depth[i];
+    const int sl = gslab_of(z, zlo, zhi);
+    const uint32_t pos = s_sub[sl] + atomicAdd(&slab_cur[sl * NM_GSUB + sub], 1u);
+    gkeys[pos] = ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)(uint32_t)i;
+  }
+}
+
+// count pass over depth-ordered chunks: see the header of this section.  Dynamic LDS: nbin * 8 mask words | nbin + 1 prefix words.
+__global__ void __launch_bounds__(256) k_bin_count2(RK k, int nbx, int nbin, const uint32_t* __restrict__ hdr2,
+                                                    const unsigned long long* __restrict__ gkeys, const int* __restrict__ radii,
+                                                    const float2* __restrict__ xy, const float4* __restrict__ conop,
+                                                    uint32_t* __restrict__ hist, PairLog* __restrict__ log, uint32_t* __restrict__ hdr,
+                                                    long long cap) {
+  extern __shared__ uint32_t s_dyn[];
+  uint32_t* s_mask = s_dyn;                    // [nbin][8]
+  uint32_t* s_pref = s_dyn + (size_t)nbin * 8;   // [nbin + 1]
+  __shared__ int s_excl[4][64];
+  __shared__ RowCull s_tc[4][64];
+  __shared__ int4 s_geo[4][64], s_bin[4][64];
+  __shared__ uint32_t s_id[4][64];
+  __shared__ unsigned char s_owner[4][NM_B2_OWN];
+  __shared__ uint2 s_stash[4][NM_B2_STASH];
+  __shared__ uint32_t s_wsum[4], s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int chunk = blockIdx.x;
+  const uint32_t nvis = hdr2[0];
+  for (int q = tid; q < nbin * 8; q += 256) s_mask[q] = 0u;
+  const uint32_t at_ = (uint32_t)chunk * 256u + (uint32_t)tid;
+  bool live = at_ < nvis;
+  int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+  uint32_t id = 0u;
+  RowCull tc = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f, -1.f, 0.f};
+  if (live) {
+    id = (uint32_t)gkeys[at_];
+    const float2 p = xy[id];
+    get_rect(k, p.x, p.y, radii[id], x0, y0, x1, y1, k.ty0, k.ty1);
+    tc = make_row_cull(p.x, p.y, conop[id]);
+  }
+  const int bx0 = x0 / NM_BT, bx1 = live ? (x1 - 1) / NM_BT : -1, by0 = y0 / NM_BT, by1 = live ? (y1 - 1) / NM_BT : -1;
+  const int nbw = bx1 - bx0 + 1;
+  const int mine = live ? nbw * (by1 - by0 + 1) : 0;
+  int incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
+  const int wave_total = __shfl(incl, 63, 64);
+  s_excl[wv][lane] = incl - mine;
+  s_tc[wv][lane] = tc;
+  s_geo[wv][lane] = make_int4(x0, y0, x1, y1);
+  s_bin[wv][lane] = make_int4(bx0, by0, nbw, 0);
+  s_id[wv][lane] = id;
+  for (int q = 0; q < mine; ++q) {
+    const int w_ = incl - mine + q;
+    if (w_ < NM_B2_OWN) s_owner[wv][w_] = (unsigned char)lane;
+  }
+  __syncthreads();
+  // one candidate pair (position pr of the wave's sequence): its owner lane, bin and exact tile mask
+  auto pair_at = [&](int pr, int& owner, int& bin, uint32_t& m) {
+    if (pr < NM_B2_OWN) owner = (int)s_owner[wv][pr];
+    else {
+      owner = 0;
+      int hi_ = 64;
+#pragma unroll
+      for (int it = 0; it < 6; ++it) { const int mid = (owner + hi_) >> 1; if (s_excl[wv][mid] <= pr) owner = mid; else hi_ = mid; }
+    }
+    const int q = pr - s_excl[wv][owner];
+    const int4 g = s_geo[wv][owner], bn = s_bin[wv][owner];
+    const RowCull t = s_tc[wv][owner];
+    const int by = bn.y + q / bn.z, bx = bn.x + q % bn.z;
+    m = bin_tile_mask(t, g, bx, by);
+    bin = by * nbx + bx;
+  };
+  // ---- walk 1: membership bits
+  for (int p0 = 0; p0 < wave_total; p0 += 64) {
+    const int pr = p0 + lane;
+    if (pr < wave_total) {
+      int owner, bin;
+      uint32_t m;
+      pair_at(pr, owner, bin, m);
+      const int gl = 64 * wv + owner;
+      if (m) atomicOr(&s_mask[bin * 8 + (gl >> 5)], 1u << (gl & 31));
+      if (pr < NM_B2_STASH) s_stash[wv][pr] = make_uint2((uint32_t)bin | ((uint32_t)gl << 16), m);
+    }
+  }
+  __syncthreads();
+  // ---- per-bin counts of this chunk -> global row; exclusive prefix over the bins in LDS
+  uint32_t run = 0u;
+  const int per = (nbin + 255) / 256;
+  const int b_lo = tid * per, b_hi = min(nbin, b_lo + per);
+  for (int b = b_lo; b < b_hi; ++b) {
+    uint32_t n = 0u;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) n += (uint32_t)__popc(s_mask[b * 8 + w]);
+    hist[(size_t)chunk * nbin + b] = n;
+    s_pref[b] = run;          // (exclusive inside this thread's stretch; the stretch's offset is added below)
+    run += n;
+  }
+  uint32_t inc2 = run;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)inc2, o, 64); if (lane >= o) inc2 += y; }
+  if (lane == 63) s_wsum[wv] = inc2;
+  __syncthreads();
+  uint32_t before = inc2 - run;
+  for (int w = 0; w < wv; ++w) before += s_wsum[w];
+  for (int b = b_lo; b < b_hi; ++b) s_pref[b] += before;
+  if (tid == 0) {
+    const uint32_t tot = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    s_base = tot ? atomicAdd(&hdr[2], tot) : 0u;      // ONE reservation per workgroup
+  }
+  __syncthreads();
+  const long long base = (long long)s_base;
+  // ---- walk 2: ranks and log entries (grouped by bin, inside a bin in Gaussian = depth order)
+  for (int p0 = 0; p0 < wave_total; p0 += 64) {
+    const int pr = p0 + lane;
+    if (pr < wave_total) {
+      int bin, gl;
+      uint32_t m;
+      if (pr < NM_B2_STASH) {
+        const uint2 e = s_stash[wv][pr];
+        bin = (int)(e.x & 0xffffu); gl = (int)(e.x >> 16); m = e.y;
+      } else {
+        int owner;
+        pair_at(pr, owner, bin, m);
+        gl = 64 * wv + owner;
+      }
+      if (m) {
+        uint32_t rank = 0u;
+        const int wq = gl >> 5;
+        for (int w = 0; w < wq; ++w) rank += (uint32_t)__popc(s_mask[bin * 8 + w]);
+        rank += (uint32_t)__popc(s_mask[bin * 8 + wq] & ((1u << (gl & 31)) - 1u));
+        const long long slot = base + (long long)s_pref[bin] + rank;
+        if (slot < cap) {
+          PairLog e;
+          e.cell = (uint32_t)chunk * (uint32_t)nbin + (uint32_t)bin; e.rank = rank; e.id = s_id[gl >> 6][gl & 63]; e.mask = m;
+          log[slot] = e;
+        }
+      }
+    }
+  }
+}
+// per bin: pairs of all chunks
+__global__ void __launch_bounds__(256) k_col_sum(int nbin, int nchunk, const uint32_t* __restrict__ hist, uint32_t* __restrict__ bin_total) {
+  __shared__ uint32_t s_w[4];
+  const int bin = blockIdx.x, lane = threadIdx.x & 63;
+  uint32_t sum = 0u;
+  for (int c = threadIdx.x; c < nchunk; c += 256) sum += hist[(size_t)c * nbin + bin];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += (uint32_t)__shfl_xor((int)sum, o, 64);
+  if (lane == 0) s_w[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) bin_total[bin] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+// per bin: offset of the bin's list (= the totals of the bins in front of it) + exclusive scan of its chunks' counts
+__global__ void __launch_bounds__(256) k_col_scan(int nbin, int nchunk, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ bin_total,
+                                                  uint32_t* __restrict__ coff, uint32_t* __restrict__ off, uint32_t* __restrict__ hdr,
+                                                  long long cap) {
+  __shared__ uint32_t s_p[4], s_w[4];
+  const int bin = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t pre = 0u;
+  for (int b = threadIdx.x; b < bin; b += 256) pre += bin_total[b];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) pre += (uint32_t)__shfl_xor((int)pre, o, 64);
+  const int per = (nchunk + 255) / 256;
+  const int c_lo = threadIdx.x * per, c_hi = min(nchunk, c_lo + per);
+  uint32_t run = 0u;
+  for (int c = c_lo; c < c_hi; ++c) run += hist[(size_t)c * nbin + bin];
+  uint32_t incl = run;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += y; }
+  if (lane == 63) s_w[wave] = incl;
+  if (lane == 0) s_p[wave] = pre;
+  __syncthreads();
+  const uint32_t base = s_p[0] + s_p[1] + s_p[2] + s_p[3];
+  uint32_t at = base + incl - run;
+  for (int w = 0; w < wave; ++w) at += s_w[w];
+  for (int c = c_lo; c < c_hi; ++c) { coff[(size_t)c * nbin + bin] = at; at += hist[(size_t)c * nbin + bin]; }
+  if (threadIdx.x == 0) {
+    off[(size_t)bin * NM_NS] = base;
+    if (bin == nbin - 1) {
+      const uint32_t total = base + s_w[0] + s_w[1] + s_w[2] + s_w[3];
+      off[(size_t)nbin * NM_NS] = total;
+      hdr[3] = ((long long)hdr[2] > cap) ? 1u : 0u;
+      hdr[6] = 0u;
+    }
+  }
+}
+
 #ifdef NM_FIXDBG
 __device__ unsigned long long* g_fixdbg;
 extern "C" int nm_debug_fix_buffer(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_fixdbg), &p, sizeof(p)) == hipSuccess ? 0 : -2; }
@@ -854,17 +1215,21 @@ __device__ __forceinline__ uint32_t composite_range(CompLds& L, long long lo, lo
     // ---- NM_SCAN candidates: which of them touch this tile (bit of their tile mask)?
     const long long c = base + 16 * tid;
     uint32_t m16 = 0;
+    // All four loads are requested before any of them is looked at (round 5): written as `if (q0 < b) { load; test }` four
+    // times, the compiler kept each load inside its own branch - four HBM / L2 round trips in a row per round and thread.  A
+    // group past the end reads the range's last group instead (in bounds: the array is padded to 256 bytes) and is masked out.
+    uint4 v[4];
+    const long long qlast = (b - 1) & ~3ll;
+#pragma unroll
+    for (int v4 = 0; v4 < 4; ++v4) v[v4] = *(const uint4*)(vals + min(c + 4 * v4, qlast));
 #pragma unroll
     for (int v4 = 0; v4 < 4; ++v4) {
       const long long q0 = c + 4 * v4;
-      if (q0 < b) {                      // the array is padded to 256 bytes: a 16-byte load at an aligned q0 < cap stays inside
-        const uint4 v = *(const uint4*)(vals + q0);
-        const uint32_t b4 = ((v.x & bit) ? 1u : 0u) | ((v.y & bit) ? 2u : 0u) | ((v.z & bit) ? 4u : 0u) | ((v.w & bit) ? 8u : 0u);
-        uint32_t ok = 0;
+      const uint32_t b4 = ((v[v4].x & bit) ? 1u : 0u) | ((v[v4].y & bit) ? 2u : 0u) | ((v[v4].z & bit) ? 4u : 0u) | ((v[v4].w & bit) ? 8u : 0u);
+      uint32_t ok = 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) ok |= (q0 + q >= a && q0 + q < b) ? (1u << q) : 0u;
-        m16 |= (b4 & ok) << (4 * v4);
-      }
+      for (int q = 0; q < 4; ++q) ok |= (q0 + q >= a && q0 + q < b) ? (1u << q) : 0u;
+      m16 |= (b4 & ok) << (4 * v4);
     }
     const int mine = __popc(m16);
     int incl = mine;
@@ -890,9 +1255,14 @@ __device__ __forceinline__ uint32_t composite_range(CompLds& L, long long lo, lo
       const int nb = min(NM_TPB, nh - h0);
       uint32_t idr[4];
 #pragma unroll
+      for (int q = 0; q < 4; ++q)        // all four keys requested at clamped slots ...
+        idr[q] = (uint32_t)keys[lo + L.hit[h0 + min(64 * q + lane, nb - 1)] - 1];
+#pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int t = 64 * q + lane;
-        idr[q] = t < nb ? (uint32_t)keys[lo + L.hit[h0 + t] - 1] * (uint32_t)sizeof(GRec) : null_off;
+        // ... and pinned as unconditional (the empty asm): `t < nb ? load : null` - however it is spelled - is sunk into a branch
+        // per load by the compiler, i.e. four round trips in a row per batch of 256 hits
+        asm volatile("" : "+v"(idr[q]));
+        idr[q] = 64 * q + lane < nb ? idr[q] * (uint32_t)sizeof(GRec) : null_off;
       }
       FIXACC(3, tph);
       int lastj = -1;
@@ -1444,9 +1814,13 @@ __global__ void __launch_bounds__(256) k_count_pairs(RK k, int K, const int* __r
     const float2 p = xy[i];
     int x0, y0, x1, y1;
     get_rect(k, p.x, p.y, radii[i], x0, y0, x1, y1, k.ty0, k.ty1);
-    const TileCull tc = make_tile_cull(p.x, p.y, conop[i]);
-    for (int y = y0; y < y1; ++y)
-      for (int x = x0; x < x1; ++x) cnt += tile_contributes(tc, x, y) ? 1ull : 0ull;
+    // (the binning passes' own function, bin by bin: the count is the number of mask bits they set)
+    if ((x1 - x0) * (y1 - y0) != 0) {
+      const RowCull rc = make_row_cull(p.x, p.y, conop[i]);
+      const int4 g = make_int4(x0, y0, x1, y1);
+      for (int by = y0 / NM_BT; by <= (y1 - 1) / NM_BT; ++by)
+        for (int bx = x0 / NM_BT; bx <= (x1 - 1) / NM_BT; ++bx) cnt += (unsigned long long)__popc(bin_tile_mask(rc, g, bx, by));
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) cnt += (unsigned long long)__shfl_xor((long long)cnt, o, 64);
@@ -1582,9 +1956,14 @@ __device__ __forceinline__ void render_bwd_range(BwdLdsR& L, const RK& k, long l
     const long long c = top - 1 - 16 * tid;     // this thread's candidates: c, c-1, ..., c-15
     uint32_t m16 = 0;
     if (tid < NM_RB_SCAN / 16) {
+      // (the sixteen masks are requested together, a candidate below the range reads the range's first entry and is masked
+      //  out: `if (in range && (vals[..] & bit))` sixteen times was sixteen round trips in a row, round 5)
+      uint32_t vv[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) vv[q] = vals[max(c - q, bottom)];
 #pragma unroll
       for (int q = 0; q < 16; ++q)
-        if (c - q >= bottom && (vals[c - q] & bit)) m16 |= 1u << q;
+        if (c - q >= bottom && (vv[q] & bit)) m16 |= 1u << q;
     }
     const int mine = __popc(m16);
     int incl = mine;
@@ -1606,15 +1985,18 @@ __device__ __forceinline__ void render_bwd_range(BwdLdsR& L, const RK& k, long l
     // (lane l: hits l and l + 64), pulls hit j's out with v_readlane and fetches the record with scalar loads (see GRec)
     uint32_t offr[NM_RB_BATCH / 64], posr[NM_RB_BATCH / 64];
 #pragma unroll
+    for (int q = 0; q < NM_RB_BATCH / 64; ++q) {      // both groups' keys requested at clamped slots ...
+      posr[q] = L.hit[h0 + min(64 * q + lane, nb - 1)];
+      offr[q] = (uint32_t)keys[lo + posr[q] - 1];
+    }
+#pragma unroll
     for (int q = 0; q < NM_RB_BATCH / 64; ++q) {
       const int t = 64 * q + lane;
-      offr[q] = k.K * (uint32_t)sizeof(GRec); posr[q] = 0xFFFFFFFFu;        // padding: the null record, behind everything
-      if (t < nb) {
-        const uint32_t pos = L.hit[h0 + t];
-        const uint32_t id = (uint32_t)keys[lo + pos - 1];
-        offr[q] = id * (uint32_t)sizeof(GRec); posr[q] = pos;
-        if (wave == 0) L.id[t] = id;
-      }
+      asm volatile("" : "+v"(offr[q]));      // ... and pinned as unconditional (the compiler sinks a conditional load into its branch)
+      const uint32_t id = offr[q];
+      offr[q] = t < nb ? id * (uint32_t)sizeof(GRec) : k.K * (uint32_t)sizeof(GRec);        // padding: the null record ...
+      posr[q] = t < nb ? posr[q] : 0xFFFFFFFFu;                                             // ... behind everything
+      if (t < nb && wave == 0) L.id[t] = id;
     }
     auto one = [&](const float4& g0, const float4& g1, const float2& g2, uint32_t pos, int j) {
       if (pos > wave_last) return;              // wave-uniform: behind every pixel's last contributor
@@ -1821,9 +2203,12 @@ __device__ __forceinline__ void render_bwd_range2(BwdLdsR2& L, const RK& k, long
     __syncthreads();
     const long long c = top - 1 - 16 * tid;     // this thread's candidates: c, c-1, ..., c-15 (128 threads x 16 = NM_RB_SCAN)
     uint32_t m16 = 0;
+    uint32_t vv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) vv[q] = vals[max(c - q, bottom)];
 #pragma unroll
     for (int q = 0; q < 16; ++q)
-      if (c - q >= bottom && (vals[c - q] & bit)) m16 |= 1u << q;
+      if (c - q >= bottom && (vv[q] & bit)) m16 |= 1u << q;
     const int mine = __popc(m16);
     int incl = mine;
 #pragma unroll
@@ -1841,14 +2226,17 @@ __device__ __forceinline__ void render_bwd_range2(BwdLdsR2& L, const RK& k, long
       uint32_t offr[NM_RB_BATCH / 64], posr[NM_RB_BATCH / 64];
 #pragma unroll
       for (int q = 0; q < NM_RB_BATCH / 64; ++q) {
+        posr[q] = L.hit[h0 + min(64 * q + lane, nb - 1)];
+        offr[q] = (uint32_t)keys[lo + posr[q] - 1];
+      }
+#pragma unroll
+      for (int q = 0; q < NM_RB_BATCH / 64; ++q) {
         const int t = 64 * q + lane;
-        offr[q] = k.K * (uint32_t)sizeof(GRec); posr[q] = 0xFFFFFFFFu;        // padding: the null record, behind everything
-        if (t < nb) {
-          const uint32_t pos = L.hit[h0 + t];
-          const uint32_t id = (uint32_t)keys[lo + pos - 1];
-          offr[q] = id * (uint32_t)sizeof(GRec); posr[q] = pos;
-          if (wave == 0) L.id[t] = id;
-        }
+        asm volatile("" : "+v"(offr[q]));
+        const uint32_t id = offr[q];
+        offr[q] = t < nb ? id * (uint32_t)sizeof(GRec) : k.K * (uint32_t)sizeof(GRec);        // padding: the null record ...
+        posr[q] = t < nb ? posr[q] : 0xFFFFFFFFu;                                             // ... behind everything
+        if (t < nb && wave == 0) L.id[t] = id;
       }
       auto one = [&](const float4& g0, const float4& g1, const float2& g2, uint32_t pos, int j) {
         if (pos > wave_last) return;              // wave-uniform: behind every pixel's last contributor
@@ -2247,7 +2635,52 @@ static int raster_forward_impl(const nm_raster_cfg* cfg, int32_t K, int32_t m, c
   }
   hipStream_t s = (hipStream_t)stream;
   const int nrange = nm_div_up(K, 256);
+  const int nbin = t.nbx * t.nby;
   if (K == 0) NM_HIP_CHECK(hipMemsetAsync(t.hdr, 0, 256, s));      // (otherwise k_preprocess zeroes the header)
+  static const int binning_cells = [] { const char* e = getenv("NEUMA_BINNING"); return (e && !strcmp(e, "cells")) ? 1 : 0; }();
+  const size_t b2_lds = ((size_t)nbin * 9 + 1) * sizeof(uint32_t);
+  const bool chunks = !binning_cells && nbin <= NM_B2_MAXBIN;       // (binning by depth-ordered chunks: see k_bin_count2)
+  if (chunks) {
+    NM_HIP_CHECK(hipMemsetAsync(t.slab_blk, 0, (2 * NM_GS * NM_GSUB + 64) * sizeof(uint32_t), s));
+    uint32_t* hdr2 = t.slab_blk + 2 * NM_GS * NM_GSUB;
+    if (K > 0) {
+      NM_LAUNCH(k_preprocess, dim3(nrange), dim3(256), 0, s, k, K, means3D, shs, colors_precomp, opacities, cov3D, radii,
+                t.xy, t.depth, t.conop, t.rgb, t.clamped, t.rad, t.zrange, t.recs, t.hdr);
+      NM_LAUNCH_CHECK();
+      NM_LAUNCH(k_slab_hist, dim3(nrange), dim3(256), 0, s, k, K, (const int*)t.rad, (const float2*)t.xy, (const float*)t.depth,
+                (const uint2*)t.zrange, nrange, t.slab_blk);
+      NM_LAUNCH_CHECK();
+      NM_LAUNCH(k_slab_scatter, dim3(nrange), dim3(256), 0, s, k, K, (const int*)t.rad, (const float2*)t.xy, (const float*)t.depth,
+                (const uint2*)t.zrange, nrange, (const uint32_t*)t.slab_blk, t.slab_blk + NM_GS * NM_GSUB, t.slab_off, t.gkeys, hdr2);
+      NM_LAUNCH_CHECK();
+      NM_LAUNCH(k_cell_sort, dim3(NM_GS / 4), dim3(256), 0, s, NM_GS, (const uint32_t*)t.slab_off, t.gkeys, t.gvals, (long long)K,
+                (const uint32_t*)hdr2);
+      NM_LAUNCH_CHECK();
+      static bool attr_set = false;
+      if (!attr_set) {
+        NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_bin_count2, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)(((size_t)NM_B2_MAXBIN * 9 + 1) * sizeof(uint32_t))));
+        attr_set = true;
+      }
+      NM_LAUNCH(k_bin_count2, dim3(t.nchunk), dim3(256), b2_lds, s, k, t.nbx, nbin, (const uint32_t*)hdr2,
+                (const unsigned long long*)t.gkeys, (const int*)t.rad, (const float2*)t.xy, (const float4*)t.conop, t.hist, t.log, t.hdr,
+                (long long)cap_pairs);
+      NM_LAUNCH_CHECK();
+    } else {
+      NM_HIP_CHECK(hipMemsetAsync(t.hist, 0, (size_t)t.nchunk * nbin * sizeof(uint32_t), s));
+    }
+    NM_LAUNCH(k_col_sum, dim3(nbin), dim3(256), 0, s, nbin, t.nchunk, (const uint32_t*)t.hist, t.bin_total);
+    NM_LAUNCH_CHECK();
+    NM_LAUNCH(k_col_scan, dim3(nbin), dim3(256), 0, s, nbin, t.nchunk, (const uint32_t*)t.hist, (const uint32_t*)t.bin_total, t.coff, t.off,
+              t.hdr, (long long)cap_pairs);
+    NM_LAUNCH_CHECK();
+    if (K > 0) {
+      NM_LAUNCH(k_bin_fill, dim3(min(2048, nm_div_up((int)min((int64_t)cap_pairs, (int64_t)K * 64), 256) + 1)), dim3(256), 0, s,
+                (const uint32_t*)t.hdr, (const PairLog*)t.log, (const uint32_t*)t.coff, (const float*)t.depth, t.keys, t.vals,
+                (long long)cap_pairs);
+      NM_LAUNCH_CHECK();
+    }
+  } else {
   NM_HIP_CHECK(hipMemsetAsync(t.pad, 0, (size_t)t.ncell * NM_PAD * sizeof(uint32_t), s));
   if (K > 0) {
     NM_LAUNCH(k_preprocess, dim3(nrange), dim3(256), 0, s, k, K, means3D, shs, colors_precomp, opacities, cov3D, radii,
@@ -2257,7 +2690,6 @@ static int raster_forward_impl(const nm_raster_cfg* cfg, int32_t K, int32_t m, c
               t.pad, t.log, t.hdr, (long long)cap_pairs);
     NM_LAUNCH_CHECK();
   }
-  const int nbin = t.nbx * t.nby;
   NM_LAUNCH(k_bin_compact, dim3(nbin), dim3(NM_NS), 0, s, nbin, (const uint32_t*)t.pad, t.cnt, t.bin_total, t.hdr);
   NM_LAUNCH_CHECK();
   NM_LAUNCH(k_cell_offsets, dim3(nbin), dim3(NM_NS), 0, s, nbin, (const uint32_t*)t.cnt, (const uint32_t*)t.bin_total, t.off, t.hdr,
@@ -2271,6 +2703,7 @@ static int raster_forward_impl(const nm_raster_cfg* cfg, int32_t K, int32_t m, c
     NM_LAUNCH(k_cell_sort, dim3(min(nm_div_up(t.ncell, 4), 8192)), dim3(256), 0, s, t.ncell, (const uint32_t*)t.off, t.keys, t.vals,
               (long long)cap_pairs, (const uint32_t*)t.hdr);
     NM_LAUNCH_CHECK();
+  }
   }
   NM_LAUNCH(k_split_plan, dim3(1), dim3(1024), 0, s, k, t.nbx, (uint32_t)g_split_busy, (uint32_t)g_split_minseg,
             (unsigned long long)g_split_fwd,
