@@ -22,6 +22,8 @@ def group(case: str) -> str:
     return re.sub(r"\s+", " ", case).strip()
 
 
+auto = [r for r in rows if re.match(r"[\w /,'-]+ @ test_\w+\.py:\d+: ", r["tensor"])]
+rows = [r for r in rows if r not in auto]
 agg = collections.OrderedDict()
 for r in rows:
     k = (group(r["case"]), r["tensor"])
@@ -34,3 +36,19 @@ print("| comparison | tensor | measured (max) | bound in the test | reference's 
 for (c, t), a in agg.items():
     noise = "-" if a["n"] is None else f"{a['n']:.1e}"
     print(f"| {c} | {t} | {a['m']:.1e} | {a['b']:.1e} | {noise} |")
+
+
+# ---- comparisons that publish themselves (tests/gpu_util.Measured): one row per source line of a test
+if auto:
+    sites = collections.OrderedDict()
+    for r in auto:
+        m = re.match(r"([\w /,'-]+) @ (test_\w+\.py):(\d+): (.*)", r["tensor"])
+        test = r["case"].split("::")[-1].split("[")[0]
+        k = (m.group(2), int(m.group(3)), r["bound"])
+        a = sites.setdefault(k, {"m": 0.0, "n": 0, "kind": m.group(1), "test": test, "src": m.group(4)})
+        a["m"] = max(a["m"], r["measured"]); a["n"] += 1
+    print("\n| test (file:line) | quantity | comparisons | measured (max) | bound in the test |\n|---|---|---:|---:|---:|")
+    for (f, ln, b), a in sorted(sites.items()):
+        src = re.sub(r"\s*#.*$", "", a["src"]).replace("|", "/").replace("assert ", "")
+        src = re.sub(r"\s+", " ", src)[:70]
+        print(f"| `{a['test']}` ({f.replace('test_gpu_', '').replace('.py', '')}:{ln}) | {a['kind']}: `{src}` | {a['n']} | {a['m']:.1e} | {b:.1e} |")
