@@ -22,7 +22,7 @@ def group(case: str) -> str:
     return re.sub(r"\s+", " ", case).strip()
 
 
-auto = [r for r in rows if re.match(r"[\w /,'-]+ @ test_\w+\.py:\d+: ", r["tensor"])]
+auto = [r for r in rows if re.match(r".+? @ test_\w+\.py:\d+: ", r["tensor"])]
 rows = [r for r in rows if r not in auto]
 agg = collections.OrderedDict()
 for r in rows:
@@ -42,7 +42,7 @@ for (c, t), a in agg.items():
 if auto:
     sites = collections.OrderedDict()
     for r in auto:
-        m = re.match(r"([\w /,'-]+) @ (test_\w+\.py):(\d+): (.*)", r["tensor"])
+        m = re.match(r"(.+?) @ (test_\w+\.py):(\d+): (.*)", r["tensor"])
         test = r["case"].split("::")[-1].split("[")[0]
         k = (m.group(2), int(m.group(3)), r["bound"])
         a = sites.setdefault(k, {"m": 0.0, "n": 0, "kind": m.group(1), "test": test, "src": m.group(4)})
