@@ -349,6 +349,11 @@ int nm_rccl_time_all_reduce(nm_rccl* c, float* buf, int64_t count, int32_t warm,
  * The backward (B^T g) is the same call on the transposed CSR. */
 int nm_spmm_csr(int32_t rows, int32_t D, const int32_t* rowptr, const int32_t* col,
                 const float* val, const float* in, float* out, void* stream);
+/* The reverse sweep's form of the same product (d loss / d particle positions, the adjoint of compute_bindings_xyz,
+ * tune/utils.py:424-448, through finetune.py:373's (x - center) / size): out (rows x 3) = scale * A (in0 + in1 + in2 + in3),
+ * the inputs being the views' dL/dmeans3D (in1..in3 may be NULL, in order), A the transposed CSR. */
+int nm_spmm_csr_sum3(int32_t rows, const int32_t* rowptr, const int32_t* col, const float* val, const float* in0,
+                     const float* in1, const float* in2, const float* in3, float scale, float* out, void* stream);
 /* Binding construction (data preparation): gaussian_binding_with_clip_v1 / gaussian_binding,
  * modules/d3gs/utils/binding_utils.py:199-285 / 123-196.  Particle j binds to Gaussian k iff (x_j - mean_k)^T inv(cov_k)
  * (x_j - mean_k) <= threshold (= chi2.ppf(confidence, 3)); at most max_particles (<= 16) per Gaussian, the ones with the

@@ -98,6 +98,7 @@ SIGNATURES = {
     "nm_material_bwd_workspace": (_SZ, [_I32]),
     "nm_material_bwd": (C.c_int, [_I32, _I32, _F, _P, C.POINTER(nm_mlp), _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "nm_spmm_csr": (C.c_int, [_I32, _I32, _P, _P, _P, _P, _P, _P]),
+    "nm_spmm_csr_sum3": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P]),
     "nm_cov_deform": (C.c_int, [_I32, _P, _P, _P, _P]),
     "nm_bind_build_workspace": (_SZ, [_I32, _I32]),
     "nm_bind_build": (C.c_int, [_I32, _I32, _P, _P, _P, C.POINTER(C.c_float), _F, C.POINTER(_I32), _F, _I32, _P, _P, _P, _P, _P, _SZ,

@@ -50,6 +50,47 @@ extern "C" int nm_spmm_csr(int32_t rows, int32_t D, const int32_t* rowptr, const
   return NM_OK;
 }
 
+// out = scale * A (in0 + in1 + in2 + in3), three columns: B^T of the views' summed dL/dmeans3D and the 1 / size of finetune.py:373
+// in one pass (the frame's reverse sweep ran two adds, the product and a division as four launches between the renders' adjoints
+// and the roll-out's).  Sixteen lanes share a row's entries, as in k_spmm_csr's D <= 4 branch.
+__global__ void __launch_bounds__(256) k_spmm_csr_sum3(int rows, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                       const float* __restrict__ val, const float* __restrict__ in0,
+                                                       const float* __restrict__ in1, const float* __restrict__ in2,
+                                                       const float* __restrict__ in3, float scale, float* __restrict__ out) {
+  const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int c = threadIdx.x & 15;
+  if (r >= rows) return;
+  const int b = rowptr[r], e = rowptr[r + 1];
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int q = b + c; q < e; q += 16) {
+    const float w = val[q];
+    const size_t o = (size_t)col[q] * 3;
+    float s0 = in0[o], s1 = in0[o + 1], s2 = in0[o + 2];
+    if (in1) { s0 += in1[o]; s1 += in1[o + 1]; s2 += in1[o + 2]; }
+    if (in2) { s0 += in2[o]; s1 += in2[o + 1]; s2 += in2[o + 2]; }
+    if (in3) { s0 += in3[o]; s1 += in3[o + 1]; s2 += in3[o + 2]; }
+    a0 += w * s0; a1 += w * s1; a2 += w * s2;
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    a0 += __shfl_xor(a0, o, 16); a1 += __shfl_xor(a1, o, 16); a2 += __shfl_xor(a2, o, 16);
+  }
+  if (c < 3) out[(size_t)r * 3 + c] = scale * (c == 0 ? a0 : (c == 1 ? a1 : a2));
+}
+
+extern "C" int nm_spmm_csr_sum3(int32_t rows, const int32_t* rowptr, const int32_t* col, const float* val, const float* in0,
+                                const float* in1, const float* in2, const float* in3, float scale, float* out, void* stream) {
+  NM_REQUIRE(rows >= 0, "bad shape");
+  if (rows == 0) return NM_OK;
+  NM_REQUIRE(rowptr && col && val && in0 && out, "null pointer");
+  NM_REQUIRE(in2 || !in3, "inputs must be given in order (in3 without in2)");
+  NM_REQUIRE(in1 || !in2, "inputs must be given in order (in2 without in1)");
+  NM_LAUNCH(k_spmm_csr_sum3, dim3(nm_div_up((int64_t)rows * 16, 256)), dim3(256), 0, (hipStream_t)stream, rows, rowptr, col, val,
+                     in0, in1, in2, in3, scale, out);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}
+
 __device__ __forceinline__ void cov_push(const float* __restrict__ c6, const M3& Fm, float* __restrict__ o6) {
   M3 S;
   S.m[0] = c6[0]; S.m[1] = c6[1]; S.m[2] = c6[2];

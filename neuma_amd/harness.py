@@ -127,13 +127,18 @@ class _FrameTail(torch.autograd.Function):
         return None, dx * g, None, None, None, None
 
 
-def _tail_forward(rt, p_cur, Fc, weight, jobs, streams, gt=None, step=None):
+def _tail_forward(rt, p_cur, Fc, weight, jobs, streams, gt=None, step=None, eager=None):
     """Binding + covariance push-forward (one launch), then per render job rasterizer forward + pixel loss (value and dL/dimage
     in one pass).  p_cur (N, 3), Fc (N, 9): contiguous fp32, outside autograd.  gt / step: the ground-truth images and the
     dataset step of THIS frame (multi-frame epochs; default: the runtime's single frame).  Returns (loss, records, dL/dimage
-    per job, tensors the records point into)."""
+    per job, tensors the records point into).
+    eager: a list = the caller WILL run the reverse sweep of exactly this forward pass with dL/dloss = const (SceneRuntime.frame:
+    forward and reverse are two calls back to back): dL/dimage of a job depends on nothing but that job's image, so its
+    rasterizer adjoint is enqueued right behind its loss, on the job's own stream - no join of the streams between the sweeps
+    (two event round trips and the loss sum were ~70 us of an otherwise idle device per frame) and the adjoint of the job that
+    finishes first fills the chip while the others' forward tails drain.  The jobs' dL/dmeans3D are appended to the list."""
     from . import _lib as L
-    from .render import get_rasterizer, raster_forward_raw
+    from .render import get_rasterizer, raster_forward_raw, raster_backward_raw
     lib, dev = L.lib(), p_cur.device
     b = rt.bindings
     K = b.K
@@ -159,33 +164,44 @@ def _tail_forward(rt, p_cur, Fc, weight, jobs, streams, gt=None, step=None):
         L.check(lib.nm_pixel_loss(kind, float(weight), h, w, r0, r1, L.ptr(img), L.ptr((rt.gt if gt is None else gt)[vi]), L.ptr(part), L.ptr(gimg),
                                   L.stream_ptr(dev)), "nm_pixel_loss")
         recs.append(rec); grads.append(gimg); parts.append(part)
+        if eager is not None:
+            eager.append(raster_backward_raw(rec, gimg)[0])
 
     for i, (vi, rows) in enumerate(jobs):
         if streams:
             st = streams[i]
             st.wait_stream(main)
             with torch.cuda.stream(st):
-                job(vi, rows, torch.zeros((), dtype=torch.float32, device=dev))
+                job(vi, rows, loss)         # every job's workgroups add to the ONE loss word (zeroed on main in front of the fork)
+                loss.record_stream(st)
         else:
             job(vi, rows, loss)
     if streams:
-        for st in set(streams):
-            main.wait_stream(st)
-        for t in [means3D, cov] + grads + parts:
+        if eager is None:                   # (eager: _tail_backward joins, behind whatever the caller enqueues on main meanwhile)
+            for st in set(streams):
+                main.wait_stream(st)
+        for t in [means3D, cov] + grads + (eager or []):
             t.record_stream(main)
-        loss = torch.stack(parts).sum() if len(parts) > 1 else parts[0]
     return loss, recs, grads, (means3D, cov)
 
 
-def _tail_backward(rt, recs, grads, streams, dx_out):
-    """Rasterizer adjoints of every job, dL/dmeans3D summed over the jobs (and the ranks), then B^T into dx_out (N, 3)."""
+def _tail_backward(rt, recs, grads, streams, dx_out, outs=None, scale=1.0):
+    """Rasterizer adjoints of every job, dL/dmeans3D summed over the jobs (and the ranks), then scale * B^T of the sum into
+    dx_out (N, 3).  outs: the jobs' dL/dmeans3D if _tail_forward already enqueued the adjoints (eager; its join covers them)."""
     import torch.distributed as dist
     from . import _lib as L
     from .render import raster_backward_raw
     lib, dev = L.lib(), rt.device
     total = None
-    outs = []
-    if streams:
+    b = rt.bindings
+    multi = rt.world > 1 and dist.is_available() and dist.is_initialized() and dist.get_world_size(rt.group) > 1
+    if outs is not None:
+        if streams:
+            main = torch.cuda.current_stream(dev)
+            for st in set(streams):
+                main.wait_stream(st)
+    elif streams:
+        outs = []
         main = torch.cuda.current_stream(dev)
         for st, rec, gimg in zip(streams, recs, grads):
             st.wait_stream(main)
@@ -196,24 +212,27 @@ def _tail_backward(rt, recs, grads, streams, dx_out):
         for t in outs:
             t.record_stream(main)
     else:
-        for rec, gimg in zip(recs, grads):
-            outs.append(raster_backward_raw(rec, gimg)[0])
+        outs = [raster_backward_raw(rec, gimg)[0] for rec, gimg in zip(recs, grads)]
+    if not multi and 1 <= len(outs) <= 4:       # one GPU: the sum of the jobs, B^T and the scale in ONE launch
+        ins = [L.ptr(d) for d in outs] + [None] * (4 - len(outs))
+        L.check(lib.nm_spmm_csr_sum3(b.N, L.ptr(b.t_rowptr), L.ptr(b.t_col), L.ptr(b.t_val), ins[0], ins[1], ins[2], ins[3],
+                                     float(scale), L.ptr(dx_out), L.stream_ptr(dev)), "nm_spmm_csr_sum3")
+        return
     for d in outs:
         total = d if total is None else total.add_(d)
     if total is None:       # a rank without render jobs (more ranks than tile rows): zeros, and it still joins the all-reduce
         total = torch.zeros(rt.bindings.K, 3, dtype=torch.float32, device=dev)
-    if rt.world > 1 and dist.is_available() and dist.is_initialized() and dist.get_world_size(rt.group) > 1:
+    if multi:
         from .sim.shard import all_reduce_sum_
         all_reduce_sum_(total, rt.group)        # the frame's one K x 3 all-reduce (ncclAllReduce on the library's communicator)
-    b = rt.bindings
-    L.check(lib.nm_spmm_csr(b.N, 3, L.ptr(b.t_rowptr), L.ptr(b.t_col), L.ptr(b.t_val), L.ptr(total), L.ptr(dx_out), L.stream_ptr(dev)),
-            "nm_spmm_csr")
+    L.check(lib.nm_spmm_csr_sum3(b.N, L.ptr(b.t_rowptr), L.ptr(b.t_col), L.ptr(b.t_val), L.ptr(total), None, None, None, float(scale),
+                                 L.ptr(dx_out), L.stream_ptr(dev)), "nm_spmm_csr_sum3")
 
 
 class _FrameState(object):
     """What the forward half of a one-node frame keeps for its reverse sweep."""
     __slots__ = ("recs", "grads", "streams", "keep", "states", "eff", "gcache", "svdc", "actc", "status", "ev", "cache_blocks",
-                 "adj", "weight", "ws_token", "ws_ptr")
+                 "adj", "weight", "ws_token", "ws_ptr", "outs")
 
 
 def _frame_static(rt):
@@ -242,7 +261,7 @@ def _frame_static(rt):
     return c
 
 
-def _frame_forward(rt, weight, jobs, streams):
+def _frame_forward(rt, weight, jobs, streams, eager=False):
     """Forward half of the whole frame of a one-GPU runtime, outside autograd: effective weights of both nets (one launch), the
     S-substep roll-out (nm_rollout_forward), binding + covariance push-forward, every render job + loss (finetune.py:331-389).
     Returns (loss, x, F (N, 9), _FrameState)."""
@@ -302,7 +321,8 @@ def _frame_forward(rt, weight, jobs, streams):
     last = states[S]
     x, Fl = last[:3 * n].view(n, 3), last[15 * n:24 * n].view(n, 9)
     p_cur = x if rt._unit_frame() else ((x - rt.center) / rt.size).contiguous()      # finetune.py:373
-    loss, fs.recs, fs.grads, fs.keep = _tail_forward(rt, p_cur, Fl, weight, jobs, streams)
+    fs.outs = [] if eager else None      # eager: the rasterizer adjoints ride behind their own forward pass (_tail_forward)
+    loss, fs.recs, fs.grads, fs.keep = _tail_forward(rt, p_cur, Fl, weight, jobs, streams, eager=fs.outs)
     fs.streams, fs.states, fs.eff, fs.gcache, fs.svdc, fs.actc = streams, states, eff, gcache, svdc, actc
     fs.cache_blocks, fs.adj = (cache_blocks if gcache is not None else 0), adj
     return loss, x, Fl, fs
@@ -322,7 +342,7 @@ def _frame_backward(rt, fs, g=None):
     # tail (v, C, F: nothing downstream of the roll-out reads them) stays zero
     glast = rt._scratch("glast", 4 * 24 * n, zero=True)
     dx = glast[:12 * n].view(torch.float32).view(n, 3)
-    _tail_backward(rt, fs.recs, fs.grads, fs.streams, dx)
+    _tail_backward(rt, fs.recs, fs.grads, fs.streams, dx, outs=fs.outs)
     if not rt._unit_frame():
         dx.div_(rt.size)
     if g is not None:
@@ -366,7 +386,7 @@ def _frame_backward(rt, fs, g=None):
         j.o0 = ob + 4 * goff[i]
         j.o1 = ob + 4 * (goff[i] + sizes[2 * i])
     L.check(lib.nm_lora_merge_layers_bwd(6, jb, stream), "nm_lora_merge_layers_bwd")
-    fs.recs = fs.grads = fs.keep = fs.states = fs.eff = fs.gcache = fs.svdc = fs.actc = None
+    fs.recs = fs.grads = fs.keep = fs.states = fs.eff = fs.gcache = fs.svdc = fs.actc = fs.outs = None
     return [v.view(sh) for v, sh in zip(gba.split(sizes), shapes)]
 
 
@@ -917,7 +937,7 @@ class SceneRuntime(object):
                 return FrameResult(loss.detach(), x, F.view(-1, 3, 3))
             # forward, reverse sweep, and what loss.backward() would do with the result: accumulate into .grad
             with torch.no_grad():
-                loss, x, F, fs = _frame_forward(self, float(weight), jobs, streams)
+                loss, x, F, fs = _frame_forward(self, float(weight), jobs, streams, eager=os.environ.get("NEUMA_EAGER_RENDER_BWD", "1") != "0")
                 for p, gr in zip(ba, _frame_backward(self, fs)):
                     if p.grad is None:
                         p.grad = gr

@@ -158,9 +158,13 @@ def test_one_node_frame_equals_the_composition_of_nodes(scene, over, monkeypatch
         res = {}
         # "direct": the two halves called back to back, gradients added to .grad by the runtime (what frame() does);
         # "graph": the same as an autograd node (harness._Frame) through loss.backward(); "nodes": the composition
-        for mode, (lean, graph) in {"direct": ("1", "0"), "graph": ("1", "1"), "nodes": ("0", "0")}.items():
+        # ("direct": each view's rasterizer adjoint rides behind its own forward pass and loss, no join between the sweeps;
+        # "joined": NEUMA_EAGER_RENDER_BWD=0, all adjoints after the join, as the autograd forms have it)
+        for mode, (lean, graph, eager) in {"direct": ("1", "0", "1"), "joined": ("1", "0", "0"), "graph": ("1", "1", "1"),
+                                           "nodes": ("0", "0", "1")}.items():
             monkeypatch.setenv("NEUMA_LEAN_FRAME", lean)
             monkeypatch.setenv("NEUMA_LEAN_GRAPH", graph)
+            monkeypatch.setenv("NEUMA_EAGER_RENDER_BWD", eager)
             assert rt._lean_ok() == (lean == "1")
             for _ in range(2):          # (second frame: cached capacities, pooled buffers, hinted plans)
                 for p in rt.parameters():
@@ -172,7 +176,7 @@ def test_one_node_frame_equals_the_composition_of_nodes(scene, over, monkeypatch
                 assert rel_max(p.grad, 2 * g) < 2e-5
             res[mode] = (r, grads)
         (r0, g0) = res["nodes"]
-        for mode in ("direct", "graph"):
+        for mode in ("direct", "joined", "graph"):
             r1, g1 = res[mode]
             assert torch.isfinite(r1.loss) and abs(float(r1.loss) - float(r0.loss)) < 1e-6 * max(1.0, abs(float(r0.loss)))
             assert rel_max(r1.x, r0.x) < 3e-7 and rel_max(r1.F, r0.F) < 7e-7 and r1.F.shape == r0.F.shape      # measured 9.7e-08
