@@ -733,7 +733,23 @@ class SceneRuntime(object):
                     lin.lora_B.data.copy_(0.01 * torch.randn(lin.lora_B.shape, generator=g))
         self.sim_cached = MPMCacheDiffSim(self.model, 4096)
         self.sim_fused = MPMFusedDiffSim(self.model, self.elasticity, self.plasticity, self.S)
-        # Gaussians
+        # Gaussians.  A trained 3DGS checkpoint lists its kernels in training order - random in space - while the particles are
+        # Hilbert-ordered: every binding row then gathers particle rows from all over the array (k_bind_frame: 4.6x its
+        # compulsory traffic) and every particle's B^T row gathers Gaussians from all over theirs.  The runtime keeps its OWN
+        # order - the Hilbert order of the kernels' rest positions, `gaussian_perm[i]` = the caller's index of kernel i -
+        # for every per-kernel array and the binding matrix's rows; nothing per-kernel leaves the runtime (images and particle
+        # gradients do), and the depth sort's tie break is by this index instead of the caller's.  NEUMA_GAUSSIAN_ORDER=given
+        # keeps the caller's order.
+        self.gaussian_perm = None
+        if os.environ.get("NEUMA_GAUSSIAN_ORDER", "spatial") == "spatial" and scene.g_xyz.shape[0] > 1:
+            import copy
+            lo, hi = scene.g_xyz.min(0), scene.g_xyz.max(0)
+            cells = np.clip(((scene.g_xyz - lo) / np.maximum(hi - lo, 1e-12).max() * 1023.0).astype(np.int64), 0, 1023)
+            perm = np.argsort(synth.hilbert_index(cells, 10), kind="stable")
+            scene = copy.copy(scene)
+            for k in ("g_xyz", "g_sh", "g_logscale", "g_rot", "g_opacity_logit", "bind_idx", "bind_w"):
+                setattr(scene, k, np.ascontiguousarray(getattr(scene, k)[perm]))
+            self.gaussian_perm = torch.from_numpy(perm)
         gm = GaussianModel(cfg["sh"])
         sh = torch.tensor(scene.g_sh, device=self.device)
         gm.set_params(torch.tensor(scene.g_xyz, device=self.device), sh[:, :1].contiguous(), sh[:, 1:].contiguous(),

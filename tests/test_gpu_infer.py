@@ -140,9 +140,12 @@ def test_scene_round_trips_through_the_on_disk_formats(tmp_path):
     (root / "data_dynamic").mkdir(parents=True)
     nio.save_gaussians_ply(rt.gaussians, root / "kernels.ply")
     nio.save_particles_ply(root / "particles.ply", scene.x0)
-    K, nb = scene.bind_idx.shape
-    ind = torch.stack([torch.arange(K).repeat_interleave(nb), torch.tensor(scene.bind_idx.reshape(-1))], 0)
-    nio.save_bindings(root / "bindings.pt", ind, torch.tensor(scene.bind_w.reshape(-1)), (K, rt.N), torch.full((K,), nb))
+    # (the runtime keeps its kernels in its own - spatial - order, rt.gaussian_perm; the files are written in that order too)
+    order = np.arange(scene.bind_idx.shape[0]) if rt.gaussian_perm is None else rt.gaussian_perm.numpy()
+    bind_idx, bind_w = scene.bind_idx[order], scene.bind_w[order]
+    K, nb = bind_idx.shape
+    ind = torch.stack([torch.arange(K).repeat_interleave(nb), torch.tensor(bind_idx.reshape(-1))], 0)
+    nio.save_bindings(root / "bindings.pt", ind, torch.tensor(bind_w.reshape(-1)), (K, rt.N), torch.full((K,), nb))
     torch.save({"init_x": torch.tensor(scene.x0), "init_v": torch.tensor(scene.v0)}, root / "init.pt")
     entries = []
     W, H = scene.cfg["W"], scene.cfg["H"]
