@@ -280,11 +280,24 @@ def main():
         # measures; the maxima are used everywhere, so that all ranks take the same decision
         from neuma_amd.harness import measure_substep_us
         n_all = int(scene.x0.shape[0])
+        # ... and both forms of the shared-block exchange: the all-reduce over the world and the buffers swapped with the
+        # neighbour ranks only (nm_comm.exchange_peers_f32; needs the library's communicator) - the faster one is used
+        from neuma_amd.sim.shard import library_comm_for, time_exchange_peers_us
+        rc_comm = library_comm_for(dist.group.WORLD, dev) if backend == "nccl" else None
+        t_ar = time_all_reduce_us(None, dev, count=1 << 16, rccl=rc_comm)
+        t_px = time_exchange_peers_us(dev, rank, world, count=1 << 16, rccl=rc_comm)
         vals = torch.tensor([measure_substep_us(args.workload, n_all, dev), measure_substep_us(args.workload, -(-n_all // world), dev),
-                             time_all_reduce_us(None, dev, count=1 << 16)], dtype=torch.float64, device=dev)
+                             t_ar, -1.0 if t_px is None else t_px], dtype=torch.float64, device=dev)
         dist.all_reduce(vals, op=dist.ReduceOp.MAX)
         measured = {"substep_us_full": round(float(vals[0]), 1), "substep_us_shard": round(float(vals[1]), 1),
                     "allreduce_us": round(float(vals[2]), 1), "allreduce_floats": 1 << 16}
+        if float(vals[3]) > 0.0:
+            measured["exchange_peers_us"] = round(float(vals[3]), 1)
+            measured["allreduce_world_us"] = measured["allreduce_us"]
+            if "NEUMA_SHARD_EXCHANGE" not in os.environ and float(vals[3]) < float(vals[2]):
+                os.environ["NEUMA_SHARD_EXCHANGE"] = "peers"      # (read by GridExchange when the runtime shards its model)
+                measured["allreduce_us"] = measured["exchange_peers_us"]      # the cost model's per-exchange latency
+        measured["exchange"] = os.environ.get("NEUMA_SHARD_EXCHANGE", "allreduce")
     cost = shard_cost_model(int(scene.x0.shape[0]), world, int(scene.cfg["S"]), measured)
     shard_sim = world > 1 and (args.shard_sim == "on" or (args.shard_sim == "auto" and cost["shard"]))
     if world == 1 and args.shard_sim == "on" and os.environ.get("NEUMA_SHARD_FORCE") == "1":

@@ -301,14 +301,27 @@ int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cfg, const n
  * shard_ws: device memory of nm_rollout_shard_workspace(world, cap, cap_shared, substeps) bytes, written by the forward
  * pass (the shared-block list of every substep) and handed unchanged to the backward pass.  Capacity overflows do not
  * stop the roll-out: they set bits in a status word (nm_rollout_shard_status: 1 = a rank listed more than `cap` blocks,
- * 2 = more than `cap_shared` blocks are shared, 4 = a grid cache record overflowed) - any bit means the results are
+ * 2 = more than `cap_shared` blocks are shared, 4 = a grid cache record overflowed, 8 = a particle left the neighbourhood its
+ * rank announced, 16 = a block is shared with a rank outside nm_comm.peers) - any bit means the results are
  * incomplete and the caller must enlarge the capacity and redo the roll-out.  A rank with n = 0 particles takes part. */
 typedef struct nm_comm {
   int32_t world, rank;
   int (*all_gather_i32)(void* user, const int32_t* send, int32_t* recv, int64_t count, void* stream);
   int (*all_reduce_sum_f32)(void* user, float* buf, int64_t count, void* stream);
   void* user;
+  /* Optional neighbour-only exchange of the shared blocks (round 5).  A grid block is shared by the 2-3 ranks whose particle
+   * ranges meet there, not by the world: instead of all-reducing the exchange buffer over every rank, a rank sends its buffer
+   * to the ranks it shares at least one block with (`peers`, bit q = rank q; symmetric; sim/shard.py derives it from the same
+   * all-gathered neighbourhood lists on every rank) and adds what they send, in ascending rank order - the same operands
+   * in the same order on every owner of a block, so the owners still hold identical sums.
+   *   exchange_peers_f32  send `count` floats at `send` to every rank in `peers` and receive that rank's `count` floats into
+   *                       recv + k * count, k = the rank's position among the set bits of `peers` (ascending); stream-ordered.
+   * NULL or peers == 0xFFFFFFFF: the all-reduce above.  A rank that turns out to share a block with a rank outside `peers`
+   * sets status bit 16 (rank-uniform like the others): the caller re-derives `peers` and redoes the roll-out. */
+  int (*exchange_peers_f32)(void* user, const float* send, float* recv, int64_t count, uint32_t peers, void* stream);
+  uint32_t peers;
 } nm_comm;
+#define NM_COMM_ALL_RANKS 0xFFFFFFFFu
 size_t nm_rollout_shard_workspace(int32_t world, int32_t cap, int32_t cap_shared, int32_t substeps);
 int nm_rollout_forward_sharded(nm_mpm* h, int32_t n, const nm_rollout_cfg* cfg, const nm_statics* st,
                                const nm_mlp* elasticity, const nm_mlp* plasticity, float* states, void* gridcache,
@@ -340,6 +353,15 @@ int nm_rccl_destroy(nm_rccl* c);
 int nm_rccl_comm(nm_rccl* c, nm_comm* out);
 int nm_rccl_all_reduce_sum_f32(nm_rccl* c, float* buf, int64_t count, void* stream);
 int nm_rccl_all_gather_i32(nm_rccl* c, const int32_t* send, int32_t* recv, int64_t count, void* stream);
+/* nm_comm.exchange_peers_f32 on this communicator: ncclSend / ncclRecv to and from every rank in `peers` inside ONE group call */
+int nm_rccl_exchange_peers_f32(nm_rccl* c, const float* send, float* recv, int64_t count, uint32_t peers, void* stream);
+/* start-up calibration (like nm_rccl_time_all_reduce): mean microseconds of `reps` such exchanges of `count` floats */
+int nm_rccl_time_exchange_peers(nm_rccl* c, const float* send, float* recv, int64_t count, uint32_t peers, int32_t warm, int32_t reps,
+                                float* us_out, void* stream);
+/* Which ranks share a block with this one: adj[q] = 1 iff a block of rank q's list in `gathered` (world x (1 + cap), the
+ * all-gathered neighbourhood lists of nm_mpm_dilated_list) lies in THIS rank's current neighbourhood (device array of `world`
+ * int32, adj[rank] = 0).  The predicate is symmetric, so the masks the ranks derive from it match pairwise. */
+int nm_mpm_peer_ranks(nm_mpm* h, const int32_t* gathered, int32_t world, int32_t cap, int32_t rank, int32_t* adj, void* stream);
 int nm_rccl_time_all_reduce(nm_rccl* c, float* buf, int64_t count, int32_t warm, int32_t reps, float* us_out, void* stream);
 
 /* ------------------------------------------------------------------ Particle-GS binding (modules/tune/utils.py) */

@@ -52,9 +52,14 @@ COMM_ALL_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_i
 COMM_ALL_REDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
 
+COMM_EXCHANGE_PEERS = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint32, C.c_void_p)
+COMM_ALL_RANKS = 0xFFFFFFFF     # nm_comm.peers: exchange by all-reduce
+
+
 class nm_comm(C.Structure):
     _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("all_gather_i32", COMM_ALL_GATHER),
-                ("all_reduce_sum_f32", COMM_ALL_REDUCE), ("user", C.c_void_p)]
+                ("all_reduce_sum_f32", COMM_ALL_REDUCE), ("user", C.c_void_p), ("exchange_peers_f32", COMM_EXCHANGE_PEERS),
+                ("peers", C.c_uint32)]
 
 
 # name -> (restype, argtypes); kept in one table so tests can check the exports against the header
@@ -145,6 +150,9 @@ SIGNATURES = {
     "nm_rccl_all_reduce_sum_f32": (C.c_int, [_P, _P, _I64, _P]),
     "nm_rccl_all_gather_i32": (C.c_int, [_P, _P, _P, _I64, _P]),
     "nm_rccl_time_all_reduce": (C.c_int, [_P, _P, _I64, _I32, _I32, C.POINTER(C.c_float), _P]),
+    "nm_rccl_exchange_peers_f32": (C.c_int, [_P, _P, _P, _I64, C.c_uint32, _P]),
+    "nm_rccl_time_exchange_peers": (C.c_int, [_P, _P, _P, _I64, C.c_uint32, _I32, _I32, C.POINTER(C.c_float), _P]),
+    "nm_mpm_peer_ranks": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P]),
 }
 
 _lib = None

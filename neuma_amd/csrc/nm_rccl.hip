@@ -22,6 +22,9 @@ typedef int (*fnCommDestroy)(nmNcclComm);
 typedef int (*fnAllReduce)(const void*, void*, size_t, int, int, nmNcclComm, hipStream_t);
 typedef int (*fnAllGather)(const void*, void*, size_t, int, nmNcclComm, hipStream_t);
 typedef const char* (*fnGetErrorString)(int);
+typedef int (*fnSend)(const void*, size_t, int, int, nmNcclComm, hipStream_t);
+typedef int (*fnRecv)(void*, size_t, int, int, nmNcclComm, hipStream_t);
+typedef int (*fnGroup)(void);
 
 static struct RcclApi {
   void* dl = nullptr;
@@ -31,6 +34,9 @@ static struct RcclApi {
   fnAllReduce all_reduce = nullptr;
   fnAllGather all_gather = nullptr;
   fnGetErrorString error_string = nullptr;
+  fnSend send = nullptr;          // (optional: only the neighbour-only exchange needs the four point-to-point entry points)
+  fnRecv recv = nullptr;
+  fnGroup group_start = nullptr, group_end = nullptr;
   char path[64] = "";
   char err[256] = "-";        // why RCCL could not be bound (recorded once by rccl_load)
 } g_rccl;
@@ -56,6 +62,10 @@ static void rccl_load() {
   g_rccl.all_reduce = (fnAllReduce)dlsym(g_rccl.dl, "ncclAllReduce");
   g_rccl.all_gather = (fnAllGather)dlsym(g_rccl.dl, "ncclAllGather");
   g_rccl.error_string = (fnGetErrorString)dlsym(g_rccl.dl, "ncclGetErrorString");
+  g_rccl.send = (fnSend)dlsym(g_rccl.dl, "ncclSend");
+  g_rccl.recv = (fnRecv)dlsym(g_rccl.dl, "ncclRecv");
+  g_rccl.group_start = (fnGroup)dlsym(g_rccl.dl, "ncclGroupStart");
+  g_rccl.group_end = (fnGroup)dlsym(g_rccl.dl, "ncclGroupEnd");
   if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.comm_destroy || !g_rccl.all_reduce || !g_rccl.all_gather) {
     const char* e = dlerror();
     snprintf(g_rccl.err, sizeof(g_rccl.err), "%s: %s", g_rccl.path, e ? e : "a collective entry point is missing");
@@ -133,12 +143,39 @@ extern "C" int nm_rccl_all_gather_i32(nm_rccl* c, const int32_t* send, int32_t* 
   return NM_OK;
 }
 
+// neighbour-only exchange: one group call with a send and a receive per peer (the peers' buffers land behind one another)
+extern "C" int nm_rccl_exchange_peers_f32(nm_rccl* c, const float* send, float* recv, int64_t count, uint32_t peers, void* stream) {
+  NM_REQUIRE(c && count >= 0, "bad arguments");
+  // (the caller leaves its own rank out of `peers` - nm_rollout.hip does; a self pair is legal in RCCL, a copy through the
+  //  communicator, and is how the one-rank test exercises the four point-to-point entry points)
+  if (c->world < 32) peers &= (1u << c->world) - 1u;
+  if (count == 0 || peers == 0) return NM_OK;
+  NM_REQUIRE(send && recv, "null buffer");
+  NM_REQUIRE(g_rccl.send && g_rccl.recv && g_rccl.group_start && g_rccl.group_end, "this RCCL has no ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd");
+  NM_RCCL_CHECK(g_rccl.group_start(), "ncclGroupStart");
+  int k = 0, bad = 0;
+  for (int q = 0; q < c->world && q < 32; ++q) {
+    if (!((peers >> q) & 1u)) continue;
+    int r = g_rccl.send(send, (size_t)count, 7 /* ncclFloat32 */, q, c->comm, (hipStream_t)stream);
+    if (!r) r = g_rccl.recv(recv + (size_t)k * (size_t)count, (size_t)count, 7, q, c->comm, (hipStream_t)stream);
+    if (r && !bad) bad = r;
+    ++k;
+  }
+  const int e = g_rccl.group_end();
+  NM_RCCL_CHECK(bad, "ncclSend / ncclRecv");
+  NM_RCCL_CHECK(e, "ncclGroupEnd");
+  return NM_OK;
+}
+
 // the nm_comm of the sharded roll-out, bound to this communicator: the roll-out loop then never leaves the library
 static int cb_all_gather(void* user, const int32_t* send, int32_t* recv, int64_t count, void* stream) {
   return nm_rccl_all_gather_i32((nm_rccl*)user, send, recv, count, stream);
 }
 static int cb_all_reduce(void* user, float* buf, int64_t count, void* stream) {
   return nm_rccl_all_reduce_sum_f32((nm_rccl*)user, buf, count, stream);
+}
+static int cb_exchange_peers(void* user, const float* send, float* recv, int64_t count, uint32_t peers, void* stream) {
+  return nm_rccl_exchange_peers_f32((nm_rccl*)user, send, recv, count, peers, stream);
 }
 extern "C" int nm_rccl_comm(nm_rccl* c, nm_comm* out) {
   NM_REQUIRE(c && out, "null pointer");
@@ -147,6 +184,8 @@ extern "C" int nm_rccl_comm(nm_rccl* c, nm_comm* out) {
   out->all_gather_i32 = cb_all_gather;
   out->all_reduce_sum_f32 = cb_all_reduce;
   out->user = c;
+  out->exchange_peers_f32 = (g_rccl.send && g_rccl.recv && g_rccl.group_start && g_rccl.group_end) ? cb_exchange_peers : nullptr;
+  out->peers = NM_COMM_ALL_RANKS;      // (the caller narrows it: sim/shard.py)
   return NM_OK;
 }
 
@@ -166,6 +205,31 @@ extern "C" int nm_rccl_time_all_reduce(nm_rccl* c, float* buf, int64_t count, in
   NM_HIP_CHECK(hipEventRecord(a, s));
   for (int i = 0; i < reps; ++i) {
     int rc = nm_rccl_all_reduce_sum_f32(c, buf, count, stream);
+    if (rc) { hipEventDestroy(a); hipEventDestroy(b); return rc; }
+  }
+  NM_HIP_CHECK(hipEventRecord(b, s));
+  NM_HIP_CHECK(hipEventSynchronize(b));
+  float ms = 0.f;
+  NM_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+  hipEventDestroy(a); hipEventDestroy(b);
+  *us_out = 1e3f * ms / (float)reps;
+  return NM_OK;
+}
+
+extern "C" int nm_rccl_time_exchange_peers(nm_rccl* c, const float* send, float* recv, int64_t count, uint32_t peers, int32_t warm,
+                                           int32_t reps, float* us_out, void* stream) {
+  NM_REQUIRE(c && us_out && count > 0 && reps > 0 && warm >= 0, "bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  for (int i = 0; i < warm; ++i) {
+    int rc = nm_rccl_exchange_peers_f32(c, send, recv, count, peers, stream);
+    if (rc) return rc;
+  }
+  hipEvent_t a, b;
+  NM_HIP_CHECK(hipEventCreate(&a));
+  NM_HIP_CHECK(hipEventCreate(&b));
+  NM_HIP_CHECK(hipEventRecord(a, s));
+  for (int i = 0; i < reps; ++i) {
+    int rc = nm_rccl_exchange_peers_f32(c, send, recv, count, peers, stream);
     if (rc) { hipEventDestroy(a); hipEventDestroy(b); return rc; }
   }
   NM_HIP_CHECK(hipEventRecord(b, s));

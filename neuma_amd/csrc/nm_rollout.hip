@@ -242,23 +242,24 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
 // the frame enters collectives the others are not in.  One 4-float all-reduce at the end of the forward sweep (a flag per
 // bit, summed) costs one small collective per roll-out; every rank then reports, and recovers, together.
 __global__ void k_status_to_flags(const int32_t* __restrict__ status, float* __restrict__ flags) {
-  if (threadIdx.x < 4) flags[threadIdx.x] = ((status[0] >> threadIdx.x) & 1) ? 1.f : 0.f;
+  if (threadIdx.x < 8) flags[threadIdx.x] = ((status[0] >> threadIdx.x) & 1) ? 1.f : 0.f;
 }
 __global__ void k_flags_to_status(const float* __restrict__ flags, int32_t* __restrict__ status) {
   if (threadIdx.x == 0) {
     int bits = status[0];
-    for (int b = 0; b < 4; ++b) bits |= flags[b] > 0.f ? (1 << b) : 0;
+    for (int b = 0; b < 8; ++b) bits |= flags[b] > 0.f ? (1 << b) : 0;
     status[0] = bits;
   }
 }
 
 struct ShardWs {
-  int32_t* status;   // capacity / neighbourhood bits of the roll-out (see nm_rollout_shard_status); [16..19] as floats: the flags
+  int32_t* status;   // capacity / neighbourhood bits of the roll-out (see nm_rollout_shard_status); [16..23] as floats: the flags
   int32_t* mine;     // this rank's neighbourhood list: [0] count, [1..cap] block ids
   int32_t* gathered; // world x (1 + cap)
   int32_t* shared;   // the frame's exchange list: 2 + 2 * cap_shared (kept for the reverse sweep)
   unsigned char* held;   // per substep and slot: the rank held the block in that substep (kept for the reverse sweep)
   float* buf;        // cap_shared x 64 float4: the all-reduced payload
+  float* recv;       // (world - 1) x the same: the peers' buffers of the neighbour-only exchange
   void* sws;         // workspace of nm_mpm_shared_blocks
   size_t sws_bytes, held_stride, total;
 };
@@ -274,6 +275,7 @@ static ShardWs carve_shard(void* base, int world, int cap, int cap_shared, int s
   w.held_stride = al256r((size_t)cap_shared);
   w.held = (unsigned char*)take((size_t)(substeps > 0 ? substeps : 1) * w.held_stride);
   w.buf = (float*)take((size_t)cap_shared * 64 * 4 * sizeof(float));
+  w.recv = (float*)take((size_t)(world > 1 ? world - 1 : 1) * cap_shared * 64 * 4 * sizeof(float));
   w.sws_bytes = nm_mpm_shared_workspace(world, cap);
   w.sws = take(w.sws_bytes);
   w.total = o;
@@ -297,8 +299,23 @@ static int shard_args_ok(const nm_comm* comm, int32_t cap, int32_t cap_shared, c
   }
   return NM_OK;
 }
-static int shard_all_reduce(const nm_comm* comm, float* buf, int cap_shared, void* stream) {
-  if (comm->all_reduce_sum_f32(comm->user, buf, (int64_t)cap_shared * 64 * 4, stream)) {
+int nm_shard_peer_check(nm_mpm* h, const int32_t* gathered, int32_t world, int32_t cap, int32_t rank, uint32_t peers, int32_t* status,
+                        void* stream);
+int nm_shard_peer_sum(float* buf, const float* recv, size_t count, uint32_t peers, int32_t rank, int32_t world, void* stream);
+static bool shard_by_peers(const nm_comm* comm) { return comm->exchange_peers_f32 != nullptr && comm->peers != NM_COMM_ALL_RANKS && comm->world <= 32; }
+// the sum of the ranks' exchange buffers: all-reduce over the world, or buffers swapped with the neighbour ranks and added here
+static int shard_all_reduce(const nm_comm* comm, const ShardWs& sw, int cap_shared, void* stream) {
+  const int64_t count = (int64_t)cap_shared * 64 * 4;
+  if (shard_by_peers(comm)) {
+    uint32_t peers = comm->peers & ~(1u << comm->rank);
+    if (comm->world < 32) peers &= (1u << comm->world) - 1u;
+    if (peers && comm->exchange_peers_f32(comm->user, sw.buf, sw.recv, count, peers, stream)) {
+      nm_set_error("nm_comm.exchange_peers_f32 failed");
+      return NM_ERR_INVALID;
+    }
+    return peers ? nm_shard_peer_sum(sw.buf, sw.recv, (size_t)count, peers, comm->rank, comm->world, stream) : NM_OK;
+  }
+  if (comm->all_reduce_sum_f32(comm->user, sw.buf, count, stream)) {
     nm_set_error("nm_comm.all_reduce_sum_f32 failed");
     return NM_ERR_INVALID;
   }
@@ -359,10 +376,14 @@ extern "C" int nm_rollout_forward_sharded(nm_mpm* h, int32_t n, const nm_rollout
       if (rc) break;
       rc = nm_shard_slots(h, sw.shared, cap_shared, 1, stream);
       if (rc) break;
+      if (shard_by_peers(comm)) {      // every rank this one shares a block with must be among its peers (status bit 16)
+        rc = nm_shard_peer_check(h, sw.gathered, comm->world, cap, comm->rank, comm->peers, sw.status, stream);
+        if (rc) break;
+      }
     }
     rc = nm_shard_pack_fwd(h, sw.shared, cap_shared, sw.buf, sw.held + (size_t)t * sw.held_stride, sw.status, stream);
     if (rc) break;
-    rc = shard_all_reduce(comm, sw.buf, cap_shared, stream);
+    rc = shard_all_reduce(comm, sw, cap_shared, stream);
     if (rc) break;
     rc = nm_mpm_forward_gridop_x(h, grid_rec(gridcache, cfg, t), cfg->grid_cache_blocks, sw.status, sw.buf, stream);   // :291-297
     if (rc) break;
@@ -388,7 +409,7 @@ extern "C" int nm_rollout_forward_sharded(nm_mpm* h, int32_t n, const nm_rollout
     float* flags = reinterpret_cast<float*>(sw.status + 16);
     NM_LAUNCH(k_status_to_flags, dim3(1), dim3(64), 0, (hipStream_t)stream, (const int32_t*)sw.status, flags);
     NM_LAUNCH_CHECK();
-    if (comm->all_reduce_sum_f32(comm->user, flags, 4, stream)) {
+    if (comm->all_reduce_sum_f32(comm->user, flags, 8, stream)) {
       nm_set_error("nm_comm.all_reduce_sum_f32 failed (status word)");
       return NM_ERR_INVALID;
     }
@@ -451,7 +472,7 @@ extern "C" int nm_rollout_backward_sharded(nm_mpm* h, int32_t n, const nm_rollou
     restored = false;
     rc = nm_shard_pack_bwd(h, sw.shared, cap_shared, sw.buf, sw.held + (size_t)t * sw.held_stride, stream);
     if (rc) break;
-    rc = shard_all_reduce(comm, sw.buf, cap_shared, stream);
+    rc = shard_all_reduce(comm, sw, cap_shared, stream);
     if (rc) break;
     rc = nm_mpm_backward_cached_finish(h, n, st, &cur, &gc, (n > 0 && t > 0) ? grid_rec(gridcache, cfg, t - 1) : nullptr,
                                        cfg->grid_cache_blocks, sw.buf, stream);

@@ -347,3 +347,73 @@ int nm_shard_pack_bwd(nm_mpm* h, const int32_t* shared, int32_t cap_shared, floa
   NM_LAUNCH_CHECK();
   return NM_OK;
 }
+
+
+// ---------------------------------------------------------------- neighbour-only exchange (round 5; nm_comm.exchange_peers_f32)
+// A shared block belongs to the 2-3 ranks whose particle ranges meet there.  With the frame's exchange buffer laid out by
+// slot - the same on every rank, zeros where a rank does not hold a block - a rank only has to swap buffers with the ranks it
+// shares at least one block with and add them up; ranks further away would contribute zeros to every slot it reads.
+__global__ void k_peer_adj(const int* __restrict__ gathered, int total, int cap, int nblocks, const int* __restrict__ dil, int tag,
+                           int rank, int* __restrict__ adj, unsigned peers, int* __restrict__ status) {
+  // adj != NULL: adj[q] = 1 for every rank q that lists a block of this rank's neighbourhood;
+  // status != NULL: bit 16 if such a rank is not in `peers`
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int b;
+  if (i >= total || !gathered_entry(gathered, i, cap, nblocks, b)) return;
+  const int q = i / (1 + cap);
+  if (q == rank || dil[b] != tag) return;
+  if (adj) adj[q] = 1;
+  if (status && q < 32 && !((peers >> q) & 1u)) atomicOr(status, 16);
+}
+// buf[i] = sum over {this rank} + peers, in ascending rank order, of the ranks' buffers (the peers' lie behind one another in recv)
+__global__ void __launch_bounds__(256) k_peer_sum(float4* __restrict__ buf, const float4* __restrict__ recv, size_t n4, unsigned peers,
+                                                  int rank, int world) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = 0;
+    for (int q = 0; q < world && q < 32; ++q) {
+      float4 v;
+      if (q == rank) v = buf[i];
+      else if ((peers >> q) & 1u) { v = recv[(size_t)k * n4 + i]; ++k; }
+      else continue;
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    buf[i] = acc;
+  }
+}
+
+extern "C" int nm_mpm_peer_ranks(nm_mpm* h, const int32_t* gathered, int32_t world, int32_t cap, int32_t rank, int32_t* adj,
+                                 void* stream) {
+  NM_REQUIRE(h && gathered && adj, "null handle / buffer");
+  NM_REQUIRE(world >= 1 && cap > 0 && rank >= 0 && rank < world, "bad world / cap / rank");
+  nm_mpm_view v = nm_mpm_get_view(h);
+  int* dil = nullptr;
+  int rc = nm_mpm_xchg_arrays(h, nullptr, &dil, nullptr);
+  if (rc) return rc;
+  NM_HIP_CHECK(hipMemsetAsync(adj, 0, (size_t)world * sizeof(int32_t), (hipStream_t)stream));
+  const int total = world * (1 + cap);
+  NM_LAUNCH(k_peer_adj, dim3(nm_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, gathered, total, cap, v.nblocks, (const int*)dil,
+                     nm_mpm_dil_tag(h), rank, adj, 0u, (int*)nullptr);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}
+int nm_shard_peer_check(nm_mpm* h, const int32_t* gathered, int32_t world, int32_t cap, int32_t rank, uint32_t peers, int32_t* status,
+                        void* stream) {
+  nm_mpm_view v = nm_mpm_get_view(h);
+  int* dil = nullptr;
+  int rc = nm_mpm_xchg_arrays(h, nullptr, &dil, nullptr);
+  if (rc) return rc;
+  const int total = world * (1 + cap);
+  NM_LAUNCH(k_peer_adj, dim3(nm_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, gathered, total, cap, v.nblocks, (const int*)dil,
+                     nm_mpm_dil_tag(h), rank, (int*)nullptr, peers, status);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}
+int nm_shard_peer_sum(float* buf, const float* recv, size_t count, uint32_t peers, int32_t rank, int32_t world, void* stream) {
+  const size_t n4 = count / 4;
+  if (n4 == 0) return NM_OK;
+  NM_LAUNCH(k_peer_sum, dim3((unsigned)min((size_t)1024, (n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (float4*)buf,
+                     (const float4*)recv, n4, peers, rank, world);
+  NM_LAUNCH_CHECK();
+  return NM_OK;
+}

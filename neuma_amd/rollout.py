@@ -144,7 +144,25 @@ class _ShardLink(object):
                 self.error = e
                 return 1
 
+        def exchange_peers(user, send, recv, count, peers, stream):
+            # transport of the tests (gloo has no device send / recv): every rank's buffer is all-gathered and the peers' rows are
+            # copied behind one another - the same bytes in the same places as ncclSend / ncclRecv leave them
+            try:
+                mine = view(send, count, torch.float32)
+                rows = torch.empty(self.world, int(count), dtype=torch.float32, device=mine.device)
+                dist.all_gather_into_tensor(rows.view(-1), mine, group=self.group)
+                k = 0
+                for q in range(self.world):
+                    if q != exchange.rank and (int(peers) >> q) & 1:
+                        view(int(recv) + 4 * k * int(count), count, torch.float32).copy_(rows[q])
+                        k += 1
+                return 0
+            except Exception as e:
+                self.error = e
+                return 1
+
         rccl = exchange.library_comm() if hasattr(exchange, "library_comm") else None
+        peers = getattr(exchange, "peers", None)
         if rccl is not None:
             # the library's own communicator: ncclAllGather / ncclAllReduce issued from the C loop, no Python in between
             self._cbs = None
@@ -152,9 +170,13 @@ class _ShardLink(object):
             L.check(L.lib().nm_rccl_comm(rccl, C.byref(self.comm)), "nm_rccl_comm")
             self.backend = "rccl (library-owned communicator)"
         else:
-            self._cbs = (L.COMM_ALL_GATHER(all_gather), L.COMM_ALL_REDUCE(all_reduce))      # keep the thunks alive
-            self.comm = L.nm_comm(exchange.world, exchange.rank, self._cbs[0], self._cbs[1], None)
+            self._cbs = (L.COMM_ALL_GATHER(all_gather), L.COMM_ALL_REDUCE(all_reduce), L.COMM_EXCHANGE_PEERS(exchange_peers))      # keep the thunks alive
+            self.comm = L.nm_comm(exchange.world, exchange.rank, self._cbs[0], self._cbs[1], None, self._cbs[2], L.COMM_ALL_RANKS)
             self.backend = "torch.distributed callbacks"
+        # neighbour-only exchange of the shared blocks (GridExchange.peers, derived with the frame-level capacities), else all-reduce
+        self.comm.peers = L.COMM_ALL_RANKS if peers is None else int(peers)
+        if peers is not None:
+            self.backend += f", shared blocks swapped with ranks {[q for q in range(exchange.world) if (int(peers) >> q) & 1]}"
         try:
             exchange.link_backend = self.backend
         except AttributeError:
@@ -249,7 +271,7 @@ class _Rollout(autograd.Function):
             probe_start_state()          # capacities from the blocks the start state touches (two host reads)
             probed = True
             ex._ensure_sized()
-        if ex.cap_dil is None or ex.cap_frame is None:
+        if ex.needs_frame_sizing() if hasattr(ex, "needs_frame_sizing") else (ex.cap_dil is None or ex.cap_frame is None):
             # The frame-level capacities are sized from the grid the handle holds NOW: it must be the start state's, whatever
             # the handle did before (model.shard(cap=..., cap_shared=...) with a fused roll-out as the first operation used to
             # size them from an empty grid: 64 each, and every later frame overflowed - ADVICE r3)

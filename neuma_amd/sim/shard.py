@@ -13,6 +13,7 @@ the backward pass (include/neuma_hip.h, "Particle-sharded substep"; kernels in c
     reduce_param_grads(params)  sum the LoRA gradients of the ranks after loss.backward()
 """
 import ctypes as C
+import os
 from typing import Iterable, Optional, Tuple
 
 import torch
@@ -36,7 +37,9 @@ STATUS_TEXT = {1: "a rank touched more grid blocks than the list capacity `cap`"
                2: "more blocks are shared between ranks than `cap_shared`",
                4: "a substep touched more blocks than its grid cache record holds",
                8: "a particle left the block neighbourhood its rank announced at the frame's first substep (it moved more than "
-                  "a block - 4 grid cells - within one roll-out): use fewer substeps per roll-out node"}
+                  "a block - 4 grid cells - within one roll-out): use fewer substeps per roll-out node",
+               16: "a grid block is shared with a rank that is not among the peers of the neighbour-only exchange (the bodies' "
+                   "neighbourhoods have come to touch since the peers were derived)"}
 
 
 def dilate_blocks_host(ids, nb: int):
@@ -138,6 +141,47 @@ def time_all_reduce_us(group, device, count: int = 1 << 16, reps: int = 20, rccl
     return 1e6 * (time.perf_counter() - t0) / reps
 
 
+def time_exchange_peers_us(device, rank: int, world: int, count: int = 1 << 16, reps: int = 20, rccl=None) -> Optional[float]:
+    """Mean microseconds of one neighbour-only exchange of `count` floats with the ranks next to this one in rank order (r - 1,
+    r + 1: what contiguous ranges of a space-filling particle order mostly share blocks with) through the library's
+    communicator - the figure the start-up calibration holds against the all-reduce's.  None without a library communicator
+    (the callback table is a test transport: its time means nothing).  Collective."""
+    if rccl is None:
+        return None
+    peers = sum(1 << q for q in (rank - 1, rank + 1) if 0 <= q < world)
+    send = torch.zeros(count, dtype=torch.float32, device=device)
+    recv = torch.zeros(2 * count, dtype=torch.float32, device=device)
+    us = C.c_float(0.0)
+    L.check(L.lib().nm_rccl_time_exchange_peers(rccl, L.ptr(send), L.ptr(recv), count, peers, 5, reps, C.byref(us), L.stream_ptr(device)),
+            "nm_rccl_time_exchange_peers")
+    return float(us.value)
+
+
+def peers_mask(adj, rank: int) -> int:
+    """nm_comm.peers of `rank` from its adjacency row (adj[q] != 0: rank q shares a block of the neighbourhoods with it)."""
+    return sum(1 << q for q, a in enumerate(adj) if a and q != rank)
+
+
+def peer_ranks_host(lists, rank: int):
+    """Host statement of nm_mpm_peer_ranks: lists[q] = the (dilated) block ids rank q announced; adj[q] = 1 iff one of them lies
+    in `rank`'s own list.  Symmetric in (rank, q)."""
+    mine = set(int(b) for b in lists[rank])
+    return [1 if (q != rank and any(int(b) in mine for b in lists[q])) else 0 for q in range(len(lists))]
+
+
+def exchange_peers_host(bufs, peers):
+    """What the neighbour-only exchange leaves in every rank's buffer: bufs[r] (array per rank, same layout) summed over r and its
+    peers in ascending rank order.  For a slot whose owners are all among each other's peers this equals the all-reduce."""
+    out = []
+    for r, mine in enumerate(bufs):
+        acc = None
+        for q in range(len(bufs)):
+            if q == r or (peers[r] >> q) & 1:
+                acc = bufs[q].copy() if acc is None else acc + bufs[q]
+        out.append(acc)
+    return out
+
+
 def explain_status(bits: int) -> str:
     return "; ".join(text for bit, text in STATUS_TEXT.items() if bits & bit)
 
@@ -224,6 +268,10 @@ class GridExchange(object):
         self.generation = 0
         self._mine = self._gathered = self._ws = self._buf = self._scratch_shared = None
         self._watched = []          # (pinned int32, event) of fused sharded roll-outs whose status word has not been examined
+        # fused roll-out: which ranks this one swaps exchange buffers with (bit q = rank q), or None = all-reduce over the world.
+        # NEUMA_SHARD_EXCHANGE: "allreduce" (default), "peers" (neighbour-only: derived by size_frame_lists from the probe)
+        self.exchange_mode = os.environ.get("NEUMA_SHARD_EXCHANGE", "allreduce")
+        self.peers: Optional[int] = None
         self._rccl = None           # library-owned RCCL communicator (library_comm): None = not tried yet, False = not available
 
     def library_comm(self):
@@ -264,12 +312,20 @@ class GridExchange(object):
             self._buf = torch.empty(self.cap_shared * 64 * 4, dtype=torch.float32, device=self.device)
             self._scratch_shared = self.new_shared()
 
+    def needs_frame_sizing(self) -> bool:
+        """The fused roll-out must probe the start state first: a frame-level capacity, or the peer set of the neighbour-only
+        exchange, is unknown (first roll-out, or forgotten after a status bit)."""
+        return (self.cap_dil is None or self.cap_frame is None or
+                (self.exchange_mode == "peers" and self.peers is None and self.world <= 32))
+
     def size_frame_lists(self) -> None:
         """Capacities of the fused roll-out's frame-level negotiation, from the grid the handle holds now (one probe: the
         ranks' neighbourhoods all-gathered, the exchange list selected, two host reads)."""
         import torch.distributed as dist
-        if self.cap_dil is not None and self.cap_frame is not None:
+        if not self.needs_frame_sizing():
             return
+        given = (self.cap_dil, self.cap_frame) if (self.cap_dil is not None and self.cap_frame is not None) else None
+        self.cap_dil = self.cap_frame = None
         lib, h, s = L.lib(), self.model.handle(), self.model._stream()
         nb3 = ((int(self.model.constant.num_grids) + 2 + 3) // 4) ** 3
         probe_cap = min(nb3, 27 * int(self.cap))
@@ -290,6 +346,15 @@ class GridExchange(object):
         L.check(lib.nm_mpm_shared_blocks(h, L.ptr(gathered), self.world, self.cap_dil, L.ptr(probe), upper, None, L.ptr(ws),
                                          ws.numel(), s), "nm_mpm_shared_blocks")
         self.cap_frame = size_with_slack(int(probe[0].item()))
+        self.peers = None
+        if self.exchange_mode == "peers" and self.world <= 32:
+            # neighbour-only exchange: the ranks whose neighbourhood meets this rank's, from the same gathered lists (the rule is
+            # symmetric, so rank q finds this rank among ITS peers); a rank that becomes a neighbour later raises status bit 16
+            adj = torch.zeros(self.world, dtype=torch.int32, device=self.device)
+            L.check(lib.nm_mpm_peer_ranks(h, L.ptr(gathered), self.world, self.cap_dil, self.rank, L.ptr(adj), s), "nm_mpm_peer_ranks")
+            self.peers = peers_mask(adj.tolist(), self.rank)
+        if given is not None:       # (the caller's capacities stand; the probe was for the peers)
+            self.cap_dil, self.cap_frame = max(given[0], self.cap_dil), max(given[1], self.cap_frame)
 
     def new_shared(self) -> torch.Tensor:
         return torch.empty(2 + 2 * self.cap_shared, dtype=torch.int32, device=self.device)
@@ -327,8 +392,8 @@ class GridExchange(object):
     def _raise(self, bits: int) -> None:
         """An incomplete exchange: say which capacity it was, and forget the frame-level capacities so that the next fused
         roll-out probes them again (they are sized from a start state; cap / cap_shared are the constructor's)."""
-        if bits & (1 | 2 | 8):
-            self.cap_dil = self.cap_frame = None
+        if bits & (1 | 2 | 8 | 16):
+            self.cap_dil = self.cap_frame = self.peers = None
         hint = []
         if bits & 1:
             hint.append(f"cap={self.cap} (per-rank block list; fused roll-outs: cap_dil, re-probed at the next roll-out)")
@@ -338,6 +403,8 @@ class GridExchange(object):
             hint.append(f"cap={self.cap} (blocks per grid cache record): model.shard(group, cap=...)")
         if bits & 8:
             hint.append("fewer substeps per roll-out node (the neighbourhood is negotiated once per node)")
+        if bits & 16:
+            hint.append("nothing (the peer ranks of the neighbour-only exchange are derived again at the next roll-out)")
         raise L.NeumaHipError(f"sharded substep incomplete ({explain_status(bits)}); adjust: " + "; ".join(hint) +
                               ".  The gradients of that roll-out are wrong: discard them (do not step the optimizer) and re-run it")
 
@@ -375,7 +442,7 @@ class GridExchange(object):
             # (Every rank calls check(wait=True) at the same point - once per backward pass / frame; fused roll-outs have
             #  already OR-ed their word over the ranks on the device, nm_rollout_forward_sharded.)
             import torch.distributed as dist
-            flags = torch.tensor([(bits >> b) & 1 for b in range(4)], dtype=torch.int32, device=self.device)
+            flags = torch.tensor([(bits >> b) & 1 for b in range(8)], dtype=torch.int32, device=self.device)
             dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
             bits = sum(int(f) << b for b, f in enumerate(flags.tolist()))
         self.generation += 1

@@ -80,12 +80,13 @@ def gpu_substeps(rank, world, port, q, steps=3, cap_shared=None, cap=None):
         q.put({"rank": rank, "error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()})
 
 
-def gpu_frame(rank, world, port, q, name="tiny", fused=False, preset_caps=False):
+def gpu_frame(rank, world, port, q, name="tiny", fused=False, preset_caps=False, exchange="allreduce"):
     """One frame of the driver (materials + roll-out + bindings + render + loss, forward and backward): sharded
     simulation on `world` ranks vs the single-process frame.  fused: the sharded ranks run nm_rollout_forward_sharded /
     nm_rollout_backward_sharded (substep loop, phases and collectives inside the library) instead of the per-operator
     classes driven from Python."""
     try:
+        os.environ["NEUMA_SHARD_EXCHANGE"] = exchange      # "peers": shared blocks swapped with the neighbour ranks only
         dist = _init(rank, world, port)
         from neuma_amd import synth
         from neuma_amd.harness import SceneRuntime
@@ -94,7 +95,7 @@ def gpu_frame(rank, world, port, q, name="tiny", fused=False, preset_caps=False)
         ref = SceneRuntime(scene, dev, fused=False)
         ref.make_ground_truth()
         rt = SceneRuntime(scene, dev, rank=rank, world=world, shard_sim=True, fused=fused)
-        assert rt.fused == fused and rt.model.exchange is not None
+        assert rt.fused == fused and rt.model.exchange is not None and rt.model.exchange.exchange_mode == exchange
         if preset_caps:      # the caller fixes cap / cap_shared and the FIRST operation is a fused roll-out: the frame-level
             rt.model.shard(rt.group, cap=4096, cap_shared=4096)      # capacities must still be probed from the start state
         rt.gt = ref.gt
@@ -143,6 +144,8 @@ def gpu_frame(rank, world, port, q, name="tiny", fused=False, preset_caps=False)
             grads.append([p.grad.clone() for p in run.parameters()])
         res["grad_err"] = [_err(a, b) for a, b in zip(grads[1], grads[0])]
         res["grad_mag"] = [float(b.abs().max()) for b in grads[0]]
+        res["peers"] = rt.model.exchange.peers
+        res["backend"] = getattr(rt.model.exchange, "link_backend", None)
         q.put(res)
         dist.destroy_process_group()
     except Exception as e:
@@ -292,7 +295,19 @@ def cpu_comm_link(rank, world, port, q):
             ok_err = False
         except L.NeumaHipError as e:
             ok_err = ok_err and "collective failed" in str(e)
-        q.put({"rank": rank, "ok": [ok_gather, ok_reduce, ok_err]})
+        # neighbour-only exchange (nm_comm.exchange_peers_f32): a chain 0 - 1 - 2 ...: every rank swaps `n` floats with the ranks next
+        # to it; the peers' buffers land behind one another, in rank order, at `recv`
+        peers = sum(1 << q for q in (rank - 1, rank + 1) if 0 <= q < world)
+        send2, recv2 = 3072, 3200
+        ws[send2:send2 + 4 * n].view(torch.float32).copy_(torch.arange(n, dtype=torch.float32) + 10.0 * rank)
+        ws[recv2:recv2 + 4 * n * 2].zero_()
+        link.error = None
+        rc = link.comm.exchange_peers_f32(None, base + send2, base + recv2, n, peers, None)
+        got = ws[recv2:recv2 + 4 * n * 2].view(torch.float32).view(2, n)
+        nbrs = [q for q in (rank - 1, rank + 1) if 0 <= q < world]
+        ok_peers = rc == 0 and all(bool(torch.equal(got[k], torch.arange(n, dtype=torch.float32) + 10.0 * qq)) for k, qq in enumerate(nbrs))
+        ok_peers = ok_peers and link.comm.peers == L.COMM_ALL_RANKS      # (no peer set on this exchange object: all-reduce mode)
+        q.put({"rank": rank, "ok": [ok_gather, ok_reduce, ok_err, ok_peers]})
         dist.destroy_process_group()
     except Exception as e:
         import traceback
@@ -346,6 +361,7 @@ def gpu_nccl_one_rank(rank, world, port, q, name="tiny", comm="rccl"):
         os.environ["MASTER_PORT"] = str(port)
         os.environ["NEUMA_SHARD_FORCE"] = "1"
         os.environ["NEUMA_COMM"] = comm          # "rccl": the library's own communicator; "python": the callback table
+        os.environ["NEUMA_SHARD_EXCHANGE"] = "peers"     # (a one-rank world has no peers: the exchange is the empty one, no all-reduce)
         dev = torch.device("cuda", 0)
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         from neuma_amd import synth
@@ -373,6 +389,20 @@ def gpu_nccl_one_rank(rank, world, port, q, name="tiny", comm="rccl"):
         from neuma_amd import _lib as L
         from neuma_amd.sim.shard import time_all_reduce_us
         res["rccl_library"] = (L.lib().nm_rccl_library() or b"").decode()
+        res["peers"] = rt.model.exchange.peers
+        rc_comm = rt.model.exchange.library_comm()
+        if rc_comm is not None:
+            # the neighbour-only exchange's transport on a real communicator: ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd
+            # with the one pair a one-rank world has - this rank with itself
+            import ctypes as C
+            send, recv = torch.arange(10, dtype=torch.float32, device=dev) + 0.5, torch.zeros(10, dtype=torch.float32, device=dev)
+            L.check(L.lib().nm_rccl_exchange_peers_f32(rc_comm, L.ptr(send), L.ptr(recv), 10, 1, L.stream_ptr(dev)), "nm_rccl_exchange_peers_f32")
+            us = C.c_float(-1.0)
+            L.check(L.lib().nm_rccl_time_exchange_peers(rc_comm, L.ptr(send), L.ptr(recv), 10, 1, 2, 5, C.byref(us), L.stream_ptr(dev)),
+                    "nm_rccl_time_exchange_peers")
+            torch.cuda.synchronize()
+            res["self_swap_ok"] = bool(torch.equal(send, recv))
+            res["exchange_us"] = float(us.value)
         res["allreduce_us"] = time_all_reduce_us(None, dev, count=1 << 16, rccl=rt.model.exchange.library_comm())
         # the stripe mode's collective: identity forward, all-reduce(sum) of the gradient backward
         g = torch.randn(1000, 3, device=dev)

@@ -65,15 +65,22 @@ def test_capacity_overflow_is_reported_on_every_rank():
         assert "error" in r and "cap_shared" in r["error"] and "NeumaHipError" in r["error"], r
 
 
-@pytest.mark.parametrize("world,fused,preset", [(2, False, False), (2, True, False), (3, True, False), (2, True, True)])
-def test_sharded_frame_matches_the_single_process_frame(world, fused, preset):
+@pytest.mark.parametrize("world,fused,preset,exchange", [(2, False, False, "allreduce"), (2, True, False, "allreduce"),
+                                                         (3, True, False, "allreduce"), (2, True, True, "allreduce"),
+                                                         (2, True, False, "peers"), (3, True, True, "peers")])
+def test_sharded_frame_matches_the_single_process_frame(world, fused, preset, exchange):
     """fused: the library-level sharded roll-out (nm_rollout_forward_sharded: the loop over substeps, phases and collectives
     runs in C and calls back for the two collectives per substep); otherwise the phases are driven from Python.
     preset: model.shard(group, cap=..., cap_shared=...) given by the caller and a fused roll-out as the very first operation -
     the frame-level capacities used to be sized from an empty grid then."""
-    res = _run(shard_worker.gpu_frame, world, "tiny", fused, preset)
+    res = _run(shard_worker.gpu_frame, world, "tiny", fused, preset, exchange)
     for r in res:
         from gpu_util import measured
+        if exchange == "peers":
+            # exchange="peers": nm_comm.exchange_peers_f32 - every rank swaps its exchange buffer with the ranks its neighbourhood
+            # meets (here: all of them, the ball is small) and adds them in rank order - instead of the all-reduce
+            assert "error" not in r, r
+            assert r["peers"] == sum(1 << q for q in range(world) if q != r["rank"]) and "swapped with ranks" in r["backend"], r
         assert measured(abs(r["loss"] - r["ref_loss"]) / abs(r["ref_loss"]), "rel loss, sharded frame") <= 1e-6, r      # measured 2.4e-07
         assert measured(r["x_err"], "rel_max x") < 7e-7 and measured(r["F_err"], "rel_max F") < 7e-7, r      # measured 2.0e-7
         # (deformed start state: at F = I the gradients of this small scene carry 3e-3 of atomics-order noise even between two
@@ -139,9 +146,11 @@ def test_one_rank_on_the_rccl_backend_runs_both_multi_gpu_collective_paths(comm)
     "python": the nm_comm callback table on device-workspace views (what the gloo tests use)."""
     (r,) = _run(shard_worker.gpu_nccl_one_rank, 1, "tiny", comm)
     assert r["backend"] == "nccl" and r["allreduce_ok"]
+    assert r["peers"] == 0, r
     if comm == "rccl":
         assert r["link"].startswith("rccl") and "librccl" in r["rccl_library"], r
         assert 0.0 < r["allreduce_us"] < 1e4, r
+        assert r["self_swap_ok"] and 0.0 < r["exchange_us"] < 1e4, r      # ncclSend / ncclRecv inside one group call
     else:
         assert r["link"].startswith("torch.distributed"), r
     from gpu_util import measured
@@ -164,6 +173,70 @@ def test_a_particle_leaving_its_announced_neighbourhood_is_reported_on_every_ran
     res = _run(shard_worker.gpu_neighbourhood_miss, 2, 40.0, 1, timeout=240)
     for r in res:
         assert r["raised"] and "neighbourhood" in r["text"] and r["rerun_ok"], r
+
+
+def test_device_peer_rule_equals_the_host_statement_and_is_symmetric():
+    """nm_mpm_peer_ranks (which ranks announce a block of THIS rank's neighbourhood) against sim.shard.peer_ranks_host, for every
+    rank of a four-rank world laid out along a bar: ranks two apart do not meet, so the peer sets are proper subsets of the world
+    - and rank r is among q's peers exactly when q is among r's."""
+    import ctypes as C
+    import numpy as np
+    from neuma_amd import _lib as L
+    from neuma_amd.sim import MPMModelBuilder
+    from neuma_amd.sim.shard import dilate_blocks_host, peer_ranks_host, peers_mask
+    d = torch.device("cuda", 0)
+    G, world = 64, 4
+    nb = (G + 2 + 3) // 4
+    model = MPMModelBuilder().parse_cfg(dict(gravity=[0.0, -9.8, 0.0], bc="noslip", num_grids=G, dt=1e-3, bound=1, eps=6e-7)).finalize(d)
+    lib, h, s = L.lib(), model.handle(), L.stream_ptr(d)
+    from gpu_util import build_statics
+    # rank r's particles: a slab of the bar, three blocks (12 cells) long with a one-block gap to the next - neighbourhoods
+    # (+-1 block) of consecutive ranks overlap, those of ranks two apart do not
+    rng = np.random.default_rng(3)
+    parts = []
+    for r in range(world):
+        x0 = (1 + 16 * r + 0.5) / G
+        parts.append(np.stack([x0 + rng.random(400) * (11.0 / G), 0.4 + rng.random(400) * 0.1, 0.4 + rng.random(400) * 0.1], 1).astype(np.float32))
+    lists = []
+    for r in range(world):       # every rank's dilated list, from the device (host statement checked elsewhere)
+        n = parts[r].shape[0]
+        x = torch.from_numpy(parts[r]).to(d)
+        v, Cm, F, S = torch.zeros(n, 3, device=d), torch.zeros(n, 3, 3, device=d), torch.eye(3, device=d).repeat(n, 1, 1), torch.zeros(n, 3, 3, device=d)
+        st = build_statics(model, torch.full((n,), 1e-6), torch.full((n,), 1000.0), torch.full((n,), 0.1), torch.ones(n, dtype=torch.int32), d)
+        keep = [t.float().contiguous() for t in (x, v, Cm, F, S)]
+        cur = L.nm_particles(*[L.ptr(t) for t in keep])
+        for _ in range(2):       # (twice: the first clear carries the previous rank's blocks - one handle plays every rank here)
+            L.check(lib.nm_mpm_p2g(h, n, C.byref(st.c_struct()), C.byref(cur), s), "nm_mpm_p2g")
+        out = torch.zeros(1 + nb ** 3, dtype=torch.int32, device=d)
+        L.check(lib.nm_mpm_dilated_list(h, L.ptr(out), nb ** 3, s), "nm_mpm_dilated_list")
+        got = out.cpu().numpy()
+        lists.append(np.sort(got[1:1 + int(got[0])]))
+    cap = max(len(l) for l in lists) + 5
+    g = np.full((world, 1 + cap), -1, np.int32)
+    for r in range(world):
+        g[r, 0] = len(lists[r]); g[r, 1:1 + len(lists[r])] = lists[r]
+    gathered = torch.from_numpy(g).to(d)
+    masks = []
+    for r in range(world):       # rank r's turn: ITS neighbourhood must be the one the handle holds (dilated_list tags it)
+        n = parts[r].shape[0]
+        x = torch.from_numpy(parts[r]).to(d)
+        keep = [t.float().contiguous() for t in (x, torch.zeros(n, 3, device=d), torch.zeros(n, 3, 3, device=d),
+                                                 torch.eye(3, device=d).repeat(n, 1, 1), torch.zeros(n, 3, 3, device=d))]
+        st = build_statics(model, torch.full((n,), 1e-6), torch.full((n,), 1000.0), torch.full((n,), 0.1), torch.ones(n, dtype=torch.int32), d)
+        cur = L.nm_particles(*[L.ptr(t) for t in keep])
+        for _ in range(2):
+            L.check(lib.nm_mpm_p2g(h, n, C.byref(st.c_struct()), C.byref(cur), s), "nm_mpm_p2g")
+        out = torch.zeros(1 + nb ** 3, dtype=torch.int32, device=d)
+        L.check(lib.nm_mpm_dilated_list(h, L.ptr(out), nb ** 3, s), "nm_mpm_dilated_list")
+        adj = torch.full((world,), 7, dtype=torch.int32, device=d)
+        L.check(lib.nm_mpm_peer_ranks(h, L.ptr(gathered), world, cap, r, L.ptr(adj), s), "nm_mpm_peer_ranks")
+        want = peer_ranks_host(lists, r)
+        assert adj.tolist() == want, (r, adj.tolist(), want)
+        masks.append(peers_mask(want, r))
+    assert masks == [0b0010, 0b0101, 0b1010, 0b0100], [bin(m) for m in masks]
+    for r in range(world):
+        for q in range(world):
+            assert ((masks[r] >> q) & 1) == ((masks[q] >> r) & 1)
 
 
 def test_device_neighbourhood_list_equals_the_host_statement():

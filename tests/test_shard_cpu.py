@@ -226,3 +226,36 @@ def test_stripe_measurements_are_adopted_by_frame_count_not_by_local_event_state
     bad = torch.ones(V * T + 1)
     rt._stripe_pending = (bad, Ev(), 12)
     assert SceneRuntime._stripe_weights(rt) is w
+
+
+def test_neighbour_only_exchange_equals_the_all_reduce_on_every_owned_slot():
+    """Host statement of nm_comm.exchange_peers_f32 + the ordered sum (sim.shard.exchange_peers_host) with the peer sets of
+    sim.shard.peer_ranks_host: on a chain of ranks whose block sets overlap only with their neighbours', every rank ends up with
+    the world's sum in every slot it owns, the owners of a slot hold bitwise identical values, and the peer relation is symmetric."""
+    import numpy as np
+    from neuma_amd.sim.shard import peer_ranks_host, peers_mask, exchange_peers_host
+    rng = np.random.default_rng(11)
+    world, per, overlap = 6, 20, 6
+    lists = [list(range(r * (per - overlap), r * (per - overlap) + per)) for r in range(world)]      # windows of a line of blocks
+    lists[3] = lists[3] + lists[0][:2]                                                               # and one long-range contact
+    peers = [peers_mask(peer_ranks_host(lists, r), r) for r in range(world)]
+    for r in range(world):
+        for q in range(world):
+            assert ((peers[r] >> q) & 1) == ((peers[q] >> r) & 1)
+    assert peers[1] == 0b000101 and peers[0] == 0b001010 and peers[3] == 0b010101 and peers[5] == 0b010000
+    shared = sorted(b for b in set(sum(lists, [])) if sum(b in l for l in lists) >= 2)
+    bufs = []
+    for r in range(world):
+        buf = np.zeros((len(shared), 8), np.float32)
+        for i, b in enumerate(shared):
+            if b in lists[r]:
+                buf[i] = rng.standard_normal(8).astype(np.float32) * 10.0 ** rng.integers(-3, 4)
+        bufs.append(buf)
+    out = exchange_peers_host(bufs, peers)
+    for i, b in enumerate(shared):
+        owners = [r for r in range(world) if b in lists[r]]
+        want = None
+        for r in owners:                      # ascending rank order, the order every owner sums in
+            want = bufs[r][i].copy() if want is None else want + bufs[r][i]
+        for r in owners:
+            assert np.array_equal(out[r][i], want), (b, r)          # bitwise: same operands, same order (zeros are exact)
