@@ -295,8 +295,10 @@ int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cfg, const n
  * must enqueue, in stream order on `stream`,
  *   all_gather_i32      recv[r * count + i] = rank r's send[i]   (count = 1 + cap int32 per rank: the ranks' block lists)
  *   all_reduce_sum_f32  buf[i] = sum over ranks of buf[i]        (count = cap_shared * 256 floats: the shared blocks)
- * and return 0 on success.  send / recv / buf point into `shard_ws`.  Per substep: one all-gather + one all-reduce in the
- * forward pass, one all-reduce in the reverse sweep.  gridcache is mandatory (grid_cache_blocks >= the blocks a rank
+ * and return 0 on success.  send / recv / buf point into `shard_ws`.  Per roll-out: one all-gather (the ranks' block
+ * neighbourhoods, negotiated at the first substep) and one 8-float all-reduce (the status bits, OR-ed over the ranks); per
+ * substep: one all-reduce of the exchange buffer in the forward pass and one in the reverse sweep - or, with
+ * exchange_peers_f32 and a peer set, one swap of the buffer with the neighbour ranks each.  gridcache is mandatory (grid_cache_blocks >= the blocks a rank
  * touches): the reverse sweep restores the already-summed grid from it - there is no recompute across ranks.
  * shard_ws: device memory of nm_rollout_shard_workspace(world, cap, cap_shared, substeps) bytes, written by the forward
  * pass (the shared-block list of every substep) and handed unchanged to the backward pass.  Capacity overflows do not

@@ -687,6 +687,9 @@ __global__ void __launch_bounds__(NM_NS) k_cell_offsets(int nbin, const uint32_t
 // a time: all four log reads are requested together, then the eight dependent reads (cell offset, depth), then the stores - the
 // rolled loop (one entry per trip: log -> offset / depth -> store) was two HBM round trips per entry, three to five entries per
 // thread, one after the other (35 us per view for 28 MB of traffic).
+// PACKED (chunk binning): an entry is {cell, rank | mask << 16, id, depth bits}; otherwise {cell, rank, id, mask} and the depth is
+// fetched per entry
+template <bool PACKED>
 __global__ void __launch_bounds__(256) k_bin_fill(const uint32_t* __restrict__ hdr, const PairLog* __restrict__ log,
                                                   const uint32_t* __restrict__ off, const float* __restrict__ depth,
                                                   unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals, long long cap) {
@@ -705,15 +708,16 @@ __global__ void __launch_bounds__(256) k_bin_fill(const uint32_t* __restrict__ h
     for (int u = 0; u < 4; ++u) {
       const bool liv = q[u].cell != 0xffffffffu;      // (dead entry: no tile of that bin passed the conic test)
       o[u] = liv ? off[q[u].cell] : 0u;
-      d[u] = liv ? __float_as_uint(depth[q[u].id]) : 0u;
+      if (PACKED) d[u] = q[u].mask;
+      else d[u] = liv ? __float_as_uint(depth[q[u].id]) : 0u;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (q[u].cell == 0xffffffffu) continue;
-      const long long slot = (long long)o[u] + q[u].rank;
+      const long long slot = (long long)o[u] + (PACKED ? (q[u].rank & 0xffffu) : q[u].rank);
       if (slot < cap) {
         keys[slot] = ((unsigned long long)d[u] << 32) | (unsigned long long)q[u].id;
-        vals[slot] = q[u].mask;
+        vals[slot] = PACKED ? (q[u].rank >> 16) : q[u].mask;
       }
     }
   }
@@ -987,7 +991,7 @@ __global__ void __launch_bounds__(256) k_bin_count2(RK k, int nbx, int nbin, con
   __shared__ int s_excl[4][64];
   __shared__ RowCull s_tc[4][64];
   __shared__ int4 s_geo[4][64], s_bin[4][64];
-  __shared__ uint32_t s_id[4][64];
+  __shared__ uint32_t s_id[4][64], s_dep[4][64];
   __shared__ unsigned char s_owner[4][NM_B2_OWN];
   __shared__ uint2 s_stash[4][NM_B2_STASH];
   __shared__ uint32_t s_wsum[4], s_base;
@@ -998,10 +1002,11 @@ __global__ void __launch_bounds__(256) k_bin_count2(RK k, int nbx, int nbin, con
   const uint32_t at_ = (uint32_t)chunk * 256u + (uint32_t)tid;
   bool live = at_ < nvis;
   int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
-  uint32_t id = 0u;
+  uint32_t id = 0u, dep = 0u;
   RowCull tc = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f, -1.f, 0.f};
   if (live) {
-    id = (uint32_t)gkeys[at_];
+    const unsigned long long gk = gkeys[at_];
+    id = (uint32_t)gk; dep = (uint32_t)(gk >> 32);
     const float2 p = xy[id];
     get_rect(k, p.x, p.y, radii[id], x0, y0, x1, y1, k.ty0, k.ty1);
     tc = make_row_cull(p.x, p.y, conop[id]);
@@ -1018,6 +1023,7 @@ __global__ void __launch_bounds__(256) k_bin_count2(RK k, int nbx, int nbin, con
   s_geo[wv][lane] = make_int4(x0, y0, x1, y1);
   s_bin[wv][lane] = make_int4(bx0, by0, nbw, 0);
   s_id[wv][lane] = id;
+  s_dep[wv][lane] = dep;
   for (int q = 0; q < mine; ++q) {
     const int w_ = incl - mine + q;
     if (w_ < NM_B2_OWN) s_owner[wv][w_] = (unsigned char)lane;
@@ -1100,7 +1106,10 @@ __global__ void __launch_bounds__(256) k_bin_count2(RK k, int nbx, int nbin, con
         const long long slot = base + (long long)s_pref[bin] + rank;
         if (slot < cap) {
           PairLog e;
-          e.cell = (uint32_t)chunk * (uint32_t)nbin + (uint32_t)bin; e.rank = rank; e.id = s_id[gl >> 6][gl & 63]; e.mask = m;
+          // packed form (k_bin_fill<true>): rank (< 256) and the 16-bit tile mask share a word, the fourth carries the depth bits,
+          // so the fill pass has no per-entry gather left
+          e.cell = (uint32_t)chunk * (uint32_t)nbin + (uint32_t)bin; e.rank = rank | (m << 16); e.id = s_id[gl >> 6][gl & 63];
+          e.mask = s_dep[gl >> 6][gl & 63];
           log[slot] = e;
         }
       }
@@ -2675,7 +2684,7 @@ static int raster_forward_impl(const nm_raster_cfg* cfg, int32_t K, int32_t m, c
               t.hdr, (long long)cap_pairs);
     NM_LAUNCH_CHECK();
     if (K > 0) {
-      NM_LAUNCH(k_bin_fill, dim3(min(2048, nm_div_up((int)min((int64_t)cap_pairs, (int64_t)K * 64), 256) + 1)), dim3(256), 0, s,
+      NM_LAUNCH(k_bin_fill<true>, dim3(min(2048, nm_div_up((int)min((int64_t)cap_pairs, (int64_t)K * 64), 256) + 1)), dim3(256), 0, s,
                 (const uint32_t*)t.hdr, (const PairLog*)t.log, (const uint32_t*)t.coff, (const float*)t.depth, t.keys, t.vals,
                 (long long)cap_pairs);
       NM_LAUNCH_CHECK();
@@ -2696,7 +2705,7 @@ static int raster_forward_impl(const nm_raster_cfg* cfg, int32_t K, int32_t m, c
             (long long)cap_pairs);
   NM_LAUNCH_CHECK();
   if (K > 0) {
-    NM_LAUNCH(k_bin_fill, dim3(min(2048, nm_div_up((int)min((int64_t)cap_pairs, (int64_t)K * 64), 256) + 1)), dim3(256), 0, s,
+    NM_LAUNCH(k_bin_fill<false>, dim3(min(2048, nm_div_up((int)min((int64_t)cap_pairs, (int64_t)K * 64), 256) + 1)), dim3(256), 0, s,
               (const uint32_t*)t.hdr, (const PairLog*)t.log, (const uint32_t*)t.off, (const float*)t.depth, t.keys, t.vals,
               (long long)cap_pairs);
     NM_LAUNCH_CHECK();
