@@ -279,6 +279,11 @@ int nm_rollout_forward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cfg, const nm
  * experiments/finetune.py:364 and :362 make back to back across the loop edge - run as ONE launch per substep boundary, F_{t+1}
  * passing from one net to the other in registers; off = one launch per net.  Results are bit-identical either way. */
 int nm_rollout_set_forward_pair(int32_t on);
+/* Experiment kept as a switch (round 5; default off, NEUMA_GRIDOP_FOLD=1 turns it on at load time): the forward sweep launches
+ * no grid update (mpm.py:373-429) in front of a pair launch - the launch's g2p forms the node velocities from {mv, m} as it
+ * gathers them, and its prologue workgroups write the substep's cache record, wait for the gathers and clear the grid behind
+ * them.  Same results (tests/test_gpu_rollout.py); measured slower at 100k particles. */
+int nm_rollout_set_gridop_fold(int32_t on);
 /* gstate_last: dL/d(x,v,C,F of record S) (24*N floats: x|v|C|F); gstate_first: dL/d(x,v,C,F of record 0) (written);
  * gw_e / gw_p: 5504 floats each = dL/d(w0 | w1 | w2) of the elasticity / plasticity nets, summed over
  * particles and substeps (overwritten). */

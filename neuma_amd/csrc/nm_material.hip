@@ -50,6 +50,20 @@ __device__ __forceinline__ bool material_prologue(const GridPrologue& pro) {
   grid_prologue(pro, blockIdx.x, gridDim.x);
   return false;
 }
+// forward pair kernel: mode 1 (clear + carry) or - FLY - mode 3 only; the restore of mode 2 is not compiled in
+template <bool FLY>
+__device__ __forceinline__ bool material_prologue_fwd(const GridPrologue& pro) {
+  if (pro.mode == 0) return false;
+  const int mat = pro.mat_grid;
+  if ((int)gridDim.x > mat) {
+    if ((int)blockIdx.x < mat) return false;
+    if (FLY) grid_prologue_fly(pro, blockIdx.x - mat, gridDim.x - mat);
+    else grid_prologue_clear(pro, blockIdx.x - mat, gridDim.x - mat);
+    return true;
+  }
+  if (!FLY) grid_prologue_clear(pro, blockIdx.x, gridDim.x);
+  return false;
+}
 #define NM_W0 (64 * 13)
 #define NM_W1 (64 * 64)
 #define NM_W2 (9 * 64)
@@ -602,7 +616,7 @@ __global__ void __launch_bounds__(256) k_material_fwd(int n, int q, float alpha,
 // trial F -> plasticity net -> F_{t+1} (checkpointed) -> elasticity net -> stress_{t+1}.  F_{t+1} stays in registers between
 // the nets, both nets' operands are staged once, and the launch carries the grid housekeeping of substep t+1 (GridPrologue
 // mode 1 with keep_gv: the velocities are still being gathered here; the grid update of substep t+1 zeroes what drops out).
-template <bool ACT>
+template <bool ACT, bool FLY>
 __global__ void __launch_bounds__(256) k_material_fwd_pair(int n, int q, float alpha, const float* __restrict__ wperm_p,
                                                            const float* __restrict__ wperm_e, float* __restrict__ F_next,
                                                            float* __restrict__ stress_next, GridPrologue pro, G2pFuse gf,
@@ -613,7 +627,9 @@ __global__ void __launch_bounds__(256) k_material_fwd_pair(int n, int q, float a
   __shared__ __attribute__((aligned(16))) float sBuf[4 * 64 * 17 + 4 * 64 * 9];
   float (*sZ)[64 * 17] = reinterpret_cast<float (*)[64 * 17]>(sBuf);
   float (*sY)[64 * 9] = reinterpret_cast<float (*)[64 * 9]>(sBuf + 4 * 64 * 17);
-  if (NM_PROLOGUE_SPLIT(pro)) return;
+  // (FLY is a template parameter, not a run-time branch: with both g2p bodies inlined the kernel was 73 KB of code - past the
+  //  64 KB instruction cache two CUs share - and every wave ran 1.4x slower, whatever it executed)
+  if (material_prologue_fwd<FLY>(pro)) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int pbeg = min(n, (blockIdx.x * 4 + wave) * q), pend = min(n, pbeg + q);
   // the stencil-independent loads of a round's particles (enabled, x, clip, F) are issued one round ahead - the first round's in
@@ -621,6 +637,8 @@ __global__ void __launch_bounds__(256) k_material_fwd_pair(int n, int q, float a
   // HBM round trip (~2 us) doing nothing
   G2pIn nxt{};
   if (pbeg + lane < pend) nxt = g2p_in_load(pbeg + lane, gf.clip, gf.enabled, gf.x, gf.F);
+  else if (FLY && pbeg >= pend && lane == 0)      // a wave without particles gathers nothing: it is done at once
+    __hip_atomic_fetch_add(gf.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   NM_SB();
   stage_permuted<NM_PERM_FWD>(wperm_p, sPp);
   stage_permuted<NM_PERM_FWD>(wperm_e, sPe);
@@ -635,7 +653,22 @@ __global__ void __launch_bounds__(256) k_material_fwd_pair(int n, int q, float a
     const G2pIn cur = nxt;
     if (p + 64 < pend) nxt = g2p_in_load(p + 64, gf.clip, gf.enabled, gf.x, gf.F);
     NM_SB();
-    if (valid) g2p_particle<true>(gf.K, p, cur, gf.x, gf.gv, gf.xn, gf.vn, gf.Cn, Ftr, nullptr, 0, true);
+    if (FLY) {      // velocities formed from {mv, m} per gathered node: no k_grid_op ran
+      if (valid) g2p_particle<true, false, true>(gf.K, p, cur, gf.x, gf.gv, gf.xn, gf.vn, gf.Cn, Ftr, nullptr, 0, true);
+      if (c0 + 64 >= pend) {
+        // this wave's last gathers have returned (their values are in Ftr / the stored state): tell the prologue workgroups,
+        // which are waiting to clear the array they came from.  Loads retire in order and vmcnt(0) is all it takes - a WAR
+        // hazard needs no cache maintenance, and a release fence at agent scope would write the L2 back (§5)
+        // (not s_waitcnt vmcnt(0): that also waits for the wave's outstanding STORES - the previous round's activation records -
+        //  5 us on average.  The increment is made to depend on a value computed from the gathers instead: an instruction that
+        //  reads it cannot issue before the loads behind it have returned, and vmcnt retires loads in order)
+        int zero;
+        asm volatile("v_and_b32 %0, 0, %1" : "=v"(zero) : "v"(Ftr.m[0] + Ftr.m[4] + Ftr.m[8]) : "memory");
+        if (lane == 0) __hip_atomic_fetch_add(gf.done, 1 + zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else if (valid) {
+      g2p_particle<true>(gf.K, p, cur, gf.x, gf.gv, gf.xn, gf.vn, gf.Cn, Ftr, nullptr, 0, true);
+    }
     const M3 Fn = material_fwd_round<NM_PLASTICITY, ACT>(Ftr, valid, n, p, c0, ntile, lane, alpha, sPp, sPp + 16 * 64,
                                                          sPp + 16 * 64 + 64 * 64, zb, yb, svd_p, act_p);
     if (valid) m3_store(F_next + 9 * p, Fn);
@@ -684,14 +717,29 @@ int nm_material_fwd_pair_launch(int32_t n, float alpha_p, const float* wperm_p, 
   gp.mat_grid = grid;
   const int launch = (pro && grid + NM_PRO_WGS <= NM_BWD_GRID) ? grid + NM_PRO_WGS : grid;
   f4 *ap = reinterpret_cast<f4*>(act_p), *ae = reinterpret_cast<f4*>(act_e);
-  if (ap && ae)
-    NM_LAUNCH((k_material_fwd_pair<true>), dim3(launch), dim3(256), 0, s, n, q, alpha_p, wperm_p, wperm_e, F_next, stress_next, gp, *g2p,
+  const bool fly = g2p->fly != 0;
+  if (fly && !(gp.mode == 3 && launch > grid)) { nm_set_error("folded pair launch without prologue workgroups of its own"); return NM_ERR_INVALID; }
+  if (ap && ae && fly)
+    NM_LAUNCH((k_material_fwd_pair<true, true>), dim3(launch), dim3(256), 0, s, n, q, alpha_p, wperm_p, wperm_e, F_next, stress_next, gp, *g2p,
+              svd_p, svd_e, ap, ae);
+  else if (ap && ae)
+    NM_LAUNCH((k_material_fwd_pair<true, false>), dim3(launch), dim3(256), 0, s, n, q, alpha_p, wperm_p, wperm_e, F_next, stress_next, gp, *g2p,
+              svd_p, svd_e, ap, ae);
+  else if (fly)
+    NM_LAUNCH((k_material_fwd_pair<false, true>), dim3(launch), dim3(256), 0, s, n, q, alpha_p, wperm_p, wperm_e, F_next, stress_next, gp, *g2p,
               svd_p, svd_e, ap, ae);
   else
-    NM_LAUNCH((k_material_fwd_pair<false>), dim3(launch), dim3(256), 0, s, n, q, alpha_p, wperm_p, wperm_e, F_next, stress_next, gp, *g2p,
+    NM_LAUNCH((k_material_fwd_pair<false, false>), dim3(launch), dim3(256), 0, s, n, q, alpha_p, wperm_p, wperm_e, F_next, stress_next, gp, *g2p,
               svd_p, svd_e, ap, ae);
   NM_LAUNCH_CHECK();
   return NM_OK;
+}
+// particle waves of a forward pair launch that has workgroups to spare for a prologue of its own (0: it has none - the
+// prologue then runs on the first particle workgroups, before their particles, and cannot wait for anybody)
+int nm_material_fwd_pair_fly_waves(int32_t n) {
+  int grid, q;
+  nm_wave_quota(n, grid, q);
+  return (n > 0 && grid + NM_PRO_WGS <= NM_BWD_GRID) ? 4 * grid : 0;
 }
 int nm_material_prepare(const nm_mlp* w, float* wperm, void* stream) {
   NM_LAUNCH(k_permute_weights, dim3(1), dim3(256), 0, (hipStream_t)stream, w->w0, w->w1, w->w2, wperm, (const float*)nullptr,

@@ -100,6 +100,13 @@ extern "C" int nm_rollout_cache_status(const void* gridcache, const nm_rollout_c
 
 // forward sweep: plasticity(t) and elasticity(t+1) in one launch (default) or one launch per net (A/B measurements, tests)
 static int g_forward_pair = 1;
+// forward sweep: no k_grid_op in front of a pair launch (velocities formed inside its g2p, GridPrologue mode 3).  OFF by default:
+// built, correct, measured 22 us per substep SLOWER at the metric size - kept as a switch with its test
+static int g_gridop_fold = [] { const char* e = getenv("NEUMA_GRIDOP_FOLD"); return (e && e[0] == '1') ? 1 : 0; }();
+extern "C" int nm_rollout_set_gridop_fold(int32_t on) {
+  g_gridop_fold = on ? 1 : 0;
+  return NM_OK;
+}
 extern "C" int nm_rollout_set_forward_pair(int32_t on) {
   g_forward_pair = on ? 1 : 0;
   return NM_OK;
@@ -130,13 +137,24 @@ extern "C" int nm_rollout_forward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cf
       if (rc) return rc;
     }
     // p2g + grid update here; the substep's g2p runs inside the plasticity kernel, which consumes its trial F from
-    // registers (the reverse sweep recomputes the trial F from the checkpointed C', so it is never stored)
-    rc = nm_mpm_forward_prepared_nog2p(h, n, st, &cur, grid_rec(gridcache, cfg, t), cfg->grid_cache_blocks, stream);  // finetune.py:363
+    // registers (the reverse sweep recomputes the trial F from the checkpointed C', so it is never stored).
+    // Round 5: in front of a pair launch that has workgroups to spare, the grid update is not launched at all - the pair kernel's
+    // g2p forms the node velocities from {mv, m} as it gathers them, and its prologue workgroups write the cache record, wait for
+    // the gathers and clear the grid behind them (GridPrologue mode 3; nm_rollout_set_gridop_fold / NEUMA_GRIDOP_FOLD=1, off by default)
+    const int fly_waves = (g_forward_pair && g_gridop_fold && t + 1 < cfg->substeps) ? nm_material_fwd_pair_fly_waves(n) : 0;
+    if (fly_waves > 0) rc = nm_mpm_forward_prepared_p2g(h, n, st, &cur, stream);
+    else rc = nm_mpm_forward_prepared_nog2p(h, n, st, &cur, grid_rec(gridcache, cfg, t), cfg->grid_cache_blocks, stream);  // finetune.py:363
     if (rc) return rc;
     G2pFuse g2p;
     rc = nm_mpm_g2p_fuse(h, st, &cur, &nxt, &g2p);
     if (rc) return rc;
-    if (g_forward_pair && t + 1 < cfg->substeps) {
+    if (fly_waves > 0) {
+      GridPrologue pro;
+      rc = nm_mpm_prologue_forward_fly(h, grid_rec(gridcache, cfg, t), cfg->grid_cache_blocks, fly_waves, &pro, &g2p, stream);
+      if (rc) return rc;
+      rc = nm_material_fwd_pair_launch(n, cfg->plasticity_alpha, w.perm_p, w.perm_e, nxt.F, nxt.stress, &pro, &g2p, stream,
+                                       svd_rec(cfg, n, t, 1), svd_rec(cfg, n, t + 1, 0), act_rec(cfg, n, t, 1), act_rec(cfg, n, t + 1, 0));
+    } else if (g_forward_pair && t + 1 < cfg->substeps) {
       // plasticity of this substep and elasticity of the next in one launch (F_{t+1} goes from one net to the other in
       // registers), which also carries the grid clear of substep t+1 - with the velocities left in place, because this very
       // launch gathers them (finetune.py:364 -> :362 of the next iteration)

@@ -167,8 +167,13 @@ def _tail_forward(rt, p_cur, Fc, weight, jobs, streams, gt=None, step=None, eage
         if eager is not None:
             eager.append(raster_backward_raw(rec, gimg)[0])
 
+    inline_last = streams and eager is not None and os.environ.get("NEUMA_INLINE_LAST_VIEW", "1") != "0"
     for i, (vi, rows) in enumerate(jobs):
-        if streams:
+        if inline_last and i == len(jobs) - 1:
+            # the last job stays on the caller's stream: the frame's critical path then crosses no queue at the fork, and none at the
+            # join either unless one of the other jobs outlasts it (a hop between two HIP queues costs the device ~15 us)
+            job(vi, rows, loss)
+        elif streams:
             st = streams[i]
             st.wait_stream(main)
             with torch.cuda.stream(st):
