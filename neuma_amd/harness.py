@@ -1212,6 +1212,7 @@ class DiskRuntime(SceneRuntime):
         self.sim_cached = MPMCacheDiffSim(self.model, 1 << 16)
         self._sim_fused = None
         self.gaussians = gaussians
+        self.gaussian_perm = None       # (the caller's GaussianModel is used as it is: its order is the caller's)
         self._opacity = gaussians.get_opacity.contiguous()
         self._shs = gaussians.get_features.contiguous()
         self._cov = gaussians.get_covariance(scaling_modifier)
