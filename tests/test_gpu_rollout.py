@@ -140,6 +140,39 @@ def test_frame_forward_backward_finite_and_consistent():
     assert abs(total - float(r1.loss)) < 1e-5 * max(1.0, abs(float(r1.loss)))
 
 
+def test_the_runtimes_own_kernel_order_changes_nothing_but_the_order(monkeypatch):
+    """SceneRuntime keeps its Gaussians in the Hilbert order of their rest positions (NEUMA_GAUSSIAN_ORDER=spatial, the default:
+    the binding's gathers stay local) and records the permutation; with `given` it keeps the caller's order.  Same scene either
+    way: images, loss, final state and the LoRA gradients agree to the atomics-order level, and the per-kernel arrays of the
+    spatial runtime are the caller's arrays permuted by `gaussian_perm`."""
+    from neuma_amd import synth
+    from neuma_amd.harness import SceneRuntime
+    scene = synth.make_scene("tiny", override=dict(S=3, V=2))
+    res = {}
+    for mode in ("given", "spatial"):
+        monkeypatch.setenv("NEUMA_GAUSSIAN_ORDER", mode)
+        rt = SceneRuntime(scene, dev(), fused=True)
+        assert (rt.gaussian_perm is None) == (mode == "given")
+        rt.set_start_state("deformed")
+        rt.make_ground_truth()
+        with torch.no_grad():
+            for p in rt.parameters():
+                if p.shape[0] in (64, 9):       # lora_B: a material that is visibly off the ground truth's, so the gradients are a signal
+                    p.mul_(-4.0)
+        r = rt.frame()
+        res[mode] = (rt, r, [p.grad.clone() for p in rt.parameters()], [g.clone() for g in rt.gt])
+    (rt0, r0, g0, gt0), (rt1, r1, g1, gt1) = res["given"], res["spatial"]
+    perm = rt1.gaussian_perm.to(dev())
+    assert sorted(perm.tolist()) == list(range(rt0.K)) and perm.tolist() != list(range(rt0.K))
+    assert torch.equal(rt1.gaussians.get_xyz, rt0.gaussians.get_xyz[perm]) and torch.equal(rt1._opacity, rt0._opacity[perm])
+    for a, b in zip(gt1, gt0):
+        assert abs_max(a, b) < 2e-6          # the ground-truth renders: the same picture (depth ties aside)
+    assert abs(float(r1.loss) - float(r0.loss)) < 2e-5 * max(1e-12, abs(float(r0.loss)))
+    assert rel_max(r1.x, r0.x) < 3e-7 and rel_max(r1.F, r0.F) < 7e-7
+    for a, b in zip(g1, g0):
+        assert torch.isfinite(a).all() and float(b.abs().max()) > 0 and rel_max(a, b) < 2e-5
+
+
 @pytest.mark.parametrize("scene,over", [("tiny", None), ("tiny", dict(S=4, V=2))])
 def test_one_node_frame_equals_the_composition_of_nodes(scene, over, monkeypatch):
     """SceneRuntime.frame() on one GPU runs the whole frame as ONE autograd node over the LoRA factors (harness._Frame: merge of
