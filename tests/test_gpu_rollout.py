@@ -166,11 +166,11 @@ def test_the_runtimes_own_kernel_order_changes_nothing_but_the_order(monkeypatch
     assert sorted(perm.tolist()) == list(range(rt0.K)) and perm.tolist() != list(range(rt0.K))
     assert torch.equal(rt1.gaussians.get_xyz, rt0.gaussians.get_xyz[perm]) and torch.equal(rt1._opacity, rt0._opacity[perm])
     for a, b in zip(gt1, gt0):
-        assert abs_max(a, b) < 2e-6          # the ground-truth renders: the same picture (depth ties aside)
+        assert abs_max(a, b) < 1e-6          # the ground-truth renders: the same picture (depth ties aside); measured 3.0e-07
     assert abs(float(r1.loss) - float(r0.loss)) < 2e-5 * max(1e-12, abs(float(r0.loss)))
     assert rel_max(r1.x, r0.x) < 3e-7 and rel_max(r1.F, r0.F) < 7e-7
     for a, b in zip(g1, g0):
-        assert torch.isfinite(a).all() and float(b.abs().max()) > 0 and rel_max(a, b) < 2e-5
+        assert torch.isfinite(a).all() and float(b.abs().max()) > 0 and rel_max(a, b) < 3e-6      # measured 1.0e-06
 
 
 @pytest.mark.parametrize("scene,over", [("tiny", None), ("tiny", dict(S=4, V=2))])
