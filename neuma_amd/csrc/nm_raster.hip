@@ -687,9 +687,6 @@ __global__ void __launch_bounds__(NM_NS) k_cell_offsets(int nbin, const uint32_t
 // a time: all four log reads are requested together, then the eight dependent reads (cell offset, depth), then the stores - the
 // rolled loop (one entry per trip: log -> offset / depth -> store) was two HBM round trips per entry, three to five entries per
 // thread, one after the other (35 us per view for 28 MB of traffic).
-// PACKED (chunk binning): an entry is {cell, rank | mask << 16, id, depth bits}; otherwise {cell, rank, id, mask} and the depth is
-// fetched per entry
-template <bool PACKED>
 __global__ void __launch_bounds__(256) k_bin_fill(const uint32_t* __restrict__ hdr, const PairLog* __restrict__ log,
                                                   const uint32_t* __restrict__ off, const float* __restrict__ depth,
                                                   unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals, long long cap) {
@@ -708,16 +705,47 @@ __global__ void __launch_bounds__(256) k_bin_fill(const uint32_t* __restrict__ h
     for (int u = 0; u < 4; ++u) {
       const bool liv = q[u].cell != 0xffffffffu;      // (dead entry: no tile of that bin passed the conic test)
       o[u] = liv ? off[q[u].cell] : 0u;
-      if (PACKED) d[u] = q[u].mask;
-      else d[u] = liv ? __float_as_uint(depth[q[u].id]) : 0u;
+      d[u] = liv ? __float_as_uint(depth[q[u].id]) : 0u;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (q[u].cell == 0xffffffffu) continue;
-      const long long slot = (long long)o[u] + (PACKED ? (q[u].rank & 0xffffu) : q[u].rank);
+      const long long slot = (long long)o[u] + q[u].rank;
       if (slot < cap) {
         keys[slot] = ((unsigned long long)d[u] << 32) | (unsigned long long)q[u].id;
-        vals[slot] = PACKED ? (q[u].rank >> 16) : q[u].mask;
+        vals[slot] = q[u].mask;
+      }
+    }
+  }
+}
+// the same for the chunk binning's 8-byte entries (k_bin_count2): slot = coff[chunk, bin] + rank, key = gkeys[chunk * 256 + position]
+__global__ void __launch_bounds__(256) k_bin_fill8(const uint32_t* __restrict__ hdr, const unsigned long long* __restrict__ log,
+                                                   const uint32_t* __restrict__ coff, int nbin,
+                                                   const unsigned long long* __restrict__ gkeys,
+                                                   unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals, long long cap) {
+  const long long n = min((long long)hdr[2], cap);
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long e0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; e0 < n; e0 += 4 * stride) {
+    unsigned long long q[4], kk[4];
+    uint32_t o[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long e = e0 + u * stride;
+      q[u] = log[min(e, n - 1)];            // (clamped: all four requests go out together, see the scans)
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t chunk = (uint32_t)(q[u] >> 43), bin = (uint32_t)(q[u] >> 32) & 0x7ffu, pos = ((uint32_t)q[u] >> 16) & 0xffu;
+      o[u] = coff[(size_t)chunk * nbin + bin];
+      kk[u] = gkeys[(size_t)chunk * 256 + pos];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (e0 + u * stride >= n) continue;
+      const long long slot = (long long)o[u] + ((uint32_t)q[u] >> 24);
+      if (slot < cap) {
+        keys[slot] = kk[u];
+        vals[slot] = (uint32_t)q[u] & 0xffffu;
       }
     }
   }
@@ -991,7 +1019,7 @@ __global__ void __launch_bounds__(256) k_bin_count2(RK k, int nbx, int nbin, con
   __shared__ int s_excl[4][64];
   __shared__ RowCull s_tc[4][64];
   __shared__ int4 s_geo[4][64], s_bin[4][64];
-  __shared__ uint32_t s_id[4][64], s_dep[4][64];
+  __shared__ uint32_t s_id[4][64];
   __shared__ unsigned char s_owner[4][NM_B2_OWN];
   __shared__ uint2 s_stash[4][NM_B2_STASH];
   __shared__ uint32_t s_wsum[4], s_base;
@@ -1002,11 +1030,10 @@ __global__ void __launch_bounds__(256) k_bin_count2(RK k, int nbx, int nbin, con
   const uint32_t at_ = (uint32_t)chunk * 256u + (uint32_t)tid;
   bool live = at_ < nvis;
   int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
-  uint32_t id = 0u, dep = 0u;
+  uint32_t id = 0u;
   RowCull tc = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f, -1.f, 0.f};
   if (live) {
-    const unsigned long long gk = gkeys[at_];
-    id = (uint32_t)gk; dep = (uint32_t)(gk >> 32);
+    id = (uint32_t)gkeys[at_];
     const float2 p = xy[id];
     get_rect(k, p.x, p.y, radii[id], x0, y0, x1, y1, k.ty0, k.ty1);
     tc = make_row_cull(p.x, p.y, conop[id]);
@@ -1023,7 +1050,6 @@ __global__ void __launch_bounds__(256) k_bin_count2(RK k, int nbx, int nbin, con
   s_geo[wv][lane] = make_int4(x0, y0, x1, y1);
   s_bin[wv][lane] = make_int4(bx0, by0, nbw, 0);
   s_id[wv][lane] = id;
-  s_dep[wv][lane] = dep;
   for (int q = 0; q < mine; ++q) {
     const int w_ = incl - mine + q;
     if (w_ < NM_B2_OWN) s_owner[wv][w_] = (unsigned char)lane;
@@ -1105,12 +1131,12 @@ __global__ void __launch_bounds__(256) k_bin_count2(RK k, int nbx, int nbin, con
         rank += (uint32_t)__popc(s_mask[bin * 8 + wq] & ((1u << (gl & 31)) - 1u));
         const long long slot = base + (long long)s_pref[bin] + rank;
         if (slot < cap) {
-          PairLog e;
-          // packed form (k_bin_fill<true>): rank (< 256) and the 16-bit tile mask share a word, the fourth carries the depth bits,
-          // so the fill pass has no per-entry gather left
-          e.cell = (uint32_t)chunk * (uint32_t)nbin + (uint32_t)bin; e.rank = rank | (m << 16); e.id = s_id[gl >> 6][gl & 63];
-          e.mask = s_dep[gl >> 6][gl & 63];
-          log[slot] = e;
+          // 8-byte entries (k_bin_fill8): chunk | bin (11 bits) | rank (8) | position in the chunk (8) | tile mask (16).  The fill pass
+          // finds (depth bits, id) at gkeys[chunk * 256 + position] - the chunk's 2 KB of the sorted list, read by the entries of one
+          // chunk, which lie together in the log
+          reinterpret_cast<unsigned long long*>(log)[slot] =
+              ((unsigned long long)(uint32_t)chunk << 43) | ((unsigned long long)(uint32_t)bin << 32) |
+              (unsigned long long)((rank << 24) | ((uint32_t)gl << 16) | (m & 0xffffu));
         }
       }
     }
@@ -2684,9 +2710,9 @@ static int raster_forward_impl(const nm_raster_cfg* cfg, int32_t K, int32_t m, c
               t.hdr, (long long)cap_pairs);
     NM_LAUNCH_CHECK();
     if (K > 0) {
-      NM_LAUNCH(k_bin_fill<true>, dim3(min(2048, nm_div_up((int)min((int64_t)cap_pairs, (int64_t)K * 64), 256) + 1)), dim3(256), 0, s,
-                (const uint32_t*)t.hdr, (const PairLog*)t.log, (const uint32_t*)t.coff, (const float*)t.depth, t.keys, t.vals,
-                (long long)cap_pairs);
+      NM_LAUNCH(k_bin_fill8, dim3(min(2048, nm_div_up((int)min((int64_t)cap_pairs, (int64_t)K * 64), 256) + 1)), dim3(256), 0, s,
+                (const uint32_t*)t.hdr, (const unsigned long long*)t.log, (const uint32_t*)t.coff, nbin,
+                (const unsigned long long*)t.gkeys, t.keys, t.vals, (long long)cap_pairs);
       NM_LAUNCH_CHECK();
     }
   } else {
@@ -2705,7 +2731,7 @@ static int raster_forward_impl(const nm_raster_cfg* cfg, int32_t K, int32_t m, c
             (long long)cap_pairs);
   NM_LAUNCH_CHECK();
   if (K > 0) {
-    NM_LAUNCH(k_bin_fill<false>, dim3(min(2048, nm_div_up((int)min((int64_t)cap_pairs, (int64_t)K * 64), 256) + 1)), dim3(256), 0, s,
+    NM_LAUNCH(k_bin_fill, dim3(min(2048, nm_div_up((int)min((int64_t)cap_pairs, (int64_t)K * 64), 256) + 1)), dim3(256), 0, s,
               (const uint32_t*)t.hdr, (const PairLog*)t.log, (const uint32_t*)t.off, (const float*)t.depth, t.keys, t.vals,
               (long long)cap_pairs);
     NM_LAUNCH_CHECK();
