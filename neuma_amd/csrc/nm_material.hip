@@ -19,19 +19,22 @@
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 #ifdef NM_PHASES
-__device__ long long g_nm_phase[8 * 2048];
+__device__ long long g_nm_phase[2 * 8 * 2048];     // [net kind][wave][phase]: the reverse pair kernel's two bodies do not overwrite each other
 extern "C" int nm_debug_phases(long long* out, int n) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nm_phase), (size_t)n * sizeof(long long)) == hipSuccess ? 0 : -2;
 }
 #define NM_PH_DECL long long ph_t0 = clock64(); long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define NM_PH(i) { long long t1 = clock64(); ph[i] += t1 - ph_t0; ph_t0 = t1; }
-#define NM_PH_STORE if ((threadIdx.x & 63) == 0) { int w = blockIdx.x * 4 + (threadIdx.x >> 6); if (w < 2048) for (int i = 0; i < 8; ++i) g_nm_phase[w * 8 + i] = ph[i]; }
+#define NM_PH_STORE_K(kind) if ((threadIdx.x & 63) == 0) { int w = blockIdx.x * 4 + (threadIdx.x >> 6); if (w < 2048) for (int i = 0; i < 8; ++i) g_nm_phase[((kind) * 2048 + w) * 8 + i] = ph[i]; }
+#define NM_PH_STORE NM_PH_STORE_K(0)
 #else
+#define NM_PH_STORE_K(kind)
 #define NM_PH_DECL
 #define NM_PH(i)
 #define NM_PH_STORE
 #endif
 #define NM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define NM_SB_() __builtin_amdgcn_sched_barrier(0)
 
 #define NM_BWD_GRID 256   // workgroups of the constitutive kernels = CUs
 // A GridPrologue runs on NM_PRO_WGS extra workgroups (blockIdx >= pro.mat_grid) when the constitutive work leaves that many
@@ -284,8 +287,13 @@ __device__ __forceinline__ void stage_bwd_weights(const float* raw, float* Q0, f
 // forward operands, NM_PERM_ALL with the transposed ones.  Staging is then a straight 16-byte copy.
 #define NM_PERM_FWD (16 * 64 + 64 * 64 + 16 * 64)
 #define NM_PERM_ALL (NM_PERM_FWD + 16 * 64 + 64 * 64 + 12 * 64)
-template <int NFLOAT>
-__device__ __forceinline__ void stage_permuted(const float* __restrict__ wperm, float* dst) {
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+// `between` runs after the loads are issued and before the first LDS write waits for them: loads placed there are younger than
+// the weights' and are not waited for here (vmcnt retires in order)
+template <int NFLOAT, class HOOK = NoHook>
+__device__ __forceinline__ void stage_permuted(const float* __restrict__ wperm, float* dst, HOOK between = HOOK()) {
   constexpr int NV = NFLOAT / 4, PER = (NV + 255) / 256;
   float4 v[PER];
 #pragma unroll
@@ -293,10 +301,54 @@ __device__ __forceinline__ void stage_permuted(const float* __restrict__ wperm, 
     int i = threadIdx.x + 256 * k;
     v[k] = i < NV ? reinterpret_cast<const float4*>(wperm)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  NM_SB_();
+  between();
+  NM_SB_();
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     int i = threadIdx.x + 256 * k;
     if (i < NV) reinterpret_cast<float4*>(dst)[i] = v[k];
+  }
+}
+// Two pieces staged with ONE round trip, and without waiting for anything but themselves.  The loads are inline assembly:
+// written as C++ the compiler (a) put the loads of the last, partly filled slice under a lane predicate - a branch region,
+// behind which its wait-count bookkeeping drains EVERY outstanding load, the particles' HBM requests in front included - and,
+// with clamped indices instead of predicates, (b) sank each load next to its LDS write: seven round trips in a row.  Here
+// the order is what is written: all weight loads, then `between` - which must issue exactly NHOOK vector-memory loads,
+// unconditionally; they stay in flight - then one s_waitcnt that leaves those NHOOK outstanding (vmcnt retires in order),
+// then the LDS writes.  Loads the compiler knows about and that were issued earlier are older and therefore complete too.
+template <int NA, int NB, int NHOOK, class HOOK>
+__device__ __forceinline__ void stage_permuted2(const float* __restrict__ srca, float* dsta, const float* __restrict__ srcb, float* dstb,
+                                                HOOK between) {
+  constexpr int VA = NA / 4, PA = (VA + 255) / 256, VB = NB / 4, PB = (VB + 255) / 256;
+  f4 va[PA], vb[PB];
+#pragma unroll
+  for (int k = 0; k < PA; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    const f4* ptr = reinterpret_cast<const f4*>(srca) + (i < VA ? i : VA - 1);
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(va[k]) : "v"(ptr));
+  }
+#pragma unroll
+  for (int k = 0; k < PB; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    const f4* ptr = reinterpret_cast<const f4*>(srcb) + (i < VB ? i : VB - 1);
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(vb[k]) : "v"(ptr));
+  }
+  asm volatile("" ::: "memory");
+  between();
+  static_assert(NHOOK >= 0 && NHOOK < 48, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NHOOK) : "memory");
+#pragma unroll
+  for (int k = 0; k < PA; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    asm volatile("" : "+v"(va[k]));      // (the value is only now defined as far as the compiler may assume)
+    if (i < VA) *reinterpret_cast<f4*>(dsta + 4 * i) = va[k];
+  }
+#pragma unroll
+  for (int k = 0; k < PB; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    asm volatile("" : "+v"(vb[k]));
+    if (i < VB) *reinterpret_cast<f4*>(dstb + 4 * i) = vb[k];
   }
 }
 // one workgroup: raw (out,in) weights -> operand order in global memory (once per roll-out and net)
@@ -814,38 +866,64 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
   // (round 4): the wave is alone on its SIMD, and a round that started with its own loads sat through their whole HBM round trip
   // (the first record "took 8 k cycles to arrive", §5) four times per pair launch.  Loads are issued in the order they are
   // needed (vmcnt retires in order); `enabled` gates nothing any more - a disabled particle's values are replaced afterwards.
+  // (the three 3x3 inputs stay in the shape their loads return them in - 16 + 16 + 4 bytes - until the round that uses them
+  //  begins: as nine scalars the compiler re-packed the loaded registers right behind the load instructions, i.e. waited for
+  //  the first round's HBM round trip before it had issued the rest of the loads, twice per body)
+  struct M3Raw {
+    f4 a, b;
+    float c;
+  };
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  auto raw_load = [](const float* __restrict__ ptr, M3Raw& r) {
+    r.a = *reinterpret_cast<const f4u*>(ptr); r.b = *reinterpret_cast<const f4u*>(ptr + 4); r.c = ptr[8];
+  };
+  auto raw_m3 = [](const M3Raw& r) {
+    M3 m;
+    m.m[0] = r.a[0]; m.m[1] = r.a[1]; m.m[2] = r.a[2]; m.m[3] = r.a[3];
+    m.m[4] = r.b[0]; m.m[5] = r.b[1]; m.m[6] = r.b[2]; m.m[7] = r.b[3]; m.m[8] = r.c;
+    return m;
+  };
   struct RoundIn {
     int en_p;
-    M3 Fp, go, T, U, V;
+    M3Raw Fp, go, T;
+    M3 U, V;
     float s[3];
     f4 nx[ACT ? NM_ACT_SLOTS : 1];
   };
-  auto load_round = [&](int c0_, RoundIn& o) {
-    const int p_ = c0_ + lane;
-    const bool valid_ = p_ < pend;
-    o.en_p = (fz.trial_C && valid_) ? fz.enabled[p_] : 0;
-    o.Fp = valid_ ? m3_load(F + 9 * p_) : m3_ident();
-    o.go = valid_ ? m3_load(gout + 9 * p_) : m3_zero();
-    o.T = (fz.trial_C && valid_) ? m3_load(fz.trial_C + 9 * p_) : m3_zero();
-    if (fz.svd_in) {        // (workgroup-uniform)
-      if (valid_) svd_load(fz.svd_in, n, p_, o.U, o.s, o.V);
-      else { o.U = m3_ident(); o.V = m3_ident(); o.s[0] = o.s[1] = o.s[2] = 1.f; }
-    }
+  auto load_round_act = [&](int c0_, RoundIn& o) {
     if (ACT) {
       const f4* at_ = a.act + (size_t)(c0_ >> 4) * NM_ACT_SLOTS * 64 + lane;
 #pragma unroll
       for (int k = 0; k < NM_ACT_SLOTS; ++k) o.nx[k] = __builtin_nontemporal_load(&at_[k * 64]);
     }
   };
-  // ... and the FIRST round's are issued here, in front of the weight staging: its round trip hides theirs
+  auto load_round = [&](int c0_, RoundIn& o, bool with_act) {
+    const int p_ = c0_ + lane;
+    const bool valid_ = p_ < pend;
+    o.en_p = (fz.trial_C && valid_) ? fz.enabled[p_] : 0;
+    if (valid_) {
+      raw_load(F + (size_t)9 * p_, o.Fp);
+      raw_load(gout + (size_t)9 * p_, o.go);
+      if (fz.trial_C) raw_load(fz.trial_C + (size_t)9 * p_, o.T);
+    }
+    if (fz.svd_in) {        // (workgroup-uniform)
+      if (valid_) svd_load(fz.svd_in, n, p_, o.U, o.s, o.V);
+      else { o.U = m3_ident(); o.V = m3_ident(); o.s[0] = o.s[1] = o.s[2] = 1.f; }
+    }
+    if (ACT && with_act) load_round_act(c0_, o);
+  };
+  // ... and the FIRST round's are issued here, in front of the weight staging: its round trip hides theirs.  Every wave of the
+  // launch asks for its first round at the same moment (13 MB at once, and the staging cannot finish before the loads in front
+  // of it have returned): the first tile's activation record - half of those bytes, not needed before the first tile - is
+  // requested BEHIND the weights
   RoundIn ahead;
-  if (pbeg < pend) load_round(pbeg, ahead);
+  if (pbeg < pend) load_round(pbeg, ahead, false);
   NM_SB();
   if (wperm) {
     static_assert(offsetof(BwdLds, Z) == NM_PERM_ALL * sizeof(float), "P0..Q2 must be contiguous in operand order");
     if (ACT) {      // only the first layer is recomputed: its operands + the transposed ones
-      stage_permuted<16 * 64>(wperm, L.P0);
-      stage_permuted<NM_PERM_ALL - NM_PERM_FWD>(wperm + NM_PERM_FWD, L.Q0);
+      stage_permuted2<16 * 64, NM_PERM_ALL - NM_PERM_FWD, NM_ACT_SLOTS>(wperm, L.P0, wperm + NM_PERM_FWD, L.Q0,
+                                                          [&]() { load_round_act(pbeg < pend ? pbeg : 0, ahead); });      // (unconditional: NM_ACT_SLOTS loads)
     } else {
       stage_permuted<NM_PERM_ALL>(wperm, L.P0);
     }
@@ -881,13 +959,14 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
     const int ntile = (min(64, pend - c0) + 15) >> 4;
     f4 nx[ACT ? NM_ACT_SLOTS : 1];
     const f4* act_tile = ACT ? a.act + (size_t)(c0 >> 4) * NM_ACT_SLOTS * 64 + lane : nullptr;
-    M3 Fp = ahead.Fp, go = ahead.go, T = ahead.T;
+    M3 Fp = valid ? raw_m3(ahead.Fp) : m3_ident(), go = valid ? raw_m3(ahead.go) : m3_zero();
+    M3 T = (fz.trial_C && valid) ? raw_m3(ahead.T) : m3_zero();
     M3 R, U = ahead.U, V = ahead.V;
     float z[13], s[3] = {ahead.s[0], ahead.s[1], ahead.s[2]};
     const bool trial = ahead.en_p != 0;
 #pragma unroll
     for (int k = 0; k < (ACT ? NM_ACT_SLOTS : 1); ++k) nx[k] = ahead.nx[k];
-    if (c0 + 64 < pend) load_round(c0 + 64, ahead);      // (wave-uniform)
+    if (c0 + 64 < pend) load_round(c0 + 64, ahead, true);      // (wave-uniform)
     NM_SB();
     // roll-out: the forward pass fed the plasticity net I for a disabled particle (the fresh state of its next row, nm_grid.h)
     if (fz.trial_C && !trial) { Fp = m3_ident(); T = m3_zero(); }
@@ -1195,7 +1274,7 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
     __builtin_amdgcn_wave_barrier();
     NM_PH(7)
   }
-  NM_PH_STORE
+  NM_PH_STORE_K(KIND == NM_PLASTICITY ? 1 : 0)
 
   if (!want_w) return;   // (workgroup-uniform)
   // combine the four waves' weight-gradient accumulators: every wave stores its own copy in plain (out,in) layout to a
@@ -1362,6 +1441,37 @@ int nm_material_bwd_launch(int32_t n, int32_t kind, float alpha, const float* F,
   return NM_OK;
 }
 
+// EXPERIMENT (NEUMA_WARM=1): touch the first round's inputs of a reverse pair launch - what every wave asks for at the very
+// start of each body, 13 MB at once - so that they sit in the memory-side cache when the launch begins.
+struct WarmSet { const float* F; const float* svd; const f4* act; const float* C; };
+__global__ void __launch_bounds__(256) k_warm_first_round(int n, int q, WarmSet a, WarmSet b, float* sink) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int pbeg = min(n, (blockIdx.x * 4 + wave) * q), pend = min(n, pbeg + q);
+  const int cnt = min(64, pend - pbeg);
+  if (cnt <= 0) return;
+  float acc = 0.f;
+  const WarmSet sets[2] = {a, b};
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const WarmSet& w = sets[u];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int i = lane + 64 * k;
+      if (i < 9 * cnt) { acc += w.F[(size_t)9 * pbeg + i]; if (w.C) acc += w.C[(size_t)9 * pbeg + i]; }
+    }
+    if (w.svd && lane < cnt) {
+#pragma unroll
+      for (int c = 0; c < 21; ++c) acc += w.svd[(size_t)c * n + pbeg + lane];
+    }
+    if (w.act) {
+      const f4* at = w.act + (size_t)(pbeg >> 4) * NM_ACT_SLOTS * 64 + lane;
+#pragma unroll
+      for (int k = 0; k < NM_ACT_SLOTS; ++k) acc += at[k * 64][0];
+    }
+  }
+  if (acc == 1.2345e-30f) sink[0] = acc;      // (never: keeps the loads alive)
+}
+
 // roll-out reverse sweep: elasticity adjoint (dL/dstress gS -> += gF) of one substep, then the plasticity adjoint of the
 // substep before it (dL/dF = that gF -> gFtrial), one launch (k_material_bwd_pair)
 int nm_material_bwd_pair_launch(int32_t n, const float* F_e, const nm_mlp* we, const float* wperm_e, const float* gS, float* gF,
@@ -1380,6 +1490,11 @@ int nm_material_bwd_pair_launch(int32_t n, const float* F_e, const nm_mlp* we, c
   if (rc) return rc;
   BwdArgs e = bwd_args(n, q, 0.f, F_e, we, wperm_e, gS, gF, wpart_e, wmode_e, nullptr, nullptr, 0.f, 1 | (polar ? 2 : 0), svd_in_e, act_e);
   BwdArgs p = bwd_args(n, q, alpha_p, F_p, wp, wperm_p, gF, gFtrial, wpart_p, wmode_p, trial_C, enabled, dt, polar ? 2 : 0, svd_in_p, act_p);
+  static const int warm = getenv("NEUMA_WARM") ? atoi(getenv("NEUMA_WARM")) : 0;
+  if (warm && act_e && act_p) {
+    WarmSet a{F_e, svd_in_e, reinterpret_cast<const f4*>(act_e), nullptr}, b{F_p, svd_in_p, reinterpret_cast<const f4*>(act_p), trial_C};
+    NM_LAUNCH(k_warm_first_round, dim3(grid), dim3(256), 0, s, n, q, a, b, wpart_e);
+  }
   if (act_e && act_p)
     NM_LAUNCH(k_material_bwd_pair<true>, dim3(launch), dim3(256), sizeof(BwdLds), s, e, p, gp);
   else

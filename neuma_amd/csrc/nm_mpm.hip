@@ -1000,10 +1000,12 @@ __global__ void __launch_bounds__(256) k_grid_restore(MpmK K, GridRec rec, float
 // adjoint of grid_op: gg {vbar} -> {mvbar, mbar}
 // stamp != null (verified reverse sweep of a roll-out): also marks the blocks of the NEXT record of the sweep with the
 // epoch its restore will run under, which is what lets that restore share one pass with the clear (GridPrologue mode 2)
-__global__ void __launch_bounds__(256) k_grid_op_bwd(MpmK K, const float4* __restrict__ gm, float4* __restrict__ gg,
-                                                     const int* __restrict__ list, const int* __restrict__ count,
-                                                     GridRec stamp, int stamp_epoch, int* __restrict__ flags,
-                                                     const int* __restrict__ slot, const float4* __restrict__ xbuf) {
+// (the pointers the first loads go through come first: seven of them are what the dispatcher can hand over in registers -
+//  -amdgpu-kernarg-preload-count - so that the list / count requests need not wait for the kernel-argument fetch)
+__global__ void __launch_bounds__(256) k_grid_op_bwd(const int* __restrict__ list, const int* __restrict__ count,
+                                                     const float4* __restrict__ gm, float4* __restrict__ gg,
+                                                     int* __restrict__ flags, const int* __restrict__ slot,
+                                                     const float4* __restrict__ xbuf, MpmK K, GridRec stamp, int stamp_epoch) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b_first = (int)(blockIdx.x * 4 + wave) < K.nb * K.nb * K.nb ? list[blockIdx.x * 4 + wave] : 0;      // (with the count, not behind it: see k_grid_op)
   const int cnt = *count;
@@ -1614,8 +1616,8 @@ int nm_mpm_backward_cached_finish(nm_mpm* h, int32_t n, const nm_statics* st, co
   const int now = h->cur;
   GridRec stamp = {nullptr, nullptr, nullptr};
   if (stamp_rec) stamp = gridrec_at(const_cast<void*>(stamp_rec), cap_blocks);
-  NM_LAUNCH(k_grid_op_bwd, dim3(kSweepGrid), dim3(256), 0, s, h->k, h->gm, h->gg, h->list[now], h->count + now, stamp,
-                     h->epoch + 1, h->flags, (const int*)(xbuf ? h->sh_slot : nullptr), (const float4*)xbuf);
+  NM_LAUNCH(k_grid_op_bwd, dim3(kSweepGrid), dim3(256), 0, s, (const int*)h->list[now], (const int*)(h->count + now), (const float4*)h->gm, h->gg,
+                     h->flags, (const int*)(xbuf ? h->sh_slot : nullptr), (const float4*)xbuf, h->k, stamp, h->epoch + 1);
   NM_LAUNCH_CHECK();
   if (n == 0) return NM_OK;
   NM_LAUNCH(k_p2g_bwd, dim3(nm_div_up(n, 256)), dim3(256), 0, s, h->k, n, st->vol, st->rho, st->enabled, cur->x, cur->v, cur->C,
@@ -1790,8 +1792,8 @@ extern "C" int nm_mpm_backward_finish(nm_mpm* h, int32_t n, const nm_statics* st
   hipStream_t s = (hipStream_t)stream;
   const int now = h->cur;
   GridRec nostamp = {nullptr, nullptr, nullptr};
-  NM_LAUNCH(k_grid_op_bwd, dim3(kSweepGrid), dim3(256), 0, s, h->k, h->gm, h->gg, h->list[now], h->count + now, nostamp, 0,
-                     h->flags, (const int*)nullptr, (const float4*)nullptr);
+  NM_LAUNCH(k_grid_op_bwd, dim3(kSweepGrid), dim3(256), 0, s, (const int*)h->list[now], (const int*)(h->count + now), (const float4*)h->gm, h->gg,
+                     h->flags, (const int*)nullptr, (const float4*)nullptr, h->k, nostamp, 0);
   NM_LAUNCH_CHECK();
   if (n == 0) return NM_OK;
   int rc = check_particles(st, cur, true);

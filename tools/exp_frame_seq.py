@@ -13,13 +13,15 @@ for r in csv.DictReader(open(f)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n[:70], r.get("Queue_Id", "")))
 rows.sort()
 marks = [i for i, r in enumerate(rows) if r[2].startswith("k_lora_merge_layers") and not r[2].startswith("k_lora_merge_layers_bwd")]
-# frame = from an elasticity merge (every second merge launch) to the next
-# a frame = from one elasticity merge (every second merge launch) to the next, with renders in between; take the last one
+# a frame = from one LoRA merge launch to the next with renders in between (one launch merges both nets' layers; builds that
+# merged per net launched two - then every second mark opens a frame); the last complete one of the timed region is taken
 seq = None
-for a, b in zip(marks[-2::-2][1:], marks[-2::-2]):
-    if any(r[2].startswith("k_render_bwd") for r in rows[a:b]):
-        seq = rows[a:b]
-        break
+step = 2 if len(marks) >= 4 and not any(r[2].startswith("k_render_bwd") for r in rows[marks[-3]:marks[-2]]) else 1
+cands = marks[::step]
+frames = [rows[a:b] for a, b in zip(cands, cands[1:]) if any(r[2].startswith("k_render_bwd") for r in rows[a:b])]
+if frames:                          # the frame of median span (the timed region's frames outnumber warm-up and accounting passes)
+    frames.sort(key=lambda f: f[-1][1] - f[0][0])
+    seq = frames[len(frames) // 2]
 if seq is None:
     raise SystemExit("no frame found")
 cover, end = 0, seq[0][0]

@@ -25,10 +25,15 @@ for _ in range(3):
     (o[0].sum() + o[3].sum()).backward()
 torch.cuda.synchronize()
 fn = lib.nm_debug_phases; fn.argtypes = [C.c_void_p, C.c_int]
-buf = np.zeros(8 * 2048, dtype=np.int64)
-print("rc", fn(buf.ctypes.data, 8 * 2048), "act cache:", os.environ.get("NEUMA_ACT_CACHE", "auto"))
-b = buf.reshape(2048, 8)[:893]
-names = ["stage weights", "svd+feat+ybar", "fwd recompute / act", "(a) W2 grad", "(b) h2bar", "(c) W1 grad", "(d) h1bar", "(e,f)+epilogue"]
-for i, nm in enumerate(names):
-    print(f"{nm:20s} mean {b[:, i].mean():9.0f} median {np.median(b[:, i]):9.0f} max {b[:, i].max():9.0f}")
-print("total mean", b.sum(1).mean(), "max", b.sum(1).max())
+buf = np.zeros(2 * 8 * 2048, dtype=np.int64)
+print("rc", fn(buf.ctypes.data, 2 * 8 * 2048), "act cache:", os.environ.get("NEUMA_ACT_CACHE", "auto"))
+# phase marks: (2) closes behind the first-layer recompute of a tile and therefore also holds (f) + (e) of the tile before it
+names = ["stage weights", "svd+feat+ybar", "(f,e) of prev tile + fwd / act", "(a) W2 grad", "(b) h2bar", "(c) W1 grad", "(d) h1bar", "last (f,e)+epilogue"]
+for kind, what in ((0, "elasticity adjoint of substep 0: a launch of its own (cycles from the kernel's start)"),
+                   (1, "plasticity adjoint of substep 0: the SECOND body of the last pair launch")):
+    b = buf.reshape(2, 2048, 8)[kind][:893]
+    b = b[b.sum(1) > 0]
+    print(what, "-", len(b), "waves")
+    for i, nm in enumerate(names):
+        print(f"  {nm:32s} mean {b[:, i].mean():9.0f} median {np.median(b[:, i]):9.0f} max {b[:, i].max():9.0f}")
+    print("  total mean", b.sum(1).mean(), "max", b.sum(1).max())
