@@ -93,19 +93,30 @@ __device__ __forceinline__ float sel3(const float* a, int i) { return i == 0 ? a
 // constitutive wave is issued before the current round's MLP, so that its HBM round trip hides behind it)
 struct TagEdge { static constexpr bool value = true; };
 struct TagInner { static constexpr bool value = false; };
+// (x and F stay in the shape their loads return them in - 12 and 16 + 16 + 4 bytes - until g2p_particle unpacks them: as
+//  scalars under a lane predicate the compiler re-packed the loaded registers right behind the loads, which put an HBM round
+//  trip - and, vmcnt counting stores too, the drain of every store of the round before - at the top of each round of the
+//  constitutive kernels.  Callers that load ahead do so unconditionally, at a clamped particle index.)
+typedef float nm_f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float nm_f3u __attribute__((ext_vector_type(3), aligned(4)));
+typedef float nm_f4v __attribute__((ext_vector_type(4)));
+typedef float nm_f3v __attribute__((ext_vector_type(3)));
 struct G2pIn {
   int e;
-  float x[3];
   float clip;
-  M3 F;
+  nm_f3v x;
+  nm_f4v Fa, Fb;
+  float Fc;
 };
 __device__ __forceinline__ G2pIn g2p_in_load(int p, const float* __restrict__ clip, const int* __restrict__ enabled, const float* x,
                                              const float* F) {
   G2pIn in;
   in.e = enabled[p];
-  in.x[0] = x[3 * p]; in.x[1] = x[3 * p + 1]; in.x[2] = x[3 * p + 2];
+  in.x = *reinterpret_cast<const nm_f3u*>(x + (size_t)3 * p);
   in.clip = clip[p];
-  in.F = m3_load(F + 9 * p);
+  in.Fa = *reinterpret_cast<const nm_f4u*>(F + (size_t)9 * p);
+  in.Fb = *reinterpret_cast<const nm_f4u*>(F + (size_t)9 * p + 4);
+  in.Fc = F[(size_t)9 * p + 8];
   return in;
 }
 // FLY (round 5, forward roll-out): `gv` is the {mv, m} array as p2g left it and the node velocities are formed here - the grid
@@ -131,7 +142,9 @@ __device__ __forceinline__ void g2p_particle(const MpmK& K, int p, const G2pIn& 
   const int e_ = in.e;
   float xp[3] = {in.x[0], in.x[1], in.x[2]};
   const float clip_p = in.clip;
-  const M3 Fp = in.F;
+  M3 Fp;
+  Fp.m[0] = in.Fa[0]; Fp.m[1] = in.Fa[1]; Fp.m[2] = in.Fa[2]; Fp.m[3] = in.Fa[3];
+  Fp.m[4] = in.Fb[0]; Fp.m[5] = in.Fb[1]; Fp.m[6] = in.Fb[2]; Fp.m[7] = in.Fb[3]; Fp.m[8] = in.Fc;
   if (e_ == 0) {
     if (fresh && xn != x) {
       Fo = m3_ident();

@@ -19,7 +19,7 @@
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 #ifdef NM_PHASES
-__device__ long long g_nm_phase[2 * 8 * 2048];     // [net kind][wave][phase]: the reverse pair kernel's two bodies do not overwrite each other
+__device__ long long g_nm_phase[3 * 8 * 2048];     // [0: elasticity adjoint / single forward, 1: plasticity adjoint, 2: forward pair][wave][phase]
 extern "C" int nm_debug_phases(long long* out, int n) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nm_phase), (size_t)n * sizeof(long long)) == hipSuccess ? 0 : -2;
 }
@@ -682,19 +682,20 @@ __global__ void __launch_bounds__(256) k_material_fwd_pair(int n, int q, float a
   // (FLY is a template parameter, not a run-time branch: with both g2p bodies inlined the kernel was 73 KB of code - past the
   //  64 KB instruction cache two CUs share - and every wave ran 1.4x slower, whatever it executed)
   if (material_prologue_fwd<FLY>(pro)) return;
+  NM_PH_DECL
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int pbeg = min(n, (blockIdx.x * 4 + wave) * q), pend = min(n, pbeg + q);
   // the stencil-independent loads of a round's particles (enabled, x, clip, F) are issued one round ahead - the first round's in
   // front of the weight staging -: the wave is alone on its SIMD, so a round that starts with its own loads spends their whole
   // HBM round trip (~2 us) doing nothing
-  G2pIn nxt{};
-  if (pbeg + lane < pend) nxt = g2p_in_load(pbeg + lane, gf.clip, gf.enabled, gf.x, gf.F);
-  else if (FLY && pbeg >= pend && lane == 0)      // a wave without particles gathers nothing: it is done at once
+  // (unconditional, at a clamped index - a lane without a particle loads the last one's and ignores it: see G2pIn)
+  G2pIn nxt = g2p_in_load(min(pbeg + lane, n - 1), gf.clip, gf.enabled, gf.x, gf.F);
+  if (FLY && pbeg >= pend && lane == 0)      // a wave without particles gathers nothing: it is done at once
     __hip_atomic_fetch_add(gf.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   NM_SB();
-  stage_permuted<NM_PERM_FWD>(wperm_p, sPp);
-  stage_permuted<NM_PERM_FWD>(wperm_e, sPe);
+  stage_permuted2<NM_PERM_FWD, NM_PERM_FWD, 0>(wperm_p, sPp, wperm_e, sPe, NoHook());     // both nets: one round trip
   __syncthreads();
+  NM_PH(0)
   float* zb = sZ[wave];
   float* yb = sY[wave];
   for (int c0 = pbeg; c0 < pend; c0 += 64) {
@@ -703,7 +704,7 @@ __global__ void __launch_bounds__(256) k_material_fwd_pair(int n, int q, float a
     const int ntile = (min(64, pend - c0) + 15) >> 4;
     M3 Ftr = m3_ident();
     const G2pIn cur = nxt;
-    if (p + 64 < pend) nxt = g2p_in_load(p + 64, gf.clip, gf.enabled, gf.x, gf.F);
+    nxt = g2p_in_load(min(p + 64, n - 1), gf.clip, gf.enabled, gf.x, gf.F);      // (also in the last round: nothing conditional)
     NM_SB();
     if (FLY) {      // velocities formed from {mv, m} per gathered node: no k_grid_op ran
       if (valid) g2p_particle<true, false, true>(gf.K, p, cur, gf.x, gf.gv, gf.xn, gf.vn, gf.Cn, Ftr, nullptr, 0, true);
@@ -721,13 +722,17 @@ __global__ void __launch_bounds__(256) k_material_fwd_pair(int n, int q, float a
     } else if (valid) {
       g2p_particle<true>(gf.K, p, cur, gf.x, gf.gv, gf.xn, gf.vn, gf.Cn, Ftr, nullptr, 0, true);
     }
+    NM_PH(1)
     const M3 Fn = material_fwd_round<NM_PLASTICITY, ACT>(Ftr, valid, n, p, c0, ntile, lane, alpha, sPp, sPp + 16 * 64,
                                                          sPp + 16 * 64 + 64 * 64, zb, yb, svd_p, act_p);
     if (valid) m3_store(F_next + 9 * p, Fn);
+    NM_PH(2)
     const M3 S = material_fwd_round<NM_ELASTICITY, ACT>(Fn, valid, n, p, c0, ntile, lane, 0.f, sPe, sPe + 16 * 64,
                                                         sPe + 16 * 64 + 64 * 64, zb, yb, svd_e, act_e);
     if (valid) m3_store(stress_next + 9 * p, S);
+    NM_PH(3)
   }
+  NM_PH_STORE_K(2)
 }
 
 // floats of one net's activation cache for n particles (one record per 16-particle tile)

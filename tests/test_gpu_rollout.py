@@ -7,7 +7,7 @@ import torch
 from oracle import material as omat
 from oracle import mpm as om
 from oracle import raster as orr
-from gpu_util import dev, rel_max, abs_max
+from gpu_util import dev, rel_max, abs_max, measured
 
 pytestmark = pytest.mark.gpu
 
@@ -166,7 +166,12 @@ def test_the_runtimes_own_kernel_order_changes_nothing_but_the_order(monkeypatch
     assert sorted(perm.tolist()) == list(range(rt0.K)) and perm.tolist() != list(range(rt0.K))
     assert torch.equal(rt1.gaussians.get_xyz, rt0.gaussians.get_xyz[perm]) and torch.equal(rt1._opacity, rt0._opacity[perm])
     for a, b in zip(gt1, gt0):
-        assert abs_max(a, b) < 1e-6          # the ground-truth renders: the same picture (depth ties aside); measured 3.0e-07
+        # the ground-truth renders: the same picture (measured 3.0e-07) - apart from single pixels for which a Gaussian sits on the
+        # rasterizer's alpha >= 1/255 cut-off: the two runs' particle states differ by the atomics order (1e-7), and such a pixel
+        # then gains or loses one contribution of at most 1/255 of a colour (seen: 1 pixel of 12 288 at 7.1e-05, one run in six)
+        d = (a - b).abs().amax(0)
+        assert int((d > 1e-6).sum()) <= 3 and abs_max(a, b) < 4e-3
+        assert measured(d.flatten().kthvalue(d.numel() - 3).values, "abs") < 1e-6
     assert abs(float(r1.loss) - float(r0.loss)) < 2e-5 * max(1e-12, abs(float(r0.loss)))
     assert rel_max(r1.x, r0.x) < 3e-7 and rel_max(r1.F, r0.F) < 7e-7
     for a, b in zip(g1, g0):
