@@ -893,16 +893,19 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
     M3Raw Fp, go, T;
     M3 U, V;
     float s[3];
-    f4 nx[ACT ? NM_ACT_SLOTS : 1];
   };
-  auto load_round_act = [&](int c0_, RoundIn& o) {
+  // activation record of the tile about to be processed (ACT): requested one tile ahead - ACROSS the round boundaries too, a
+  // wave's tiles are consecutive records - and never copied (round 5: as part of a round's inputs it was copied at the top of
+  // the round, i.e. waited for right behind the weights in the first round)
+  f4 nx[ACT ? NM_ACT_SLOTS : 1];
+  auto load_first_act = [&](int c0_) {
     if (ACT) {
       const f4* at_ = a.act + (size_t)(c0_ >> 4) * NM_ACT_SLOTS * 64 + lane;
 #pragma unroll
-      for (int k = 0; k < NM_ACT_SLOTS; ++k) o.nx[k] = __builtin_nontemporal_load(&at_[k * 64]);
+      for (int k = 0; k < NM_ACT_SLOTS; ++k) nx[k] = __builtin_nontemporal_load(&at_[k * 64]);
     }
   };
-  auto load_round = [&](int c0_, RoundIn& o, bool with_act) {
+  auto load_round = [&](int c0_, RoundIn& o) {
     const int p_ = c0_ + lane;
     const bool valid_ = p_ < pend;
     o.en_p = (fz.trial_C && valid_) ? fz.enabled[p_] : 0;
@@ -915,20 +918,19 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
       if (valid_) svd_load(fz.svd_in, n, p_, o.U, o.s, o.V);
       else { o.U = m3_ident(); o.V = m3_ident(); o.s[0] = o.s[1] = o.s[2] = 1.f; }
     }
-    if (ACT && with_act) load_round_act(c0_, o);
   };
   // ... and the FIRST round's are issued here, in front of the weight staging: its round trip hides theirs.  Every wave of the
   // launch asks for its first round at the same moment (13 MB at once, and the staging cannot finish before the loads in front
   // of it have returned): the first tile's activation record - half of those bytes, not needed before the first tile - is
   // requested BEHIND the weights
   RoundIn ahead;
-  if (pbeg < pend) load_round(pbeg, ahead, false);
+  if (pbeg < pend) load_round(pbeg, ahead);
   NM_SB();
   if (wperm) {
     static_assert(offsetof(BwdLds, Z) == NM_PERM_ALL * sizeof(float), "P0..Q2 must be contiguous in operand order");
     if (ACT) {      // only the first layer is recomputed: its operands + the transposed ones
       stage_permuted2<16 * 64, NM_PERM_ALL - NM_PERM_FWD, NM_ACT_SLOTS>(wperm, L.P0, wperm + NM_PERM_FWD, L.Q0,
-                                                          [&]() { load_round_act(pbeg < pend ? pbeg : 0, ahead); });      // (unconditional: NM_ACT_SLOTS loads)
+                                                          [&]() { load_first_act(pbeg < pend ? pbeg : 0); });      // (unconditional: NM_ACT_SLOTS loads)
     } else {
       stage_permuted<NM_PERM_ALL>(wperm, L.P0);
     }
@@ -962,16 +964,13 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
     const int p = c0 + lane;
     const bool valid = p < pend;
     const int ntile = (min(64, pend - c0) + 15) >> 4;
-    f4 nx[ACT ? NM_ACT_SLOTS : 1];
     const f4* act_tile = ACT ? a.act + (size_t)(c0 >> 4) * NM_ACT_SLOTS * 64 + lane : nullptr;
     M3 Fp = valid ? raw_m3(ahead.Fp) : m3_ident(), go = valid ? raw_m3(ahead.go) : m3_zero();
     M3 T = (fz.trial_C && valid) ? raw_m3(ahead.T) : m3_zero();
     M3 R, U = ahead.U, V = ahead.V;
     float z[13], s[3] = {ahead.s[0], ahead.s[1], ahead.s[2]};
     const bool trial = ahead.en_p != 0;
-#pragma unroll
-    for (int k = 0; k < (ACT ? NM_ACT_SLOTS : 1); ++k) nx[k] = ahead.nx[k];
-    if (c0 + 64 < pend) load_round(c0 + 64, ahead, true);      // (wave-uniform)
+    if (c0 + 64 < pend) load_round(c0 + 64, ahead);      // (wave-uniform)
     NM_SB();
     // roll-out: the forward pass fed the plasticity net I for a disabled particle (the fresh state of its next row, nm_grid.h)
     if (fz.trial_C && !trial) { Fp = m3_ident(); T = m3_zero(); }
@@ -1020,7 +1019,8 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) { h2[rt] = nx[rt]; m.g2[rt] = nx[4 + rt]; }
         m.y = nx[8];
-        if (ct + 1 < ntile) {
+        const bool more = c0 + 16 * (ct + 1) < pend;      // (wave-uniform: the wave has another tile, in this round or the next)
+        if (more) {
 #pragma unroll
           for (int k = 0; k < 5; ++k) nx[k] = __builtin_nontemporal_load(&act_tile[((size_t)(ct + 1) * NM_ACT_SLOTS + k) * 64]);
         }
@@ -1113,7 +1113,7 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
         }
       }
       NM_PH(3)
-      if (ACT && ct + 1 < ntile) {      // second half of the next tile's record
+      if (ACT && c0 + 16 * (ct + 1) < pend) {      // second half of the next tile's record
 #pragma unroll
         for (int k = 5; k < NM_ACT_SLOTS; ++k) nx[k] = __builtin_nontemporal_load(&act_tile[((size_t)(ct + 1) * NM_ACT_SLOTS + k) * 64]);
       }
@@ -1211,6 +1211,11 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
     __builtin_amdgcn_wave_barrier();
 
     // per-particle epilogue: gradients through R X F^T / F + alpha R X and through the invariants
+    // (roll-out: dL/dF of the sim step is already there and the elasticity path adds to it - asked for HERE, a few hundred
+    //  instructions before it is needed: read at the point of use it was a round trip with nothing left to hide it)
+    M3Raw prev_raw;
+    const bool add_prev = fz.add_to_gF && valid;
+    if (add_prev) raw_load(gF + (size_t)9 * p, prev_raw);
     M3 X;
 #pragma unroll
     for (int i = 0; i < 9; ++i) X.m[i] = yb[lane * 9 + i];
@@ -1269,8 +1274,8 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
 #pragma unroll
     for (int i = 0; i < 9; ++i) Fb.m[i] += t.m[i] + FG.m[i] + zbv[12] * cof.m[i];
     if (valid) {
-      if (fz.add_to_gF) {   // roll-out: dL/dF of the sim step is already there, the elasticity path adds to it
-        M3 prev = m3_load(gF + 9 * p);
+      if (add_prev) {
+        const M3 prev = raw_m3(prev_raw);
 #pragma unroll
         for (int i = 0; i < 9; ++i) Fb.m[i] += prev.m[i];
       }

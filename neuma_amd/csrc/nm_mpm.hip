@@ -437,11 +437,14 @@ __device__ __forceinline__ void wg_scatter_f64(const MpmK& K, bool en, int lp, c
       const int i = (base[0] >> 2) + (q >> 2), j = (base[1] >> 2) + ((q >> 1) & 1), k = (base[2] >> 2) + (q & 1);
       const bool ok = i <= (base[0] + 2) >> 2 && j <= (base[1] + 2) >> 2 && k <= (base[2] + 2) >> 2;
       bid[q] = ok ? (i * K.nb + j) * K.nb + k : -1;
-      fl[q] = ok ? flags[bid[q]] : epoch;
     }
+    // (eight UNCONDITIONAL loads - q = 0 is always a block of the stencil and stands in for the ones that are not: a load under
+    //  a lane predicate is a branch region of its own, and the eight stamps came back one round trip after the other)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) fl[q] = flags[bid[q] >= 0 ? bid[q] : bid[0]];
 #pragma unroll
     for (int q = 0; q < 8; ++q)
-      if (fl[q] != epoch) mark_block(bid[q], flags, list, count, epoch);
+      if (bid[q] >= 0 && fl[q] != epoch) mark_block(bid[q], flags, list, count, epoch);
   }
   __syncthreads();
   SC_PH(2)
@@ -728,11 +731,12 @@ __device__ __forceinline__ void wg_scatter(const MpmK& K, bool en, int lp, const
         const int i = (o0 >> 2) + (q >> 2), j = (o1 >> 2) + ((q >> 1) & 1), k = (o2 >> 2) + (q & 1);
         const bool ok = i <= (o0 + 2) >> 2 && j <= (o1 + 2) >> 2 && k <= (o2 + 2) >> 2;
         bid[q] = ok ? (i * K.nb + j) * K.nb + k : -1;
-        fl[q] = ok ? flags[bid[q]] : epoch;
       }
 #pragma unroll
+      for (int q = 0; q < 8; ++q) fl[q] = flags[bid[q] >= 0 ? bid[q] : bid[0]];      // (unconditional: see wg_scatter_f64)
+#pragma unroll
       for (int q = 0; q < 8; ++q)
-        if (fl[q] != epoch) mark_block(bid[q], flags, list, count, epoch);
+        if (bid[q] >= 0 && fl[q] != epoch) mark_block(bid[q], flags, list, count, epoch);
     }
 #pragma unroll 1
     for (int i = 0; i < 3; ++i) {
@@ -1380,7 +1384,10 @@ static MpmK scatter_k(const nm_mpm* h, int n) {
   K.ppw = scatter_ppw(h, n);
   return K;
 }
-static const int kSweepGrid = 512;  // workgroups for the active-block sweeps (grid-stride over the list)
+#ifndef NM_SWEEP_GRID
+#define NM_SWEEP_GRID 512
+#endif
+static const int kSweepGrid = NM_SWEEP_GRID;  // workgroups for the active-block sweeps (grid-stride over the list)
 
 // clear + p2g + grid_op (shared by forward, backward-recompute and forward_extra).
 // save != null: the forward pass also writes a grid cache record.  restore != null: the reverse sweep restores the
