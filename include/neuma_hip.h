@@ -475,6 +475,10 @@ int nm_raster_forward_ex(const nm_raster_cfg* cfg, int32_t k, int32_t m, const f
  * checkpoints) and only their reverse sweep runs in segments.  min_segment: shortest segment (rounded up to a multiple of
  * 16).  Defaults 0 (every planned tile: measured best for forward + backward together) and 256. */
 int nm_raster_set_hinted(int32_t forward_split_length, int32_t min_segment);
+/* Reverse compositing with two pixels per lane (process-wide; read by the following nm_raster_backward calls): pays when
+ * several views' reverse sweeps share the chip, costs latency for a view that has it to itself.  Default 0.  Same gradients.
+ * (Underneath the reference's stateless rasterizer interface, like the two knobs around it: no counterpart there.) */
+int nm_raster_set_reverse_px2(int32_t on);
 /* Tuning of the split compositing (process-wide; read by the following nm_raster_forward calls).  A view with fewer than
  * `busy_tiles` non-empty tiles leaves most of the chip idle; its tiles whose depth-sorted list is longer than a segment
  * (>= `min_segment` entries, ~4096 segments per view at most) are walked segment by segment on separate workgroups:

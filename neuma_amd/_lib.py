@@ -115,6 +115,7 @@ SIGNATURES = {
     "nm_raster_forward_ex": (C.c_int, [C.POINTER(nm_raster_cfg), _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _SZ, _I64, _P, _P, _P,
                                        _P]),
     "nm_raster_set_hinted": (C.c_int, [_I32, _I32]),
+    "nm_raster_set_reverse_px2": (C.c_int, [_I32]),
     "nm_raster_set_split": (C.c_int, [_I32, _I32, _I64]),
     "nm_raster_count_pairs": (C.c_int, [C.POINTER(nm_raster_cfg), _I32, _P, _I64, _P, _P]),
     "nm_raster_bwd_workspace": (_SZ, [_I32]),

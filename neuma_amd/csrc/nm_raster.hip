@@ -1454,18 +1454,24 @@ __global__ void __launch_bounds__(1024) k_split_plan(RK k, int nbx, uint32_t bus
     {
       // thread t owns tiles t, t + 1024, ...: this kernel is ONE workgroup on one CU, and with eight consecutive tiles per
       // thread every load and store instruction of a wave touched 64 different cache lines (32 us; 9 us this way)
+      // (all 3 x NM_PLAN_PER loads UNCONDITIONAL, at a clamped tile index, and issued before the first is used: under
+      //  `if (i < ntile)` each tile's three loads sat in a branch region of their own and the compiler waited for them
+      //  before it issued the next tile's - NM_PLAN_PER round trips in a row on the one CU this launch has)
+      uint32_t hh[NM_PLAN_PER], lo_[NM_PLAN_PER], hi_[NM_PLAN_PER];
 #pragma unroll
       for (int u = 0; u < NM_PLAN_PER; ++u) {
-        const int i = u * 1024 + tid;
-        uint32_t h = 0u; ln[u] = 0u; tt[u] = -1;
-        if (i < ntile) {
-          const int ty = i / k.gx, tx = i - ty * k.gx, tyy = ty + k.ty0;
-          tt[u] = tyy * k.gx + tx;
-          h = hint[tt[u]];
-          const int bin = (tyy / NM_BT) * nbx + tx / NM_BT;
-          const long long lo = off[bin * NM_NS], hi = min((long long)off[(bin + 1) * NM_NS], cap);
-          ln[u] = hi > lo ? (uint32_t)(hi - lo) : 0u;
-        }
+        const int i = u * 1024 + tid, ic = min(i, ntile - 1);
+        const int ty = ic / k.gx, tx = ic - ty * k.gx, tyy = ty + k.ty0;
+        const int t = tyy * k.gx + tx;
+        tt[u] = i < ntile ? t : -1;
+        const int bin = (tyy / NM_BT) * nbx + tx / NM_BT;
+        hh[u] = hint[t]; lo_[u] = off[bin * NM_NS]; hi_[u] = off[(bin + 1) * NM_NS];
+      }
+#pragma unroll
+      for (int u = 0; u < NM_PLAN_PER; ++u) {
+        const long long lo = lo_[u], hi = min((long long)hi_[u], cap);
+        const uint32_t h = tt[u] >= 0 ? hh[u] : 0u;
+        ln[u] = (tt[u] >= 0 && hi > lo) ? (uint32_t)(hi - lo) : 0u;
         ll[u] = h ? min(ln[u], h + h / 4u + 64u) : 0u;
         tot += ll[u]; any += ll[u] ? 1u : 0u;
       }
@@ -2616,6 +2622,12 @@ extern "C" int nm_raster_set_hinted(int32_t forward_split_length, int32_t min_se
   g_hint_seg = (min_segment + 15) & ~15;
   return NM_OK;
 }
+// reverse compositing with two pixels per lane (k_render_bwd2): 0 off, 1 on.  NM_BWD_PX2 in the environment overrides (A/B runs)
+static int g_bwd_px2 = 0;
+extern "C" int nm_raster_set_reverse_px2(int32_t on) {
+  g_bwd_px2 = on != 0;
+  return NM_OK;
+}
 extern "C" int nm_raster_set_split(int32_t busy_tiles, int32_t min_segment, int64_t forward_budget) {
   NM_REQUIRE(busy_tiles >= 0 && min_segment >= 1 && forward_budget >= 0, "busy_tiles >= 0, min_segment >= 1, forward_budget >= 0");
   g_split_busy = busy_tiles;
@@ -2859,11 +2871,12 @@ extern "C" int nm_raster_backward(const nm_raster_cfg* cfg, int32_t K, int32_t m
   float* acc = (float*)workspace;
   NM_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)K * NM_NGS * sizeof(float), s));
   const int ntile = k.gx * (k.ty1 - k.ty0);
-  // NM_BWD_PX2=1: two pixels per lane (k_render_bwd2).  Measured: 4 % less reverse-compositing time when three
-  // views share the chip, 15 % MORE for a view that has it to itself (half the waves per tile: the long tiles' latency
-  // counts there) - off by default, read per call so that the tests can exercise both.
+  // Two pixels per lane (k_render_bwd2): less reverse-compositing work per pixel when several views share the chip (metric
+  // frame, each view's adjoint behind its own forward pass: 186.7 -> 188.9 frames/s), 15 % MORE time for a view that has the
+  // chip to itself (half the waves per tile: the long tiles' latency counts there).  The caller says which situation it is in
+  // (nm_raster_set_reverse_px2; SceneRuntime sets it with its view streams); NM_BWD_PX2 overrides, read per call (tests, A/B).
   const char* px2_env = getenv("NM_BWD_PX2");
-  const bool px2 = px2_env && atoi(px2_env) != 0;
+  const bool px2 = px2_env ? atoi(px2_env) != 0 : g_bwd_px2 != 0;
   if (px2 && dL_dopacity)
     NM_LAUNCH(k_render_bwd2<true>, dim3(ntile + t.items), dim3(128), 0, s, k, t.nbx, ntile, (const uint32_t*)t.off,
               (const unsigned long long*)t.keys, (const uint32_t*)t.vals, (const uint32_t*)t.hdr, (const uint32_t*)t.tile_rec,

@@ -1046,6 +1046,9 @@ class SceneRuntime(object):
             # latency (sf 603 -> 1035 frames/s).  Process-wide knob of the library, set when the situation changes.
             from . import _lib as L
             L.check(L.lib().nm_raster_set_hinted(0x7FFFFFFF if streams else 0, 256), "nm_raster_set_hinted")      # (>= any capacity: the library then skips its second and third compositing pass)
+            # ... and the reverse sweeps of views that share the chip composite two pixels per lane (metric frame 186.7 -> 188.9
+            # frames/s; a lone view would lose 15 %)
+            L.check(L.lib().nm_raster_set_reverse_px2(1 if streams else 0), "nm_raster_set_reverse_px2")
             self._hint_mode = bool(streams)
         return streams
 
