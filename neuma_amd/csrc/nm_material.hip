@@ -71,6 +71,18 @@ __device__ __forceinline__ bool material_prologue_fwd(const GridPrologue& pro) {
 #define NM_W1 (64 * 64)
 #define NM_W2 (9 * 64)
 #define NM_WTOT (NM_W0 + NM_W1 + NM_W2)
+// weight-gradient partials in accumulator order: W1's sixteen 16x16 blocks | W0's four (13 of 16 columns used) | W2's four
+// (9 of 16 rows used); element ((block * 64 + lane) * 4 + reg) = row 4 * (lane >> 4) + reg, column lane & 15 of the block
+#define NM_WACC_W0 (64 * 64)
+#define NM_WACC_W2 (64 * 64 + 16 * 64)
+#define NM_WACC (64 * 64 + 16 * 64 + 16 * 64)
+// accumulator-order index -> index in w0 | w1 | w2 ((out, in) order, back to back), -1 for the padding
+__host__ __device__ inline int wacc_to_plain(int e) {
+  const int reg = e & 3, lane = (e >> 2) & 63, blk = e >> 8, g = lane >> 4, j = lane & 15;
+  if (blk < 16) return NM_W0 + (16 * (blk >> 2) + 4 * g + reg) * 64 + 16 * (blk & 3) + j;            // W1: block (rt, ctp)
+  if (blk < 20) return j < 13 ? (16 * (blk - 16) + 4 * g + reg) * 13 + j : -1;                       // W0: block rt
+  return 4 * g + reg < 9 ? NM_W0 + NM_W1 + (4 * g + reg) * 64 + 16 * (blk - 20) + j : -1;           // W2: block ctp
+}
 
 // Standard normal cdf Phi(x) and pdf phi(x) sharing ONE exponential: Abramowitz-Stegun 7.1.26 writes
 // erf(z) = 1 - poly(t) e^{-z^2}, t = 1/(1 + p z) (|error| <= 1.5e-7, the fp32 rounding level), and with z = |x|/sqrt2
@@ -1287,53 +1299,48 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
   NM_PH_STORE_K(KIND == NM_PLASTICITY ? 1 : 0)
 
   if (!want_w) return;   // (workgroup-uniform)
-  // combine the four waves' weight-gradient accumulators: every wave stores its own copy in plain (out,in) layout to a
-  // private LDS region (the weights and per-wave buffers are dead by now), then the workgroup sums the four copies.
+  // combine the four waves' weight-gradient accumulators: every wave stores its own copy to a private LDS region (the weights
+  // and per-wave buffers are dead by now), then the workgroup sums the four copies.
   // (LDS float atomics would serialise here: ds_add_f32 sustains ~0.3 lanes/clk/CU on gfx950, i.e. ~70k cycles for the
   // 24 576 lane-adds, against ~3k for this.)
+  // The copies - and the per-workgroup partials in global memory - are in ACCUMULATOR order (NM_WACC floats: a lane's four
+  // rows of one 16x16 block side by side, wacc_to_plain), not in (out, in) order: 24 16-byte LDS writes per lane instead of 96
+  // scattered words, 24 16-byte reads and 6 + 6 16-byte global accesses per thread instead of 88 + 22 + 22 words; the one
+  // place that needs (out, in) order is k_wgrad_reduce, once per roll-out.
   // want_w == 2: add to the partial this workgroup wrote in earlier launches (the roll-out sums over substeps and
   // reduces once); the order of additions is fixed, so the result stays deterministic.  All of a thread's old values are
   // requested HERE, in front of the LDS staging: the rolled read-add-write loop this replaces paid one L2 round trip per
   // iteration - 22 in a row at the end of every net, with nothing else left on the SIMD to hide them (round 5: the
   // ~15 k cycles per net that no phase counter covered).
-  constexpr int WPER = (NM_WTOT + 255) / 256;
-  float* dst = wpart + (size_t)blockIdx.x * NM_WTOT;
-  float prev[WPER];
+  constexpr int W4 = NM_WACC / 4, WPER = W4 / 256;
+  static_assert(W4 % 256 == 0, "whole 16-byte pieces per thread");
+  f4* dst = reinterpret_cast<f4*>(wpart + (size_t)blockIdx.x * NM_WACC);
+  f4 prev[WPER];
+  if (want_w == 2) {
 #pragma unroll
-  for (int k = 0; k < WPER; ++k) {
-    const int i = threadIdx.x + 256 * k;
-    prev[k] = (want_w == 2 && i < NM_WTOT) ? dst[i] : 0.f;
+    for (int k = 0; k < WPER; ++k) prev[k] = dst[threadIdx.x + 256 * k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < WPER; ++k) prev[k] = zero;
   }
   NM_SB();
   __syncthreads();
-  static_assert(sizeof(BwdLds) >= 4 * NM_WTOT * sizeof(float), "four weight-gradient copies must fit");
-  float* red = reinterpret_cast<float*>(smem_raw) + wave * NM_WTOT;
+  static_assert(sizeof(BwdLds) >= 4 * NM_WACC * sizeof(float), "four weight-gradient copies must fit");
+  f4* red = reinterpret_cast<f4*>(smem_raw) + wave * W4;
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int row = 16 * rt + 4 * g + r;
-      if (j < 13) red[row * 13 + j] = gW0[rt][r];
-#pragma unroll
-      for (int ctp = 0; ctp < 4; ++ctp) red[NM_W0 + row * 64 + 16 * ctp + j] = gW1[rt][ctp][r];
-    }
+    for (int ctp = 0; ctp < 4; ++ctp) red[(rt * 4 + ctp) * 64 + lane] = gW1[rt][ctp];
+    red[NM_WACC_W0 / 4 + rt * 64 + lane] = gW0[rt];
+    red[NM_WACC_W2 / 4 + rt * 64 + lane] = gW2[rt];
   }
-#pragma unroll
-  for (int ctp = 0; ctp < 4; ++ctp)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int row = 4 * g + r;
-      if (row < 9) red[NM_W0 + NM_W1 + row * 64 + 16 * ctp + j] = gW2[ctp][r];
-    }
   __syncthreads();
-  const float* all = reinterpret_cast<const float*>(smem_raw);
+  const f4* all = reinterpret_cast<const f4*>(smem_raw);
 #pragma unroll
   for (int k = 0; k < WPER; ++k) {
     const int i = threadIdx.x + 256 * k;
-    if (i < NM_WTOT) {
-      const float v = (all[i] + all[NM_WTOT + i]) + (all[2 * NM_WTOT + i] + all[3 * NM_WTOT + i]);
-      dst[i] = prev[k] + v;      // (prev = 0 unless want_w == 2; x + 0 is exact)
-    }
+    const f4 v = (all[i] + all[W4 + i]) + (all[2 * W4 + i] + all[3 * W4 + i]);
+    dst[i] = prev[k] + v;      // (prev = 0 unless want_w == 2; x + 0 is exact)
   }
 }
 
@@ -1359,8 +1366,9 @@ __global__ void __launch_bounds__(256, 1) k_material_bwd_pair(BwdArgs e, BwdArgs
   material_bwd_body<NM_PLASTICITY, ACT>(p, smem_raw);
 }
 
-// sum the per-workgroup partials: a workgroup owns 64 consecutive weights, its four waves each sum a quarter of the
-// partials (coalesced 256 B rows) and combine through LDS — deterministic, ~86 workgroups instead of 22 serial ones
+// sum the per-workgroup partials (accumulator order, NM_WACC floats each): a workgroup owns 64 consecutive elements, its four
+// waves each sum a quarter of the partials (coalesced 256 B rows) and combine through LDS - deterministic - and the result
+// goes to its place in (out, in) order
 __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ wpart, int nparts, float* __restrict__ g0,
                                                       float* __restrict__ g1, float* __restrict__ g2, int accumulate,
                                                       const float* __restrict__ wpart_b, float* __restrict__ gb) {
@@ -1369,23 +1377,24 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
     wpart = wpart_b; g0 = gb; g1 = gb + NM_W0; g2 = gb + NM_W0 + NM_W1;
   }
   const int li = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + li;
+  const int e = blockIdx.x * 64 + li;      // (< NM_WACC: the grid is NM_WACC / 64 workgroups)
+  const int i = wacc_to_plain(e);
   float acc = 0.f;
-  if (i < NM_WTOT) {
+  if (i >= 0) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int b = sl;
     for (; b + 12 < nparts; b += 16) {
-      a0 += wpart[(size_t)b * NM_WTOT + i];
-      a1 += wpart[(size_t)(b + 4) * NM_WTOT + i];
-      a2 += wpart[(size_t)(b + 8) * NM_WTOT + i];
-      a3 += wpart[(size_t)(b + 12) * NM_WTOT + i];
+      a0 += wpart[(size_t)b * NM_WACC + e];
+      a1 += wpart[(size_t)(b + 4) * NM_WACC + e];
+      a2 += wpart[(size_t)(b + 8) * NM_WACC + e];
+      a3 += wpart[(size_t)(b + 12) * NM_WACC + e];
     }
-    for (; b < nparts; b += 4) a0 += wpart[(size_t)b * NM_WTOT + i];
+    for (; b < nparts; b += 4) a0 += wpart[(size_t)b * NM_WACC + e];
     acc = (a0 + a1) + (a2 + a3);
   }
   part[sl][li] = acc;
   __syncthreads();
-  if (sl == 0 && i < NM_WTOT) {
+  if (sl == 0 && i >= 0) {
     acc = (part[0][li] + part[1][li]) + (part[2][li] + part[3][li]);
     float* dst = i < NM_W0 ? g0 + i : (i < NM_W0 + NM_W1 ? g1 + (i - NM_W0) : g2 + (i - NM_W0 - NM_W1));
     *dst = accumulate ? *dst + acc : acc;
@@ -1451,37 +1460,6 @@ int nm_material_bwd_launch(int32_t n, int32_t kind, float alpha, const float* F,
   return NM_OK;
 }
 
-// EXPERIMENT (NEUMA_WARM=1): touch the first round's inputs of a reverse pair launch - what every wave asks for at the very
-// start of each body, 13 MB at once - so that they sit in the memory-side cache when the launch begins.
-struct WarmSet { const float* F; const float* svd; const f4* act; const float* C; };
-__global__ void __launch_bounds__(256) k_warm_first_round(int n, int q, WarmSet a, WarmSet b, float* sink) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int pbeg = min(n, (blockIdx.x * 4 + wave) * q), pend = min(n, pbeg + q);
-  const int cnt = min(64, pend - pbeg);
-  if (cnt <= 0) return;
-  float acc = 0.f;
-  const WarmSet sets[2] = {a, b};
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const WarmSet& w = sets[u];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const int i = lane + 64 * k;
-      if (i < 9 * cnt) { acc += w.F[(size_t)9 * pbeg + i]; if (w.C) acc += w.C[(size_t)9 * pbeg + i]; }
-    }
-    if (w.svd && lane < cnt) {
-#pragma unroll
-      for (int c = 0; c < 21; ++c) acc += w.svd[(size_t)c * n + pbeg + lane];
-    }
-    if (w.act) {
-      const f4* at = w.act + (size_t)(pbeg >> 4) * NM_ACT_SLOTS * 64 + lane;
-#pragma unroll
-      for (int k = 0; k < NM_ACT_SLOTS; ++k) acc += at[k * 64][0];
-    }
-  }
-  if (acc == 1.2345e-30f) sink[0] = acc;      // (never: keeps the loads alive)
-}
-
 // roll-out reverse sweep: elasticity adjoint (dL/dstress gS -> += gF) of one substep, then the plasticity adjoint of the
 // substep before it (dL/dF = that gF -> gFtrial), one launch (k_material_bwd_pair)
 int nm_material_bwd_pair_launch(int32_t n, const float* F_e, const nm_mlp* we, const float* wperm_e, const float* gS, float* gF,
@@ -1500,11 +1478,6 @@ int nm_material_bwd_pair_launch(int32_t n, const float* F_e, const nm_mlp* we, c
   if (rc) return rc;
   BwdArgs e = bwd_args(n, q, 0.f, F_e, we, wperm_e, gS, gF, wpart_e, wmode_e, nullptr, nullptr, 0.f, 1 | (polar ? 2 : 0), svd_in_e, act_e);
   BwdArgs p = bwd_args(n, q, alpha_p, F_p, wp, wperm_p, gF, gFtrial, wpart_p, wmode_p, trial_C, enabled, dt, polar ? 2 : 0, svd_in_p, act_p);
-  static const int warm = getenv("NEUMA_WARM") ? atoi(getenv("NEUMA_WARM")) : 0;
-  if (warm && act_e && act_p) {
-    WarmSet a{F_e, svd_in_e, reinterpret_cast<const f4*>(act_e), nullptr}, b{F_p, svd_in_p, reinterpret_cast<const f4*>(act_p), trial_C};
-    NM_LAUNCH(k_warm_first_round, dim3(grid), dim3(256), 0, s, n, q, a, b, wpart_e);
-  }
   if (act_e && act_p)
     NM_LAUNCH(k_material_bwd_pair<true>, dim3(launch), dim3(256), sizeof(BwdLds), s, e, p, gp);
   else
@@ -1516,7 +1489,7 @@ int nm_material_bwd_pair_launch(int32_t n, const float* F_e, const nm_mlp* we, c
 int nm_material_wgrad_reduce(const float* wpart, int32_t n, float* gw0, float* gw1, float* gw2, int accumulate, void* stream) {
   int grid, q;
   nm_wave_quota(n, grid, q);
-  NM_LAUNCH(k_wgrad_reduce, dim3(nm_div_up(NM_WTOT, 64)), dim3(256), 0, (hipStream_t)stream, wpart, grid, gw0, gw1, gw2,
+  NM_LAUNCH(k_wgrad_reduce, dim3(NM_WACC / 64), dim3(256), 0, (hipStream_t)stream, wpart, grid, gw0, gw1, gw2,
                      accumulate, (const float*)nullptr, (float*)nullptr);
   NM_LAUNCH_CHECK();
   return NM_OK;
@@ -1525,7 +1498,7 @@ int nm_material_wgrad_reduce(const float* wpart, int32_t n, float* gw0, float* g
 int nm_material_wgrad_reduce2(const float* wpart_a, const float* wpart_b, int32_t n, float* gw_a, float* gw_b, void* stream) {
   int grid, q;
   nm_wave_quota(n, grid, q);
-  NM_LAUNCH(k_wgrad_reduce, dim3(nm_div_up(NM_WTOT, 64), 2), dim3(256), 0, (hipStream_t)stream, wpart_a, grid, gw_a, gw_a + NM_W0,
+  NM_LAUNCH(k_wgrad_reduce, dim3(NM_WACC / 64, 2), dim3(256), 0, (hipStream_t)stream, wpart_a, grid, gw_a, gw_a + NM_W0,
             gw_a + NM_W0 + NM_W1, 0, wpart_b, gw_b);
   NM_LAUNCH_CHECK();
   return NM_OK;
@@ -1533,7 +1506,7 @@ int nm_material_wgrad_reduce2(const float* wpart_a, const float* wpart_b, int32_
 
 extern "C" size_t nm_material_bwd_workspace(int32_t n) {
   (void)n;
-  return (size_t)NM_BWD_GRID * NM_WTOT * sizeof(float);
+  return (size_t)NM_BWD_GRID * NM_WACC * sizeof(float);
 }
 
 extern "C" int nm_material_bwd(int32_t n, int32_t kind, float alpha, const float* F, const nm_mlp* w, const float* gout,
