@@ -58,6 +58,15 @@ void nm_mpm_set_fresh_rows(nm_mpm* h, int on) { h->fresh_rows = on; }
 __device__ int g_nm_markslow[4];
 extern "C" int nm_debug_markslow(int* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nm_markslow), 16) == hipSuccess ? 0 : -2; }
 #endif
+// Keep a loaded value where it was loaded: the compiler sinks a load into the only branch that uses its result - behind the
+// `enabled` test, i.e. behind another load's round trip.  An empty asm that "modifies" the register makes the value needed
+// HERE; placed behind ALL of a particle's loads, the pins wait for the whole batch once.
+__device__ __forceinline__ void nm_pin(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void nm_pin(int& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void nm_pin(M3& m) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) nm_pin(m.m[i]);
+}
 __device__ __forceinline__ void mark_block(int b, int* __restrict__ flags, int* __restrict__ list,
                                            int* __restrict__ count, int epoch) {
 #ifdef NM_PHASES
@@ -1081,13 +1090,18 @@ __device__ __forceinline__ bool g2p_bwd_particle(const MpmK& K, int n, int p, co
   q.Ct = m3_zero();
   q.Fbar = m3_zero();
   if (p < n) {
-    const int e = enabled[p];
-    const float xp[3] = {x[3 * p], x[3 * p + 1], x[3 * p + 2]};
-    const float vn[3] = {vnext[3 * p], vnext[3 * p + 1], vnext[3 * p + 2]};
-    const float gxv[3] = {gxn[3 * p], gxn[3 * p + 1], gxn[3 * p + 2]};
-    const float gvv[3] = {gvn[3 * p], gvn[3 * p + 1], gvn[3 * p + 2]};
-    const float bnd = clip[p] * K.dx;
-    const M3 Fp = m3_load(F + 9 * p), gFp = m3_load(gFn + 9 * p), Cn = m3_load(Cnext + 9 * p), gCp = m3_load(gCn + 9 * p);
+    int e = enabled[p];
+    float xp[3] = {x[3 * p], x[3 * p + 1], x[3 * p + 2]};
+    float vn[3] = {vnext[3 * p], vnext[3 * p + 1], vnext[3 * p + 2]};
+    float gxv[3] = {gxn[3 * p], gxn[3 * p + 1], gxn[3 * p + 2]};
+    float gvv[3] = {gvn[3 * p], gvn[3 * p + 1], gvn[3 * p + 2]};
+    float clp = clip[p];
+    M3 Fp = m3_load(F + 9 * p), gFp = m3_load(gFn + 9 * p), Cn = m3_load(Cnext + 9 * p), gCp = m3_load(gCn + 9 * p);
+    // (the comment above was not what the compiler made of it: every load but `enabled` had been sunk into `if (active)`)
+    nm_pin(e); nm_pin(clp); nm_pin(Fp); nm_pin(gFp); nm_pin(Cn); nm_pin(gCp);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { nm_pin(xp[a]); nm_pin(vn[a]); nm_pin(gxv[a]); nm_pin(gvv[a]); }
+    const float bnd = clp * K.dx;
     active = e != 0;
     if (active) {
       make_stencil(K, xp, q.st);
@@ -1137,7 +1151,7 @@ __global__ void __launch_bounds__(NM_SC_T) k_g2p_bwd(MpmK K, int n, const float*
   // (1) per-particle outputs: gF and gx (direct + through weights/dpos, gathering the forward grid velocity)
   if (active) {
 #pragma unroll 1
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 3; ++i) {      // (27 gathers in flight at once cost an occupancy step: 20.7 -> 26.5 us, measured again in round 5)
       float d0 = ((float)i - q.st.f[0]) * K.dx;
       const float w0i = sel3(q.st.w[0], i), dw0i = sel3(q.st.dw[0], i);
 #pragma unroll
@@ -1199,12 +1213,16 @@ __global__ void __launch_bounds__(256, 2) k_p2g_bwd(MpmK K, int n, const float* 
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   // (all of the particle's loads are issued before `enabled` is looked at: one HBM round trip instead of two)
-  const int e_ = enabled[p];
+  int e_ = enabled[p];
   float xp[3] = {x[3 * p], x[3 * p + 1], x[3 * p + 2]};
-  const float vp[3] = {v[3 * p], v[3 * p + 1], v[3 * p + 2]};
+  float vp[3] = {v[3 * p], v[3 * p + 1], v[3 * p + 2]};
   float vl = vol[p];
-  const float rh = rho[p];
+  float rh = rho[p];
   M3 Sp = m3_load(S + 9 * p), Cp = m3_load(C + 9 * p), A;
+  // (... which the compiler undid: every load but `enabled` sat behind the branch below - nm_pin keeps them here)
+  nm_pin(e_); nm_pin(vl); nm_pin(rh); nm_pin(Sp); nm_pin(Cp);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { nm_pin(xp[a]); nm_pin(vp[a]); }
   if (e_ == 0) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) { gvp[3 * p + a] = 0.f; gx[3 * p + a] = nm_finite_or_zero(gx[3 * p + a]); }
