@@ -234,6 +234,23 @@ def _tail_backward(rt, recs, grads, streams, dx_out, outs=None, scale=1.0):
                                  L.ptr(dx_out), L.stream_ptr(dev)), "nm_spmm_csr_sum3")
 
 
+def _status_copy_aside(rt, lib, gptr, cfg, status, ev, gcache):
+    """The grid cache records' status words, copied to pinned memory on a stream of their OWN behind the forward sweep, `ev`
+    recorded there.  On the frame's stream the (strided, 20-word) device-to-host copy was a 20 us hole between the roll-out and
+    the frame's tail (device-side trace, round 5): nothing on that stream waits for it any more."""
+    import ctypes as C
+    from . import _lib as L
+    dev = rt.device
+    side = rt.__dict__.get("_status_stream")
+    if side is None:
+        side = rt._status_stream = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream(dev)
+    side.wait_stream(main)
+    gcache.record_stream(side)
+    L.check(lib.nm_rollout_cache_status(gptr, C.byref(cfg), C.c_void_p(status.data_ptr()), C.c_void_p(side.cuda_stream)), "nm_rollout_cache_status")
+    ev.record(side)
+
+
 class _FrameState(object):
     """What the forward half of a one-node frame keeps for its reverse sweep."""
     __slots__ = ("recs", "grads", "streams", "keep", "states", "eff", "gcache", "svdc", "actc", "status", "ev", "cache_blocks",
@@ -318,8 +335,7 @@ def _frame_forward(rt, weight, jobs, streams, eager=False):
             fs.status, fs.ev = pool.pop()
         else:
             fs.status, fs.ev = torch.empty(S, dtype=torch.int32, pin_memory=True), torch.cuda.Event()
-        L.check(lib.nm_rollout_cache_status(gptr, C.byref(cfg), C.c_void_p(fs.status.data_ptr()), stream), "nm_rollout_cache_status")
-        fs.ev.record()
+        _status_copy_aside(rt, lib, gptr, cfg, fs.status, fs.ev, gcache)
     if sim._cache_blocks is None:      # first roll-out: size the grid cache from what the scene touches (one host sync)
         blocks, _ = rt.model.grid_stats()
         sim._cache_blocks = int(1.5 * blocks) + 64
@@ -490,8 +506,7 @@ def _epoch_forward(rt, gt_frames, weights, views=None, frame_steps=None, start=N
         status = ev = None
         if gcache is not None and R._CACHE_STATUS:
             status, ev = torch.empty(S, dtype=torch.int32, pin_memory=True), torch.cuda.Event()
-            L.check(lib.nm_rollout_cache_status(gptr, C.byref(cfg), C.c_void_p(status.data_ptr()), stream), "nm_rollout_cache_status")
-            ev.record()
+            _status_copy_aside(rt, lib, gptr, cfg, status, ev, gcache)
         fr = {"gcache": gcache, "svdc": svdc, "actc": actc, "status": status, "ev": ev, "cache_blocks": cache_blocks if gcache is not None else 0,
               "tail": None}
         es.frames.append(fr)
