@@ -1417,8 +1417,16 @@ __device__ __forceinline__ void render_whole(CompLds& L, const RK& k, int nbx, i
 // The render's status words for the host, as three 64-bit values behind one another (one 24-byte copy instead of three
 // 4-byte ones - each was a blit kernel of its own): pairs binned | overflow flag (NM_RASTER_DEBUG: high half = the largest cell) |
 // work items the plan asked for.  Written by the last thread that knows them all.
-__device__ __forceinline__ void plan_status(uint32_t* __restrict__ hdr, int dbg) {
+// host_status (optional): the caller's pinned words as the device sees them - written from here, so that no device-to-host
+// copy (a blit of its own, ~5 us plus its dependency bubbles) sits in the view's stream between the compositing and the loss
+__device__ __forceinline__ void plan_status(uint32_t* __restrict__ hdr, int dbg, unsigned long long* __restrict__ host_status = nullptr,
+                                            int host_words = 0) {
   hdr[16] = hdr[2]; hdr[17] = 0u; hdr[18] = hdr[3]; hdr[19] = dbg ? hdr[6] : 0u; hdr[20] = hdr[12]; hdr[21] = 0u;
+  if (host_status) {
+    host_status[0] = (unsigned long long)hdr[2];
+    host_status[1] = (unsigned long long)hdr[3] | ((unsigned long long)(dbg ? hdr[6] : 0u) << 32);
+    if (host_words > 2) host_status[2] = (unsigned long long)hdr[12];
+  }
 }
 __global__ void __launch_bounds__(1024) k_split_plan(RK k, int nbx, uint32_t busy_limit, uint32_t min_seg, unsigned long long fwd_max,
                                                      const uint32_t* __restrict__ off, long long cap,
@@ -1426,7 +1434,8 @@ __global__ void __launch_bounds__(1024) k_split_plan(RK k, int nbx, uint32_t bus
                                                      uint32_t* __restrict__ tile_ns, uint32_t* __restrict__ tile_cnt,
                                                      uint32_t* __restrict__ tile_mode, uint2* __restrict__ work,
                                                      uint32_t* __restrict__ seg_pos, const uint32_t* __restrict__ hint,
-                                                     uint32_t fwd_len, uint32_t hint_seg, int dbg) {
+                                                     uint32_t fwd_len, uint32_t hint_seg, int dbg,
+                                                     unsigned long long* __restrict__ host_status, int host_words) {
   __shared__ unsigned long long s_total, s_lists;
   __shared__ uint32_t s_busy, s_base, s_used, s_scan[1024];
   const int tid = threadIdx.x, rows = k.ty1 - k.ty0, ntile = k.gx * rows;
@@ -1524,7 +1533,7 @@ __global__ void __launch_bounds__(1024) k_split_plan(RK k, int nbx, uint32_t bus
       }
       __syncthreads();
       if (tid == 0) { hdr[8] = s_used; hdr[9] = seg; hdr[10] = 1u; hdr[11] = 1u; hdr[12] = s_base; }
-      if (tid == 0) { const unsigned long long lt = s_lists; hdr[14] = (uint32_t)lt; hdr[15] = (uint32_t)(lt >> 32); plan_status(hdr, dbg); }
+      if (tid == 0) { const unsigned long long lt = s_lists; hdr[14] = (uint32_t)lt; hdr[15] = (uint32_t)(lt >> 32); plan_status(hdr, dbg, host_status, host_words); }
       return;
     }
     // nothing known yet (the first render with this camera, or nothing in view): every tile is walked whole and leaves its
@@ -1538,7 +1547,7 @@ __global__ void __launch_bounds__(1024) k_split_plan(RK k, int nbx, uint32_t bus
     if (tid == 0) {
       const unsigned long long lt = s_lists;
       hdr[8] = 0u; hdr[9] = (hint_seg + 15u) & ~15u; hdr[10] = 1u; hdr[11] = 1u; hdr[12] = 0u; hdr[14] = (uint32_t)lt; hdr[15] = (uint32_t)(lt >> 32);
-      plan_status(hdr, dbg);
+      plan_status(hdr, dbg, host_status, host_words);
     }
     return;
   }
@@ -1565,7 +1574,7 @@ __global__ void __launch_bounds__(1024) k_split_plan(RK k, int nbx, uint32_t bus
       const int t = (i / k.gx + k.ty0) * k.gx + i % k.gx;
       tile_rec[t] = 0xFFFFFFFFu; tile_ns[t] = 0u; tile_cnt[t] = 0u; tile_mode[t] = 0u;
     }
-    if (tid == 0) { hdr[8] = 0u; hdr[9] = seg; hdr[10] = 0u; hdr[14] = (uint32_t)s_total; hdr[15] = (uint32_t)(s_total >> 32); plan_status(hdr, dbg); }
+    if (tid == 0) { hdr[8] = 0u; hdr[9] = seg; hdr[10] = 0u; hdr[14] = (uint32_t)s_total; hdr[15] = (uint32_t)(s_total >> 32); plan_status(hdr, dbg, host_status, host_words); }
     return;
   }
   for (int i0 = 0; i0 < ntile; i0 += 1024) {     // segments per tile, exclusive prefix in tile order
@@ -1601,7 +1610,7 @@ __global__ void __launch_bounds__(1024) k_split_plan(RK k, int nbx, uint32_t bus
   }
   if (tid == 0) {
     hdr[8] = s_used; hdr[9] = seg; hdr[10] = s_total <= fwd_max ? 1u : 0u; hdr[12] = s_base; hdr[14] = (uint32_t)s_total; hdr[15] = (uint32_t)(s_total >> 32);
-    plan_status(hdr, dbg);
+    plan_status(hdr, dbg, host_status, host_words);
   }
 }
 
@@ -2752,11 +2761,19 @@ static int raster_forward_impl(const nm_raster_cfg* cfg, int32_t K, int32_t m, c
     NM_LAUNCH_CHECK();
   }
   }
+  // the status words go straight to the caller's pinned memory if the device can address it (hipHostMalloc'ed memory can;
+  // anything else gets the copy at the end)
+  unsigned long long* status_dev = nullptr;
+  if (status_host) {
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, status_host, 0) == hipSuccess && dp) status_dev = (unsigned long long*)dp;
+    else (void)hipGetLastError();
+  }
   NM_LAUNCH(k_split_plan, dim3(1), dim3(1024), 0, s, k, t.nbx, (uint32_t)g_split_busy, (uint32_t)g_split_minseg,
             (unsigned long long)g_split_fwd,
             (const uint32_t*)t.off, (long long)cap_pairs, t.hdr, t.tile_rec,
             t.tile_ns, t.tile_cnt, t.tile_mode, t.work, t.seg_pos, (const uint32_t*)tile_walk, (uint32_t)g_hint_fwd, (uint32_t)g_hint_seg,
-            getenv("NM_RASTER_DEBUG") ? 1 : 0);
+            getenv("NM_RASTER_DEBUG") ? 1 : 0, status_dev, status_words < 3 ? status_words : 3);
   NM_LAUNCH_CHECK();
   if (tile_walk) {
     NM_LAUNCH(k_hint_fill, dim3(nm_div_up(k.gx * (k.ty1 - k.ty0), 4)), dim3(256), 0, s, k, t.nbx, (const uint32_t*)t.off,
@@ -2793,7 +2810,7 @@ static int raster_forward_impl(const nm_raster_cfg* cfg, int32_t K, int32_t m, c
             (const uint32_t*)t.seg_last, t.seg_pos, (const GRec*)t.recs, t.final_T, t.n_contrib, out_color, tile_walk);
   NM_LAUNCH_CHECK();
   }
-  if (status_host)      // pairs | overflow | items wanted (plan_status), one copy
+  if (status_host && !status_dev)      // pairs | overflow | items wanted (plan_status), one copy
     NM_HIP_CHECK(hipMemcpyAsync(status_host, t.hdr + 16, sizeof(int64_t) * (size_t)(status_words < 3 ? status_words : 3), hipMemcpyDeviceToHost, s));
   return NM_OK;
 }
