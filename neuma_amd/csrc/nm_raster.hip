@@ -2764,7 +2764,8 @@ static int raster_forward_impl(const nm_raster_cfg* cfg, int32_t K, int32_t m, c
   // the status words go straight to the caller's pinned memory if the device can address it (hipHostMalloc'ed memory can;
   // anything else gets the copy at the end)
   unsigned long long* status_dev = nullptr;
-  if (status_host) {
+  static const bool status_direct = !(getenv("NM_RASTER_STATUS_DIRECT") && atoi(getenv("NM_RASTER_STATUS_DIRECT")) == 0);
+  if (status_host && status_direct) {
     void* dp = nullptr;
     if (hipHostGetDevicePointer(&dp, status_host, 0) == hipSuccess && dp) status_dev = (unsigned long long*)dp;
     else (void)hipGetLastError();

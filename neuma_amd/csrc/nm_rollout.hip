@@ -90,9 +90,24 @@ static inline float* svd_rec(const nm_rollout_cfg* cfg, int n, int t, int net) {
   return (float*)cfg->svd_cache + ((size_t)t * 2 + net) * 21 * (size_t)n;
 }
 
+// the S record headers, one word each at the records' stride, written by one wave straight into the caller's pinned words
+__global__ void k_cache_status_out(const char* __restrict__ gridcache, size_t stride, int substeps, int32_t* __restrict__ host_words) {
+  for (int t = threadIdx.x; t < substeps; t += blockDim.x) host_words[t] = *reinterpret_cast<const int32_t*>(gridcache + (size_t)t * stride);
+}
 extern "C" int nm_rollout_cache_status(const void* gridcache, const nm_rollout_cfg* cfg, int32_t* status_host, void* stream) {
   NM_REQUIRE(gridcache && cfg && status_host, "null pointer");
   NM_REQUIRE(cfg->substeps >= 1 && cfg->grid_cache_blocks >= 1, "no grid cache configured");
+  // pinned memory the device can address (hipHostMalloc'ed: torch's pin_memory) is written directly - a strided device-to-host
+  // copy is a blit of its own and a 20 us hole in the stream; anything else gets the copy
+  void* dp = nullptr;
+  static const bool direct = !(getenv("NEUMA_STATUS_DIRECT") && atoi(getenv("NEUMA_STATUS_DIRECT")) == 0);
+  if (direct && hipHostGetDevicePointer(&dp, status_host, 0) == hipSuccess && dp) {
+    NM_LAUNCH(k_cache_status_out, dim3(1), dim3(64), 0, (hipStream_t)stream, (const char*)gridcache,
+              nm_mpm_gridcache_bytes(cfg->grid_cache_blocks), (int)cfg->substeps, (int32_t*)dp);
+    NM_LAUNCH_CHECK();
+    return NM_OK;
+  }
+  (void)hipGetLastError();
   NM_HIP_CHECK(hipMemcpy2DAsync(status_host, sizeof(int32_t), gridcache, nm_mpm_gridcache_bytes(cfg->grid_cache_blocks), sizeof(int32_t),
                                 (size_t)cfg->substeps, hipMemcpyDeviceToHost, (hipStream_t)stream));
   return NM_OK;

@@ -235,20 +235,15 @@ def _tail_backward(rt, recs, grads, streams, dx_out, outs=None, scale=1.0):
 
 
 def _status_copy_aside(rt, lib, gptr, cfg, status, ev, gcache):
-    """The grid cache records' status words, copied to pinned memory on a stream of their OWN behind the forward sweep, `ev`
-    recorded there.  On the frame's stream the (strided, 20-word) device-to-host copy was a 20 us hole between the roll-out and
-    the frame's tail (device-side trace, round 5): nothing on that stream waits for it any more."""
+    """The grid cache records' status words on their way to pinned memory behind the forward sweep, `ev` recorded behind them.
+    The library writes them from a one-wave kernel straight into the pinned words (nm_rollout_cache_status): the strided
+    device-to-host copy it replaces was a 20 us hole on the frame's stream between the roll-out and the frame's tail.
+    (Round 5 also tried the copy on a stream of its own: neutral for the single frame, -5 % for the epoch - a fifth stream
+    shares a hardware queue with one of the four the epoch already uses.)"""
     import ctypes as C
     from . import _lib as L
-    dev = rt.device
-    side = rt.__dict__.get("_status_stream")
-    if side is None:
-        side = rt._status_stream = torch.cuda.Stream(device=dev)
-    main = torch.cuda.current_stream(dev)
-    side.wait_stream(main)
-    gcache.record_stream(side)
-    L.check(lib.nm_rollout_cache_status(gptr, C.byref(cfg), C.c_void_p(status.data_ptr()), C.c_void_p(side.cuda_stream)), "nm_rollout_cache_status")
-    ev.record(side)
+    L.check(lib.nm_rollout_cache_status(gptr, C.byref(cfg), C.c_void_p(status.data_ptr()), L.stream_ptr(rt.device)), "nm_rollout_cache_status")
+    ev.record()
 
 
 class _FrameState(object):
