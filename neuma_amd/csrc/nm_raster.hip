@@ -367,8 +367,11 @@ __global__ void __launch_bounds__(256) k_preprocess(RK k, int K, const float* __
                                                     const float* __restrict__ cov3D, int* __restrict__ radii, float2* __restrict__ xy,
                                                     float* __restrict__ depth, float4* __restrict__ conop, float* __restrict__ rgb,
                                                     uint32_t* __restrict__ clamped, int* __restrict__ grad_, uint2* __restrict__ zrange,
-                                                    GRec* __restrict__ recs, uint32_t* __restrict__ hdr) {
+                                                    GRec* __restrict__ recs, uint32_t* __restrict__ hdr,
+                                                    uint32_t* __restrict__ zero_words, int n_zero) {
   if (blockIdx.x == 0 && threadIdx.x < 64) hdr[threadIdx.x] = 0u;      // the view's header words (counters, flags): no memset launch for them
+  // ... nor for the slab counters of the binning that follows (64 KB: a fill launch of its own was the first thing on a view's stream)
+  for (int z = blockIdx.x * blockDim.x + threadIdx.x; z < n_zero; z += gridDim.x * blockDim.x) zero_words[z] = 0u;
   __shared__ uint32_t s_lo[4], s_hi[4];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   // depth range of the visible Gaussians (positive floats order like their bit patterns), reduced per workgroup; the
@@ -2697,11 +2700,11 @@ static int raster_forward_impl(const nm_raster_cfg* cfg, int32_t K, int32_t m, c
   const size_t b2_lds = ((size_t)nbin * 9 + 1) * sizeof(uint32_t);
   const bool chunks = !binning_cells && nbin <= NM_B2_MAXBIN;       // (binning by depth-ordered chunks: see k_bin_count2)
   if (chunks) {
-    NM_HIP_CHECK(hipMemsetAsync(t.slab_blk, 0, (2 * NM_GS * NM_GSUB + 64) * sizeof(uint32_t), s));
+    if (K == 0) NM_HIP_CHECK(hipMemsetAsync(t.slab_blk, 0, (2 * NM_GS * NM_GSUB + 64) * sizeof(uint32_t), s));      // (otherwise k_preprocess zeroes them)
     uint32_t* hdr2 = t.slab_blk + 2 * NM_GS * NM_GSUB;
     if (K > 0) {
       NM_LAUNCH(k_preprocess, dim3(nrange), dim3(256), 0, s, k, K, means3D, shs, colors_precomp, opacities, cov3D, radii,
-                t.xy, t.depth, t.conop, t.rgb, t.clamped, t.rad, t.zrange, t.recs, t.hdr);
+                t.xy, t.depth, t.conop, t.rgb, t.clamped, t.rad, t.zrange, t.recs, t.hdr, t.slab_blk, 2 * NM_GS * NM_GSUB + 64);
       NM_LAUNCH_CHECK();
       NM_LAUNCH(k_slab_hist, dim3(nrange), dim3(256), 0, s, k, K, (const int*)t.rad, (const float2*)t.xy, (const float*)t.depth,
                 (const uint2*)t.zrange, nrange, t.slab_blk);
@@ -2740,7 +2743,7 @@ static int raster_forward_impl(const nm_raster_cfg* cfg, int32_t K, int32_t m, c
   NM_HIP_CHECK(hipMemsetAsync(t.pad, 0, (size_t)t.ncell * NM_PAD * sizeof(uint32_t), s));
   if (K > 0) {
     NM_LAUNCH(k_preprocess, dim3(nrange), dim3(256), 0, s, k, K, means3D, shs, colors_precomp, opacities, cov3D, radii,
-              t.xy, t.depth, t.conop, t.rgb, t.clamped, t.rad, t.zrange, t.recs, t.hdr);
+              t.xy, t.depth, t.conop, t.rgb, t.clamped, t.rad, t.zrange, t.recs, t.hdr, (uint32_t*)nullptr, 0);
     NM_LAUNCH_CHECK();
     NM_LAUNCH(k_bin_count, dim3(nrange), dim3(256), 0, s, k, K, t.nbx, (const int*)t.rad, t.xy, t.depth, t.conop, t.zrange, nrange,
               t.pad, t.log, t.hdr, (long long)cap_pairs);

@@ -1,5 +1,8 @@
+"""How many pixels of the ground-truth renders differ between the caller's Gaussian order and the runtime's spatial order
+(rasterizer cut-off events: single pixels, one run in a few).   python tools/exp_order_pixels.py"""
 import sys, os
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch
 from neuma_amd import synth
 from neuma_amd.harness import SceneRuntime
