@@ -45,7 +45,7 @@ class nm_lora_layer(C.Structure):
 class nm_rollout_cfg(C.Structure):
     _fields_ = [("substeps", C.c_int32), ("plasticity_alpha", C.c_float), ("grid_cache_blocks", C.c_int32),
                 ("cache_verified", C.c_int32), ("svd_adjoint", C.c_int32), ("svd_cache", C.c_void_p), ("act_cache", C.c_void_p),
-                ("weights_prepared", C.c_int32)]
+                ("weights_prepared", C.c_int32), ("last_gF_zero", C.c_int32)]
 
 
 COMM_ALL_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)

@@ -215,6 +215,8 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
   const int polar = cfg->svd_adjoint == NM_SVD_ADJOINT_POLAR ? 1 : 0;
   const float dt = nm_mpm_get_dt(h);
   bool restored = false;   // the grid of the substep about to be visited was restored by the previous launch's prologue
+  // (with one substep there is no pair launch that could write the plasticity partials in its place)
+  const bool skip_last = cfg->last_gF_zero != 0 && cfg->substeps >= 2;
   for (int t = cfg->substeps - 1; t >= 0; --t) {
     nm_particles cur = rec(states_m, n, t), nxt = rec(states_m, n, t + 1);
     float* gout = (t == 0) ? gstate_first : ((gin == w.ga) ? w.gb : w.ga);
@@ -222,9 +224,15 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
     if (t == cfg->substeps - 1) {
       // plasticity backward on the trial F of the last substep (recomputed in-kernel from the checkpoints):
       // dL/dF_{t+1} -> dL/dFtrial.  For every earlier substep it rides in the pair launch at the end of this loop body.
-      rc = nm_material_bwd_launch(n, NM_PLASTICITY, cfg->plasticity_alpha, cur.F, wp, w.perm_p, gin + 15 * N, w.gFtr, w.part_p, wmode,
-                                  nxt.C, st->enabled, dt, polar ? 2 : 0, nullptr, stream, svd_rec(cfg, n, t, 1), act_rec(cfg, n, t, 1));
-      if (rc) return rc;
+      if (skip_last) {
+        // dL/dF of the last record is zero by the caller's word (a frame whose loss sees positions only): the adjoint of the
+        // last plasticity step is zero too, its weight gradients as well - a 46 us launch that computed zeros every frame
+        NM_HIP_CHECK(hipMemsetAsync(w.gFtr, 0, 9 * N * sizeof(float), s));
+      } else {
+        rc = nm_material_bwd_launch(n, NM_PLASTICITY, cfg->plasticity_alpha, cur.F, wp, w.perm_p, gin + 15 * N, w.gFtr, w.part_p, wmode,
+                                    nxt.C, st->enabled, dt, polar ? 2 : 0, nullptr, stream, svd_rec(cfg, n, t, 1), act_rec(cfg, n, t, 1));
+        if (rc) return rc;
+      }
     }
     // sim backward (stress of this step was checkpointed by the forward pass).  Verified sweep: from the second substep
     // on the grid has been restored by the prologue of the preceding constitutive launch (GridPrologue mode 2; the block
@@ -253,8 +261,10 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
         if (rc) return rc;
         restored = true;
       }
+      // (the plasticity partials: added to - written, if the skipped launch of the last substep has not done so)
       rc = nm_material_bwd_pair_launch(n, cur.F, we, w.perm_e, w.gS, gc.F, w.part_e, wmode, cfg->plasticity_alpha, prev.F, wp,
-                                       w.perm_p, w.gFtr, w.part_p, 2, cur.C, st->enabled, dt, polar, verified ? &pro : nullptr, stream,
+                                       w.perm_p, w.gFtr, w.part_p, (skip_last && t == cfg->substeps - 1) ? 1 : 2, cur.C, st->enabled, dt,
+                                       polar, verified ? &pro : nullptr, stream,
                                        svd_rec(cfg, n, t, 0), svd_rec(cfg, n, t - 1, 1), act_rec(cfg, n, t, 0), act_rec(cfg, n, t - 1, 1));
       if (rc) return rc;
     }

@@ -234,6 +234,11 @@ def _tail_backward(rt, recs, grads, streams, dx_out, outs=None, scale=1.0):
                                  L.ptr(dx_out), L.stream_ptr(dev)), "nm_spmm_csr_sum3")
 
 
+# nm_rollout_cfg.last_gF_zero of the frame / epoch drivers: the reverse sweep leaves out the last substep's plasticity adjoint (all
+# zeros when only dL/dx flows into the last record).  NEUMA_LAST_GF_ZERO=0: launch it all the same (A/B, tests)
+_LAST_GF_ZERO = 0 if os.environ.get("NEUMA_LAST_GF_ZERO", "1") == "0" else 1
+
+
 def _status_copy_aside(rt, lib, gptr, cfg, status, ev, gcache):
     """The grid cache records' status words on their way to pinned memory behind the forward sweep, `ev` recorded behind them.
     The library writes them from a one-wave kernel straight into the pinned words (nm_rollout_cache_status): the strided
@@ -380,7 +385,8 @@ def _frame_backward(rt, fs, g=None):
     svdc, actc = fs.svdc, fs.actc
     cfg = L.nm_rollout_cfg(S, float(sim.plasticity.alpha), fs.cache_blocks, verified, fs.adj,
                            svdc.t.data_ptr() if svdc is not None else None, actc.t.data_ptr() if actc is not None else None,
-                           1 if rt.__dict__.get("_ws_token") == fs.ws_token and ws.data_ptr() == fs.ws_ptr else 0)
+                           1 if rt.__dict__.get("_ws_token") == fs.ws_token and ws.data_ptr() == fs.ws_ptr else 0,
+                           _LAST_GF_ZERO)      # (glast holds dL/dx and zeros - the loss sees the last record's positions only)
     base = fs.eff.data_ptr()
     w0, w1 = R._WSZ[0], R._WSZ[0] + R._WSZ[1]
     mle = L.nm_mlp(base, base + 4 * w0, base + 4 * w1)
@@ -604,7 +610,8 @@ def _epoch_backward(rt, es):
                 verified = int(min(fr["status"].tolist()) >= 0)
         svdc, actc = fr["svdc"], fr["actc"]
         cfg = L.nm_rollout_cfg(S, float(sim.plasticity.alpha), fr["cache_blocks"], verified, es.adj,
-                               svdc.t.data_ptr() if svdc is not None else None, actc.t.data_ptr() if actc is not None else None, 0)
+                               svdc.t.data_ptr() if svdc is not None else None, actc.t.data_ptr() if actc is not None else None, 0,
+                               _LAST_GF_ZERO if f == nf - 1 else 0)     # (the epoch's last frame: nothing flows into its last record but dL/dx)
         gbase = gw.data_ptr()
         L.check(lib.nm_rollout_backward(rt.model.handle(), n, C.byref(cfg), C.byref(st), C.byref(mle), C.byref(mlp),
                                         es.states.data_ptr() + f * S * rec_bytes,

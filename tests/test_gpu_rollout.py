@@ -500,3 +500,26 @@ def test_disabled_particles_get_the_reference_rows_in_the_fused_and_the_per_oper
     for a, b in zip(res[True][1], res[False][1]):
         assert rel_max(a, b) < 2e-5      # measured 6.7e-06
     rt.statics.enabled.fill_(1)
+
+
+def test_skipping_the_zero_plasticity_adjoint_of_the_last_substep_changes_nothing(monkeypatch):
+    """nm_rollout_cfg.last_gF_zero (round 5): the frame driver promises dL/dF of the last record is zero - the loss sees positions
+    only, as the reference's (tune/utils.py:353-373) - and the reverse sweep leaves out the last substep's plasticity adjoint, whose
+    output and weight gradients are zeros.  Same loss, same twelve LoRA gradients as with the launch (atomics order aside)."""
+    from neuma_amd import synth, harness
+    from neuma_amd.harness import SceneRuntime
+    res = {}
+    for flag in (1, 0):
+        monkeypatch.setattr(harness, "_LAST_GF_ZERO", flag)
+        rt = SceneRuntime(synth.make_scene("tiny", override=dict(S=4, V=2)), dev(), fused=True)
+        rt.set_start_state("deformed")
+        rt.make_ground_truth()
+        with torch.no_grad():
+            for p in rt.parameters():
+                if p.shape[0] in (64, 9):
+                    p.mul_(-4.0)
+        r = rt.frame()
+        res[flag] = (float(r.loss), [p.grad.clone() for p in rt.parameters()])
+    assert abs(res[1][0] - res[0][0]) <= 2e-5 * abs(res[0][0])
+    for a, b in zip(res[1][1], res[0][1]):
+        assert float(b.abs().max()) > 0 and rel_max(a, b) < 3e-6
