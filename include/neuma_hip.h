@@ -259,11 +259,12 @@ typedef struct nm_rollout_cfg {
   int32_t weights_prepared;  /* nm_rollout_backward only: the workspace is the one the forward call of this node used and
                               * nothing has touched it since, so both nets' weights still sit there in operand order and the
                               * reverse sweep skips that launch.  0 (and every caller that does not know) = prepare them. */
-  int32_t last_gF_zero;      /* nm_rollout_backward only (not the sharded form): the caller promises that dL/dF of the last record
+  int32_t last_gF_zero;      /* (not the sharded forms) backward: the caller promises that dL/dF of the last record
                               * (gstate_last + 15 n) is zero everywhere - a loss that sees the final positions only, as the
                               * reference's does (the covariance push-forward is not differentiated, tune/utils.py:353-373).  The
                               * last substep's plasticity adjoint then has nothing to propagate (zero dL/dF, zero weight
-                              * gradients) and is not launched.  0 = make no assumption. */
+                              * gradients) and is not launched.  Given to nm_rollout_forward as well, the last plasticity step
+                              * leaves no SVD / activation records (nobody would read them).  0 = make no assumption. */
 } nm_rollout_cfg;
 #define NM_SVD_ADJOINT_REFERENCE 0
 #define NM_SVD_ADJOINT_POLAR 1

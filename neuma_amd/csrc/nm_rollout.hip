@@ -179,8 +179,11 @@ extern "C" int nm_rollout_forward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cf
       rc = nm_material_fwd_pair_launch(n, cfg->plasticity_alpha, w.perm_p, w.perm_e, nxt.F, nxt.stress, &pro, &g2p, stream,
                                        svd_rec(cfg, n, t, 1), svd_rec(cfg, n, t + 1, 0), act_rec(cfg, n, t, 1), act_rec(cfg, n, t + 1, 0));
     } else {
+      // (last_gF_zero: the reverse sweep will not visit the last substep's plasticity adjoint - nobody reads its SVD / activation
+      //  records, 74 MB at the metric size; the pair launches' records are untouched by this)
+      const bool unread = cfg->last_gF_zero != 0 && cfg->substeps >= 2 && t == cfg->substeps - 1;
       rc = nm_material_fwd_launch(n, NM_PLASTICITY, cfg->plasticity_alpha, nullptr, wp, w.perm_p, nxt.F, nullptr, &g2p, stream,
-                                  svd_rec(cfg, n, t, 1), act_rec(cfg, n, t, 1));  // finetune.py:364
+                                  unread ? nullptr : svd_rec(cfg, n, t, 1), unread ? nullptr : act_rec(cfg, n, t, 1));  // finetune.py:364
     }
     if (rc) return rc;
   }

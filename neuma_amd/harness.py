@@ -317,7 +317,8 @@ def _frame_forward(rt, weight, jobs, streams, eager=False):
     actc = R.lease_cache(act_bytes, dev, force=R._ACT_CACHE == '1') if R._ACT_CACHE != '0' else None
     adj = L.SVD_ADJOINT[sim.svd_adjoint]
     cfg = L.nm_rollout_cfg(S, float(sim.plasticity.alpha), cache_blocks if gcache is not None else 0, 0, adj,
-                           svdc.t.data_ptr() if svdc is not None else None, actc.t.data_ptr() if actc is not None else None)
+                           svdc.t.data_ptr() if svdc is not None else None, actc.t.data_ptr() if actc is not None else None, 0,
+                           _LAST_GF_ZERO)      # (the reverse sweep will say the same: see _frame_backward)
     w0, w1 = R._WSZ[0], R._WSZ[0] + R._WSZ[1]
     mle = L.nm_mlp(base, base + 4 * w0, base + 4 * w1)
     pb = base + 4 * nw
@@ -499,7 +500,8 @@ def _epoch_forward(rt, gt_frames, weights, views=None, frame_steps=None, start=N
         cached += actc is not None
         recomputed += actc is None
         cfg = L.nm_rollout_cfg(S, float(sim.plasticity.alpha), cache_blocks if gcache is not None else 0, 0, adj,
-                               svdc.t.data_ptr() if svdc is not None else None, actc.t.data_ptr() if actc is not None else None)
+                               svdc.t.data_ptr() if svdc is not None else None, actc.t.data_ptr() if actc is not None else None, 0,
+                               _LAST_GF_ZERO if f == nf - 1 else 0)      # (as the reverse sweep of the last frame will: _epoch_backward)
         sptr = states.data_ptr() + f * S * rec_bytes
         gptr = gcache.data_ptr() if gcache is not None else None
         L.check(lib.nm_rollout_forward(rt.model.handle(), n, C.byref(cfg), C.byref(st), C.byref(mle), C.byref(mlp), sptr, gptr,
