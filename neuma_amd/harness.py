@@ -239,7 +239,7 @@ def _tail_backward(rt, recs, grads, streams, dx_out, outs=None, scale=1.0):
 _LAST_GF_ZERO = 0 if os.environ.get("NEUMA_LAST_GF_ZERO", "1") == "0" else 1
 
 
-def _status_copy_aside(rt, lib, gptr, cfg, status, ev, gcache):
+def _status_words_out(rt, lib, gptr, cfg, status, ev, gcache):
     """The grid cache records' status words on their way to pinned memory behind the forward sweep, `ev` recorded behind them.
     The library writes them from a one-wave kernel straight into the pinned words (nm_rollout_cache_status): the strided
     device-to-host copy it replaces was a 20 us hole on the frame's stream between the roll-out and the frame's tail.
@@ -336,7 +336,7 @@ def _frame_forward(rt, weight, jobs, streams, eager=False):
             fs.status, fs.ev = pool.pop()
         else:
             fs.status, fs.ev = torch.empty(S, dtype=torch.int32, pin_memory=True), torch.cuda.Event()
-        _status_copy_aside(rt, lib, gptr, cfg, fs.status, fs.ev, gcache)
+        _status_words_out(rt, lib, gptr, cfg, fs.status, fs.ev, gcache)
     if sim._cache_blocks is None:      # first roll-out: size the grid cache from what the scene touches (one host sync)
         blocks, _ = rt.model.grid_stats()
         sim._cache_blocks = int(1.5 * blocks) + 64
@@ -509,7 +509,7 @@ def _epoch_forward(rt, gt_frames, weights, views=None, frame_steps=None, start=N
         status = ev = None
         if gcache is not None and R._CACHE_STATUS:
             status, ev = torch.empty(S, dtype=torch.int32, pin_memory=True), torch.cuda.Event()
-            _status_copy_aside(rt, lib, gptr, cfg, status, ev, gcache)
+            _status_words_out(rt, lib, gptr, cfg, status, ev, gcache)
         fr = {"gcache": gcache, "svdc": svdc, "actc": actc, "status": status, "ev": ev, "cache_blocks": cache_blocks if gcache is not None else 0,
               "tail": None}
         es.frames.append(fr)
