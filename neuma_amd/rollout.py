@@ -236,6 +236,7 @@ class _Rollout(autograd.Function):
                                        L.ptr(gcache) if gcache is not None else None, L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
                 "nm_rollout_forward")
         ctx.model, ctx.statics, ctx.S, ctx.alpha, ctx.n = model, statics, S, float(alpha), n
+        ctx.set_materialize_grads(False)      # (backward tells an absent gradient from a zero one: nm_rollout_cfg.last_gF_zero)
         ctx.svd_adjoint = int(svd_adjoint)
         ctx.cache_blocks, ctx.gcache = int(cfg.grid_cache_blocks), gcache
         ctx.cache_status = ctx.cache_event = None
@@ -292,6 +293,7 @@ class _Rollout(autograd.Function):
                                                   sws_bytes, L.stream_ptr(dev)), "nm_rollout_forward_sharded")
         ex.watch(lib, sws, dev)          # status word -> pinned host memory; ex.check() raises on a capacity overflow
         ctx.model, ctx.statics, ctx.S, ctx.alpha, ctx.n = model, statics, S, alpha, n
+        ctx.set_materialize_grads(False)
         ctx.svd_adjoint = svd_adjoint
         ctx.cache_blocks, ctx.gcache = cap_rec, gcache
         ctx.cache_status = ctx.cache_event = None
@@ -328,8 +330,10 @@ class _Rollout(autograd.Function):
                 ctx.cache_event.synchronize()
             verified = int(bool((ctx.cache_status >= 0).all()))
         svdc, actc = getattr(ctx, "svdc", None), getattr(ctx, "actc", None)
+        # (no gradient arrived for F of the last record: the last substep's plasticity adjoint would propagate zeros - the
+        #  library leaves that launch out, nm_rollout_cfg.last_gF_zero; the sharded sweep ignores the word)
         cfg = L.nm_rollout_cfg(S, ctx.alpha, ctx.cache_blocks, verified, ctx.svd_adjoint, L.ptr(svdc.t) if svdc is not None else None,
-                               L.ptr(actc.t) if actc is not None else None)
+                               L.ptr(actc.t) if actc is not None else None, 0, 1 if gF is None else 0)
         st = ctx.statics.c_struct()
         mle = L.nm_mlp(L.ptr(e0), L.ptr(e1), L.ptr(e2))
         mlp = L.nm_mlp(L.ptr(p0), L.ptr(p1), L.ptr(p2))
