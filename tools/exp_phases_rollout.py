@@ -20,7 +20,7 @@ from neuma_amd import _lib, synth
 from neuma_amd.harness import SceneRuntime
 lib = _lib.lib()
 dev = torch.device("cuda", 0)
-rt = SceneRuntime(synth.make_scene("metric", override=dict(K=1000, S=3)), dev)
+rt = SceneRuntime(synth.make_scene("metric", override=dict(K=1000, S=int(os.environ.get("NM_EXP_S", "3")))), dev)
 for _ in range(3):
     x = rt.x0.clone().requires_grad_(True)
     o = rt.rollout(x, rt.v0, rt.C0, rt.F0)
