@@ -385,6 +385,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     fps = args.steps / elapsed
+    # every rank's loss is the partial sum over its own render stripes (harness.pixel_loss_rows): the ranks' parts add up to the
+    # one-GPU loss of the same frame - summed here, outside the timed region, so that an N-rank line can be held against the 1-rank one
+    loss_local = float(last.loss)
+    loss_total = loss_local
+    if world > 1:
+        t = torch.tensor([loss_local], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        loss_total = float(t)
 
     # (Gaussian, tile) pairs, list entries and walked list entries of one full view, for the byte accounting
     D, vstats = 0.0, None
@@ -629,7 +637,8 @@ def main():
             "frame_ms_gpu": {"median": round(per_frame[len(per_frame) // 2], 3), "p10": round(per_frame[len(per_frame) // 10], 3),
                              "p90": round(per_frame[(9 * len(per_frame)) // 10], 3)},
             "rates": rates,
-            "loss": float(last.loss),
+            "loss": loss_total,
+            "loss_rank0_part": loss_local,
         }
     else:
         out = None

@@ -16,6 +16,7 @@ Outputs (data only — inputs and expected outputs):
     tests/golden/camera_sh_golden.npz         view/proj matrices, SH evaluations, l1/l2 loss values
     tests/golden/scheduler_golden.npz         learning-rate curves of the reference's cosine / exponential schedulers
 """
+import os
 import sys
 import types
 import math
@@ -25,7 +26,8 @@ import numpy as np
 import torch
 
 REF = Path("/root/reference")
-OUT = Path(__file__).resolve().parent
+HERE = Path(__file__).resolve().parent
+OUT = Path(os.environ.get("NEUMA_GOLDEN_OUT", HERE))      # (tests/test_golden_regen.py regenerates into a temporary directory)
 
 
 def install_stubs():
@@ -154,7 +156,7 @@ def main():
             out["Fp_lora_merged"] = P(F).numpy()
         np.savez_compressed(OUT / f"material_{name}.npz", **out)
     np.savez_compressed(OUT / "base_models.npz", **base)
-    np.savez_compressed(OUT.parent.parent / "neuma_amd" / "data" / "base_models.npz", **base)
+    np.savez_compressed((HERE.parent.parent / "neuma_amd" / "data" if OUT == HERE else OUT / "data") / "base_models.npz", **base)
 
     # ---- camera / SH / loss conventions (pure torch/numpy reference modules, loaded by file path)
     import importlib.util

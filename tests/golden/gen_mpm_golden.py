@@ -27,6 +27,7 @@ Outputs (data only - inputs and expected outputs):
     tests/golden/svd_rule.npz            batch_svd outputs (both raw-factor conventions)
     tests/golden/cov_deform.npz          deform_cov_by_F outputs
 """
+import os
 import sys
 from pathlib import Path
 
@@ -34,8 +35,9 @@ import numpy as np
 import torch
 
 REF = Path("/root/reference")
-OUT = Path(__file__).resolve().parent
-sys.path.insert(0, str(OUT))
+HERE = Path(__file__).resolve().parent
+OUT = Path(os.environ.get("NEUMA_GOLDEN_OUT", HERE))      # (tests/test_golden_regen.py regenerates into a temporary directory)
+sys.path.insert(0, str(HERE))
 
 import warp_scalar as wps  # noqa: E402
 

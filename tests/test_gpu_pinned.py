@@ -6,13 +6,19 @@ import pytest
 import torch
 
 from oracle import mpm as om
-from gpu_util import dev, build_model, build_statics, parity
+from gpu_util import dev, build_model, build_statics, parity, measured
 
 pytestmark = pytest.mark.gpu
 
 STEP_TAGS = ["n64_g16_noslip", "n64_g16_freeslip", "n2048_g32_noslip", "n2048_g32_freeslip"]
 GRAD_TAGS = ["n64_g16_noslip", "n64_g16_freeslip", "n384_g16_noslip", "n384_g16_freeslip"]
 GRAVITY = (0.0, float(np.float32(-9.8)), 0.0)
+# bounds of the comparisons that used to be bare asserts (round 6: logged through gpu_util.parity like the rest; values in DESIGN.md §2)
+GV_BOUND = 2e-5
+FD_REL, FD_ABS = 2e-3, 2e-6
+XE_BOUND = 2e-6
+SVD_BOUND = dict(sigma=2e-6, det=1e-5, recon=5e-6, rot=2e-5, rank1=2e-4)
+COV_BOUND = 5e-7
 
 
 def _case(z, bc):
@@ -59,10 +65,10 @@ def test_substep_vs_reference_run(golden_dir, tag, reorder):
         parity(f"substep {tag} grid vs reference f64 run", "mv (rel)", np.abs(mv - z["f64_mv"]).max() / np.abs(z["f64_mv"]).max(),
                max(5e-7, 3 * gn("mv")), gn("mv"))
         w = z["f64_m"][..., None]
-        assert np.abs(gv * m[..., None] - z["f64_gv"] * w).max() <= 2e-5 * np.abs(z["f64_gv"] * w).max()
+        parity(f"substep {tag} grid vs reference f64 run", "v * m (rel)", np.abs(gv * m[..., None] - z["f64_gv"] * w).max() / np.abs(z["f64_gv"] * w).max(), GV_BOUND)
         # untouched nodes: the reference's dense sweep leaves v = BC(g dt) there; the block-sparse grid must export the same
         un = z["f64_m"] == 0
-        assert np.abs(gv[un] - z["f64_gv"][un]).max() <= 1e-9
+        parity(f"substep {tag} grid vs reference f64 run", "v of untouched nodes (abs)", np.abs(gv[un] - z["f64_gv"][un]).max(), 1e-9)
 
 
 @pytest.mark.parametrize("tag", GRAD_TAGS)
@@ -76,14 +82,18 @@ def test_adjoints_vs_central_differences_of_the_reference(golden_dir, tag):
     W = [torch.from_numpy(z["W_" + k]).float().to(dev()) for k in ["x", "v", "C", "F"]]
     L = sum((w[e] * o[e]).sum() for w, o in zip(W, outs))
     grads = torch.autograd.grad(L, ins)
+    worst = {}
     for name, g in zip(["x", "v", "C", "F", "stress"], grads):
         gd = g.double().cpu()
         for d, fd in zip(z["dir_" + name], z["fd_" + name]):
             d = torch.from_numpy(d)
             an = float((gd * d).sum())
             # fp32 error budget of an inner product: relative to |g|.|d| rather than to the (possibly cancelling) result
-            budget = 2e-3 * abs(fd) + 2e-6 * float(gd.abs().mul(d.abs()).sum())
-            assert abs(an - fd) <= budget, (name, an, fd)
+            budget = FD_REL * abs(fd) + FD_ABS * float(gd.abs().mul(d.abs()).sum())
+            worst[name] = max(worst.get(name, 0.0), abs(an - fd) / budget)
+    # |analytic - fd| over its budget (FD_REL |fd| + FD_ABS sum |g||d|), worst direction per input: logged, <= 1
+    for name, wv in worst.items():
+        parity(f"adjoint {tag} vs central differences of the reference forward", f"dL/d{name}: |an - fd| / budget", wv, 1.0)
 
 
 def _stress(F, mu, lam):
@@ -126,7 +136,7 @@ def test_inplace_forward_rollout_spans_and_extra_vs_reference_run(golden_dir):
         state.from_torch(stress=_stress(F.double(), float(z["mu"]), float(z["lam"])).float())
         if step in (3, 9):
             xe = extra(statics, state, st_e, state_e)
-            assert np.abs(xe.cpu().double().numpy() - z[f"f64_xe_{step}"]).max() < 2e-6
+            parity(f"in-place roll-out, step {step}, passive extra set vs reference f64 run", "x_extra", np.abs(xe.cpu().double().numpy() - z[f"f64_xe_{step}"]).max(), XE_BOUND)
         x, v, C, Fn = sim(statics, state)
         sti.update(statics, step)
         if step in tol:
@@ -145,16 +155,18 @@ def test_svd_vs_reference_sign_rule(golden_dir):
     A = torch.from_numpy(z["A"]).float().to(dev())
     U, s, Vh = (t.double().cpu() for t in SVD()(A))
     rU, rs, rVh = (torch.from_numpy(z[f"numpy_f64_{k}"]) for k in ["U", "sigma", "Vh"])
-    assert (s - rs).abs().max() < 2e-6
-    assert (torch.linalg.det(U) - 1).abs().max() < 1e-5 and (torch.linalg.det(Vh) - 1).abs().max() < 1e-5
-    assert (U @ torch.diag_embed(s) @ Vh - torch.from_numpy(z["A"])).abs().max() < 5e-6
+    case = "SVD vs numpy f64 factors under the reference's sign rule"
+    parity(case, "sigma", (s - rs).abs().max(), SVD_BOUND["sigma"])
+    parity(case, "det U - 1", (torch.linalg.det(U) - 1).abs().max(), SVD_BOUND["det"])
+    parity(case, "det Vh - 1", (torch.linalg.det(Vh) - 1).abs().max(), SVD_BOUND["det"])
+    parity(case, "U diag(s) Vh - A", (U @ torch.diag_embed(s) @ Vh - torch.from_numpy(z["A"])).abs().max(), SVD_BOUND["recon"])
     distinct = ((rs[:, 0] - rs[:, 1]).abs() > 1e-2) & ((rs[:, 1] - rs[:, 2].abs()).abs() > 1e-2)
     assert int(distinct.sum()) > 60
-    assert ((U @ Vh) - (rU @ rVh))[distinct].abs().max() < 2e-5
+    parity(case, "U Vh (rotation), distinct sigma", ((U @ Vh) - (rU @ rVh))[distinct].abs().max(), SVD_BOUND["rot"])
     for i in range(3):      # rank-one pieces u_i v_i^T are sign-invariant: same factors up to the joint column flips
         P = U[:, :, i, None] * Vh[:, None, i, :]
         rP = rU[:, :, i, None] * rVh[:, None, i, :]
-        assert (P - rP)[distinct].abs().max() < 2e-4
+        parity(case, f"u_{i} v_{i}^T, distinct sigma", (P - rP)[distinct].abs().max(), SVD_BOUND["rank1"])
 
 
 def test_cov_deform_vs_reference_run(golden_dir):
@@ -162,4 +174,4 @@ def test_cov_deform_vs_reference_run(golden_dir):
     z = np.load(golden_dir / "cov_deform.npz")
     out = deform_cov_by_F(torch.from_numpy(z["cov6"]).float().to(dev()), torch.from_numpy(z["F"]).float().to(dev()))
     ref = z["f64_out"]
-    assert np.abs(out.cpu().double().numpy() - ref).max() <= 5e-7 * np.abs(ref).max()
+    parity("deform_cov_by_F vs reference f64 run", "cov (rel)", np.abs(out.cpu().double().numpy() - ref).max() / np.abs(ref).max(), COV_BOUND)
