@@ -410,10 +410,18 @@ def main():
         print(f"[bench] view statistics unavailable: {e}", file=sys.stderr)
     Dacc = vstats if (vstats is not None and world == 1) else D
 
-    pmc, pmc_mfma = {}, {}
+    pmc, pmc_mfma, pmc_stale, pmc_digest = {}, {}, None, None
     try:        # HBM bytes per launch and matrix-pipe counters from the committed PMC passes (profiles/pmc_traffic.json, tools/make_profile_md.py)
         _p = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
-        pmc, pmc_mfma = _p.get("kernels", {}), _p.get("mfma", {})
+        pmc_digest = _p.get("csrc_digest")
+        # the counters are copies: valid only for the sources they were measured on.  A library built from other sources gets
+        # no traffic figure at all (roofline.traffic null, no *_static fields) and the line says so
+        pmc_stale = pmc_digest != _lib.csrc_digest()
+        if not pmc_stale:
+            pmc, pmc_mfma = _p.get("kernels", {}), _p.get("mfma", {})
+        else:
+            print(f"[bench] profiles/pmc_traffic.json was measured on sources {pmc_digest}, this checkout is {_lib.csrc_digest()}: "
+                  "counter-derived fields dropped (pmc_stale)", file=sys.stderr)
     except Exception:
         pass
     roof = None
@@ -619,6 +627,7 @@ def main():
             "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
             "devices": devices,
             "roofline": roof,
+            "pmc_stale": pmc_stale, "pmc_csrc_digest": pmc_digest, "csrc_digest": _lib.csrc_digest(),
             "cpu_baseline": cpu,
             "epoch": epoch,
             "kernel_breakdown_ms_per_frame": {k: round(v[1], 3) for k, v in sorted(full.items(), key=lambda kv: -kv[1][1])[:12]},

@@ -12,6 +12,18 @@ LIB_PATH = Path(os.environ.get("NEUMA_HIP_LIB", _HERE / "lib" / "libneuma_hip.so
 c_float_p = C.c_void_p  # device pointers travel as integers
 
 
+def csrc_digest() -> str:
+    """sha256 (first 16 hex digits) over the library's sources (csrc/*.hip, csrc/*.h, csrc/Makefile, include/neuma_hip.h, in name
+    order): recorded next to every counter file under profiles/ so that bench.py can tell a counter pass of THIS build from a
+    stale one (`pmc_stale`).  Content-based: works on the GPU box, where there is no .git."""
+    import hashlib
+    h = hashlib.sha256()
+    src = sorted(list((_HERE / "csrc").glob("*.hip")) + list((_HERE / "csrc").glob("*.h")) + [_HERE / "csrc" / "Makefile"])
+    for f in src + [_HERE.parent / "include" / "neuma_hip.h"]:
+        h.update(f.name.encode() + b"\0" + f.read_bytes() + b"\0")
+    return h.hexdigest()[:16]
+
+
 class nm_mpm_cfg(C.Structure):
     _fields_ = [("num_grids", C.c_int32), ("dt", C.c_float), ("bound", C.c_int32), ("gravity", C.c_float * 3),
                 ("eps", C.c_float), ("bc", C.c_int32)]

@@ -71,3 +71,17 @@ def test_cpu_tensors_are_rejected_loudly():
     from neuma_amd.svd import SVD
     with pytest.raises(NeumaHipError):
         SVD()(torch.eye(3)[None])
+
+
+def test_counter_file_carries_the_digest_of_the_sources_it_was_measured_on():
+    """profiles/pmc_traffic.json (copied into bench.py's line as *_static fields) names the sources of its library build; bench.py
+    compares it with the checkout's and reports `pmc_stale` instead of a traffic figure when they differ."""
+    import json
+    from pathlib import Path
+    from neuma_amd import _lib
+    d = json.loads((Path(__file__).resolve().parent.parent / "profiles" / "pmc_traffic.json").read_text())
+    dig = _lib.csrc_digest()
+    assert len(dig) == 16 and int(dig, 16) >= 0
+    assert isinstance(d.get("csrc_digest"), str) and len(d["csrc_digest"]) == 16
+    src = (Path(__file__).resolve().parent.parent / "bench.py").read_text()
+    assert "pmc_stale" in src and "csrc_digest()" in src

@@ -79,6 +79,10 @@ if mf:
             mfma_json[k.split("<")[0]] = {"avg_us": round(us, 1), "mfma_busy_cycles": busy, "mfma_flops": flops,
                                           "mfma_busy_pct_of_simd_cycles": round(100 * busy / simd_cycles, 2)}
 import json
+import sys as _sys
+from pathlib import Path as _Path
+_sys.path.insert(0, str(_Path(__file__).resolve().parent.parent))
+from neuma_amd._lib import csrc_digest as _csrc_digest      # noqa: E402
 traffic = {}
 for k in sorted(set(fetch) | set(write)):
     if k.startswith(("torch", "Cijk", "rocprim", "__amd")): continue
@@ -92,5 +96,8 @@ for base, t in traffic.items():
     t["hbm_bytes_per_launch"] = int((2.0 * t["fetch_kib"] + t["write_kib"]) * 1024)
 json.dump({"source": f"profiles/{tag}_bench_metric_kernel_stats.md (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)",
            "correction": "bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB counters; FETCH under-reports wide coalesced reads by 2x on gfx950)",
+           "csrc_digest": _csrc_digest(),
+           "csrc_digest_note": "neuma_amd._lib.csrc_digest() of the sources the profiled library was built from; bench.py drops the "
+                               "copied counters and prints pmc_stale when the checkout's digest differs",
            "kernels": traffic, "mfma": mfma_json}, open("profiles/pmc_traffic.json", "w"), indent=1)
 print(open(f"profiles/{tag}_bench_metric_kernel_stats.md").read())
