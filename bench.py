@@ -282,8 +282,8 @@ def main():
         n_all = int(scene.x0.shape[0])
         # ... and both forms of the shared-block exchange: the all-reduce over the world and the buffers swapped with the
         # neighbour ranks only (nm_comm.exchange_peers_f32; needs the library's communicator) - the faster one is used
-        from neuma_amd.sim.shard import library_comm_for, time_exchange_peers_us
-        rc_comm = library_comm_for(dist.group.WORLD, dev) if backend == "nccl" else None
+        from neuma_amd.sim.shard import create_library_comm, time_exchange_peers_us
+        rc_comm = create_library_comm(dist.group.WORLD, dev) if backend == "nccl" else None
         t_ar = time_all_reduce_us(None, dev, count=1 << 16, rccl=rc_comm)
         t_px = time_exchange_peers_us(dev, rank, world, count=1 << 16, rccl=rc_comm)
         vals = torch.tensor([measure_substep_us(args.workload, n_all, dev), measure_substep_us(args.workload, -(-n_all // world), dev),

@@ -726,6 +726,14 @@ class SceneRuntime(object):
         self.F0 = torch.eye(3, device=self.device).repeat(N, 1, 1)
         # the particle rows this rank simulates: all of them, or its contiguous range of the (Hilbert-ordered) list
         self.rows = slice(0, N)
+        if world > 1:
+            # the one collective point at which the library's RCCL communicator of this group comes into being (every rank builds
+            # its runtime): the frame's collectives (sim.shard.all_reduce_sum_ / all_gather_rows_, reached from autograd backward
+            # functions) only look it up
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+                from .sim.shard import create_library_comm
+                create_library_comm(group, self.device)
         if self.shard_sim:
             from .sim.shard import shard_range
             self.rows = slice(*shard_range(N, world, rank))

@@ -273,7 +273,8 @@ class GridExchange(object):
         # NEUMA_SHARD_EXCHANGE: "allreduce" (default), "peers" (neighbour-only: derived by size_frame_lists from the probe)
         self.exchange_mode = os.environ.get("NEUMA_SHARD_EXCHANGE", "allreduce")
         self.peers: Optional[int] = None
-        self._rccl = None           # library-owned RCCL communicator (library_comm): None = not tried yet, False = not available
+        self._rccl = None           # library-owned RCCL communicator (library_comm): None = not looked up yet, False = not available
+        create_library_comm(group, self.device)      # COLLECTIVE, here and only here for a sharded model: model.shard() is called by every rank
 
     def library_comm(self):
         """The library's own RCCL communicator for this group (library_comm_for: one per process group, shared with the per-frame
@@ -282,6 +283,8 @@ class GridExchange(object):
         NEUMA_COMM=python asks for the callbacks."""
         if self._rccl is None:
             self._rccl = library_comm_for(self.group, self.device) or False
+        elif self._rccl and library_comm_for(self.group, self.device) is None:
+            self._rccl = False          # released behind this object's back (close_library_comms, group destroyed)
         return self._rccl or None
 
     def close(self) -> None:
@@ -499,61 +502,114 @@ class GridExchange(object):
 
 
 # ---------------------------------------------------------------- the library's RCCL communicator, one per process group
-_LIB_COMMS = {}        # id(group) -> ctypes handle | False (tried, not available)
+# id(pg) -> (pg, handle | False).  The entry keeps a strong reference to the ProcessGroup object, so its id cannot be handed to
+# another object while the entry exists; an entry whose group has left torch.distributed's table (destroy_process_group, then a
+# new group) is purged - and its communicator destroyed - at the next look-up instead of being returned for the new group.
+_LIB_COMMS = {}
 
 
-def library_comm_for(group, device):
-    """The library-owned RCCL communicator of a torch.distributed group (csrc/nm_rccl.hip), created on first use: rank 0's
-    ncclUniqueId goes round through ONE torch.distributed broadcast, every rank runs ncclCommInitRank.  None when the group's
-    backend is not nccl (the gloo tests) or NEUMA_COMM=python asks for torch.distributed.  Collective: every rank of the group
-    must make its first call at the same point.  Used by the sharded roll-out (its C loop issues the collectives itself) and by
-    the per-frame collectives below, so that a multi-GPU frame makes no torch.distributed call at all."""
+def _resolve_group(group):
+    import torch.distributed as dist
+    if group is not None:
+        return group
+    return dist.distributed_c10d._get_default_group()
+
+
+def _group_alive(pg) -> bool:
+    import torch.distributed as dist
+    try:
+        return pg in dist.distributed_c10d._world.pg_map
+    except Exception:       # noqa: BLE001 - private table moved: assume alive (the strong reference still rules out an id clash)
+        return True
+
+
+def _purge_dead_comms() -> None:
+    for key, (pg, h) in list(_LIB_COMMS.items()):
+        if not _group_alive(pg):
+            if h:
+                try:
+                    L.lib().nm_rccl_destroy(h)
+                except Exception:       # noqa: BLE001
+                    pass
+            del _LIB_COMMS[key]
+
+
+def create_library_comm(group, device):
+    """COLLECTIVE: create (once) the library-owned RCCL communicator of a torch.distributed group (csrc/nm_rccl.hip) - rank 0's
+    ncclUniqueId goes round through ONE torch.distributed broadcast, every rank runs ncclCommInitRank, one MIN all-reduce makes
+    the ranks agree on whether it exists.  Every rank of the group must call this at the same point: it is called where a
+    multi-rank object is set up (MPMModel.shard / GridExchange, SceneRuntime.__init__, bench.py's calibration), never from inside
+    a collective wrapper or an autograd backward.  Returns the handle, or None when the group's backend is not nccl (the gloo
+    tests), NEUMA_COMM=python asks for torch.distributed, or some rank could not create it (then no rank uses it)."""
     import os
     import torch.distributed as dist
-    key = id(group) if group is not None else 0
-    h = _LIB_COMMS.get(key)
-    if h is None:
-        h = False
-        if os.environ.get("NEUMA_COMM", "rccl") != "python" and str(dist.get_backend(group)) == "nccl":
-            lib = L.lib()
-            world, rank = dist.get_world_size(group), dist.get_rank(group)
-            idt = torch.zeros(128, dtype=torch.uint8)
-            rc0 = 0
-            if rank == 0:
-                # a failure here (librccl cannot be bound, ncclGetUniqueId failed) must not raise: the other ranks are on their
-                # way into the broadcast below.  Rank 0 sends zeros, skips its own create and the MIN all-reduce makes every
-                # rank fall back to torch.distributed together
-                rc0 = int(lib.nm_rccl_unique_id(C.c_void_p(idt.data_ptr())))
-                if rc0:
-                    idt.zero_()
-            dev_id = idt.to(device)
-            src = dist.get_global_rank(group, 0) if group is not None else 0
-            dist.broadcast(dev_id, src=src, group=group)
-            idt = dev_id.cpu()
-            hh = C.c_void_p()
-            rc = rc0
+    _purge_dead_comms()
+    pg = _resolve_group(group)
+    key = id(pg)
+    ent = _LIB_COMMS.get(key)
+    if ent is not None:
+        return ent[1] or None
+    h = False
+    if os.environ.get("NEUMA_COMM", "rccl") != "python" and str(dist.get_backend(group)) == "nccl":
+        lib = L.lib()
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        idt = torch.zeros(128, dtype=torch.uint8)
+        rc0 = 0
+        if rank == 0:
+            # a failure here (librccl cannot be bound, ncclGetUniqueId failed) must not raise: the other ranks are on their
+            # way into the broadcast below.  Rank 0 sends zeros, skips its own create and the MIN all-reduce makes every
+            # rank fall back to torch.distributed together
+            rc0 = int(lib.nm_rccl_unique_id(C.c_void_p(idt.data_ptr())))
+            if rc0:
+                idt.zero_()
+        dev_id = idt.to(device)
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast(dev_id, src=src, group=group)
+        idt = dev_id.cpu()
+        hh = C.c_void_p()
+        rc = rc0
+        if rc == 0:
+            with torch.cuda.device(device):
+                rc = lib.nm_rccl_create(C.c_void_p(idt.data_ptr()), world, rank, C.byref(hh))
+        # every rank uses the library's communicator or none does: a rank on which it could not be created must not leave
+        # the others waiting inside a collective it never issues
+        ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 1:
+            h = hh
+        else:
+            import warnings
+            why = (lib.nm_last_error() or b"").decode() if rc else "another rank could not create it"
+            warnings.warn(f"library-owned RCCL communicator not available ({why}): collectives go through torch.distributed")
             if rc == 0:
-                with torch.cuda.device(device):
-                    rc = lib.nm_rccl_create(C.c_void_p(idt.data_ptr()), world, rank, C.byref(hh))
-            # every rank uses the library's communicator or none does: a rank on which it could not be created must not leave
-            # the others waiting inside a collective it never issues
-            ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=device)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-            if int(ok.item()) == 1:
-                h = hh
-            else:
-                import warnings
-                why = (lib.nm_last_error() or b"").decode() if rc else "another rank could not create it"
-                warnings.warn(f"library-owned RCCL communicator not available ({why}): collectives go through torch.distributed")
-                if rc == 0:
-                    lib.nm_rccl_destroy(hh)
-        _LIB_COMMS[key] = h
+                lib.nm_rccl_destroy(hh)
+    _LIB_COMMS[key] = (pg, h)
     return h or None
 
 
+def library_comm_for(group, device=None):
+    """LOOK-UP ONLY (never collective, never creates): the communicator create_library_comm made for this group, or None - the
+    per-frame collectives below then go through torch.distributed, on every rank alike (creation is all-or-none)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    try:
+        pg = _resolve_group(group)
+    except Exception:       # noqa: BLE001 - no default group
+        return None
+    ent = _LIB_COMMS.get(id(pg))
+    if ent is None:
+        return None
+    if ent[0] is not pg or not _group_alive(pg):
+        _purge_dead_comms()
+        return None
+    return ent[1] or None
+
+
 def close_library_comms() -> None:
-    """Release every library-owned communicator of this process (call before dist.destroy_process_group())."""
-    for key, h in list(_LIB_COMMS.items()):
+    """Release every library-owned communicator of this process (call before dist.destroy_process_group(); entries of groups
+    destroyed without it are released at the next create / look-up)."""
+    for key, (_pg, h) in list(_LIB_COMMS.items()):
         if h:
             try:
                 L.lib().nm_rccl_destroy(h)

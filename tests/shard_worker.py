@@ -188,8 +188,20 @@ def cpu_rows(rank, world, port, q):
         dist.all_reduce(vals, op=dist.ReduceOp.MAX)
         cost = shard_cost_model(100_000, world, 20, dict(substep_us_full=float(vals[0]), substep_us_shard=float(vals[1]), allreduce_us=float(vals[2])))
         ok_cal = bool(ar > 0.0 and cost["inputs"] == "measured at start-up" and float(vals[0]) == 223.0 + world - 1)
-        q.put({"rank": rank, "ok": [ok_fwd, ok_bwd, ok_sum, ok_par, ok_cal], "decision": bool(cost["shard"]), "sharded_us": cost["sharded_us"]})
+        # the communicator cache: look-ups never create (and are not collective); an entry dies with its process group - a group
+        # created after destroy_process_group() must not inherit it, whatever id() the new object gets
+        from neuma_amd.sim import shard as SH
+        ok_lookup = SH.library_comm_for(None, "cpu") is None and len(SH._LIB_COMMS) == 0      # all of the above created nothing
+        SH.create_library_comm(None, "cpu")          # gloo: recorded as "not available", no collective
+        pg_old = dist.distributed_c10d._get_default_group()
+        ok_entry = len(SH._LIB_COMMS) == 1 and SH.library_comm_for(None, "cpu") is None
+        SH._LIB_COMMS[id(pg_old)] = (pg_old, False)
+        dist.barrier()
         dist.destroy_process_group()
+        ok_dead = not SH._group_alive(pg_old)
+        SH._purge_dead_comms()
+        ok_purged = len(SH._LIB_COMMS) == 0          # the entry of a destroyed group does not survive the next create / look-up
+        q.put({"rank": rank, "ok": [ok_fwd, ok_bwd, ok_sum, ok_par, ok_cal, ok_lookup, ok_entry, ok_dead, ok_purged], "decision": bool(cost["shard"]), "sharded_us": cost["sharded_us"]})
     except Exception as e:
         import traceback
         q.put({"rank": rank, "error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()})
