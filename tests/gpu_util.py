@@ -60,6 +60,26 @@ def measured(value, kind="err") -> float:
     return Measured(float(value), kind)
 
 
+def far_image(img: torch.Tensor) -> torch.Tensor:
+    """A target image FAR from anything the scene renders (a smooth pattern, same shape / device): equivalence tests of two
+    schedules or code paths take their loss against it.  Two runs of one frame differ in the last bits of the particle states
+    (order of the scatters' float atomics), and a last-bit difference now and then flips the rasterizer's alpha >= 1/255 cut-off
+    for a pixel.  Against a near ground truth (loss ~ 1e-6, residuals ~ 1e-3) such a flip is 1e-5 .. 1e-3 of the loss and of
+    every gradient - which is why these tests once had to retry; against residuals of ~ 0.5 per pixel it is ~ 1e-8 of the loss
+    and below the atomics' rounding noise in the gradients, so the tight bound can be demanded of EVERY run."""
+    c, h, w = img.shape[-3:]
+    yy = torch.linspace(0.0, 1.0, h, device=img.device).view(1, h, 1)
+    xx = torch.linspace(0.0, 1.0, w, device=img.device).view(1, 1, w)
+    ch = torch.arange(c, device=img.device, dtype=torch.float32).view(c, 1, 1)
+    pat = 0.5 + 0.4 * torch.sin(6.0 * xx + 2.0 * ch) * torch.cos(5.0 * yy - ch)
+    return pat.expand_as(img).contiguous().to(img.dtype)
+
+
+def far_ground_truth(rt) -> None:
+    """Replace a SceneRuntime's ground-truth views by far_image targets (after make_ground_truth)."""
+    rt.gt = [far_image(g) for g in rt.gt]
+
+
 def mpm_case(N=4096, G=32, seed=0, bc="noslip", near_wall=True, disabled=True, dt=1e-3):
     g = torch.Generator().manual_seed(seed)
     const = om.MPMConstant(num_grids=G, dt=dt, bound=1, gravity=(0.0, -9.8, 0.0), eps=6e-7, bc=bc)

@@ -150,3 +150,96 @@ def test_finetune_and_render_entry_points(tmp_path):
     assert np.abs(a30 - a0).max() > 5                                         # the body fell (0.12 s of gravity)
     x30 = nio.load_particles_ply(out / "states_run" / "030.ply")
     assert x30.shape == (N, 3) and np.isfinite(x30).all() and x30[:, 1].mean() < nio.load_particles_ply(assets / "particles.ply")[:, 1].mean() - 0.03
+
+
+def test_inference_entry_point_two_objects(tmp_path):
+    """`python -m neuma_amd.inference -c demo.yaml` (experiments/inference.py:48-84, 87-377, 380-386): a two-object scene in the
+    schema of experiments/configs/demo/multiobj-bb-cc.yaml - per-object asset folders, base checkpoints (jelly / plasticine),
+    a LoRA adaptor for one of them, initial velocities, boxes one above the other, Gaussians mapped into the simulation box -
+    rolled out and rendered from the command line; the frames and particle states on disk are those of the operator-level
+    driver (infer.simulate_objects) called by hand on the same objects."""
+    from PIL import Image
+    from neuma_amd import io as nio, synth
+    from neuma_amd.config import load_config
+    from neuma_amd.inference import inference, load_object, main as inference_main
+    from neuma_amd.infer import simulate_objects
+    from neuma_amd.material import InvariantFullMetaElasticity
+    from neuma_amd.sim import MPMModelBuilder
+    path, scene = _write_experiment(tmp_path, frames=1)
+    base = yaml.safe_load(path.read_text())
+    raw, assets = tmp_path / "raw", tmp_path / "assets"
+    w = synth.load_base_weights("plasticine")
+    keys = ("layers.0.fc.weight", "layers.1.fc.weight", "final_layer.fc.weight")
+    torch.save({t: {k: torch.tensor(a) for k, a in zip(keys, w[s])} for t, s in (("elasticity", "e"), ("plasticity", "p"))}, raw / "plasticine_0300.pt")
+    # a LoRA adaptor file in the layout finetune writes (NNNN_lora.pt: the lora_A / lora_B entries of both nets)
+    lora = {}
+    for tag in ("elasticity", "plasticity"):
+        net = InvariantFullMetaElasticity(base["constitution"]["elasticity"])
+        net.init_lora_layers(r=16, lora_alpha=4)
+        g = torch.Generator().manual_seed(5)
+        lora[tag] = {k: (0.05 * torch.randn(v.shape, generator=g)) for k, v in net.state_dict().items() if "lora_" in k}
+    torch.save(dict(lora, loss=0.0), raw / "0100_lora.pt")
+    # the second object uses the same prepared asset folder under its own name (a copy: kernels.ply, particles.ply, bindings.pt)
+    import shutil
+    shutil.copytree(assets / "tinyball", assets / "tinycat")
+    for f in (assets / "tinycat").glob("particles.npz"):
+        f.unlink()              # the MPMInitData cache is rebuilt from particles.ply, as for a fresh asset folder
+
+    def obj(name, ckpt, lo, vel, lora_path=None):
+        c = dict(sim_data_name=name, pretrained_ckpt=str(raw / ckpt), gaussian=dict(sh_degree=3),
+                 particle_data=dict(shape=dict(asset_root=None, sort=None, ori_bounds=[[0.0, 0.0, 0.0], [1.0, 1.0, 1.0]],
+                                               sim_bounds=[[0.25, lo, 0.25], [0.75, lo + 0.5, 0.75]]),
+                                    vel=dict(lin_vel=vel, ang_vel=[0.0, 0.0, 0.0]), rho=1000.0, clip_bound=0.1),
+                 constitution=dict(elasticity=base["constitution"]["elasticity"], plasticity=base["constitution"]["plasticity"], views=["r_0"]))
+        if lora_path:
+            c["constitution"].update(load_lora=str(lora_path), lora=dict(r=16, alpha=4))
+        return c
+
+    cfg = dict(gpu=0, seed=42, debug=True, debug_views=["r_1"], resume=False, overwrite=False, denormalize=False, assets_root=str(assets),
+               video_data=dict(base["video_data"], data=dict(base["video_data"]["data"], init_frame=0, used_views=["r_1"])),
+               sim=dict(base["sim"], num_grids=32, eps=6e-7),
+               objects=[obj("tinyball", "jelly_0300.pt", 0.45, [0.0, -0.5, 0.0], raw / "0100_lora.pt"),
+                        obj("tinycat", "plasticine_0300.pt", 0.02, [0.0, -0.5, 0.0])])
+    demo = tmp_path / "multiobj-tiny.yaml"
+    demo.write_text(yaml.safe_dump(cfg, sort_keys=False))
+    steps = 12
+    inference_main(["-c", str(demo), "-s", str(steps), "-vn", "pair", "-dv", "r_0", "-sp", "pair", "--result_root", str(tmp_path / "results")])
+    img_root = tmp_path / "results" / "inference" / "images_pair"
+    assert sorted(p.name for p in img_root.glob("*.png")) == [f"r_0_{i:03d}.png" for i in range(steps + 1)]      # -dv overrides the YAML's r_1
+    st_root = tmp_path / "results" / "inference_states" / "states_pair"
+    assert sorted(p.name for p in st_root.glob("*.ply")) == [f"{i:03d}.ply" for i in range(1, steps + 1)]
+    assert (tmp_path / "results" / "inference_videos").is_dir()
+    # ---- the same scene through the operators, by hand
+    c = load_config(demo)
+    d = dev()
+    objects = [load_object(o, assets, steps, d) for o in c.objects]
+    n0, n1 = (o.init_data.num_particles for o in objects)
+    assert objects[0].elasticity.layers[0].fc.r == 16 and not getattr(objects[1].elasticity.layers[0].fc, "r", 0)      # adaptor on the first object only
+    assert abs(objects[0].init_data.pos[:, 1].mean() - objects[1].init_data.pos[:, 1].mean() - 0.43) < 0.02         # one box above the other
+    model = MPMModelBuilder().parse_cfg(c.sim).finalize(d, False)
+    from neuma_amd.dataset import CameraDataset
+    c.video_data.data.used_views = ["r_0"]
+    ds = CameraDataset(c.video_data)
+    cam = ds.getCameras("r_0", ds.steps[0])
+    frames = list(simulate_objects(model, objects, steps, [cam], torch.ones(3, device=d)))
+    x_last = nio.load_particles_ply(st_root / f"{steps:03d}.ply")
+    assert x_last.shape == (n0 + n1, 3)
+    # two runs of one scene differ by the order of the scatters' float atomics: positions to 1e-6, 8-bit frames to one level
+    from gpu_util import measured
+    assert measured(np.abs(x_last - frames[-1]["x"].cpu().numpy()).max(), "x after 12 steps: command line vs operators (abs)") < 2e-6
+    for i in (0, steps):
+        a = np.array(Image.open(img_root / f"r_0_{i:03d}.png")).astype(np.int32)
+        b = (frames[i]["images"][0].clamp(0, 1) * 255 + 0.5).to(torch.uint8).permute(1, 2, 0).cpu().numpy().astype(np.int32)
+        assert measured(np.abs(a - b).max(), f"frame {i}: 8-bit levels, command line vs operators") <= 1
+    a0 = np.array(Image.open(img_root / "r_0_000.png")).astype(np.int32)
+    aN = np.array(Image.open(img_root / f"r_0_{steps:03d}.png")).astype(np.int32)
+    assert (a0 < 250).any(axis=2).sum() > 50 and np.abs(aN - a0).max() > 5          # both bodies visible on white, and they moved
+    # both bodies fall; the first section is the upper one
+    x0 = frames[0]["x"].cpu().numpy()
+    assert (x_last[:n0, 1].mean() < x0[:n0, 1].mean() - 5e-3) and (x_last[n0:, 1].mean() < x0[n0:, 1].mean() - 1e-3)
+    # an object without an initial velocity is refused with the reason
+    bad = yaml.safe_load(demo.read_text())
+    del bad["objects"][1]["particle_data"]["vel"]
+    (tmp_path / "bad.yaml").write_text(yaml.safe_dump(bad))
+    with pytest.raises(ValueError, match="particle_data.vel"):
+        inference_main(["-c", str(tmp_path / "bad.yaml"), "-s", "2", "-vn", "bad", "--result_root", str(tmp_path / "results")])

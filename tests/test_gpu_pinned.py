@@ -14,11 +14,14 @@ STEP_TAGS = ["n64_g16_noslip", "n64_g16_freeslip", "n2048_g32_noslip", "n2048_g3
 GRAD_TAGS = ["n64_g16_noslip", "n64_g16_freeslip", "n384_g16_noslip", "n384_g16_freeslip"]
 GRAVITY = (0.0, float(np.float32(-9.8)), 0.0)
 # bounds of the comparisons that used to be bare asserts (round 6: logged through gpu_util.parity like the rest; values in DESIGN.md §2)
-GV_BOUND = 2e-5
-FD_REL, FD_ABS = 2e-3, 2e-6
-XE_BOUND = 2e-6
-SVD_BOUND = dict(sigma=2e-6, det=1e-5, recon=5e-6, rot=2e-5, rank1=2e-4)
-COV_BOUND = 5e-7
+# measured on MI355X (gpurun_out r06b, profiles/r06_parity_table.md): v * m 4.5e-7; |an - fd| at most 7.2e-3 of the round-5 budget
+# (2e-3 |fd| + 2e-6 sum |g||d|) - the budget is now 1/20 of that; x_extra 6.8e-8; sigma 3.8e-7, det 3.6e-7, reconstruction 4.9e-7,
+# rotation 2.1e-7, rank-one pieces 8.8e-7; cov 5.3e-8.  Fixture comparisons are deterministic up to the scatters' atomics order.
+GV_BOUND = 3e-6
+FD_REL, FD_ABS = 1e-4, 1e-7
+XE_BOUND = 4e-7
+SVD_BOUND = dict(sigma=1.5e-6, det=1.5e-6, recon=2e-6, rot=1e-6, rank1=4e-6)
+COV_BOUND = 3e-7
 
 
 def _case(z, bc):
@@ -68,7 +71,7 @@ def test_substep_vs_reference_run(golden_dir, tag, reorder):
         parity(f"substep {tag} grid vs reference f64 run", "v * m (rel)", np.abs(gv * m[..., None] - z["f64_gv"] * w).max() / np.abs(z["f64_gv"] * w).max(), GV_BOUND)
         # untouched nodes: the reference's dense sweep leaves v = BC(g dt) there; the block-sparse grid must export the same
         un = z["f64_m"] == 0
-        parity(f"substep {tag} grid vs reference f64 run", "v of untouched nodes (abs)", np.abs(gv[un] - z["f64_gv"][un]).max(), 1e-9)
+        parity(f"substep {tag} grid vs reference f64 run", "v of untouched nodes (abs)", np.abs(gv[un] - z["f64_gv"][un]).max(), 2e-9)      # (8.6e-10: g dt in fp32 against fp64)
 
 
 @pytest.mark.parametrize("tag", GRAD_TAGS)

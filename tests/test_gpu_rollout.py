@@ -7,9 +7,13 @@ import torch
 from oracle import material as omat
 from oracle import mpm as om
 from oracle import raster as orr
-from gpu_util import dev, rel_max, abs_max, measured
+from gpu_util import dev, rel_max, abs_max, measured, far_ground_truth
 
 pytestmark = pytest.mark.gpu
+
+# two frames of one runtime against far targets (atomics order only): >= 10x the worst of the measured runs
+# measured on MI355X over 5 runs x 3 modes x 2 scenes (gpurun_out r06b): loss <= 3.2e-7, gradients <= 3.5e-7
+BOUND_FRAME_LOSS, BOUND_FRAME_GRAD = 4e-6, 5e-6
 
 
 def _runtime(name="tiny", fused=True, **over):
@@ -193,6 +197,7 @@ def test_one_node_frame_equals_the_composition_of_nodes(scene, over, monkeypatch
             rt.size = torch.tensor([1.5, 0.8, 1.1], device=dev())
         rt.set_start_state("deformed")      # (at F = I the gradients are run-to-run noise of a cancelling sum in either path)
         rt.make_ground_truth()
+        far_ground_truth(rt)
         res = {}
         # "direct": the two halves called back to back, gradients added to .grad by the runtime (what frame() does);
         # "graph": the same as an autograd node (harness._Frame) through loss.backward(); "nodes": the composition
@@ -219,23 +224,17 @@ def test_one_node_frame_equals_the_composition_of_nodes(scene, over, monkeypatch
         for mode in modes:
             res[mode] = run(mode)
         for mode in ("direct", "joined", "graph"):
-            # two frames of this scene differ by the order of the scatters' float atomics - and, about one comparison in twenty,
-            # by a rasterizer cut-off event in one of them (a pixel gains or loses a 1/255 contribution: 1e-5 .. 1e-3 of a
-            # gradient).  An event is an accident of one pair of frames: up to three pairs, the tight bound in one of them, a
-            # cut-off's worth in all (as test_gpu_train.py::test_render_on_a_second_stream...)
-            worst = None
-            for attempt in range(3):
-                (r0, g0), (r1, g1) = res["nodes"], res[mode]
-                assert torch.isfinite(r1.loss) and abs(float(r1.loss) - float(r0.loss)) < 1e-3 * max(1e-12, abs(float(r0.loss))) + 1e-6
-                assert rel_max(r1.x, r0.x) < 3e-7 and rel_max(r1.F, r0.F) < 7e-7 and r1.F.shape == r0.F.shape      # measured 9.7e-08
-                assert len(g1) == 12 and any(float(g.abs().max()) > 0 for g in g1)
-                assert all(a.shape == b.shape and bool(torch.isfinite(a).all()) for a, b in zip(g1, g0))
-                worst = max(float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30) for a, b in zip(g1, g0))
-                assert worst < 1e-2, (mode, attempt, worst)
-                if worst < 1e-5 and abs(float(r1.loss) - float(r0.loss)) < 1e-6 * max(1.0, abs(float(r0.loss))):
-                    break
-                res["nodes"], res[mode] = run("nodes"), run(mode)
-            assert measured(worst, "rel max of the LoRA gradients, " + mode) < 1e-5      # measured 3.0e-06
+            # two frames of this scene differ by the order of the scatters' float atomics only: the loss is taken against far
+            # targets (gpu_util.far_ground_truth), so that a rasterizer cut-off flipping for a pixel between two frames is below
+            # that noise and the bound holds for every pair (round 5 retried here)
+            (r0, g0), (r1, g1) = res["nodes"], res[mode]
+            assert torch.isfinite(r1.loss) and float(r0.loss) > 1e-3
+            assert measured(abs(float(r1.loss) - float(r0.loss)) / abs(float(r0.loss)), "rel loss, " + mode) < BOUND_FRAME_LOSS
+            assert rel_max(r1.x, r0.x) < 3e-7 and rel_max(r1.F, r0.F) < 7e-7 and r1.F.shape == r0.F.shape      # measured 9.7e-08
+            assert len(g1) == 12 and any(float(g.abs().max()) > 0 for g in g1)
+            assert all(a.shape == b.shape and bool(torch.isfinite(a).all()) for a, b in zip(g1, g0))
+            worst = max(float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30) for a, b in zip(g1, g0))
+            assert measured(worst, "rel max of the LoRA gradients, " + mode) < BOUND_FRAME_GRAD
 
 
 def test_frame_image_matches_oracle_render():
@@ -522,8 +521,8 @@ def test_skipping_the_zero_plasticity_adjoint_of_the_last_substep_changes_nothin
     only, as the reference's (tune/utils.py:353-373) - and the reverse sweep leaves out the last substep's plasticity adjoint, whose
     output and weight gradients are zeros (and the forward sweep that step's SVD / activation records).  Same loss, same twelve
     LoRA gradients as with the launch - up to the order of the scatters' float atomics (two frames of ONE runtime differ by as
-    much: measured 1.8e-6 .. 2.4e-6 over eight runs) and, rarely, a rasterizer cut-off event in one of the two frames: up to
-    three attempts, the tight bounds once, a cut-off's worth always (as test_render_on_a_second_stream...)."""
+    much: measured 1.8e-6 .. 2.4e-6 over eight runs).  Far targets, so that no rasterizer cut-off event can show: three pairs of
+    frames, each held to the bound."""
     from neuma_amd import synth, harness
     from neuma_amd.harness import SceneRuntime
     rt = SceneRuntime(synth.make_scene("tiny", override=dict(S=4, V=2)), dev(), fused=True)
@@ -533,8 +532,8 @@ def test_skipping_the_zero_plasticity_adjoint_of_the_last_substep_changes_nothin
         for p in rt.parameters():
             if p.shape[0] in (64, 9):
                 p.mul_(-4.0)
-    best = None
-    for attempt in range(3):
+    far_ground_truth(rt)        # a cut-off event between the two frames is below the atomics' noise against far targets: every run is held to the bound
+    for attempt in range(3):    # three independent pairs
         res = {}
         for flag in (1, 0):
             monkeypatch.setattr(harness, "_LAST_GF_ZERO", flag)
@@ -544,10 +543,6 @@ def test_skipping_the_zero_plasticity_adjoint_of_the_last_substep_changes_nothin
             res[flag] = (float(r.loss), [p.grad.clone() for p in rt.parameters()])
         dl = abs(res[1][0] - res[0][0]) / abs(res[0][0])
         dg = max(float((a - b).abs().max()) / float(b.abs().max()) for a, b in zip(res[1][1], res[0][1]))
-        assert all(float(b.abs().max()) > 0 for b in res[0][1]) and dl < 1e-3 and dg < 1e-2, (attempt, dl, dg)
-        if best is None or dl + dg < best[0] + best[1]:
-            best = (dl, dg)
-        if dl < 2e-5 and dg < 8e-6:
-            break
-    assert measured(best[0], "rel loss, last plasticity adjoint skipped") < 2e-5
-    assert measured(best[1], "rel max of the LoRA gradients") < 8e-6
+        assert all(float(b.abs().max()) > 0 for b in res[0][1]) and res[0][0] > 1e-3
+        assert measured(dl, "rel loss, last plasticity adjoint skipped (far targets)") < BOUND_FRAME_LOSS
+        assert measured(dg, "rel max of the LoRA gradients (far targets)") < BOUND_FRAME_GRAD

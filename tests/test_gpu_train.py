@@ -2,9 +2,14 @@
 import pytest
 import torch
 
-from gpu_util import dev, measured
+from gpu_util import dev, measured, far_image
 
 pytestmark = pytest.mark.gpu
+
+# equivalence of two schedules against far targets: >= 10x the worst of the measured runs
+# measured on MI355X over 5 x 3 runs (gpurun_out r06b): stream loss <= 9.4e-8, gradients <= 3.3e-7; epoch loss <= 2.4e-7, gradients <= 3.6e-7 (two epochs 1.1e-6)
+BOUND_STREAM_LOSS, BOUND_STREAM_GRAD = 4e-6, 5e-6
+BOUND_EPOCH_LOSS, BOUND_EPOCH_GRAD = 4e-6, 1e-5
 
 
 def test_finetune_recovers_towards_ground_truth_and_checkpoints(tmp_path):
@@ -149,13 +154,12 @@ def test_render_on_a_second_stream_changes_the_schedule_not_the_result():
     rt = SceneRuntime(scene, dev(), fused=True)
     rt.F0 = true.F0.clone()
     c = dict(DEFAULT_CFG, num_frames=4, decay_steps=2, exclude_steps=(3,))
-    # same kernels, different interleaving: equal up to the order of fp32 atomics - which, rarely, flips a rasterizer cut-off for
-    # a pixel (the next test): such an event is worth 1e-5 .. 1e-3 of this loss and fails the comparison about one run in six.
-    # A cut-off event is a discrete accident of one run, a scheduling bug would show in every run: up to three attempts, the
-    # tight bounds must hold in one of them and a cut-off's worth (1e-3 / 1e-2) in all.
-    # measured over nine runs without an event: loss 0 .. 1.8e-6 (a loss of 7e-6: 1e-11 absolute), gradients 3.0e-6 .. 6.2e-6
-    best = None
-    for attempt in range(3):
+    # same kernels, different interleaving: equal up to the order of fp32 atomics.  The loss is taken against FAR targets
+    # (gpu_util.far_image): a rasterizer cut-off flipping for a pixel between the two runs (the next test) is then ~1e-8 of the loss
+    # instead of 1e-5 .. 1e-3, and the bound is demanded of every run - round 5 retried up to three times here, which an
+    # intermittent stream-ordering race could have hidden behind
+    gt = [[far_image(img) for img in views] for views in gt]
+    for attempt in range(3):            # three independent runs, each held to the bound
         res = {}
         for overlap in (False, True):
             for p in rt.parameters():
@@ -164,16 +168,11 @@ def test_render_on_a_second_stream_changes_the_schedule_not_the_result():
             L.backward()
             torch.cuda.synchronize()
             res[overlap] = (float(L), torch.cat([p.grad.reshape(-1) for p in rt.parameters()]).clone())
-        assert res[False][0] > 1e-7
+        assert res[False][0] > 1e-3
         dl = abs(res[True][0] - res[False][0]) / res[False][0]
         dg = float((res[True][1] - res[False][1]).norm()) / float(res[False][1].norm())
-        assert dl < 1e-3 and dg < 1e-2, (attempt, dl, dg)
-        if best is None or dl + dg < best[0] + best[1]:
-            best = (dl, dg)
-        if dl < 6e-6 and dg < 2e-5:
-            break
-    assert measured(best[0], "rel loss, render on a second stream") < 6e-6
-    assert measured(best[1], "rel 2-norm of all gradients") < 2e-5
+        assert measured(dl, "rel loss, render on a second stream (far targets)") < BOUND_STREAM_LOSS
+        assert measured(dg, "rel 2-norm of all gradients (far targets)") < BOUND_STREAM_GRAD
 
 
 def test_loss_differences_between_equivalent_paths_are_rasterizer_cut_off_events():
@@ -233,7 +232,7 @@ def test_native_epoch_matches_the_composition_of_autograd_nodes(overlap):
         for lin in (net.layers[0].fc, net.layers[1].fc, net.final_layer.fc):
             lin.lora_B.data.mul_(40.0)
     frames = 5
-    gt = simulate_video(true, frames)
+    gt = [[far_image(img) for img in vs] for vs in simulate_video(true, frames)]      # far targets: no cut-off event can show (gpu_util.far_image)
     c = dict(DEFAULT_CFG, num_frames=frames, decay_steps=2, exclude_steps=(3,))
     decay = 0.7
     rt = SceneRuntime(scene, dev(), fused=True)
@@ -251,12 +250,12 @@ def test_native_epoch_matches_the_composition_of_autograd_nodes(overlap):
     assert w[2] is None and abs(w[4] - decay ** 2) < 1e-12 and w[0] == 1.0
     loss = rt.epoch(gt, w, views=views, frame_steps=steps, overlap=overlap)
     got = [p.grad.clone() for p in rt.parameters()]
-    assert measured(abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)), "rel loss") <= 5e-5, (float(loss), float(ref_loss))      # measured 3e-7 .. 5e-7, once 1.4e-5 (a rasterizer cut-off flipped for a pixel: a jump, not a rounding error)
+    assert measured(abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)), "rel loss (far targets)") <= BOUND_EPOCH_LOSS, (float(loss), float(ref_loss))
     for a, b in zip(got, ref):
         assert torch.isfinite(a).all()
-        assert measured(float((a - b).abs().max()) / (float(b.abs().max()) + 1e-30), "rel_max LoRA grad") <= 2.5e-4      # measured <= 4.1e-5 in five of seven runs, 7.5e-5 in the two where a rasterizer cut-off flipped for a pixel (rel loss 1.4e-5)
+        assert measured(float((a - b).abs().max()) / (float(b.abs().max()) + 1e-30), "rel_max LoRA grad (far targets)") <= BOUND_EPOCH_GRAD
     # a second epoch accumulates into .grad like loss.backward() does
     rt.epoch(gt, w, views=views, frame_steps=steps, overlap=overlap)
     for a, b in zip([p.grad for p in rt.parameters()], ref):
-        assert measured(float((a - 2 * b).abs().max()) / (float(b.abs().max()) + 1e-30), "rel_max LoRA grad, two epochs") <= 3e-4      # measured <= 8.7e-5 over four runs
+        assert measured(float((a - 2 * b).abs().max()) / (float(b.abs().max()) + 1e-30), "rel_max LoRA grad, two epochs (far targets)") <= 2 * BOUND_EPOCH_GRAD
     assert rt.last_epoch_note["frames_with_activation_cache"] + rt.last_epoch_note["frames_recomputing"] == frames
