@@ -680,8 +680,14 @@ __global__ void __launch_bounds__(256) k_material_fwd(int n, int q, float alpha,
 // trial F -> plasticity net -> F_{t+1} (checkpointed) -> elasticity net -> stress_{t+1}.  F_{t+1} stays in registers between
 // the nets, both nets' operands are staged once, and the launch carries the grid housekeeping of substep t+1 (GridPrologue
 // mode 1 with keep_gv: the velocities are still being gathered here; the grid update of substep t+1 zeroes what drops out).
+// Round 6: the non-FLY instances are held to 256 registers per lane (`__launch_bounds__(256, 2)`; they needed 231 + 16): with
+// the whole budget addressable as VGPRs the compiler keeps the MFMA accumulators in VGPRs and the v_accvgpr_read / _write copies
+// around every GELU go away (52.4 -> 50.1 us per launch, same box).  TWO workgroups per CU - which the bound also allows (74 KB
+// of LDS each) - were built and measured too: 1920 waves of 3-4 tiles, two per SIMD, 51.5 us against 50.1: the SIMD's datapath,
+// not a lone wave's issue rate, is what the lane-per-particle phases fill (f32 MFMA and VALU share it), so a second wave has
+// nothing to run in; the launch stays one workgroup per CU.
 template <bool ACT, bool FLY>
-__global__ void __launch_bounds__(256) k_material_fwd_pair(int n, int q, float alpha, const float* __restrict__ wperm_p,
+__global__ void __launch_bounds__(256, FLY ? 1 : 2) k_material_fwd_pair(int n, int q, float alpha, const float* __restrict__ wperm_p,
                                                            const float* __restrict__ wperm_e, float* __restrict__ F_next,
                                                            float* __restrict__ stress_next, GridPrologue pro, G2pFuse gf,
                                                            float* __restrict__ svd_p, float* __restrict__ svd_e,
@@ -783,10 +789,10 @@ int nm_material_fwd_pair_launch(int32_t n, float alpha_p, const float* wperm_p, 
   hipStream_t s = (hipStream_t)stream;
   GridPrologue gp;
   if (pro) gp = *pro; else { memset(&gp, 0, sizeof(gp)); }
+  const bool fly = g2p->fly != 0;
   gp.mat_grid = grid;
   const int launch = (pro && grid + NM_PRO_WGS <= NM_BWD_GRID) ? grid + NM_PRO_WGS : grid;
   f4 *ap = reinterpret_cast<f4*>(act_p), *ae = reinterpret_cast<f4*>(act_e);
-  const bool fly = g2p->fly != 0;
   if (fly && !(gp.mode == 3 && launch > grid)) { nm_set_error("folded pair launch without prologue workgroups of its own"); return NM_ERR_INVALID; }
   if (ap && ae && fly)
     NM_LAUNCH((k_material_fwd_pair<true, true>), dim3(launch), dim3(256), 0, s, n, q, alpha_p, wperm_p, wperm_e, F_next, stress_next, gp, *g2p,
@@ -844,16 +850,22 @@ struct BwdFuse {
   int polar;              // 0: the reference's SVD adjoint (denominators clamped like warp's adj_svd3); 1: exact polar derivative
   const float* svd_in;    // != NULL: U | sigma | V of the input as the forward kernel left them (svd_store layout)
 };
+// per-wave buffers, one wave's side by side (round 6): every offset inside a wave's 26 KB is a 16-bit DS immediate on the wave's
+// base register; as seven arrays of [4 waves] the ones beyond 64 KB cost a v_add_u32 per access (36 per tile, and VALU issue
+// is what this kernel is made of)
+struct BwdWave {
+  float Z[64 * 17];     // features [particle][17]
+  float GY[64 * 13];    // ybar     [particle][13] (rows 9..12 zero)
+  float Y[64 * 9];      // forward y
+  float GZ[64 * 13];    // zbar     [particle][13]
+  float TA[64 * 17];    // [feature][16 particles + pad]: pre2bar
+  float TB[64 * 17];    //   h2, then pre1bar
+  float TC[64 * 17];    //   h1
+};
 struct BwdLds {
   float P0[16 * 64], P1[64 * 64], P2[16 * 64];
   float Q0[16 * 64], Q1[64 * 64], Q2[12 * 64];
-  float Z[4][64 * 17];    // features [particle][17]
-  float GY[4][64 * 13];   // ybar     [particle][13] (rows 9..12 zero)
-  float Y[4][64 * 9];     // forward y
-  float GZ[4][64 * 13];   // zbar     [particle][13]
-  float TA[4][64 * 17];   // [feature][16 particles + pad]: pre2bar
-  float TB[4][64 * 17];   //   h2, then pre1bar
-  float TC[4][64 * 17];   //   h1
+  BwdWave W[4];
 };
 
 struct BwdArgs {
@@ -866,9 +878,13 @@ struct BwdArgs {
   const f4* act;      // activation cache written by the forward kernel (mlp_forward_tile), or NULL: recompute
 };
 
-template <int KIND, bool ACT>
+// WW: the weight gradients are wanted, known at compile time (the roll-out's pair launches): as a run-time flag the test sat in
+// front of every LDS write of the tile loop - a scalar branch per GELU pair, each the end of a basic block, so that no two
+// GELU chains were ever interleaved (round 6)
+template <int KIND, bool ACT, bool WW = false>
 __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_raw) {
-  const int n = a.n, q = a.q, want_w = a.want_w;
+  const int n = a.n, q = a.q, wmode = a.want_w;
+  const bool want_w = WW ? true : (wmode != 0);
   const float alpha = a.alpha;
   const float* __restrict__ F = a.F;
   const float *__restrict__ w0 = a.w0, *__restrict__ w1 = a.w1, *__restrict__ w2 = a.w2, *__restrict__ wperm = a.wperm;
@@ -939,7 +955,7 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
   if (pbeg < pend) load_round(pbeg, ahead);
   NM_SB();
   if (wperm) {
-    static_assert(offsetof(BwdLds, Z) == NM_PERM_ALL * sizeof(float), "P0..Q2 must be contiguous in operand order");
+    static_assert(offsetof(BwdLds, W) == NM_PERM_ALL * sizeof(float), "P0..Q2 must be contiguous in operand order");
     if (ACT) {      // only the first layer is recomputed: its operands + the transposed ones
       stage_permuted2<16 * 64, NM_PERM_ALL - NM_PERM_FWD, NM_ACT_SLOTS>(wperm, L.P0, wperm + NM_PERM_FWD, L.Q0,
                                                           [&]() { load_first_act(pbeg < pend ? pbeg : 0); });      // (unconditional: NM_ACT_SLOTS loads)
@@ -948,7 +964,8 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
     }
     __syncthreads();
   } else {
-    float* raw = &L.Z[0][0];   // the per-wave buffers (>= 22 016 floats) are free until the main loop
+    static_assert(sizeof(BwdWave) * 4 >= NM_RAWTOT * sizeof(float), "raw weights must fit the per-wave buffers");
+    float* raw = &L.W[0].Z[0];   // the per-wave buffers (26 368 floats, contiguous) are free until the main loop
     stage_raw_weights(w0, w1, w2, raw);
     __syncthreads();
     stage_fwd_weights(raw, L.P0, L.P1, L.P2);
@@ -957,13 +974,13 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
   }
   NM_PH(0)
   const int j = lane & 15, g = lane >> 4;
-  float* zb = L.Z[wave];
-  float* gyb = L.GY[wave];
-  float* yb = L.Y[wave];
-  float* gzb = L.GZ[wave];
-  float* ta = L.TA[wave];
-  float* tb = L.TB[wave];
-  float* tc = L.TC[wave];
+  float* zb = L.W[wave].Z;
+  float* gyb = L.W[wave].GY;
+  float* yb = L.W[wave].Y;
+  float* gzb = L.W[wave].GZ;
+  float* ta = L.W[wave].TA;
+  float* tb = L.W[wave].TB;
+  float* tc = L.W[wave].TC;
   const f4 zero = {0.f, 0.f, 0.f, 0.f};
   f4 gW1[4][4], gW0[4], gW2[4];
 #pragma unroll
@@ -1316,7 +1333,7 @@ __device__ __forceinline__ void material_bwd_body(const BwdArgs& a, char* smem_r
   static_assert(W4 % 256 == 0, "whole 16-byte pieces per thread");
   f4* dst = reinterpret_cast<f4*>(wpart + (size_t)blockIdx.x * NM_WACC);
   f4 prev[WPER];
-  if (want_w == 2) {
+  if (wmode == 2) {
 #pragma unroll
     for (int k = 0; k < WPER; ++k) prev[k] = dst[threadIdx.x + 256 * k];
   } else {
@@ -1356,14 +1373,14 @@ __global__ void __launch_bounds__(256, 1) k_material_bwd(BwdArgs a, GridPrologue
 // second only needs the first's dL/dF of the same particle (a wave owns the same particles in both), so the pair saves a
 // launch boundary - and k_material_bwd's boundaries are expensive: its waves own a SIMD's whole register file, so the
 // neighbouring kernels cannot overlap its ramp-up / drain (~5 us).  `pro` is the grid prologue of substep t-1.
-template <bool ACT>
+template <bool ACT, bool WW>
 __global__ void __launch_bounds__(256, 1) k_material_bwd_pair(BwdArgs e, BwdArgs p, GridPrologue pro) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (NM_PROLOGUE_SPLIT(pro)) return;
-  material_bwd_body<NM_ELASTICITY, ACT>(e, smem_raw);
+  material_bwd_body<NM_ELASTICITY, ACT, WW>(e, smem_raw);
   __threadfence_block();     // dL/dF written by this workgroup's lanes is read back by the same lanes below
   __syncthreads();
-  material_bwd_body<NM_PLASTICITY, ACT>(p, smem_raw);
+  material_bwd_body<NM_PLASTICITY, ACT, WW>(p, smem_raw);
 }
 
 // sum the per-workgroup partials (accumulator order, NM_WACC floats each): a workgroup owns 64 consecutive elements, its four
@@ -1410,13 +1427,17 @@ static int bwd_attr_once() {
                                      (int)sizeof(BwdLds)));
     NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd<NM_PLASTICITY, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)sizeof(BwdLds)));
-    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd_pair<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd_pair<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)sizeof(BwdLds)));
+    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd_pair<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)sizeof(BwdLds)));
     NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd<NM_ELASTICITY, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)sizeof(BwdLds)));
     NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd<NM_PLASTICITY, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)sizeof(BwdLds)));
-    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd_pair<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd_pair<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)sizeof(BwdLds)));
+    NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd_pair<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)sizeof(BwdLds)));
     attr_set = true;
   }
@@ -1478,10 +1499,15 @@ int nm_material_bwd_pair_launch(int32_t n, const float* F_e, const nm_mlp* we, c
   if (rc) return rc;
   BwdArgs e = bwd_args(n, q, 0.f, F_e, we, wperm_e, gS, gF, wpart_e, wmode_e, nullptr, nullptr, 0.f, 1 | (polar ? 2 : 0), svd_in_e, act_e);
   BwdArgs p = bwd_args(n, q, alpha_p, F_p, wp, wperm_p, gF, gFtrial, wpart_p, wmode_p, trial_C, enabled, dt, polar ? 2 : 0, svd_in_p, act_p);
-  if (act_e && act_p)
-    NM_LAUNCH(k_material_bwd_pair<true>, dim3(launch), dim3(256), sizeof(BwdLds), s, e, p, gp);
+  const bool ww = wmode_e != 0 && wmode_p != 0;      // (the reverse sweep of a roll-out whose nets both train: the rule)
+  if (act_e && act_p && ww)
+    NM_LAUNCH((k_material_bwd_pair<true, true>), dim3(launch), dim3(256), sizeof(BwdLds), s, e, p, gp);
+  else if (act_e && act_p)
+    NM_LAUNCH((k_material_bwd_pair<true, false>), dim3(launch), dim3(256), sizeof(BwdLds), s, e, p, gp);
+  else if (ww)
+    NM_LAUNCH((k_material_bwd_pair<false, true>), dim3(launch), dim3(256), sizeof(BwdLds), s, e, p, gp);
   else
-    NM_LAUNCH(k_material_bwd_pair<false>, dim3(launch), dim3(256), sizeof(BwdLds), s, e, p, gp);
+    NM_LAUNCH((k_material_bwd_pair<false, false>), dim3(launch), dim3(256), sizeof(BwdLds), s, e, p, gp);
   NM_LAUNCH_CHECK();
   return NM_OK;
 }
