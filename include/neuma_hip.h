@@ -264,7 +264,8 @@ typedef struct nm_rollout_cfg {
                               * reference's does (the covariance push-forward is not differentiated, tune/utils.py:353-373).  The
                               * last substep's plasticity adjoint then has nothing to propagate (zero dL/dF, zero weight
                               * gradients) and is not launched.  Given to nm_rollout_forward as well, the last plasticity step
-                              * leaves no SVD / activation records (nobody would read them).  0 = make no assumption. */
+                              * leaves no SVD / activation records (nobody would read them); nm_rollout_backward WITHOUT the flag over
+                              * caches whose forward sweep ran with it fails with NM_ERR_INVALID.  0 = make no assumption. */
 } nm_rollout_cfg;
 #define NM_SVD_ADJOINT_REFERENCE 0
 #define NM_SVD_ADJOINT_POLAR 1
@@ -285,11 +286,6 @@ int nm_rollout_forward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cfg, const nm
  * experiments/finetune.py:364 and :362 make back to back across the loop edge - run as ONE launch per substep boundary, F_{t+1}
  * passing from one net to the other in registers; off = one launch per net.  Results are bit-identical either way. */
 int nm_rollout_set_forward_pair(int32_t on);
-/* Experiment kept as a switch (round 5; default off, NEUMA_GRIDOP_FOLD=1 turns it on at load time): the forward sweep launches
- * no grid update (mpm.py:373-429) in front of a pair launch - the launch's g2p forms the node velocities from {mv, m} as it
- * gathers them, and its prologue workgroups write the substep's cache record, wait for the gathers and clear the grid behind
- * them.  Same results (tests/test_gpu_rollout.py); measured slower at 100k particles. */
-int nm_rollout_set_gridop_fold(int32_t on);
 /* gstate_last: dL/d(x,v,C,F of record S) (24*N floats: x|v|C|F); gstate_first: dL/d(x,v,C,F of record 0) (written);
  * gw_e / gw_p: 5504 floats each = dL/d(w0 | w1 | w2) of the elasticity / plasticity nets, summed over
  * particles and substeps (overwritten). */

@@ -144,7 +144,6 @@ SIGNATURES = {
     "nm_rollout_forward": (C.c_int, [_P, _I32, C.POINTER(nm_rollout_cfg), C.POINTER(nm_statics), C.POINTER(nm_mlp),
                                      C.POINTER(nm_mlp), _P, _P, _P, _SZ, _P]),
     "nm_rollout_set_forward_pair": (C.c_int, [_I32]),
-    "nm_rollout_set_gridop_fold": (C.c_int, [_I32]),
     "nm_rollout_backward": (C.c_int, [_P, _I32, C.POINTER(nm_rollout_cfg), C.POINTER(nm_statics), C.POINTER(nm_mlp),
                                       C.POINTER(nm_mlp), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "nm_rollout_svdcache_bytes": (_SZ, [_I32, _I32]),

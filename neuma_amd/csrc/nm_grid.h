@@ -91,8 +91,6 @@ __device__ __forceinline__ float sel3(const float* a, int i) { return i == 0 ? a
 // block-sparse grid's zero; `flags[block] == epoch` marks the blocks this substep built.
 // the loads of a particle's g2p that do not depend on its stencil (issued as a block; g2p_in_load of the NEXT round of a
 // constitutive wave is issued before the current round's MLP, so that its HBM round trip hides behind it)
-struct TagEdge { static constexpr bool value = true; };
-struct TagInner { static constexpr bool value = false; };
 // (x and F stay in the shape their loads return them in - 12 and 16 + 16 + 4 bytes - until g2p_particle unpacks them: as
 //  scalars under a lane predicate the compiler re-packed the loaded registers right behind the loads, which put an HBM round
 //  trip - and, vmcnt counting stores too, the drain of every store of the round before - at the top of each round of the
@@ -119,9 +117,7 @@ __device__ __forceinline__ G2pIn g2p_in_load(int p, const float* __restrict__ cl
   in.Fc = F[(size_t)9 * p + 8];
   return in;
 }
-// FLY (round 5, forward roll-out): `gv` is the {mv, m} array as p2g left it and the node velocities are formed here - the grid
-// update (mpm.py:373-429) evaluated per gathered node instead of by a k_grid_op launch in front of this kernel.
-template <bool UNROLL, bool FILL = false, bool FLY = false>
+template <bool UNROLL, bool FILL = false>
 __device__ __forceinline__ void g2p_particle(const MpmK& K, int p, const G2pIn& in, const float* x,
                                              const float4* __restrict__ gv, float* xn, float* vn, float* Cn, M3& Fo,
                                              const int* __restrict__ flags = nullptr, int epoch = 0, bool fresh = false);
@@ -135,7 +131,7 @@ __device__ __forceinline__ void g2p_particle(const MpmK& K, int p, const float* 
   const G2pIn in = g2p_in_load(p, clip, enabled, x, F);
   g2p_particle<UNROLL, FILL>(K, p, in, x, gv, xn, vn, Cn, Fo, flags, epoch, fresh);
 }
-template <bool UNROLL, bool FILL, bool FLY>
+template <bool UNROLL, bool FILL>
 __device__ __forceinline__ void g2p_particle(const MpmK& K, int p, const G2pIn& in, const float* x,
                                              const float4* __restrict__ gv, float* xn, float* vn, float* Cn, M3& Fo,
                                              const int* __restrict__ flags, int epoch, bool fresh) {
@@ -162,27 +158,7 @@ __device__ __forceinline__ void g2p_particle(const MpmK& K, int p, const G2pIn& 
   float nv[3] = {0.f, 0.f, 0.f};
   M3 nC = m3_zero();
   const float kap = 4.0f * K.inv_dx * K.inv_dx;
-  // FLY: a stencil that stays clear of the boundary layer (and of the padding) needs no boundary condition on any of its nodes
-  bool edge_wave = false;
-  if (FLY) {
-    bool inner = true;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) inner = inner && st.b[a] >= K.bound && st.b[a] + 2 < K.G - K.bound;
-    edge_wave = __ballot(!inner) != 0ull;
-  }
-  // FLY: all 27 nodes are requested first and pinned as unconditional loads (left alone the compiler fetches a node's mass, branches
-  // on it and only then fetches its momentum: two dependent round trips per node); the arithmetic below has no branch on a loaded value
-  float4 gq[FLY ? 27 : 1];
-  if (FLY) {
-#pragma unroll
-    for (int t = 0; t < 27; ++t) gq[t] = gv[node_addr(st.b[0] + t / 9, st.b[1] + (t / 3) % 3, st.b[2] + t % 3, K.nb)];
-#pragma unroll
-    for (int t = 0; t < 27; ++t) asm volatile("" : "+v"(gq[t].x), "+v"(gq[t].y), "+v"(gq[t].z), "+v"(gq[t].w));
-  }
-  // (EDGE is a compile-time tag: a run-time branch per node - even a wave-uniform one - cuts the unrolled body into 27 basic
-  //  blocks, the gathers are no longer hoisted over them and a round's g2p becomes 27 L2 round trips in a row: 3 -> 10 us)
-  auto slab = [&](int i, auto edge_tag) {
-    constexpr bool EDGE = decltype(edge_tag)::value;
+  auto slab = [&](int i) {
     float d0 = ((float)i - st.f[0]) * K.dx;
     const float w0i = sel3(st.w[0], i);
 #pragma unroll
@@ -194,28 +170,7 @@ __device__ __forceinline__ void g2p_particle(const MpmK& K, int p, const G2pIn& 
         float d2 = ((float)k - st.f[2]) * K.dx;
         float w = wij * st.w[2][k];
         const int ni = st.b[0] + i, nj = st.b[1] + j, nk = st.b[2] + k;
-        float4 g = FLY ? gq[FLY ? (i * 9 + j * 3 + k) : 0] : gv[node_addr(ni, nj, nk, K.nb)];
-        if (FLY) {       // g = {mv, m}: the node's velocity as k_grid_op would have stored it (grid_velocity's expressions), without a
-          // branch on the loaded value - the 27 gathers must stay in flight together -: reciprocal + one Newton step instead of
-          // the division's expansion, selects instead of ifs
-          const float d = g.w + K.eps;
-          float inv = __builtin_amdgcn_rcpf(d);
-          inv = __builtin_fmaf(__builtin_fmaf(-d, inv, 1.f), inv, inv);
-          const bool has = g.w > 0.f;
-          g.x = has ? __builtin_fmaf(g.x, inv, K.gdt[0]) : K.gdt[0];
-          g.y = has ? __builtin_fmaf(g.y, inv, K.gdt[1]) : K.gdt[1];
-          g.z = has ? __builtin_fmaf(g.z, inv, K.gdt[2]) : K.gdt[2];
-          if (EDGE) {           // (some lane's stencil touches the boundary layer or the padding: whole wave, selects per lane)
-            const bool in_range = ni < K.G && nj < K.G && nk < K.G;
-            const bool h0 = (ni < K.bound && g.x < 0.f) || (ni >= K.G - K.bound && g.x > 0.f);
-            const bool h1 = (nj < K.bound && g.y < 0.f) || (nj >= K.G - K.bound && g.y > 0.f);
-            const bool h2 = (nk < K.bound && g.z < 0.f) || (nk >= K.G - K.bound && g.z > 0.f);
-            const bool any = h0 || h1 || h2;
-            const bool z0 = !in_range || (K.bc == 0 ? any : h0), z1 = !in_range || (K.bc == 0 ? any : h1),
-                       z2 = !in_range || (K.bc == 0 ? any : h2);
-            g.x = z0 ? 0.f : g.x; g.y = z1 ? 0.f : g.y; g.z = z2 ? 0.f : g.z;
-          }
-        }
+        float4 g = gv[node_addr(ni, nj, nk, K.nb)];
         if (FILL) {
           if (ni < K.G && nj < K.G && nk < K.G && flags[((ni >> 2) * K.nb + (nj >> 2)) * K.nb + (nk >> 2)] != epoch) {
             const float4 empty = {0.f, 0.f, 0.f, 0.f};
@@ -233,11 +188,10 @@ __device__ __forceinline__ void g2p_particle(const MpmK& K, int p, const G2pIn& 
     }
   };
   if (UNROLL) {
-    if (FLY && edge_wave) { slab(0, TagEdge{}); slab(1, TagEdge{}); slab(2, TagEdge{}); }
-    else { slab(0, TagInner{}); slab(1, TagInner{}); slab(2, TagInner{}); }
+    slab(0); slab(1); slab(2);
   } else {
 #pragma unroll 1
-    for (int i = 0; i < 3; ++i) slab(i, TagInner{});
+    for (int i = 0; i < 3; ++i) slab(i);
   }
   M3 T = nC;
 #pragma unroll
@@ -257,9 +211,7 @@ __device__ __forceinline__ void g2p_particle(const MpmK& K, int p, const G2pIn& 
 
 // g2p of the substep fused into the plasticity kernel that consumes its trial F (roll-out forward): gv == NULL -> off
 struct G2pFuse {
-  const float4* gv;      // node velocities - or, with fly != 0, the {mv, m} array (velocities formed per gathered node)
-  int fly;
-  int* done;             // fly: every wave adds one here once its last gather has returned (GridPrologue mode 3 waits for it)
+  const float4* gv;      // node velocities
   MpmK K;
   const float *clip; const int* enabled;
   const float *x, *v, *C, *F;
@@ -359,11 +311,6 @@ __device__ __forceinline__ void grid_restore(const MpmK& K, const GridRec& rec, 
 //           previous list that is also in the record (flags[b] == epoch - stamped by the previous substep's
 //           k_grid_op_bwd, which knows the next record) only has its adjoint scratch zeroed, because its {mv, m} and v
 //           are being overwritten by whichever workgroup restores it; a block that left the list is zeroed entirely.
-//   mode 3 (round 5, forward pair launch that forms the node velocities itself - no k_grid_op in front of it): the extra
-//           workgroups first write the substep's cache record from {mv, m} (k_grid_op's other duty), then WAIT until every
-//           particle wave of the launch has finished its gathers (G2pFuse.done reaches done_target) and only then run the
-//           clear + carry of mode 1 - which zeroes the very {mv, m} the gathers read.  Only on workgroups of their own,
-//           dispatched behind the particle workgroups (they spin; the waves they wait for are running by then).
 struct GridPrologue {
   int mode;   // 0 = none
   int keep_gv;    // mode 1 only: leave the velocity array alone (see grid_clear_carry)
@@ -375,48 +322,12 @@ struct GridPrologue {
   int* flags;
   int epoch;
   GridRec rec;
-  int rec_cap;          // mode 3: capacity of rec (blocks); rec.hdr == NULL: no record is kept
-  const int* done;      // mode 3
-  int done_target;
-  int* status;          // mode 3: bit 32 if the wait gave up (never seen; the clear then runs anyway)
 };
 
 __device__ __forceinline__ void grid_prologue_clear(const GridPrologue& g, int wg, int nwg_all) {      // mode 1 alone
   const int nwg = min(nwg_all, NM_CLEAR_WGS);
   if (wg < nwg) grid_clear_carry(g.gm, g.gv, g.gg, g.list_prev, g.count_prev, g.list_now, g.count_now, g.count_next, g.flags,
                                  g.epoch, wg, nwg, g.keep_gv != 0);
-}
-__device__ __forceinline__ void grid_prologue_fly(const GridPrologue& g, int wg, int nwg_all) {        // mode 3 alone
-  const int nwg = min(nwg_all, NM_CLEAR_WGS);
-  {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (wg < nwg) {
-      // (a) the cache record of the substep whose {mv, m} the grid holds: list_prev is that substep's list
-      const int cnt = *g.count_prev;
-      if (g.rec.hdr) {
-        const bool save = cnt <= g.rec_cap;
-        if (wg == 0 && threadIdx.x == 0) g.rec.hdr[0] = save ? cnt : -1;
-        if (save)
-          for (int li = wg * 4 + wave; li < cnt; li += nwg * 4) {
-            const int b = g.list_prev[li];
-            g.rec.gm[(li << 6) + lane] = g.gm[(b << 6) + lane];
-            if (lane == 0) g.rec.list[li] = b;
-          }
-      }
-      // (b) every particle wave has its velocities: wait (the counter is monotone across launches)
-      if (threadIdx.x == 0) {
-        int spins = 0;
-        while (__hip_atomic_load(g.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g.done_target < 0) {
-          __builtin_amdgcn_s_sleep(32);
-          if (++spins > (1 << 18)) { if (g.status) atomicOr(g.status, 32); break; }      // (~0.3 s: a wait lasts < 100 us)
-        }
-      }
-      __syncthreads();
-      // (c) clear + carry, velocities included (nothing reads them between two folded substeps)
-      grid_clear_carry(g.gm, g.gv, g.gg, g.list_prev, g.count_prev, g.list_now, g.count_now, g.count_next, g.flags, g.epoch, wg, nwg,
-                       false);
-    }
-  }
 }
 __device__ __forceinline__ void grid_prologue(const GridPrologue& g, int wg, int nwg_all) {
   if (g.mode == 0) return;
@@ -448,10 +359,6 @@ __device__ __forceinline__ void grid_prologue(const GridPrologue& g, int wg, int
 
 // ---- internal cross-file entry points of the fused roll-out (nm_rollout.hip)
 int nm_mpm_prologue_forward(nm_mpm* h, GridPrologue* g, bool keep_gv = false);
-// round 5: the forward pair launch forms the node velocities itself (no k_grid_op): fills mode 3 of the prologue and the fly
-// fields of the g2p descriptor; `waves` = particle waves of the launch (nm_material_fwd_pair_fly_waves)
-int nm_mpm_prologue_forward_fly(nm_mpm* h, void* gridrec, int cap, int waves, GridPrologue* g, G2pFuse* f, void* stream);
-int nm_material_fwd_pair_fly_waves(int32_t n);      // 0: the launch has no workgroups to spare for a waiting prologue
 int nm_mpm_prologue_backward(nm_mpm* h, const void* gridrec, int cap, GridPrologue* g);
 int nm_mpm_forward_prepared(nm_mpm* h, int32_t n, const nm_statics* st, const nm_particles* cur, nm_particles* next, void* gridrec,
                             int32_t cap_blocks, void* stream);

@@ -53,18 +53,16 @@ __device__ __forceinline__ bool material_prologue(const GridPrologue& pro) {
   grid_prologue(pro, blockIdx.x, gridDim.x);
   return false;
 }
-// forward pair kernel: mode 1 (clear + carry) or - FLY - mode 3 only; the restore of mode 2 is not compiled in
-template <bool FLY>
+// forward pair kernel: mode 1 (clear + carry) only; the restore of mode 2 is not compiled in
 __device__ __forceinline__ bool material_prologue_fwd(const GridPrologue& pro) {
   if (pro.mode == 0) return false;
   const int mat = pro.mat_grid;
   if ((int)gridDim.x > mat) {
     if ((int)blockIdx.x < mat) return false;
-    if (FLY) grid_prologue_fly(pro, blockIdx.x - mat, gridDim.x - mat);
-    else grid_prologue_clear(pro, blockIdx.x - mat, gridDim.x - mat);
+    grid_prologue_clear(pro, blockIdx.x - mat, gridDim.x - mat);
     return true;
   }
-  if (!FLY) grid_prologue_clear(pro, blockIdx.x, gridDim.x);
+  grid_prologue_clear(pro, blockIdx.x, gridDim.x);
   return false;
 }
 #define NM_W0 (64 * 13)
@@ -680,14 +678,14 @@ __global__ void __launch_bounds__(256) k_material_fwd(int n, int q, float alpha,
 // trial F -> plasticity net -> F_{t+1} (checkpointed) -> elasticity net -> stress_{t+1}.  F_{t+1} stays in registers between
 // the nets, both nets' operands are staged once, and the launch carries the grid housekeeping of substep t+1 (GridPrologue
 // mode 1 with keep_gv: the velocities are still being gathered here; the grid update of substep t+1 zeroes what drops out).
-// Round 6: the non-FLY instances are held to 256 registers per lane (`__launch_bounds__(256, 2)`; they needed 231 + 16): with
-// the whole budget addressable as VGPRs the compiler keeps the MFMA accumulators in VGPRs and the v_accvgpr_read / _write copies
-// around every GELU go away (52.4 -> 50.1 us per launch, same box).  TWO workgroups per CU - which the bound also allows (74 KB
-// of LDS each) - were built and measured too: 1920 waves of 3-4 tiles, two per SIMD, 51.5 us against 50.1: the SIMD's datapath,
-// not a lone wave's issue rate, is what the lane-per-particle phases fill (f32 MFMA and VALU share it), so a second wave has
-// nothing to run in; the launch stays one workgroup per CU.
-template <bool ACT, bool FLY>
-__global__ void __launch_bounds__(256, FLY ? 1 : 2) k_material_fwd_pair(int n, int q, float alpha, const float* __restrict__ wperm_p,
+// Round 6: the kernel is held to 256 registers per lane (`__launch_bounds__(256, 2)`; it needed 231 + 16): with the whole
+// budget addressable as VGPRs the compiler keeps the MFMA accumulators in VGPRs and the v_accvgpr_read / _write copies around
+// every GELU go away (52.4 -> 50.1 us per launch, same box).  TWO workgroups per CU - which the bound also allows (74 KB of LDS
+// each) - were built and measured too: 1920 waves of 3-4 tiles, two per SIMD, 51.5 us against 50.1: the SIMD's datapath, not a
+// lone wave's issue rate, is what the lane-per-particle phases fill (f32 MFMA and VALU share it), so a second wave has nothing
+// to run in; the launch stays one workgroup per CU.
+template <bool ACT>
+__global__ void __launch_bounds__(256, 2) k_material_fwd_pair(int n, int q, float alpha, const float* __restrict__ wperm_p,
                                                            const float* __restrict__ wperm_e, float* __restrict__ F_next,
                                                            float* __restrict__ stress_next, GridPrologue pro, G2pFuse gf,
                                                            float* __restrict__ svd_p, float* __restrict__ svd_e,
@@ -697,9 +695,7 @@ __global__ void __launch_bounds__(256, FLY ? 1 : 2) k_material_fwd_pair(int n, i
   __shared__ __attribute__((aligned(16))) float sBuf[4 * 64 * 17 + 4 * 64 * 9];
   float (*sZ)[64 * 17] = reinterpret_cast<float (*)[64 * 17]>(sBuf);
   float (*sY)[64 * 9] = reinterpret_cast<float (*)[64 * 9]>(sBuf + 4 * 64 * 17);
-  // (FLY is a template parameter, not a run-time branch: with both g2p bodies inlined the kernel was 73 KB of code - past the
-  //  64 KB instruction cache two CUs share - and every wave ran 1.4x slower, whatever it executed)
-  if (material_prologue_fwd<FLY>(pro)) return;
+  if (material_prologue_fwd(pro)) return;
   NM_PH_DECL
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int pbeg = min(n, (blockIdx.x * 4 + wave) * q), pend = min(n, pbeg + q);
@@ -708,8 +704,6 @@ __global__ void __launch_bounds__(256, FLY ? 1 : 2) k_material_fwd_pair(int n, i
   // HBM round trip (~2 us) doing nothing
   // (unconditional, at a clamped index - a lane without a particle loads the last one's and ignores it: see G2pIn)
   G2pIn nxt = g2p_in_load(min(pbeg + lane, n - 1), gf.clip, gf.enabled, gf.x, gf.F);
-  if (FLY && pbeg >= pend && lane == 0)      // a wave without particles gathers nothing: it is done at once
-    __hip_atomic_fetch_add(gf.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   NM_SB();
   stage_permuted2<NM_PERM_FWD, NM_PERM_FWD, 0>(wperm_p, sPp, wperm_e, sPe, NoHook());     // both nets: one round trip
   __syncthreads();
@@ -724,22 +718,7 @@ __global__ void __launch_bounds__(256, FLY ? 1 : 2) k_material_fwd_pair(int n, i
     const G2pIn cur = nxt;
     nxt = g2p_in_load(min(p + 64, n - 1), gf.clip, gf.enabled, gf.x, gf.F);      // (also in the last round: nothing conditional)
     NM_SB();
-    if (FLY) {      // velocities formed from {mv, m} per gathered node: no k_grid_op ran
-      if (valid) g2p_particle<true, false, true>(gf.K, p, cur, gf.x, gf.gv, gf.xn, gf.vn, gf.Cn, Ftr, nullptr, 0, true);
-      if (c0 + 64 >= pend) {
-        // this wave's last gathers have returned (their values are in Ftr / the stored state): tell the prologue workgroups,
-        // which are waiting to clear the array they came from.  Loads retire in order and vmcnt(0) is all it takes - a WAR
-        // hazard needs no cache maintenance, and a release fence at agent scope would write the L2 back (§5)
-        // (not s_waitcnt vmcnt(0): that also waits for the wave's outstanding STORES - the previous round's activation records -
-        //  5 us on average.  The increment is made to depend on a value computed from the gathers instead: an instruction that
-        //  reads it cannot issue before the loads behind it have returned, and vmcnt retires loads in order)
-        int zero;
-        asm volatile("v_and_b32 %0, 0, %1" : "=v"(zero) : "v"(Ftr.m[0] + Ftr.m[4] + Ftr.m[8]) : "memory");
-        if (lane == 0) __hip_atomic_fetch_add(gf.done, 1 + zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    } else if (valid) {
-      g2p_particle<true>(gf.K, p, cur, gf.x, gf.gv, gf.xn, gf.vn, gf.Cn, Ftr, nullptr, 0, true);
-    }
+    if (valid) g2p_particle<true>(gf.K, p, cur, gf.x, gf.gv, gf.xn, gf.vn, gf.Cn, Ftr, nullptr, 0, true);
     NM_PH(1)
     const M3 Fn = material_fwd_round<NM_PLASTICITY, ACT>(Ftr, valid, n, p, c0, ntile, lane, alpha, sPp, sPp + 16 * 64,
                                                          sPp + 16 * 64 + 64 * 64, zb, yb, svd_p, act_p);
@@ -789,32 +768,17 @@ int nm_material_fwd_pair_launch(int32_t n, float alpha_p, const float* wperm_p, 
   hipStream_t s = (hipStream_t)stream;
   GridPrologue gp;
   if (pro) gp = *pro; else { memset(&gp, 0, sizeof(gp)); }
-  const bool fly = g2p->fly != 0;
   gp.mat_grid = grid;
   const int launch = (pro && grid + NM_PRO_WGS <= NM_BWD_GRID) ? grid + NM_PRO_WGS : grid;
   f4 *ap = reinterpret_cast<f4*>(act_p), *ae = reinterpret_cast<f4*>(act_e);
-  if (fly && !(gp.mode == 3 && launch > grid)) { nm_set_error("folded pair launch without prologue workgroups of its own"); return NM_ERR_INVALID; }
-  if (ap && ae && fly)
-    NM_LAUNCH((k_material_fwd_pair<true, true>), dim3(launch), dim3(256), 0, s, n, q, alpha_p, wperm_p, wperm_e, F_next, stress_next, gp, *g2p,
-              svd_p, svd_e, ap, ae);
-  else if (ap && ae)
-    NM_LAUNCH((k_material_fwd_pair<true, false>), dim3(launch), dim3(256), 0, s, n, q, alpha_p, wperm_p, wperm_e, F_next, stress_next, gp, *g2p,
-              svd_p, svd_e, ap, ae);
-  else if (fly)
-    NM_LAUNCH((k_material_fwd_pair<false, true>), dim3(launch), dim3(256), 0, s, n, q, alpha_p, wperm_p, wperm_e, F_next, stress_next, gp, *g2p,
+  if (ap && ae)
+    NM_LAUNCH(k_material_fwd_pair<true>, dim3(launch), dim3(256), 0, s, n, q, alpha_p, wperm_p, wperm_e, F_next, stress_next, gp, *g2p,
               svd_p, svd_e, ap, ae);
   else
-    NM_LAUNCH((k_material_fwd_pair<false, false>), dim3(launch), dim3(256), 0, s, n, q, alpha_p, wperm_p, wperm_e, F_next, stress_next, gp, *g2p,
+    NM_LAUNCH(k_material_fwd_pair<false>, dim3(launch), dim3(256), 0, s, n, q, alpha_p, wperm_p, wperm_e, F_next, stress_next, gp, *g2p,
               svd_p, svd_e, ap, ae);
   NM_LAUNCH_CHECK();
   return NM_OK;
-}
-// particle waves of a forward pair launch that has workgroups to spare for a prologue of its own (0: it has none - the
-// prologue then runs on the first particle workgroups, before their particles, and cannot wait for anybody)
-int nm_material_fwd_pair_fly_waves(int32_t n) {
-  int grid, q;
-  nm_wave_quota(n, grid, q);
-  return (n > 0 && grid + NM_PRO_WGS <= NM_BWD_GRID) ? 4 * grid : 0;
 }
 int nm_material_prepare(const nm_mlp* w, float* wperm, void* stream) {
   NM_LAUNCH(k_permute_weights, dim3(1), dim3(256), 0, (hipStream_t)stream, w->w0, w->w1, w->w2, wperm, (const float*)nullptr,

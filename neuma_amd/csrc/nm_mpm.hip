@@ -50,7 +50,6 @@ struct nm_mpm {
   int resident_epoch;         // ... as long as the epoch has not moved: the reverse sweep's first substep then restores nothing
   int gv_stale;   // the last clear left the velocity array alone (GridPrologue keep_gv): the next grid update zeroes what dropped out
   int fresh_rows; // g2p writes a fresh state's values into the rows of disabled particles (roll-out checkpoints, nm_grid.h)
-  int fly_target; // what count[6] reads once every particle wave of the folded forward launches enqueued so far has gathered
 };
 void nm_mpm_set_fresh_rows(nm_mpm* h, int on) { h->fresh_rows = on; }
 
@@ -1365,7 +1364,6 @@ extern "C" int nm_mpm_create(const nm_mpm_cfg* cfg, nm_mpm** out) {
   h->cur = 0;
   h->epoch = 0;
   h->gv_stale = 0;
-  h->fly_target = 0;
   h->resident_rec = nullptr; h->resident_epoch = -1;
   h->sh_cnt = h->sh_pos = nullptr;
   *out = h;
@@ -1475,27 +1473,6 @@ int nm_mpm_prologue_forward(nm_mpm* h, GridPrologue* g, bool keep_gv) {
   g->rec.hdr = nullptr; g->rec.list = nullptr; g->rec.gm = nullptr;
   return NM_OK;
 }
-int nm_mpm_prologue_forward_fly(nm_mpm* h, void* gridrec, int cap, int waves, GridPrologue* g, G2pFuse* f, void* stream) {
-  if (h->fly_target > (1 << 30)) {      // (the counter is compared by difference; start over long before it wraps)
-    NM_HIP_CHECK(hipMemsetAsync(h->count + 6, 0, sizeof(int), (hipStream_t)stream));
-    h->fly_target = 0;
-  }
-  nm_mpm_prologue_forward(h, g, false);
-  h->resident_rec = nullptr;            // (no velocities are stored for this substep: nothing for a reverse sweep to find resident)
-  h->gv_stale = 0;
-  g->mode = 3;
-  if (gridrec && cap > 0) g->rec = gridrec_at(gridrec, cap);
-  g->rec_cap = cap;
-  int* done = h->count + 6;             // (count[0..2]: the three lists, [4..5]: nm_mpm_grid_stats, [6]: this counter - monotone)
-  h->fly_target += waves;
-  g->done = done;
-  g->done_target = h->fly_target;
-  g->status = nullptr;
-  f->gv = h->gm;                        // the particle waves gather {mv, m} and form the velocities themselves
-  f->fly = 1;
-  f->done = done;
-  return NM_OK;
-}
 int nm_mpm_prologue_backward(nm_mpm* h, const void* gridrec, int cap, GridPrologue* g) {
   NM_REQUIRE(gridrec && cap > 0, "prologue restore needs a grid cache record");
   nm_mpm_prologue_forward(h, g);
@@ -1561,7 +1538,6 @@ int nm_mpm_g2p_fuse(nm_mpm* h, const nm_statics* st, const nm_particles* cur, nm
   if (rc) return rc;
   NM_REQUIRE(next && next->x && next->v && next->C, "null next state");
   f->gv = h->gv; f->K = h->k;
-  f->fly = 0; f->done = nullptr;
   f->clip = st->clip_bound; f->enabled = st->enabled;
   f->x = cur->x; f->v = cur->v; f->C = cur->C; f->F = cur->F;
   f->xn = next->x; f->vn = next->v; f->Cn = next->C;

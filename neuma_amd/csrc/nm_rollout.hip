@@ -117,11 +117,26 @@ extern "C" int nm_rollout_cache_status(const void* gridcache, const nm_rollout_c
 static int g_forward_pair = 1;
 // forward sweep: no k_grid_op in front of a pair launch (velocities formed inside its g2p, GridPrologue mode 3).  OFF by default:
 // built, correct, measured 22 us per substep SLOWER at the metric size - kept as a switch with its test
-static int g_gridop_fold = [] { const char* e = getenv("NEUMA_GRIDOP_FOLD"); return (e && e[0] == '1') ? 1 : 0; }();
-extern "C" int nm_rollout_set_gridop_fold(int32_t on) {
-  g_gridop_fold = on ? 1 : 0;
-  return NM_OK;
+// Cache buffers whose last-substep plasticity records the forward sweep did NOT write (nm_rollout_cfg.last_gF_zero given to
+// nm_rollout_forward): a reverse sweep over the same buffers without the flag would read a previous frame's records from the
+// pooled buffer and return wrong gradients with no error.  Host-side bookkeeping keyed by the cache pointers (a forward sweep
+// that writes the records takes the entry out again); the reverse sweep refuses the mismatch.
+#include <mutex>
+#include <unordered_set>
+static std::mutex g_skip_mu;
+static std::unordered_set<const void*> g_skipped_last;
+static void note_last_records(const nm_rollout_cfg* cfg, bool skipped) {
+  std::lock_guard<std::mutex> lk(g_skip_mu);
+  for (const void* key : {(const void*)cfg->svd_cache, (const void*)cfg->act_cache}) {
+    if (!key) continue;
+    if (skipped) g_skipped_last.insert(key); else g_skipped_last.erase(key);
+  }
 }
+static bool last_records_missing(const nm_rollout_cfg* cfg) {
+  std::lock_guard<std::mutex> lk(g_skip_mu);
+  return (cfg->svd_cache && g_skipped_last.count(cfg->svd_cache)) || (cfg->act_cache && g_skipped_last.count(cfg->act_cache));
+}
+
 extern "C" int nm_rollout_set_forward_pair(int32_t on) {
   g_forward_pair = on ? 1 : 0;
   return NM_OK;
@@ -153,23 +168,15 @@ extern "C" int nm_rollout_forward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cf
     }
     // p2g + grid update here; the substep's g2p runs inside the plasticity kernel, which consumes its trial F from
     // registers (the reverse sweep recomputes the trial F from the checkpointed C', so it is never stored).
-    // Round 5: in front of a pair launch that has workgroups to spare, the grid update is not launched at all - the pair kernel's
-    // g2p forms the node velocities from {mv, m} as it gathers them, and its prologue workgroups write the cache record, wait for
-    // the gathers and clear the grid behind them (GridPrologue mode 3; nm_rollout_set_gridop_fold / NEUMA_GRIDOP_FOLD=1, off by default)
-    const int fly_waves = (g_forward_pair && g_gridop_fold && t + 1 < cfg->substeps) ? nm_material_fwd_pair_fly_waves(n) : 0;
-    if (fly_waves > 0) rc = nm_mpm_forward_prepared_p2g(h, n, st, &cur, stream);
-    else rc = nm_mpm_forward_prepared_nog2p(h, n, st, &cur, grid_rec(gridcache, cfg, t), cfg->grid_cache_blocks, stream);  // finetune.py:363
+    // (round 5 also built a variant without the grid-update launch - the pair kernel's g2p forming the node velocities from
+    //  {mv, m}, its prologue workgroups waiting for the gathers before they clear the grid: 56 -> 84 us for the 5 us saved, and a
+    //  wait between workgroups of one launch; removed in round 6)
+    rc = nm_mpm_forward_prepared_nog2p(h, n, st, &cur, grid_rec(gridcache, cfg, t), cfg->grid_cache_blocks, stream);  // finetune.py:363
     if (rc) return rc;
     G2pFuse g2p;
     rc = nm_mpm_g2p_fuse(h, st, &cur, &nxt, &g2p);
     if (rc) return rc;
-    if (fly_waves > 0) {
-      GridPrologue pro;
-      rc = nm_mpm_prologue_forward_fly(h, grid_rec(gridcache, cfg, t), cfg->grid_cache_blocks, fly_waves, &pro, &g2p, stream);
-      if (rc) return rc;
-      rc = nm_material_fwd_pair_launch(n, cfg->plasticity_alpha, w.perm_p, w.perm_e, nxt.F, nxt.stress, &pro, &g2p, stream,
-                                       svd_rec(cfg, n, t, 1), svd_rec(cfg, n, t + 1, 0), act_rec(cfg, n, t, 1), act_rec(cfg, n, t + 1, 0));
-    } else if (g_forward_pair && t + 1 < cfg->substeps) {
+    if (g_forward_pair && t + 1 < cfg->substeps) {
       // plasticity of this substep and elasticity of the next in one launch (F_{t+1} goes from one net to the other in
       // registers), which also carries the grid clear of substep t+1 - with the velocities left in place, because this very
       // launch gathers them (finetune.py:364 -> :362 of the next iteration)
@@ -182,6 +189,7 @@ extern "C" int nm_rollout_forward(nm_mpm* h, int32_t n, const nm_rollout_cfg* cf
       // (last_gF_zero: the reverse sweep will not visit the last substep's plasticity adjoint - nobody reads its SVD / activation
       //  records, 74 MB at the metric size; the pair launches' records are untouched by this)
       const bool unread = cfg->last_gF_zero != 0 && cfg->substeps >= 2 && t == cfg->substeps - 1;
+      if (t == cfg->substeps - 1) note_last_records(cfg, unread);
       rc = nm_material_fwd_launch(n, NM_PLASTICITY, cfg->plasticity_alpha, nullptr, wp, w.perm_p, nxt.F, nullptr, &g2p, stream,
                                   unread ? nullptr : svd_rec(cfg, n, t, 1), unread ? nullptr : act_rec(cfg, n, t, 1));  // finetune.py:364
     }
@@ -220,6 +228,11 @@ extern "C" int nm_rollout_backward(nm_mpm* h, int32_t n, const nm_rollout_cfg* c
   bool restored = false;   // the grid of the substep about to be visited was restored by the previous launch's prologue
   // (with one substep there is no pair launch that could write the plasticity partials in its place)
   const bool skip_last = cfg->last_gF_zero != 0 && cfg->substeps >= 2;
+  if (!skip_last && cfg->substeps >= 2 && last_records_missing(cfg)) {
+    nm_set_error("nm_rollout_backward without last_gF_zero on caches whose forward sweep ran with it: the last substep's "
+                 "plasticity SVD / activation records were not written (give the flag to both calls or to neither)");
+    return NM_ERR_INVALID;
+  }
   for (int t = cfg->substeps - 1; t >= 0; --t) {
     nm_particles cur = rec(states_m, n, t), nxt = rec(states_m, n, t + 1);
     float* gout = (t == 0) ? gstate_first : ((gin == w.ga) ? w.gb : w.ga);

@@ -455,13 +455,8 @@ def test_forward_pair_launch_equals_one_launch_per_net():
     gw = [torch.randn(rt.N, 3, generator=gen).to(dev()), torch.randn(rt.N, 3, 3, generator=gen).to(dev())]
     res = {}
     try:
-        # on = 2: the pair launch with nm_rollout_set_gridop_fold(1) - no k_grid_op in front of it, the node velocities formed inside
-        # its g2p from {mv, m} (boundary conditions included: the ball reaches the floor on the way), the substep's cache record
-        # written and the grid cleared by the launch's prologue workgroups once every wave has gathered (an experiment kept as a
-        # switch, off by default: same results, slower)
-        for on in (1, 0, 2):
+        for on in (1, 0):
             assert _lib.lib().nm_rollout_set_forward_pair(1 if on else 0) == 0
-            assert _lib.lib().nm_rollout_set_gridop_fold(1 if on == 2 else 0) == 0
             for p in params:
                 p.grad = None
             ins = [t.clone().requires_grad_(True) for t in (rt.x0, rt.v0)]
@@ -471,8 +466,7 @@ def test_forward_pair_launch_equals_one_launch_per_net():
             res[on] = ([o.detach().clone() for o in out] + [m, vg], [t.grad.clone() for t in ins + params])
     finally:
         _lib.lib().nm_rollout_set_forward_pair(1)
-        _lib.lib().nm_rollout_set_gridop_fold(0)
-    for on in (1, 2):
+    for on in (1,):
         for a, b in zip(res[on][0], res[0][0]):
             assert torch.isfinite(a).all() and rel_max(a, b) < 2e-5, on
         for a, b in zip(res[on][1], res[0][1]):
@@ -546,3 +540,33 @@ def test_skipping_the_zero_plasticity_adjoint_of_the_last_substep_changes_nothin
         assert all(float(b.abs().max()) > 0 for b in res[0][1]) and res[0][0] > 1e-3
         assert measured(dl, "rel loss, last plasticity adjoint skipped (far targets)") < BOUND_FRAME_LOSS
         assert measured(dg, "rel max of the LoRA gradients (far targets)") < BOUND_FRAME_GRAD
+
+
+def test_reverse_sweep_refuses_caches_whose_forward_skipped_the_last_records(monkeypatch):
+    """nm_rollout_cfg.last_gF_zero on the forward side only: the last plasticity step's SVD / activation records were not written,
+    the pooled cache buffers still hold an earlier frame's - a reverse sweep that asks for them gets NM_ERR_INVALID instead of
+    stale records.  The library keeps the skipped buffers in a host-side set; a forward sweep that writes the
+    records takes them out again."""
+    from neuma_amd import synth, harness, _lib
+    from neuma_amd.harness import SceneRuntime
+    rt = SceneRuntime(synth.make_scene("tiny", override=dict(S=4, V=2)), dev(), fused=True)
+    rt.set_start_state("deformed")
+    rt.make_ground_truth()
+    rt.frame()                                  # (both sides with the flag: fine)
+    real = harness._frame_backward
+
+    def other_word(rt_, fs):
+        monkeypatch.setattr(harness, "_LAST_GF_ZERO", 0)
+        return real(rt_, fs)
+
+    monkeypatch.setattr(harness, "_LAST_GF_ZERO", 1)
+    monkeypatch.setattr(harness, "_frame_backward", other_word)
+    with pytest.raises(_lib.NeumaHipError, match="last_gF_zero"):
+        rt.frame()
+    monkeypatch.setattr(harness, "_frame_backward", real)
+    for flag in (0, 1):                         # neither side / both sides: the same buffers serve again
+        monkeypatch.setattr(harness, "_LAST_GF_ZERO", flag)
+        for p in rt.parameters():
+            p.grad = None
+        r = rt.frame()
+        assert torch.isfinite(r.loss) and all(torch.isfinite(p.grad).all() for p in rt.parameters())
