@@ -614,23 +614,20 @@ def main():
                              "the simulation of frame f+1) + one reverse sweep; finetune.py:331-414",
                      args.workload: measure_epoch(rt, args.epoch_frames, fps)}
             from neuma_amd import rollout as _R
-            _R._POOL.clear()                 # (the pooled cache buffers of one measurement would count towards the next one's peak)
-            torch.cuda.empty_cache()
+            _R.trim_pool()                   # (the pooled cache buffers of one measurement would count towards the next one's peak)
             # the same epoch without the activation cache: the speed / memory trade as a measured pair (the reference: "an 80 GB
             # A100", README.md:202; experiments/finetune.py:331-414)
             epoch[args.workload + " recompute"] = measure_epoch(rt, args.epoch_frames, fps, reps=3, recompute=True)
             # a training run on the same runtime: the epoch above re-runs identical weights; this one steps them
             try:
-                _R._POOL.clear()
-                torch.cuda.empty_cache()
+                _R.trim_pool()
                 epoch["train"] = measure_training(rt, args.epoch_frames, epoch[args.workload]["frames_per_s"])
             except Exception as e:
                 import traceback
                 print(f"[bench] training leg failed: {e}\n{traceback.format_exc()}", file=sys.stderr)
                 epoch["train"] = {"error": f"{type(e).__name__}: {e}"}
             if args.workload != "bb":
-                _R._POOL.clear()
-                torch.cuda.empty_cache()
+                _R.trim_pool()
                 rt_bb = SceneRuntime(synth.make_scene("bb"), dev)
                 rt_bb.make_ground_truth()
                 for _ in range(20):

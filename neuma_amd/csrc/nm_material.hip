@@ -1385,7 +1385,10 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
 // internal (also used by the fused roll-out): launch the backward kernel only.  wmode 0: no weight gradients,
 // 1: write this launch's per-workgroup partial sums to wpart, 2: add them to wpart.
 static int bwd_attr_once() {
-  static bool attr_set = false;
+  static bool attr_done[64] = {};       // (a function attribute belongs to the device it was set on)
+  int devid = 0;
+  NM_HIP_CHECK(hipGetDevice(&devid));
+  const bool attr_set = devid >= 0 && devid < 64 && attr_done[devid];
   if (!attr_set) {
     NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd<NM_ELASTICITY, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)sizeof(BwdLds)));
@@ -1403,7 +1406,7 @@ static int bwd_attr_once() {
                                      (int)sizeof(BwdLds)));
     NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_material_bwd_pair<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)sizeof(BwdLds)));
-    attr_set = true;
+    if (devid >= 0 && devid < 64) attr_done[devid] = true;
   }
   return NM_OK;
 }

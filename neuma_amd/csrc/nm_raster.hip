@@ -2715,11 +2715,13 @@ static int raster_forward_impl(const nm_raster_cfg* cfg, int32_t K, int32_t m, c
       NM_LAUNCH(k_cell_sort, dim3(NM_GS / 4), dim3(256), 0, s, NM_GS, (const uint32_t*)t.slab_off, t.gkeys, t.gvals, (long long)K,
                 (const uint32_t*)hdr2);
       NM_LAUNCH_CHECK();
-      static bool attr_set = false;
-      if (!attr_set) {
+      static bool attr_set[64] = {};       // (a function attribute belongs to the device it was set on)
+      int devid = 0;
+      NM_HIP_CHECK(hipGetDevice(&devid));
+      if (devid < 0 || devid >= 64 || !attr_set[devid]) {
         NM_HIP_CHECK(hipFuncSetAttribute((const void*)k_bin_count2, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)(((size_t)NM_B2_MAXBIN * 9 + 1) * sizeof(uint32_t))));
-        attr_set = true;
+        if (devid >= 0 && devid < 64) attr_set[devid] = true;
       }
       NM_LAUNCH(k_bin_count2, dim3(t.nchunk), dim3(256), b2_lds, s, k, t.nbx, nbin, (const uint32_t*)hdr2,
                 (const unsigned long long*)t.gkeys, (const int*)t.rad, (const float2*)t.xy, (const float4*)t.conop, t.hist, t.log, t.hdr,

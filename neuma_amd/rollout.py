@@ -28,7 +28,7 @@ _FWD_PAIR = __import__('os').environ.get('NEUMA_FWD_PAIR')
 _FWD_PAIR_SET = [False]
 _ACT_CACHE_GB = __import__('os').environ.get('NEUMA_ACT_CACHE_GB')       # None: derived from the free device memory, once
 _BUDGET = {}            # device -> bytes
-_ACT_LIVE = [0]         # bytes of activation cache held by live roll-out nodes
+_ACT_LIVE = {}          # device -> bytes of activation cache held by live roll-out nodes (live_bytes)
 _POOL_CAP = [4]         # idle buffers kept per size ...
 _POOL_CAPS = {}         # ... unless the size has a cap of its own: (device, bytes) -> idle buffers kept (a multi-frame epoch
                         # keeps one pair of caches per frame between epochs: harness.SceneRuntime.epoch)
@@ -53,6 +53,25 @@ def act_cache_budget(device) -> int:
     return b
 
 
+def live_bytes(device=None) -> int:
+    """Cache bytes held by live roll-out nodes on `device` (None: on all devices)."""
+    return sum(_ACT_LIVE.values()) if device is None else _ACT_LIVE.get(str(device), 0)
+
+
+def trim_pool(device=None) -> int:
+    """Drop the idle pooled cache buffers (of `device`; None: of every device) and hand the memory back to the driver; returns the
+    bytes released.  The pool keeps GB-sized buffers alive across epochs on purpose (allocating them costs more than an epoch's
+    reverse sweep); call this when the process moves on to something else on the same GPU - an evaluation render, a larger
+    scene.  lease_cache calls it by itself when an allocation fails."""
+    freed = 0
+    for k in [k for k in _POOL if device is None or k[0] == str(device)]:
+        freed += k[1] * len(_POOL[k])
+        del _POOL[k]
+    if freed:
+        torch.cuda.empty_cache()
+    return freed
+
+
 def lease_cache(nbytes: int, device, force: bool = False):
     """A cache buffer of nbytes for one roll-out node, or None when the budget does not allow it (the node then recomputes).
     Idle pooled buffers of OTHER sizes count as held - they are device memory outside torch's caching allocator - and are
@@ -64,12 +83,24 @@ def lease_cache(nbytes: int, device, force: bool = False):
     if not force:
         budget = act_cache_budget(device)
         others = sum(k[1] * len(v) for k, v in _POOL.items() if k[0] == key[0] and k != key)
-        if _ACT_LIVE[0] + nbytes > budget:
+        live = _ACT_LIVE.get(key[0], 0)
+        if live + nbytes > budget:
             return None
-        if _ACT_LIVE[0] + others + nbytes > budget:
+        if live + others + nbytes > budget:
             for k in [k for k in _POOL if k[0] == key[0] and k != key]:
                 del _POOL[k]
-    return _Lease(nbytes, device, True)
+    try:
+        return _Lease(nbytes, device, True)
+    except torch.cuda.OutOfMemoryError:
+        # the budget was sampled once, at the first call; what is free NOW decides (another workload, another process on the
+        # GPU): give the idle buffers back and try once more - and without the memory the node recomputes, as over budget
+        trim_pool(device)
+        try:
+            return _Lease(nbytes, device, True)
+        except torch.cuda.OutOfMemoryError:
+            if force:
+                raise
+            return None
 
 
 class _Lease(object):
@@ -82,7 +113,7 @@ class _Lease(object):
         self.key, self.counted = key, counted
         self.t = free.pop() if free else torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         if counted:
-            _ACT_LIVE[0] += int(nbytes)
+            _ACT_LIVE[key[0]] = _ACT_LIVE.get(key[0], 0) + int(nbytes)
 
     def release(self):
         if self.t is not None:
@@ -93,7 +124,7 @@ class _Lease(object):
 
     def _forget(self):
         if self.t is not None and self.counted:
-            _ACT_LIVE[0] -= self.key[1]
+            _ACT_LIVE[self.key[0]] = _ACT_LIVE.get(self.key[0], 0) - self.key[1]
         self.t = None
 
     def __del__(self):

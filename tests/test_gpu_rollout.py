@@ -430,7 +430,7 @@ def test_svd_and_activation_caches_do_not_change_the_reverse_sweep():
             ((out2[0] * gw[0]).sum() + (out2[3] * gw[1]).sum() + (out[0] * gw[0]).sum() + (out[3] * gw[1]).sum()).backward()
             res[mode] = ([o.detach().clone() for o in out], [t.grad.clone() for t in ins + params])
             if mode == "both":
-                assert R._ACT_LIVE[0] == 0 and sum(len(v) for v in R._POOL.values()) >= 2      # both leases back in the pool
+                assert R.live_bytes() == 0 and sum(len(v) for v in R._POOL.values()) >= 2      # both leases back in the pool
     finally:
         R._SVD_CACHE, R._ACT_CACHE = saved
     for mode in ("svd", "both"):
