@@ -18,3 +18,8 @@ python bench.py --state deformed --no-cpu-baseline --epoch-frames 0 2>/dev/null 
 python bench.py --state impact --no-cpu-baseline --epoch-frames 0 2>/dev/null | tail -1 > $O/bench_metric_impact.json
 python bench.py 2>/dev/null | tail -1 > $O/bench_metric_cpu.json
 du -sh $O
+# memory-side atomics (round 6: what the reverse compositing's per-(tile, Gaussian) flush costs at the fabric) - own pass
+cd /tmp
+rocprofv3 -L 2>/dev/null | grep -i -o "TCC_EA0_ATOMIC[A-Z_a-z0-9]*\|TCC_ATOMIC[A-Z_a-z0-9]*\|TCC_EA0_WRREQ[A-Z_a-z0-9]*\|TCC_EA0_RDREQ[A-Z_a-z0-9]*" | sort -u > $O/atomic_counters_available.txt
+rocprofv3 --pmc TCC_EA0_ATOMIC_sum TCC_ATOMIC_sum --output-format csv -d $O/atomic -- $CMD > $O/atomic.log 2>&1
+cd $R
