@@ -1,16 +1,16 @@
-set -x
-mkdir -p gpurun_out/r06a
+#!/bin/bash
+# round 6: gloo dry runs of the multi-rank bench path on one GPU (code-path checks, not rates), the phase counters of the final
+# sources and the driver's own bench invocation -> gpurun_out/r06c (copied to profiles/r06_*)
+O=gpurun_out/r06c; mkdir -p $O
 export NEUMA_DIST_BACKEND=gloo
-for mode in on off; do
-  for ex in allreduce peers; do
-    timeout 300 python bench.py --gpus 2 --steps 3 --warmup 1 --workload tiny --no-cpu-baseline --epoch-frames 0 --shard-sim $mode > gpurun_out/r06a/g2_${mode}_${ex}.json 2> gpurun_out/r06a/g2_${mode}_${ex}.err; echo "rc=$? $mode $ex"
-  done
-done
-NEUMA_SHARD_EXCHANGE=peers timeout 300 python bench.py --gpus 2 --steps 3 --warmup 1 --workload tiny --no-cpu-baseline --epoch-frames 0 --shard-sim on > gpurun_out/r06a/g2_on_peersenv.json 2> gpurun_out/r06a/g2_on_peersenv.err; echo "rc=$?"
-timeout 300 python bench.py --gpus 2 --steps 3 --warmup 1 --workload bb --no-cpu-baseline --epoch-frames 0 --shard-sim auto > gpurun_out/r06a/g2_bb_auto.json 2> gpurun_out/r06a/g2_bb_auto.err; echo "rc=$?"
-timeout 600 python bench.py --gpus 8 --steps 3 --warmup 1 --workload tiny --no-cpu-baseline --epoch-frames 0 --shard-sim on > gpurun_out/r06a/g8_on.json 2> gpurun_out/r06a/g8_on.err; echo "rc=$?"
-timeout 600 python bench.py --gpus 8 --steps 3 --warmup 1 --workload tiny --no-cpu-baseline --epoch-frames 0 --shard-sim off > gpurun_out/r06a/g8_off.json 2> gpurun_out/r06a/g8_off.err; echo "rc=$?"
+run() { name=$1; shift; timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --epoch-frames 0 "$@" > $O/$name.json 2> $O/$name.err; echo "$name rc=$?"; }
+run gpus2_on_allreduce --gpus 2 --workload tiny --shard-sim on
+NEUMA_SHARD_EXCHANGE=peers run gpus2_on_peers --gpus 2 --workload tiny --shard-sim on
+run gpus2_off --gpus 2 --workload tiny --shard-sim off
+run gpus2_bb_auto --gpus 2 --workload bb --shard-sim auto
+run gpus8_on --gpus 8 --workload tiny --shard-sim on
+run gpus8_off --gpus 8 --workload tiny --shard-sim off
 unset NEUMA_DIST_BACKEND
-timeout 300 python bench.py --workload tiny --steps 3 --warmup 1 --no-cpu-baseline --epoch-frames 0 > gpurun_out/r06a/g1_tiny.json 2> gpurun_out/r06a/g1_tiny.err
-timeout 600 python bench.py --no-cpu-baseline > gpurun_out/r06a/bench_head.json 2> gpurun_out/r06a/bench_head.err; echo "rc=$?"
-tail -c 600 gpurun_out/r06a/*.err | tail -80
+run gpus1_tiny --workload tiny
+python tools/exp_phases_rollout.py > $O/phases_rollout.txt 2>&1
+python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "default rc=$?"
