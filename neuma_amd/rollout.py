@@ -111,6 +111,7 @@ class _Lease(object):
         key = (str(device), int(nbytes))
         free = _POOL.get(key)
         self.key, self.counted = key, counted
+        self.t = None           # (an allocation that raises leaves a half-built object behind: __del__ must find the attribute)
         self.t = free.pop() if free else torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         if counted:
             _ACT_LIVE[key[0]] = _ACT_LIVE.get(key[0], 0) + int(nbytes)

@@ -257,3 +257,69 @@ def test_checkpoint_order_is_by_epoch_number(tmp_path):
     for e in (9990, 10000, 1, 10):
         (tmp_path / f"{e:04d}_lora.pt").write_bytes(b"")
     assert [p.name for p in lora_checkpoints(tmp_path)] == ["0001_lora.pt", "0010_lora.pt", "9990_lora.pt", "10000_lora.pt"]
+
+
+def test_cache_pool_accounting_per_device_trim_and_retry(monkeypatch):
+    """neuma_amd.rollout's cache pool (host logic, CPU tensors): live bytes are counted per device, idle buffers go back to the
+    pool and trim_pool() drops them, and an allocation that fails trims the pool and retries once before the node falls back to
+    recomputing (one global counter, no way to give the pooled GB back)."""
+    from neuma_amd import rollout as R
+    monkeypatch.setattr(R, "_BUDGET", {"cpu": 1 << 20, "meta": 1 << 20})
+    monkeypatch.setattr(R, "_POOL", {})
+    monkeypatch.setattr(R, "_ACT_LIVE", {})
+    a = R.lease_cache(1000, "cpu")
+    b = R.lease_cache(3000, "cpu")
+    assert R.live_bytes("cpu") == 4000 and R.live_bytes("meta") == 0 and R.live_bytes() == 4000
+    assert R.lease_cache(1 << 21, "cpu") is None                      # over the device's budget: the node recomputes
+    a.release(); b.release()
+    assert R.live_bytes("cpu") == 0 and sum(len(v) for v in R._POOL.values()) == 2
+    c = R.lease_cache(1000, "cpu")                                    # comes out of the pool
+    assert sum(len(v) for v in R._POOL.values()) == 1 and c.t.numel() == 1000
+    c.release()
+    assert R.trim_pool("cpu") == 4000 and R._POOL == {}
+    # an allocation that fails: pool trimmed, one retry; still failing -> None (force: the error surfaces)
+    R.lease_cache(2000, "cpu").release()
+    calls = {"n": 0}
+    real_empty = torch.empty
+
+    def failing_empty(*args, **kw):
+        calls["n"] += 1
+        if calls["n"] <= fail_first:
+            raise torch.cuda.OutOfMemoryError("simulated")
+        return real_empty(*args, **kw)
+
+    monkeypatch.setattr(torch, "empty", failing_empty)
+    fail_first = 1
+    d = R.lease_cache(5000, "cpu")
+    assert d is not None and calls["n"] == 2 and R._POOL == {}        # (the idle 2000-byte buffer was given back before the retry)
+    d.release()
+    R.trim_pool()
+    calls["n"], fail_first = 0, 2
+    assert R.lease_cache(5000, "cpu") is None and R.live_bytes("cpu") == 0
+    calls["n"] = 0
+    with pytest.raises(torch.cuda.OutOfMemoryError):
+        R.lease_cache(5000, "cpu", force=True)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/experiments/configs/demo"), reason="needs the reference checkout (build container only)")
+def test_inference_entry_point_reads_the_reference_demo_configs():
+    """`python -m neuma_amd.inference`: its argument parser mirrors experiments/inference.py:48-84 and the loader turns the four
+    shipped demo YAMLs into what `inference()` consumes (objects, per-object checkpoints / adaptors / velocities, sim block)."""
+    from pathlib import Path
+    from neuma_amd.config import load_config
+    from neuma_amd.inference import parse_args
+    a = parse_args(["-c", "x.yaml", "-vn", "clip", "-s", "50", "-dv", "e_2", "e_3", "-sp", "run", "-f", "5", "-ri"])
+    assert (a.config, a.video_name, a.eval_steps, a.debug_views, a.save_particles, a.skip_frames, a.remove_images) == \
+        ("x.yaml", "clip", 50, ["e_2", "e_3"], "run", 5, True)
+    d = parse_args(["-c", "x.yaml", "-vn", "clip"])
+    assert d.eval_steps == 600 and d.debug_views == [] and d.save_particles is None and d.dataset_path is None      # inference.py:54-81
+    seen = 0
+    for f in sorted(Path("/root/reference/experiments/configs/demo").glob("*.yaml")):
+        c = load_config(f)
+        assert len(c.objects) >= 1 and c.sim.num_grids > 0 and c.sim.bc in ("noslip", "freeslip")
+        for o in c.objects:
+            assert o.pretrained_ckpt.endswith("_0300.pt") and o.constitution.lora.r == 16 and o.constitution.load_lora.endswith("_lora.pt")
+            assert len(o.particle_data.vel.lin_vel) == 3 and len(o.particle_data.shape.sim_bounds) == 2
+            assert o.constitution.elasticity.layer_widths == [64, 64] and o.gaussian.sh_degree in (0, 3)
+        seen += 1
+    assert seen == 4
